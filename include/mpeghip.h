@@ -1,0 +1,300 @@
+/*
+ * mpeghip.h — C ABI of libmpeghip, the MI355X (gfx950) reconstruction core for
+ * MPEG-1 video / MPEG-1 Audio Layer II decode.
+ *
+ * This is the drop-in boundary for the hot path of gen2brain/mpeg (reference,
+ * file:line relative to its repository root).  The reference has no FFI seam of
+ * its own: its hot functions are plain package functions called once per
+ * macroblock / per 32-sample sub-block, which is far too fine to cross cgo.
+ * The boundary is therefore cut one level up: the (serial, CPU) bitstream
+ * parser records work into flat descriptor arrays and hands a whole picture
+ * (or a batch of pictures from many independent streams) / a whole audio frame
+ * (or many) to the device in one call.  Each entry point below names the
+ * reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all multi-byte fields little-endian.
+ *   - every function returns MPEGHIP_OK (0) or a negative MPEGHIP_ERR_* code;
+ *     mpeghip_last_error() gives a human readable message for the calling thread.
+ *   - nothing throws, nothing aborts.  There is NO CPU fallback: without a
+ *     usable HIP device mpeghip_ctx_create fails with MPEGHIP_ERR_NO_DEVICE.
+ *   - a context is bound to one GPU and one HIP stream; contexts are
+ *     independent (one per GPU / per host thread), not thread-safe.
+ *   - host buffers passed in are only read/written during the call (cgo rule:
+ *     C never retains Go memory).  Use mpeghip_pinned_alloc for staging that
+ *     should be DMA-able.
+ */
+#ifndef MPEGHIP_H
+#define MPEGHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPEGHIP_ABI_VERSION 1
+
+#define MPEGHIP_OK             0
+#define MPEGHIP_ERR_INVALID   (-1) /* bad argument / malformed descriptor            */
+#define MPEGHIP_ERR_NO_DEVICE (-2) /* no HIP device / wrong architecture              */
+#define MPEGHIP_ERR_HIP       (-3) /* HIP runtime error (message has the details)     */
+#define MPEGHIP_ERR_OOM       (-4) /* host or device allocation failed                */
+#define MPEGHIP_ERR_RANGE     (-5) /* a motion vector reads outside the frame buffer  */
+
+typedef struct mpeghip_ctx   mpeghip_ctx;
+typedef struct mpeghip_video mpeghip_video;
+typedef struct mpeghip_batch mpeghip_batch;
+typedef struct mpeghip_audio mpeghip_audio;
+
+/* ------------------------------------------------------------------ context */
+
+/* device: HIP device ordinal.  stream: an existing hipStream_t (e.g. the
+ * caller's torch stream) or NULL to let the context create its own. */
+int  mpeghip_ctx_create(int device, void *stream, mpeghip_ctx **out);
+void mpeghip_ctx_destroy(mpeghip_ctx *ctx);
+int  mpeghip_ctx_sync(mpeghip_ctx *ctx);               /* wait for all queued work   */
+int  mpeghip_device_count(void);                       /* <0 on error                */
+const char *mpeghip_last_error(void);                  /* thread-local, never NULL   */
+int  mpeghip_abi_version(void);
+
+/* Pinned (page-locked) host staging memory, hipHostMalloc-backed. */
+void *mpeghip_pinned_alloc(mpeghip_ctx *ctx, size_t bytes);
+void  mpeghip_pinned_free(mpeghip_ctx *ctx, void *p);
+
+/* Stream-ordered timing helpers (hipEvent on the context's stream). */
+int mpeghip_timer_start(mpeghip_ctx *ctx);
+int mpeghip_timer_stop_ms(mpeghip_ctx *ctx, float *ms); /* records, syncs, returns elapsed */
+
+/* -------------------------------------------------------------------- video */
+
+/*
+ * Frame store (replaces Video.initFrame, video.go:333-372, and the three
+ * rotating Frame values frameCurrent/frameForward/frameBackward,
+ * video.go:97-99).  For every stream the handle owns 3 frame "slots".  One
+ * slot is one contiguous, zero-initialised allocation laid out exactly like
+ * the reference's `base` slice:
+ *
+ *     Y  [luma_w  * luma_h ]   luma_w  = mb_w*16, luma_h  = mb_h*16
+ *     Cb [chroma_w*chroma_h]   chroma_w= mb_w*8,  chroma_h= mb_h*8
+ *     Cr [chroma_w*chroma_h]
+ *     pad[luma_w * 16]         zero; half-pel reads past a plane end land here
+ *
+ * Which slot plays current/forward/backward is the caller's business (the
+ * parser mirrors the rotation of video.go:406-409/430-433) and is stated per
+ * picture in mpeghip_pic_desc.
+ */
+typedef struct mpeghip_video_info {
+    uint32_t width, height;          /* display size                              */
+    uint32_t mb_w, mb_h;             /* macroblocks per row / column              */
+    uint32_t luma_w, luma_h;         /* padded plane sizes                        */
+    uint32_t chroma_w, chroma_h;
+    uint32_t n_streams;
+    uint32_t reserved;
+    uint64_t luma_bytes, chroma_bytes;
+    uint64_t frame_bytes;            /* Y+Cb+Cr+pad, the reference's len(base)    */
+    uint64_t frame_stride;           /* device bytes between consecutive slots    */
+    uint64_t rgba_bytes;             /* width*height*4                            */
+} mpeghip_video_info;
+
+#define MPEGHIP_SLOTS 3
+
+int  mpeghip_video_open(mpeghip_ctx *ctx, uint32_t width, uint32_t height,
+                        uint32_t n_streams, mpeghip_video **out);
+void mpeghip_video_close(mpeghip_video *v);
+int  mpeghip_video_info_get(const mpeghip_video *v, mpeghip_video_info *info);
+
+/* Quantiser matrices of one stream, row-major natural order (already
+ * de-zigzagged, as video.go:291-312 stores them).  Defaults are the MPEG-1
+ * default matrices (video.go:1055-1075). */
+int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream,
+                            const uint8_t intra[64], const uint8_t non_intra[64]);
+
+/* One picture of one stream. */
+typedef struct mpeghip_pic_desc {
+    uint32_t stream;      /* stream index inside the video handle                    */
+    uint8_t  cur;         /* slot written by this picture (frameCurrent)             */
+    uint8_t  fwd;         /* slot read for forward prediction (frameForward)         */
+    uint8_t  bwd;         /* slot read for backward prediction (frameBackward)       */
+    uint8_t  flags;       /* MPEGHIP_PIC_*                                           */
+    uint32_t mb_first;    /* first macroblock descriptor of this picture             */
+    uint32_t mb_count;    /* number of macroblock descriptors                        */
+} mpeghip_pic_desc;       /* 16 bytes */
+
+#define MPEGHIP_PIC_RGBA 0x01u /* also colour-convert every written macroblock into
+                                  the cur slot's RGBA image (fused Frame.RGBA())   */
+
+/*
+ * One macroblock.  Replaces one trip through decodeMacroblock's reconstruction
+ * half: predictMacroblock (video.go:608-637) -> copyMacroblock
+ * (video_noasm.go:28-43 / video_amd64.s / video_arm64.s), then per coded block
+ * the dequantise+premultiply tail of decodeBlock (video.go:719-744), idct
+ * (video.go:801-928) and copy/add*ToDest (video.go:943-1002).
+ *
+ * Motion: mv_x/mv_y are the luma vector in half-pel units AFTER the full-pel
+ * doubling of video.go:612-624.  The reference never averages two
+ * predictions: for a B macroblock with both vectors it copies the forward
+ * prediction and then overwrites it with the backward one (video.go:626-630),
+ * so a descriptor names exactly ONE reference (the one whose bytes survive).
+ * Chroma vectors are derived on the device as mv/2 truncated toward zero
+ * (video_noasm.go:35-36).
+ *
+ * Coefficients: the macroblock's coded blocks (bit 5-b of cbp set <=> block b,
+ * b = 0..3 luma in raster order, 4 = Cb, 5 = Cr) follow each other in block
+ * order starting at coefs + coef_off*128 bytes.  Each block is 64 values in
+ * COLUMN-major order (value for row r, column c at index c*8+r):
+ *   - default: int16 quantised levels as read from the bitstream (0 = not
+ *     present), 128 bytes; for intra blocks index 0 holds the reconstructed DC
+ *     (predictor+differential, video.go:653-669) instead.  The device performs
+ *     the reference's dequantisation (video.go:719-741) with qscale and the
+ *     stream's matrices, the premultiply (video.go:744) and `<<8` for intra DC
+ *     (video.go:672).
+ *   - MPEGHIP_MB_COEF_RAW: int32 already dequantised+premultiplied values, 256
+ *     bytes (2 units).  This is a verbatim snapshot of the reference's live
+ *     `blockData`, needed where blockData carries stale coefficients from an
+ *     earlier invalid block (video.go:711-714 returns before the clears) or a
+ *     value that the int16 form cannot express.  The emitter applies the
+ *     sparse-IDCT masking (rows<4 & cols<4 when n<10, video.go:807-866) and the
+ *     DC-only rule (n==1, video.go:774-777/787-790) before snapshotting, so the
+ *     device runs ONE full IDCT for every coded block.
+ * Intra macroblocks write only their coded blocks (an invalid block leaves the
+ * old pixels, video.go:711-714); inter macroblocks write all 384 bytes.
+ */
+typedef struct mpeghip_mb_desc {
+    uint32_t pic;         /* index into the submit's mpeghip_pic_desc array          */
+    uint16_t mb_x, mb_y;  /* macroblock column / row                                 */
+    int16_t  mv_x, mv_y;  /* half-pel luma motion vector                             */
+    uint8_t  flags;       /* MPEGHIP_MB_*                                            */
+    uint8_t  cbp;         /* coded (and valid) block pattern, bit 5-b <=> block b    */
+    uint8_t  qscale;      /* quantiser_scale 1..31 (ignored for COEF_RAW)            */
+    uint8_t  reserved0;
+    uint32_t coef_off;    /* first coefficient block, in 128-byte units              */
+    uint32_t reserved[3];
+} mpeghip_mb_desc;        /* 32 bytes */
+
+#define MPEGHIP_MB_INTRA    0x01u /* no prediction, coded blocks overwrite           */
+#define MPEGHIP_MB_REF_FWD  0x02u /* predict from pic.fwd                            */
+#define MPEGHIP_MB_REF_BWD  0x04u /* predict from pic.bwd                            */
+#define MPEGHIP_MB_COEF_RAW 0x08u /* int32 premultiplied coefficient blocks          */
+
+#define MPEGHIP_COEF_UNIT 128u
+
+/* Validate + copy descriptors to the device and reconstruct, stream ordered.
+ * Macroblocks of one submit must not overlap inside one picture (the emitter
+ * starts a new submit when a damaged stream addresses a macroblock twice, so
+ * "last writer in bitstream order" is kept by stream order).  Pictures of the
+ * SAME stream in one submit must not depend on each other.
+ * Returns MPEGHIP_ERR_RANGE (nothing is launched) if any prediction would
+ * read outside [plane start, end of pad) — the reference panics there. */
+int mpeghip_video_submit(mpeghip_video *v,
+                         const mpeghip_pic_desc *pics, uint32_t n_pics,
+                         const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                         const void *coefs, size_t coef_bytes);
+
+/* Device-resident batches: validate + upload once, replay many times
+ * (synthetic benchmark batches; a real decoder double-buffers two). */
+int  mpeghip_video_batch_upload(mpeghip_video *v,
+                                const mpeghip_pic_desc *pics, uint32_t n_pics,
+                                const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                                const void *coefs, size_t coef_bytes,
+                                mpeghip_batch **out);
+/* Same descriptors replicated for `n_streams` streams on the device: the batch
+ * describes stream 0 only (all pics must have stream==0); stream s gets a copy
+ * whose pictures address stream s.  Costs one descriptor set in HBM per stream,
+ * exactly as independent streams would. */
+int  mpeghip_video_batch_upload_replicated(mpeghip_video *v,
+                                const mpeghip_pic_desc *pics, uint32_t n_pics,
+                                const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                                const void *coefs, size_t coef_bytes,
+                                uint32_t n_streams, mpeghip_batch **out);
+int  mpeghip_video_batch_run(mpeghip_video *v, const mpeghip_batch *b);
+void mpeghip_video_batch_free(mpeghip_batch *b);
+/* Algorithmic HBM bytes of one run of the batch:
+ * sum over macroblocks of 32 + coefficient bytes + reference window + 384
+ * (+1024 per macroblock of pictures flagged MPEGHIP_PIC_RGBA). */
+uint64_t mpeghip_video_batch_alg_bytes(const mpeghip_batch *b);
+uint64_t mpeghip_video_batch_mbs(const mpeghip_batch *b);
+
+/* Plane access (replaces reading Frame.Y/Cb/Cr.Data, video.go:17-19).  Sizes
+ * are luma_bytes / chroma_bytes.  Synchronous. `pad` (luma_w*16 bytes) may be
+ * NULL. */
+int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
+                              uint8_t *y, uint8_t *cb, uint8_t *cr);
+int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
+                               const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
+                               const uint8_t *pad);
+/* Copy one slot of stream `src` to the same slot of streams [dst0, dst0+n). */
+int mpeghip_video_broadcast_slot(mpeghip_video *v, uint32_t src, uint32_t slot,
+                                 uint32_t dst0, uint32_t n);
+/* FNV-1a-64 over Y||Cb||Cr (the byte order TestVideoGolden hashes,
+ * mpeg_test.go:221-223) of every stream's slot, computed on the device; used
+ * by full-size property tests.  out[n_streams]. */
+int mpeghip_video_hash_slots(mpeghip_video *v, uint32_t slot, uint64_t *out);
+
+/* Frame.RGBA() (video.go:31-36 -> Go image/draw YCbCr 4:2:0 -> RGBA, JFIF
+ * full range, alpha 255).  Converts the slot's planes into the slot's RGBA
+ * image on the device (all streams in [stream0, stream0+n)), stream ordered. */
+int mpeghip_video_rgba_convert(mpeghip_video *v, uint32_t slot,
+                               uint32_t stream0, uint32_t n);
+/* Read the slot's RGBA image (width*height*4 bytes, stride 4*width). Synchronous. */
+int mpeghip_video_read_rgba(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *dst);
+
+/* Raw device addresses (for zero-copy consumers and on-device checks). */
+void *mpeghip_video_slot_devptr(mpeghip_video *v, uint32_t stream, uint32_t slot);
+void *mpeghip_video_rgba_devptr(mpeghip_video *v, uint32_t stream, uint32_t slot);
+
+/* -------------------------------------------------------------------- audio */
+
+/*
+ * MP2 synthesis (replaces the synthesis loop of Audio.decodeFrame,
+ * audio.go:378-422: idct36 audio.go:492-772 — the 32-point matrixing DCT —,
+ * synthWindow audio_noasm.go:8-38 / audio_amd64.s / audio_arm64.s, and the
+ * output scaling audio.go:386-418).
+ *
+ * Input per stream and frame: the requantised sub-band samples
+ * (Audio.sample after readSamples, audio.go:440-490) for both channels, laid
+ * out int32 [2 ch][36 sub-blocks][32 sub-bands]; sub-block t = (part*4 +
+ * granule)*3 + p in the reference's loop order.  The reference synthesises
+ * both channels even for mono (audio.go:382), so does the device.
+ * Per-stream state carried between calls: the V ring v[2][1024] and vPos
+ * (audio.go:63,78), zero at open; Audio.Rewind does NOT clear it (audio.go:149).
+ */
+#define MPEGHIP_AUDIO_F32N   0 /* float32 normalised, interleaved L R (Samples.Interleaved) */
+#define MPEGHIP_AUDIO_F32NLR 1 /* float32 normalised, planar: 1152 L then 1152 R            */
+#define MPEGHIP_AUDIO_F32    2 /* float32 scaled by 2^31, interleaved (Samples.F32)         */
+#define MPEGHIP_AUDIO_S16    3 /* int16 interleaved (Samples.S16)                           */
+
+#define MPEGHIP_AUDIO_FMA_NONE   0 /* mul and add rounded separately: amd64 pure-Go/SSE2,
+                                      golden hash 0xf1b76cdf8e6cdea5 (mpeg_test.go:194)   */
+#define MPEGHIP_AUDIO_FMA_WINDOW 1 /* fused multiply-add in the window only: amd64 AVX2,
+                                      golden hash 0x50f3ab75f5fb0fb5 (mpeg_test.go:195)   */
+
+#define MPEGHIP_AUDIO_FRAME_SAMPLES 1152
+#define MPEGHIP_AUDIO_FRAME_INTS    (2 * 36 * 32)
+
+int  mpeghip_audio_open(mpeghip_ctx *ctx, uint32_t n_streams, int fma_mode,
+                        mpeghip_audio **out);
+void mpeghip_audio_close(mpeghip_audio *a);
+
+/* samples: host int32 [n_streams][n_frames][2][36][32]; out: host buffer,
+ * [n_streams][n_frames][2304] elements of the format's type.  Synchronous. */
+int mpeghip_audio_synth(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames,
+                        int format, void *out);
+/* Same with device-resident input/output (stream ordered, asynchronous). */
+int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples,
+                               uint32_t n_frames, int format, void *d_out);
+/* Device scratch owned by the handle, big enough for n_frames: returns device
+ * pointers (benchmarks fill d_samples once and replay). */
+int mpeghip_audio_device_buffers(mpeghip_audio *a, uint32_t n_frames, int format,
+                                 int32_t **d_samples, void **d_out);
+int mpeghip_audio_upload(mpeghip_audio *a, int32_t *d_dst, const int32_t *src, size_t n_ints);
+int mpeghip_audio_download(mpeghip_audio *a, void *dst, const void *d_src, size_t bytes);
+/* V ring + vPos of one stream: v[2][1024] float32, vpos in [0,1024) multiple of 64. */
+int mpeghip_audio_get_state(mpeghip_audio *a, uint32_t stream, float *v, int32_t *vpos);
+int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, int32_t vpos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPEGHIP_H */
