@@ -1,0 +1,71 @@
+"""In-tree builds.  Everything is compiled with explicit command lines (no cmake,
+no JIT cache) so that the resulting .so files sit next to their sources and
+travel with the repository snapshot to the GPU box."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "mpeg_amd" / "csrc"
+HOST = ROOT / "mpeg_amd" / "host"
+INCLUDE = ROOT / "include"
+
+LIBMPEGHIP = ROOT / "mpeg_amd" / "libmpeghip.so"
+LIBMPEGHOST = ROOT / "mpeg_amd" / "libmpeghost.so"
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _newer(target: Path, sources) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(s).stat().st_mtime <= t for s in sources)
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run([str(c) for c in cmd], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(str(c) for c in cmd), r.stdout))
+    return r.stdout
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libmpeghip is HIP-only and cannot be built without ROCm")
+
+
+def build_libmpeghip(force: bool = False) -> Path:
+    """hipcc cross-compiles the gfx950 code objects; no GPU is needed to build."""
+    srcs = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hip")) + [INCLUDE / "mpeghip.h"]
+    if not force and _newer(LIBMPEGHIP, srcs):
+        return LIBMPEGHIP
+    _run([hipcc_path(), *HIPCC_FLAGS, "-I", INCLUDE, "-I", CSRC, CSRC / "mpeghip.hip", "-o", LIBMPEGHIP])
+    return LIBMPEGHIP
+
+
+def build_libmpeghost(force: bool = False) -> Path:
+    """Host-side mirror of the reference API (bitstream parse -> descriptors).
+    Plain C++; it dlopens nothing and links libmpeghip for all device work."""
+    srcs = sorted(HOST.glob("*.h")) + sorted(HOST.glob("*.hpp")) + sorted(HOST.glob("*.cpp")) + [INCLUDE / "mpeghip.h"]
+    cpps = sorted(HOST.glob("*.cpp"))
+    if not cpps:
+        raise RuntimeError("no host sources")
+    if not force and _newer(LIBMPEGHOST, srcs + [LIBMPEGHIP]):
+        return LIBMPEGHOST
+    build_libmpeghip()
+    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-I", HOST, *cpps,
+          "-o", LIBMPEGHOST, "-L", LIBMPEGHIP.parent, "-lmpeghip", "-Wl,-rpath,$ORIGIN"])
+    return LIBMPEGHOST
+
+
+def build_all(force: bool = False):
+    out = [build_libmpeghip(force)]
+    if sorted(HOST.glob("*.cpp")):
+        out.append(build_libmpeghost(force))
+    return out

@@ -1,0 +1,130 @@
+// lane_common.h — per-lane building blocks shared by every kernel of libmpeghip.
+//
+// The kernels are written as "lane functions": plain C++ that describes what ONE
+// lane of a 64-wide wavefront does in one phase, with LDS passed in as a pointer.
+// hipcc compiles them for gfx950 (the product).  The same source also builds with
+// g++ into tests/kernel_emu (a test-only lane emulator that runs the 64 lanes of
+// a wave in a loop) so the index arithmetic can be checked against the oracle on
+// a machine without a GPU.  The emulator is NOT a fallback: libmpeghip never
+// links it and refuses to create a context without a HIP device.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MPG_HD __host__ __device__ __forceinline__
+#define MPG_HDM __host__ __device__ __forceinline__ /* for static member functions */
+#else
+#define MPG_HD static inline __attribute__((always_inline))
+#define MPG_HDM inline __attribute__((always_inline))
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPG_ON_DEVICE 1
+#else
+#define MPG_ON_DEVICE 0
+#endif
+
+// Emulator-only invariant checks (range proofs the device arithmetic relies on).
+#if defined(MPG_EMU_CHECKS)
+#include <assert.h>
+#define MPG_CHECK(c) assert(c)
+#else
+#define MPG_CHECK(c) ((void)0)
+#endif
+
+namespace mpg {
+
+// ---- unaligned little-endian loads / stores (gfx950 global memory handles any
+// byte alignment in hardware; amdhsa enables unaligned-access-mode, so these
+// become single global_load/store_dwordx2 instructions).
+struct __attribute__((packed)) u64_unaligned { uint64_t v; };
+struct __attribute__((packed)) u32_unaligned { uint32_t v; };
+
+MPG_HD uint64_t ld64u(const uint8_t *p) { return reinterpret_cast<const u64_unaligned *>(p)->v; }
+MPG_HD uint32_t ld32u(const uint8_t *p) { return reinterpret_cast<const u32_unaligned *>(p)->v; }
+MPG_HD void st64u(uint8_t *p, uint64_t v) { reinterpret_cast<u64_unaligned *>(p)->v = v; }
+
+// ---- naturally aligned 16-byte groups (one dwordx4 / ds_read_b128 each)
+struct alignas(16) i16x8 { int16_t v[8]; };
+struct alignas(16) i32x4 { int32_t v[4]; };
+struct alignas(16) u32x4 { uint32_t v[4]; };
+struct alignas(16) f32x4 { float v[4]; };
+
+// ---- 24-bit multiply: v_mul_i32_i24 is full rate on CDNA, v_mul_lo_u32 is not.
+// Callers guarantee both operands fit in 24 signed bits (checked in the emulator).
+MPG_HD int32_t mul24(int32_t a, int32_t b)
+{
+    MPG_CHECK(a >= -(1 << 23) && a < (1 << 23) && b >= -(1 << 23) && b < (1 << 23));
+#if MPG_ON_DEVICE
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
+
+MPG_HD int32_t clampi(int32_t x, int32_t lo, int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// ---- packed-byte averages on 4 pixels (video_noasm.go:14-26 roundAvg / bilinAvg)
+// floor / ceil average per byte.  On the device this is V_LERP_U8:
+//   D.byte[i] = (S0.byte[i] + S1.byte[i] + (S2.byte[i] & 1)) >> 1
+MPG_HD uint32_t avg_floor_u8x4(uint32_t a, uint32_t b)
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_lerp(a, b, 0u);
+#else
+    return (a & b) + (((a ^ b) >> 1) & 0x7f7f7f7fu);
+#endif
+}
+
+MPG_HD uint32_t avg_ceil_u8x4(uint32_t a, uint32_t b) // (a+b+1)>>1 per byte == roundAvg
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_lerp(a, b, 0x01010101u);
+#else
+    return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
+#endif
+}
+
+// (a+b+c+d+2)>>2 per byte == bilinAvg, without widening:
+//   p=(a+b)>>1, q=(c+d)>>1, e = both pair sums odd
+//   (a+b+c+d+2)>>2 = (p+q+1+e)>>1 = ceil_avg(p,q) + (e & ~(p^q) & 1)
+MPG_HD uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    uint32_t p = avg_floor_u8x4(a, b);
+    uint32_t q = avg_floor_u8x4(c, d);
+    uint32_t e = (a ^ b) & (c ^ d);
+    uint32_t r = avg_ceil_u8x4(p, q);
+    return r + (e & ~(p ^ q) & 0x01010101u);
+}
+
+MPG_HD uint64_t avg2_u8x8(uint64_t a, uint64_t b)
+{
+    uint32_t lo = avg_ceil_u8x4((uint32_t)a, (uint32_t)b);
+    uint32_t hi = avg_ceil_u8x4((uint32_t)(a >> 32), (uint32_t)(b >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+MPG_HD uint64_t avg4_u8x8(uint64_t a, uint64_t b, uint64_t c, uint64_t d)
+{
+    uint32_t lo = avg4_u8x4((uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d);
+    uint32_t hi = avg4_u8x4((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), (uint32_t)(d >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its
+// own L2).  Gives every XCD one contiguous range of work chunks so that
+// neighbouring macroblocks — which share 128-byte destination lines and overlapping
+// reference windows — meet in the same L2.  Bijective for any grid size.
+MPG_HD uint32_t xcd_chunk(uint32_t block, uint32_t n_blocks)
+{
+    const uint32_t nx = 8;
+    uint32_t q = n_blocks / nx, r = n_blocks % nx;
+    uint32_t xcd = block % nx, k = block / nx;
+    uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+} // namespace mpg

@@ -1,0 +1,1007 @@
+// mpeghip.hip — gfx950 kernels and the C ABI of include/mpeghip.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+//        -I include -I mpeg_amd/csrc mpeg_amd/csrc/mpeghip.hip -o mpeg_amd/libmpeghip.so
+//
+// There is no CPU path in this library.  Every entry point that needs the GPU
+// fails with MPEGHIP_ERR_NO_DEVICE / MPEGHIP_ERR_HIP when it is not there.
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "audio_lane.h"
+#include "iso11172_synth_window.h"
+#include "mpeghip.h"
+#include "video_lane.h"
+
+using namespace mpg;
+
+// ============================================================ device kernels
+
+// LDS ordering inside ONE wavefront: DS operations of a wave execute in issue
+// order, so a ds_read that follows a ds_write sees it without an s_barrier; the
+// fences only stop the compiler from moving accesses across the hand-off.
+static __device__ __forceinline__ void wave_lds_handoff()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kWaveLdsBytes = kTileDwords * 4 + kRgbaBytes; // 1728 + 384
+
+// One wavefront per macroblock, WAVES macroblocks (consecutive descriptors, i.e.
+// normally consecutive macroblocks of one row) per workgroup so that the 8-byte
+// row stores of neighbouring macroblocks combine into full lines in one L2.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES * kWaveLdsBytes];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+    const uint32_t mb_index = chunk * WAVES + wave;
+    if (mb_index >= a.n_mbs)
+        return;
+    int32_t *tile = reinterpret_cast<int32_t *>(lds + wave * kWaveLdsBytes);
+    uint8_t *stage = lds + wave * kWaveLdsBytes + kTileDwords * 4;
+
+    const MbU u = load_mb(a, mb_index);
+    MbLane st;
+    mb_phase_a(a, u, lane, st, tile);
+    wave_lds_handoff();
+    bool wrote;
+    const uint64_t out = mb_phase_b(a, u, lane, st, tile, wrote);
+    if (u.rgba) { // wave-uniform
+        mb_phase_c_stage(a, u, lane, out, wrote, stage);
+        wave_lds_handoff();
+        mb_phase_c_convert(a, u, lane, stage);
+    }
+}
+
+// Frame.RGBA for whole slots: grid (x quads, rows, streams).
+__global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64_t frame_stride,
+                                                  uint8_t *rgba, uint64_t rgba_stride,
+                                                  uint32_t luma_w, uint32_t chroma_w,
+                                                  uint32_t luma_bytes, uint32_t chroma_bytes,
+                                                  uint32_t width, uint32_t height,
+                                                  uint32_t slot, uint32_t stream0)
+{
+    const uint32_t x4 = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const uint64_t fs = (uint64_t)(stream0 + blockIdx.z) * MPEGHIP_SLOTS + slot;
+    rgba_convert_quad(frames + fs * frame_stride, luma_w, chroma_w, luma_bytes, chroma_bytes,
+                      width, height, x4, y, rgba + fs * rgba_stride);
+}
+
+// Replicate a one-stream descriptor set for streams 1..n-1 (benchmark batches).
+__global__ void replicate_desc_kernel(mpeghip_pic_desc *pics, uint32_t n_pics,
+                                      mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                                      uint32_t coef_units, uint32_t n_streams)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total_mbs = (uint64_t)n_mbs * n_streams;
+    if (gid >= (uint64_t)n_mbs && gid < total_mbs) {
+        const uint32_t s = (uint32_t)(gid / n_mbs), i = (uint32_t)(gid % n_mbs);
+        mpeghip_mb_desc d = mbs[i];
+        d.pic += s * n_pics;
+        d.coef_off += s * coef_units;
+        mbs[gid] = d;
+    }
+    const uint64_t total_pics = (uint64_t)n_pics * n_streams;
+    if (gid >= (uint64_t)n_pics && gid < total_pics) {
+        const uint32_t s = (uint32_t)(gid / n_pics), i = (uint32_t)(gid % n_pics);
+        mpeghip_pic_desc p = pics[i];
+        p.stream = s;
+        p.mb_first += s * n_mbs;
+        pics[gid] = p;
+    }
+}
+
+// FNV-1a-64 over Y||Cb||Cr of one slot per stream (mpeg_test.go:221-223); one
+// thread per stream — a test aid, not a hot path.
+__global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32_t slot,
+                            uint64_t n_bytes, uint32_t n_streams, uint64_t *out)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams)
+        return;
+    const uint8_t *p = frames + ((uint64_t)s * MPEGHIP_SLOTS + slot) * frame_stride;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint64_t i = 0; i < n_bytes; i += 8) {
+        uint64_t w = *reinterpret_cast<const uint64_t *>(p + i);
+        for (int k = 0; k < 8; k++) {
+            h ^= (w >> (8 * k)) & 0xff;
+            h *= 0x100000001b3ull;
+        }
+    }
+    out[s] = h;
+}
+
+__global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[kAudioLdsFloats];
+    const uint32_t stream = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int32_t vpos0 = a.vpos[stream];
+    audio_load_state(a, stream, vpos0, tid, lds);
+    __syncthreads();
+    for (uint32_t f = 0; f < a.n_frames; f++) {
+        audio_phase_dct(a, stream, f, tid, lds);
+        __syncthreads();
+        audio_phase_window(a, stream, vpos0, f, tid, lds);
+        __syncthreads();
+    }
+    audio_store_state(a, stream, vpos0, tid, lds);
+    __syncthreads();
+    if (tid == 0)
+        audio_store_vpos(a, stream, vpos0);
+}
+
+// ================================================================ host side
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? MPEGHIP_ERR_OOM : MPEGHIP_ERR_HIP,             \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct mpeghip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct mpeghip_batch {
+    mpeghip_video *owner = nullptr;
+    mpeghip_pic_desc *d_pics = nullptr;
+    mpeghip_mb_desc *d_mbs = nullptr;
+    uint8_t *d_coefs = nullptr;
+    uint64_t n_pics = 0, n_mbs = 0, coef_bytes = 0;
+    uint64_t alg_bytes = 0;
+    size_t cap_pics = 0, cap_mbs = 0, cap_coefs = 0; // capacities (transient batch reuse)
+};
+
+struct mpeghip_video {
+    mpeghip_ctx *ctx = nullptr;
+    mpeghip_video_info info{};
+    uint8_t *d_frames = nullptr;
+    uint8_t *d_rgba = nullptr;
+    uint8_t *d_qmat = nullptr;    // [n_streams][2][64] column-major
+    uint8_t *d_premult = nullptr; // [64]
+    uint64_t *d_hash = nullptr;
+    mpeghip_batch transient;
+};
+
+struct mpeghip_audio {
+    mpeghip_ctx *ctx = nullptr;
+    uint32_t n_streams = 0;
+    int fma = 0;
+    float *d_ring = nullptr;
+    int32_t *d_vpos = nullptr;
+    float *d_window = nullptr;
+    int32_t *d_samples = nullptr;
+    void *d_out = nullptr;
+    size_t cap_samples = 0, cap_out = 0;
+};
+
+static const uint8_t k_default_intra[64] = { // ISO 11172-2 default intra matrix (video.go:1055-1064)
+    8,  16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37,
+    19, 22, 26, 27, 29, 34, 34, 38, 22, 22, 26, 27, 29, 34, 37, 40,
+    22, 26, 27, 29, 32, 35, 40, 48, 26, 27, 29, 32, 35, 40, 48, 58,
+    26, 27, 29, 34, 38, 46, 56, 69, 27, 29, 35, 38, 46, 56, 69, 83};
+
+// AAN-style premultiplier (video.go:1077-1086): round(32 * s_r * s_c) style scale
+// factors of the reference's IDCT; symmetric, so row- and column-major coincide.
+static const uint8_t k_premult[64] = {
+    32, 44, 42, 38, 32, 25, 17, 9,  44, 62, 58, 52, 44, 35, 24, 12,
+    42, 58, 55, 49, 42, 33, 23, 12, 38, 52, 49, 44, 38, 30, 20, 10,
+    32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30, 25, 20, 14, 7,
+    17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
+
+extern "C" {
+
+int mpeghip_abi_version(void) { return MPEGHIP_ABI_VERSION; }
+const char *mpeghip_last_error(void) { return g_err; }
+
+int mpeghip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+        return fail(MPEGHIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int mpeghip_ctx_create(int device, void *stream, mpeghip_ctx **out)
+{
+    if (!out)
+        return fail(MPEGHIP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MPEGHIP_ERR_NO_DEVICE, "no HIP device (%s); libmpeghip has no CPU path",
+                    e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(MPEGHIP_ERR_NO_DEVICE, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MPEGHIP_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device,
+                    prop.gcnArchName);
+    mpeghip_ctx *c = new (std::nothrow) mpeghip_ctx();
+    if (!c)
+        return fail(MPEGHIP_ERR_OOM, "host allocation failed");
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete c;
+            return fail(MPEGHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+        }
+        c->owns_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(MPEGHIP_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = c;
+    return MPEGHIP_OK;
+}
+
+void mpeghip_ctx_destroy(mpeghip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ev0)
+        (void)hipEventDestroy(c->ev0);
+    if (c->ev1)
+        (void)hipEventDestroy(c->ev1);
+    if (c->owns_stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mpeghip_ctx_sync(mpeghip_ctx *c)
+{
+    if (!c)
+        return fail(MPEGHIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPEGHIP_OK;
+}
+
+void *mpeghip_pinned_alloc(mpeghip_ctx *c, size_t bytes)
+{
+    if (!c)
+        return nullptr;
+    void *p = nullptr;
+    (void)hipSetDevice(c->device);
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        fail(MPEGHIP_ERR_OOM, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void mpeghip_pinned_free(mpeghip_ctx *c, void *p)
+{
+    if (c && p) {
+        (void)hipSetDevice(c->device);
+        (void)hipHostFree(p);
+    }
+}
+
+int mpeghip_timer_start(mpeghip_ctx *c)
+{
+    if (!c)
+        return fail(MPEGHIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_timer_stop_ms(mpeghip_ctx *c, float *ms)
+{
+    if (!c || !ms)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MPEGHIP_OK;
+}
+
+// -------------------------------------------------------------------- video
+
+static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t n_streams, mpeghip_video **out)
+{
+    if (!c || !out)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 4095 || height > 4095 || n_streams == 0)
+        return fail(MPEGHIP_ERR_INVALID, "bad geometry %ux%u x %u streams", width, height, n_streams);
+    HIP_TRY(hipSetDevice(c->device));
+    mpeghip_video *v = new (std::nothrow) mpeghip_video();
+    if (!v)
+        return fail(MPEGHIP_ERR_OOM, "host allocation failed");
+    v->ctx = c;
+    mpeghip_video_info &in = v->info;
+    in.width = width;
+    in.height = height;
+    in.mb_w = (width + 15) >> 4; // video.go:314-322
+    in.mb_h = (height + 15) >> 4;
+    in.luma_w = in.mb_w << 4;
+    in.luma_h = in.mb_h << 4;
+    in.chroma_w = in.mb_w << 3;
+    in.chroma_h = in.mb_h << 3;
+    in.n_streams = n_streams;
+    in.luma_bytes = (uint64_t)in.luma_w * in.luma_h;
+    in.chroma_bytes = (uint64_t)in.chroma_w * in.chroma_h;
+    in.frame_bytes = in.luma_bytes + 2 * in.chroma_bytes + (uint64_t)in.luma_w * 16; // video.go:340
+    in.frame_stride = align_up(in.frame_bytes + 64, 256); // slack keeps 8-byte row loads inside the slot
+    in.rgba_bytes = (uint64_t)width * height * 4;
+    const uint64_t total = in.frame_stride * MPEGHIP_SLOTS * n_streams;
+    int rc = MPEGHIP_OK;
+    do {
+        if (hipMalloc((void **)&v->d_frames, total) != hipSuccess) {
+            rc = fail(MPEGHIP_ERR_OOM, "hipMalloc(%llu) for the frame store failed", (unsigned long long)total);
+            break;
+        }
+        if (hipMalloc((void **)&v->d_qmat, (size_t)n_streams * 128) != hipSuccess ||
+            hipMalloc((void **)&v->d_premult, 64) != hipSuccess ||
+            hipMalloc((void **)&v->d_hash, (size_t)n_streams * 8) != hipSuccess) {
+            rc = fail(MPEGHIP_ERR_OOM, "hipMalloc for tables failed");
+            break;
+        }
+        if (hipMemsetAsync(v->d_frames, 0, total, c->stream) != hipSuccess) {
+            rc = fail(MPEGHIP_ERR_HIP, "hipMemsetAsync failed");
+            break;
+        }
+        std::vector<uint8_t> qm((size_t)n_streams * 128);
+        for (uint32_t s = 0; s < n_streams; s++) {
+            for (int r = 0; r < 8; r++)
+                for (int col = 0; col < 8; col++) {
+                    qm[(size_t)s * 128 + col * 8 + r] = k_default_intra[r * 8 + col];
+                    qm[(size_t)s * 128 + 64 + col * 8 + r] = 16; // video.go:1066-1075
+                }
+        }
+        if (hipMemcpy(v->d_qmat, qm.data(), qm.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(v->d_premult, k_premult, 64, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(MPEGHIP_ERR_HIP, "table upload failed");
+            break;
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = fail(MPEGHIP_ERR_HIP, "sync failed");
+            break;
+        }
+    } while (0);
+    if (rc != MPEGHIP_OK) {
+        mpeghip_video_close(v);
+        return rc;
+    }
+    v->transient.owner = v;
+    *out = v;
+    return MPEGHIP_OK;
+}
+
+static void batch_release(mpeghip_batch *b)
+{
+    if (b->d_pics)
+        (void)hipFree(b->d_pics);
+    if (b->d_mbs)
+        (void)hipFree(b->d_mbs);
+    if (b->d_coefs)
+        (void)hipFree(b->d_coefs);
+    b->d_pics = nullptr;
+    b->d_mbs = nullptr;
+    b->d_coefs = nullptr;
+    b->cap_pics = b->cap_mbs = b->cap_coefs = 0;
+}
+
+void mpeghip_video_close(mpeghip_video *v)
+{
+    if (!v)
+        return;
+    (void)hipSetDevice(v->ctx->device);
+    (void)hipStreamSynchronize(v->ctx->stream);
+    batch_release(&v->transient);
+    if (v->d_frames)
+        (void)hipFree(v->d_frames);
+    if (v->d_rgba)
+        (void)hipFree(v->d_rgba);
+    if (v->d_qmat)
+        (void)hipFree(v->d_qmat);
+    if (v->d_premult)
+        (void)hipFree(v->d_premult);
+    if (v->d_hash)
+        (void)hipFree(v->d_hash);
+    delete v;
+}
+
+int mpeghip_video_info_get(const mpeghip_video *v, mpeghip_video_info *info)
+{
+    if (!v || !info)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    *info = v->info;
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64])
+{
+    if (!v || !intra || !non_intra || stream >= v->info.n_streams)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    uint8_t t[128];
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) {
+            t[c * 8 + r] = intra[r * 8 + c];
+            t[64 + c * 8 + r] = non_intra[r * 8 + c];
+        }
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream)); // earlier pictures may still read the old matrices
+    HIP_TRY(hipMemcpy(v->d_qmat + (size_t)stream * 128, t, 128, hipMemcpyHostToDevice));
+    return MPEGHIP_OK;
+}
+
+static int ensure_rgba(mpeghip_video *v)
+{
+    if (v->d_rgba)
+        return MPEGHIP_OK;
+    const uint64_t total = align_up(v->info.rgba_bytes, 256) * MPEGHIP_SLOTS * v->info.n_streams;
+    HIP_TRY(hipMalloc((void **)&v->d_rgba, total));
+    // RGBA of an all-zero frame is (0,135,0,255), not zero: convert the (zero or
+    // already decoded) planes so image and planes agree from the start.
+    for (uint32_t slot = 0; slot < MPEGHIP_SLOTS; slot++) {
+        int rc = mpeghip_video_rgba_convert(v, slot, 0, v->info.n_streams);
+        if (rc != MPEGHIP_OK)
+            return rc;
+    }
+    return MPEGHIP_OK;
+}
+
+static uint64_t rgba_stride_of(const mpeghip_video *v) { return align_up(v->info.rgba_bytes, 256); }
+
+// Host-side validation of one submit; also totals the algorithmic bytes.
+static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                    const mpeghip_mb_desc *mbs, uint32_t n_mbs, size_t coef_bytes, uint64_t *alg_bytes)
+{
+    const mpeghip_video_info &in = v->info;
+    if (n_pics && !pics)
+        return fail(MPEGHIP_ERR_INVALID, "pics is NULL");
+    if (n_mbs && !mbs)
+        return fail(MPEGHIP_ERR_INVALID, "mbs is NULL");
+    if (coef_bytes % MPEGHIP_COEF_UNIT)
+        return fail(MPEGHIP_ERR_INVALID, "coef_bytes %zu is not a multiple of 128", coef_bytes);
+    for (uint32_t p = 0; p < n_pics; p++) {
+        const mpeghip_pic_desc &pd = pics[p];
+        if (pd.stream >= in.n_streams || pd.cur >= MPEGHIP_SLOTS || pd.fwd >= MPEGHIP_SLOTS || pd.bwd >= MPEGHIP_SLOTS)
+            return fail(MPEGHIP_ERR_INVALID, "picture %u: bad stream/slot", p);
+        if ((uint64_t)pd.mb_first + pd.mb_count > n_mbs)
+            return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock range out of bounds", p);
+    }
+    const int64_t cap_y = (int64_t)in.frame_bytes;
+    const int64_t cap_c0 = (int64_t)(in.frame_bytes - in.luma_bytes);
+    const int64_t cap_c1 = (int64_t)(in.frame_bytes - in.luma_bytes - in.chroma_bytes);
+    uint64_t alg = 0;
+    const uint64_t coef_units = coef_bytes / MPEGHIP_COEF_UNIT;
+    for (uint32_t i = 0; i < n_mbs; i++) {
+        const mpeghip_mb_desc &m = mbs[i];
+        if (m.pic >= n_pics)
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: picture index %u out of range", i, m.pic);
+        if (m.mb_x >= in.mb_w || m.mb_y >= in.mb_h)
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: position (%u,%u) outside %ux%u", i, m.mb_x, m.mb_y,
+                        in.mb_w, in.mb_h);
+        const bool intra = m.flags & MPEGHIP_MB_INTRA;
+        const uint32_t nref = ((m.flags & MPEGHIP_MB_REF_FWD) ? 1 : 0) + ((m.flags & MPEGHIP_MB_REF_BWD) ? 1 : 0);
+        if ((intra && nref != 0) || (!intra && nref != 1))
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: flags 0x%x name %u references", i, m.flags, nref);
+        if (m.cbp > 0x3f)
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: cbp 0x%x", i, m.cbp);
+        const uint32_t nb = (uint32_t)__builtin_popcount(m.cbp);
+        const bool raw = m.flags & MPEGHIP_MB_COEF_RAW;
+        const uint64_t units = (uint64_t)nb * (raw ? 2 : 1);
+        if (nb && (uint64_t)m.coef_off + units > coef_units)
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: coefficient blocks beyond the buffer", i);
+        if (!raw && nb && (m.qscale == 0 || m.qscale > 31))
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: quantiser_scale %u", i, m.qscale);
+        uint64_t ref_bytes = 0;
+        if (!intra) {
+            // extents of the reference's copyBlock reads (video_noasm.go:48-80): Go
+            // indexes src[:cap(src)], i.e. [plane start, end of base); anything else panics.
+            const int mh = m.mv_x, mv = m.mv_y;
+            const int64_t lsi = ((int64_t)(m.mb_y << 4) + (mv >> 1)) * in.luma_w + (m.mb_x << 4) + (mh >> 1);
+            const int loh = mh & 1, lov = mv & 1;
+            const int64_t llast = lsi + (int64_t)(15 + lov) * in.luma_w + 15 + loh;
+            const int cmh = mh / 2, cmv = mv / 2;
+            const int64_t csi = ((int64_t)(m.mb_y << 3) + (cmv >> 1)) * in.chroma_w + (m.mb_x << 3) + (cmh >> 1);
+            const int coh = cmh & 1, cov = cmv & 1;
+            const int64_t clast = csi + (int64_t)(7 + cov) * in.chroma_w + 7 + coh;
+            if (lsi < 0 || llast >= cap_y || csi < 0 || clast >= cap_c1 || clast >= cap_c0)
+                return fail(MPEGHIP_ERR_RANGE,
+                            "macroblock %u at (%u,%u): motion vector (%d,%d) reads outside the frame buffer", i, m.mb_x,
+                            m.mb_y, mh, mv);
+            ref_bytes = (uint64_t)(16 + lov) * (16 + loh) + 2ull * (8 + cov) * (8 + coh);
+        }
+        alg += 32 + units * MPEGHIP_COEF_UNIT + ref_bytes + (intra ? 64ull * nb : 384);
+        if (pics[m.pic].flags & MPEGHIP_PIC_RGBA)
+            alg += 1024;
+    }
+    if (alg_bytes)
+        *alg_bytes = alg;
+    return MPEGHIP_OK;
+}
+
+static int grow(void **p, size_t *cap, size_t need)
+{
+    if (need <= *cap)
+        return MPEGHIP_OK;
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 4 + 4096;
+    if (hipMalloc(p, want) != hipSuccess)
+        return fail(MPEGHIP_ERR_OOM, "hipMalloc(%zu) failed", want);
+    *cap = want;
+    return MPEGHIP_OK;
+}
+
+static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
+{
+    if (b->n_mbs == 0)
+        return MPEGHIP_OK;
+    const mpeghip_video_info &in = v->info;
+    VideoArgs a;
+    a.frames = v->d_frames;
+    a.frame_stride = in.frame_stride;
+    a.luma_w = in.luma_w;
+    a.luma_h = in.luma_h;
+    a.chroma_w = in.chroma_w;
+    a.chroma_h = in.chroma_h;
+    a.luma_bytes = (uint32_t)in.luma_bytes;
+    a.chroma_bytes = (uint32_t)in.chroma_bytes;
+    a.pics = b->d_pics;
+    a.mbs = b->d_mbs;
+    a.coefs = b->d_coefs;
+    a.qmat = v->d_qmat;
+    a.premult = v->d_premult;
+    a.n_mbs = (uint32_t)b->n_mbs;
+    a.width = in.width;
+    a.height = in.height;
+    a.rgba = v->d_rgba;
+    a.rgba_stride = rgba_stride_of(v);
+    constexpr int WAVES = 8;
+    const uint32_t blocks = (uint32_t)((b->n_mbs + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL(recon_kernel<WAVES>, dim3(blocks), dim3(WAVES * 64), 0, v->ctx->stream, a);
+    HIP_TRY(hipGetLastError());
+    return MPEGHIP_OK;
+}
+
+static bool wants_rgba(const mpeghip_pic_desc *pics, uint32_t n_pics)
+{
+    for (uint32_t p = 0; p < n_pics; p++)
+        if (pics[p].flags & MPEGHIP_PIC_RGBA)
+            return true;
+    return false;
+}
+
+static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                       const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
+                       uint32_t replicas)
+{
+    int rc = validate(v, pics, n_pics, mbs, n_mbs, coef_bytes, &b->alg_bytes);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    if (n_mbs > 0 && coef_bytes > 0 && !coefs)
+        return fail(MPEGHIP_ERR_INVALID, "coefs is NULL");
+    if ((uint64_t)n_mbs * replicas > 0xffffffffull || (uint64_t)(coef_bytes / MPEGHIP_COEF_UNIT) * replicas > 0xffffffffull)
+        return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit descriptor indices");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    if (wants_rgba(pics, n_pics)) {
+        rc = ensure_rgba(v);
+        if (rc != MPEGHIP_OK)
+            return rc;
+    }
+    hipStream_t st = v->ctx->stream;
+    // the transient batch may still be in use by the previous submit
+    if (b == &v->transient)
+        HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
+        (rc = grow((void **)&b->d_mbs, &b->cap_mbs, sizeof(mpeghip_mb_desc) * (size_t)n_mbs * replicas + 32)) != 0 ||
+        (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0)
+        return rc;
+    if (n_pics)
+        HIP_TRY(hipMemcpyAsync(b->d_pics, pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics, hipMemcpyHostToDevice, st));
+    if (n_mbs)
+        HIP_TRY(hipMemcpyAsync(b->d_mbs, mbs, sizeof(mpeghip_mb_desc) * (size_t)n_mbs, hipMemcpyHostToDevice, st));
+    if (coef_bytes)
+        HIP_TRY(hipMemcpyAsync(b->d_coefs, coefs, coef_bytes, hipMemcpyHostToDevice, st));
+    if (replicas > 1) {
+        for (uint32_t s = 1; s < replicas && coef_bytes; s++)
+            HIP_TRY(hipMemcpyAsync(b->d_coefs + (size_t)s * coef_bytes, b->d_coefs, coef_bytes, hipMemcpyDeviceToDevice, st));
+        const uint64_t work = (uint64_t)(n_mbs > n_pics ? n_mbs : n_pics) * replicas;
+        hipLaunchKernelGGL(replicate_desc_kernel, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, st, b->d_pics, n_pics,
+                           b->d_mbs, n_mbs, (uint32_t)(coef_bytes / MPEGHIP_COEF_UNIT), replicas);
+        HIP_TRY(hipGetLastError());
+    }
+    // pageable host memory: the copies above may still be reading it
+    HIP_TRY(hipStreamSynchronize(st));
+    b->n_pics = (uint64_t)n_pics * replicas;
+    b->n_mbs = (uint64_t)n_mbs * replicas;
+    b->coef_bytes = (uint64_t)coef_bytes * replicas;
+    b->alg_bytes *= replicas;
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs,
+                         uint32_t n_mbs, const void *coefs, size_t coef_bytes)
+{
+    if (!v)
+        return fail(MPEGHIP_ERR_INVALID, "video is NULL");
+    int rc = upload_into(v, &v->transient, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, 1);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    return launch_batch(v, &v->transient);
+}
+
+int mpeghip_video_batch_upload_replicated(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                                          const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs,
+                                          size_t coef_bytes, uint32_t n_streams, mpeghip_batch **out)
+{
+    if (!v || !out)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_streams == 0 || n_streams > v->info.n_streams)
+        return fail(MPEGHIP_ERR_INVALID, "n_streams %u out of range", n_streams);
+    if (n_streams > 1)
+        for (uint32_t p = 0; p < n_pics; p++)
+            if (pics[p].stream != 0)
+                return fail(MPEGHIP_ERR_INVALID, "replicated batches must describe stream 0");
+    mpeghip_batch *b = new (std::nothrow) mpeghip_batch();
+    if (!b)
+        return fail(MPEGHIP_ERR_OOM, "host allocation failed");
+    b->owner = v;
+    int rc = upload_into(v, b, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, n_streams);
+    if (rc != MPEGHIP_OK) {
+        batch_release(b);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_batch_upload(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                               const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
+                               mpeghip_batch **out)
+{
+    return mpeghip_video_batch_upload_replicated(v, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, 1, out);
+}
+
+int mpeghip_video_batch_run(mpeghip_video *v, const mpeghip_batch *b)
+{
+    if (!v || !b || b->owner != v)
+        return fail(MPEGHIP_ERR_INVALID, "batch does not belong to this video handle");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    return launch_batch(v, b);
+}
+
+void mpeghip_video_batch_free(mpeghip_batch *b)
+{
+    if (!b)
+        return;
+    if (b->owner) {
+        (void)hipSetDevice(b->owner->ctx->device);
+        (void)hipStreamSynchronize(b->owner->ctx->stream);
+    }
+    batch_release(b);
+    delete b;
+}
+
+uint64_t mpeghip_video_batch_alg_bytes(const mpeghip_batch *b) { return b ? b->alg_bytes : 0; }
+uint64_t mpeghip_video_batch_mbs(const mpeghip_batch *b) { return b ? b->n_mbs : 0; }
+
+static uint8_t *slot_ptr(const mpeghip_video *v, uint32_t stream, uint32_t slot)
+{
+    return v->d_frames + ((uint64_t)stream * MPEGHIP_SLOTS + slot) * v->info.frame_stride;
+}
+
+void *mpeghip_video_slot_devptr(mpeghip_video *v, uint32_t stream, uint32_t slot)
+{
+    if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
+        return nullptr;
+    return slot_ptr(v, stream, slot);
+}
+
+void *mpeghip_video_rgba_devptr(mpeghip_video *v, uint32_t stream, uint32_t slot)
+{
+    if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS || ensure_rgba(v) != MPEGHIP_OK)
+        return nullptr;
+    return v->d_rgba + ((uint64_t)stream * MPEGHIP_SLOTS + slot) * rgba_stride_of(v);
+}
+
+int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr)
+{
+    if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
+        return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    const uint8_t *p = slot_ptr(v, stream, slot);
+    if (y)
+        HIP_TRY(hipMemcpy(y, p, v->info.luma_bytes, hipMemcpyDeviceToHost));
+    if (cb)
+        HIP_TRY(hipMemcpy(cb, p + v->info.luma_bytes, v->info.chroma_bytes, hipMemcpyDeviceToHost));
+    if (cr)
+        HIP_TRY(hipMemcpy(cr, p + v->info.luma_bytes + v->info.chroma_bytes, v->info.chroma_bytes, hipMemcpyDeviceToHost));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, const uint8_t *y, const uint8_t *cb,
+                               const uint8_t *cr, const uint8_t *pad)
+{
+    if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
+        return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    uint8_t *p = slot_ptr(v, stream, slot);
+    if (y)
+        HIP_TRY(hipMemcpy(p, y, v->info.luma_bytes, hipMemcpyHostToDevice));
+    if (cb)
+        HIP_TRY(hipMemcpy(p + v->info.luma_bytes, cb, v->info.chroma_bytes, hipMemcpyHostToDevice));
+    if (cr)
+        HIP_TRY(hipMemcpy(p + v->info.luma_bytes + v->info.chroma_bytes, cr, v->info.chroma_bytes, hipMemcpyHostToDevice));
+    if (pad)
+        HIP_TRY(hipMemcpy(p + v->info.luma_bytes + 2 * v->info.chroma_bytes, pad, (size_t)v->info.luma_w * 16,
+                          hipMemcpyHostToDevice));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_broadcast_slot(mpeghip_video *v, uint32_t src, uint32_t slot, uint32_t dst0, uint32_t n)
+{
+    if (!v || src >= v->info.n_streams || slot >= MPEGHIP_SLOTS || (uint64_t)dst0 + n > v->info.n_streams)
+        return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    for (uint32_t s = dst0; s < dst0 + n; s++) {
+        if (s == src)
+            continue;
+        HIP_TRY(hipMemcpyAsync(slot_ptr(v, s, slot), slot_ptr(v, src, slot), v->info.frame_stride,
+                               hipMemcpyDeviceToDevice, v->ctx->stream));
+    }
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_hash_slots(mpeghip_video *v, uint32_t slot, uint64_t *out)
+{
+    if (!v || !out || slot >= MPEGHIP_SLOTS)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    const uint64_t n_bytes = v->info.luma_bytes + 2 * v->info.chroma_bytes; // multiple of 128
+    hipLaunchKernelGGL(hash_kernel, dim3((v->info.n_streams + 63) / 64), dim3(64), 0, v->ctx->stream, v->d_frames,
+                       v->info.frame_stride, slot, n_bytes, v->info.n_streams, v->d_hash);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    HIP_TRY(hipMemcpy(out, v->d_hash, (size_t)v->info.n_streams * 8, hipMemcpyDeviceToHost));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_rgba_convert(mpeghip_video *v, uint32_t slot, uint32_t stream0, uint32_t n)
+{
+    if (!v || slot >= MPEGHIP_SLOTS || n == 0 || (uint64_t)stream0 + n > v->info.n_streams)
+        return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    if (!v->d_rgba) {
+        // allocate without the initial conversion pass of ensure_rgba (we are it)
+        const uint64_t total = rgba_stride_of(v) * MPEGHIP_SLOTS * v->info.n_streams;
+        HIP_TRY(hipMalloc((void **)&v->d_rgba, total));
+        for (uint32_t s = 0; s < MPEGHIP_SLOTS; s++)
+            if (s != slot || stream0 != 0 || n != v->info.n_streams) {
+                int rc = mpeghip_video_rgba_convert(v, s, 0, v->info.n_streams);
+                if (rc != MPEGHIP_OK)
+                    return rc;
+            }
+    }
+    const mpeghip_video_info &in = v->info;
+    const uint32_t quads = (in.width + 3) / 4;
+    // grid.z is limited to 65535
+    for (uint32_t s0 = 0; s0 < n; s0 += 32768) {
+        const uint32_t ns = n - s0 < 32768 ? n - s0 : 32768;
+        dim3 grid((quads + 63) / 64, (in.height + 3) / 4, ns);
+        hipLaunchKernelGGL(rgba_kernel, grid, dim3(256), 0, v->ctx->stream, v->d_frames, in.frame_stride, v->d_rgba,
+                           rgba_stride_of(v), in.luma_w, in.chroma_w, (uint32_t)in.luma_bytes, (uint32_t)in.chroma_bytes,
+                           in.width, in.height, slot, stream0 + s0);
+        HIP_TRY(hipGetLastError());
+    }
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_read_rgba(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *dst)
+{
+    if (!v || !dst || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    int rc = ensure_rgba(v);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    HIP_TRY(hipMemcpy(dst, v->d_rgba + ((uint64_t)stream * MPEGHIP_SLOTS + slot) * rgba_stride_of(v), v->info.rgba_bytes,
+                      hipMemcpyDeviceToHost));
+    return MPEGHIP_OK;
+}
+
+// -------------------------------------------------------------------- audio
+
+int mpeghip_audio_open(mpeghip_ctx *c, uint32_t n_streams, int fma_mode, mpeghip_audio **out)
+{
+    if (!c || !out || n_streams == 0)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    if (fma_mode != MPEGHIP_AUDIO_FMA_NONE && fma_mode != MPEGHIP_AUDIO_FMA_WINDOW)
+        return fail(MPEGHIP_ERR_INVALID, "fma_mode %d", fma_mode);
+    HIP_TRY(hipSetDevice(c->device));
+    mpeghip_audio *a = new (std::nothrow) mpeghip_audio();
+    if (!a)
+        return fail(MPEGHIP_ERR_OOM, "host allocation failed");
+    a->ctx = c;
+    a->n_streams = n_streams;
+    a->fma = fma_mode;
+    float win[512];
+    for (int i = 0; i < 512; i++)
+        win[i] = (float)mpg_synth_window_x2[i] * 0.5f; // exact: entries are multiples of 0.5
+    if (hipMalloc((void **)&a->d_ring, (size_t)n_streams * 2048 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&a->d_vpos, (size_t)n_streams * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void **)&a->d_window, sizeof(win)) != hipSuccess ||
+        hipMemset(a->d_ring, 0, (size_t)n_streams * 2048 * sizeof(float)) != hipSuccess ||
+        hipMemset(a->d_vpos, 0, (size_t)n_streams * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(a->d_window, win, sizeof(win), hipMemcpyHostToDevice) != hipSuccess) {
+        mpeghip_audio_close(a);
+        return fail(MPEGHIP_ERR_OOM, "audio state allocation failed");
+    }
+    *out = a;
+    return MPEGHIP_OK;
+}
+
+void mpeghip_audio_close(mpeghip_audio *a)
+{
+    if (!a)
+        return;
+    (void)hipSetDevice(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    void *ps[] = {a->d_ring, a->d_vpos, a->d_window, a->d_samples, a->d_out};
+    for (void *p : ps)
+        if (p)
+            (void)hipFree(p);
+    delete a;
+}
+
+static size_t audio_elem_size(int format) { return format == MPEGHIP_AUDIO_S16 ? 2 : 4; }
+
+int mpeghip_audio_device_buffers(mpeghip_audio *a, uint32_t n_frames, int format, int32_t **d_samples, void **d_out)
+{
+    if (!a || format < 0 || format > MPEGHIP_AUDIO_S16)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    const size_t n = (size_t)a->n_streams * n_frames * MPEGHIP_AUDIO_FRAME_INTS;
+    int rc;
+    if ((rc = grow((void **)&a->d_samples, &a->cap_samples, n * sizeof(int32_t))) != 0 ||
+        (rc = grow(&a->d_out, &a->cap_out, n * audio_elem_size(format))) != 0)
+        return rc;
+    if (d_samples)
+        *d_samples = a->d_samples;
+    if (d_out)
+        *d_out = a->d_out;
+    return MPEGHIP_OK;
+}
+
+int mpeghip_audio_upload(mpeghip_audio *a, int32_t *d_dst, const int32_t *src, size_t n_ints)
+{
+    if (!a || !d_dst || !src)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipMemcpy(d_dst, src, n_ints * sizeof(int32_t), hipMemcpyHostToDevice));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_audio_download(mpeghip_audio *a, void *dst, const void *d_src, size_t bytes)
+{
+    if (!a || !dst || !d_src)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_frames, int format, void *d_out)
+{
+    if (!a || !d_samples || !d_out || format < 0 || format > MPEGHIP_AUDIO_S16)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    if (n_frames == 0)
+        return MPEGHIP_OK;
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    AudioArgs args;
+    args.samples = d_samples;
+    args.out = d_out;
+    args.ring = a->d_ring;
+    args.vpos = a->d_vpos;
+    args.window = a->d_window;
+    args.n_streams = a->n_streams;
+    args.n_frames = n_frames;
+    args.format = format;
+    args.fma = a->fma;
+    hipLaunchKernelGGL(audio_kernel, dim3(a->n_streams), dim3(kAudioThreads), 0, a->ctx->stream, args);
+    HIP_TRY(hipGetLastError());
+    return MPEGHIP_OK;
+}
+
+int mpeghip_audio_synth(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames, int format, void *out)
+{
+    if (!a || !samples || !out)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    int32_t *ds;
+    void *dout;
+    int rc = mpeghip_audio_device_buffers(a, n_frames, format, &ds, &dout);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    const size_t n = (size_t)a->n_streams * n_frames * MPEGHIP_AUDIO_FRAME_INTS;
+    HIP_TRY(hipMemcpy(ds, samples, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = mpeghip_audio_synth_device(a, ds, n_frames, format, dout);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    HIP_TRY(hipMemcpy(out, dout, n * audio_elem_size(format), hipMemcpyDeviceToHost));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_audio_get_state(mpeghip_audio *a, uint32_t stream, float *v, int32_t *vpos)
+{
+    if (!a || stream >= a->n_streams)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    if (v)
+        HIP_TRY(hipMemcpy(v, a->d_ring + (size_t)stream * 2048, 2048 * sizeof(float), hipMemcpyDeviceToHost));
+    if (vpos)
+        HIP_TRY(hipMemcpy(vpos, a->d_vpos + stream, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, int32_t vpos)
+{
+    if (!a || stream >= a->n_streams || vpos < 0 || vpos > 1023 || (vpos & 63))
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    if (v)
+        HIP_TRY(hipMemcpy(a->d_ring + (size_t)stream * 2048, v, 2048 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(a->d_vpos + stream, &vpos, sizeof(int32_t), hipMemcpyHostToDevice));
+    return MPEGHIP_OK;
+}
+
+} // extern "C"

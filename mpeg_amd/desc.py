@@ -1,0 +1,79 @@
+"""Descriptor layouts of include/mpeghip.h as numpy dtypes, plus the frame-slot
+rotation of the reference decoder (video.go:406-409, 430-433, 247-256)."""
+from __future__ import annotations
+
+import numpy as np
+
+PIC_DTYPE = np.dtype([
+    ("stream", "<u4"), ("cur", "u1"), ("fwd", "u1"), ("bwd", "u1"), ("flags", "u1"),
+    ("mb_first", "<u4"), ("mb_count", "<u4"),
+])
+MB_DTYPE = np.dtype([
+    ("pic", "<u4"), ("mb_x", "<u2"), ("mb_y", "<u2"), ("mv_x", "<i2"), ("mv_y", "<i2"),
+    ("flags", "u1"), ("cbp", "u1"), ("qscale", "u1"), ("reserved0", "u1"),
+    ("coef_off", "<u4"), ("reserved", "<u4", (3,)),
+])
+assert PIC_DTYPE.itemsize == 16 and MB_DTYPE.itemsize == 32
+
+PIC_RGBA = 0x01
+MB_INTRA, MB_REF_FWD, MB_REF_BWD, MB_COEF_RAW = 0x01, 0x02, 0x04, 0x08
+COEF_UNIT = 128
+SLOTS = 3
+
+PIC_I, PIC_P, PIC_B = 1, 2, 3
+
+AUDIO_F32N, AUDIO_F32NLR, AUDIO_F32, AUDIO_S16 = 0, 1, 2, 3
+AUDIO_FMA_NONE, AUDIO_FMA_WINDOW = 0, 1
+AUDIO_FRAME_INTS = 2 * 36 * 32
+
+# video.go:1044-1053 (ISO 11172-2 zig-zag scan), natural index of scan position n
+ZIGZAG = np.array([
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+    12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63], dtype=np.int64)
+
+
+def geometry(width: int, height: int) -> dict:
+    """video.go:314-322, 333-340."""
+    mb_w, mb_h = (width + 15) >> 4, (height + 15) >> 4
+    luma_w, luma_h = mb_w << 4, mb_h << 4
+    luma = luma_w * luma_h
+    chroma = luma // 4
+    return dict(width=width, height=height, mb_w=mb_w, mb_h=mb_h, luma_w=luma_w, luma_h=luma_h,
+                chroma_w=luma_w // 2, chroma_h=luma_h // 2, luma_bytes=luma, chroma_bytes=chroma,
+                frame_bytes=luma + 2 * chroma + luma_w * 16, mb_count=mb_w * mb_h)
+
+
+class SlotRotation:
+    """Which of a stream's three frame slots is current / forward / backward.
+
+    Mirrors decodePicture (video.go:406-409: `frameTemp = frameForward; if I/P
+    { frameForward = frameBackward }`, and :430-433 `frameBackward =
+    frameCurrent; frameCurrent = frameTemp` after a reference picture) and the
+    output selection of Video.Decode (video.go:247-256)."""
+
+    def __init__(self):
+        self.cur, self.fwd, self.bwd = 0, 1, 2
+        self.has_reference = False
+
+    def begin(self, picture_type: int):
+        """Slots to decode `picture_type` with: (cur, fwd, bwd)."""
+        self._temp = self.fwd
+        if picture_type in (PIC_I, PIC_P):
+            self.fwd = self.bwd
+        return self.cur, self.fwd, self.bwd
+
+    def end(self, picture_type: int, no_delay: bool = False):
+        """Finish the picture; returns the slot Video.Decode would hand out, or None."""
+        if picture_type in (PIC_I, PIC_P):
+            self.bwd = self.cur
+            self.cur = self._temp
+        if no_delay:
+            return self.bwd
+        if picture_type == PIC_B:
+            return self.cur
+        if self.has_reference:
+            return self.fwd
+        self.has_reference = True
+        return None

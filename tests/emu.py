@@ -1,0 +1,161 @@
+"""Python face of tests/kernel_emu (TEST INFRASTRUCTURE): runs the lane functions of
+the GPU kernels on the CPU so their index logic can be compared with the oracle
+without a GPU.  Same surface as mpeg_amd.abi.VideoStore / AudioSynth."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from mpeg_amd import desc, synth
+
+HERE = Path(__file__).resolve().parent / "kernel_emu"
+ROOT = HERE.parent.parent
+LIB = HERE / "libkernel_emu.so"
+
+_lib = None
+
+
+def build(force=False):
+    srcs = [HERE / "emu.cpp"] + sorted((ROOT / "mpeg_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "mpeghip.h"]
+    if not force and LIB.exists() and all(s.stat().st_mtime <= LIB.stat().st_mtime for s in srcs):
+        return LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DMPG_EMU_CHECKS", "-Wall", "-Wextra",
+           "-Wno-unknown-pragmas", "-I", str(ROOT / "include"), "-I", str(ROOT / "mpeg_amd" / "csrc"),
+           str(HERE / "emu.cpp"), "-o", str(LIB)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("emulator build failed:\n" + r.stdout)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(LIB))
+        P = C.c_void_p
+        L.emu_video_run.restype = C.c_int
+        L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, P, C.c_uint32, P, P, P, P, C.c_uint64]
+        L.emu_rgba_convert.restype = None
+        L.emu_rgba_convert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P]
+        L.emu_audio_run.restype = C.c_int
+        L.emu_audio_run.argtypes = [P, P, P, P, P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32]
+        for n in ("emu_avg4", "emu_avg2", "emu_xcd_chunk", "emu_ycbcr"):
+            getattr(L, n).restype = C.c_uint32
+        L.emu_avg4.argtypes = [C.c_uint32] * 4
+        L.emu_avg2.argtypes = [C.c_uint32] * 2
+        L.emu_xcd_chunk.argtypes = [C.c_uint32] * 2
+        L.emu_ycbcr.argtypes = [C.c_uint32] * 3
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _colmajor(m):
+    return np.ascontiguousarray(np.asarray(m, np.uint8).reshape(8, 8).T).reshape(64)
+
+
+class EmuStore:
+    def __init__(self, width, height, n_streams=1):
+        self.g = desc.geometry(width, height)
+        self.n_streams = n_streams
+        self.stride = (self.g["frame_bytes"] + 64 + 255) // 256 * 256
+        self.frames = np.zeros(self.stride * 3 * n_streams, np.uint8)
+        self.rgba_stride = (width * height * 4 + 255) // 256 * 256
+        self.rgba = np.zeros(self.rgba_stride * 3 * n_streams, np.uint8)
+        self.qmat = np.zeros((n_streams, 2, 64), np.uint8)
+        for s in range(n_streams):
+            self.qmat[s, 0] = _colmajor(synth.INTRA_Q)
+            self.qmat[s, 1] = _colmajor(synth.NON_INTRA_Q)
+        self.premult = _colmajor(synth.PREMULT)
+        self._rgba_init = False
+
+    def set_quant(self, stream, intra, non_intra):
+        self.qmat[stream, 0] = _colmajor(intra)
+        self.qmat[stream, 1] = _colmajor(non_intra)
+
+    def _slot(self, stream, slot):
+        o = (stream * 3 + slot) * self.stride
+        return self.frames[o:o + self.stride]
+
+    def submit(self, pics, mbs, coefs):
+        pics = np.ascontiguousarray(pics, desc.PIC_DTYPE)
+        mbs = np.ascontiguousarray(mbs, desc.MB_DTYPE)
+        coefs = np.ascontiguousarray(coefs).view(np.uint8).reshape(-1)
+        if (pics["flags"] & desc.PIC_RGBA).any() and not self._rgba_init:
+            for s in range(self.n_streams):
+                for slot in range(3):
+                    self.rgba_convert(slot, s, 1)
+            self._rgba_init = True
+        g = self.g
+        rc = lib().emu_video_run(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
+                                 _ptr(pics), _ptr(mbs), len(mbs), _ptr(coefs), _ptr(self.qmat), _ptr(self.premult),
+                                 _ptr(self.rgba), self.rgba_stride)
+        assert rc == 0
+
+    def read_planes(self, stream, slot):
+        f, g = self._slot(stream, slot), self.g
+        L, Cb = g["luma_bytes"], g["chroma_bytes"]
+        return f[:L].copy(), f[L:L + Cb].copy(), f[L + Cb:L + 2 * Cb].copy()
+
+    def write_planes(self, stream, slot, y, cb, cr, pad=None):
+        f, g = self._slot(stream, slot), self.g
+        L, Cb = g["luma_bytes"], g["chroma_bytes"]
+        f[:L], f[L:L + Cb], f[L + Cb:L + 2 * Cb] = y, cb, cr
+        if pad is not None:
+            f[L + 2 * Cb:L + 2 * Cb + g["luma_w"] * 16] = pad
+
+    def rgba_convert(self, slot, stream0=0, n=None):
+        g = self.g
+        for s in range(stream0, stream0 + (self.n_streams if n is None else n)):
+            o = (s * 3 + slot) * self.rgba_stride
+            lib().emu_rgba_convert(_ptr(self._slot(s, slot)), g["luma_w"], g["luma_h"], g["width"], g["height"],
+                                   _ptr(self.rgba[o:]))
+
+    def read_rgba(self, stream, slot):
+        g = self.g
+        o = (stream * 3 + slot) * self.rgba_stride
+        return self.rgba[o:o + g["width"] * g["height"] * 4].reshape(g["height"], g["width"], 4).copy()
+
+    def close(self):
+        pass
+
+
+class EmuSynth:
+    def __init__(self, n_streams=1, fma=0):
+        self.n_streams, self.fma = n_streams, fma
+        self.ring = np.zeros((n_streams, 2, 1024), np.float32)
+        self.vpos = np.zeros(n_streams, np.int32)
+        self.window = (np.array(_window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
+
+    def synth(self, samples, fmt=0):
+        s = np.ascontiguousarray(samples, np.int32)
+        n_frames = s.shape[1]
+        out = np.zeros((self.n_streams, n_frames, 2304), np.int16 if fmt == desc.AUDIO_S16 else np.float32)
+        rc = lib().emu_audio_run(_ptr(s), _ptr(out), _ptr(self.ring), _ptr(self.vpos), _ptr(self.window),
+                                 self.n_streams, n_frames, fmt, self.fma)
+        assert rc == 0
+        return out
+
+    def get_state(self, stream):
+        return self.ring[stream].copy(), int(self.vpos[stream])
+
+    def set_state(self, stream, v, vpos):
+        if v is not None:
+            self.ring[stream] = v
+        self.vpos[stream] = vpos
+
+
+def _window_x2():
+    import re
+    txt = (ROOT / "mpeg_amd" / "csrc" / "iso11172_synth_window.h").read_text()
+    body = txt[txt.index("{") + 1:txt.rindex("}")]
+    vals = [int(x) for x in re.findall(r"-?\d+", body)]
+    assert len(vals) == 512
+    return vals

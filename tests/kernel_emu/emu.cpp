@@ -1,0 +1,131 @@
+// emu.cpp — TEST INFRASTRUCTURE ONLY: a CPU "lane emulator" for the kernels of
+// libmpeghip.  It compiles the very same lane functions the GPU kernels are made
+// of (mpeg_amd/csrc/*_lane.h) with g++ and runs the 64 lanes of a wavefront /
+// the 384 threads of an audio workgroup in plain loops, phase by phase, with LDS
+// as an ordinary array.  Purpose: check lane mapping, addressing and the integer
+// range invariants (MPG_EMU_CHECKS) against the oracle on a machine without a
+// GPU, under ASan/UBSan if wanted.
+//
+// It is NOT a fallback: it is built into tests/kernel_emu/libkernel_emu.so, which
+// only tests load; the product library has no CPU path and fails without a GPU.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "audio_lane.h"
+#include "video_lane.h"
+
+using namespace mpg;
+
+extern "C" {
+
+// Reconstruct n_mbs macroblocks exactly as recon_kernel<W> does, one "wave" at a time.
+int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
+                  uint32_t width, uint32_t height,
+                  const mpeghip_pic_desc *pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                  const uint8_t *coefs, const uint8_t *qmat_colmajor, const uint8_t *premult,
+                  uint8_t *rgba, uint64_t rgba_stride)
+{
+    VideoArgs a;
+    a.frames = frames;
+    a.frame_stride = frame_stride;
+    a.luma_w = luma_w;
+    a.luma_h = luma_h;
+    a.chroma_w = luma_w / 2;
+    a.chroma_h = luma_h / 2;
+    a.luma_bytes = luma_w * luma_h;
+    a.chroma_bytes = a.luma_bytes / 4;
+    a.pics = pics;
+    a.mbs = mbs;
+    a.coefs = coefs;
+    a.qmat = qmat_colmajor;
+    a.premult = premult;
+    a.n_mbs = n_mbs;
+    a.width = width;
+    a.height = height;
+    a.rgba = rgba;
+    a.rgba_stride = rgba_stride;
+
+    alignas(16) int32_t tile[kTileDwords];
+    alignas(16) uint8_t stage[kRgbaBytes];
+    // walk the grid the way the kernel does (8 waves per block, XCD remap) so the
+    // chunk mapping is exercised too; the result must not depend on the order
+    const uint32_t WAVES = 8;
+    const uint32_t blocks = (n_mbs + WAVES - 1) / WAVES;
+    for (uint32_t blk = 0; blk < blocks; blk++) {
+        const uint32_t chunk = xcd_chunk(blk, blocks);
+        for (uint32_t wave = 0; wave < WAVES; wave++) {
+            const uint32_t mb_index = chunk * WAVES + wave;
+            if (mb_index >= n_mbs)
+                continue;
+            const MbU u = load_mb(a, mb_index);
+            MbLane st[64];
+            memset(tile, 0xCD, sizeof(tile)); // poison: reads of unwritten LDS must not matter
+            for (int lane = 0; lane < 64; lane++)
+                mb_phase_a(a, u, lane, st[lane], tile);
+            uint64_t out[64];
+            bool wrote[64];
+            for (int lane = 0; lane < 64; lane++)
+                out[lane] = mb_phase_b(a, u, lane, st[lane], tile, wrote[lane]);
+            if (u.rgba) {
+                for (int lane = 0; lane < 64; lane++)
+                    mb_phase_c_stage(a, u, lane, out[lane], wrote[lane], stage);
+                for (int lane = 0; lane < 64; lane++)
+                    mb_phase_c_convert(a, u, lane, stage);
+            }
+        }
+    }
+    return 0;
+}
+
+void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, uint32_t width, uint32_t height,
+                      uint8_t *rgba)
+{
+    const uint32_t quads = (width + 3) / 4;
+    for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+        for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
+            rgba_convert_quad(frame, luma_w, luma_w / 2, luma_w * luma_h, luma_w * luma_h / 4, width, height, x4, y, rgba);
+}
+
+// audio_kernel: one workgroup per stream.
+int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos, const float *window,
+                  uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma)
+{
+    AudioArgs a;
+    a.samples = samples;
+    a.out = out;
+    a.ring = ring;
+    a.vpos = vpos;
+    a.window = window;
+    a.n_streams = n_streams;
+    a.n_frames = n_frames;
+    a.format = format;
+    a.fma = fma;
+    std::vector<float> lds(kAudioLdsFloats);
+    for (uint32_t stream = 0; stream < n_streams; stream++) {
+        for (auto &x : lds)
+            x = 1e30f; // poison
+        const int32_t vpos0 = a.vpos[stream];
+        for (int tid = 0; tid < kAudioThreads; tid++)
+            audio_load_state(a, stream, vpos0, tid, lds.data());
+        for (uint32_t f = 0; f < n_frames; f++) {
+            for (int tid = 0; tid < kAudioThreads; tid++)
+                audio_phase_dct(a, stream, f, tid, lds.data());
+            for (int tid = 0; tid < kAudioThreads; tid++)
+                audio_phase_window(a, stream, vpos0, f, tid, lds.data());
+        }
+        for (int tid = 0; tid < kAudioThreads; tid++)
+            audio_store_state(a, stream, vpos0, tid, lds.data());
+        audio_store_vpos(a, stream, vpos0);
+    }
+    return 0;
+}
+
+// scalar helpers exposed for unit tests
+uint32_t emu_avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return avg4_u8x4(a, b, c, d); }
+uint32_t emu_avg2(uint32_t a, uint32_t b) { return avg_ceil_u8x4(a, b); }
+uint32_t emu_xcd_chunk(uint32_t b, uint32_t n) { return xcd_chunk(b, n); }
+uint32_t emu_ycbcr(uint32_t y, uint32_t cb, uint32_t cr) { return ycbcr_to_rgba(y, cb, cr); }
+}
