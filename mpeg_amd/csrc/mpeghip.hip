@@ -964,6 +964,8 @@ int mpeghip_audio_synth(mpeghip_audio *a, const int32_t *samples, uint32_t n_fra
 {
     if (!a || !samples || !out)
         return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    if (n_frames == 0)
+        return MPEGHIP_OK;
     int32_t *ds;
     void *dout;
     int rc = mpeghip_audio_device_buffers(a, n_frames, format, &ds, &dout);

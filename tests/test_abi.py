@@ -1,0 +1,53 @@
+"""The C-ABI library builds, loads, and exports every symbol include/mpeghip.h
+declares; without a GPU it refuses to work instead of falling back."""
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "mpeghip.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpeghip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from mpeg_amd import _build, abi
+    _build.build_libmpeghip()
+    lib = abi.load_library()
+    names = declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), "libmpeghip.so does not export %s" % n
+        assert n in abi.SYMBOLS, "mpeg_amd.abi does not bind %s" % n
+    assert lib.mpeghip_abi_version() == 1
+
+
+def test_descriptor_layouts_match_header():
+    from mpeg_amd import desc
+    assert desc.PIC_DTYPE.itemsize == 16 and desc.MB_DTYPE.itemsize == 32
+    assert desc.MB_DTYPE.fields["coef_off"][1] == 16 and desc.MB_DTYPE.fields["mv_x"][1] == 8
+    assert desc.PIC_DTYPE.fields["mb_first"][1] == 8
+
+
+def test_no_cpu_fallback():
+    """On a machine without a gfx950 device the product must fail loudly."""
+    import torch
+    from mpeg_amd import abi
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the loud-failure path is exercised on the CPU-only builder")
+    with pytest.raises(abi.MpegHipError) as ei:
+        abi.Context(0)
+    assert ei.value.code == abi.ERR_NO_DEVICE
+    assert "no CPU path" in str(ei.value) or "no HIP device" in str(ei.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under mpeg_amd/ or include/ may include, import or link oracle/."""
+    for p in list((ROOT / "mpeg_amd").rglob("*")) + list((ROOT / "include").rglob("*")):
+        if p.is_file() and p.suffix in (".py", ".h", ".hpp", ".hip", ".cpp", ".c"):
+            txt = p.read_text(errors="replace")
+            assert "pyoracle" not in txt and "liboracle" not in txt and "mpeg_oracle" not in txt and "oracle_desc" not in txt, p

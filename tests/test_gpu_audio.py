@@ -1,0 +1,70 @@
+"""-m gpu: MP2 synthesis kernel through the C ABI vs the oracle.  The bar of the
+north star is RMS <= 1e-6; the kernel is built to be bit-identical (no-FMA and
+window-FMA variants), so bit equality is asserted and RMS reported on top."""
+import numpy as np
+import pytest
+
+from mpeg_amd import abi, desc, synth
+from parity import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fma", [desc.AUDIO_FMA_NONE, desc.AUDIO_FMA_WINDOW])
+@pytest.mark.parametrize("fmt", [desc.AUDIO_F32N, desc.AUDIO_F32NLR, desc.AUDIO_F32, desc.AUDIO_S16])
+def test_formats_and_state(oracle, hip_ctx, fma, fmt):
+    s = synth.audio_frames(3, 5)
+    ref, dut = oracle.OracleSynth(3, fma), abi.AudioSynth(hip_ctx, 3, fma)
+    for _ in range(3):
+        assert bits_equal(ref.synth(s, fmt), dut.synth(s, fmt))
+        for st in range(3):
+            (va, pa), (vb, pb) = ref.get_state(st), dut.get_state(st)
+            assert pa == pb and bits_equal(va, vb)
+    dut.close()
+
+
+@pytest.mark.parametrize("fma,want", [(0, 0xf1b76cdf8e6cdea5), (1, 0x50f3ab75f5fb0fb5)])
+def test_golden_hash_through_the_gpu(oracle, hip_ctx, golden_dir, fma, want):
+    """test.mp2's real sub-band samples -> HIP synthesis -> the reference's golden FNV (mpeg_test.go:193-197)."""
+    dec = oracle.AudioDecoder((golden_dir / "test.mp2").read_bytes(), fma)
+    frames = []
+    while True:
+        r = dec.decode(True)
+        if r is None:
+            break
+        frames.append(r[1])
+    S = np.stack(frames)[None]
+    dut, h, i = abi.AudioSynth(hip_ctx, 1, fma), oracle.FNV_OFFSET, 0
+    for chunk in (1, 2, 5, 17, 100, 1000):
+        part = S[:, i:i + chunk]
+        if part.shape[1]:
+            h = oracle.fnv1a64(dut.synth(part, desc.AUDIO_F32N), h)
+        i += chunk
+    dut.close()
+    assert h == want
+
+
+def test_config4_256_streams(oracle, hip_ctx):
+    """BASELINE config 4: 256 stereo streams; 100 consecutive frames so the V ring wraps many times."""
+    n_streams, n_frames = 256, 100
+    s = synth.audio_frames(n_streams, n_frames)
+    dut = abi.AudioSynth(hip_ctx, n_streams, desc.AUDIO_FMA_NONE)
+    got = dut.synth(s, desc.AUDIO_F32N)
+    ref = oracle.OracleSynth(n_streams, 0)
+    pick = [0, 1, 17, 128, 255]
+    want = oracle.OracleSynth(len(pick), 0).synth(s[pick], desc.AUDIO_F32N)
+    rms = float(np.sqrt(np.mean((got[pick].astype(np.float64) - want.astype(np.float64)) ** 2)))
+    assert rms <= 1e-6, rms          # the north star's tolerance
+    assert bits_equal(got[pick], want)  # and the stronger property this kernel is built for
+    dut.close()
+
+
+def test_zero_frames_and_rewind_semantics(hip_ctx):
+    dut = abi.AudioSynth(hip_ctx, 1)
+    v = np.arange(2048, dtype=np.float32).reshape(2, 1024)
+    dut.set_state(0, v, 192)
+    out = dut.synth(np.zeros((1, 0, 2, 36, 32), np.int32))
+    assert out.shape == (1, 0, 2304)
+    v2, p2 = dut.get_state(0)
+    assert p2 == 192 and bits_equal(v, v2)
+    dut.close()

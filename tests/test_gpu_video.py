@@ -1,0 +1,171 @@
+"""-m gpu: the HIP reconstruction path, called through the C ABI (libmpeghip.so),
+against the CPU oracle on the same seeded descriptor batches.  Bit-exact."""
+import numpy as np
+import pytest
+
+from mpeg_amd import abi, desc, synth
+from parity import assert_planes_equal, run_and_compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,n,profile,raw,rgba", [
+    (352, 240, 30, "typical", 0.0, False),    # BASELINE config 2: SIF, one GOP of 30 pictures
+    (352, 240, 8, "typical", 0.15, False),    # with int32 snapshot (COEF_RAW) blocks
+    (352, 240, 6, "dense", 0.0, False),       # every block full, odd vectors
+    (160, 120, 10, "typical", 0.05, True),    # fused Frame.RGBA
+    (176, 144, 5, "typical", 0.0, True),
+    (24, 40, 4, "typical", 0.0, True),
+    (1920, 1080, 4, "typical", 0.0, True),    # BASELINE config 3: 1080p, fused IDCT+MC+RGBA
+    (1920, 1080, 2, "dense", 0.0, False),
+])
+def test_reconstruction_bit_exact(oracle, hip_ctx, w, h, n, profile, raw, rgba):
+    seq = synth.generate_sequence(w, h, n, profile=profile, raw_fraction=raw, rgba=rgba)
+    ref, dut = oracle.OracleStore(w, h, threads=4), abi.VideoStore(hip_ctx, w, h)
+    try:
+        run_and_compare(ref, dut, seq, check_rgba=rgba)
+    finally:
+        dut.close()
+        ref.close()
+
+
+def test_custom_quant_matrices(oracle, hip_ctx):
+    rng = np.random.default_rng(5)
+    iq, nq = rng.integers(1, 256, 64), rng.integers(1, 256, 64)
+    ref, dut = oracle.OracleStore(64, 48), abi.VideoStore(hip_ctx, 64, 48)
+    ref.set_quant(0, iq, nq)
+    dut.set_quant(0, iq, nq)
+    run_and_compare(ref, dut, synth.generate_sequence(64, 48, 6, seed=11))
+    dut.close()
+
+
+def test_standalone_rgba(oracle, hip_ctx):
+    w, h = 100, 60
+    ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h, 2)
+    rng = np.random.default_rng(3)
+    g = desc.geometry(w, h)
+    y, cb, cr = (rng.integers(0, 256, n, dtype=np.uint8) for n in (g["luma_bytes"], g["chroma_bytes"], g["chroma_bytes"]))
+    ref.write_planes(0, 1, y, cb, cr)
+    dut.write_planes(1, 1, y, cb, cr)
+    dut.rgba_convert(1)
+    assert np.array_equal(ref.read_rgba(0, 1), dut.read_rgba(1, 1))
+    # untouched stream: RGBA of the all-zero frame
+    zero = oracle.OracleStore(w, h)
+    assert np.array_equal(zero.read_rgba(0, 0), dut.read_rgba(0, 0))
+    dut.close()
+
+
+def test_edge_cases(oracle, hip_ctx):
+    """Empty submits, a single macroblock, pictures that touch only part of a frame."""
+    w, h = 64, 64
+    ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h)
+    dut.submit(np.zeros(0, desc.PIC_DTYPE), np.zeros(0, desc.MB_DTYPE), np.zeros(0, np.uint8))
+    seq = synth.generate_sequence(w, h, 3, seed=7)
+    for s in seq:
+        keep = np.arange(len(s.mbs))[::3]            # ragged: every third macroblock only
+        mbs = s.mbs[keep].copy()
+        pics = s.pics.copy()
+        pics["mb_count"] = len(mbs)
+        ref.submit(pics, mbs, s.coefs)
+        dut.submit(pics, mbs, s.coefs)
+        for slot in range(3):
+            assert_planes_equal(ref.read_planes(0, slot), dut.read_planes(0, slot), "ragged slot %d" % slot)
+    one = seq[0]
+    pics = one.pics.copy()
+    pics["mb_count"] = 1
+    ref.submit(pics, one.mbs[:1], one.coefs)
+    dut.submit(pics, one.mbs[:1], one.coefs)
+    assert_planes_equal(ref.read_planes(0, one.cur), dut.read_planes(0, one.cur), "single macroblock")
+    dut.close()
+
+
+def test_out_of_range_vector_is_rejected(hip_ctx):
+    """The reference panics when a prediction reads before a plane / past the buffer; the ABI refuses the submit."""
+    dut = abi.VideoStore(hip_ctx, 64, 64)
+    pics = np.zeros(1, desc.PIC_DTYPE)
+    pics["cur"], pics["fwd"], pics["bwd"], pics["mb_count"] = 0, 1, 2, 1
+    mbs = np.zeros(1, desc.MB_DTYPE)
+    mbs["flags"], mbs["mv_x"], mbs["mv_y"] = desc.MB_REF_FWD, -2, -2   # macroblock (0,0) reading above the plane
+    with pytest.raises(abi.MpegHipError) as ei:
+        dut.submit(pics, mbs, np.zeros(0, np.uint8))
+    assert ei.value.code == abi.ERR_RANGE
+    mbs["mv_x"], mbs["mv_y"], mbs["mb_x"], mbs["mb_y"] = 0, 200, 3, 3  # far below the pad
+    with pytest.raises(abi.MpegHipError):
+        dut.submit(pics, mbs, np.zeros(0, np.uint8))
+    dut.close()
+
+
+def test_overread_into_next_plane_and_pad(oracle, hip_ctx):
+    """Legal reads past a plane end: bottom-row macroblocks with downward half-pel vectors
+    read the first rows of the next plane / the zero pad, exactly like the reference's shared buffer."""
+    w, h = 48, 32
+    g = desc.geometry(w, h)
+    ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h)
+    rng = np.random.default_rng(9)
+    y, cb, cr = (rng.integers(0, 256, n, dtype=np.uint8) for n in (g["luma_bytes"], g["chroma_bytes"], g["chroma_bytes"]))
+    for st in (ref, dut):
+        st.write_planes(0, 1, y, cb, cr)
+    pics = np.zeros(1, desc.PIC_DTYPE)
+    pics["cur"], pics["fwd"], pics["bwd"] = 0, 1, 2
+    cases = [(mx, my) for mx in (-3, 0, 1, 5) for my in (1, 3, 9, 31)]
+    for mx, my in cases:
+        mbs = np.zeros(g["mb_w"], desc.MB_DTYPE)
+        mbs["mb_x"], mbs["mb_y"] = np.arange(g["mb_w"]), g["mb_h"] - 1
+        mbs["flags"], mbs["mv_x"], mbs["mv_y"] = desc.MB_REF_FWD, mx, my
+        ok = synth.mv_in_range(g, mbs["mb_x"], mbs["mb_y"], mbs["mv_x"], mbs["mv_y"])
+        mbs = mbs[ok]
+        pics["mb_count"] = len(mbs)
+        ref.submit(pics, mbs, np.zeros(0, np.uint8))
+        dut.submit(pics, mbs, np.zeros(0, np.uint8))
+        assert_planes_equal(ref.read_planes(0, 0), dut.read_planes(0, 0), "mv (%d,%d)" % (mx, my))
+    dut.close()
+
+
+def test_many_streams_replicated_batch(oracle, hip_ctx):
+    """BASELINE config 5 in miniature: independent streams, one descriptor set each, no cross-talk.
+    Property: identical inputs => identical FNV-1a-64 per stream, equal to the oracle's."""
+    w, h, n_streams = 352, 240, 64
+    seq = synth.generate_sequence(w, h, 6, seed=21)
+    ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h, n_streams)
+    for s in seq:
+        ref.submit(s.pics, s.mbs, s.coefs)
+        b = dut.upload(s.pics, s.mbs, s.coefs, replicate=n_streams)
+        assert b.n_mbs == len(s.mbs) * n_streams
+        assert b.alg_bytes == synth.alg_bytes(desc.geometry(w, h), s) * n_streams
+        b.run()
+        b.free()
+        want = 0
+        for slot in range(3):
+            hashes = dut.hash_slots(slot)
+            want = oracle.FNV_OFFSET
+            for p in ref.read_planes(0, slot):
+                want = oracle.fnv1a64(p, want)
+            assert (hashes == np.uint64(want)).all(), "slot %d" % slot
+    dut.close()
+
+
+def test_streams_are_independent(oracle, hip_ctx):
+    """Different streams decode different pictures in ONE submit without interfering."""
+    w, h = 96, 80
+    seqs = [synth.generate_sequence(w, h, 4, seed=100 + i) for i in range(3)]
+    ref, dut = oracle.OracleStore(w, h, 3), abi.VideoStore(hip_ctx, w, h, 3)
+    for step in range(4):
+        pics, mbs, coefs, mb0, c0 = [], [], [], 0, 0
+        for sidx, seq in enumerate(seqs):
+            s = seq[step]
+            p, m = s.pics.copy(), s.mbs.copy()
+            p["stream"], p["mb_first"] = sidx, mb0
+            m["pic"] = sidx
+            m["coef_off"] += c0
+            pics.append(p)
+            mbs.append(m)
+            coefs.append(s.coefs)
+            mb0 += len(m)
+            c0 += len(s.coefs) // desc.COEF_UNIT
+        pics, mbs, coefs = np.concatenate(pics), np.concatenate(mbs), np.concatenate(coefs)
+        ref.submit(pics, mbs, coefs)
+        dut.submit(pics, mbs, coefs)
+        for sidx in range(3):
+            for slot in range(3):
+                assert_planes_equal(ref.read_planes(sidx, slot), dut.read_planes(sidx, slot), "stream %d slot %d" % (sidx, slot))
+    dut.close()

@@ -1,0 +1,31 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, rocprof.  Everything lands in gpurun_out/.
+# usage: tools/gpu_round.sh <tag> [bench extra args...]
+set -u
+TAG=${1:-r01}; shift || true
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+echo "== env" | tee $OUT/env.txt
+(rocminfo | grep -E "Name:|Compute Unit|Max Clock" | head -12; nproc; lscpu | grep -E "Model name|Socket|Thread|Core" ; free -g | head -2; go version 2>&1 | head -1) >> $OUT/env.txt 2>&1
+echo "== pytest -m gpu"
+timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -15 $OUT/pytest_gpu.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log
+tail -3 $OUT/smoke.log
+echo "== bench typical"
+timeout 900 python bench.py "$@" > $OUT/bench_typical.json 2> $OUT/bench_typical.err; echo "bench rc=$?"
+tail -c 3000 $OUT/bench_typical.json; tail -5 $OUT/bench_typical.err
+echo "== bench dense"
+timeout 600 python bench.py --profile dense --cpu-seconds 0 --audio-streams 0 "$@" > $OUT/bench_dense.json 2> $OUT/bench_dense.err; echo "bench dense rc=$?"
+tail -c 2500 $OUT/bench_dense.json; tail -5 $OUT/bench_dense.err
+echo "== rocprofv3 kernel trace"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 13 --warmup 13 --cpu-seconds 0 --check 0 "$@" > $GRAFT_REPO_ROOT/$OUT/prof_trace.log 2>&1; echo "rocprof rc=$?"
+cd $GRAFT_REPO_ROOT
+find $OUT/prof_trace -name "*stats*" | head; 
+for f in $(find $OUT/prof_trace -name "*kernel_stats.csv" | head -1); do head -12 $f; done
+# keep the merge-back small: drop the big per-dispatch trace, keep stats
+find $OUT/prof_trace -name "*kernel_trace.csv" -size +20M -delete
+du -sh $OUT
