@@ -1,0 +1,288 @@
+// mpeg.hpp — host-side mirror of the gen2brain/mpeg API above the libmpeghip C ABI.
+//
+// The reference is a Go package; no Go toolchain exists in the build image, so
+// the host layer is C++ with the reference's names, argument meaning and error
+// behaviour (the Go package + cgo shim a maintainer would ship is in go/, see
+// INTEGRATION.md).  The serial work stays on the CPU exactly as in the
+// reference — program-stream demux (demux.go), bit buffer (buffer.go), MPEG-1
+// video VLC parse (video.go:209-745) and MP2 frame parse (audio.go:163-490) —
+// but instead of reconstructing pixels / samples inline, the parsers RECORD
+// macroblock descriptors / sub-band samples and hand one whole picture / audio
+// frame to the GPU through mpeghip_video_submit / mpeghip_audio_synth.
+//
+// There is no CPU reconstruction path here: without a gfx950 device the
+// constructors fail (they need a mpeghip context).
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mpeghip.h"
+
+namespace mpeg {
+
+// ------------------------------------------------------------------ buffer.go
+class Buffer;
+using LoadFunc = std::function<void(Buffer *)>; // buffer.go:14
+
+// buffer.go:17-221.  Data source of all decoders: a growable byte buffer with a
+// bit cursor, fed by Write() or on demand through the load callback.
+class Buffer {
+public:
+    // NewBuffer (buffer.go:32-61).  `reader` may be empty (push mode: Write()).
+    struct Reader {                       // minimal io.ReadSeeker
+        std::function<size_t(uint8_t *, size_t)> read; // returns bytes read, 0 = EOF
+        std::function<bool(size_t)> seek;              // absolute; may be empty (not seekable)
+        size_t size = 0;                               // total size if seekable
+    };
+    explicit Buffer(Reader reader = Reader());
+    static std::unique_ptr<Buffer> FromMemory(const uint8_t *data, size_t len); // bytes.NewReader + LoadReaderCallback
+
+    static size_t BufferSize;            // buffer.go:10 (default 128 KiB)
+
+    const uint8_t *Bytes() const { return bytes_.data(); }
+    size_t Len() const { return bytes_.size(); }
+    size_t Index() const { return bit_index_ >> 3; }            // buffer.go:69
+    bool Seekable() const { return has_reader_ && total_size_ > 0; }
+    size_t Write(const uint8_t *p, size_t n);                   // buffer.go:79-89
+    void SignalEnd() { total_size_ = bytes_.size(); }           // buffer.go:94-96
+    void SetLoadCallback(LoadFunc cb) { load_ = std::move(cb); }
+    void Rewind() { seek(0); }                                  // buffer.go:105-107
+    size_t Size() const { return total_size_ > 0 ? total_size_ : bytes_.size(); }
+    size_t Remaining() const { return bytes_.size() - (bit_index_ >> 3); }
+    bool HasEnded() const { return has_ended_; }
+    void LoadReaderCallback(Buffer *);                           // buffer.go:131-156
+
+    // package-private in the reference; used by the decoders
+    void seek(size_t pos);
+    size_t tell();
+    void discardReadBytes();
+    bool has(size_t count);
+    int read(int count);
+    int read1();
+    uint32_t peek(int count);            // next `count` (<= 24) bits, zero-padded past the end
+    void drop(int count) { bit_index_ += (size_t)count; }
+    void align() { bit_index_ = ((bit_index_ + 7) >> 3) << 3; }
+    void skip(size_t count);
+    int skipBytes(uint8_t v);
+    int nextStartCode();
+    int findStartCode(int code);
+    int hasStartCode(int code);
+    bool findFrameSync();
+    bool peekNonZero(int bitCount);
+    size_t bitIndex() const { return bit_index_; }
+    void setBitIndex(size_t b) { bit_index_ = b; }
+
+private:
+    Reader reader_;
+    bool has_reader_ = false;
+    std::vector<uint8_t> bytes_;
+    size_t bit_index_ = 0;
+    size_t total_size_ = 0;
+    bool has_ended_ = false;
+    bool discard_read_ = true;
+    std::vector<uint8_t> available_;
+    LoadFunc load_;
+};
+
+// -------------------------------------------------------------------- video.go
+struct Plane {                // video.go:50-54
+    int Width = 0, Height = 0;
+    const uint8_t *Data = nullptr;   // host copy (pinned), valid until the next Decode
+    size_t Len = 0;
+};
+
+class Video;
+struct Frame {                // video.go:11-23
+    double Time = 0;
+    int Width = 0, Height = 0;
+    Plane Y, Cb, Cr;
+    // Frame.RGBA (video.go:31-36): width*height*4 bytes, stride 4*width, computed on
+    // the device.  Valid until the next Decode.
+    const uint8_t *RGBA();
+    Video *owner = nullptr;
+    uint32_t slot = 0;
+};
+
+struct VideoStats {
+    uint64_t pictures = 0, submits = 0, macroblocks = 0, coded_blocks = 0, raw_macroblocks = 0;
+    uint64_t invalid_blocks = 0, duplicate_splits = 0, range_skips = 0;
+};
+
+// Shared device context for decoders (one per GPU).
+class Device {
+public:
+    explicit Device(int ordinal = 0);   // throws std::runtime_error without a gfx950 GPU
+    ~Device();
+    mpeghip_ctx *ctx() const { return ctx_; }
+private:
+    mpeghip_ctx *ctx_ = nullptr;
+};
+
+class Video {
+public:
+    Video(Buffer *buf, Device *dev);                 // NewVideo (video.go:110-121)
+    ~Video();
+    Buffer *GetBuffer() { return buf_; }
+    bool HasHeader();                                // video.go:130-147
+    double Framerate() { return HasHeader() ? frame_rate_ : 0; }
+    int Width() { return HasHeader() ? width_ : 0; }
+    int Height() { return HasHeader() ? height_ : 0; }
+    void SetNoDelay(bool v) { assume_no_b_frames_ = v; }
+    double Time() const { return time_; }
+    void SetTime(double t);
+    void Rewind();
+    bool HasEnded() const { return buf_->HasEnded(); }
+    Frame *Decode();                                 // video.go:209-268
+    const VideoStats &Stats() const { return stats_; }
+
+    // used by Frame
+    const uint8_t *fetchRGBA(uint32_t slot);
+
+private:
+    struct Motion { int FullPx = 0, RSize = 0, H = 0, V = 0; bool IsSet = false; };
+    bool decodeSequenceHeader();
+    void decodePicture();
+    void decodeSlice(int slice);
+    void decodeMacroblock();
+    void decodeMotionVectors();
+    int decodeMotionVector(int rSize, int motion);
+    void predictMacroblock();
+    void emitPrediction(int mh, int mv, bool backward);
+    void decodeBlock(int block);
+    void beginMacroblockRecord(bool intra);
+    void endMacroblockRecord();
+    void flushSubmit();
+    Frame *frameForSlot(uint32_t slot);
+
+    Buffer *buf_;
+    Device *dev_;
+    mpeghip_video *store_ = nullptr;
+
+    double frame_rate_ = 0, time_ = 0;
+    int frames_decoded_ = 0;
+    int width_ = 0, height_ = 0, mb_width_ = 0, mb_height_ = 0, mb_size_ = 0;
+    int luma_width_ = 0, luma_height_ = 0, chroma_width_ = 0, chroma_height_ = 0;
+    int start_code_ = -1, picture_type_ = 0;
+    Motion motion_forward_, motion_backward_;
+    bool has_sequence_header_ = false;
+    int quantizer_scale_ = 0;
+    bool slice_begin_ = false;
+    int macroblock_address_ = 0, mb_row_ = 0, mb_col_ = 0, macroblock_type_ = 0;
+    bool macroblock_intra_ = false;
+    int dc_predictor_[3] = {128, 128, 128};
+    uint8_t intra_quant_[64], non_intra_quant_[64];
+    bool has_reference_frame_ = false, assume_no_b_frames_ = false;
+
+    // frame slots (rotation of video.go:406-409 / 430-433)
+    uint32_t slot_cur_ = 0, slot_fwd_ = 1, slot_bwd_ = 2;
+
+    // persistent blockData (video.go:101): only ever non-zero after an invalid block
+    int32_t block_data_[64];
+    bool block_dirty_ = false;
+
+    // per-picture recording
+    std::vector<mpeghip_mb_desc> mbs_;
+    std::vector<uint8_t> coefs_;
+    std::vector<uint8_t> written_;      // macroblock address already emitted in this submit
+    struct BlockRec { bool valid; bool needs_raw; int16_t q[64]; int32_t raw[64]; };
+    struct MbRec { bool active = false, intra = false; int mb_x = 0, mb_y = 0; bool has_pred = false, backward = false;
+                   int mv_x = 0, mv_y = 0; int qscale = 0; int cbp = 0; BlockRec blocks[6]; bool any_raw = false; } rec_;
+
+    Frame frames_[3];
+    std::vector<uint8_t> host_planes_[3];
+    std::vector<uint8_t> host_rgba_;
+    VideoStats stats_;
+};
+
+// -------------------------------------------------------------------- audio.go
+enum AudioFormat { AudioF32N = 0, AudioF32NLR = 1, AudioF32 = 2, AudioS16 = 3 }; // audio.go:12-23
+constexpr int SamplesPerFrame = 1152;                                             // audio.go:9
+
+struct Samples {              // audio.go:27-36
+    double Time = 0;
+    std::vector<int16_t> S16;
+    std::vector<float> F32, Left, Right, Interleaved;
+    AudioFormat format = AudioF32N;
+    const uint8_t *Bytes(size_t *len) const;     // audio.go:39-50
+};
+
+class Audio {
+public:
+    Audio(Buffer *buf, Device *dev, int fma_mode = MPEGHIP_AUDIO_FMA_NONE); // NewAudio (audio.go:83-104)
+    ~Audio();
+    Buffer *GetBuffer() { return buf_; }
+    bool HasHeader();
+    int Samplerate();
+    int Channels() const { return channels_; }
+    double Time() const { return time_; }
+    void SetTime(double t);
+    void Rewind();
+    bool HasEnded() const { return buf_->HasEnded(); }
+    void SetFormat(AudioFormat f) { format_ = f; samples_.format = f; }
+    Samples *Decode();                            // audio.go:163-182
+
+private:
+    struct QuantizerSpec { uint16_t Levels; uint8_t Group, Bits; };
+    int decodeHeader();
+    void decodeFrame();
+    const QuantizerSpec *readAllocation(int sb, int tab3);
+    void readSamples(int ch, int sb, int part);
+
+    Buffer *buf_;
+    Device *dev_;
+    mpeghip_audio *synth_ = nullptr;
+    double time_ = 0;
+    int samples_decoded_ = 0, samplerate_index_ = 3, bitrate_index_ = 0, version_ = 0, layer_ = 0, mode_ = 0;
+    int channels_ = 0, bound_ = 0, next_frame_data_size_ = 0;
+    bool has_header_ = false;
+    const QuantizerSpec *allocation_[2][32] = {};
+    uint8_t scale_factor_info_[2][32] = {};
+    int scale_factor_[2][32][3] = {};
+    int sample_[2][32][3] = {};
+    int32_t frame_samples_[2][36][32];
+    Samples samples_;
+    AudioFormat format_ = AudioF32N;
+    static const QuantizerSpec quant_tab_[17];
+};
+
+// -------------------------------------------------------------------- demux.go
+struct Packet {               // demux.go:11-17
+    int Type = 0;
+    double Pts = 0;
+    const uint8_t *Data = nullptr;
+    size_t Len = 0;
+    int length = 0;
+};
+constexpr int PacketInvalidTS = -1, PacketPrivate = 0xBD, PacketAudio1 = 0xC0, PacketAudio2 = 0xC1,
+              PacketAudio3 = 0xC2, PacketAudio4 = 0xC3, PacketVideo1 = 0xE0; // demux.go:20-29
+
+class Demux {
+public:
+    explicit Demux(Buffer *buf);                   // NewDemux (demux.go:61-76); check HasHeaders()
+    Buffer *GetBuffer() { return buf_; }
+    bool HasHeaders();                             // demux.go:85-155
+    int NumVideoStreams() { return HasHeaders() ? num_video_streams_ : 0; }
+    int NumAudioStreams() { return HasHeaders() ? num_audio_streams_ : 0; }
+    void Rewind();
+    bool HasEnded() const { return buf_->HasEnded(); }
+    Packet *Decode();                              // demux.go:473-516
+
+private:
+    double decodeTime();
+    Packet *decodePacket(int type);
+    Packet *packet();
+    Buffer *buf_;
+    double sys_clock_ref_ = 0;
+    int start_code_ = -1;
+    bool has_pack_header_ = false, has_system_header_ = false, has_headers_ = false;
+    int num_audio_streams_ = 0, num_video_streams_ = 0;
+    Packet current_, next_;
+};
+
+} // namespace mpeg

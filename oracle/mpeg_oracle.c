@@ -226,7 +226,7 @@ enum { START_PICTURE = 0x00, START_SLICE_FIRST = 0x01, START_SLICE_LAST = 0xAF,
 
 /* ============================================================ video: kernels */
 
-static int64_t g_idct_mid; /* running max |intermediate| of the last orc_idct call */
+static _Thread_local int64_t g_idct_mid; /* running max |intermediate| of the last orc_idct call */
 #define TRACK(x) do { int64_t a_ = i64abs(x); if (a_ > g_idct_mid) g_idct_mid = a_; } while (0)
 
 /* One 8-point pass of video.go:870-895 (columns) / :900-925 (rows). */
@@ -431,7 +431,7 @@ static void copy_block(const uint8_t *src, uint8_t *dst, int stride, int64_t si,
     }
 }
 
-static int g_last_overread;
+static _Thread_local int g_last_overread;
 
 int orc_copy_macroblock(int motion_h, int motion_v, int mb_row, int mb_col,
                         const orc_frame *s, orc_frame *d)
