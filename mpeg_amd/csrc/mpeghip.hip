@@ -36,25 +36,39 @@ static __device__ __forceinline__ void wave_lds_handoff()
 
 constexpr int kWaveLdsBytes = kTileDwords * 4 + kRgbaBytes; // 1728 + 384
 
-// One wavefront per macroblock, WAVES macroblocks (consecutive descriptors, i.e.
-// normally consecutive macroblocks of one row) per workgroup so that the 8-byte
-// row stores of neighbouring macroblocks combine into full lines in one L2.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a)
+// One wavefront per macroblock at a time, WAVES macroblocks (consecutive
+// descriptors, i.e. normally consecutive macroblocks of one row) per workgroup
+// so that the 8-byte row stores of neighbouring macroblocks combine into full
+// lines in one L2.
+//
+// MODE 0: one chunk (WAVES macroblocks) per workgroup, grid = all chunks.
+// MODE 1: persistent workgroups; every XCD walks one contiguous range of chunks.
+// MODE 2: MODE 1 + software pipeline: while macroblock i is computed, the global
+//         loads of macroblock i+1 are in flight and the (scalar) descriptor of
+//         macroblock i+2 is being fetched.  The kernel is latency-bound without
+//         it: a wave's life is a chain of dependent round trips (descriptor ->
+//         picture -> pixels/coefficients -> store).
+template <int MODE>
+static __device__ __forceinline__ void chunk_range(uint32_t n_chunks, uint32_t &first, uint32_t &last, uint32_t &step)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES * kWaveLdsBytes];
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const uint32_t mb_index = chunk * WAVES + wave;
-    if (mb_index >= a.n_mbs)
-        return;
-    int32_t *tile = reinterpret_cast<int32_t *>(lds + wave * kWaveLdsBytes);
-    uint8_t *stage = lds + wave * kWaveLdsBytes + kTileDwords * 4;
+    if (MODE == 0) {
+        first = xcd_chunk(blockIdx.x, gridDim.x);
+        last = first + 1;
+        step = 1;
+    } else {
+        const uint32_t nx = 8; // gridDim.x is a multiple of 8
+        const uint32_t xcd = blockIdx.x % nx, k = blockIdx.x / nx, K = gridDim.x / nx;
+        const uint32_t lo = (uint32_t)(((uint64_t)n_chunks * xcd) / nx);
+        const uint32_t hi = (uint32_t)(((uint64_t)n_chunks * (xcd + 1)) / nx);
+        first = lo + k;
+        last = hi;
+        step = K;
+    }
+}
 
-    const MbU u = load_mb(a, mb_index);
-    MbLane st;
-    mb_phase_a(a, u, lane, st, tile);
+static __device__ __forceinline__ void finish_mb(const VideoArgs &a, const MbU &u, int lane, const MbLane &st,
+                                                 int32_t *tile, uint8_t *stage)
+{
     wave_lds_handoff();
     bool wrote;
     const uint64_t out = mb_phase_b(a, u, lane, st, tile, wrote);
@@ -62,6 +76,60 @@ __global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a)
         mb_phase_c_stage(a, u, lane, out, wrote, stage);
         wave_lds_handoff();
         mb_phase_c_convert(a, u, lane, stage);
+    }
+    wave_lds_handoff(); // the tile is rewritten by this wave's next macroblock
+}
+
+template <int WAVES, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a, const uint32_t n_chunks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES * kWaveLdsBytes];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int32_t *tile = reinterpret_cast<int32_t *>(lds + wave * kWaveLdsBytes);
+    uint8_t *stage = lds + wave * kWaveLdsBytes + kTileDwords * 4;
+    uint32_t first, last, step;
+    chunk_range<MODE>(n_chunks, first, last, step);
+
+    if (MODE < 2) {
+        for (uint32_t c = first; c < last; c += step) {
+            const uint32_t mb_index = c * WAVES + wave;
+            if (mb_index >= a.n_mbs)
+                break;
+            const MbU u = load_mb(a, mb_index);
+            MbLane st;
+            mb_phase_a(a, u, lane, st, tile);
+            finish_mb(a, u, lane, st, tile, stage);
+        }
+    } else {
+        // indices of this wave's macroblocks: i0, i0+S, i0+2S, ... while < limit (all wave-uniform)
+        const uint32_t S = step * WAVES;
+        uint32_t i = __builtin_amdgcn_readfirstlane(first * WAVES + wave);
+        const uint64_t chunk_limit = (uint64_t)last * WAVES;
+        const uint32_t limit = (uint32_t)(chunk_limit < a.n_mbs ? chunk_limit : a.n_mbs);
+        if (i >= limit)
+            return;
+        MbU u0 = load_mb(a, i);
+        MbLoads l0;
+        mb_issue_loads(a, u0, lane, l0);
+        // look-ahead indices are clamped instead of branched on: the descriptor loads stay scalar and unconditional
+        MbU u1 = load_mb(a, __builtin_amdgcn_readfirstlane(i + S < limit ? i + S : i));
+        for (;;) {
+            const bool has1 = i + S < limit;
+            const uint32_t i2 = (uint64_t)i + 2ull * S < limit ? i + 2 * S : i;
+            const MbU u2 = load_mb(a, __builtin_amdgcn_readfirstlane(i2)); // scalar loads, two macroblocks ahead
+            MbLoads l1;
+            mb_issue_loads(a, u1, lane, l1); // vector loads of the next macroblock: in flight during the compute below
+            MbLane st;
+            mb_phase_a_compute(a, u0, lane, l0, st, tile);
+            finish_mb(a, u0, lane, st, tile, stage);
+            if (!has1)
+                break;
+            u0 = u1;
+            l0 = l1;
+            u1 = u2;
+            i += S;
+        }
     }
 }
 
@@ -596,9 +664,42 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.height = in.height;
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
-    constexpr int WAVES = 8;
-    const uint32_t blocks = (uint32_t)((b->n_mbs + WAVES - 1) / WAVES);
-    hipLaunchKernelGGL(recon_kernel<WAVES>, dim3(blocks), dim3(WAVES * 64), 0, v->ctx->stream, a);
+    // Development knob (not part of the ABI): MPEGHIP_RECON="mode,waves,blocks_per_cu".
+    int mode = 2, waves = 8, bpc = 4;
+    if (const char *e = getenv("MPEGHIP_RECON"))
+        sscanf(e, "%d,%d,%d", &mode, &waves, &bpc);
+    if (waves != 4 && waves != 8 && waves != 16)
+        waves = 8;
+    if (mode < 0 || mode > 2)
+        mode = 2;
+    const uint32_t n_chunks = (uint32_t)((b->n_mbs + waves - 1) / waves);
+    uint32_t blocks = n_chunks;
+    if (mode != 0) {
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, v->ctx->device);
+        uint32_t want = (uint32_t)n_cu * (uint32_t)(bpc < 1 ? 1 : bpc);
+        want = (want + 7) / 8 * 8;
+        blocks = want;
+    }
+    hipStream_t st = v->ctx->stream;
+#define LAUNCH(W, M) hipLaunchKernelGGL((recon_kernel<W, M>), dim3(blocks), dim3(W * 64), 0, st, a, n_chunks)
+#define LAUNCH_W(W)                                                                                                    \
+    do {                                                                                                               \
+        if (mode == 0)                                                                                                 \
+            LAUNCH(W, 0);                                                                                              \
+        else if (mode == 1)                                                                                            \
+            LAUNCH(W, 1);                                                                                              \
+        else                                                                                                           \
+            LAUNCH(W, 2);                                                                                              \
+    } while (0)
+    if (waves == 4)
+        LAUNCH_W(4);
+    else if (waves == 16)
+        LAUNCH_W(16);
+    else
+        LAUNCH_W(8);
+#undef LAUNCH_W
+#undef LAUNCH
     HIP_TRY(hipGetLastError());
     return MPEGHIP_OK;
 }

@@ -57,10 +57,21 @@ struct MbU {
     uint8_t *rgba;       // RGBA image of the cur slot (or nullptr)
 };
 
+// Descriptors are read-only for the whole launch.  On the device they are read
+// through the constant address space so that the compiler keeps them as scalar
+// (s_load) instructions even inside the persistent loop, after global stores.
+#if MPG_ON_DEVICE
+#define MPG_CONST_AS __attribute__((address_space(4)))
+#else
+#define MPG_CONST_AS
+#endif
+
 MPG_HD MbU load_mb(const VideoArgs &a, uint32_t mb_index)
 {
-    const mpeghip_mb_desc &d = a.mbs[mb_index];
-    const mpeghip_pic_desc &p = a.pics[d.pic];
+    const MPG_CONST_AS mpeghip_mb_desc *mbs = (const MPG_CONST_AS mpeghip_mb_desc *)(uintptr_t)a.mbs;
+    const MPG_CONST_AS mpeghip_pic_desc *pics = (const MPG_CONST_AS mpeghip_pic_desc *)(uintptr_t)a.pics;
+    const MPG_CONST_AS mpeghip_mb_desc &d = mbs[mb_index];
+    const MPG_CONST_AS mpeghip_pic_desc &p = pics[d.pic];
     MbU u;
     u.flags = d.flags;
     u.cbp = d.cbp;
@@ -71,8 +82,7 @@ MPG_HD MbU load_mb(const VideoArgs &a, uint32_t mb_index)
     u.mb_x = d.mb_x;
     u.mb_y = d.mb_y;
     // cur | fwd<<8 | bwd<<16 | flags<<24 in one (scalar) dword load
-    uint32_t slots;
-    __builtin_memcpy(&slots, &p.cur, 4);
+    const uint32_t slots = *(const MPG_CONST_AS uint32_t *)((const MPG_CONST_AS uint8_t *)&p + 4);
     const uint32_t cur_slot = slots & 0xff;
     u.pic_flags = slots >> 24;
     const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
@@ -145,15 +155,28 @@ struct MbLane {
 MPG_HD uint32_t popc6(uint32_t x) { return (uint32_t)__builtin_popcount(x & 0x3f); }
 
 // ------------------------------------------------------------------ phase A
-MPG_HD void mb_phase_a(const VideoArgs &a, const MbU &u, int lane, MbLane &st, int32_t *tile)
+// Phase A is split in two so that a persistent wave can have the loads of the
+// NEXT macroblock in flight while it computes the current one:
+//   mb_issue_loads  — every global load the macroblock needs (prediction source
+//                     qwords, coefficient column, quantiser-matrix column), no use
+//   mb_phase_a_compute — averages, dequantisation, column pass, LDS tile write
+struct MbLoads {
+    uint64_t pa, pb, pc, pd; // prediction source: (row), (row,+1 px), (row+1), (row+1,+1 px)
+    i32x4 c0, c1;            // coefficient column: int16 x8 in c0, or int32 x8 in c0,c1
+    uint64_t qm;             // quantiser matrix column (8 bytes)
+    uint64_t pm;             // premultiplier column (8 bytes)
+};
+
+MPG_HD void mb_issue_loads(const VideoArgs &a, const MbU &u, int lane, MbLoads &ld)
 {
-    st.pred = 0;
     const int b = lane >> 3, j = lane & 7;
+    ld.pa = ld.pb = ld.pc = ld.pd = 0;
+    ld.qm = ld.pm = 0;
+    ld.c0 = i32x4{{0, 0, 0, 0}};
+    ld.c1 = i32x4{{0, 0, 0, 0}};
     if (b >= 6)
         return;
     const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
-
-    // ---- prediction: row j of block b, straight from the reference frame
     if (!intra) {
         int32_t mvx = u.mv_x, mvy = u.mv_y;
         int32_t stride, off;
@@ -172,52 +195,90 @@ MPG_HD void mb_phase_a(const VideoArgs &a, const MbU &u, int lane, MbLane &st, i
         }
         const uint8_t *src = u.ref + off;
         const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
-        const uint64_t A = ld64u(src);
-        if (!oh && !ov) {
-            st.pred = A;
-        } else if (oh && ov) {
-            st.pred = avg4_u8x8(A, ld64u(src + 1), ld64u(src + stride), ld64u(src + stride + 1));
-        } else {
-            st.pred = avg2_u8x8(A, ld64u(src + (oh ? 1 : stride)));
+        ld.pa = ld64u(src);
+        if (oh)
+            ld.pb = ld64u(src + 1);
+        if (ov)
+            ld.pc = ld64u(src + stride);
+        if (oh && ov)
+            ld.pd = ld64u(src + stride + 1);
+    }
+    if (!(u.cbp & (0x20u >> b)))
+        return;
+    const uint32_t k = popc6(u.cbp >> (6 - b)); // coded blocks before b
+    if (u.flags & MPEGHIP_MB_COEF_RAW) {
+        const i32x4 *c = reinterpret_cast<const i32x4 *>(
+            a.coefs + ((uint64_t)u.coef_off + 2 * k) * MPEGHIP_COEF_UNIT + (uint32_t)j * 32);
+        ld.c0 = c[0];
+        ld.c1 = c[1];
+    } else {
+        ld.c0 = *reinterpret_cast<const i32x4 *>(
+            a.coefs + ((uint64_t)u.coef_off + k) * MPEGHIP_COEF_UNIT + (uint32_t)j * 16);
+        ld.qm = *reinterpret_cast<const uint64_t *>(u.qm + j * 8);
+        ld.pm = *reinterpret_cast<const uint64_t *>(a.premult + j * 8);
+    }
+}
+
+MPG_HD void mb_phase_a_compute(const VideoArgs &a, const MbU &u, int lane, const MbLoads &ld, MbLane &st, int32_t *tile)
+{
+    (void)a;
+    st.pred = 0;
+    const int b = lane >> 3, j = lane & 7;
+    if (b >= 6)
+        return;
+    const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
+
+    // ---- prediction: row j of block b (video_noasm.go:48-80)
+    if (!intra) {
+        int32_t mvx = u.mv_x, mvy = u.mv_y;
+        if (b >= 4) {
+            mvx /= 2;
+            mvy /= 2;
         }
+        const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
+        if (!oh && !ov)
+            st.pred = ld.pa;
+        else if (oh && ov)
+            st.pred = avg4_u8x8(ld.pa, ld.pb, ld.pc, ld.pd);
+        else
+            st.pred = avg2_u8x8(ld.pa, oh ? ld.pb : ld.pc);
     }
 
     // ---- residual: column j of block b
     if (!(u.cbp & (0x20u >> b)))
         return;
-    const uint32_t k = popc6(u.cbp >> (6 - b)); // coded blocks before b
     int32_t v[8];
     if (u.flags & MPEGHIP_MB_COEF_RAW) {
-        const i32x4 *c = reinterpret_cast<const i32x4 *>(
-            a.coefs + ((uint64_t)u.coef_off + 2 * k) * MPEGHIP_COEF_UNIT + (uint32_t)j * 32);
-        const i32x4 c0 = c[0], c1 = c[1];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            v[r] = c0.v[r];
-            v[r + 4] = c1.v[r];
+            v[r] = ld.c0.v[r];
+            v[r + 4] = ld.c1.v[r];
         }
     } else {
-        const i16x8 cc = *reinterpret_cast<const i16x8 *>(
-            a.coefs + ((uint64_t)u.coef_off + k) * MPEGHIP_COEF_UNIT + (uint32_t)j * 16);
-        const int16_t *c = cc.v;
-        const uint64_t qm = *reinterpret_cast<const uint64_t *>(u.qm + j * 8);
-        const uint64_t pm = *reinterpret_cast<const uint64_t *>(a.premult + j * 8);
         const int32_t qs = (int32_t)u.qscale;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int32_t q = c[r];
-            const int32_t qsqm = qs * (int32_t)((qm >> (8 * r)) & 0xff);
-            const int32_t p = (int32_t)((pm >> (8 * r)) & 0xff);
+            const int32_t w = ld.c0.v[r >> 1];
+            const int32_t q = (r & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
+            const int32_t qsqm = qs * (int32_t)((ld.qm >> (8 * r)) & 0xff);
+            const int32_t p = (int32_t)((ld.pm >> (8 * r)) & 0xff);
             v[r] = q ? dequant(q, intra, qsqm, p) : 0;
         }
         if (intra && j == 0)
-            v[0] = (int32_t)c[0] * 256; // DC: `<<= 3+5`, video.go:672
+            v[0] = (int32_t)(int16_t)(ld.c0.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
     }
     idct8<false>(v);
     int32_t *t = tile + b * kTileStride + j;
 #pragma unroll
     for (int r = 0; r < 8; r++)
         t[r * 8] = v[r];
+}
+
+MPG_HD void mb_phase_a(const VideoArgs &a, const MbU &u, int lane, MbLane &st, int32_t *tile)
+{
+    MbLoads ld;
+    mb_issue_loads(a, u, lane, ld);
+    mb_phase_a_compute(a, u, lane, ld, st, tile);
 }
 
 // ------------------------------------------------------------------ phase B
