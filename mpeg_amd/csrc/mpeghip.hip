@@ -19,6 +19,7 @@
 #include "iso11172_synth_window.h"
 #include "mpeghip.h"
 #include "video_lane.h"
+#include "video_split_lane.h"
 
 using namespace mpg;
 
@@ -91,7 +92,60 @@ __global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a, co
     uint32_t first, last, step;
     chunk_range<MODE>(n_chunks, first, last, step);
 
-    if (MODE < 2) {
+    if (MODE == 3) {
+        // Software pipeline with compile-time load / store counts (see mb_issue_loads_static):
+        // two macroblocks' worth of loads are in flight per wave, the descriptor of a third
+        // is being fetched by scalar loads.  Unrolled by two so the load registers ping-pong
+        // without moves (a move would have to wait for the data).
+        const uint32_t S = step * WAVES;
+        uint32_t i = __builtin_amdgcn_readfirstlane(first * WAVES + wave);
+        const uint64_t chunk_limit = (uint64_t)last * WAVES;
+        const uint32_t limit = (uint32_t)(chunk_limit < a.n_mbs ? chunk_limit : a.n_mbs);
+        if (i >= limit)
+            return;
+        uint8_t *sink = a.dump + ((uint64_t)blockIdx.x * WAVES + wave) * 512 + (uint32_t)lane * 8;
+        auto clampi = [&](uint64_t x) { return __builtin_amdgcn_readfirstlane((uint32_t)(x < limit ? x : limit - 1)); };
+        auto finish = [&](const MbU &u, const MbLane &st) {
+            wave_lds_handoff();
+            bool wrote;
+            const uint64_t out = mb_phase_b_t<true>(a, u, lane, st, tile, wrote, sink);
+            if (u.rgba) {
+                mb_phase_c_stage(a, u, lane, out, wrote, stage);
+                wave_lds_handoff();
+                mb_phase_c_convert(a, u, lane, stage);
+            }
+            wave_lds_handoff();
+        };
+        MbU ua = load_mb(a, i);
+        MbLoads la, lb;
+        mb_issue_loads_static(a, ua, lane, la);
+        MbU ub = load_mb(a, clampi((uint64_t)i + S));
+        for (;;) {
+            // even step: compute A while B's loads fly
+            MbU uc = load_mb(a, clampi((uint64_t)i + 2ull * S));
+            mb_issue_loads_static(a, ub, lane, lb);
+            {
+                MbLane st;
+                mb_phase_a_compute_static(a, ua, lane, la, st, tile);
+                finish(ua, st);
+            }
+            if ((uint64_t)i + S >= limit)
+                break;
+            // odd step: compute B while C's loads fly (C's loads land in A's registers)
+            MbU ud = load_mb(a, clampi((uint64_t)i + 3ull * S));
+            mb_issue_loads_static(a, uc, lane, la);
+            {
+                MbLane st;
+                mb_phase_a_compute_static(a, ub, lane, lb, st, tile);
+                finish(ub, st);
+            }
+            if ((uint64_t)i + 2ull * S >= limit)
+                break;
+            ua = uc;
+            ub = ud;
+            i += 2 * S;
+        }
+    } else if (MODE < 2) {
         for (uint32_t c = first; c < last; c += step) {
             const uint32_t mb_index = c * WAVES + wave;
             if (mb_index >= a.n_mbs)
@@ -131,6 +185,47 @@ __global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a, co
             i += S;
         }
     }
+}
+
+// ---- split path (video_split_lane.h): K1 prediction, K2 dense residual
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pred_kernel(const SplitArgs s)
+{
+    const uint32_t wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+    const uint32_t mb_index = (chunk * WAVES + wave) * 2 + (uint32_t)(lane >> 5);
+    if (mb_index < s.v.n_mbs)
+        pred_lane(s, mb_index, lane & 31);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void resid_kernel(const SplitArgs s)
+{
+    __shared__ __attribute__((aligned(16))) int32_t tiles[WAVES * kResidTileDwords];
+    const uint32_t wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 3, j = lane & 7;
+    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+    const uint32_t unit = (chunk * WAVES + wave) * 8 + (uint32_t)g;
+    int32_t *tile_g = tiles + wave * kResidTileDwords + g * kTileStride;
+    ResidLane st;
+    resid_phase_a(s, unit, j, tile_g, st);
+    wave_lds_handoff();
+    resid_phase_b(s, j, tile_g, st);
+}
+
+// Frame.RGBA of the cur slot of every picture flagged MPEGHIP_PIC_RGBA: grid (x quads, rows, pictures).
+__global__ __launch_bounds__(256) void rgba_pics_kernel(const VideoArgs a, uint32_t pic0)
+{
+    const mpeghip_pic_desc p = a.pics[pic0 + blockIdx.z];
+    if (!(p.flags & MPEGHIP_PIC_RGBA))
+        return;
+    const uint32_t x4 = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const uint64_t fs = (uint64_t)p.stream * MPEGHIP_SLOTS + p.cur;
+    rgba_convert_quad(a.frames + fs * a.frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, a.width,
+                      a.height, x4, y, a.rgba + fs * a.rgba_stride);
 }
 
 // Frame.RGBA for whole slots: grid (x quads, rows, streams).
@@ -247,7 +342,10 @@ struct mpeghip_batch {
     uint8_t *d_coefs = nullptr;
     uint64_t n_pics = 0, n_mbs = 0, coef_bytes = 0;
     uint64_t alg_bytes = 0;
-    size_t cap_pics = 0, cap_mbs = 0, cap_coefs = 0; // capacities (transient batch reuse)
+    BlockEntry *d_entries = nullptr; // split path work list, one per coefficient unit
+    bool dense_partition = false;   // coefficient units are an ordered partition of the stream: no memset needed
+    bool any_rgba = false;
+    size_t cap_pics = 0, cap_mbs = 0, cap_coefs = 0, cap_entries = 0; // capacities (transient batch reuse)
 };
 
 struct mpeghip_video {
@@ -255,8 +353,9 @@ struct mpeghip_video {
     mpeghip_video_info info{};
     uint8_t *d_frames = nullptr;
     uint8_t *d_rgba = nullptr;
-    uint8_t *d_qmat = nullptr;    // [n_streams][2][64] column-major
-    uint8_t *d_premult = nullptr; // [64]
+    uint8_t *d_qmat = nullptr;    // [n_streams][2][8][16]: per column {8 matrix bytes, 8 premultiplier bytes}
+    uint8_t *d_dump = nullptr;    // sink for the static-count stores of the pipelined kernel
+    size_t dump_bytes = 0;
     uint64_t *d_hash = nullptr;
     mpeghip_batch transient;
 };
@@ -286,6 +385,18 @@ static const uint8_t k_premult[64] = {
     42, 58, 55, 49, 42, 33, 23, 12, 38, 52, 49, 44, 38, 30, 20, 10,
     32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30, 25, 20, 14, 7,
     17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
+
+// One stream's device table: for each class (intra, non-intra) and column c, the 8
+// matrix entries of that column (rows 0..7) followed by the 8 premultipliers.
+static void make_qtable(uint8_t out[256], const uint8_t intra[64], const uint8_t non_intra[64])
+{
+    for (int cls = 0; cls < 2; cls++)
+        for (int c = 0; c < 8; c++)
+            for (int r = 0; r < 8; r++) {
+                out[cls * 128 + c * 16 + r] = (cls ? non_intra : intra)[r * 8 + c];
+                out[cls * 128 + c * 16 + 8 + r] = k_premult[r * 8 + c];
+            }
+}
 
 extern "C" {
 
@@ -442,8 +553,11 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
             rc = fail(MPEGHIP_ERR_OOM, "hipMalloc(%llu) for the frame store failed", (unsigned long long)total);
             break;
         }
-        if (hipMalloc((void **)&v->d_qmat, (size_t)n_streams * 128) != hipSuccess ||
-            hipMalloc((void **)&v->d_premult, 64) != hipSuccess ||
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        v->dump_bytes = (size_t)(n_cu + 8) * 32 /* waves per CU */ * 512;
+        if (hipMalloc((void **)&v->d_qmat, (size_t)n_streams * 256) != hipSuccess ||
+            hipMalloc((void **)&v->d_dump, v->dump_bytes) != hipSuccess ||
             hipMalloc((void **)&v->d_hash, (size_t)n_streams * 8) != hipSuccess) {
             rc = fail(MPEGHIP_ERR_OOM, "hipMalloc for tables failed");
             break;
@@ -452,16 +566,12 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
             rc = fail(MPEGHIP_ERR_HIP, "hipMemsetAsync failed");
             break;
         }
-        std::vector<uint8_t> qm((size_t)n_streams * 128);
-        for (uint32_t s = 0; s < n_streams; s++) {
-            for (int r = 0; r < 8; r++)
-                for (int col = 0; col < 8; col++) {
-                    qm[(size_t)s * 128 + col * 8 + r] = k_default_intra[r * 8 + col];
-                    qm[(size_t)s * 128 + 64 + col * 8 + r] = 16; // video.go:1066-1075
-                }
-        }
-        if (hipMemcpy(v->d_qmat, qm.data(), qm.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(v->d_premult, k_premult, 64, hipMemcpyHostToDevice) != hipSuccess) {
+        std::vector<uint8_t> qm((size_t)n_streams * 256);
+        uint8_t non_intra[64];
+        memset(non_intra, 16, 64); // video.go:1066-1075
+        for (uint32_t s = 0; s < n_streams; s++)
+            make_qtable(&qm[(size_t)s * 256], k_default_intra, non_intra);
+        if (hipMemcpy(v->d_qmat, qm.data(), qm.size(), hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(MPEGHIP_ERR_HIP, "table upload failed");
             break;
         }
@@ -487,6 +597,10 @@ static void batch_release(mpeghip_batch *b)
         (void)hipFree(b->d_mbs);
     if (b->d_coefs)
         (void)hipFree(b->d_coefs);
+    if (b->d_entries)
+        (void)hipFree(b->d_entries);
+    b->d_entries = nullptr;
+    b->cap_entries = 0;
     b->d_pics = nullptr;
     b->d_mbs = nullptr;
     b->d_coefs = nullptr;
@@ -506,8 +620,8 @@ void mpeghip_video_close(mpeghip_video *v)
         (void)hipFree(v->d_rgba);
     if (v->d_qmat)
         (void)hipFree(v->d_qmat);
-    if (v->d_premult)
-        (void)hipFree(v->d_premult);
+    if (v->d_dump)
+        (void)hipFree(v->d_dump);
     if (v->d_hash)
         (void)hipFree(v->d_hash);
     delete v;
@@ -525,15 +639,11 @@ int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream, const uint8_t int
 {
     if (!v || !intra || !non_intra || stream >= v->info.n_streams)
         return fail(MPEGHIP_ERR_INVALID, "bad argument");
-    uint8_t t[128];
-    for (int r = 0; r < 8; r++)
-        for (int c = 0; c < 8; c++) {
-            t[c * 8 + r] = intra[r * 8 + c];
-            t[64 + c * 8 + r] = non_intra[r * 8 + c];
-        }
+    uint8_t t[256];
+    make_qtable(t, intra, non_intra);
     HIP_TRY(hipSetDevice(v->ctx->device));
     HIP_TRY(hipStreamSynchronize(v->ctx->stream)); // earlier pictures may still read the old matrices
-    HIP_TRY(hipMemcpy(v->d_qmat + (size_t)stream * 128, t, 128, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(v->d_qmat + (size_t)stream * 256, t, 256, hipMemcpyHostToDevice));
     return MPEGHIP_OK;
 }
 
@@ -553,11 +663,13 @@ static int ensure_rgba(mpeghip_video *v)
     return MPEGHIP_OK;
 }
 
+static bool wants_rgba(const mpeghip_pic_desc *pics, uint32_t n_pics);
 static uint64_t rgba_stride_of(const mpeghip_video *v) { return align_up(v->info.rgba_bytes, 256); }
 
 // Host-side validation of one submit; also totals the algorithmic bytes.
 static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
-                    const mpeghip_mb_desc *mbs, uint32_t n_mbs, size_t coef_bytes, uint64_t *alg_bytes)
+                    const mpeghip_mb_desc *mbs, uint32_t n_mbs, size_t coef_bytes, uint64_t *alg_bytes,
+                    bool *dense_partition)
 {
     const mpeghip_video_info &in = v->info;
     if (n_pics && !pics)
@@ -578,6 +690,8 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
     const int64_t cap_c1 = (int64_t)(in.frame_bytes - in.luma_bytes - in.chroma_bytes);
     uint64_t alg = 0;
     const uint64_t coef_units = coef_bytes / MPEGHIP_COEF_UNIT;
+    uint64_t next_unit = 0;
+    bool dense = true;
     for (uint32_t i = 0; i < n_mbs; i++) {
         const mpeghip_mb_desc &m = mbs[i];
         if (m.pic >= n_pics)
@@ -598,6 +712,11 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
             return fail(MPEGHIP_ERR_INVALID, "macroblock %u: coefficient blocks beyond the buffer", i);
         if (!raw && nb && (m.qscale == 0 || m.qscale > 31))
             return fail(MPEGHIP_ERR_INVALID, "macroblock %u: quantiser_scale %u", i, m.qscale);
+        if (nb) {
+            if (m.coef_off != next_unit)
+                dense = false;
+            next_unit = (uint64_t)m.coef_off + units;
+        }
         uint64_t ref_bytes = 0;
         if (!intra) {
             // extents of the reference's copyBlock reads (video_noasm.go:48-80): Go
@@ -622,6 +741,8 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
     }
     if (alg_bytes)
         *alg_bytes = alg;
+    if (dense_partition)
+        *dense_partition = dense && next_unit == coef_units;
     return MPEGHIP_OK;
 }
 
@@ -658,20 +779,57 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.mbs = b->d_mbs;
     a.coefs = b->d_coefs;
     a.qmat = v->d_qmat;
-    a.premult = v->d_premult;
+    a.dump = v->d_dump;
     a.n_mbs = (uint32_t)b->n_mbs;
     a.width = in.width;
     a.height = in.height;
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
     // Development knob (not part of the ABI): MPEGHIP_RECON="mode,waves,blocks_per_cu".
-    int mode = 2, waves = 8, bpc = 4;
+    //   mode 4 (default): split path, K1 prediction + K2 dense residual (+ RGBA pass)
+    //   mode 0: fused one-wave-per-macroblock kernel;  1-3: its persistent / pipelined variants
+    int mode = 4, waves = 8, bpc = 4;
     if (const char *e = getenv("MPEGHIP_RECON"))
         sscanf(e, "%d,%d,%d", &mode, &waves, &bpc);
     if (waves != 4 && waves != 8 && waves != 16)
         waves = 8;
-    if (mode < 0 || mode > 2)
-        mode = 2;
+    if (mode < 0 || mode > 4)
+        mode = 4;
+    if (mode == 4) {
+        hipStream_t st = v->ctx->stream;
+        SplitArgs s;
+        s.v = a;
+        s.entries = b->d_entries;
+        s.n_units = (uint32_t)(b->coef_bytes / MPEGHIP_COEF_UNIT);
+        if (!b->dense_partition && s.n_units)
+            HIP_TRY(hipMemsetAsync(b->d_entries, 0xff, (size_t)s.n_units * sizeof(BlockEntry), st));
+        const uint32_t pred_blocks = (uint32_t)((b->n_mbs + 2 * waves - 1) / (2 * waves));
+        const uint32_t resid_blocks = (s.n_units + 8 * waves - 1) / (8 * waves);
+#define LAUNCH_SPLIT(W)                                                                                                \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((pred_kernel<W>), dim3(pred_blocks), dim3(W * 64), 0, st, s);                               \
+        if (resid_blocks)                                                                                              \
+            hipLaunchKernelGGL((resid_kernel<W>), dim3(resid_blocks), dim3(W * 64), 0, st, s);                         \
+    } while (0)
+        if (waves == 4)
+            LAUNCH_SPLIT(4);
+        else if (waves == 16)
+            LAUNCH_SPLIT(16);
+        else
+            LAUNCH_SPLIT(8);
+#undef LAUNCH_SPLIT
+        HIP_TRY(hipGetLastError());
+        if (b->any_rgba) {
+            const uint32_t quads = (in.width + 3) / 4;
+            for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
+                const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
+                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 3) / 4, np), dim3(256), 0, st, a,
+                                   (uint32_t)p0);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        return MPEGHIP_OK;
+    }
     const uint32_t n_chunks = (uint32_t)((b->n_mbs + waves - 1) / waves);
     uint32_t blocks = n_chunks;
     if (mode != 0) {
@@ -679,6 +837,8 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, v->ctx->device);
         uint32_t want = (uint32_t)n_cu * (uint32_t)(bpc < 1 ? 1 : bpc);
         want = (want + 7) / 8 * 8;
+        while ((size_t)want * (size_t)waves * 512 > v->dump_bytes && want > 8)
+            want -= 8;
         blocks = want;
     }
     hipStream_t st = v->ctx->stream;
@@ -689,6 +849,8 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
             LAUNCH(W, 0);                                                                                              \
         else if (mode == 1)                                                                                            \
             LAUNCH(W, 1);                                                                                              \
+        else if (mode == 3)                                                                                            \
+            LAUNCH(W, 3);                                                                                              \
         else                                                                                                           \
             LAUNCH(W, 2);                                                                                              \
     } while (0)
@@ -716,7 +878,8 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
                        const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
                        uint32_t replicas)
 {
-    int rc = validate(v, pics, n_pics, mbs, n_mbs, coef_bytes, &b->alg_bytes);
+    int rc = validate(v, pics, n_pics, mbs, n_mbs, coef_bytes, &b->alg_bytes, &b->dense_partition);
+    b->any_rgba = wants_rgba(pics, n_pics);
     if (rc != MPEGHIP_OK)
         return rc;
     if (n_mbs > 0 && coef_bytes > 0 && !coefs)
@@ -735,7 +898,8 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
         HIP_TRY(hipStreamSynchronize(st));
     if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
         (rc = grow((void **)&b->d_mbs, &b->cap_mbs, sizeof(mpeghip_mb_desc) * (size_t)n_mbs * replicas + 32)) != 0 ||
-        (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0)
+        (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0 ||
+        (rc = grow((void **)&b->d_entries, &b->cap_entries, (coef_bytes / MPEGHIP_COEF_UNIT) * replicas * sizeof(BlockEntry) + 64)) != 0)
         return rc;
     if (n_pics)
         HIP_TRY(hipMemcpyAsync(b->d_pics, pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics, hipMemcpyHostToDevice, st));

@@ -33,8 +33,9 @@ struct VideoArgs {
     const mpeghip_pic_desc *pics;
     const mpeghip_mb_desc *mbs;
     const uint8_t *coefs;         // 128-byte units
-    const uint8_t *qmat;          // [n_streams][2][64]: intra, non-intra; column-major
-    const uint8_t *premult;       // [64] column-major (the matrix is symmetric)
+    const uint8_t *qmat;          // [n_streams][2 classes][8 columns][16]: per column 8 quantiser-matrix
+                                  // bytes (rows 0-7) then the 8 premultiplier bytes of that column
+    uint8_t *dump;                // scratch: 512 bytes per resident wave (sink of the static-count stores)
     uint32_t n_mbs;
     uint32_t width, height;       // display size (RGBA image)
     uint8_t *rgba;                // base of RGBA images, same (stream, slot) indexing
@@ -53,7 +54,7 @@ struct MbU {
     uint32_t pic_flags;
     uint8_t *cur;
     const uint8_t *ref;
-    const uint8_t *qm;   // 64-byte column-major matrix for this macroblock's class
+    const uint8_t *qm;   // 128-byte column table {matrix column, premultiplier column} of this macroblock's class
     uint8_t *rgba;       // RGBA image of the cur slot (or nullptr)
 };
 
@@ -89,7 +90,7 @@ MPG_HD MbU load_mb(const VideoArgs &a, uint32_t mb_index)
     u.cur = a.frames + (s3 + cur_slot) * a.frame_stride;
     const uint32_t ref_slot = (d.flags & MPEGHIP_MB_REF_BWD) ? (slots >> 16) & 0xff : (slots >> 8) & 0xff;
     u.ref = a.frames + (s3 + ref_slot) * a.frame_stride;
-    u.qm = a.qmat + (uint64_t)p.stream * 128 + ((d.flags & MPEGHIP_MB_INTRA) ? 0 : 64);
+    u.qm = a.qmat + (uint64_t)p.stream * 256 + ((d.flags & MPEGHIP_MB_INTRA) ? 0 : 128);
     u.rgba = (u.pic_flags & MPEGHIP_PIC_RGBA) ? a.rgba + (s3 + cur_slot) * a.rgba_stride : nullptr;
     return u;
 }
@@ -214,8 +215,9 @@ MPG_HD void mb_issue_loads(const VideoArgs &a, const MbU &u, int lane, MbLoads &
     } else {
         ld.c0 = *reinterpret_cast<const i32x4 *>(
             a.coefs + ((uint64_t)u.coef_off + k) * MPEGHIP_COEF_UNIT + (uint32_t)j * 16);
-        ld.qm = *reinterpret_cast<const uint64_t *>(u.qm + j * 8);
-        ld.pm = *reinterpret_cast<const uint64_t *>(a.premult + j * 8);
+        const i32x4 t = *reinterpret_cast<const i32x4 *>(u.qm + j * 16);
+        ld.qm = (uint64_t)(uint32_t)t.v[0] | ((uint64_t)(uint32_t)t.v[1] << 32);
+        ld.pm = (uint64_t)(uint32_t)t.v[2] | ((uint64_t)(uint32_t)t.v[3] << 32);
     }
 }
 
@@ -274,6 +276,61 @@ MPG_HD void mb_phase_a_compute(const VideoArgs &a, const MbU &u, int lane, const
         t[r * 8] = v[r];
 }
 
+// Branch-free variant of mb_issue_loads for the software pipeline: EVERY lane issues
+// exactly six loads (4 x 8 bytes of prediction source, 2 x 16 bytes of coefficients /
+// tables) whatever the macroblock type, so the compiler can count them and wait for
+// "all but the newest six" (s_waitcnt vmcnt(N)) instead of draining the queue.
+// Loads a macroblock does not need go to harmless valid addresses (its own
+// destination rows, the head of the coefficient buffer) and their results are ignored.
+MPG_HD void mb_issue_loads_static(const VideoArgs &a, const MbU &u, int lane, MbLoads &ld)
+{
+    const int b0 = lane >> 3, j = lane & 7;
+    const int b = b0 < 6 ? b0 : 5;
+    const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
+    int32_t mvx = intra ? 0 : u.mv_x, mvy = intra ? 0 : u.mv_y;
+    int32_t stride, off;
+    if (b < 4) {
+        stride = (int32_t)a.luma_w;
+        const int32_t y = (int32_t)(u.mb_y << 4) + j + ((b >> 1) << 3) + (mvy >> 1);
+        const int32_t x = (int32_t)(u.mb_x << 4) + ((b & 1) << 3) + (mvx >> 1);
+        off = y * stride + x;
+    } else {
+        mvx /= 2;
+        mvy /= 2;
+        stride = (int32_t)a.chroma_w;
+        const int32_t y = (int32_t)(u.mb_y << 3) + j + (mvy >> 1);
+        const int32_t x = (int32_t)(u.mb_x << 3) + (mvx >> 1);
+        off = (int32_t)(a.luma_bytes + (b == 5 ? a.chroma_bytes : 0)) + y * stride + x;
+    }
+    const uint8_t *src = (intra ? (const uint8_t *)u.cur : u.ref) + off;
+    const int32_t dx = mvx & 1, dy = (mvy & 1) ? stride : 0;
+    ld.pa = ld64u(src);
+    ld.pb = ld64u(src + dx);
+    ld.pc = ld64u(src + dy);
+    ld.pd = ld64u(src + dy + dx);
+
+    const bool coded = b0 < 6 && (u.cbp & (0x20u >> b)) != 0;
+    const bool raw = (u.flags & MPEGHIP_MB_COEF_RAW) != 0;
+    const uint32_t k = popc6(u.cbp >> (6 - b));
+    const uint8_t *cp = a.coefs + ((uint64_t)u.coef_off + (raw ? 2 * k : k)) * MPEGHIP_COEF_UNIT + (uint32_t)j * (raw ? 32u : 16u);
+    if (!coded)
+        cp = a.coefs + (uint32_t)lane * 16;
+    const uint8_t *cp2 = (coded && raw) ? cp + 16 : u.qm + j * 16;
+    ld.c0 = *reinterpret_cast<const i32x4 *>(cp);
+    ld.c1 = *reinterpret_cast<const i32x4 *>(cp2);
+    ld.qm = ld.pm = 0;
+}
+
+// compute half for loads issued by mb_issue_loads_static
+MPG_HD void mb_phase_a_compute_static(const VideoArgs &a, const MbU &u, int lane, MbLoads &ld, MbLane &st, int32_t *tile)
+{
+    if (!(u.flags & MPEGHIP_MB_COEF_RAW)) {
+        ld.qm = (uint64_t)(uint32_t)ld.c1.v[0] | ((uint64_t)(uint32_t)ld.c1.v[1] << 32);
+        ld.pm = (uint64_t)(uint32_t)ld.c1.v[2] | ((uint64_t)(uint32_t)ld.c1.v[3] << 32);
+    }
+    mb_phase_a_compute(a, u, lane, ld, st, tile);
+}
+
 MPG_HD void mb_phase_a(const VideoArgs &a, const MbU &u, int lane, MbLane &st, int32_t *tile)
 {
     MbLoads ld;
@@ -283,16 +340,25 @@ MPG_HD void mb_phase_a(const VideoArgs &a, const MbU &u, int lane, MbLane &st, i
 
 // ------------------------------------------------------------------ phase B
 // Returns the lane's 8 output bytes (also when nothing is stored) for phase C.
-MPG_HD uint64_t mb_phase_b(const VideoArgs &a, const MbU &u, int lane, const MbLane &st, const int32_t *tile, bool &wrote)
+// kStaticStore: every lane (also idle ones) issues exactly one 8-byte store; lanes with
+// nothing to write aim it at their private slot of the dump buffer (`sink`).
+template <bool kStaticStore>
+MPG_HD uint64_t mb_phase_b_t(const VideoArgs &a, const MbU &u, int lane, const MbLane &st, const int32_t *tile, bool &wrote, uint8_t *sink)
 {
     wrote = false;
     const int b = lane >> 3, j = lane & 7;
-    if (b >= 6)
+    if (b >= 6) {
+        if (kStaticStore)
+            *reinterpret_cast<uint64_t *>(sink) = 0;
         return 0;
+    }
     const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
     const bool coded = (u.cbp & (0x20u >> b)) != 0;
-    if (intra && !coded)
+    if (intra && !coded) {
+        if (kStaticStore)
+            *reinterpret_cast<uint64_t *>(sink) = 0;
         return 0; // an invalid intra block leaves the old pixels (video.go:711-714)
+    }
 
     uint64_t out = st.pred;
     if (coded) {
@@ -325,6 +391,11 @@ MPG_HD uint64_t mb_phase_b(const VideoArgs &a, const MbU &u, int lane, const MbL
     *reinterpret_cast<uint64_t *>(u.cur + off) = out; // 8-byte aligned: x is a multiple of 8
     wrote = true;
     return out;
+}
+
+MPG_HD uint64_t mb_phase_b(const VideoArgs &a, const MbU &u, int lane, const MbLane &st, const int32_t *tile, bool &wrote)
+{
+    return mb_phase_b_t<false>(a, u, lane, st, tile, wrote, nullptr);
 }
 
 // ------------------------------------------------------------------ colour

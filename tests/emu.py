@@ -38,7 +38,9 @@ def lib():
         L = C.CDLL(str(LIB))
         P = C.c_void_p
         L.emu_video_run.restype = C.c_int
-        L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, P, C.c_uint32, P, P, P, P, C.c_uint64]
+        L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, P, C.c_uint32, P, P, P, P, C.c_uint64, C.c_int]
+        L.emu_video_run_split.restype = C.c_int
+        L.emu_video_run_split.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, C.c_uint64]
         L.emu_rgba_convert.restype = None
         L.emu_rgba_convert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P]
         L.emu_audio_run.restype = C.c_int
@@ -57,28 +59,35 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def _colmajor(m):
-    return np.ascontiguousarray(np.asarray(m, np.uint8).reshape(8, 8).T).reshape(64)
+def _qtable(intra, non_intra):
+    """[2 classes][8 columns][16]: 8 matrix bytes of the column (rows 0-7), then its 8 premultipliers."""
+    t = np.zeros((2, 8, 16), np.uint8)
+    pm = np.asarray(synth.PREMULT, np.uint8).reshape(8, 8)
+    for cls, m in enumerate((intra, non_intra)):
+        m = np.asarray(m, np.uint8).reshape(8, 8)
+        t[cls, :, :8] = m.T
+        t[cls, :, 8:] = pm.T
+    return t.reshape(256)
 
 
 class EmuStore:
-    def __init__(self, width, height, n_streams=1):
+    def __init__(self, width, height, n_streams=1, static_pipeline=False, split=False):
+        self.static_pipeline = int(static_pipeline)
+        self.split = split
+        self.dump = np.zeros(512, np.uint8)
         self.g = desc.geometry(width, height)
         self.n_streams = n_streams
         self.stride = (self.g["frame_bytes"] + 64 + 255) // 256 * 256
         self.frames = np.zeros(self.stride * 3 * n_streams, np.uint8)
         self.rgba_stride = (width * height * 4 + 255) // 256 * 256
         self.rgba = np.zeros(self.rgba_stride * 3 * n_streams, np.uint8)
-        self.qmat = np.zeros((n_streams, 2, 64), np.uint8)
+        self.qmat = np.zeros((n_streams, 256), np.uint8)
         for s in range(n_streams):
-            self.qmat[s, 0] = _colmajor(synth.INTRA_Q)
-            self.qmat[s, 1] = _colmajor(synth.NON_INTRA_Q)
-        self.premult = _colmajor(synth.PREMULT)
+            self.qmat[s] = _qtable(synth.INTRA_Q, synth.NON_INTRA_Q)
         self._rgba_init = False
 
     def set_quant(self, stream, intra, non_intra):
-        self.qmat[stream, 0] = _colmajor(intra)
-        self.qmat[stream, 1] = _colmajor(non_intra)
+        self.qmat[stream] = _qtable(intra, non_intra)
 
     def _slot(self, stream, slot):
         o = (stream * 3 + slot) * self.stride
@@ -94,9 +103,15 @@ class EmuStore:
                     self.rgba_convert(slot, s, 1)
             self._rgba_init = True
         g = self.g
+        if self.split:
+            rc = lib().emu_video_run_split(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
+                                           _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs), len(coefs) // 128,
+                                           _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
+            assert rc == 0
+            return
         rc = lib().emu_video_run(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
-                                 _ptr(pics), _ptr(mbs), len(mbs), _ptr(coefs), _ptr(self.qmat), _ptr(self.premult),
-                                 _ptr(self.rgba), self.rgba_stride)
+                                 _ptr(pics), _ptr(mbs), len(mbs), _ptr(coefs), _ptr(self.qmat), _ptr(self.dump),
+                                 _ptr(self.rgba), self.rgba_stride, self.static_pipeline)
         assert rc == 0
 
     def read_planes(self, stream, slot):

@@ -16,6 +16,7 @@
 
 #include "audio_lane.h"
 #include "video_lane.h"
+#include "video_split_lane.h"
 
 using namespace mpg;
 
@@ -25,8 +26,8 @@ extern "C" {
 int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
                   uint32_t width, uint32_t height,
                   const mpeghip_pic_desc *pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
-                  const uint8_t *coefs, const uint8_t *qmat_colmajor, const uint8_t *premult,
-                  uint8_t *rgba, uint64_t rgba_stride)
+                  const uint8_t *coefs, const uint8_t *qtable, uint8_t *dump,
+                  uint8_t *rgba, uint64_t rgba_stride, int static_pipeline)
 {
     VideoArgs a;
     a.frames = frames;
@@ -40,8 +41,8 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     a.pics = pics;
     a.mbs = mbs;
     a.coefs = coefs;
-    a.qmat = qmat_colmajor;
-    a.premult = premult;
+    a.qmat = qtable;
+    a.dump = dump;
     a.n_mbs = n_mbs;
     a.width = width;
     a.height = height;
@@ -63,12 +64,22 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
             const MbU u = load_mb(a, mb_index);
             MbLane st[64];
             memset(tile, 0xCD, sizeof(tile)); // poison: reads of unwritten LDS must not matter
-            for (int lane = 0; lane < 64; lane++)
-                mb_phase_a(a, u, lane, st[lane], tile);
             uint64_t out[64];
             bool wrote[64];
-            for (int lane = 0; lane < 64; lane++)
-                out[lane] = mb_phase_b(a, u, lane, st[lane], tile, wrote[lane]);
+            if (static_pipeline) { // the lane functions of recon_kernel<W, 3>
+                MbLoads ld[64];
+                for (int lane = 0; lane < 64; lane++)
+                    mb_issue_loads_static(a, u, lane, ld[lane]);
+                for (int lane = 0; lane < 64; lane++)
+                    mb_phase_a_compute_static(a, u, lane, ld[lane], st[lane], tile);
+                for (int lane = 0; lane < 64; lane++)
+                    out[lane] = mb_phase_b_t<true>(a, u, lane, st[lane], tile, wrote[lane], dump + lane * 8);
+            } else {
+                for (int lane = 0; lane < 64; lane++)
+                    mb_phase_a(a, u, lane, st[lane], tile);
+                for (int lane = 0; lane < 64; lane++)
+                    out[lane] = mb_phase_b(a, u, lane, st[lane], tile, wrote[lane]);
+            }
             if (u.rgba) {
                 for (int lane = 0; lane < 64; lane++)
                     mb_phase_c_stage(a, u, lane, out[lane], wrote[lane], stage);
@@ -76,6 +87,85 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                     mb_phase_c_convert(a, u, lane, stage);
             }
         }
+    }
+    return 0;
+}
+
+// The split path: pred_kernel<W> then resid_kernel<W> (then the RGBA pass for flagged pictures).
+int emu_video_run_split(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
+                        uint32_t width, uint32_t height,
+                        const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                        const uint8_t *coefs, uint32_t n_units, const uint8_t *qtable,
+                        uint8_t *rgba, uint64_t rgba_stride)
+{
+    SplitArgs s;
+    VideoArgs &a = s.v;
+    a.frames = frames;
+    a.frame_stride = frame_stride;
+    a.luma_w = luma_w;
+    a.luma_h = luma_h;
+    a.chroma_w = luma_w / 2;
+    a.chroma_h = luma_h / 2;
+    a.luma_bytes = luma_w * luma_h;
+    a.chroma_bytes = a.luma_bytes / 4;
+    a.pics = pics;
+    a.mbs = mbs;
+    a.coefs = coefs;
+    a.qmat = qtable;
+    a.dump = nullptr;
+    a.n_mbs = n_mbs;
+    a.width = width;
+    a.height = height;
+    a.rgba = rgba;
+    a.rgba_stride = rgba_stride;
+    std::vector<BlockEntry> entries(n_units ? n_units : 1);
+    memset(entries.data(), 0xff, entries.size() * sizeof(BlockEntry));
+    s.entries = entries.data();
+    s.n_units = n_units;
+    const uint32_t WAVES = 8;
+    // K1
+    {
+        const uint32_t blocks = (n_mbs + 2 * WAVES - 1) / (2 * WAVES);
+        for (uint32_t blk = 0; blk < blocks; blk++) {
+            const uint32_t chunk = xcd_chunk(blk, blocks);
+            for (uint32_t wave = 0; wave < WAVES; wave++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const uint32_t mb_index = (chunk * WAVES + wave) * 2 + (uint32_t)(lane >> 5);
+                    if (mb_index < n_mbs)
+                        pred_lane(s, mb_index, lane & 31);
+                }
+        }
+    }
+    // K2
+    {
+        const uint32_t blocks = (n_units + 8 * WAVES - 1) / (8 * WAVES);
+        alignas(16) int32_t tile[kResidTileDwords];
+        for (uint32_t blk = 0; blk < blocks; blk++) {
+            const uint32_t chunk = xcd_chunk(blk, blocks);
+            for (uint32_t wave = 0; wave < WAVES; wave++) {
+                ResidLane st[64];
+                memset(tile, 0xCD, sizeof(tile));
+                for (int lane = 0; lane < 64; lane++) {
+                    const int g = lane >> 3, j = lane & 7;
+                    resid_phase_a(s, (chunk * WAVES + wave) * 8 + (uint32_t)g, j, tile + g * kTileStride, st[lane]);
+                }
+                for (int lane = 0; lane < 64; lane++) {
+                    const int g = lane >> 3, j = lane & 7;
+                    resid_phase_b(s, j, tile + g * kTileStride, st[lane]);
+                }
+            }
+        }
+    }
+    // RGBA pass
+    for (uint32_t p = 0; p < n_pics; p++) {
+        if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
+            continue;
+        const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
+        const uint32_t quads = (width + 3) / 4;
+        for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+            for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
+                rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
+                                  x4, y, rgba + fs * rgba_stride);
     }
     return 0;
 }

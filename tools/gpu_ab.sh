@@ -8,14 +8,14 @@ mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "== quick parity"
 timeout 600 python -m pytest tests/test_gpu_video.py -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
-for V in "0,8,4" "1,8,4" "2,8,4"; do
+for V in ${PARITY_VARIANTS:-"0,8,4" "3,8,4" "4,8,4" "4,4,4" "4,16,4"}; do
   MPEGHIP_RECON=$V timeout 300 python -m pytest tests/test_gpu_video.py -m gpu -x -q -k "reconstruction or streams" > $OUT/pytest_$V.log 2>&1; echo "variant $V: $(tail -1 $OUT/pytest_$V.log)"
 done
 echo "== A/B"
 timeout 900 python tools/ab_variants.py $STREAMS "$@" 2>&1 | tee $OUT/ab.txt | grep -v amdgpu.ids
 echo "== PMC"
 cd /tmp
-for V in ${PMC_VARIANTS:-"0,8,4" "2,8,4"}; do
+for V in ${PMC_VARIANTS:-"4,8,4"}; do
   for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" \
              "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
