@@ -191,12 +191,19 @@ __global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a, co
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pred_kernel(const SplitArgs s)
 {
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const uint32_t mb_index = (chunk * WAVES + wave) * 2 + (uint32_t)(lane >> 5);
-    if (mb_index < s.v.n_mbs)
-        pred_lane(s, mb_index, lane & 31);
+    const uint32_t first = (chunk * WAVES + wave) * 2; // wave-uniform
+    if (first >= s.v.n_mbs)
+        return;
+    const uint32_t second = first + 1 < s.v.n_mbs ? first + 1 : first;
+    const PredMb m0 = load_pred_mb(s.v, first);   // scalar loads
+    const PredMb m1 = load_pred_mb(s.v, second);
+    const bool hi = lane >= 32;
+    if (hi && first + 1 >= s.v.n_mbs)
+        return;
+    pred_lane(s, select_pred_mb(hi, m0, m1), lane & 31);
 }
 
 template <int WAVES>

@@ -57,33 +57,83 @@ MPG_HD u8x16 ld128u(const uint8_t *p)
 }
 
 // ------------------------------------------------------------------------- K1
-// `half` = which of the wave's two macroblocks, t = lane & 31.
-MPG_HD void pred_lane(const SplitArgs &s, uint32_t mb_index, int t)
+// Everything K1 needs to know about one macroblock, resolved from the two
+// descriptors.  On the device it is produced by SCALAR loads through the constant
+// address space (one set per half-wave, then a per-lane select): the descriptor and
+// picture fetches stay off the vector-memory path, which shortens the dependent
+// chain descriptor -> picture -> reference pixels -> store that bounds this kernel.
+struct PredMb {
+    uint32_t flags, cbp, qscale, coef_off;
+    int32_t mv_x, mv_y;
+    uint32_t mb_x, mb_y;
+    uint32_t stream;
+    uint32_t cur_slot, ref_slot;
+};
+
+MPG_HD PredMb load_pred_mb(const VideoArgs &a, uint32_t mb_index)
+{
+    const MPG_CONST_AS mpeghip_mb_desc *mbs = (const MPG_CONST_AS mpeghip_mb_desc *)(uintptr_t)a.mbs;
+    const MPG_CONST_AS mpeghip_pic_desc *pics = (const MPG_CONST_AS mpeghip_pic_desc *)(uintptr_t)a.pics;
+    const MPG_CONST_AS mpeghip_mb_desc &d = mbs[mb_index];
+    const MPG_CONST_AS mpeghip_pic_desc &p = pics[d.pic];
+    const uint32_t slots = *(const MPG_CONST_AS uint32_t *)((const MPG_CONST_AS uint8_t *)&p + 4);
+    PredMb m;
+    m.flags = d.flags;
+    m.cbp = d.cbp;
+    m.qscale = d.qscale;
+    m.coef_off = d.coef_off;
+    m.mv_x = d.mv_x;
+    m.mv_y = d.mv_y;
+    m.mb_x = d.mb_x;
+    m.mb_y = d.mb_y;
+    m.stream = p.stream;
+    m.cur_slot = slots & 0xff;
+    m.ref_slot = (d.flags & MPEGHIP_MB_REF_BWD) ? (slots >> 16) & 0xff : (slots >> 8) & 0xff;
+    return m;
+}
+
+MPG_HD PredMb select_pred_mb(bool second, const PredMb &x, const PredMb &y)
+{
+    PredMb m;
+    m.flags = second ? y.flags : x.flags;
+    m.cbp = second ? y.cbp : x.cbp;
+    m.qscale = second ? y.qscale : x.qscale;
+    m.coef_off = second ? y.coef_off : x.coef_off;
+    m.mv_x = second ? y.mv_x : x.mv_x;
+    m.mv_y = second ? y.mv_y : x.mv_y;
+    m.mb_x = second ? y.mb_x : x.mb_x;
+    m.mb_y = second ? y.mb_y : x.mb_y;
+    m.stream = second ? y.stream : x.stream;
+    m.cur_slot = second ? y.cur_slot : x.cur_slot;
+    m.ref_slot = second ? y.ref_slot : x.ref_slot;
+    return m;
+}
+
+// One lane of K1: t = lane & 31 within the macroblock's half-wave.
+MPG_HD void pred_lane(const SplitArgs &s, const PredMb &d, int t)
 {
     const VideoArgs &a = s.v;
-    const mpeghip_mb_desc d = a.mbs[mb_index];
-    const mpeghip_pic_desc p = a.pics[d.pic];
     const bool intra = (d.flags & MPEGHIP_MB_INTRA) != 0;
-    const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
-    const uint64_t cur_off = (s3 + p.cur) * a.frame_stride;
+    const uint64_t s3 = (uint64_t)d.stream * MPEGHIP_SLOTS;
+    const uint64_t cur_off = (s3 + d.cur_slot) * a.frame_stride;
 
     // ---- work-list entries for K2 (lanes 0..5 <-> blocks 0..5)
     if (t < 6 && (d.cbp & (0x20u >> t))) {
         const int b = t;
         const bool raw = (d.flags & MPEGHIP_MB_COEF_RAW) != 0;
-        const uint32_t k = popc6((uint32_t)d.cbp >> (6 - b));
+        const uint32_t k = popc6(d.cbp >> (6 - b));
         const uint32_t unit = d.coef_off + (raw ? 2 * k : k);
         uint64_t off;
         if (b < 4)
-            off = (uint64_t)(((uint32_t)d.mb_y << 4) + ((uint32_t)(b >> 1) << 3)) * a.luma_w + ((uint32_t)d.mb_x << 4) + ((uint32_t)(b & 1) << 3);
+            off = (uint64_t)((d.mb_y << 4) + ((uint32_t)(b >> 1) << 3)) * a.luma_w + (d.mb_x << 4) + ((uint32_t)(b & 1) << 3);
         else
-            off = (uint64_t)a.luma_bytes + (b == 5 ? a.chroma_bytes : 0) + (uint64_t)((uint32_t)d.mb_y << 3) * a.chroma_w + ((uint32_t)d.mb_x << 3);
+            off = (uint64_t)a.luma_bytes + (b == 5 ? a.chroma_bytes : 0) + (uint64_t)(d.mb_y << 3) * a.chroma_w + (d.mb_x << 3);
         off += cur_off;
         BlockEntry e;
         e.dest_lo = (uint32_t)off;
         e.dest_hi = (uint32_t)(off >> 32) | (intra ? kEntryIntra : 0) | (raw ? kEntryRaw : 0) | (b >= 4 ? kEntryChroma : 0) |
-                    ((uint32_t)d.qscale << 24);
-        e.qtable = p.stream * 256 + (intra ? 0 : 128);
+                    (d.qscale << 24);
+        e.qtable = d.stream * 256 + (intra ? 0 : 128);
         e.skip = 0;
         if (unit < s.n_units)
             s.entries[unit] = e;
@@ -96,14 +146,13 @@ MPG_HD void pred_lane(const SplitArgs &s, uint32_t mb_index, int t)
         return;
 
     // ---- prediction
-    const uint32_t ref_slot = (d.flags & MPEGHIP_MB_REF_BWD) ? p.bwd : p.fwd;
-    const uint8_t *ref = a.frames + (s3 + ref_slot) * a.frame_stride;
+    const uint8_t *ref = a.frames + (s3 + d.ref_slot) * a.frame_stride;
     uint8_t *cur = a.frames + cur_off;
     int32_t mvx = d.mv_x, mvy = d.mv_y;
     if (t < 16) { // luma row t: 16 pixels
         const int32_t stride = (int32_t)a.luma_w;
-        const int32_t y = ((int32_t)d.mb_y << 4) + t;
-        const int32_t x = (int32_t)d.mb_x << 4;
+        const int32_t y = (int32_t)(d.mb_y << 4) + t;
+        const int32_t x = (int32_t)(d.mb_x << 4);
         const uint8_t *src = ref + (y + (mvy >> 1)) * stride + x + (mvx >> 1);
         const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
         u8x16 o = ld128u(src);
@@ -125,8 +174,8 @@ MPG_HD void pred_lane(const SplitArgs &s, uint32_t mb_index, int t)
         const int32_t stride = (int32_t)a.chroma_w;
         const int32_t r = (t - 16) & 7;
         const uint32_t plane = a.luma_bytes + (t >= 24 ? a.chroma_bytes : 0);
-        const int32_t y = ((int32_t)d.mb_y << 3) + r;
-        const int32_t x = (int32_t)d.mb_x << 3;
+        const int32_t y = (int32_t)(d.mb_y << 3) + r;
+        const int32_t x = (int32_t)(d.mb_x << 3);
         const uint8_t *src = ref + plane + (y + (mvy >> 1)) * stride + x + (mvx >> 1);
         const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
         uint64_t o = ld64u(src);

@@ -1,0 +1,737 @@
+// video.cpp — mpeg::Video: MPEG-1 video bitstream parse on the CPU, reconstruction
+// on the GPU.  Mirrors the parse half of video.go (:209-745) and replaces its
+// reconstruction half (:608-637, :747-1016) by descriptor recording +
+// mpeghip_video_submit.
+//
+// What is recorded per macroblock is exactly what the reference would have
+// executed inline:
+//   predictMacroblock  -> one (reference slot, half-pel vector) pair — the LAST copy
+//                         wins, so a bidirectional B macroblock records only the
+//                         backward prediction (video.go:626-630)
+//   decodeBlock        -> the block's quantised levels (int16, dequantised on the GPU)
+//                         or, where the reference's persistent blockData carries stale
+//                         coefficients from an earlier invalid block, a snapshot of
+//                         blockData itself (int32, MPEGHIP_MB_COEF_RAW)
+#include <stdexcept>
+#include <string.h>
+
+#include "mpeg.hpp"
+#include "vlc.hpp"
+
+namespace mpeg {
+
+namespace {
+
+const VlcTable &tabMba() { static const VlcTable t(mpg_vlc_mba_increment); return t; }
+const VlcTable &tabType(int picture_type)
+{
+    static const VlcTable ti(mpg_vlc_mb_type_i), tp(mpg_vlc_mb_type_p), tb(mpg_vlc_mb_type_b);
+    return picture_type == 1 ? ti : (picture_type == 2 ? tp : tb);
+}
+const VlcTable &tabCbp() { static const VlcTable t(mpg_vlc_coded_block_pattern); return t; }
+const VlcTable &tabMotion() { static const VlcTable t(mpg_vlc_motion_code); return t; }
+const VlcTable &tabDcSize(int plane)
+{
+    static const VlcTable tl(mpg_vlc_dct_dc_size_luma), tc(mpg_vlc_dct_dc_size_chroma);
+    return plane == 0 ? tl : tc;
+}
+const VlcTable &tabCoeff() { static const VlcTable t(mpg_vlc_dct_coeff); return t; }
+
+constexpr int kPictureTypeIntra = 1, kPictureTypePredictive = 2, kPictureTypeB = 3;
+constexpr int kStartPicture = 0x00, kStartSliceFirst = 0x01, kStartSliceLast = 0xAF, kStartUserData = 0xB2,
+              kStartSequence = 0xB3, kStartExtension = 0xB5;
+
+const double kPictureRate[16] = {0.000, 23.976, 24.000, 25.000, 29.970, 30.000, 50.000, 59.940,
+                                 60.000, 0, 0, 0, 0, 0, 0, 0}; // ISO 11172-2 table 2-D.4 (video.go:1034-1037)
+
+const uint8_t kZigZag[64] = { // ISO 11172-2 zig-zag scan (video.go:1044-1053)
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+const uint8_t kDefaultIntraQuant[64] = { // ISO default intra matrix (video.go:1055-1064)
+    8,  16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37, 19, 22, 26, 27, 29, 34,
+    34, 38, 22, 22, 26, 27, 29, 34, 37, 40, 22, 26, 27, 29, 32, 35, 40, 48, 26, 27, 29, 32,
+    35, 40, 48, 58, 26, 27, 29, 34, 38, 46, 56, 69, 27, 29, 35, 38, 46, 56, 69, 83};
+
+const uint8_t kPremultiplier[64] = { // video.go:1077-1086
+    32, 44, 42, 38, 32, 25, 17, 9,  44, 62, 58, 52, 44, 35, 24, 12, 42, 58, 55, 49, 42, 33,
+    23, 12, 38, 52, 49, 44, 38, 30, 20, 10, 32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30,
+    25, 20, 14, 7,  17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
+
+// dequantise + premultiply one level on the host — only needed on the rare paths
+// that must reproduce the reference's blockData bit for bit (video.go:719-744)
+int32_t dequantPremult(int level, bool intra, int qscale, int qm, int idx)
+{
+    level <<= 1;
+    if (!intra)
+        level += level < 0 ? -1 : 1;
+    level = (level * qscale * qm) >> 4;
+    if ((level & 1) == 0)
+        level -= level > 0 ? 1 : -1;
+    if (level > 2047)
+        level = 2047;
+    else if (level < -2048)
+        level = -2048;
+    return level * (int)kPremultiplier[idx];
+}
+
+void check(int rc, const char *what)
+{
+    if (rc != MPEGHIP_OK)
+        throw std::runtime_error(std::string(what) + ": " + mpeghip_last_error());
+}
+
+} // namespace
+
+Device::Device(int ordinal)
+{
+    int rc = mpeghip_ctx_create(ordinal, nullptr, &ctx_);
+    if (rc != MPEGHIP_OK)
+        throw std::runtime_error(std::string("mpeg::Device: ") + mpeghip_last_error());
+}
+
+Device::~Device() { mpeghip_ctx_destroy(ctx_); }
+
+Video::Video(Buffer *buf, Device *dev) : buf_(buf), dev_(dev)
+{ // video.go:110-121
+    memset(block_data_, 0, sizeof(block_data_));
+    memset(intra_quant_, 0, sizeof(intra_quant_));
+    memset(non_intra_quant_, 0, sizeof(non_intra_quant_));
+    start_code_ = buf_->findStartCode(kStartSequence);
+    if (start_code_ != -1)
+        decodeSequenceHeader();
+}
+
+Video::~Video()
+{
+    if (store_)
+        mpeghip_video_close(store_);
+}
+
+bool Video::HasHeader()
+{ // video.go:130-147
+    if (has_sequence_header_)
+        return true;
+    if (start_code_ != kStartSequence)
+        start_code_ = buf_->findStartCode(kStartSequence);
+    if (start_code_ == -1)
+        return false;
+    return decodeSequenceHeader();
+}
+
+void Video::SetTime(double t)
+{ // video.go:189-192
+    frames_decoded_ = (int)(frame_rate_ * t);
+    time_ = t;
+}
+
+void Video::Rewind()
+{ // video.go:195-201
+    buf_->Rewind();
+    time_ = 0;
+    frames_decoded_ = 0;
+    has_reference_frame_ = false;
+    start_code_ = -1;
+}
+
+bool Video::decodeSequenceHeader()
+{ // video.go:270-331
+    const size_t max_header_size = 64 + 2 * 64 * 8;
+    if (!buf_->has(max_header_size))
+        return false;
+    width_ = buf_->read(12);
+    height_ = buf_->read(12);
+    if (width_ <= 0 || height_ <= 0)
+        return false;
+    buf_->read(4); // aspect ratio: not used by the decode path
+    frame_rate_ = kPictureRate[buf_->read(4)];
+    buf_->read(18); // bit rate
+    buf_->skip(1 + 10 + 1);
+    if (buf_->read1()) {
+        for (int i = 0; i < 64; i++)
+            intra_quant_[kZigZag[i]] = (uint8_t)buf_->read(8);
+    } else {
+        memcpy(intra_quant_, kDefaultIntraQuant, 64);
+    }
+    if (buf_->read1()) {
+        for (int i = 0; i < 64; i++)
+            non_intra_quant_[kZigZag[i]] = (uint8_t)buf_->read(8);
+    } else {
+        memset(non_intra_quant_, 16, 64); // video.go:1066-1075
+    }
+    mb_width_ = (width_ + 15) >> 4;
+    mb_height_ = (height_ + 15) >> 4;
+    mb_size_ = mb_width_ * mb_height_;
+    luma_width_ = mb_width_ << 4;
+    luma_height_ = mb_height_ << 4;
+    chroma_width_ = mb_width_ << 3;
+    chroma_height_ = mb_height_ << 3;
+
+    // initFrame x3 (video.go:324-326): the three slots live in the device frame store
+    if (store_)
+        mpeghip_video_close(store_);
+    store_ = nullptr;
+    check(mpeghip_video_open(dev_->ctx(), (uint32_t)width_, (uint32_t)height_, 1, &store_), "mpeghip_video_open");
+    check(mpeghip_video_set_quant(store_, 0, intra_quant_, non_intra_quant_), "mpeghip_video_set_quant");
+    mpeghip_video_info info;
+    mpeghip_video_info_get(store_, &info);
+    for (int s = 0; s < 3; s++) {
+        host_planes_[s].assign(info.luma_bytes + 2 * info.chroma_bytes, 0);
+        Frame &f = frames_[s];
+        f.owner = this;
+        f.slot = (uint32_t)s;
+        f.Width = width_;
+        f.Height = height_;
+        f.Y = Plane{luma_width_, luma_height_, host_planes_[s].data(), (size_t)info.luma_bytes};
+        f.Cb = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + info.luma_bytes, (size_t)info.chroma_bytes};
+        f.Cr = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + info.luma_bytes + info.chroma_bytes,
+                     (size_t)info.chroma_bytes};
+    }
+    host_rgba_.assign(info.rgba_bytes, 0);
+    written_.assign((size_t)mb_size_, 0);
+    slot_cur_ = 0;
+    slot_fwd_ = 1;
+    slot_bwd_ = 2;
+    has_sequence_header_ = true;
+    return true;
+}
+
+Frame *Video::frameForSlot(uint32_t slot)
+{
+    // Frame.Y/Cb/Cr.Data are host-visible: fetch the slot's planes (synchronises with the device)
+    Frame &f = frames_[slot];
+    mpeghip_video_info info;
+    mpeghip_video_info_get(store_, &info);
+    uint8_t *base = host_planes_[slot].data();
+    check(mpeghip_video_read_planes(store_, 0, slot, base, base + info.luma_bytes, base + info.luma_bytes + info.chroma_bytes),
+          "mpeghip_video_read_planes");
+    return &f;
+}
+
+const uint8_t *Video::fetchRGBA(uint32_t slot)
+{ // Frame.RGBA, video.go:31-36
+    check(mpeghip_video_rgba_convert(store_, slot, 0, 1), "mpeghip_video_rgba_convert");
+    check(mpeghip_video_read_rgba(store_, 0, slot, host_rgba_.data()), "mpeghip_video_read_rgba");
+    return host_rgba_.data();
+}
+
+const uint8_t *Frame::RGBA() { return owner->fetchRGBA(slot); }
+
+Frame *Video::Decode()
+{ // video.go:209-268
+    if (!HasHeader())
+        return nullptr;
+    int out_slot = -1;
+    for (;;) {
+        if (start_code_ != kStartPicture) {
+            start_code_ = buf_->findStartCode(kStartPicture);
+            if (start_code_ == -1) {
+                if (has_reference_frame_ && !assume_no_b_frames_ && buf_->HasEnded() &&
+                    (picture_type_ == kPictureTypeIntra || picture_type_ == kPictureTypePredictive)) {
+                    has_reference_frame_ = false;
+                    out_slot = (int)slot_bwd_;
+                    break;
+                }
+                return nullptr;
+            }
+        }
+        if (buf_->hasStartCode(kStartPicture) == -1 && !buf_->HasEnded())
+            return nullptr;
+        buf_->discardReadBytes();
+
+        decodePicture();
+
+        if (assume_no_b_frames_)
+            out_slot = (int)slot_bwd_;
+        else if (picture_type_ == kPictureTypeB)
+            out_slot = (int)slot_cur_;
+        else if (has_reference_frame_)
+            out_slot = (int)slot_fwd_;
+        else
+            has_reference_frame_ = true;
+        if (out_slot >= 0)
+            break;
+    }
+    Frame *frame = frameForSlot((uint32_t)out_slot);
+    frame->Time = time_;
+    frames_decoded_++;
+    time_ = (double)frames_decoded_ / frame_rate_;
+    return frame;
+}
+
+void Video::decodePicture()
+{ // video.go:374-434
+    buf_->skip(10);
+    picture_type_ = buf_->read(3);
+    buf_->skip(16);
+    if (picture_type_ <= 0 || picture_type_ > kPictureTypeB)
+        return;
+    if (picture_type_ == kPictureTypePredictive || picture_type_ == kPictureTypeB) {
+        motion_forward_.FullPx = buf_->read1();
+        int f_code = buf_->read(3);
+        if (f_code == 0)
+            return;
+        motion_forward_.RSize = f_code - 1;
+    }
+    if (picture_type_ == kPictureTypeB) {
+        motion_backward_.FullPx = buf_->read1();
+        int f_code = buf_->read(3);
+        if (f_code == 0)
+            return;
+        motion_backward_.RSize = f_code - 1;
+    }
+    stats_.pictures++;
+
+    const uint32_t slot_temp = slot_fwd_;
+    if (picture_type_ == kPictureTypeIntra || picture_type_ == kPictureTypePredictive)
+        slot_fwd_ = slot_bwd_;
+
+    mbs_.clear();
+    coefs_.clear();
+    std::fill(written_.begin(), written_.end(), 0);
+
+    do {
+        start_code_ = buf_->nextStartCode();
+    } while (start_code_ == kStartExtension || start_code_ == kStartUserData);
+
+    while (start_code_ >= kStartSliceFirst && start_code_ <= kStartSliceLast) {
+        decodeSlice(start_code_ & 0xFF);
+        if (macroblock_address_ >= mb_size_ - 2)
+            break;
+        start_code_ = buf_->nextStartCode();
+    }
+    flushSubmit();
+
+    if (picture_type_ == kPictureTypeIntra || picture_type_ == kPictureTypePredictive) {
+        slot_bwd_ = slot_cur_;
+        slot_cur_ = slot_temp;
+    }
+}
+
+void Video::flushSubmit()
+{
+    if (mbs_.empty())
+        return;
+    mpeghip_pic_desc pic;
+    memset(&pic, 0, sizeof(pic));
+    pic.stream = 0;
+    pic.cur = (uint8_t)slot_cur_;
+    pic.fwd = (uint8_t)slot_fwd_;
+    pic.bwd = (uint8_t)slot_bwd_;
+    pic.mb_first = 0;
+    pic.mb_count = (uint32_t)mbs_.size();
+    check(mpeghip_video_submit(store_, &pic, 1, mbs_.data(), (uint32_t)mbs_.size(), coefs_.data(), coefs_.size()),
+          "mpeghip_video_submit");
+    stats_.submits++;
+    stats_.macroblocks += mbs_.size();
+    mbs_.clear();
+    coefs_.clear();
+    std::fill(written_.begin(), written_.end(), 0);
+}
+
+void Video::decodeSlice(int slice)
+{ // video.go:436-460
+    slice_begin_ = true;
+    macroblock_address_ = (slice - 1) * mb_width_ - 1;
+    motion_backward_.H = motion_forward_.H = 0;
+    motion_backward_.V = motion_forward_.V = 0;
+    dc_predictor_[0] = dc_predictor_[1] = dc_predictor_[2] = 128;
+    quantizer_scale_ = buf_->read(5);
+    while (buf_->read1())
+        buf_->skip(8);
+    do {
+        decodeMacroblock();
+    } while (macroblock_address_ < mb_size_ - 1 && buf_->peekNonZero(23));
+}
+
+void Video::beginMacroblockRecord(bool intra)
+{
+    // A damaged stream can address a macroblock twice in one picture; the reference
+    // simply executes both in bitstream order.  Macroblocks of one submit run
+    // concurrently on the device, so the earlier ones are flushed first.
+    const size_t addr = (size_t)mb_row_ * (size_t)mb_width_ + (size_t)mb_col_;
+    if (written_[addr]) {
+        flushSubmit();
+        stats_.duplicate_splits++;
+    }
+    written_[addr] = 1;
+    rec_ = MbRec();
+    rec_.active = true;
+    rec_.intra = intra;
+    rec_.mb_x = mb_col_;
+    rec_.mb_y = mb_row_;
+    rec_.qscale = quantizer_scale_;
+}
+
+void Video::emitPrediction(int mh, int mv, bool backward)
+{
+    // copyMacroblock(mh, mv, mbRow, mbCol, ..., src, &frameCurrent): a later call overwrites an earlier one
+    rec_.has_pred = true;
+    rec_.backward = backward;
+    rec_.mv_x = mh;
+    rec_.mv_y = mv;
+}
+
+void Video::endMacroblockRecord()
+{
+    if (!rec_.active)
+        return;
+    rec_.active = false;
+    if (!rec_.intra && !rec_.has_pred)
+        return; // cannot happen: every non-intra macroblock is predicted (video.go:543-544)
+
+    // legal read range of copyMacroblock (video_noasm.go:48-50): [plane start, end of base)
+    if (!rec_.intra) {
+        const int64_t lw = luma_width_, cw = chroma_width_;
+        const int64_t luma = (int64_t)luma_width_ * luma_height_, chroma = (int64_t)chroma_width_ * chroma_height_;
+        const int64_t total = luma + 2 * chroma + lw * 16;
+        const int mh = rec_.mv_x, mv = rec_.mv_y;
+        const int64_t lsi = ((int64_t)(rec_.mb_y << 4) + (mv >> 1)) * lw + (rec_.mb_x << 4) + (mh >> 1);
+        const int64_t llast = lsi + (15 + (mv & 1)) * lw + 15 + (mh & 1);
+        const int cmh = mh / 2, cmv = mv / 2;
+        const int64_t csi = ((int64_t)(rec_.mb_y << 3) + (cmv >> 1)) * cw + (rec_.mb_x << 3) + (cmh >> 1);
+        const int64_t clast = csi + (7 + (cmv & 1)) * cw + 7 + (cmh & 1);
+        if (lsi < 0 || llast >= total || csi < 0 || clast >= total - luma - chroma) {
+            stats_.range_skips++; // the reference panics here; the macroblock is dropped instead
+            return;
+        }
+    }
+
+    bool raw = false;
+    int cbp = 0;
+    for (int b = 0; b < 6; b++)
+        if (rec_.cbp & (0x20 >> b)) {
+            if (rec_.blocks[b].valid) {
+                cbp |= 0x20 >> b;
+                raw |= rec_.blocks[b].needs_raw;
+            }
+        }
+    mpeghip_mb_desc d;
+    memset(&d, 0, sizeof(d));
+    d.pic = 0;
+    d.mb_x = (uint16_t)rec_.mb_x;
+    d.mb_y = (uint16_t)rec_.mb_y;
+    d.mv_x = (int16_t)rec_.mv_x;
+    d.mv_y = (int16_t)rec_.mv_y;
+    d.flags = (uint8_t)(rec_.intra ? MPEGHIP_MB_INTRA : (rec_.backward ? MPEGHIP_MB_REF_BWD : MPEGHIP_MB_REF_FWD));
+    if (raw)
+        d.flags |= MPEGHIP_MB_COEF_RAW;
+    d.cbp = (uint8_t)cbp;
+    d.qscale = (uint8_t)(rec_.qscale < 1 ? 1 : (rec_.qscale > 31 ? 31 : rec_.qscale));
+    d.coef_off = (uint32_t)(coefs_.size() / MPEGHIP_COEF_UNIT);
+    if (rec_.qscale < 1 && cbp)
+        raw = true, d.flags |= MPEGHIP_MB_COEF_RAW; // quantiser_scale 0 (forbidden value): keep the reference's arithmetic
+
+    for (int b = 0; b < 6; b++) {
+        if (!(cbp & (0x20 >> b)))
+            continue;
+        const BlockRec &br = rec_.blocks[b];
+        stats_.coded_blocks++;
+        if (raw) {
+            int32_t snap[64];
+            if (br.needs_raw) {
+                memcpy(snap, br.raw, sizeof(snap));
+            } else { // this block was clean: dequantise it here so the whole macroblock shares one format
+                const uint8_t *qm = rec_.intra ? intra_quant_ : non_intra_quant_;
+                for (int i = 0; i < 64; i++)
+                    snap[i] = br.q[i] ? dequantPremult(br.q[i], rec_.intra, rec_.qscale, qm[i], i) : 0;
+                if (rec_.intra)
+                    snap[0] = (int32_t)br.q[0] * 256;
+            }
+            const size_t at = coefs_.size();
+            coefs_.resize(at + 2 * MPEGHIP_COEF_UNIT);
+            int32_t *dst = reinterpret_cast<int32_t *>(coefs_.data() + at);
+            for (int r = 0; r < 8; r++)
+                for (int c = 0; c < 8; c++)
+                    dst[c * 8 + r] = snap[r * 8 + c]; // column-major
+        } else {
+            const size_t at = coefs_.size();
+            coefs_.resize(at + MPEGHIP_COEF_UNIT);
+            int16_t *dst = reinterpret_cast<int16_t *>(coefs_.data() + at);
+            for (int r = 0; r < 8; r++)
+                for (int c = 0; c < 8; c++)
+                    dst[c * 8 + r] = br.q[r * 8 + c];
+        }
+    }
+    if (raw)
+        stats_.raw_macroblocks++;
+    mbs_.push_back(d);
+}
+
+void Video::decodeMacroblock()
+{ // video.go:462-562
+    int increment = 0;
+    int t = tabMba().read(buf_);
+    while (t == 34)
+        t = tabMba().read(buf_); // macroblock_stuffing
+    while (t == 35) {
+        increment += 33; // macroblock_escape
+        t = tabMba().read(buf_);
+    }
+    increment += t;
+
+    if (slice_begin_) {
+        slice_begin_ = false;
+        macroblock_address_ += increment;
+    } else {
+        if (macroblock_address_ + increment >= mb_size_)
+            return; // invalid
+        if (increment > 1) {
+            dc_predictor_[0] = dc_predictor_[1] = dc_predictor_[2] = 128;
+            if (picture_type_ == kPictureTypePredictive) {
+                motion_forward_.H = 0;
+                motion_forward_.V = 0;
+            }
+        }
+        while (increment > 1) { // skipped macroblocks are predicted
+            macroblock_address_++;
+            mb_row_ = macroblock_address_ / mb_width_;
+            mb_col_ = macroblock_address_ % mb_width_;
+            beginMacroblockRecord(false);
+            predictMacroblock();
+            endMacroblockRecord();
+            increment--;
+        }
+        macroblock_address_++;
+    }
+
+    mb_row_ = macroblock_address_ / mb_width_;
+    mb_col_ = macroblock_address_ % mb_width_;
+    if (mb_col_ >= mb_width_ || mb_row_ >= mb_height_ || macroblock_address_ < 0)
+        return; // corrupt stream
+
+    macroblock_type_ = tabType(picture_type_).read(buf_);
+    macroblock_intra_ = (macroblock_type_ & 0x01) != 0;
+    motion_forward_.IsSet = (macroblock_type_ & 0x08) != 0;
+    motion_backward_.IsSet = (macroblock_type_ & 0x04) != 0;
+    if (macroblock_type_ & 0x10)
+        quantizer_scale_ = buf_->read(5);
+
+    beginMacroblockRecord(macroblock_intra_);
+    if (macroblock_intra_) {
+        motion_backward_.H = motion_forward_.H = 0;
+        motion_backward_.V = motion_forward_.V = 0;
+    } else {
+        dc_predictor_[0] = dc_predictor_[1] = dc_predictor_[2] = 128;
+        decodeMotionVectors();
+        predictMacroblock();
+    }
+
+    int cbp = 0;
+    if (macroblock_type_ & 0x02)
+        cbp = tabCbp().read(buf_);
+    else if (macroblock_intra_)
+        cbp = 0x3f;
+    rec_.cbp = cbp;
+    for (int block = 0, mask = 0x20; block < 6; block++, mask >>= 1) {
+        rec_.blocks[block].valid = false;
+        if (cbp & mask)
+            decodeBlock(block);
+    }
+    endMacroblockRecord();
+}
+
+void Video::decodeMotionVectors()
+{ // video.go:564-581
+    if (motion_forward_.IsSet) {
+        const int r = motion_forward_.RSize;
+        motion_forward_.H = decodeMotionVector(r, motion_forward_.H);
+        motion_forward_.V = decodeMotionVector(r, motion_forward_.V);
+    } else if (picture_type_ == kPictureTypePredictive) {
+        motion_forward_.H = 0;
+        motion_forward_.V = 0;
+    }
+    if (motion_backward_.IsSet) {
+        const int r = motion_backward_.RSize;
+        motion_backward_.H = decodeMotionVector(r, motion_backward_.H);
+        motion_backward_.V = decodeMotionVector(r, motion_backward_.V);
+    }
+}
+
+int Video::decodeMotionVector(int rSize, int motion)
+{ // video.go:583-606
+    const int fscale = 1 << rSize;
+    const int m_code = tabMotion().read(buf_);
+    int d;
+    if (m_code != 0 && fscale != 1) {
+        const int r = buf_->read(rSize);
+        d = (((m_code < 0 ? -m_code : m_code) - 1) << rSize) + r + 1;
+        if (m_code < 0)
+            d = -d;
+    } else {
+        d = m_code;
+    }
+    motion += d;
+    if (motion > (fscale << 4) - 1)
+        motion -= fscale << 5;
+    else if (motion < ((-fscale) << 4))
+        motion += fscale << 5;
+    return motion;
+}
+
+void Video::predictMacroblock()
+{ // video.go:608-637
+    int fw_h = motion_forward_.H, fw_v = motion_forward_.V;
+    if (motion_forward_.FullPx) {
+        fw_h <<= 1;
+        fw_v <<= 1;
+    }
+    if (picture_type_ == kPictureTypeB) {
+        int bw_h = motion_backward_.H, bw_v = motion_backward_.V;
+        if (motion_backward_.FullPx) {
+            bw_h <<= 1;
+            bw_v <<= 1;
+        }
+        if (motion_forward_.IsSet) {
+            emitPrediction(fw_h, fw_v, false);
+            if (motion_backward_.IsSet)
+                emitPrediction(bw_h, bw_v, true); // overwrites the forward copy: no averaging in the reference
+        } else {
+            emitPrediction(bw_h, bw_v, true);
+        }
+    } else {
+        emitPrediction(fw_h, fw_v, false);
+    }
+}
+
+void Video::decodeBlock(int block)
+{ // video.go:639-745 (parse) + the bookkeeping that replaces :747-798
+    BlockRec &br = rec_.blocks[block];
+    br.valid = false;
+    br.needs_raw = false;
+    memset(br.q, 0, sizeof(br.q));
+    int n = 0;
+    const uint8_t *quant_matrix;
+    // block_data_ mirrors the reference's persistent blockData.  It is all zero except
+    // after an invalid block (video.go:711-714 returns before the clears); only then —
+    // or when this block itself ends invalid — do its exact contents matter.
+    const bool dirty_at_start = block_dirty_;
+    bool explicit_zero = false;
+    int32_t dc256 = 0;
+
+    if (macroblock_intra_) {
+        const int plane_index = block > 3 ? block - 3 : 0;
+        const int predictor = dc_predictor_[plane_index];
+        const int dct_size = tabDcSize(plane_index).read(buf_);
+        int dc;
+        if (dct_size > 0) {
+            const int differential = buf_->read(dct_size);
+            if (differential & (1 << (dct_size - 1)))
+                dc = predictor + differential;
+            else
+                dc = predictor + ((-(1 << dct_size)) | (differential + 1));
+        } else {
+            dc = predictor;
+        }
+        dc_predictor_[plane_index] = dc;
+        if (dc < -32768 || dc > 32767)
+            br.needs_raw = true; // not expressible as int16: goes through the snapshot path
+        br.q[0] = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc));
+        // blockData[0] = dc << 8.  Beyond +-2^30 the pixel saturates whatever the AC terms add
+        // (their sum is below 0.6 * 2^30), so clamping there is exact and keeps int32.
+        int64_t v = (int64_t)dc * 256;
+        if (v > (1 << 30))
+            v = 1 << 30;
+        if (v < -(1 << 30))
+            v = -(1 << 30);
+        dc256 = (int32_t)v;
+        if (dirty_at_start)
+            block_data_[0] = dc256;
+        quant_matrix = intra_quant_;
+        n = 1;
+    } else {
+        quant_matrix = non_intra_quant_;
+    }
+
+    int touched[64], n_touched = 0; // natural indices written by this block, in scan order
+    int level = 0;
+    bool invalid = false;
+    for (;;) {
+        int run;
+        const int coeff = tabCoeff().read(buf_);
+        if (coeff == 0x0001 && n > 0 && buf_->read1() == 0)
+            break; // end_of_block
+        if (coeff == 0xffff) { // escape
+            run = buf_->read(6);
+            level = buf_->read(8);
+            if (level == 0)
+                level = buf_->read(8);
+            else if (level == 128)
+                level = buf_->read(8) - 256;
+            else if (level > 128)
+                level -= 256;
+        } else {
+            run = coeff >> 8;
+            level = coeff & 0xff;
+            if (buf_->read1())
+                level = -level;
+        }
+        n += run;
+        if (n < 0 || n >= 64) {
+            invalid = true;
+            break;
+        }
+        const int dz = kZigZag[n] & 63;
+        n++;
+        if (level == 0)
+            explicit_zero = true; // dequantises to +-1, which "0 = absent" cannot express
+        br.q[dz] = (int16_t)level;
+        touched[n_touched++] = dz;
+        if (dirty_at_start)
+            block_data_[dz] = dequantPremult(level, macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
+    }
+
+    // bring block_data_ up to date when it was not maintained on the fly
+    auto materialize = [&]() {
+        if (dirty_at_start)
+            return;
+        if (macroblock_intra_)
+            block_data_[0] = dc256;
+        for (int k = 0; k < n_touched; k++) {
+            const int dz = touched[k];
+            block_data_[dz] = dequantPremult(br.q[dz], macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
+        }
+    };
+
+    if (invalid) {
+        // video.go:711-714: return without reconstructing and WITHOUT clearing blockData
+        stats_.invalid_blocks++;
+        materialize();
+        block_dirty_ = true;
+        return;
+    }
+
+    if (!dirty_at_start && !explicit_zero && !br.needs_raw) {
+        // the common case: blockData held nothing but this block, and the reference clears it
+        // again after use (video.go:777, 781-783, 790, 794-796) — nothing to keep on the host
+        br.valid = true;
+        return;
+    }
+
+    // snapshot path: reproduce exactly what idct() / the DC fast path would consume
+    materialize();
+    br.needs_raw = true;
+    if (n == 1) { // video.go:774-777 / 787-790: only blockData[0] is used, and only it is cleared
+        memset(br.raw, 0, sizeof(br.raw));
+        br.raw[0] = block_data_[0];
+        block_data_[0] = 0;
+    } else {
+        if (n < 10) { // video.go:807-866: the reduced IDCT ignores rows >= 4 and columns >= 4
+            for (int i = 0; i < 64; i++)
+                br.raw[i] = ((i >> 3) < 4 && (i & 7) < 4) ? block_data_[i] : 0;
+        } else {
+            memcpy(br.raw, block_data_, sizeof(br.raw));
+        }
+        memset(block_data_, 0, sizeof(block_data_)); // video.go:781-783 / 794-796
+    }
+    block_dirty_ = false;
+    for (int i = 0; i < 64; i++)
+        if (block_data_[i] != 0) {
+            block_dirty_ = true;
+            break;
+        }
+    br.valid = true;
+}
+
+} // namespace mpeg

@@ -132,7 +132,7 @@ int emu_video_run_split(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w,
                 for (int lane = 0; lane < 64; lane++) {
                     const uint32_t mb_index = (chunk * WAVES + wave) * 2 + (uint32_t)(lane >> 5);
                     if (mb_index < n_mbs)
-                        pred_lane(s, mb_index, lane & 31);
+                        pred_lane(s, load_pred_mb(s.v, mb_index), lane & 31);
                 }
         }
     }

@@ -13,6 +13,13 @@ for V in ${PARITY_VARIANTS:-"0,8,4" "3,8,4" "4,8,4" "4,4,4" "4,16,4"}; do
 done
 echo "== A/B"
 timeout 900 python tools/ab_variants.py $STREAMS "$@" 2>&1 | tee $OUT/ab.txt | grep -v amdgpu.ids
+echo "== per-kernel times (kernel trace)"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/ktrace -o kt -- python $GRAFT_REPO_ROOT/tools/ab_variants.py $STREAMS ${TRACE_VARIANT:-4,8,4} > $GRAFT_REPO_ROOT/$OUT/ktrace.log 2>&1
+cd $GRAFT_REPO_ROOT
+for f in $(find $OUT/ktrace -name "*kernel_stats.csv" | head -1); do head -8 $f | cut -c1-200; done
+find $OUT/ktrace -name "*kernel_trace.csv" -delete
+if [ "${SKIP_PMC:-0}" = "1" ]; then du -sh $OUT; exit 0; fi
 echo "== PMC"
 cd /tmp
 for V in ${PMC_VARIANTS:-"4,8,4"}; do

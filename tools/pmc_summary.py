@@ -12,9 +12,10 @@ for f in sorted(root.rglob("*counter_collection.csv")):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name", "")
-            if "recon_kernel" not in name:
+            key = next((k for k in ("recon_kernel", "pred_kernel", "resid_kernel", "rgba", "audio_kernel") if k in name), None)
+            if key is None:
                 continue
-            agg[variant][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            agg[variant + " " + key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for variant, d in agg.items():
     print("== variant", variant)
     for k, v in sorted(d.items()):
