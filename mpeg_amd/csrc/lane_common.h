@@ -47,6 +47,20 @@ MPG_HD uint64_t ld64u(const uint8_t *p) { return reinterpret_cast<const u64_unal
 MPG_HD uint32_t ld32u(const uint8_t *p) { return reinterpret_cast<const u32_unaligned *>(p)->v; }
 MPG_HD void st64u(uint8_t *p, uint64_t v) { reinterpret_cast<u64_unaligned *>(p)->v = v; }
 
+// 16 bytes at any byte alignment (one global_load_dwordx4)
+struct alignas(16) u8x16 { uint32_t v[4]; };
+struct __attribute__((packed)) u8x16_unaligned { uint32_t v[4]; };
+MPG_HD u8x16 ld128u(const uint8_t *p)
+{
+    const u8x16_unaligned *q = reinterpret_cast<const u8x16_unaligned *>(p);
+    u8x16 r;
+    r.v[0] = q->v[0];
+    r.v[1] = q->v[1];
+    r.v[2] = q->v[2];
+    r.v[3] = q->v[3];
+    return r;
+}
+
 // ---- naturally aligned 16-byte groups (one dwordx4 / ds_read_b128 each)
 struct alignas(16) i16x8 { int16_t v[8]; };
 struct alignas(16) i32x4 { int32_t v[4]; };
@@ -112,6 +126,65 @@ MPG_HD uint64_t avg4_u8x8(uint64_t a, uint64_t b, uint64_t c, uint64_t d)
     uint32_t lo = avg4_u8x4((uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d);
     uint32_t hi = avg4_u8x4((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), (uint32_t)(d >> 32));
     return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// ---- write-back: 8 residuals + 8 prediction bytes -> 8 clamped output bytes
+// (addBlockToDest / copyBlockToDest, video.go:943-971; clamp video.go:1014-1016).
+// Device: per pixel pair v_cvt_pk_i16_i32 (saturating pack), v_perm_b32 (prediction
+// bytes to 16-bit lanes), v_pk_add_i16 clamp, v_sat_pk_u8_i16 — 18 VALU for 8 pixels
+// instead of ~40 scalar ones.  Saturating at +-32767 first is exact: anything that
+// far out clamps to 0 / 255 either way.
+MPG_HD uint32_t add_clamp_pack4(uint32_t pred4, int32_t v0, int32_t v1, int32_t v2, int32_t v3)
+{
+#if MPG_ON_DEVICE
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 r01 = __builtin_amdgcn_cvt_pk_i16(v0, v1), r23 = __builtin_amdgcn_cvt_pk_i16(v2, v3);
+    const uint32_t p01 = __builtin_amdgcn_perm(0u, pred4, 0x0c010c00u); // bytes 0,1 -> two zero-extended u16
+    const uint32_t p23 = __builtin_amdgcn_perm(0u, pred4, 0x0c030c02u);
+    const s16x2 s01 = __builtin_elementwise_add_sat(r01, __builtin_bit_cast(s16x2, p01));
+    const s16x2 s23 = __builtin_elementwise_add_sat(r23, __builtin_bit_cast(s16x2, p23));
+    uint32_t u01, u23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(u01) : "v"(__builtin_bit_cast(uint32_t, s01)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(u23) : "v"(__builtin_bit_cast(uint32_t, s23)));
+    return __builtin_amdgcn_perm(u23, u01, 0x05040100u); // {u01.b0, u01.b1, u23.b0, u23.b1}
+#else
+    const int32_t v[4] = {v0, v1, v2, v3};
+    uint32_t out = 0;
+    for (int c = 0; c < 4; c++) {
+        int32_t r = v[c] < -32768 ? -32768 : (v[c] > 32767 ? 32767 : v[c]);
+        int32_t x = (int32_t)((pred4 >> (8 * c)) & 0xff) + r;
+        out |= (uint32_t)(x < 0 ? 0 : (x > 255 ? 255 : x)) << (8 * c);
+    }
+    return out;
+#endif
+}
+
+MPG_HD uint64_t add_clamp_pack8(uint64_t pred, const int32_t (&v)[8])
+{
+    const uint32_t lo = add_clamp_pack4((uint32_t)pred, v[0], v[1], v[2], v[3]);
+    const uint32_t hi = add_clamp_pack4((uint32_t)(pred >> 32), v[4], v[5], v[6], v[7]);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// bytes 1..4 of the 8-byte little-endian value {hi:lo} (one v_alignbyte_b32)
+MPG_HD uint32_t shift_in_byte(uint32_t hi, uint32_t lo)
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_alignbyte(hi, lo, 1);
+#else
+    return (lo >> 8) | (hi << 24);
+#endif
+}
+
+// true if `pred` is false for every lane of the wavefront (wave-uniform branch key)
+MPG_HD bool none_in_wave(bool pred)
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_ballot_w64(pred) == 0;
+#else
+    (void)pred;
+    return false; // the emulator runs one lane at a time: never take the shortcut
+#endif
 }
 
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its

@@ -139,14 +139,35 @@ MPG_HD void idct8(int32_t (&v)[8])
 // then premultiply (video.go:744).  q != 0.  qsqm = quantiser_scale * matrix entry.
 MPG_HD int32_t dequant(int32_t q, bool intra, int32_t qsqm, int32_t pm)
 {
+    // level = 2q (+ sign(q) unless intra); q != 0 so sign(q) = (q >> 31) | 1
     int32_t l = 2 * q;
     if (!intra)
-        l += (q < 0) ? -1 : 1;
+        l += (q >> 31) | 1;
     l = mul24(l, qsqm) >> 4;          // |l| <= 513, qsqm <= 31*255
-    if ((l & 1) == 0)
-        l -= (l > 0) ? 1 : -1;        // 0 counts as "not positive" and becomes +1
+    // "if even, move one toward zero; 0 becomes +1" == (l - (l > 0)) | 1
+    l = (l - (l > 0 ? 1 : 0)) | 1;
     l = clampi(l, -2048, 2047);
     return mul24(l, pm);
+}
+
+// the 8 quantised levels of one coefficient column -> dequantised, premultiplied
+MPG_HD void dequant_column(int32_t (&v)[8], const i32x4 &c0, uint64_t qm, uint64_t pm, int32_t qs, bool intra, bool dc_lane)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int32_t w = c0.v[r >> 1];
+        const int32_t q = (r & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
+        if (none_in_wave(q != 0)) { // most rows of most blocks are empty: skip them wave-wide
+            v[r] = 0;
+            continue;
+        }
+        const int32_t qsqm = qs * (int32_t)((qm >> (8 * r)) & 0xff);
+        const int32_t p = (int32_t)((pm >> (8 * r)) & 0xff);
+        const int32_t d = dequant(q, intra, qsqm, p);
+        v[r] = q ? d : 0;
+    }
+    if (intra && dc_lane)
+        v[0] = (int32_t)(int16_t)(c0.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
 }
 
 struct MbLane {
@@ -162,7 +183,9 @@ MPG_HD uint32_t popc6(uint32_t x) { return (uint32_t)__builtin_popcount(x & 0x3f
 //                     qwords, coefficient column, quantiser-matrix column), no use
 //   mb_phase_a_compute — averages, dequantisation, column pass, LDS tile write
 struct MbLoads {
-    uint64_t pa, pb, pc, pd; // prediction source: (row), (row,+1 px), (row+1), (row+1,+1 px)
+    u8x16 r0, r1;            // prediction source rows: 16 bytes from (row, x) and from (row+1, x); the lane
+                             // needs bytes 0..8 of each — ONE load per row serves both horizontal taps
+                             // (the reference reads the same 9 bytes as two overlapping 8-byte words)
     i32x4 c0, c1;            // coefficient column: int16 x8 in c0, or int32 x8 in c0,c1
     uint64_t qm;             // quantiser matrix column (8 bytes)
     uint64_t pm;             // premultiplier column (8 bytes)
@@ -171,7 +194,8 @@ struct MbLoads {
 MPG_HD void mb_issue_loads(const VideoArgs &a, const MbU &u, int lane, MbLoads &ld)
 {
     const int b = lane >> 3, j = lane & 7;
-    ld.pa = ld.pb = ld.pc = ld.pd = 0;
+    ld.r0 = u8x16{{0, 0, 0, 0}};
+    ld.r1 = u8x16{{0, 0, 0, 0}};
     ld.qm = ld.pm = 0;
     ld.c0 = i32x4{{0, 0, 0, 0}};
     ld.c1 = i32x4{{0, 0, 0, 0}};
@@ -195,14 +219,9 @@ MPG_HD void mb_issue_loads(const VideoArgs &a, const MbU &u, int lane, MbLoads &
             off = (int32_t)(a.luma_bytes + (b == 5 ? a.chroma_bytes : 0)) + y * stride + x;
         }
         const uint8_t *src = u.ref + off;
-        const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
-        ld.pa = ld64u(src);
-        if (oh)
-            ld.pb = ld64u(src + 1);
-        if (ov)
-            ld.pc = ld64u(src + stride);
-        if (oh && ov)
-            ld.pd = ld64u(src + stride + 1);
+        ld.r0 = ld128u(src);
+        if (mvy & 1)
+            ld.r1 = ld128u(src + stride);
     }
     if (!(u.cbp & (0x20u >> b)))
         return;
@@ -238,12 +257,23 @@ MPG_HD void mb_phase_a_compute(const VideoArgs &a, const MbU &u, int lane, const
             mvy /= 2;
         }
         const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
-        if (!oh && !ov)
-            st.pred = ld.pa;
-        else if (oh && ov)
-            st.pred = avg4_u8x8(ld.pa, ld.pb, ld.pc, ld.pd);
-        else
-            st.pred = avg2_u8x8(ld.pa, oh ? ld.pb : ld.pc);
+        const uint64_t pa = (uint64_t)ld.r0.v[0] | ((uint64_t)ld.r0.v[1] << 32);
+        if (!oh && !ov) {
+            st.pred = pa;
+        } else {
+            const uint64_t pc = (uint64_t)ld.r1.v[0] | ((uint64_t)ld.r1.v[1] << 32);
+            if (!oh) {
+                st.pred = avg2_u8x8(pa, pc);
+            } else {
+                const uint64_t pb = (uint64_t)shift_in_byte(ld.r0.v[1], ld.r0.v[0]) | ((uint64_t)shift_in_byte(ld.r0.v[2], ld.r0.v[1]) << 32);
+                if (!ov) {
+                    st.pred = avg2_u8x8(pa, pb);
+                } else {
+                    const uint64_t pd = (uint64_t)shift_in_byte(ld.r1.v[1], ld.r1.v[0]) | ((uint64_t)shift_in_byte(ld.r1.v[2], ld.r1.v[1]) << 32);
+                    st.pred = avg4_u8x8(pa, pb, pc, pd);
+                }
+            }
+        }
     }
 
     // ---- residual: column j of block b
@@ -257,17 +287,7 @@ MPG_HD void mb_phase_a_compute(const VideoArgs &a, const MbU &u, int lane, const
             v[r + 4] = ld.c1.v[r];
         }
     } else {
-        const int32_t qs = (int32_t)u.qscale;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int32_t w = ld.c0.v[r >> 1];
-            const int32_t q = (r & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
-            const int32_t qsqm = qs * (int32_t)((ld.qm >> (8 * r)) & 0xff);
-            const int32_t p = (int32_t)((ld.pm >> (8 * r)) & 0xff);
-            v[r] = q ? dequant(q, intra, qsqm, p) : 0;
-        }
-        if (intra && j == 0)
-            v[0] = (int32_t)(int16_t)(ld.c0.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
+        dequant_column(v, ld.c0, ld.qm, ld.pm, (int32_t)u.qscale, intra, j == 0);
     }
     idct8<false>(v);
     int32_t *t = tile + b * kTileStride + j;
@@ -277,7 +297,7 @@ MPG_HD void mb_phase_a_compute(const VideoArgs &a, const MbU &u, int lane, const
 }
 
 // Branch-free variant of mb_issue_loads for the software pipeline: EVERY lane issues
-// exactly six loads (4 x 8 bytes of prediction source, 2 x 16 bytes of coefficients /
+// exactly four loads (2 x 16 bytes of prediction source, 2 x 16 bytes of coefficients /
 // tables) whatever the macroblock type, so the compiler can count them and wait for
 // "all but the newest six" (s_waitcnt vmcnt(N)) instead of draining the queue.
 // Loads a macroblock does not need go to harmless valid addresses (its own
@@ -303,11 +323,9 @@ MPG_HD void mb_issue_loads_static(const VideoArgs &a, const MbU &u, int lane, Mb
         off = (int32_t)(a.luma_bytes + (b == 5 ? a.chroma_bytes : 0)) + y * stride + x;
     }
     const uint8_t *src = (intra ? (const uint8_t *)u.cur : u.ref) + off;
-    const int32_t dx = mvx & 1, dy = (mvy & 1) ? stride : 0;
-    ld.pa = ld64u(src);
-    ld.pb = ld64u(src + dx);
-    ld.pc = ld64u(src + dy);
-    ld.pd = ld64u(src + dy + dx);
+    const int32_t dy = (mvy & 1) ? stride : 0;
+    ld.r0 = ld128u(src);
+    ld.r1 = ld128u(src + dy);
 
     const bool coded = b0 < 6 && (u.cbp & (0x20u >> b)) != 0;
     const bool raw = (u.flags & MPEGHIP_MB_COEF_RAW) != 0;
@@ -371,12 +389,7 @@ MPG_HD uint64_t mb_phase_b_t(const VideoArgs &a, const MbU &u, int lane, const M
             v[c + 4] = t1.v[c];
         }
         idct8<true>(v);
-        out = 0;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int32_t p = (int32_t)((st.pred >> (8 * c)) & 0xff);
-            out |= (uint64_t)(uint32_t)clampi(p + v[c], 0, 255) << (8 * c);
-        }
+        out = add_clamp_pack8(st.pred, v);
     }
 
     uint32_t off;

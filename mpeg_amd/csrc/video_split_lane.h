@@ -43,19 +43,6 @@ struct SplitArgs {
     uint32_t n_units;      // coefficient stream length in 128-byte units
 };
 
-struct alignas(16) u8x16 { uint32_t v[4]; };
-struct __attribute__((packed)) u8x16_unaligned { uint32_t v[4]; };
-MPG_HD u8x16 ld128u(const uint8_t *p)
-{
-    const u8x16_unaligned *q = reinterpret_cast<const u8x16_unaligned *>(p);
-    u8x16 r;
-    r.v[0] = q->v[0];
-    r.v[1] = q->v[1];
-    r.v[2] = q->v[2];
-    r.v[3] = q->v[3];
-    return r;
-}
-
 // ------------------------------------------------------------------------- K1
 // Everything K1 needs to know about one macroblock, resolved from the two
 // descriptors.  On the device it is produced by SCALAR loads through the constant
@@ -230,17 +217,7 @@ MPG_HD void resid_phase_a(const SplitArgs &s, uint32_t unit, int j, int32_t *til
         const i32x4 tq = *reinterpret_cast<const i32x4 *>(a.qmat + e.qtable + j * 16);
         const uint64_t qm = (uint64_t)(uint32_t)tq.v[0] | ((uint64_t)(uint32_t)tq.v[1] << 32);
         const uint64_t pm = (uint64_t)(uint32_t)tq.v[2] | ((uint64_t)(uint32_t)tq.v[3] << 32);
-        const int32_t qs = (int32_t)((e.dest_hi >> 24) & 31);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int32_t w = c0.v[r >> 1];
-            const int32_t q = (r & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
-            const int32_t qsqm = qs * (int32_t)((qm >> (8 * r)) & 0xff);
-            const int32_t pr = (int32_t)((pm >> (8 * r)) & 0xff);
-            v[r] = q ? dequant(q, intra, qsqm, pr) : 0;
-        }
-        if (intra && j == 0)
-            v[0] = (int32_t)(int16_t)(c0.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
+        dequant_column(v, c0, qm, pm, (int32_t)((e.dest_hi >> 24) & 31), intra, j == 0);
     }
     idct8<false>(v);
     int32_t *t = tile_g + j;
@@ -263,13 +240,7 @@ MPG_HD void resid_phase_b(const SplitArgs &s, int j, const int32_t *tile_g, cons
         v[c + 4] = t1.v[c];
     }
     idct8<true>(v);
-    uint64_t out = 0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int32_t p = (int32_t)((st.pred >> (8 * c)) & 0xff);
-        out |= (uint64_t)(uint32_t)clampi(p + v[c], 0, 255) << (8 * c);
-    }
-    *reinterpret_cast<uint64_t *>(s.v.frames + st.dest) = out;
+    *reinterpret_cast<uint64_t *>(s.v.frames + st.dest) = add_clamp_pack8(st.pred, v);
 }
 
 } // namespace mpg
