@@ -20,6 +20,7 @@
 #include "mpeghip.h"
 #include "video_lane.h"
 #include "video_split_lane.h"
+#include "video_compact_lane.h"
 
 using namespace mpg;
 
@@ -185,6 +186,35 @@ __global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a, co
             i += S;
         }
     }
+}
+
+// ---- compact path (video_compact_lane.h): fused, single pass over the pixels, dense residual stage
+__global__ __launch_bounds__(kChunkMbs * 64) void recon_compact_kernel(const VideoArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kCompactLdsBytes];
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+    const ChunkInfo ci = load_chunk(a, chunk);   // scalar loads of the chunk's 8 descriptors
+    const bool have_mb = w < ci.n;
+    MbU u;
+    MbLoads ld;
+    if (have_mb) {
+        u = load_mb(a, chunk * kChunkMbs + w);
+        compact_phase1(a, u, lane, ld);          // prediction loads: in flight during phase 2
+    }
+    if (8 * w < ci.base[kChunkMbs]) {            // wave-uniform: this wave has coded blocks to transform
+        const int g = lane >> 3, j = lane & 7;
+        const uint32_t slot = 8 * w + (uint32_t)g;
+        int32_t *tile_g = reinterpret_cast<int32_t *>(lds + kResidStoreBytes) + (w * 8 + (uint32_t)g) * kTileStride;
+        bool active;
+        compact_phase2(a, ci, slot, j, tile_g, active);
+        wave_lds_handoff();
+        compact_phase2_rows(slot, j, tile_g, active, lds);
+    }
+    __syncthreads();
+    if (have_mb)
+        compact_phase3(a, u, ci, w, lane, ld, lds);
 }
 
 // ---- split path (video_split_lane.h): K1 prediction, K2 dense residual
@@ -793,15 +823,32 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
     // Development knob (not part of the ABI): MPEGHIP_RECON="mode,waves,blocks_per_cu".
-    //   mode 4 (default): split path, K1 prediction + K2 dense residual (+ RGBA pass)
+    //   mode 5 (default): compact fused kernel (dense residual stage inside the workgroup) (+ RGBA pass)
+    //   mode 4: split path, K1 prediction + K2 dense residual (+ RGBA pass)
     //   mode 0: fused one-wave-per-macroblock kernel;  1-3: its persistent / pipelined variants
-    int mode = 4, waves = 8, bpc = 4;
+    int mode = 5, waves = 8, bpc = 4;
     if (const char *e = getenv("MPEGHIP_RECON"))
         sscanf(e, "%d,%d,%d", &mode, &waves, &bpc);
     if (waves != 4 && waves != 8 && waves != 16)
         waves = 8;
-    if (mode < 0 || mode > 4)
-        mode = 4;
+    if (mode < 0 || mode > 5)
+        mode = 5;
+    if (mode == 5) {
+        hipStream_t st = v->ctx->stream;
+        const uint32_t blocks = (uint32_t)((b->n_mbs + kChunkMbs - 1) / kChunkMbs);
+        hipLaunchKernelGGL(recon_compact_kernel, dim3(blocks), dim3(kChunkMbs * 64), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        if (b->any_rgba) {
+            const uint32_t quads = (in.width + 3) / 4;
+            for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
+                const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
+                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 3) / 4, np), dim3(256), 0, st, a,
+                                   (uint32_t)p0);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        return MPEGHIP_OK;
+    }
     if (mode == 4) {
         hipStream_t st = v->ctx->stream;
         SplitArgs s;

@@ -1,0 +1,243 @@
+// video_compact_lane.h — fused reconstruction with a DENSE residual stage.
+//
+// One workgroup = 8 waves = one chunk of 8 consecutive macroblocks.
+//   phase 1  wave w, lane (b, j): issue the prediction loads of ITS macroblock (row j of
+//            block b) — they stay in flight during phase 2.
+//   phase 2  the chunk's coded blocks (at most 48, typically ~15) are numbered 0..T-1 in
+//            (macroblock, block) order; wave w takes slots 8w..8w+7, lane (g, j) = column j
+//            of slot 8w+g: dequantise, column pass, wave-private LDS transpose, row pass,
+//            saturate to int16 and park the residual ROW in the chunk's LDS residual store.
+//            Waves with 8w >= T skip straight to the barrier.  Every lane of a working wave
+//            has a coded block: the IDCT instruction stream is paid once per 8 coded blocks
+//            instead of once per macroblock (measured: 61 % of macroblock-waves ran it with
+//            at most half their lanes coded).
+//   barrier
+//   phase 3  wave w, lane (b, j): prediction average, + residual row from LDS (if coded),
+//            clamp, one 8-byte store.  Destination bytes are written exactly once and never
+//            read: no traffic beyond the fused kernel's.
+//
+// Same arithmetic, same results as video_lane.h (bit-exact; the int16 saturation of the
+// residual is exact because |residual| >= 32767 saturates the pixel either way).
+#pragma once
+
+#include "video_lane.h"
+
+namespace mpg {
+
+constexpr int kChunkMbs = 8;
+constexpr int kMaxChunkBlocks = 6 * kChunkMbs;                    // 48
+constexpr int kResidStoreBytes = kMaxChunkBlocks * 128;            // int16 8x8 per slot
+constexpr int kCompactTileBytes = 6 * 8 * kTileStride * 4;         // 6 working waves x 8 blocks x 72 dwords
+constexpr int kCompactLdsBytes = kResidStoreBytes + kCompactTileBytes;
+
+// Wave-uniform summary of the chunk's 8 descriptors (SGPRs on the device).
+struct ChunkInfo {
+    uint32_t n;                       // macroblocks in this chunk (tail chunk < 8)
+    uint32_t cbp[kChunkMbs];          // 0 for macroblocks beyond n
+    uint32_t flags[kChunkMbs];        // MPEGHIP_MB_* | quantiser_scale << 8
+    uint32_t coef_off[kChunkMbs];
+    uint32_t qtab[kChunkMbs];         // byte offset of the macroblock's {matrix, premultiplier} table
+    uint32_t base[kChunkMbs + 1];     // slot number of each macroblock's first coded block; base[8] = total
+};
+
+MPG_HD ChunkInfo load_chunk(const VideoArgs &a, uint32_t chunk)
+{
+    const MPG_CONST_AS mpeghip_mb_desc *mbs = (const MPG_CONST_AS mpeghip_mb_desc *)(uintptr_t)a.mbs;
+    const MPG_CONST_AS mpeghip_pic_desc *pics = (const MPG_CONST_AS mpeghip_pic_desc *)(uintptr_t)a.pics;
+    ChunkInfo ci;
+    const uint32_t first = chunk * kChunkMbs;
+    ci.n = a.n_mbs - first < (uint32_t)kChunkMbs ? a.n_mbs - first : (uint32_t)kChunkMbs;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kChunkMbs; k++) {
+        const uint32_t idx = (uint32_t)k < ci.n ? first + (uint32_t)k : first; // clamp: keeps the loads unconditional
+        const MPG_CONST_AS mpeghip_mb_desc &d = mbs[idx];
+        const bool live = (uint32_t)k < ci.n;
+        ci.cbp[k] = live ? (uint32_t)d.cbp : 0u;
+        ci.flags[k] = (uint32_t)d.flags | ((uint32_t)d.qscale << 8);
+        ci.coef_off[k] = d.coef_off;
+        ci.qtab[k] = pics[d.pic].stream * 256 + ((d.flags & MPEGHIP_MB_INTRA) ? 0u : 128u);
+        ci.base[k] = acc;
+        acc += popc6(ci.cbp[k]);
+    }
+    ci.base[kChunkMbs] = acc;
+    return ci;
+}
+
+// ------------------------------------------------------------------ phase 2
+// lane (g, j) of a working wave: slot = 8*wave + g.
+MPG_HD void compact_phase2(const VideoArgs &a, const ChunkInfo &ci, uint32_t slot, int j, int32_t *tile_g, bool &active)
+{
+    active = slot < ci.base[kChunkMbs];
+    if (!active)
+        return;
+    // which macroblock owns this slot: k = #{i >= 1 : base[i] <= slot}
+    uint32_t k = 0;
+#pragma unroll
+    for (int i = 1; i < kChunkMbs; i++)
+        k += (slot >= ci.base[i]) ? 1u : 0u;
+    uint32_t cbp = ci.cbp[0], flags = ci.flags[0], coef_off = ci.coef_off[0], qtab = ci.qtab[0], base = ci.base[0];
+#pragma unroll
+    for (int i = 1; i < kChunkMbs; i++) {
+        const bool sel = k == (uint32_t)i;
+        cbp = sel ? ci.cbp[i] : cbp;
+        flags = sel ? ci.flags[i] : flags;
+        coef_off = sel ? ci.coef_off[i] : coef_off;
+        qtab = sel ? ci.qtab[i] : qtab;
+        base = sel ? ci.base[i] : base;
+    }
+    const uint32_t idx = slot - base; // ordinal among the macroblock's coded blocks
+    const bool intra = (flags & MPEGHIP_MB_INTRA) != 0, raw = (flags & MPEGHIP_MB_COEF_RAW) != 0;
+    (void)cbp;
+
+    int32_t v[8];
+    if (raw) {
+        const i32x4 *c = reinterpret_cast<const i32x4 *>(a.coefs + ((uint64_t)coef_off + 2 * idx) * MPEGHIP_COEF_UNIT + (uint32_t)j * 32);
+        const i32x4 c0 = c[0], c1 = c[1];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[r] = c0.v[r];
+            v[r + 4] = c1.v[r];
+        }
+    } else {
+        const i32x4 c0 = *reinterpret_cast<const i32x4 *>(a.coefs + ((uint64_t)coef_off + idx) * MPEGHIP_COEF_UNIT + (uint32_t)j * 16);
+        const i32x4 tq = *reinterpret_cast<const i32x4 *>(a.qmat + qtab + j * 16);
+        const uint64_t qm = (uint64_t)(uint32_t)tq.v[0] | ((uint64_t)(uint32_t)tq.v[1] << 32);
+        const uint64_t pm = (uint64_t)(uint32_t)tq.v[2] | ((uint64_t)(uint32_t)tq.v[3] << 32);
+        dequant_column(v, c0, qm, pm, (int32_t)((flags >> 8) & 31), intra, j == 0);
+    }
+    idct8<false>(v);
+    int32_t *t = tile_g + j;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        t[r * 8] = v[r];
+}
+
+// pack two int32 into saturated int16 pair
+MPG_HD uint32_t sat_pack_i16(int32_t lo, int32_t hi)
+{
+#if MPG_ON_DEVICE
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (s16x2)__builtin_amdgcn_cvt_pk_i16(lo, hi));
+#else
+    const int32_t l = lo < -32768 ? -32768 : (lo > 32767 ? 32767 : lo);
+    const int32_t h = hi < -32768 ? -32768 : (hi > 32767 ? 32767 : hi);
+    return ((uint32_t)l & 0xffffu) | ((uint32_t)h << 16);
+#endif
+}
+
+// second half of phase 2 (after the wave-private LDS hand-off): lane (g, j) = row j
+MPG_HD void compact_phase2_rows(uint32_t slot, int j, const int32_t *tile_g, bool active, uint8_t *resid_store)
+{
+    if (!active)
+        return;
+    int32_t v[8];
+    const i32x4 *t = reinterpret_cast<const i32x4 *>(tile_g + j * 8);
+    const i32x4 t0 = t[0], t1 = t[1];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        v[c] = t0.v[c];
+        v[c + 4] = t1.v[c];
+    }
+    idct8<true>(v);
+    u32x4 row;
+    row.v[0] = sat_pack_i16(v[0], v[1]);
+    row.v[1] = sat_pack_i16(v[2], v[3]);
+    row.v[2] = sat_pack_i16(v[4], v[5]);
+    row.v[3] = sat_pack_i16(v[6], v[7]);
+    *reinterpret_cast<u32x4 *>(resid_store + slot * 128 + (uint32_t)j * 16) = row;
+}
+
+// 4 prediction bytes + two int16 pairs -> 4 clamped bytes
+MPG_HD uint32_t add_resid_pack4(uint32_t pred4, uint32_t r01, uint32_t r23)
+{
+#if MPG_ON_DEVICE
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t p01 = __builtin_amdgcn_perm(0u, pred4, 0x0c010c00u);
+    const uint32_t p23 = __builtin_amdgcn_perm(0u, pred4, 0x0c030c02u);
+    const s16x2 s01 = __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, r01), __builtin_bit_cast(s16x2, p01));
+    const s16x2 s23 = __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, r23), __builtin_bit_cast(s16x2, p23));
+    uint32_t u01, u23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(u01) : "v"(__builtin_bit_cast(uint32_t, s01)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(u23) : "v"(__builtin_bit_cast(uint32_t, s23)));
+    return __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+#else
+    const int32_t r[4] = {(int16_t)(r01 & 0xffff), (int16_t)(r01 >> 16), (int16_t)(r23 & 0xffff), (int16_t)(r23 >> 16)};
+    uint32_t out = 0;
+    for (int c = 0; c < 4; c++) {
+        const int32_t x = (int32_t)((pred4 >> (8 * c)) & 0xff) + r[c];
+        out |= (uint32_t)(x < 0 ? 0 : (x > 255 ? 255 : x)) << (8 * c);
+    }
+    return out;
+#endif
+}
+
+// ------------------------------------------------------------------ phase 3
+// wave w (macroblock w of the chunk), lane (b, j): finish row j of block b.
+MPG_HD void compact_phase3(const VideoArgs &a, const MbU &u, const ChunkInfo &ci, uint32_t w, int lane, const MbLoads &ld,
+                           const uint8_t *resid_store)
+{
+    const int b = lane >> 3, j = lane & 7;
+    if (b >= 6)
+        return;
+    const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
+    const bool coded = (u.cbp & (0x20u >> b)) != 0;
+    if (intra && !coded)
+        return; // an invalid intra block leaves the old pixels (video.go:711-714)
+
+    // prediction (video_noasm.go:48-80) from the rows loaded in phase 1
+    uint64_t pred = 0;
+    if (!intra) {
+        int32_t mvx = u.mv_x, mvy = u.mv_y;
+        if (b >= 4) {
+            mvx /= 2;
+            mvy /= 2;
+        }
+        const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
+        const uint64_t pa = (uint64_t)ld.r0.v[0] | ((uint64_t)ld.r0.v[1] << 32);
+        if (!oh && !ov) {
+            pred = pa;
+        } else {
+            const uint64_t pc = (uint64_t)ld.r1.v[0] | ((uint64_t)ld.r1.v[1] << 32);
+            if (!oh) {
+                pred = avg2_u8x8(pa, pc);
+            } else {
+                const uint64_t pb = (uint64_t)shift_in_byte(ld.r0.v[1], ld.r0.v[0]) | ((uint64_t)shift_in_byte(ld.r0.v[2], ld.r0.v[1]) << 32);
+                if (!ov) {
+                    pred = avg2_u8x8(pa, pb);
+                } else {
+                    const uint64_t pd = (uint64_t)shift_in_byte(ld.r1.v[1], ld.r1.v[0]) | ((uint64_t)shift_in_byte(ld.r1.v[2], ld.r1.v[1]) << 32);
+                    pred = avg4_u8x8(pa, pb, pc, pd);
+                }
+            }
+        }
+    }
+    uint64_t out = pred;
+    if (coded) {
+        const uint32_t slot = ci.base[w] + popc6(u.cbp >> (6 - b));
+        const u32x4 row = *reinterpret_cast<const u32x4 *>(resid_store + slot * 128 + (uint32_t)j * 16);
+        const uint32_t lo = add_resid_pack4((uint32_t)pred, row.v[0], row.v[1]);
+        const uint32_t hi = add_resid_pack4((uint32_t)(pred >> 32), row.v[2], row.v[3]);
+        out = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    uint32_t off;
+    if (b < 4) {
+        const uint32_t y = (u.mb_y << 4) + (uint32_t)j + ((uint32_t)(b >> 1) << 3);
+        const uint32_t x = (u.mb_x << 4) + ((uint32_t)(b & 1) << 3);
+        off = y * a.luma_w + x;
+    } else {
+        const uint32_t y = (u.mb_y << 3) + (uint32_t)j;
+        off = a.luma_bytes + (b == 5 ? a.chroma_bytes : 0) + y * a.chroma_w + (u.mb_x << 3);
+    }
+    *reinterpret_cast<uint64_t *>(u.cur + off) = out;
+}
+
+// phase 1 = prediction loads only (no coefficient loads): reuse mb_issue_loads with cbp masked off
+MPG_HD void compact_phase1(const VideoArgs &a, const MbU &u, int lane, MbLoads &ld)
+{
+    MbU v = u;
+    v.cbp = 0;
+    mb_issue_loads(a, v, lane, ld);
+}
+
+} // namespace mpg

@@ -17,6 +17,7 @@
 #include "audio_lane.h"
 #include "video_lane.h"
 #include "video_split_lane.h"
+#include "video_compact_lane.h"
 
 using namespace mpg;
 
@@ -157,6 +158,81 @@ int emu_video_run_split(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w,
         }
     }
     // RGBA pass
+    for (uint32_t p = 0; p < n_pics; p++) {
+        if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
+            continue;
+        const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
+        const uint32_t quads = (width + 3) / 4;
+        for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+            for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
+                rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
+                                  x4, y, rgba + fs * rgba_stride);
+    }
+    return 0;
+}
+
+// recon_compact_kernel: one workgroup (8 waves) per chunk of 8 macroblocks (+ the RGBA pass).
+int emu_video_run_compact(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
+                          uint32_t width, uint32_t height,
+                          const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                          const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
+{
+    VideoArgs a;
+    a.frames = frames;
+    a.frame_stride = frame_stride;
+    a.luma_w = luma_w;
+    a.luma_h = luma_h;
+    a.chroma_w = luma_w / 2;
+    a.chroma_h = luma_h / 2;
+    a.luma_bytes = luma_w * luma_h;
+    a.chroma_bytes = a.luma_bytes / 4;
+    a.pics = pics;
+    a.mbs = mbs;
+    a.coefs = coefs;
+    a.qmat = qtable;
+    a.dump = nullptr;
+    a.n_mbs = n_mbs;
+    a.width = width;
+    a.height = height;
+    a.rgba = rgba;
+    a.rgba_stride = rgba_stride;
+    alignas(16) static uint8_t lds[kCompactLdsBytes];
+    const uint32_t blocks = (n_mbs + kChunkMbs - 1) / kChunkMbs;
+    for (uint32_t blk = 0; blk < blocks; blk++) {
+        const uint32_t chunk = xcd_chunk(blk, blocks);
+        const ChunkInfo ci = load_chunk(a, chunk);
+        memset(lds, 0xCD, sizeof(lds));
+        MbU u[kChunkMbs];
+        static MbLoads ld[kChunkMbs][64];
+        for (uint32_t w = 0; w < (uint32_t)kChunkMbs; w++) {
+            if (w >= ci.n)
+                continue;
+            u[w] = load_mb(a, chunk * kChunkMbs + w);
+            for (int lane = 0; lane < 64; lane++)
+                compact_phase1(a, u[w], lane, ld[w][lane]);
+        }
+        for (uint32_t w = 0; w < (uint32_t)kChunkMbs; w++) {
+            if (8 * w >= ci.base[kChunkMbs])
+                continue;
+            bool active[64];
+            for (int lane = 0; lane < 64; lane++) {
+                const int g = lane >> 3, j = lane & 7;
+                int32_t *tile_g = reinterpret_cast<int32_t *>(lds + kResidStoreBytes) + (w * 8 + (uint32_t)g) * kTileStride;
+                compact_phase2(a, ci, 8 * w + (uint32_t)g, j, tile_g, active[lane]);
+            }
+            for (int lane = 0; lane < 64; lane++) {
+                const int g = lane >> 3, j = lane & 7;
+                const int32_t *tile_g = reinterpret_cast<const int32_t *>(lds + kResidStoreBytes) + (w * 8 + (uint32_t)g) * kTileStride;
+                compact_phase2_rows(8 * w + (uint32_t)g, j, tile_g, active[lane], lds);
+            }
+        }
+        for (uint32_t w = 0; w < (uint32_t)kChunkMbs; w++) {
+            if (w >= ci.n)
+                continue;
+            for (int lane = 0; lane < 64; lane++)
+                compact_phase3(a, u[w], ci, w, lane, ld[w][lane], lds);
+        }
+    }
     for (uint32_t p = 0; p < n_pics; p++) {
         if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
             continue;
