@@ -64,6 +64,18 @@ MPG_HD ChunkInfo load_chunk(const VideoArgs &a, uint32_t chunk)
     return ci;
 }
 
+// base[w] for a run-time (wave-uniform) w, computed arithmetically: indexing the array
+// with a run-time value (or a select chain over its elements, which LLVM folds back into
+// an indexed load) would push the whole ChunkInfo into scratch memory.
+MPG_HD uint32_t chunk_base_of(const ChunkInfo &ci, uint32_t w)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < kChunkMbs - 1; i++)
+        r += ((uint32_t)i < w) ? popc6(ci.cbp[i]) : 0u;
+    return r;
+}
+
 // ------------------------------------------------------------------ phase 2
 // lane (g, j) of a working wave: slot = 8*wave + g.
 MPG_HD void compact_phase2(const VideoArgs &a, const ChunkInfo &ci, uint32_t slot, int j, int32_t *tile_g, bool &active)
@@ -214,7 +226,7 @@ MPG_HD void compact_phase3(const VideoArgs &a, const MbU &u, const ChunkInfo &ci
     }
     uint64_t out = pred;
     if (coded) {
-        const uint32_t slot = ci.base[w] + popc6(u.cbp >> (6 - b));
+        const uint32_t slot = chunk_base_of(ci, w) + popc6(u.cbp >> (6 - b));
         const u32x4 row = *reinterpret_cast<const u32x4 *>(resid_store + slot * 128 + (uint32_t)j * 16);
         const uint32_t lo = add_resid_pack4((uint32_t)pred, row.v[0], row.v[1]);
         const uint32_t hi = add_resid_pack4((uint32_t)(pred >> 32), row.v[2], row.v[3]);

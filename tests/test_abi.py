@@ -51,3 +51,20 @@ def test_product_does_not_reference_the_oracle():
         if p.is_file() and p.suffix in (".py", ".h", ".hpp", ".hip", ".cpp", ".c"):
             txt = p.read_text(errors="replace")
             assert "pyoracle" not in txt and "liboracle" not in txt and "mpeg_oracle" not in txt and "oracle_desc" not in txt, p
+
+
+def test_no_kernel_uses_scratch():
+    """Every gfx950 kernel must keep its state in registers: a run-time indexed local array silently
+    moves to scratch memory (measured: 4x slower).  Checked on the compiler's resource-usage remarks."""
+    import subprocess
+    from mpeg_amd import _build
+    cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-c",
+           "-Rpass-analysis=kernel-resource-usage", "-I", str(_build.INCLUDE), "-I", str(_build.CSRC),
+           str(_build.CSRC / "mpeghip.hip"), "-o", "/dev/null"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stdout)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stdout)]
+    assert len(names) == len(scratch) and len(names) >= 8
+    bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert not bad, bad
