@@ -52,11 +52,14 @@ MPG_HD ChunkInfo load_chunk(const VideoArgs &a, uint32_t chunk)
     for (int k = 0; k < kChunkMbs; k++) {
         const uint32_t idx = (uint32_t)k < ci.n ? first + (uint32_t)k : first; // clamp: keeps the loads unconditional
         const MPG_CONST_AS mpeghip_mb_desc &d = mbs[idx];
-        const bool live = (uint32_t)k < ci.n;
-        ci.cbp[k] = live ? (uint32_t)d.cbp : 0u;
-        ci.flags[k] = (uint32_t)d.flags | ((uint32_t)d.qscale << 8);
+        // flags | cbp << 8 | qscale << 16 as ONE scalar dword (byte-sized member reads would become
+        // per-descriptor vector byte loads)
+        const uint32_t w3 = *(const MPG_CONST_AS uint32_t *)((const MPG_CONST_AS uint8_t *)&d + 12);
+        const uint32_t live = (uint32_t)k < ci.n ? 0x3fu : 0u;
+        ci.cbp[k] = (w3 >> 8) & live;
+        ci.flags[k] = (w3 & 0xffu) | (((w3 >> 16) & 0xffu) << 8);
         ci.coef_off[k] = d.coef_off;
-        ci.qtab[k] = pics[d.pic].stream * 256 + ((d.flags & MPEGHIP_MB_INTRA) ? 0u : 128u);
+        ci.qtab[k] = pics[d.pic].stream * 256 + ((w3 & MPEGHIP_MB_INTRA) ? 0u : 128u);
         ci.base[k] = acc;
         acc += popc6(ci.cbp[k]);
     }
