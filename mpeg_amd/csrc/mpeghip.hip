@@ -217,6 +217,47 @@ __global__ __launch_bounds__(kChunkMbs * 64) void recon_compact_kernel(const Vid
         compact_phase3(a, u, ci, w, lane, ld, lds);
 }
 
+// ---- wave-chunk path: one wave = 4 consecutive macroblocks, dense residual stage, no barrier
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a, const uint32_t n_chunks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kWcLdsBytes];
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t chunk = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w);
+    if (chunk >= n_chunks)
+        return;
+    uint8_t *resid = lds_all + w * kWcLdsBytes;
+    int32_t *tile = reinterpret_cast<int32_t *>(resid + kWcResidBytes);
+    const WcInfo ci = load_chunk_t<kWcMbs>(a, chunk);
+    const int g = lane >> 3, j = lane & 7;
+
+    // descriptors + prediction loads of every macroblock of the chunk, up front
+    MbU u[kWcMbs];
+    MbLoads ld[kWcMbs];
+#pragma unroll
+    for (int m = 0; m < kWcMbs; m++) {
+        const uint32_t idx = (uint32_t)m < ci.n ? chunk * kWcMbs + (uint32_t)m : chunk * kWcMbs;
+        u[m] = load_mb(a, idx);
+        compact_phase1(a, u[m], lane, ld[m]);
+    }
+    // dense residual stage: 8 coded blocks per pass
+    const uint32_t total = ci.base[kWcMbs];
+    for (uint32_t s0 = 0; s0 < total; s0 += 8) {
+        const uint32_t slot = s0 + (uint32_t)g;
+        bool active;
+        compact_phase2(a, ci, slot, j, tile + g * kTileStride, active);
+        wave_lds_handoff();
+        compact_phase2_rows(slot, j, tile + g * kTileStride, active, resid);
+        wave_lds_handoff();
+    }
+    // per macroblock: prediction + residual, clamp, store
+#pragma unroll
+    for (int m = 0; m < kWcMbs; m++)
+        if ((uint32_t)m < ci.n)
+            compact_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m], resid);
+}
+
 // ---- split path (video_split_lane.h): K1 prediction, K2 dense residual
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pred_kernel(const SplitArgs s)
@@ -823,16 +864,40 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
     // Development knob (not part of the ABI): MPEGHIP_RECON="mode,waves,blocks_per_cu".
-    //   mode 5 (default): compact fused kernel (dense residual stage inside the workgroup) (+ RGBA pass)
+    //   mode 6 (default): wave-chunk kernel: one wave = 4 macroblocks, dense residual stage, no barrier
+    //                     ("waves" = 4 -> 4 waves/block, 8 -> 8, 16 -> 2)
+    //   mode 5: compact fused kernel (dense residual stage inside the workgroup) (+ RGBA pass)
     //   mode 4: split path, K1 prediction + K2 dense residual (+ RGBA pass)
     //   mode 0: fused one-wave-per-macroblock kernel;  1-3: its persistent / pipelined variants
-    int mode = 5, waves = 8, bpc = 4;
+    int mode = 6, waves = 4, bpc = 4;
     if (const char *e = getenv("MPEGHIP_RECON"))
         sscanf(e, "%d,%d,%d", &mode, &waves, &bpc);
     if (waves != 4 && waves != 8 && waves != 16)
         waves = 8;
-    if (mode < 0 || mode > 5)
-        mode = 5;
+    if (mode < 0 || mode > 6)
+        mode = 6;
+    if (mode == 6) {
+        hipStream_t st = v->ctx->stream;
+        const uint32_t n_chunks = (uint32_t)((b->n_mbs + kWcMbs - 1) / kWcMbs);
+        if (waves == 8) {
+            hipLaunchKernelGGL((recon_wc_kernel<8>), dim3((n_chunks + 7) / 8), dim3(512), 0, st, a, n_chunks);
+        } else if (waves == 16) {
+            hipLaunchKernelGGL((recon_wc_kernel<2>), dim3((n_chunks + 1) / 2), dim3(128), 0, st, a, n_chunks);
+        } else {
+            hipLaunchKernelGGL((recon_wc_kernel<4>), dim3((n_chunks + 3) / 4), dim3(256), 0, st, a, n_chunks);
+        }
+        HIP_TRY(hipGetLastError());
+        if (b->any_rgba) {
+            const uint32_t quads = (in.width + 3) / 4;
+            for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
+                const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
+                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 3) / 4, np), dim3(256), 0, st, a,
+                                   (uint32_t)p0);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        return MPEGHIP_OK;
+    }
     if (mode == 5) {
         hipStream_t st = v->ctx->stream;
         const uint32_t blocks = (uint32_t)((b->n_mbs + kChunkMbs - 1) / kChunkMbs);

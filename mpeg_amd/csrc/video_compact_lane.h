@@ -30,26 +30,29 @@ constexpr int kResidStoreBytes = kMaxChunkBlocks * 128;            // int16 8x8 
 constexpr int kCompactTileBytes = 6 * 8 * kTileStride * 4;         // 6 working waves x 8 blocks x 72 dwords
 constexpr int kCompactLdsBytes = kResidStoreBytes + kCompactTileBytes;
 
-// Wave-uniform summary of the chunk's 8 descriptors (SGPRs on the device).
-struct ChunkInfo {
-    uint32_t n;                       // macroblocks in this chunk (tail chunk < 8)
-    uint32_t cbp[kChunkMbs];          // 0 for macroblocks beyond n
-    uint32_t flags[kChunkMbs];        // MPEGHIP_MB_* | quantiser_scale << 8
-    uint32_t coef_off[kChunkMbs];
-    uint32_t qtab[kChunkMbs];         // byte offset of the macroblock's {matrix, premultiplier} table
-    uint32_t base[kChunkMbs + 1];     // slot number of each macroblock's first coded block; base[8] = total
+// Wave-uniform summary of a chunk of N consecutive descriptors (SGPRs on the device).
+template <int N>
+struct ChunkInfoT {
+    uint32_t n;               // macroblocks in this chunk (tail chunk < N)
+    uint32_t cbp[N];          // 0 for macroblocks beyond n
+    uint32_t flags[N];        // MPEGHIP_MB_* | quantiser_scale << 8
+    uint32_t coef_off[N];
+    uint32_t qtab[N];         // byte offset of the macroblock's {matrix, premultiplier} table
+    uint32_t base[N + 1];     // slot number of each macroblock's first coded block; base[N] = total
 };
+using ChunkInfo = ChunkInfoT<kChunkMbs>;
 
-MPG_HD ChunkInfo load_chunk(const VideoArgs &a, uint32_t chunk)
+template <int N>
+MPG_HD ChunkInfoT<N> load_chunk_t(const VideoArgs &a, uint32_t chunk)
 {
     const MPG_CONST_AS mpeghip_mb_desc *mbs = (const MPG_CONST_AS mpeghip_mb_desc *)(uintptr_t)a.mbs;
     const MPG_CONST_AS mpeghip_pic_desc *pics = (const MPG_CONST_AS mpeghip_pic_desc *)(uintptr_t)a.pics;
-    ChunkInfo ci;
-    const uint32_t first = chunk * kChunkMbs;
-    ci.n = a.n_mbs - first < (uint32_t)kChunkMbs ? a.n_mbs - first : (uint32_t)kChunkMbs;
+    ChunkInfoT<N> ci;
+    const uint32_t first = chunk * N;
+    ci.n = a.n_mbs - first < (uint32_t)N ? a.n_mbs - first : (uint32_t)N;
     uint32_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < kChunkMbs; k++) {
+    for (int k = 0; k < N; k++) {
         const uint32_t idx = (uint32_t)k < ci.n ? first + (uint32_t)k : first; // clamp: keeps the loads unconditional
         const MPG_CONST_AS mpeghip_mb_desc &d = mbs[idx];
         // flags | cbp << 8 | qscale << 16 as ONE scalar dword (byte-sized member reads would become
@@ -63,37 +66,41 @@ MPG_HD ChunkInfo load_chunk(const VideoArgs &a, uint32_t chunk)
         ci.base[k] = acc;
         acc += popc6(ci.cbp[k]);
     }
-    ci.base[kChunkMbs] = acc;
+    ci.base[N] = acc;
     return ci;
 }
+
+MPG_HD ChunkInfo load_chunk(const VideoArgs &a, uint32_t chunk) { return load_chunk_t<kChunkMbs>(a, chunk); }
 
 // base[w] for a run-time (wave-uniform) w, computed arithmetically: indexing the array
 // with a run-time value (or a select chain over its elements, which LLVM folds back into
 // an indexed load) would push the whole ChunkInfo into scratch memory.
-MPG_HD uint32_t chunk_base_of(const ChunkInfo &ci, uint32_t w)
+template <int N>
+MPG_HD uint32_t chunk_base_of(const ChunkInfoT<N> &ci, uint32_t w)
 {
     uint32_t r = 0;
 #pragma unroll
-    for (int i = 0; i < kChunkMbs - 1; i++)
+    for (int i = 0; i < N - 1; i++)
         r += ((uint32_t)i < w) ? popc6(ci.cbp[i]) : 0u;
     return r;
 }
 
 // ------------------------------------------------------------------ phase 2
 // lane (g, j) of a working wave: slot = 8*wave + g.
-MPG_HD void compact_phase2(const VideoArgs &a, const ChunkInfo &ci, uint32_t slot, int j, int32_t *tile_g, bool &active)
+template <int N>
+MPG_HD void compact_phase2(const VideoArgs &a, const ChunkInfoT<N> &ci, uint32_t slot, int j, int32_t *tile_g, bool &active)
 {
-    active = slot < ci.base[kChunkMbs];
+    active = slot < ci.base[N];
     if (!active)
         return;
     // which macroblock owns this slot: k = #{i >= 1 : base[i] <= slot}
     uint32_t k = 0;
 #pragma unroll
-    for (int i = 1; i < kChunkMbs; i++)
+    for (int i = 1; i < N; i++)
         k += (slot >= ci.base[i]) ? 1u : 0u;
     uint32_t cbp = ci.cbp[0], flags = ci.flags[0], coef_off = ci.coef_off[0], qtab = ci.qtab[0], base = ci.base[0];
 #pragma unroll
-    for (int i = 1; i < kChunkMbs; i++) {
+    for (int i = 1; i < N; i++) {
         const bool sel = k == (uint32_t)i;
         cbp = sel ? ci.cbp[i] : cbp;
         flags = sel ? ci.flags[i] : flags;
@@ -189,7 +196,8 @@ MPG_HD uint32_t add_resid_pack4(uint32_t pred4, uint32_t r01, uint32_t r23)
 
 // ------------------------------------------------------------------ phase 3
 // wave w (macroblock w of the chunk), lane (b, j): finish row j of block b.
-MPG_HD void compact_phase3(const VideoArgs &a, const MbU &u, const ChunkInfo &ci, uint32_t w, int lane, const MbLoads &ld,
+template <int N>
+MPG_HD void compact_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci, uint32_t w, int lane, const MbLoads &ld,
                            const uint8_t *resid_store)
 {
     const int b = lane >> 3, j = lane & 7;
@@ -254,5 +262,16 @@ MPG_HD void compact_phase1(const VideoArgs &a, const MbU &u, int lane, MbLoads &
     v.cbp = 0;
     mb_issue_loads(a, v, lane, ld);
 }
+
+// ------------------------------------------------------------------ wave-chunk variant
+// The same three phases run by ONE wave on a chunk of kWcMbs macroblocks, sequentially,
+// with wave-private LDS: no barrier, no coupling between waves.  All loads of the chunk
+// (coefficient columns of the first IDCT pass, prediction rows of every macroblock) are
+// issued before the first use.
+constexpr int kWcMbs = 4;
+constexpr int kWcMaxBlocks = 6 * kWcMbs;                   // 24
+constexpr int kWcResidBytes = kWcMaxBlocks * 128;           // 3072
+constexpr int kWcLdsBytes = kWcResidBytes + 8 * kTileStride * 4; // + one 8-block transpose tile = 5376
+using WcInfo = ChunkInfoT<kWcMbs>;
 
 } // namespace mpg

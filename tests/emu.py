@@ -41,6 +41,8 @@ def lib():
         L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, P, C.c_uint32, P, P, P, P, C.c_uint64, C.c_int]
         L.emu_video_run_split.restype = C.c_int
         L.emu_video_run_split.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, C.c_uint64]
+        L.emu_video_run_wc.restype = C.c_int
+        L.emu_video_run_wc.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
         L.emu_video_run_compact.restype = C.c_int
         L.emu_video_run_compact.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
         L.emu_rgba_convert.restype = None
@@ -73,7 +75,8 @@ def _qtable(intra, non_intra):
 
 
 class EmuStore:
-    def __init__(self, width, height, n_streams=1, static_pipeline=False, split=False, compact=False):
+    def __init__(self, width, height, n_streams=1, static_pipeline=False, split=False, compact=False, wc=False):
+        self.wc = wc
         self.static_pipeline = int(static_pipeline)
         self.split = split
         self.compact = compact
@@ -106,6 +109,12 @@ class EmuStore:
                     self.rgba_convert(slot, s, 1)
             self._rgba_init = True
         g = self.g
+        if self.wc:
+            rc = lib().emu_video_run_wc(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
+                                        _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs),
+                                        _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
+            assert rc == 0
+            return
         if self.compact:
             rc = lib().emu_video_run_compact(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
                                              _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs),

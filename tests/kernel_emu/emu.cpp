@@ -246,6 +246,71 @@ int emu_video_run_compact(uint8_t *frames, uint64_t frame_stride, uint32_t luma_
     return 0;
 }
 
+// recon_wc_kernel: one wave per chunk of 4 macroblocks (+ the RGBA pass).
+int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
+                     uint32_t width, uint32_t height,
+                     const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                     const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
+{
+    VideoArgs a;
+    a.frames = frames;
+    a.frame_stride = frame_stride;
+    a.luma_w = luma_w;
+    a.luma_h = luma_h;
+    a.chroma_w = luma_w / 2;
+    a.chroma_h = luma_h / 2;
+    a.luma_bytes = luma_w * luma_h;
+    a.chroma_bytes = a.luma_bytes / 4;
+    a.pics = pics;
+    a.mbs = mbs;
+    a.coefs = coefs;
+    a.qmat = qtable;
+    a.dump = nullptr;
+    a.n_mbs = n_mbs;
+    a.width = width;
+    a.height = height;
+    a.rgba = rgba;
+    a.rgba_stride = rgba_stride;
+    alignas(16) static uint8_t lds[kWcLdsBytes];
+    const uint32_t n_chunks = (n_mbs + kWcMbs - 1) / kWcMbs;
+    for (uint32_t chunk = 0; chunk < n_chunks; chunk++) {
+        memset(lds, 0xCD, sizeof(lds));
+        uint8_t *resid = lds;
+        int32_t *tile = reinterpret_cast<int32_t *>(lds + kWcResidBytes);
+        const WcInfo ci = load_chunk_t<kWcMbs>(a, chunk);
+        MbU u[kWcMbs];
+        static MbLoads ld[kWcMbs][64];
+        for (int m = 0; m < kWcMbs; m++) {
+            const uint32_t idx = (uint32_t)m < ci.n ? chunk * kWcMbs + (uint32_t)m : chunk * kWcMbs;
+            u[m] = load_mb(a, idx);
+            for (int lane = 0; lane < 64; lane++)
+                compact_phase1(a, u[m], lane, ld[m][lane]);
+        }
+        for (uint32_t s0 = 0; s0 < ci.base[kWcMbs]; s0 += 8) {
+            bool active[64];
+            for (int lane = 0; lane < 64; lane++)
+                compact_phase2(a, ci, s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kTileStride, active[lane]);
+            for (int lane = 0; lane < 64; lane++)
+                compact_phase2_rows(s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kTileStride, active[lane], resid);
+        }
+        for (int m = 0; m < kWcMbs; m++)
+            if ((uint32_t)m < ci.n)
+                for (int lane = 0; lane < 64; lane++)
+                    compact_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], resid);
+    }
+    for (uint32_t p = 0; p < n_pics; p++) {
+        if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
+            continue;
+        const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
+        const uint32_t quads = (width + 3) / 4;
+        for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+            for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
+                rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
+                                  x4, y, rgba + fs * rgba_stride);
+    }
+    return 0;
+}
+
 void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, uint32_t width, uint32_t height,
                       uint8_t *rgba)
 {

@@ -17,18 +17,18 @@ from parity import bits_equal, run_and_compare
     (176, 144, 4, "typical", 0.0, True),     # QCIF: height not a multiple of 16 in RGBA
     (24, 40, 4, "typical", 0.0, True),       # tiny, width not a multiple of 16
 ])
-@pytest.mark.parametrize("flavour", ["compact", "split", "fused", "fused_static"])
+@pytest.mark.parametrize("flavour", ["wave_chunk", "compact", "split", "fused", "fused_static"])
 def test_video_lane_logic_matches_oracle(oracle, emu, w, h, n, profile, raw, rgba, flavour):
     seq = synth.generate_sequence(w, h, n, profile=profile, raw_fraction=raw, rgba=rgba)
     dut = emu.EmuStore(w, h, static_pipeline=(flavour == "fused_static"), split=(flavour == "split"),
-                       compact=(flavour == "compact"))
+                       compact=(flavour == "compact"), wc=(flavour == "wave_chunk"))
     run_and_compare(oracle.OracleStore(w, h), dut, seq, check_rgba=rgba)
 
 
 def test_video_custom_quant_matrices(oracle, emu):
     rng = np.random.default_rng(5)
     iq, nq = rng.integers(1, 256, 64), rng.integers(1, 256, 64)
-    o, e = oracle.OracleStore(64, 48), emu.EmuStore(64, 48, compact=True)
+    o, e = oracle.OracleStore(64, 48), emu.EmuStore(64, 48, wc=True)
     o.set_quant(0, iq, nq)
     e.set_quant(0, iq, nq)
     run_and_compare(o, e, synth.generate_sequence(64, 48, 6, seed=11))
