@@ -1,0 +1,222 @@
+// capi.cpp — flat C entry points over the C++ host mirror, for ctypes-driven tests
+// and for non-C++ callers.  Every function returns NULL / 0 on failure and keeps a
+// thread-local message (mpeghost_last_error).
+#include <stdio.h>
+#include <string.h>
+
+#include <exception>
+#include <string>
+
+#include "mpeg.hpp"
+
+using namespace mpeg;
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+auto guard(F f, decltype(f()) fail) -> decltype(f())
+{
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return fail;
+    }
+}
+
+struct VideoHandle {
+    std::unique_ptr<Buffer> buf;
+    std::unique_ptr<Video> video;
+    Frame *last = nullptr;
+};
+struct AudioHandle {
+    std::unique_ptr<Buffer> buf;
+    std::unique_ptr<Audio> audio;
+};
+} // namespace
+
+extern "C" {
+
+struct mpeghost_frame {
+    double time;
+    int width, height;
+    int luma_w, luma_h, chroma_w, chroma_h;
+    const uint8_t *y, *cb, *cr;
+    size_t luma_bytes, chroma_bytes;
+};
+
+const char *mpeghost_last_error(void) { return g_err.c_str(); }
+
+void *mpeghost_device_create(int ordinal)
+{
+    return guard([&]() -> void * { return new Device(ordinal); }, (void *)nullptr);
+}
+void mpeghost_device_destroy(void *d) { delete static_cast<Device *>(d); }
+
+// NewVideo over a complete elementary stream (the way TestVideoGolden builds it, mpeg_test.go:206-213)
+void *mpeghost_video_open(void *device, const uint8_t *data, size_t len)
+{
+    return guard([&]() -> void * {
+        auto *h = new VideoHandle();
+        h->buf = Buffer::FromMemory(data, len);
+        h->video.reset(new Video(h->buf.get(), static_cast<Device *>(device)));
+        return h;
+    }, (void *)nullptr);
+}
+// same, with a caller-supplied backend (ownership passes to the decoder) — used by tests/host_emu
+void *mpeghost_video_open_backend(void *backend, const uint8_t *data, size_t len)
+{
+    return guard([&]() -> void * {
+        auto *h = new VideoHandle();
+        h->buf = Buffer::FromMemory(data, len);
+        h->video.reset(new Video(h->buf.get(), std::unique_ptr<VideoBackend>(static_cast<VideoBackend *>(backend))));
+        return h;
+    }, (void *)nullptr);
+}
+void mpeghost_video_close(void *h) { delete static_cast<VideoHandle *>(h); }
+int mpeghost_video_width(void *h) { return static_cast<VideoHandle *>(h)->video->Width(); }
+int mpeghost_video_height(void *h) { return static_cast<VideoHandle *>(h)->video->Height(); }
+double mpeghost_video_framerate(void *h) { return static_cast<VideoHandle *>(h)->video->Framerate(); }
+void mpeghost_video_set_no_delay(void *h, int v) { static_cast<VideoHandle *>(h)->video->SetNoDelay(v != 0); }
+int mpeghost_video_decode(void *hv, mpeghost_frame *out)
+{
+    return guard([&]() -> int {
+        auto *h = static_cast<VideoHandle *>(hv);
+        Frame *f = h->video->Decode();
+        h->last = f;
+        if (!f)
+            return 0;
+        out->time = f->Time;
+        out->width = f->Width;
+        out->height = f->Height;
+        out->luma_w = f->Y.Width;
+        out->luma_h = f->Y.Height;
+        out->chroma_w = f->Cb.Width;
+        out->chroma_h = f->Cb.Height;
+        out->y = f->Y.Data;
+        out->cb = f->Cb.Data;
+        out->cr = f->Cr.Data;
+        out->luma_bytes = f->Y.Len;
+        out->chroma_bytes = f->Cb.Len;
+        return 1;
+    }, -1);
+}
+const uint8_t *mpeghost_video_rgba(void *hv)
+{
+    return guard([&]() -> const uint8_t * {
+        auto *h = static_cast<VideoHandle *>(hv);
+        return h->last ? h->last->RGBA() : nullptr;
+    }, (const uint8_t *)nullptr);
+}
+void mpeghost_video_stats(void *hv, uint64_t out[8])
+{
+    const VideoStats &s = static_cast<VideoHandle *>(hv)->video->Stats();
+    out[0] = s.pictures;
+    out[1] = s.submits;
+    out[2] = s.macroblocks;
+    out[3] = s.coded_blocks;
+    out[4] = s.raw_macroblocks;
+    out[5] = s.invalid_blocks;
+    out[6] = s.duplicate_splits;
+    out[7] = s.range_skips;
+}
+
+// NewAudio over a complete elementary stream (TestAudioGolden, mpeg_test.go:167-173)
+void *mpeghost_audio_open(void *device, const uint8_t *data, size_t len, int fma_mode, int format)
+{
+    return guard([&]() -> void * {
+        auto *h = new AudioHandle();
+        h->buf = Buffer::FromMemory(data, len);
+        h->audio.reset(new Audio(h->buf.get(), static_cast<Device *>(device), fma_mode));
+        h->audio->SetFormat((AudioFormat)format);
+        return h;
+    }, (void *)nullptr);
+}
+void *mpeghost_audio_open_backend(void *backend, const uint8_t *data, size_t len, int format)
+{
+    return guard([&]() -> void * {
+        auto *h = new AudioHandle();
+        h->buf = Buffer::FromMemory(data, len);
+        h->audio.reset(new Audio(h->buf.get(), std::unique_ptr<AudioBackend>(static_cast<AudioBackend *>(backend))));
+        h->audio->SetFormat((AudioFormat)format);
+        return h;
+    }, (void *)nullptr);
+}
+void mpeghost_audio_close(void *h) { delete static_cast<AudioHandle *>(h); }
+int mpeghost_audio_samplerate(void *h) { return static_cast<AudioHandle *>(h)->audio->Samplerate(); }
+int mpeghost_audio_channels(void *h) { return static_cast<AudioHandle *>(h)->audio->Channels(); }
+// returns Samples.Interleaved (2304 floats) / S16 / F32 / Left+Right according to the format, or NULL at the end
+const void *mpeghost_audio_decode(void *ha, double *time)
+{
+    return guard([&]() -> const void * {
+        Samples *s = static_cast<AudioHandle *>(ha)->audio->Decode();
+        if (!s)
+            return nullptr;
+        if (time)
+            *time = s->Time;
+        switch (s->format) {
+        case AudioF32N: return s->Interleaved.data();
+        case AudioF32: return s->F32.data();
+        case AudioS16: return s->S16.data();
+        default: return s->Left.data();
+        }
+    }, (const void *)nullptr);
+}
+
+// mpeg.New over a complete program stream
+void *mpeghost_mpeg_open(void *device, const uint8_t *data, size_t len)
+{
+    return guard([&]() -> void * { return new MPEG(data, len, static_cast<Device *>(device)); }, (void *)nullptr);
+}
+void mpeghost_mpeg_close(void *m) { delete static_cast<MPEG *>(m); }
+void mpeghost_mpeg_info(void *mv, int out[6])
+{
+    MPEG *m = static_cast<MPEG *>(mv);
+    out[0] = m->NumVideoStreams();
+    out[1] = m->NumAudioStreams();
+    out[2] = m->Width();
+    out[3] = m->Height();
+    out[4] = m->Samplerate();
+    out[5] = m->Channels();
+}
+double mpeghost_mpeg_framerate(void *m) { return static_cast<MPEG *>(m)->Framerate(); }
+void mpeghost_mpeg_set_enabled(void *m, int video, int audio)
+{
+    static_cast<MPEG *>(m)->SetVideoEnabled(video != 0);
+    static_cast<MPEG *>(m)->SetAudioEnabled(audio != 0);
+}
+int mpeghost_mpeg_decode_video(void *mv, mpeghost_frame *out)
+{
+    return guard([&]() -> int {
+        Frame *f = static_cast<MPEG *>(mv)->DecodeVideo();
+        if (!f)
+            return 0;
+        out->time = f->Time;
+        out->width = f->Width;
+        out->height = f->Height;
+        out->luma_w = f->Y.Width;
+        out->luma_h = f->Y.Height;
+        out->chroma_w = f->Cb.Width;
+        out->chroma_h = f->Cb.Height;
+        out->y = f->Y.Data;
+        out->cb = f->Cb.Data;
+        out->cr = f->Cr.Data;
+        out->luma_bytes = f->Y.Len;
+        out->chroma_bytes = f->Cb.Len;
+        return 1;
+    }, -1);
+}
+const float *mpeghost_mpeg_decode_audio(void *mv, double *time)
+{
+    return guard([&]() -> const float * {
+        Samples *s = static_cast<MPEG *>(mv)->DecodeAudio();
+        if (!s)
+            return nullptr;
+        if (time)
+            *time = s->Time;
+        return s->Interleaved.data();
+    }, (const float *)nullptr);
+}
+int mpeghost_mpeg_has_ended(void *m) { return static_cast<MPEG *>(m)->HasEnded() ? 1 : 0; }
+
+} // extern "C"

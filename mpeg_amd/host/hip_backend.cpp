@@ -1,0 +1,88 @@
+// hip_backend.cpp — the one and only reconstruction backend of the product: libmpeghip.
+#include <stdexcept>
+#include <string>
+
+#include "mpeg.hpp"
+
+namespace mpeg {
+
+namespace {
+
+void check(int rc, const char *what)
+{
+    if (rc != MPEGHIP_OK)
+        throw std::runtime_error(std::string(what) + ": " + mpeghip_last_error());
+}
+
+class HipVideoBackend : public VideoBackend {
+public:
+    explicit HipVideoBackend(mpeghip_ctx *ctx) : ctx_(ctx) {}
+    ~HipVideoBackend() override
+    {
+        if (store_)
+            mpeghip_video_close(store_);
+    }
+    void open(int width, int height) override
+    {
+        if (store_)
+            mpeghip_video_close(store_);
+        store_ = nullptr;
+        check(mpeghip_video_open(ctx_, (uint32_t)width, (uint32_t)height, 1, &store_), "mpeghip_video_open");
+    }
+    void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override
+    {
+        check(mpeghip_video_set_quant(store_, 0, intra, non_intra), "mpeghip_video_set_quant");
+    }
+    void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
+                size_t coef_bytes) override
+    {
+        check(mpeghip_video_submit(store_, &pic, 1, mbs, n_mbs, coefs, coef_bytes), "mpeghip_video_submit");
+    }
+    void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
+    {
+        check(mpeghip_video_read_planes(store_, 0, slot, y, cb, cr), "mpeghip_video_read_planes");
+    }
+    void readRGBA(uint32_t slot, uint8_t *dst) override
+    {
+        check(mpeghip_video_rgba_convert(store_, slot, 0, 1), "mpeghip_video_rgba_convert");
+        check(mpeghip_video_read_rgba(store_, 0, slot, dst), "mpeghip_video_read_rgba");
+    }
+
+private:
+    mpeghip_ctx *ctx_;
+    mpeghip_video *store_ = nullptr;
+};
+
+class HipAudioBackend : public AudioBackend {
+public:
+    HipAudioBackend(mpeghip_ctx *ctx, int fma_mode)
+    {
+        check(mpeghip_audio_open(ctx, 1, fma_mode, &synth_), "mpeghip_audio_open");
+    }
+    ~HipAudioBackend() override { mpeghip_audio_close(synth_); }
+    void synth(const int32_t *samples, int format, void *out) override
+    {
+        check(mpeghip_audio_synth(synth_, samples, 1, format, out), "mpeghip_audio_synth");
+    }
+
+private:
+    mpeghip_audio *synth_ = nullptr;
+};
+
+} // namespace
+
+Device::Device(int ordinal)
+{
+    if (mpeghip_ctx_create(ordinal, nullptr, &ctx_) != MPEGHIP_OK)
+        throw std::runtime_error(std::string("mpeg::Device: ") + mpeghip_last_error());
+}
+
+Device::~Device() { mpeghip_ctx_destroy(ctx_); }
+
+std::unique_ptr<VideoBackend> Device::newVideoBackend() { return std::unique_ptr<VideoBackend>(new HipVideoBackend(ctx_)); }
+std::unique_ptr<AudioBackend> Device::newAudioBackend(int fma_mode)
+{
+    return std::unique_ptr<AudioBackend>(new HipAudioBackend(ctx_, fma_mode));
+}
+
+} // namespace mpeg

@@ -30,16 +30,19 @@ namespace mpeg {
 class Buffer;
 using LoadFunc = std::function<void(Buffer *)>; // buffer.go:14
 
+// minimal io.ReadSeeker for Buffer
+struct BufferReader {
+    std::function<size_t(uint8_t *, size_t)> read; // returns bytes read, 0 = EOF
+    std::function<bool(size_t)> seek;              // absolute; may be empty (not seekable)
+    size_t size = 0;                               // total size if seekable
+};
+
 // buffer.go:17-221.  Data source of all decoders: a growable byte buffer with a
 // bit cursor, fed by Write() or on demand through the load callback.
 class Buffer {
 public:
     // NewBuffer (buffer.go:32-61).  `reader` may be empty (push mode: Write()).
-    struct Reader {                       // minimal io.ReadSeeker
-        std::function<size_t(uint8_t *, size_t)> read; // returns bytes read, 0 = EOF
-        std::function<bool(size_t)> seek;              // absolute; may be empty (not seekable)
-        size_t size = 0;                               // total size if seekable
-    };
+    using Reader = BufferReader;
     explicit Buffer(Reader reader = Reader());
     static std::unique_ptr<Buffer> FromMemory(const uint8_t *data, size_t len); // bytes.NewReader + LoadReaderCallback
 
@@ -114,12 +117,37 @@ struct VideoStats {
     uint64_t invalid_blocks = 0, duplicate_splits = 0, range_skips = 0;
 };
 
+// What the decoders need from the reconstruction device.  The product ships exactly
+// one implementation, HipVideoBackend / HipAudioBackend over libmpeghip (hip_backend.cpp);
+// there is no CPU implementation in this library.  The interface exists so that the
+// parser can be unit-tested without a GPU by injecting the test-only lane emulator
+// (tests/host_emu), never as a fallback.
+class VideoBackend {
+public:
+    virtual ~VideoBackend() {}
+    virtual void open(int width, int height) = 0;            // (re)create the 3-slot frame store, zeroed
+    virtual void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) = 0;
+    virtual void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                        const uint8_t *coefs, size_t coef_bytes) = 0;
+    virtual void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) = 0;
+    virtual void readRGBA(uint32_t slot, uint8_t *dst) = 0;  // Frame.RGBA of the slot
+};
+
+class AudioBackend {
+public:
+    virtual ~AudioBackend() {}
+    // one frame: samples int32 [2][36][32] -> 2304 elements of the format's type
+    virtual void synth(const int32_t *samples, int format, void *out) = 0;
+};
+
 // Shared device context for decoders (one per GPU).
 class Device {
 public:
     explicit Device(int ordinal = 0);   // throws std::runtime_error without a gfx950 GPU
     ~Device();
     mpeghip_ctx *ctx() const { return ctx_; }
+    std::unique_ptr<VideoBackend> newVideoBackend();
+    std::unique_ptr<AudioBackend> newAudioBackend(int fma_mode);
 private:
     mpeghip_ctx *ctx_ = nullptr;
 };
@@ -127,6 +155,7 @@ private:
 class Video {
 public:
     Video(Buffer *buf, Device *dev);                 // NewVideo (video.go:110-121)
+    Video(Buffer *buf, std::unique_ptr<VideoBackend> backend); // same, with an injected backend (tests)
     ~Video();
     Buffer *GetBuffer() { return buf_; }
     bool HasHeader();                                // video.go:130-147
@@ -160,9 +189,10 @@ private:
     void flushSubmit();
     Frame *frameForSlot(uint32_t slot);
 
+    void init();
     Buffer *buf_;
-    Device *dev_;
-    mpeghip_video *store_ = nullptr;
+    std::unique_ptr<VideoBackend> backend_;
+    size_t luma_bytes_ = 0, chroma_bytes_ = 0;
 
     double frame_rate_ = 0, time_ = 0;
     int frames_decoded_ = 0;
@@ -215,6 +245,7 @@ struct Samples {              // audio.go:27-36
 class Audio {
 public:
     Audio(Buffer *buf, Device *dev, int fma_mode = MPEGHIP_AUDIO_FMA_NONE); // NewAudio (audio.go:83-104)
+    Audio(Buffer *buf, std::unique_ptr<AudioBackend> backend);
     ~Audio();
     Buffer *GetBuffer() { return buf_; }
     bool HasHeader();
@@ -224,7 +255,7 @@ public:
     void SetTime(double t);
     void Rewind();
     bool HasEnded() const { return buf_->HasEnded(); }
-    void SetFormat(AudioFormat f) { format_ = f; samples_.format = f; }
+    void SetFormat(AudioFormat f) { format_ = f; samples_.format = f; } // MPEG.SetAudioFormat (mpeg.go:234)
     Samples *Decode();                            // audio.go:163-182
 
 private:
@@ -234,9 +265,9 @@ private:
     const QuantizerSpec *readAllocation(int sb, int tab3);
     void readSamples(int ch, int sb, int part);
 
+    void init();
     Buffer *buf_;
-    Device *dev_;
-    mpeghip_audio *synth_ = nullptr;
+    std::unique_ptr<AudioBackend> backend_;
     double time_ = 0;
     int samples_decoded_ = 0, samplerate_index_ = 3, bitrate_index_ = 0, version_ = 0, layer_ = 0, mode_ = 0;
     int channels_ = 0, bound_ = 0, next_frame_data_size_ = 0;
@@ -283,6 +314,61 @@ private:
     bool has_pack_header_ = false, has_system_header_ = false, has_headers_ = false;
     int num_audio_streams_ = 0, num_video_streams_ = 0;
     Packet current_, next_;
+};
+
+// --------------------------------------------------------------------- mpeg.go
+using VideoFunc = std::function<void(class MPEG *, Frame *)>;    // mpeg.go:48
+using AudioFunc = std::function<void(class MPEG *, Samples *)>;  // mpeg.go:51
+
+// High-level player facade (mpeg.go:57-669): demux -> per-stream buffers -> decoders,
+// A/V clocking.  Seek / SeekFrame are not ported yet.
+class MPEG {
+public:
+    // mpeg.New (mpeg.go:85-117).  Throws std::runtime_error("invalid MPEG-PS") like ErrInvalidMPEG /
+    // ErrInvalidHeader.  `data` must outlive the object.
+    MPEG(const uint8_t *data, size_t len, Device *dev, int audio_fma_mode = MPEGHIP_AUDIO_FMA_NONE);
+    ~MPEG();
+    bool HasHeaders();
+    bool HasEnded() const { return has_ended_; }
+    void SetVideoEnabled(bool e);
+    void SetAudioEnabled(bool e);
+    void SetLoop(bool l) { loop_ = l; }
+    void SetAudioLeadTime(double s) { audio_lead_time_ = s; }
+    void SetAudioFormat(AudioFormat f);
+    void SetVideoCallback(VideoFunc f) { video_cb_ = std::move(f); }
+    void SetAudioCallback(AudioFunc f) { audio_cb_ = std::move(f); }
+    int NumVideoStreams() { return demux_->NumVideoStreams(); }
+    int NumAudioStreams() { return demux_->NumAudioStreams(); }
+    int Width() { return initDecoders() && video_ ? video_->Width() : 0; }
+    int Height() { return initDecoders() && video_ ? video_->Height() : 0; }
+    double Framerate() { return initDecoders() && video_ ? video_->Framerate() : 0; }
+    int Samplerate() { return initDecoders() && audio_ ? audio_->Samplerate() : 0; }
+    int Channels() { return initDecoders() && audio_ ? audio_->Channels() : 0; }
+    double Time() const { return time_; }
+    void Rewind();
+    void Decode(double tick_seconds);   // mpeg.go:356-411
+    Frame *DecodeVideo();               // mpeg.go:416-433
+    Samples *DecodeAudio();             // mpeg.go:438-455
+    Video *GetVideo() { return video_.get(); }
+    Audio *GetAudio() { return audio_.get(); }
+
+private:
+    bool initDecoders();
+    void handleEnd();
+    void readPackets(int requested_type);
+    Device *dev_;
+    int audio_fma_mode_;
+    std::unique_ptr<Buffer> buf_, video_buf_, audio_buf_;
+    std::unique_ptr<Demux> demux_;
+    std::unique_ptr<Video> video_;
+    std::unique_ptr<Audio> audio_;
+    double time_ = 0, audio_lead_time_ = 0;
+    bool loop_ = false, has_ended_ = false, has_decoders_ = false;
+    bool video_enabled_ = true, audio_enabled_ = true;
+    int video_packet_type_ = 0, audio_packet_type_ = 0, audio_stream_index_ = 0;
+    AudioFormat audio_format_ = AudioF32N;
+    VideoFunc video_cb_;
+    AudioFunc audio_cb_;
 };
 
 } // namespace mpeg

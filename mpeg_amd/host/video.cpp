@@ -76,24 +76,12 @@ int32_t dequantPremult(int level, bool intra, int qscale, int qm, int idx)
     return level * (int)kPremultiplier[idx];
 }
 
-void check(int rc, const char *what)
-{
-    if (rc != MPEGHIP_OK)
-        throw std::runtime_error(std::string(what) + ": " + mpeghip_last_error());
-}
-
 } // namespace
 
-Device::Device(int ordinal)
-{
-    int rc = mpeghip_ctx_create(ordinal, nullptr, &ctx_);
-    if (rc != MPEGHIP_OK)
-        throw std::runtime_error(std::string("mpeg::Device: ") + mpeghip_last_error());
-}
+Video::Video(Buffer *buf, Device *dev) : buf_(buf), backend_(dev->newVideoBackend()) { init(); }
+Video::Video(Buffer *buf, std::unique_ptr<VideoBackend> backend) : buf_(buf), backend_(std::move(backend)) { init(); }
 
-Device::~Device() { mpeghip_ctx_destroy(ctx_); }
-
-Video::Video(Buffer *buf, Device *dev) : buf_(buf), dev_(dev)
+void Video::init()
 { // video.go:110-121
     memset(block_data_, 0, sizeof(block_data_));
     memset(intra_quant_, 0, sizeof(intra_quant_));
@@ -103,11 +91,7 @@ Video::Video(Buffer *buf, Device *dev) : buf_(buf), dev_(dev)
         decodeSequenceHeader();
 }
 
-Video::~Video()
-{
-    if (store_)
-        mpeghip_video_close(store_);
-}
+Video::~Video() {}
 
 bool Video::HasHeader()
 { // video.go:130-147
@@ -168,27 +152,23 @@ bool Video::decodeSequenceHeader()
     chroma_width_ = mb_width_ << 3;
     chroma_height_ = mb_height_ << 3;
 
-    // initFrame x3 (video.go:324-326): the three slots live in the device frame store
-    if (store_)
-        mpeghip_video_close(store_);
-    store_ = nullptr;
-    check(mpeghip_video_open(dev_->ctx(), (uint32_t)width_, (uint32_t)height_, 1, &store_), "mpeghip_video_open");
-    check(mpeghip_video_set_quant(store_, 0, intra_quant_, non_intra_quant_), "mpeghip_video_set_quant");
-    mpeghip_video_info info;
-    mpeghip_video_info_get(store_, &info);
+    // initFrame x3 (video.go:324-326): the three slots live in the backend's frame store
+    backend_->open(width_, height_);
+    backend_->setQuant(intra_quant_, non_intra_quant_);
+    luma_bytes_ = (size_t)luma_width_ * (size_t)luma_height_;
+    chroma_bytes_ = (size_t)chroma_width_ * (size_t)chroma_height_;
     for (int s = 0; s < 3; s++) {
-        host_planes_[s].assign(info.luma_bytes + 2 * info.chroma_bytes, 0);
+        host_planes_[s].assign(luma_bytes_ + 2 * chroma_bytes_, 0);
         Frame &f = frames_[s];
         f.owner = this;
         f.slot = (uint32_t)s;
         f.Width = width_;
         f.Height = height_;
-        f.Y = Plane{luma_width_, luma_height_, host_planes_[s].data(), (size_t)info.luma_bytes};
-        f.Cb = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + info.luma_bytes, (size_t)info.chroma_bytes};
-        f.Cr = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + info.luma_bytes + info.chroma_bytes,
-                     (size_t)info.chroma_bytes};
+        f.Y = Plane{luma_width_, luma_height_, host_planes_[s].data(), luma_bytes_};
+        f.Cb = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + luma_bytes_, chroma_bytes_};
+        f.Cr = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + luma_bytes_ + chroma_bytes_, chroma_bytes_};
     }
-    host_rgba_.assign(info.rgba_bytes, 0);
+    host_rgba_.assign((size_t)width_ * (size_t)height_ * 4, 0);
     written_.assign((size_t)mb_size_, 0);
     slot_cur_ = 0;
     slot_fwd_ = 1;
@@ -200,19 +180,14 @@ bool Video::decodeSequenceHeader()
 Frame *Video::frameForSlot(uint32_t slot)
 {
     // Frame.Y/Cb/Cr.Data are host-visible: fetch the slot's planes (synchronises with the device)
-    Frame &f = frames_[slot];
-    mpeghip_video_info info;
-    mpeghip_video_info_get(store_, &info);
     uint8_t *base = host_planes_[slot].data();
-    check(mpeghip_video_read_planes(store_, 0, slot, base, base + info.luma_bytes, base + info.luma_bytes + info.chroma_bytes),
-          "mpeghip_video_read_planes");
-    return &f;
+    backend_->readPlanes(slot, base, base + luma_bytes_, base + luma_bytes_ + chroma_bytes_);
+    return &frames_[slot];
 }
 
 const uint8_t *Video::fetchRGBA(uint32_t slot)
 { // Frame.RGBA, video.go:31-36
-    check(mpeghip_video_rgba_convert(store_, slot, 0, 1), "mpeghip_video_rgba_convert");
-    check(mpeghip_video_read_rgba(store_, 0, slot, host_rgba_.data()), "mpeghip_video_read_rgba");
+    backend_->readRGBA(slot, host_rgba_.data());
     return host_rgba_.data();
 }
 
@@ -321,8 +296,7 @@ void Video::flushSubmit()
     pic.bwd = (uint8_t)slot_bwd_;
     pic.mb_first = 0;
     pic.mb_count = (uint32_t)mbs_.size();
-    check(mpeghip_video_submit(store_, &pic, 1, mbs_.data(), (uint32_t)mbs_.size(), coefs_.data(), coefs_.size()),
-          "mpeghip_video_submit");
+    backend_->submit(pic, mbs_.data(), (uint32_t)mbs_.size(), coefs_.data(), coefs_.size());
     stats_.submits++;
     stats_.macroblocks += mbs_.size();
     mbs_.clear();

@@ -1,0 +1,106 @@
+// emu_backend.cpp — TEST INFRASTRUCTURE ONLY.  mpeg::VideoBackend / AudioBackend
+// implemented with the lane emulator (tests/kernel_emu), so that the product's
+// bitstream parser + descriptor emitter (libmpeghost) can be checked against the
+// reference's golden hashes on a machine without a GPU.  Never part of the product:
+// libmpeghost itself only knows the HIP backend.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "mpeg.hpp"
+
+extern "C" {
+int emu_video_run_wc(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *, uint32_t,
+                     const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint64_t);
+int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *,
+                  const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, uint64_t, int);
+void emu_rgba_convert(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
+int emu_audio_run(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t);
+}
+
+namespace {
+
+const uint8_t kPremult[64] = {32, 44, 42, 38, 32, 25, 17, 9,  44, 62, 58, 52, 44, 35, 24, 12, 42, 58, 55, 49, 42, 33,
+                              23, 12, 38, 52, 49, 44, 38, 30, 20, 10, 32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30,
+                              25, 20, 14, 7,  17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
+
+class EmuVideoBackend : public mpeg::VideoBackend {
+public:
+    explicit EmuVideoBackend(int flavour) : flavour_(flavour) {}
+    void open(int width, int height) override
+    {
+        w_ = width;
+        h_ = height;
+        lw_ = ((width + 15) >> 4) << 4;
+        lh_ = ((height + 15) >> 4) << 4;
+        luma_ = (size_t)lw_ * lh_;
+        chroma_ = luma_ / 4;
+        stride_ = (luma_ + 2 * chroma_ + (size_t)lw_ * 16 + 64 + 255) / 256 * 256;
+        frames_.assign(stride_ * 3, 0);
+        rgba_stride_ = ((size_t)width * height * 4 + 255) / 256 * 256;
+        rgba_.assign(rgba_stride_ * 3, 0);
+        dump_.assign(512, 0);
+    }
+    void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override
+    {
+        for (int cls = 0; cls < 2; cls++)
+            for (int c = 0; c < 8; c++)
+                for (int r = 0; r < 8; r++) {
+                    qt_[cls * 128 + c * 16 + r] = (cls ? non_intra : intra)[r * 8 + c];
+                    qt_[cls * 128 + c * 16 + 8 + r] = kPremult[r * 8 + c];
+                }
+    }
+    void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs, size_t) override
+    {
+        if (flavour_ == 0)
+            emu_video_run_wc(frames_.data(), stride_, lw_, lh_, w_, h_, &pic, 1, mbs, n_mbs, coefs, qt_, rgba_.data(), rgba_stride_);
+        else
+            emu_video_run(frames_.data(), stride_, lw_, lh_, w_, h_, &pic, mbs, n_mbs, coefs, qt_, dump_.data(), rgba_.data(),
+                          rgba_stride_, 0);
+    }
+    void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
+    {
+        const uint8_t *f = frames_.data() + slot * stride_;
+        memcpy(y, f, luma_);
+        memcpy(cb, f + luma_, chroma_);
+        memcpy(cr, f + luma_ + chroma_, chroma_);
+    }
+    void readRGBA(uint32_t slot, uint8_t *dst) override
+    {
+        emu_rgba_convert(frames_.data() + slot * stride_, lw_, lh_, w_, h_, dst);
+    }
+
+private:
+    int flavour_;
+    uint32_t w_ = 0, h_ = 0, lw_ = 0, lh_ = 0;
+    size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0;
+    std::vector<uint8_t> frames_, rgba_, dump_;
+    uint8_t qt_[256];
+};
+
+class EmuAudioBackend : public mpeg::AudioBackend {
+public:
+    EmuAudioBackend(int fma, const float *window) : fma_(fma)
+    {
+        memset(ring_, 0, sizeof(ring_));
+        memcpy(window_, window, sizeof(window_));
+    }
+    void synth(const int32_t *samples, int format, void *out) override
+    {
+        emu_audio_run(samples, out, &ring_[0][0], &vpos_, window_, 1, 1, format, fma_);
+    }
+
+private:
+    int fma_;
+    float ring_[2][1024];
+    int32_t vpos_ = 0;
+    float window_[512];
+};
+
+} // namespace
+
+extern "C" {
+void *host_emu_video_backend(int flavour) { return new EmuVideoBackend(flavour); }
+void *host_emu_audio_backend(int fma, const float *window512) { return new EmuAudioBackend(fma, window512); }
+}

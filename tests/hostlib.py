@@ -1,0 +1,155 @@
+"""ctypes face of the product's host library (mpeg_amd/libmpeghost.so: bitstream parse -> descriptors ->
+libmpeghip) and of tests/host_emu (TEST-ONLY backend built on the lane emulator, for CPU-side parser checks)."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+HOST_EMU = ROOT / "tests" / "host_emu" / "libhost_emu.so"
+
+
+class HostFrame(C.Structure):
+    _fields_ = [("time", C.c_double), ("width", C.c_int), ("height", C.c_int), ("luma_w", C.c_int), ("luma_h", C.c_int),
+                ("chroma_w", C.c_int), ("chroma_h", C.c_int), ("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p),
+                ("luma_bytes", C.c_size_t), ("chroma_bytes", C.c_size_t)]
+
+
+_host = None
+_emu = None
+
+
+def host():
+    global _host
+    if _host is None:
+        from mpeg_amd import _build
+        _build.build_libmpeghost()
+        L = C.CDLL(str(_build.LIBMPEGHOST))
+        P = C.c_void_p
+        sig = {
+            "mpeghost_last_error": (C.c_char_p, []),
+            "mpeghost_device_create": (P, [C.c_int]), "mpeghost_device_destroy": (None, [P]),
+            "mpeghost_video_open": (P, [P, C.c_char_p, C.c_size_t]),
+            "mpeghost_video_open_backend": (P, [P, C.c_char_p, C.c_size_t]),
+            "mpeghost_video_close": (None, [P]), "mpeghost_video_width": (C.c_int, [P]), "mpeghost_video_height": (C.c_int, [P]),
+            "mpeghost_video_framerate": (C.c_double, [P]), "mpeghost_video_set_no_delay": (None, [P, C.c_int]),
+            "mpeghost_video_decode": (C.c_int, [P, C.POINTER(HostFrame)]), "mpeghost_video_rgba": (P, [P]),
+            "mpeghost_video_stats": (None, [P, C.POINTER(C.c_uint64 * 8)]),
+            "mpeghost_audio_open": (P, [P, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
+            "mpeghost_audio_open_backend": (P, [P, C.c_char_p, C.c_size_t, C.c_int]),
+            "mpeghost_audio_close": (None, [P]), "mpeghost_audio_samplerate": (C.c_int, [P]), "mpeghost_audio_channels": (C.c_int, [P]),
+            "mpeghost_audio_decode": (P, [P, C.POINTER(C.c_double)]),
+            "mpeghost_mpeg_open": (P, [P, C.c_char_p, C.c_size_t]), "mpeghost_mpeg_close": (None, [P]),
+            "mpeghost_mpeg_info": (None, [P, C.POINTER(C.c_int * 6)]), "mpeghost_mpeg_framerate": (C.c_double, [P]),
+            "mpeghost_mpeg_set_enabled": (None, [P, C.c_int, C.c_int]),
+            "mpeghost_mpeg_decode_video": (C.c_int, [P, C.POINTER(HostFrame)]),
+            "mpeghost_mpeg_decode_audio": (P, [P, C.POINTER(C.c_double)]), "mpeghost_mpeg_has_ended": (C.c_int, [P]),
+        }
+        for n, (r, a) in sig.items():
+            f = getattr(L, n)
+            f.restype, f.argtypes = r, a
+        _host = L
+    return _host
+
+
+def host_emu():
+    """Build + load the test-only emulator backend (links the lane emulator sources and libmpeghost)."""
+    global _emu
+    if _emu is None:
+        from mpeg_amd import _build
+        host()
+        srcs = [ROOT / "tests" / "host_emu" / "emu_backend.cpp", ROOT / "tests" / "kernel_emu" / "emu.cpp"]
+        deps = srcs + sorted(_build.CSRC.glob("*.h")) + sorted(_build.HOST.glob("*.hpp")) + [_build.LIBMPEGHOST]
+        if not (HOST_EMU.exists() and all(d.stat().st_mtime <= HOST_EMU.stat().st_mtime for d in deps)):
+            cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DMPG_EMU_CHECKS", "-Wno-unknown-pragmas",
+                   "-I", str(_build.INCLUDE), "-I", str(_build.CSRC), "-I", str(_build.HOST), *map(str, srcs), "-o", str(HOST_EMU),
+                   "-L", str(_build.LIBMPEGHOST.parent), "-lmpeghost", "-Wl,-rpath," + str(_build.LIBMPEGHOST.parent)]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("host_emu build failed:\n" + r.stdout)
+        L = C.CDLL(str(HOST_EMU))
+        L.host_emu_video_backend.restype = C.c_void_p
+        L.host_emu_video_backend.argtypes = [C.c_int]
+        L.host_emu_audio_backend.restype = C.c_void_p
+        L.host_emu_audio_backend.argtypes = [C.c_int, C.c_void_p]
+        _emu = L
+    return _emu
+
+
+def frame_planes(f: HostFrame):
+    y = np.ctypeslib.as_array(C.cast(f.y, C.POINTER(C.c_uint8)), shape=(f.luma_bytes,)).copy()
+    cb = np.ctypeslib.as_array(C.cast(f.cb, C.POINTER(C.c_uint8)), shape=(f.chroma_bytes,)).copy()
+    cr = np.ctypeslib.as_array(C.cast(f.cr, C.POINTER(C.c_uint8)), shape=(f.chroma_bytes,)).copy()
+    return y, cb, cr
+
+
+class HostVideo:
+    """mpeg.NewVideo + Video.Decode through the product's parser; backend = HIP device or (tests) emulator."""
+
+    def __init__(self, data: bytes, device=None, emu_flavour=None):
+        self._data = data
+        L = host()
+        if device is not None:
+            self.h = L.mpeghost_video_open(device, data, len(data))
+        else:
+            be = host_emu().host_emu_video_backend(emu_flavour or 0)
+            self.h = L.mpeghost_video_open_backend(be, data, len(data))
+        if not self.h:
+            raise RuntimeError(L.mpeghost_last_error().decode())
+
+    def decode(self):
+        f = HostFrame()
+        rc = host().mpeghost_video_decode(self.h, C.byref(f))
+        if rc < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return f if rc == 1 else None
+
+    def rgba(self, w, h):
+        p = host().mpeghost_video_rgba(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h, w, 4)).copy()
+
+    def stats(self):
+        out = (C.c_uint64 * 8)()
+        host().mpeghost_video_stats(self.h, C.byref(out))
+        return dict(zip(("pictures", "submits", "macroblocks", "coded_blocks", "raw_macroblocks", "invalid_blocks",
+                         "duplicate_splits", "range_skips"), list(out)))
+
+    def close(self):
+        if self.h:
+            host().mpeghost_video_close(self.h)
+            self.h = None
+
+
+class HostAudio:
+    def __init__(self, data: bytes, device=None, fma=0, fmt=0, window=None):
+        self._data = data
+        L = host()
+        if device is not None:
+            self.h = L.mpeghost_audio_open(device, data, len(data), fma, fmt)
+        else:
+            self._win = np.ascontiguousarray(window, np.float32)
+            be = host_emu().host_emu_audio_backend(fma, self._win.ctypes.data)
+            self.h = L.mpeghost_audio_open_backend(be, data, len(data), fmt)
+        if not self.h:
+            raise RuntimeError(L.mpeghost_last_error().decode())
+        self.fmt = fmt
+
+    def decode(self):
+        t = C.c_double()
+        p = host().mpeghost_audio_decode(self.h, C.byref(t))
+        if not p:
+            return None
+        if self.fmt == 3:
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(2304,)).copy()
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(2304,)).copy()
+
+    samplerate = property(lambda s: host().mpeghost_audio_samplerate(s.h))
+    channels = property(lambda s: host().mpeghost_audio_channels(s.h))
+
+    def close(self):
+        if self.h:
+            host().mpeghost_audio_close(self.h)
+            self.h = None

@@ -1,0 +1,101 @@
+"""-m gpu: the reference's own golden tests, run through the PRODUCT: host parser (libmpeghost) ->
+descriptors -> C ABI (libmpeghip) -> HIP kernels on the MI355X -> planes / samples back on the host.
+TestVideoGolden (mpeg_test.go:205-231) and TestAudioGolden (mpeg_test.go:166-201)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hostlib
+
+pytestmark = pytest.mark.gpu
+
+VIDEO_HASH = 0xea6d7fcb1340ba3f
+TESTMPG_VIDEO_HASH = 0xd00818edcafdc702
+
+
+@pytest.fixture(scope="module")
+def device():
+    d = hostlib.host().mpeghost_device_create(0)
+    assert d, hostlib.host().mpeghost_last_error()
+    yield d
+    hostlib.host().mpeghost_device_destroy(d)
+
+
+def test_video_golden_hash_on_gpu(oracle, golden_dir, device):
+    dec = hostlib.HostVideo((golden_dir / "test.mpeg1video").read_bytes(), device=device)
+    assert (hostlib.host().mpeghost_video_width(dec.h), hostlib.host().mpeghost_video_height(dec.h)) == (160, 120)
+    h, n = oracle.FNV_OFFSET, 0
+    while True:
+        f = dec.decode()
+        if f is None:
+            break
+        for p in hostlib.frame_planes(f):
+            h = oracle.fnv1a64(p, h)
+        n += 1
+    st = dec.stats()
+    dec.close()
+    assert (h, n) == (VIDEO_HASH, 260)
+    assert st["invalid_blocks"] == 53 and st["raw_macroblocks"] > 0
+
+
+def test_frame_rgba_on_gpu_matches_oracle(oracle, golden_dir, device):
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    ref, dut = oracle.VideoDecoder(data), hostlib.HostVideo(data, device=device)
+    for i in range(12):
+        a, b = ref.decode(), dut.decode()
+        for pa, pb in zip(oracle.frame_planes(a), hostlib.frame_planes(b)):
+            assert np.array_equal(pa, pb), "frame %d" % i
+        want = np.empty((120, 160, 4), np.uint8)
+        oracle.lib().orc_ycbcr_to_rgba(C.byref(a), want.ctypes.data)
+        assert np.array_equal(want, dut.rgba(160, 120)), "Frame.RGBA of frame %d" % i
+    ref.close()
+    dut.close()
+
+
+@pytest.mark.parametrize("fma,want", [(0, 0xf1b76cdf8e6cdea5), (1, 0x50f3ab75f5fb0fb5)])
+def test_audio_golden_hash_on_gpu(oracle, golden_dir, device, fma, want):
+    dec = hostlib.HostAudio((golden_dir / "test.mp2").read_bytes(), device=device, fma=fma)
+    h, n = oracle.FNV_OFFSET, 0
+    while True:
+        s = dec.decode()
+        if s is None:
+            break
+        h = oracle.fnv1a64(s, h)
+        n += 1
+    dec.close()
+    assert (h, n) == (want, 355)
+
+
+def test_program_stream_facade_on_gpu(oracle, golden_dir, device):
+    """mpeg.New + DecodeVideo / DecodeAudio on test.mpg (TestMpeg / BenchmarkDecodeVideo's input, BASELINE config 1)."""
+    L = hostlib.host()
+    ps = (golden_dir / "test.mpg").read_bytes()
+    m = L.mpeghost_mpeg_open(device, ps, len(ps))
+    assert m, L.mpeghost_last_error()
+    info = (C.c_int * 6)()
+    L.mpeghost_mpeg_info(m, C.byref(info))
+    assert list(info) == [1, 1, 160, 120, 44100, 1]            # mpeg_test.go:300-330
+    assert L.mpeghost_mpeg_framerate(m) == 30.0
+    # video only, then audio only (the reference's benchmarks disable the other stream the same way)
+    L.mpeghost_mpeg_set_enabled(m, 1, 0)
+    h, n, f = oracle.FNV_OFFSET, 0, hostlib.HostFrame()
+    while L.mpeghost_mpeg_decode_video(m, C.byref(f)) == 1:
+        for p in hostlib.frame_planes(f):
+            h = oracle.fnv1a64(p, h)
+        n += 1
+    assert (h, n) == (TESTMPG_VIDEO_HASH, 278)
+    assert L.mpeghost_mpeg_has_ended(m) == 1
+    L.mpeghost_mpeg_close(m)
+
+    m = L.mpeghost_mpeg_open(device, ps, len(ps))
+    L.mpeghost_mpeg_set_enabled(m, 0, 1)
+    h, n, t = oracle.FNV_OFFSET, 0, C.c_double()
+    while True:
+        p = L.mpeghost_mpeg_decode_audio(m, C.byref(t))
+        if not p:
+            break
+        h = oracle.fnv1a64(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(2304,)), h)
+        n += 1
+    assert (h, n) == (0xf1b76cdf8e6cdea5, 355)
+    L.mpeghost_mpeg_close(m)
