@@ -22,10 +22,18 @@ echo "== bench dense"
 timeout 600 python bench.py --profile dense --cpu-seconds 0 --audio-streams 0 "$@" > $OUT/bench_dense.json 2> $OUT/bench_dense.err; echo "bench dense rc=$?"
 tail -c 2500 $OUT/bench_dense.json; tail -5 $OUT/bench_dense.err
 echo "== rocprofv3 kernel trace"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 13 --warmup 13 --cpu-seconds 0 --check 0 "$@" > $GRAFT_REPO_ROOT/$OUT/prof_trace.log 2>&1; echo "rocprof rc=$?"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 13 --warmup 13 --cpu-seconds 0 --check 0 "$@" > $GRAFT_REPO_ROOT/$OUT/prof_trace.log 2>&1; echo "rocprof rc=$?"
 cd $GRAFT_REPO_ROOT
-find $OUT/prof_trace -name "*stats*" | head; 
-for f in $(find $OUT/prof_trace -name "*kernel_stats.csv" | head -1); do head -12 $f; done
-# keep the merge-back small: drop the big per-dispatch trace, keep stats
-find $OUT/prof_trace -name "*kernel_trace.csv" -size +20M -delete
+for f in $(find $OUT/prof_trace -name "*kernel_stats.csv" | head -1); do head -12 $f | cut -c1-220; done
+find $OUT/prof_trace -name "*kernel_trace.csv" -delete
+echo "== rocprofv3 PMC (HBM traffic; separate passes)"
+cd /tmp
+for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
+  N=$(echo $SET | tr ' ' '_' | cut -c1-40)
+  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-seconds 0 --check 0 --audio-streams 0 "$@" > $GRAFT_REPO_ROOT/$OUT/pmc_$N.log 2>&1
+  echo "pmc [$SET] rc=$?"
+done
+cd $GRAFT_REPO_ROOT
+python tools/pmc_summary.py $OUT 2>&1 | tee $OUT/pmc_summary.txt
+find $OUT -name "*.csv" -size +5M -delete
 du -sh $OUT
