@@ -230,7 +230,7 @@ def main():
             "realtime_1080p30_streams": value / MB_PER_1080P30_STREAM,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "recon_kernel<8>", "alg_bytes_per_launch": alg_done // args.steps,
+                         "kernel": "recon_wc_kernel<4> (one wave = 4 macroblocks, dense residual stage)", "alg_bytes_per_launch": alg_done // args.steps,
                          "avg_launch_ms": launch_ms},
             "cpu_baseline": cpu,
             "audio": audio,
