@@ -95,17 +95,15 @@ def main():
     args = parse_args()
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from mpeg_amd.shard import Ranks
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ranks = Ranks(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL; only barrier + reductions
+    world, rank, dist = ranks.world, ranks.rank, ranks.dist
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world), file=sys.stderr)
 
     from mpeg_amd import abi, desc, synth
 
@@ -122,11 +120,6 @@ def main():
     batches = [store.upload(s.pics, s.mbs, s.coefs, replicate=args.streams) for s in seq]
     ctx.sync()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
     order = []
 
     def step(i):
@@ -137,23 +130,19 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    mbs_done, alg_done = 0, 0
-    for i in range(args.warmup, args.warmup + args.steps):
-        b = step(i)
-        mbs_done += b.n_mbs
-        alg_done += b.alg_bytes
-    ev_ms = ctx.timer_stop_ms()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    acc = {"mbs": 0, "alg": 0, "ev_ms": 0.0}
+
+    def timed_body():
+        ctx.timer_start()
+        for i in range(args.warmup, args.warmup + args.steps):
+            b = step(i)
+            acc["mbs"] += b.n_mbs
+            acc["alg"] += b.alg_bytes
+        acc["ev_ms"] = ctx.timer_stop_ms()  # HIP events on the stream the kernels run on
+
+    # barrier + torch.cuda.synchronize() on both sides, MAX over ranks (mpeg_amd/shard.py)
+    elapsed = ranks.timed(timed_body, device_sync=torch.cuda.synchronize)
+    mbs_done, alg_done, ev_ms = acc["mbs"], acc["alg"], acc["ev_ms"]
 
     # ---- parity at full size (rank 0): all streams identical, and equal to the oracle's replay
     check = None
@@ -241,8 +230,7 @@ def main():
         b.free()
     store.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,136 @@
+//go:build hip
+
+// Package mpeghip is the cgo binding of libmpeghip (include/mpeghip.h), the MI355X
+// reconstruction core.  It is the thin shim the north star asks for: Go stays the host
+// language, one cgo call per picture / audio frame.
+//
+// NOTE: no Go toolchain exists in the image this repository was built in, so this
+// package has been written against the C header but never compiled; every C entry point
+// it binds is exercised through ctypes by tests/ instead.  See INTEGRATION.md.
+package mpeghip
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../mpeg_amd -lmpeghip -Wl,-rpath,${SRCDIR}/../../mpeg_amd
+#include <stdlib.h>
+#include "mpeghip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"unsafe"
+)
+
+// PicDesc mirrors mpeghip_pic_desc (16 bytes).
+type PicDesc struct {
+	Stream          uint32
+	Cur, Fwd, Bwd   uint8
+	Flags           uint8
+	MbFirst, MbCount uint32
+}
+
+// MbDesc mirrors mpeghip_mb_desc (32 bytes).
+type MbDesc struct {
+	Pic        uint32
+	MbX, MbY   uint16
+	MvX, MvY   int16
+	Flags      uint8
+	Cbp        uint8
+	Qscale     uint8
+	_          uint8
+	CoefOff    uint32
+	_          [3]uint32
+}
+
+const (
+	MbIntra   = C.MPEGHIP_MB_INTRA
+	MbRefFwd  = C.MPEGHIP_MB_REF_FWD
+	MbRefBwd  = C.MPEGHIP_MB_REF_BWD
+	MbCoefRaw = C.MPEGHIP_MB_COEF_RAW
+	PicRGBA   = C.MPEGHIP_PIC_RGBA
+)
+
+func lastError(rc C.int) error {
+	if rc == C.MPEGHIP_OK {
+		return nil
+	}
+	return errors.New(C.GoString(C.mpeghip_last_error()))
+}
+
+// Context owns one GPU + stream.
+type Context struct{ h *C.mpeghip_ctx }
+
+func NewContext(device int) (*Context, error) {
+	c := &Context{}
+	if err := lastError(C.mpeghip_ctx_create(C.int(device), nil, &c.h)); err != nil {
+		return nil, err // no GPU: there is no CPU fallback
+	}
+	return c, nil
+}
+func (c *Context) Close() { C.mpeghip_ctx_destroy(c.h) }
+
+// Video is the 3-slot frame store + reconstruction of one stream.
+type Video struct {
+	h    *C.mpeghip_video
+	Info C.mpeghip_video_info
+}
+
+func (c *Context) OpenVideo(width, height int) (*Video, error) {
+	v := &Video{}
+	if err := lastError(C.mpeghip_video_open(c.h, C.uint32_t(width), C.uint32_t(height), 1, &v.h)); err != nil {
+		return nil, err
+	}
+	C.mpeghip_video_info_get(v.h, &v.Info)
+	return v, nil
+}
+func (v *Video) Close() { C.mpeghip_video_close(v.h) }
+
+func (v *Video) SetQuant(intra, nonIntra *[64]byte) error {
+	return lastError(C.mpeghip_video_set_quant(v.h, 0, (*C.uint8_t)(&intra[0]), (*C.uint8_t)(&nonIntra[0])))
+}
+
+// Submit hands one picture to the GPU.  The slices are only read during the call (cgo rule).
+func (v *Video) Submit(pic *PicDesc, mbs []MbDesc, coefs []byte) error {
+	var mp unsafe.Pointer
+	var cp unsafe.Pointer
+	if len(mbs) > 0 {
+		mp = unsafe.Pointer(&mbs[0])
+	}
+	if len(coefs) > 0 {
+		cp = unsafe.Pointer(&coefs[0])
+	}
+	return lastError(C.mpeghip_video_submit(v.h, (*C.mpeghip_pic_desc)(unsafe.Pointer(pic)), 1,
+		(*C.mpeghip_mb_desc)(mp), C.uint32_t(len(mbs)), cp, C.size_t(len(coefs))))
+}
+
+// ReadPlanes fills host slices (len = Info.luma_bytes / chroma_bytes) with the slot's planes.
+func (v *Video) ReadPlanes(slot int, y, cb, cr []byte) error {
+	return lastError(C.mpeghip_video_read_planes(v.h, 0, C.uint32_t(slot),
+		(*C.uint8_t)(&y[0]), (*C.uint8_t)(&cb[0]), (*C.uint8_t)(&cr[0])))
+}
+
+// RGBA converts the slot on the device (Frame.RGBA) and copies width*height*4 bytes into dst.
+func (v *Video) RGBA(slot int, dst []byte) error {
+	if err := lastError(C.mpeghip_video_rgba_convert(v.h, C.uint32_t(slot), 0, 1)); err != nil {
+		return err
+	}
+	return lastError(C.mpeghip_video_read_rgba(v.h, 0, C.uint32_t(slot), (*C.uint8_t)(&dst[0])))
+}
+
+// Audio is the MP2 synthesis state (V ring + vPos) of one stream.
+type Audio struct{ h *C.mpeghip_audio }
+
+func (c *Context) OpenAudio(fmaMode int) (*Audio, error) {
+	a := &Audio{}
+	if err := lastError(C.mpeghip_audio_open(c.h, 1, C.int(fmaMode), &a.h)); err != nil {
+		return nil, err
+	}
+	return a, nil
+}
+func (a *Audio) Close() { C.mpeghip_audio_close(a.h) }
+
+// Synth turns one frame of sub-band samples ([2][36][32]int32) into 2304 output elements.
+func (a *Audio) Synth(samples *[2][36][32]int32, format int, out unsafe.Pointer) error {
+	return lastError(C.mpeghip_audio_synth(a.h, (*C.int32_t)(unsafe.Pointer(samples)), 1, C.int(format), out))
+}
