@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
     for (int m = 0; m < kWcMbs; m++) {
         const uint32_t idx = (uint32_t)m < ci.n ? chunk * kWcMbs + (uint32_t)m : chunk * kWcMbs;
         u[m] = load_mb(a, idx);
-        compact_phase1(a, u[m], lane, ld[m]);
+        wc_issue_pred(a, u[m], lane, ld[m]);
     }
     // dense residual stage: 8 coded blocks per pass
     const uint32_t total = ci.base[kWcMbs];
@@ -251,11 +251,29 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
         compact_phase2_rows(slot, j, tile + g * kTileStride, active, resid);
         wave_lds_handoff();
     }
-    // per macroblock: prediction + residual, clamp, store
+    // per macroblock: prediction + residual, clamp; outputs leave as whole rows when the chunk is a horizontal run
+    const bool coalesce = wc_can_coalesce(ci, u);
+    uint8_t *out_tile = coalesce ? reinterpret_cast<uint8_t *>(tile) : nullptr;
+    const int below_lane = wc_below_lane(lane);
 #pragma unroll
-    for (int m = 0; m < kWcMbs; m++)
-        if ((uint32_t)m < ci.n)
-            compact_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m], resid);
+    for (int m = 0; m < kWcMbs; m++) {
+        if ((uint32_t)m >= ci.n)
+            continue;
+        u8x16 below = ld[m].r1;
+        if (wc_needs_below(u[m])) { // wave-uniform: fetch the row below from the lane that loaded it
+            const int src = below_lane < 0 ? lane : below_lane;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t got = (uint32_t)__shfl((int)ld[m].r0.v[k], src, 64);
+                below.v[k] = below_lane < 0 ? below.v[k] : got;
+            }
+        }
+        wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m], below, resid, out_tile);
+    }
+    if (coalesce) {
+        wave_lds_handoff();
+        wc_store_tile(a, u[0], lane, out_tile);
+    }
 }
 
 // ---- split path (video_split_lane.h): K1 prediction, K2 dense residual

@@ -267,11 +267,165 @@ MPG_HD void compact_phase1(const VideoArgs &a, const MbU &u, int lane, MbLoads &
 // The same three phases run by ONE wave on a chunk of kWcMbs macroblocks, sequentially,
 // with wave-private LDS: no barrier, no coupling between waves.  All loads of the chunk
 // (coefficient columns of the first IDCT pass, prediction rows of every macroblock) are
-// issued before the first use.
+// issued before the first use.  Two L1-access savers on top (the kernel is bound by L1 line
+// accesses, profiles/r01i_pmc_summary.txt):
+//   * the row below (vertical half-pel tap) comes from the lane that already loaded it
+//     (ds_bpermute) — only the bottom row of the macroblock is loaded a second time;
+//   * when the chunk is a horizontal run of 4 macroblocks, the outputs go through LDS and
+//     leave as whole 64-byte luma / 32-byte chroma rows (32 stores of 16 bytes per chunk
+//     instead of 192 of 8 bytes).
 constexpr int kWcMbs = 4;
 constexpr int kWcMaxBlocks = 6 * kWcMbs;                   // 24
 constexpr int kWcResidBytes = kWcMaxBlocks * 128;           // 3072
-constexpr int kWcLdsBytes = kWcResidBytes + 8 * kTileStride * 4; // + one 8-block transpose tile = 5376
+constexpr int kWcTileBytes = 8 * kTileStride * 4;           // 2304: IDCT transpose tile, later the output tile
+constexpr int kWcLdsBytes = kWcResidBytes + kWcTileBytes;   // 5376
+constexpr int kWcOutBytes = 16 * 64 + 2 * 8 * 32;           // 1536 <= kWcTileBytes
 using WcInfo = ChunkInfoT<kWcMbs>;
+
+// lane that holds the row below this lane's row, or -1 if that row must be loaded
+// (bottom row of the macroblock: luma row 16, chroma row 8)
+MPG_HD int wc_below_lane(int lane)
+{
+    const int b = lane >> 3, j = lane & 7;
+    if (b >= 6)
+        return lane;
+    if (j < 7)
+        return lane + 1;
+    if (b < 2)
+        return lane + 9; // row 0 of the block underneath (b + 2)
+    return -1;
+}
+
+// phase 1: prediction loads of one macroblock (row j of block b; + the row below only where no lane has it)
+MPG_HD void wc_issue_pred(const VideoArgs &a, const MbU &u, int lane, MbLoads &ld)
+{
+    ld.r0 = u8x16{{0, 0, 0, 0}};
+    ld.r1 = u8x16{{0, 0, 0, 0}};
+    ld.c0 = i32x4{{0, 0, 0, 0}};
+    ld.c1 = i32x4{{0, 0, 0, 0}};
+    ld.qm = ld.pm = 0;
+    const int b = lane >> 3, j = lane & 7;
+    if (b >= 6 || (u.flags & MPEGHIP_MB_INTRA))
+        return;
+    int32_t mvx = u.mv_x, mvy = u.mv_y;
+    int32_t stride, off;
+    if (b < 4) {
+        stride = (int32_t)a.luma_w;
+        off = ((int32_t)(u.mb_y << 4) + j + ((b >> 1) << 3) + (mvy >> 1)) * stride + (int32_t)(u.mb_x << 4) + ((b & 1) << 3) + (mvx >> 1);
+    } else {
+        mvx /= 2; // toward zero, video_noasm.go:35-36
+        mvy /= 2;
+        stride = (int32_t)a.chroma_w;
+        off = (int32_t)(a.luma_bytes + (b == 5 ? a.chroma_bytes : 0)) + ((int32_t)(u.mb_y << 3) + j + (mvy >> 1)) * stride +
+              (int32_t)(u.mb_x << 3) + (mvx >> 1);
+    }
+    const uint8_t *src = u.ref + off;
+    ld.r0 = ld128u(src);
+    if ((mvy & 1) && wc_below_lane(lane) < 0)
+        ld.r1 = ld128u(src + stride);
+}
+
+// does any lane of this macroblock need the row below?  (wave-uniform)
+MPG_HD bool wc_needs_below(const MbU &u)
+{
+    return !(u.flags & MPEGHIP_MB_INTRA) && (((u.mv_y & 1) != 0) || (((u.mv_y / 2) & 1) != 0));
+}
+
+// phase 3 of the wave-chunk kernel.  `below` = the 16 bytes of the row under this lane's row, already
+// fetched from the owning lane (or from ld.r1 for the bottom rows).  If out_tile != nullptr the 8 output
+// bytes are parked there (layout: luma [16 rows][4 macroblocks x 16 B], Cb [8][4 x 8 B], Cr [8][4 x 8 B])
+// instead of being stored.
+template <int N>
+MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci, uint32_t m, int lane, const MbLoads &ld,
+                      const u8x16 &below, const uint8_t *resid_store, uint8_t *out_tile)
+{
+    const int b = lane >> 3, j = lane & 7;
+    if (b >= 6)
+        return;
+    const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
+    const bool coded = (u.cbp & (0x20u >> b)) != 0;
+    if (intra && !coded)
+        return; // an invalid intra block leaves the old pixels (video.go:711-714); never taken on the LDS path
+
+    uint64_t pred = 0;
+    if (!intra) { // video_noasm.go:48-80
+        int32_t mvx = u.mv_x, mvy = u.mv_y;
+        if (b >= 4) {
+            mvx /= 2;
+            mvy /= 2;
+        }
+        const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
+        const uint64_t pa = (uint64_t)ld.r0.v[0] | ((uint64_t)ld.r0.v[1] << 32);
+        if (!oh && !ov) {
+            pred = pa;
+        } else {
+            const uint64_t pc = (uint64_t)below.v[0] | ((uint64_t)below.v[1] << 32);
+            if (!oh) {
+                pred = avg2_u8x8(pa, pc);
+            } else {
+                const uint64_t pb = (uint64_t)shift_in_byte(ld.r0.v[1], ld.r0.v[0]) | ((uint64_t)shift_in_byte(ld.r0.v[2], ld.r0.v[1]) << 32);
+                if (!ov) {
+                    pred = avg2_u8x8(pa, pb);
+                } else {
+                    const uint64_t pd = (uint64_t)shift_in_byte(below.v[1], below.v[0]) | ((uint64_t)shift_in_byte(below.v[2], below.v[1]) << 32);
+                    pred = avg4_u8x8(pa, pb, pc, pd);
+                }
+            }
+        }
+    }
+    uint64_t out = pred;
+    if (coded) {
+        const uint32_t slot = chunk_base_of(ci, m) + popc6(u.cbp >> (6 - b));
+        const u32x4 row = *reinterpret_cast<const u32x4 *>(resid_store + slot * 128 + (uint32_t)j * 16);
+        const uint32_t lo = add_resid_pack4((uint32_t)pred, row.v[0], row.v[1]);
+        const uint32_t hi = add_resid_pack4((uint32_t)(pred >> 32), row.v[2], row.v[3]);
+        out = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    if (out_tile) {
+        uint32_t o;
+        if (b < 4)
+            o = ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 64 + m * 16 + ((uint32_t)(b & 1) << 3);
+        else
+            o = 1024 + (uint32_t)(b - 4) * 256 + (uint32_t)j * 32 + m * 8;
+        *reinterpret_cast<uint64_t *>(out_tile + o) = out;
+        return;
+    }
+    uint32_t off;
+    if (b < 4)
+        off = ((u.mb_y << 4) + (uint32_t)j + ((uint32_t)(b >> 1) << 3)) * a.luma_w + (u.mb_x << 4) + ((uint32_t)(b & 1) << 3);
+    else
+        off = a.luma_bytes + (b == 5 ? a.chroma_bytes : 0) + ((u.mb_y << 3) + (uint32_t)j) * a.chroma_w + (u.mb_x << 3);
+    *reinterpret_cast<uint64_t *>(u.cur + off) = out;
+}
+
+// Is the chunk a horizontal run of 4 fully written macroblocks of one picture, 64-byte aligned?  (wave-uniform)
+MPG_HD bool wc_can_coalesce(const WcInfo &ci, const MbU (&u)[kWcMbs])
+{
+    if (ci.n != (uint32_t)kWcMbs || (u[0].mb_x & 3) != 0)
+        return false;
+    bool ok = true;
+#pragma unroll
+    for (int m = 0; m < kWcMbs; m++) {
+        ok = ok && u[m].cur == u[0].cur && u[m].mb_y == u[0].mb_y && u[m].mb_x == u[0].mb_x + (uint32_t)m;
+        ok = ok && (!(u[m].flags & MPEGHIP_MB_INTRA) || u[m].cbp == 0x3f);
+    }
+    return ok;
+}
+
+// Cooperative store of the chunk's output tile: luma 16 rows x 64 B by all 64 lanes, chroma 2 x 8 rows x 32 B by lanes 0-31.
+MPG_HD void wc_store_tile(const VideoArgs &a, const MbU &u0, int lane, const uint8_t *out_tile)
+{
+    {
+        const uint32_t row = (uint32_t)lane >> 2, seg = (uint32_t)lane & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(out_tile + row * 64 + seg * 16);
+        *reinterpret_cast<u32x4 *>(u0.cur + ((u0.mb_y << 4) + row) * a.luma_w + (u0.mb_x << 4) + seg * 16) = v;
+    }
+    if (lane < 32) {
+        const uint32_t plane = (uint32_t)lane >> 4, row = ((uint32_t)lane >> 1) & 7, seg = (uint32_t)lane & 1;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(out_tile + 1024 + plane * 256 + row * 32 + seg * 16);
+        *reinterpret_cast<u32x4 *>(u0.cur + a.luma_bytes + plane * a.chroma_bytes + ((u0.mb_y << 3) + row) * a.chroma_w +
+                                   (u0.mb_x << 3) + seg * 16) = v;
+    }
+}
 
 } // namespace mpg

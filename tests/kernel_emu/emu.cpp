@@ -284,7 +284,7 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
             const uint32_t idx = (uint32_t)m < ci.n ? chunk * kWcMbs + (uint32_t)m : chunk * kWcMbs;
             u[m] = load_mb(a, idx);
             for (int lane = 0; lane < 64; lane++)
-                compact_phase1(a, u[m], lane, ld[m][lane]);
+                wc_issue_pred(a, u[m], lane, ld[m][lane]);
         }
         for (uint32_t s0 = 0; s0 < ci.base[kWcMbs]; s0 += 8) {
             bool active[64];
@@ -293,10 +293,25 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
             for (int lane = 0; lane < 64; lane++)
                 compact_phase2_rows(s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kTileStride, active[lane], resid);
         }
-        for (int m = 0; m < kWcMbs; m++)
-            if ((uint32_t)m < ci.n)
-                for (int lane = 0; lane < 64; lane++)
-                    compact_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], resid);
+        const bool coalesce = wc_can_coalesce(ci, u);
+        uint8_t *out_tile = coalesce ? reinterpret_cast<uint8_t *>(tile) : nullptr;
+        if (coalesce)
+            memset(tile, 0xEE, kWcTileBytes);
+        for (int m = 0; m < kWcMbs; m++) {
+            if ((uint32_t)m >= ci.n)
+                continue;
+            for (int lane = 0; lane < 64; lane++) {
+                u8x16 below = ld[m][lane].r1;
+                const int bl = wc_below_lane(lane);
+                if (wc_needs_below(u[m]) && bl >= 0) // the kernel's __shfl from the owning lane
+                    for (int k = 0; k < 3; k++)
+                        below.v[k] = ld[m][bl].r0.v[k];
+                wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile);
+            }
+        }
+        if (coalesce)
+            for (int lane = 0; lane < 64; lane++)
+                wc_store_tile(a, u[0], lane, out_tile);
     }
     for (uint32_t p = 0; p < n_pics; p++) {
         if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
