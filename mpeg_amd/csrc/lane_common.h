@@ -176,6 +176,18 @@ MPG_HD uint32_t shift_in_byte(uint32_t hi, uint32_t lo)
 #endif
 }
 
+// Pin a wave-uniform value to a scalar register.  Besides documenting uniformity this stops
+// the optimiser from folding scalar arithmetic back into per-lane selects (which turned
+// s_mul_i32 into quarter-rate v_mul_lo_u32 in the address computation).
+MPG_HD int32_t uniform(int32_t x)
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_readfirstlane(x);
+#else
+    return x;
+#endif
+}
+
 // true if `pred` is false for every lane of the wavefront (wave-uniform branch key)
 MPG_HD bool none_in_wave(bool pred)
 {

@@ -255,16 +255,16 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
     const bool coalesce = wc_can_coalesce(ci, u);
     uint8_t *out_tile = coalesce ? reinterpret_cast<uint8_t *>(tile) : nullptr;
     const int below_lane = wc_below_lane(lane);
+    const int below_addr = (below_lane < 0 ? lane : below_lane) << 2; // ds_bpermute byte address of the source lane
 #pragma unroll
     for (int m = 0; m < kWcMbs; m++) {
         if ((uint32_t)m >= ci.n)
             continue;
         u8x16 below = ld[m].r1;
         if (wc_needs_below(u[m])) { // wave-uniform: fetch the row below from the lane that loaded it
-            const int src = below_lane < 0 ? lane : below_lane;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const uint32_t got = (uint32_t)__shfl((int)ld[m].r0.v[k], src, 64);
+                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(below_addr, (int)ld[m].r0.v[k]);
                 below.v[k] = below_lane < 0 ? below.v[k] : got;
             }
         }

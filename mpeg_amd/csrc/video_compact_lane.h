@@ -296,6 +296,38 @@ MPG_HD int wc_below_lane(int lane)
     return -1;
 }
 
+// Byte offset of this lane's row inside a frame, for macroblock (0, 0) and vector (0, 0): depends on the lane
+// only, so it is computed once per wave and the per-macroblock part stays on the scalar unit.
+MPG_HD int32_t wc_lane_row_offset(const VideoArgs &a, int lane)
+{
+    const int b = lane >> 3, j = lane & 7;
+    if (b < 4)
+        return (j + ((b >> 1) << 3)) * (int32_t)a.luma_w + ((b & 1) << 3);
+    return (int32_t)(a.luma_bytes + (b == 5 ? a.chroma_bytes : 0)) + j * (int32_t)a.chroma_w;
+}
+
+// Wave-uniform part of the source offset of macroblock u: luma and chroma variants (scalar arithmetic).
+struct WcPredScalars {
+    int32_t src_luma, src_chroma;   // frame offset of the block origin + integer part of the vector
+    int32_t dst_luma, dst_chroma;   // frame offset of the block origin
+    bool oh_luma, ov_luma, oh_chroma, ov_chroma;
+};
+
+MPG_HD WcPredScalars wc_pred_scalars(const VideoArgs &a, const MbU &u)
+{
+    WcPredScalars p;
+    const int32_t cmx = u.mv_x / 2, cmy = u.mv_y / 2; // toward zero, video_noasm.go:35-36
+    p.dst_luma = uniform((int32_t)(u.mb_y << 4) * (int32_t)a.luma_w + (int32_t)(u.mb_x << 4));
+    p.dst_chroma = uniform((int32_t)(u.mb_y << 3) * (int32_t)a.chroma_w + (int32_t)(u.mb_x << 3));
+    p.src_luma = uniform(p.dst_luma + (u.mv_y >> 1) * (int32_t)a.luma_w + (u.mv_x >> 1));
+    p.src_chroma = uniform(p.dst_chroma + (cmy >> 1) * (int32_t)a.chroma_w + (cmx >> 1));
+    p.oh_luma = (u.mv_x & 1) != 0;
+    p.ov_luma = (u.mv_y & 1) != 0;
+    p.oh_chroma = (cmx & 1) != 0;
+    p.ov_chroma = (cmy & 1) != 0;
+    return p;
+}
+
 // phase 1: prediction loads of one macroblock (row j of block b; + the row below only where no lane has it)
 MPG_HD void wc_issue_pred(const VideoArgs &a, const MbU &u, int lane, MbLoads &ld)
 {
@@ -304,24 +336,16 @@ MPG_HD void wc_issue_pred(const VideoArgs &a, const MbU &u, int lane, MbLoads &l
     ld.c0 = i32x4{{0, 0, 0, 0}};
     ld.c1 = i32x4{{0, 0, 0, 0}};
     ld.qm = ld.pm = 0;
-    const int b = lane >> 3, j = lane & 7;
+    const int b = lane >> 3;
     if (b >= 6 || (u.flags & MPEGHIP_MB_INTRA))
         return;
-    int32_t mvx = u.mv_x, mvy = u.mv_y;
-    int32_t stride, off;
-    if (b < 4) {
-        stride = (int32_t)a.luma_w;
-        off = ((int32_t)(u.mb_y << 4) + j + ((b >> 1) << 3) + (mvy >> 1)) * stride + (int32_t)(u.mb_x << 4) + ((b & 1) << 3) + (mvx >> 1);
-    } else {
-        mvx /= 2; // toward zero, video_noasm.go:35-36
-        mvy /= 2;
-        stride = (int32_t)a.chroma_w;
-        off = (int32_t)(a.luma_bytes + (b == 5 ? a.chroma_bytes : 0)) + ((int32_t)(u.mb_y << 3) + j + (mvy >> 1)) * stride +
-              (int32_t)(u.mb_x << 3) + (mvx >> 1);
-    }
+    const WcPredScalars p = wc_pred_scalars(a, u);
+    const bool luma = b < 4;
+    const int32_t off = wc_lane_row_offset(a, lane) + (luma ? p.src_luma : p.src_chroma);
+    const int32_t stride = luma ? (int32_t)a.luma_w : (int32_t)a.chroma_w;
     const uint8_t *src = u.ref + off;
     ld.r0 = ld128u(src);
-    if ((mvy & 1) && wc_below_lane(lane) < 0)
+    if ((luma ? p.ov_luma : p.ov_chroma) && wc_below_lane(lane) < 0)
         ld.r1 = ld128u(src + stride);
 }
 
@@ -347,14 +371,11 @@ MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci,
     if (intra && !coded)
         return; // an invalid intra block leaves the old pixels (video.go:711-714); never taken on the LDS path
 
+    const WcPredScalars ps = wc_pred_scalars(a, u);
+    const bool luma = b < 4;
     uint64_t pred = 0;
     if (!intra) { // video_noasm.go:48-80
-        int32_t mvx = u.mv_x, mvy = u.mv_y;
-        if (b >= 4) {
-            mvx /= 2;
-            mvy /= 2;
-        }
-        const bool oh = (mvx & 1) != 0, ov = (mvy & 1) != 0;
+        const bool oh = luma ? ps.oh_luma : ps.oh_chroma, ov = luma ? ps.ov_luma : ps.ov_chroma;
         const uint64_t pa = (uint64_t)ld.r0.v[0] | ((uint64_t)ld.r0.v[1] << 32);
         if (!oh && !ov) {
             pred = pa;
@@ -390,11 +411,7 @@ MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci,
         *reinterpret_cast<uint64_t *>(out_tile + o) = out;
         return;
     }
-    uint32_t off;
-    if (b < 4)
-        off = ((u.mb_y << 4) + (uint32_t)j + ((uint32_t)(b >> 1) << 3)) * a.luma_w + (u.mb_x << 4) + ((uint32_t)(b & 1) << 3);
-    else
-        off = a.luma_bytes + (b == 5 ? a.chroma_bytes : 0) + ((u.mb_y << 3) + (uint32_t)j) * a.chroma_w + (u.mb_x << 3);
+    const int32_t off = wc_lane_row_offset(a, lane) + (luma ? ps.dst_luma : ps.dst_chroma);
     *reinterpret_cast<uint64_t *>(u.cur + off) = out;
 }
 
