@@ -17,6 +17,13 @@
 //            1024-entry ring only ever holds the last 16 slots).
 //   phase W: 1152 (sub-block, sample) pairs over 384 threads, 3 each, both
 //            channels per thread: 16 taps per channel from LDS, scale, store L/R.
+//
+// Time slicing: a sub-block depends on the previous 15 only through the V history, and
+// every history slot is a pure function of one sub-block's samples.  So the frames of one
+// launch are split into n_chunks slices per stream, one workgroup each; a slice that does not
+// start at frame 0 rebuilds its 15-slot history by re-running the 15 DCTs in front of it
+// (bit-identical, 15/36 of a frame of extra DCT work per slice).  That is what fills the GPU
+// when there are fewer streams than ~8 per CU (BASELINE config 4 has 256 streams).
 #pragma once
 
 #include "lane_common.h"
@@ -27,8 +34,11 @@ namespace mpg {
 struct AudioArgs {
     const int32_t *samples; // [n_streams][n_frames][2][36][32]
     void *out;              // [n_streams][n_frames][2304] of the format's type
-    float *ring;            // [n_streams][2][1024]  (Audio.v)
-    int32_t *vpos;          // [n_streams]           (Audio.vPos)
+    const float *ring;      // [n_streams][2][1024]  (Audio.v) state before this launch
+    const int32_t *vpos;    // [n_streams]           (Audio.vPos)
+    float *ring_out;        // state after this launch (a different buffer: several workgroups of one
+    int32_t *vpos_out;      // stream read the old state while the last one writes the new one)
+    uint32_t n_chunks;      // the launch's frames are split into this many time slices per stream
     const float *window;    // [512]                 (synthesisWindow, audio.go:812-899)
     uint32_t n_streams, n_frames;
     int32_t format, fma;
@@ -152,6 +162,32 @@ MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0,
         lds[kHistFloats + idx] = a.window[idx];
 }
 
+// ---- history rebuild for a slice that starts at frame f0 > 0: the 15 sub-blocks before it
+MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t f0, int tid, float *lds)
+{
+    if (tid >= 30)
+        return;
+    const int ch = tid / 15, t = 21 + tid % 15;
+    const uint32_t f = f0 - 1;
+    const int32_t T = kT0 + (int32_t)f * 36 + t;
+    const int32_t *s = a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + (uint32_t)t * 32;
+    matrixing(s, lds + (ch * kHistSlots + (T & (kHistSlots - 1))) * kHistStride);
+}
+
+MPG_HD void audio_load_window(const AudioArgs &a, int tid, float *lds)
+{
+    for (int idx = tid; idx < 512; idx += kAudioThreads)
+        lds[kHistFloats + idx] = a.window[idx];
+}
+
+// frames [f0, f1) of time slice `chunk`
+MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, uint32_t &f1)
+{
+    const uint32_t per = (a.n_frames + a.n_chunks - 1) / a.n_chunks;
+    f0 = chunk * per < a.n_frames ? chunk * per : a.n_frames;
+    f1 = f0 + per < a.n_frames ? f0 + per : a.n_frames;
+}
+
 // ---- phase D: thread `tid` < 72 transforms (ch, t) of frame f
 MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t f, int tid, float *lds)
 {
@@ -235,9 +271,9 @@ MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos
 // ---- state out: last 16 history slots -> Audio.v ring; thread 0 advances vPos
 MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, const float *lds)
 {
+    float *ring = a.ring_out + (uint64_t)stream * 2048;
     const int32_t Tend = kT0 + (int32_t)a.n_frames * 36; // first time NOT produced
     const int32_t vpos1 = vpos_at(vpos0, Tend - 1);
-    float *ring = a.ring + (uint64_t)stream * 2048;
     for (int idx = tid; idx < 2048; idx += kAudioThreads) {
         const int ch = idx >> 10, ra = idx & 1023;
         const int e = (ra - vpos1) & 1023;
@@ -249,7 +285,7 @@ MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0
 MPG_HD void audio_store_vpos(const AudioArgs &a, uint32_t stream, int32_t vpos0)
 {
     const int32_t Tend = kT0 + (int32_t)a.n_frames * 36;
-    a.vpos[stream] = vpos_at(vpos0, Tend - 1);
+    a.vpos_out[stream] = vpos_at(vpos0, Tend - 1);
 }
 
 } // namespace mpg

@@ -386,21 +386,31 @@ __global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32
 __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kAudioLdsFloats];
-    const uint32_t stream = blockIdx.x;
+    const uint32_t stream = blockIdx.x / a.n_chunks, chunk = blockIdx.x % a.n_chunks;
     const int tid = threadIdx.x;
+    uint32_t f0, f1;
+    audio_chunk_range(a, chunk, f0, f1);
+    if (f0 >= f1)
+        return; // empty slice (wave-uniform, before any barrier)
     const int32_t vpos0 = a.vpos[stream];
-    audio_load_state(a, stream, vpos0, tid, lds);
+    if (f0 == 0) {
+        audio_load_state(a, stream, vpos0, tid, lds);
+    } else {
+        audio_load_window(a, tid, lds);
+        audio_phase_warmup(a, stream, f0, tid, lds);
+    }
     __syncthreads();
-    for (uint32_t f = 0; f < a.n_frames; f++) {
+    for (uint32_t f = f0; f < f1; f++) {
         audio_phase_dct(a, stream, f, tid, lds);
         __syncthreads();
         audio_phase_window(a, stream, vpos0, f, tid, lds);
         __syncthreads();
     }
-    audio_store_state(a, stream, vpos0, tid, lds);
-    __syncthreads();
-    if (tid == 0)
-        audio_store_vpos(a, stream, vpos0);
+    if (f1 == a.n_frames) { // the slice that ends the launch owns the state hand-over
+        audio_store_state(a, stream, vpos0, tid, lds);
+        if (tid == 0)
+            audio_store_vpos(a, stream, vpos0);
+    }
 }
 
 // ================================================================ host side
@@ -460,8 +470,8 @@ struct mpeghip_audio {
     mpeghip_ctx *ctx = nullptr;
     uint32_t n_streams = 0;
     int fma = 0;
-    float *d_ring = nullptr;
-    int32_t *d_vpos = nullptr;
+    float *d_ring = nullptr, *d_ring_alt = nullptr;   // state before / after a launch (swapped each launch)
+    int32_t *d_vpos = nullptr, *d_vpos_alt = nullptr;
     float *d_window = nullptr;
     int32_t *d_samples = nullptr;
     void *d_out = nullptr;
@@ -1277,6 +1287,8 @@ int mpeghip_audio_open(mpeghip_ctx *c, uint32_t n_streams, int fma_mode, mpeghip
         win[i] = (float)mpg_synth_window_x2[i] * 0.5f; // exact: entries are multiples of 0.5
     if (hipMalloc((void **)&a->d_ring, (size_t)n_streams * 2048 * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&a->d_vpos, (size_t)n_streams * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void **)&a->d_ring_alt, (size_t)n_streams * 2048 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&a->d_vpos_alt, (size_t)n_streams * sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void **)&a->d_window, sizeof(win)) != hipSuccess ||
         hipMemset(a->d_ring, 0, (size_t)n_streams * 2048 * sizeof(float)) != hipSuccess ||
         hipMemset(a->d_vpos, 0, (size_t)n_streams * sizeof(int32_t)) != hipSuccess ||
@@ -1294,7 +1306,7 @@ void mpeghip_audio_close(mpeghip_audio *a)
         return;
     (void)hipSetDevice(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->stream);
-    void *ps[] = {a->d_ring, a->d_vpos, a->d_window, a->d_samples, a->d_out};
+    void *ps[] = {a->d_ring, a->d_vpos, a->d_ring_alt, a->d_vpos_alt, a->d_window, a->d_samples, a->d_out};
     for (void *p : ps)
         if (p)
             (void)hipFree(p);
@@ -1352,13 +1364,40 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     args.out = d_out;
     args.ring = a->d_ring;
     args.vpos = a->d_vpos;
+    args.ring_out = a->d_ring_alt;
+    args.vpos_out = a->d_vpos_alt;
     args.window = a->d_window;
     args.n_streams = a->n_streams;
     args.n_frames = n_frames;
     args.format = format;
     args.fma = a->fma;
-    hipLaunchKernelGGL(audio_kernel, dim3(a->n_streams), dim3(kAudioThreads), 0, a->ctx->stream, args);
+    // time slices per stream: enough workgroups to fill the GPU (~8 per CU), at least 4 frames per slice
+    uint32_t chunks = 1;
+    if (const char *e = getenv("MPEGHIP_AUDIO_CHUNKS")) { // development knob
+        chunks = (uint32_t)atoi(e);
+    } else {
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, a->ctx->device);
+        const uint32_t want = ((uint32_t)n_cu * 8 + a->n_streams - 1) / a->n_streams;
+        chunks = want < 1 ? 1 : want;
+        if (chunks > n_frames / 4)
+            chunks = n_frames / 4;
+    }
+    if (chunks < 1)
+        chunks = 1;
+    if (chunks > n_frames)
+        chunks = n_frames;
+    args.n_chunks = chunks;
+    hipLaunchKernelGGL(audio_kernel, dim3(a->n_streams * chunks), dim3(kAudioThreads), 0, a->ctx->stream, args);
     HIP_TRY(hipGetLastError());
+    { // the launch wrote the new state into the alternate buffers
+        float *r = a->d_ring;
+        a->d_ring = a->d_ring_alt;
+        a->d_ring_alt = r;
+        int32_t *v = a->d_vpos;
+        a->d_vpos = a->d_vpos_alt;
+        a->d_vpos_alt = v;
+    }
     return MPEGHIP_OK;
 }
 

@@ -16,7 +16,7 @@ int emu_video_run_wc(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t
 int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *,
                   const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, uint64_t, int);
 void emu_rgba_convert(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
-int emu_audio_run(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t);
+int emu_audio_run(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t, uint32_t);
 }
 
 namespace {
@@ -88,7 +88,7 @@ public:
     }
     void synth(const int32_t *samples, int format, void *out) override
     {
-        emu_audio_run(samples, out, &ring_[0][0], &vpos_, window_, 1, 1, format, fma_);
+        emu_audio_run(samples, out, &ring_[0][0], &vpos_, window_, 1, 1, format, fma_, 1);
     }
 
 private:

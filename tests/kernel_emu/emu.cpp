@@ -335,37 +335,60 @@ void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, ui
             rgba_convert_quad(frame, luma_w, luma_w / 2, luma_w * luma_h, luma_w * luma_h / 4, width, height, x4, y, rgba);
 }
 
-// audio_kernel: one workgroup per stream.
+// audio_kernel: n_chunks workgroups (time slices) per stream; ring / vpos are updated in place for the
+// caller (the kernel writes them to the alternate buffers, emulated with a copy).
 int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos, const float *window,
-                  uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma)
+                  uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks)
 {
+    if (n_frames == 0)
+        return 0;
+    std::vector<float> ring_out((size_t)n_streams * 2048);
+    std::vector<int32_t> vpos_out(n_streams);
     AudioArgs a;
     a.samples = samples;
     a.out = out;
     a.ring = ring;
     a.vpos = vpos;
+    a.ring_out = ring_out.data();
+    a.vpos_out = vpos_out.data();
     a.window = window;
     a.n_streams = n_streams;
     a.n_frames = n_frames;
     a.format = format;
     a.fma = fma;
+    a.n_chunks = n_chunks < 1 ? 1 : (n_chunks > n_frames ? n_frames : n_chunks);
     std::vector<float> lds(kAudioLdsFloats);
-    for (uint32_t stream = 0; stream < n_streams; stream++) {
+    for (uint32_t blk = 0; blk < n_streams * a.n_chunks; blk++) {
+        const uint32_t stream = blk / a.n_chunks, chunk = blk % a.n_chunks;
+        uint32_t f0, f1;
+        audio_chunk_range(a, chunk, f0, f1);
+        if (f0 >= f1)
+            continue;
         for (auto &x : lds)
             x = 1e30f; // poison
         const int32_t vpos0 = a.vpos[stream];
-        for (int tid = 0; tid < kAudioThreads; tid++)
-            audio_load_state(a, stream, vpos0, tid, lds.data());
-        for (uint32_t f = 0; f < n_frames; f++) {
+        for (int tid = 0; tid < kAudioThreads; tid++) {
+            if (f0 == 0) {
+                audio_load_state(a, stream, vpos0, tid, lds.data());
+            } else {
+                audio_load_window(a, tid, lds.data());
+                audio_phase_warmup(a, stream, f0, tid, lds.data());
+            }
+        }
+        for (uint32_t f = f0; f < f1; f++) {
             for (int tid = 0; tid < kAudioThreads; tid++)
                 audio_phase_dct(a, stream, f, tid, lds.data());
             for (int tid = 0; tid < kAudioThreads; tid++)
                 audio_phase_window(a, stream, vpos0, f, tid, lds.data());
         }
-        for (int tid = 0; tid < kAudioThreads; tid++)
-            audio_store_state(a, stream, vpos0, tid, lds.data());
-        audio_store_vpos(a, stream, vpos0);
+        if (f1 == a.n_frames) {
+            for (int tid = 0; tid < kAudioThreads; tid++)
+                audio_store_state(a, stream, vpos0, tid, lds.data());
+            audio_store_vpos(a, stream, vpos0);
+        }
     }
+    memcpy(ring, ring_out.data(), ring_out.size() * sizeof(float));
+    memcpy(vpos, vpos_out.data(), vpos_out.size() * sizeof(int32_t));
     return 0;
 }
 

@@ -59,6 +59,19 @@ def test_config4_256_streams(oracle, hip_ctx):
     dut.close()
 
 
+@pytest.mark.parametrize("chunks", ["1", "3", "16"])
+def test_time_slicing_is_bit_identical(oracle, hip_ctx, chunks, monkeypatch):
+    """The launch is split along time (MPEGHIP_AUDIO_CHUNKS slices per stream, history rebuilt from the samples)."""
+    monkeypatch.setenv("MPEGHIP_AUDIO_CHUNKS", chunks)
+    s = synth.audio_frames(5, 33)
+    ref, dut = oracle.OracleSynth(5, 0), abi.AudioSynth(hip_ctx, 5, 0)
+    for _ in range(2):
+        assert bits_equal(ref.synth(s), dut.synth(s))
+        (va, pa), (vb, pb) = ref.get_state(4), dut.get_state(4)
+        assert pa == pb and bits_equal(va, vb)
+    dut.close()
+
+
 def test_zero_frames_and_rewind_semantics(hip_ctx):
     dut = abi.AudioSynth(hip_ctx, 1)
     v = np.arange(2048, dtype=np.float32).reshape(2, 1024)

@@ -82,6 +82,18 @@ def test_audio_lane_logic_matches_oracle(oracle, emu, fma, fmt):
             assert pa == pb and bits_equal(va, vb)
 
 
+@pytest.mark.parametrize("chunks", [2, 3, 7])
+def test_audio_time_slices_are_bit_identical(oracle, emu, chunks):
+    """Splitting a launch along time (history rebuilt from the samples) must not change a single bit."""
+    s = synth.audio_frames(2, 9)
+    o, e = oracle.OracleSynth(2, 0), emu.EmuSynth(2, 0, chunks=chunks)
+    for _ in range(2):
+        assert bits_equal(o.synth(s, desc.AUDIO_F32N), e.synth(s, desc.AUDIO_F32N))
+        for st in range(2):
+            (va, pa), (vb, pb) = o.get_state(st), e.get_state(st)
+            assert pa == pb and bits_equal(va, vb)
+
+
 @pytest.mark.parametrize("fma,want", [(0, 0xf1b76cdf8e6cdea5), (1, 0x50f3ab75f5fb0fb5)])
 def test_audio_lane_logic_reproduces_golden_hash(oracle, emu, golden_dir, fma, want):
     """Real sub-band samples of test.mp2 (parsed by the oracle) through the kernel's lane functions."""
