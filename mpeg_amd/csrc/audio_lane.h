@@ -10,13 +10,17 @@
 // MPEGHIP_AUDIO_FMA_WINDOW mode, taps are accumulated in the reference's ring
 // order (which depends on vPos), the output is a true IEEE division.
 //
-// Data flow per frame (36 sub-blocks x 2 channels):
-//   phase D: 72 threads run one 32-point DCT each, entirely in registers, and
-//            write the 64 mirrored outputs into a time-indexed V history in LDS
-//            (64 slots of 64 floats per channel, padded to 65: the reference's
-//            1024-entry ring only ever holds the last 16 slots).
-//   phase W: 1152 (sub-block, sample) pairs over 384 threads, 3 each, both
-//            channels per thread: 16 taps per channel from LDS, scale, store L/R.
+// Data flow per super-step of 32 sub-blocks (both channels; 4 waves per workgroup):
+//   phase D: wave 0 runs 64 32-point DCTs, one per lane (channel x 32 sub-blocks), entirely in
+//            registers, and writes the 64 mirrored outputs of each into a time-indexed V history in
+//            LDS: a ring of 64 slots, slot = [half][channel][32] (+1 pad).  The reference's
+//            1024-entry ring only ever holds the last 16 slots.
+//   phase W: a wave owns ONE sub-block at a time, lane = channel*32 + sample.  Which history slots
+//            and window segments the 16 taps read, and in which order, depends only on the ring
+//            position at that sub-block (16 cases), which is wave-uniform: the wave branches once
+//            to a fully unrolled variant whose LDS reads are "per-lane base + immediate".  To keep
+//            the offsets immediate across the ring wrap, the first 15 slots are mirrored behind the
+//            ring (slots 64..78), so "the 16 slots ending at T" are always contiguous.
 //
 // Time slicing: a sub-block depends on the previous 15 only through the V history, and
 // every history slot is a pure function of one sub-block's samples.  So the frames of one
@@ -44,12 +48,19 @@ struct AudioArgs {
     int32_t format, fma;
 };
 
-constexpr int kAudioThreads = 384;
-constexpr int kHistSlots = 64;
-constexpr int kHistStride = 65;                       // floats per slot (64 + 1 pad)
-constexpr int kHistFloats = 2 * kHistSlots * kHistStride;
-constexpr int kAudioLdsFloats = kHistFloats + 512;    // + window table
-constexpr int kT0 = 16;                               // local time of the first new sub-block
+constexpr int kAudioWaves = 4;
+constexpr int kAudioThreads = 64 * kAudioWaves;
+constexpr int kStep = 32;                             // sub-blocks per super-step: 64 DCTs = one full wave
+constexpr int kRingSlots = 64;
+constexpr int kMirrorSlots = 15;                      // ring slots 0..14 are repeated at 64..78
+constexpr int kSlotStride = 129;                      // floats per slot: [half 2][channel 2][32] + 1 pad
+constexpr int kHistFloats = (kRingSlots + kMirrorSlots) * kSlotStride;
+constexpr int kWinFloats = 1024;                      // window as [segment 16][channel 2][32]
+constexpr int kAudioLdsFloats = kHistFloats + kWinFloats;
+constexpr int kT0 = 16;                               // local time of the launch's first sub-block
+
+// position of V entry x (0..63) inside a history slot, before the channel offset
+MPG_HD constexpr int hx(int x) { return (x >> 5) * 64 + (x & 31); }
 
 // c_N[i] = 0.5 / cos((2i+1)*pi/(2N)); identical float32 values to the decimal
 // literals of audio.go:498-661.
@@ -98,9 +109,29 @@ struct Dct<1> {
     static MPG_HDM void run(float (&)[1]) {}
 };
 
-// idct36 for one (channel, sub-block): s = 32 sub-band samples, v = the 64-float
-// history slot that receives d[dp+0 .. dp+63] (audio.go:708-771).
-MPG_HD void matrixing(const int32_t *s, float *v)
+// scatter with the mirror / sign pattern of audio.go:708-771: X[2k] = e[k], X[2k+1] = o[k]
+MPG_HD void scatter(const float (&e)[16], const float (&o)[16], float *v)
+{
+#pragma unroll
+    for (int k = 0; k <= 31; k++) {
+        const float X = (k & 1) ? o[k >> 1] : e[k >> 1];
+        if (k <= 16)
+            v[hx(48 - k)] = -X;
+        if (k >= 1 && k <= 15)
+            v[hx(48 + k)] = -X;
+        if (k >= 17) {
+            v[hx(48 - k)] = -X;
+            v[hx(k - 16)] = X;
+        }
+        if (k == 16)
+            v[hx(0)] = X;
+    }
+    v[hx(16)] = 0.0f;
+}
+
+// idct36 for one (channel, sub-block): s = 32 sub-band samples, v = the history slot (at this
+// channel's offset) that receives d[dp+0 .. dp+63]; v2 = its mirror or nullptr.
+MPG_HD void matrixing(const int32_t *s, float *v, float *v2)
 {
     float e[16], o[16];
     int32_t in[32];
@@ -122,44 +153,50 @@ MPG_HD void matrixing(const int32_t *s, float *v)
 #pragma unroll
     for (int k = 0; k < 15; k++)
         o[k] += o[k + 1];
-    // X[2k] = e[k], X[2k+1] = o[k]; scatter with the mirror / sign pattern
-#pragma unroll
-    for (int k = 0; k <= 31; k++) {
-        const float X = (k & 1) ? o[k >> 1] : e[k >> 1];
-        if (k <= 16)
-            v[48 - k] = -X;
-        if (k >= 1 && k <= 15)
-            v[48 + k] = -X;
-        if (k >= 17) {
-            v[48 - k] = -X;
-            v[k - 16] = X;
-        }
-        if (k == 16)
-            v[0] = X;
-    }
-    v[16] = 0.0f;
+    scatter(e, o, v);
+    if (v2)
+        scatter(e, o, v2);
 }
 
-MPG_HD float tap(float acc, float d, float v, bool fma)
+template <bool kFma> MPG_HD float tap(float acc, float d, float v)
 {
-    return fma ? __builtin_fmaf(d, v, acc) : acc + d * v;
+    return kFma ? __builtin_fmaf(d, v, acc) : acc + d * v;
 }
 
-// ring position of the slot written at local time T
+// ring position of the slot written at local time T (Audio.vPos after that sub-block, audio.go:383)
 MPG_HD int32_t vpos_at(int32_t vpos0, int32_t T) { return (vpos0 - 64 * (T - kT0 + 1)) & 1023; }
 
-// ---- state in: Audio.v ring -> time-indexed history; window table -> LDS
+MPG_HD int hist_index(int32_t T, int ch, int x) { return (T & (kRingSlots - 1)) * kSlotStride + ch * 32 + hx(x); }
+
+// window table -> LDS, repeated per channel so that a tap's address is segment*64 + lane
+MPG_HD void audio_load_window(const AudioArgs &a, int tid, float *lds)
+{
+    for (int idx = tid; idx < kWinFloats; idx += kAudioThreads)
+        lds[kHistFloats + idx] = a.window[(idx >> 6) * 32 + (idx & 31)];
+}
+
+// ---- state in: Audio.v ring -> time-indexed history
 MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, float *lds)
 {
     const float *ring = a.ring + (uint64_t)stream * 2048;
     for (int idx = tid; idx < 2048; idx += kAudioThreads) {
         const int ch = idx >> 10, ra = idx & 1023;
         const int e = (ra - vpos0) & 1023;           // slot vpos0 holds the newest block (time T0-1)
-        const int T = kT0 - 1 - (e >> 6);
-        lds[(ch * kHistSlots + (T & (kHistSlots - 1))) * kHistStride + (e & 63)] = ring[idx];
+        const int T = kT0 - 1 - (e >> 6);            // 0..15: no mirror needed, the first reader has T >= 16
+        lds[hist_index(T, ch, e & 63)] = ring[idx];
     }
-    for (int idx = tid; idx < 512; idx += kAudioThreads)
-        lds[kHistFloats + idx] = a.window[idx];
+    audio_load_window(a, tid, lds);
+}
+
+// one DCT: sub-block tg (counted from the launch's first) of channel ch -> its history slot (+ mirror)
+MPG_HD void hist_matrixing(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, float *lds)
+{
+    const uint32_t f = tg / 36, t = tg % 36;
+    const int32_t T = kT0 + (int32_t)tg;
+    const int32_t slot = T & (kRingSlots - 1);
+    const int32_t *s = a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + t * 32;
+    float *v = lds + slot * kSlotStride + ch * 32;
+    matrixing(s, v, slot < kMirrorSlots ? v + kRingSlots * kSlotStride : nullptr);
 }
 
 // ---- history rebuild for a slice that starts at frame f0 > 0: the 15 sub-blocks before it
@@ -167,17 +204,7 @@ MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t f0,
 {
     if (tid >= 30)
         return;
-    const int ch = tid / 15, t = 21 + tid % 15;
-    const uint32_t f = f0 - 1;
-    const int32_t T = kT0 + (int32_t)f * 36 + t;
-    const int32_t *s = a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + (uint32_t)t * 32;
-    matrixing(s, lds + (ch * kHistSlots + (T & (kHistSlots - 1))) * kHistStride);
-}
-
-MPG_HD void audio_load_window(const AudioArgs &a, int tid, float *lds)
-{
-    for (int idx = tid; idx < 512; idx += kAudioThreads)
-        lds[kHistFloats + idx] = a.window[idx];
+    hist_matrixing(a, stream, f0 * 36 - 15 + (uint32_t)(tid % 15), tid / 15, lds);
 }
 
 // frames [f0, f1) of time slice `chunk`
@@ -188,82 +215,96 @@ MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, 
     f1 = f0 + per < a.n_frames ? f0 + per : a.n_frames;
 }
 
-// ---- phase D: thread `tid` < 72 transforms (ch, t) of frame f
-MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t f, int tid, float *lds)
+// ---- phase D: lane (channel, j) of wave 0 transforms sub-block base + j
+MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t base, uint32_t tg1, int tid, float *lds)
 {
-    if (tid >= 72)
+    if (tid >= 64)
         return;
-    const int ch = tid / 36, t = tid % 36;
-    const int32_t T = kT0 + (int32_t)f * 36 + t;
-    const int32_t *s = a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + (uint32_t)t * 32;
-    matrixing(s, lds + (ch * kHistSlots + (T & (kHistSlots - 1))) * kHistStride);
+    const uint32_t tg = base + (uint32_t)(tid & 31);
+    if (tg < tg1)
+        hist_matrixing(a, stream, tg, tid >> 5, lds);
 }
 
-// ---- phase W: thread handles pairs p = tid + 384*n (n = 0..2): t = p>>5, i = p&31
-MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t f, int tid, const float *lds)
+// The 16 taps of one output sample when the ring position is 64*M (audio_noasm.go:8-38).
+// vb = &history[(top - 15) * kSlotStride + lane] where `top` is the (possibly mirrored) slot of
+// this sub-block; db = &window_lds[lane].  Everything else folds to immediates.
+template <int M, bool kFma> MPG_HD float window_taps(const float *vb, const float *db)
 {
-    const float *dtab = lds + kHistFloats;
-    const bool fma = a.fma != 0;
-    for (int n = 0; n < 3; n++) {
-        const int p = tid + kAudioThreads * n;
-        const int t = p >> 5, i = p & 31;
-        const int32_t T = kT0 + (int32_t)f * 36 + t;
-        const int32_t pos = vpos_at(vpos0, T);
-        const int32_t v0 = (pos & 127) >> 1;
-        const int32_t d0 = 512 - (pos >> 1);
-        float accL = 0.0f, accR = 0.0f;
-        // audio_noasm.go:14-24 — first run of 8 taps
-        int32_t e = (v0 - pos) & 1023, di = d0 + i;
+    constexpr int32_t pos = 64 * M;
+    constexpr int32_t v0 = (pos & 127) >> 1;
+    constexpr int32_t d0 = 512 - (pos >> 1);
+    float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int slot = ((T - (e >> 6)) & (kHistSlots - 1)) * kHistStride + (e & 63) + i;
-            const float d = dtab[di & 511];
-            accL = tap(accL, d, lds[slot], fma);
-            accR = tap(accR, d, lds[kHistSlots * kHistStride + slot], fma);
-            e = (e + 128) & 1023;
-            di += 64;
-        }
-        // audio_noasm.go:26-37 — second run
-        e = (96 - v0 - pos) & 1023;
-        di = d0 + 32 + i;
+    for (int k = 0; k < 8; k++) { // audio_noasm.go:14-24 — first run of 8 taps
+        const int32_t e = (v0 - pos + 128 * k) & 1023;
+        const int32_t seg = ((d0 + 64 * k) & 511) >> 5;
+        acc = tap<kFma>(acc, db[seg * 64], vb[(15 - (e >> 6)) * kSlotStride + ((e & 63) >> 5) * 64]);
+    }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int slot = ((T - (e >> 6)) & (kHistSlots - 1)) * kHistStride + (e & 63) + i;
-            const float d = dtab[di & 511];
-            accL = tap(accL, d, lds[slot], fma);
-            accR = tap(accR, d, lds[kHistSlots * kHistStride + slot], fma);
-            e = (e + 128) & 1023;
-            di += 64;
-        }
-        const float sL = accL / -1090519040.0f; // audio.go:390
-        const float sR = accR / -1090519040.0f;
+    for (int k = 0; k < 8; k++) { // audio_noasm.go:26-37 — second run
+        const int32_t e = (96 - v0 - pos + 128 * k) & 1023;
+        const int32_t seg = ((d0 + 32 + 64 * k) & 511) >> 5;
+        acc = tap<kFma>(acc, db[seg * 64], vb[(15 - (e >> 6)) * kSlotStride + ((e & 63) >> 5) * 64]);
+    }
+    return acc;
+}
+
+template <bool kFma> MPG_HD float window_dispatch(int32_t m, const float *vb, const float *db)
+{
+    switch (m) {
+    case 0: return window_taps<0, kFma>(vb, db);
+    case 1: return window_taps<1, kFma>(vb, db);
+    case 2: return window_taps<2, kFma>(vb, db);
+    case 3: return window_taps<3, kFma>(vb, db);
+    case 4: return window_taps<4, kFma>(vb, db);
+    case 5: return window_taps<5, kFma>(vb, db);
+    case 6: return window_taps<6, kFma>(vb, db);
+    case 7: return window_taps<7, kFma>(vb, db);
+    case 8: return window_taps<8, kFma>(vb, db);
+    case 9: return window_taps<9, kFma>(vb, db);
+    case 10: return window_taps<10, kFma>(vb, db);
+    case 11: return window_taps<11, kFma>(vb, db);
+    case 12: return window_taps<12, kFma>(vb, db);
+    case 13: return window_taps<13, kFma>(vb, db);
+    case 14: return window_taps<14, kFma>(vb, db);
+    default: return window_taps<15, kFma>(vb, db);
+    }
+}
+
+// ---- phase W: wave w takes sub-blocks base + w + 4n (n = 0..7); lane = channel*32 + sample
+template <bool kFma>
+MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t base, uint32_t tg1, int tid,
+                               const float *lds)
+{
+    const int wave = uniform(tid >> 6), lane = tid & 63;
+    const int ch = lane >> 5, i = lane & 31;
+    const float *db = lds + kHistFloats + lane;
+    for (int n = 0; n < kStep / kAudioWaves; n++) {
+        const uint32_t tg = base + (uint32_t)(wave + kAudioWaves * n); // wave-uniform from here down to the taps
+        if (tg >= tg1)
+            break;
+        const int32_t T = kT0 + (int32_t)tg;
+        const int32_t m = vpos_at(vpos0, T) >> 6;
+        const int32_t slot = T & (kRingSlots - 1);
+        const int32_t top = slot < kMirrorSlots ? slot + kRingSlots : slot;
+        const float acc = window_dispatch<kFma>(m, lds + (top - 15) * kSlotStride + lane, db);
+        const float sv = acc / -1090519040.0f; // audio.go:390
+        const uint32_t f = tg / 36, t = tg % 36;
         const uint64_t fb = ((uint64_t)stream * a.n_frames + f) * 2304;
-        const int o = t * 32 + i;
+        const uint32_t o = t * 32 + (uint32_t)i;
         switch (a.format) {
-        case MPEGHIP_AUDIO_F32N: {
-            float *out = reinterpret_cast<float *>(a.out) + fb + 2 * o;
-            out[0] = sL;
-            out[1] = sR;
+        case MPEGHIP_AUDIO_F32N:
+            reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv;
             break;
-        }
-        case MPEGHIP_AUDIO_F32NLR: {
-            float *out = reinterpret_cast<float *>(a.out) + fb;
-            out[o] = sL;
-            out[1152 + o] = sR;
+        case MPEGHIP_AUDIO_F32NLR:
+            reinterpret_cast<float *>(a.out)[fb + (uint32_t)ch * 1152 + o] = sv;
             break;
-        }
-        case MPEGHIP_AUDIO_S16: { // audio.go:400-408
-            int16_t *out = reinterpret_cast<int16_t *>(a.out) + fb + 2 * o;
-            out[0] = (int16_t)(int32_t)(sL < 0 ? sL * 32768.0f : sL * 32767.0f);
-            out[1] = (int16_t)(int32_t)(sR < 0 ? sR * 32768.0f : sR * 32767.0f);
+        case MPEGHIP_AUDIO_S16: // audio.go:400-408
+            reinterpret_cast<int16_t *>(a.out)[fb + 2 * o + (uint32_t)ch] = (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f);
             break;
-        }
-        default: { // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
-            float *out = reinterpret_cast<float *>(a.out) + fb + 2 * o;
-            out[0] = sL * 2147483648.0f;
-            out[1] = sR * 2147483648.0f;
+        default: // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
+            reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv * 2147483648.0f;
             break;
-        }
         }
     }
 }
@@ -278,7 +319,7 @@ MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0
         const int ch = idx >> 10, ra = idx & 1023;
         const int e = (ra - vpos1) & 1023;
         const int T = Tend - 1 - (e >> 6);
-        ring[idx] = lds[(ch * kHistSlots + (T & (kHistSlots - 1))) * kHistStride + (e & 63)];
+        ring[idx] = lds[hist_index(T, ch, e & 63)];
     }
 }
 

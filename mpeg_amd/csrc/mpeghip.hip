@@ -383,7 +383,7 @@ __global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32
     out[s] = h;
 }
 
-__global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
+template <bool kFma> __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kAudioLdsFloats];
     const uint32_t stream = blockIdx.x / a.n_chunks, chunk = blockIdx.x % a.n_chunks;
@@ -400,10 +400,11 @@ __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
         audio_phase_warmup(a, stream, f0, tid, lds);
     }
     __syncthreads();
-    for (uint32_t f = f0; f < f1; f++) {
-        audio_phase_dct(a, stream, f, tid, lds);
+    const uint32_t tg1 = f1 * 36;
+    for (uint32_t base = f0 * 36; base < tg1; base += kStep) {
+        audio_phase_dct(a, stream, base, tg1, tid, lds);
         __syncthreads();
-        audio_phase_window(a, stream, vpos0, f, tid, lds);
+        audio_phase_window<kFma>(a, stream, vpos0, base, tg1, tid, lds);
         __syncthreads();
     }
     if (f1 == a.n_frames) { // the slice that ends the launch owns the state hand-over
@@ -1388,7 +1389,10 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     if (chunks > n_frames)
         chunks = n_frames;
     args.n_chunks = chunks;
-    hipLaunchKernelGGL(audio_kernel, dim3(a->n_streams * chunks), dim3(kAudioThreads), 0, a->ctx->stream, args);
+    if (args.fma)
+        hipLaunchKernelGGL(audio_kernel<true>, dim3(a->n_streams * chunks), dim3(kAudioThreads), 0, a->ctx->stream, args);
+    else
+        hipLaunchKernelGGL(audio_kernel<false>, dim3(a->n_streams * chunks), dim3(kAudioThreads), 0, a->ctx->stream, args);
     HIP_TRY(hipGetLastError());
     { // the launch wrote the new state into the alternate buffers
         float *r = a->d_ring;

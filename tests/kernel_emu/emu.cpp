@@ -375,11 +375,16 @@ int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos,
                 audio_phase_warmup(a, stream, f0, tid, lds.data());
             }
         }
-        for (uint32_t f = f0; f < f1; f++) {
+        const uint32_t tg1 = f1 * 36;
+        for (uint32_t base = f0 * 36; base < tg1; base += kStep) {
             for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_dct(a, stream, f, tid, lds.data());
-            for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_window(a, stream, vpos0, f, tid, lds.data());
+                audio_phase_dct(a, stream, base, tg1, tid, lds.data());
+            for (int tid = 0; tid < kAudioThreads; tid++) {
+                if (a.fma)
+                    audio_phase_window<true>(a, stream, vpos0, base, tg1, tid, lds.data());
+                else
+                    audio_phase_window<false>(a, stream, vpos0, base, tg1, tid, lds.data());
+            }
         }
         if (f1 == a.n_frames) {
             for (int tid = 0; tid < kAudioThreads; tid++)
