@@ -13,14 +13,14 @@
 // Data flow per super-step of 32 sub-blocks (both channels; 4 waves per workgroup):
 //   phase D: wave 0 runs 64 32-point DCTs, one per lane (channel x 32 sub-blocks), entirely in
 //            registers, and writes the 64 mirrored outputs of each into a time-indexed V history in
-//            LDS: a ring of 64 slots, slot = [half][channel][32] (+1 pad).  The reference's
+//            LDS: a ring of 48 slots, slot = [half][channel][32] (+1 pad).  The reference's
 //            1024-entry ring only ever holds the last 16 slots.
 //   phase W: a wave owns ONE sub-block at a time, lane = channel*32 + sample.  Which history slots
 //            and window segments the 16 taps read, and in which order, depends only on the ring
 //            position at that sub-block (16 cases), which is wave-uniform: the wave branches once
 //            to a fully unrolled variant whose LDS reads are "per-lane base + immediate".  To keep
 //            the offsets immediate across the ring wrap, the first 15 slots are mirrored behind the
-//            ring (slots 64..78), so "the 16 slots ending at T" are always contiguous.
+//            ring (slots 48..62), so "the 16 slots ending at T" are always contiguous.
 //
 // Time slicing: a sub-block depends on the previous 15 only through the V history, and
 // every history slot is a pure function of one sub-block's samples.  So the frames of one
@@ -51,8 +51,8 @@ struct AudioArgs {
 constexpr int kAudioWaves = 4;
 constexpr int kAudioThreads = 64 * kAudioWaves;
 constexpr int kStep = 32;                             // sub-blocks per super-step: 64 DCTs = one full wave
-constexpr int kRingSlots = 64;
-constexpr int kMirrorSlots = 15;                      // ring slots 0..14 are repeated at 64..78
+constexpr int kRingSlots = 48;                        // >= kStep + 15 (the window reaches 15 sub-blocks back)
+constexpr int kMirrorSlots = 15;                      // ring slots 0..14 are repeated behind the ring
 constexpr int kSlotStride = 129;                      // floats per slot: [half 2][channel 2][32] + 1 pad
 constexpr int kHistFloats = (kRingSlots + kMirrorSlots) * kSlotStride;
 constexpr int kWinFloats = 1024;                      // window as [segment 16][channel 2][32]
@@ -166,7 +166,8 @@ template <bool kFma> MPG_HD float tap(float acc, float d, float v)
 // ring position of the slot written at local time T (Audio.vPos after that sub-block, audio.go:383)
 MPG_HD int32_t vpos_at(int32_t vpos0, int32_t T) { return (vpos0 - 64 * (T - kT0 + 1)) & 1023; }
 
-MPG_HD int hist_index(int32_t T, int ch, int x) { return (T & (kRingSlots - 1)) * kSlotStride + ch * 32 + hx(x); }
+MPG_HD int ring_slot(int32_t T) { return (int)((uint32_t)T % (uint32_t)kRingSlots); }
+MPG_HD int hist_index(int32_t T, int ch, int x) { return ring_slot(T) * kSlotStride + ch * 32 + hx(x); }
 
 // window table -> LDS, repeated per channel so that a tap's address is segment*64 + lane
 MPG_HD void audio_load_window(const AudioArgs &a, int tid, float *lds)
@@ -193,7 +194,7 @@ MPG_HD void hist_matrixing(const AudioArgs &a, uint32_t stream, uint32_t tg, int
 {
     const uint32_t f = tg / 36, t = tg % 36;
     const int32_t T = kT0 + (int32_t)tg;
-    const int32_t slot = T & (kRingSlots - 1);
+    const int32_t slot = ring_slot(T);
     const int32_t *s = a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + t * 32;
     float *v = lds + slot * kSlotStride + ch * 32;
     matrixing(s, v, slot < kMirrorSlots ? v + kRingSlots * kSlotStride : nullptr);
@@ -215,14 +216,15 @@ MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, 
     f1 = f0 + per < a.n_frames ? f0 + per : a.n_frames;
 }
 
-// ---- phase D: lane (channel, j) of wave 0 transforms sub-block base + j
+// ---- phase D: lane (channel, j) of ONE wave transforms sub-block base + j.  The wave rotates from
+// step to step so that the workgroups resident on a CU do not all load the same SIMD.
 MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t base, uint32_t tg1, int tid, float *lds)
 {
-    if (tid >= 64)
+    if ((uint32_t)(tid >> 6) != (base / kStep) % kAudioWaves)
         return;
     const uint32_t tg = base + (uint32_t)(tid & 31);
     if (tg < tg1)
-        hist_matrixing(a, stream, tg, tid >> 5, lds);
+        hist_matrixing(a, stream, tg, (tid >> 5) & 1, lds);
 }
 
 // The 16 taps of one output sample when the ring position is 64*M (audio_noasm.go:8-38).
@@ -285,7 +287,7 @@ MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos
             break;
         const int32_t T = kT0 + (int32_t)tg;
         const int32_t m = vpos_at(vpos0, T) >> 6;
-        const int32_t slot = T & (kRingSlots - 1);
+        const int32_t slot = ring_slot(T);
         const int32_t top = slot < kMirrorSlots ? slot + kRingSlots : slot;
         const float acc = window_dispatch<kFma>(m, lds + (top - 15) * kSlotStride + lane, db);
         const float sv = acc / -1090519040.0f; // audio.go:390
