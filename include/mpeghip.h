@@ -290,7 +290,11 @@ int mpeghip_audio_device_buffers(mpeghip_audio *a, uint32_t n_frames, int format
                                  int32_t **d_samples, void **d_out);
 int mpeghip_audio_upload(mpeghip_audio *a, int32_t *d_dst, const int32_t *src, size_t n_ints);
 int mpeghip_audio_download(mpeghip_audio *a, void *dst, const void *d_src, size_t bytes);
-/* V ring + vPos of one stream: v[2][1024] float32, vpos in [0,1024) multiple of 64. */
+/* V ring + vPos of one stream: v[2][1024] float32, vpos in [0,1024) multiple of 64.
+ * set_state takes what get_state returned (or zeros): every 64-entry slot of Audio.v is idct36's
+ * signed mirror of 32 DCT outputs (audio.go:708-771: d[48-k] == d[48+k], d[k-16] == -d[48-k],
+ * d[16] == 0) and the kernel keeps only those 32; a ring that breaks the mirror is refused with
+ * MPEGHIP_ERR_INVALID rather than synthesised differently from the reference. */
 int mpeghip_audio_get_state(mpeghip_audio *a, uint32_t stream, float *v, int32_t *vpos);
 int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, int32_t vpos);
 

@@ -10,19 +10,22 @@
 // MPEGHIP_AUDIO_FMA_WINDOW mode, taps are accumulated in the reference's ring
 // order (which depends on vPos), the output is a true IEEE division.
 //
-// Data flow per super-step of 32 sub-blocks (both channels; 4 waves per workgroup):
-//   phase D: wave 0 runs 64 32-point DCTs, one per lane (channel x 32 sub-blocks), entirely in
-//            registers, and writes the 64 mirrored outputs of each into a time-indexed V history in
-//            LDS: a ring of 48 slots, slot = [half][channel][32] (+1 pad).  The reference's
+// Data flow per super-step of kStep = 32*DW sub-blocks (both channels; 4 waves per workgroup):
+//   phase D: DW waves run 64 32-point DCTs each, one per lane (channel x 32 sub-blocks), entirely in
+//            registers.  idct36's 64 outputs d[0..63] are a signed mirror of the 32 DCT outputs X[k]
+//            (audio.go:708-771: d[48-k] = d[48+k] = -X[k], d[k-16] = X[k], d[16] = 0), so only X is
+//            kept: a time-indexed history in LDS, slot = [channel][32] (+1 pad).  The reference's
 //            1024-entry ring only ever holds the last 16 slots.
-//   phase W: a wave owns ONE sub-block at a time, lane = channel*32 + sample.  Which history slots
-//            and window segments the 16 taps read, and in which order, depends only on the ring
-//            position at that sub-block (16 cases), which is wave-uniform: the wave branches once
-//            to a fully unrolled variant whose LDS reads are "per-lane base + immediate".  To keep
-//            the offsets immediate across the ring wrap, the first 15 slots are mirrored behind the
-//            ring (slots 48..62), so "the 16 slots ending at T" are always contiguous.
+//   phase W: a wave owns sub-blocks t and t+16 at a time, lane = channel*32 + sample.  Which history
+//            slots and window segments the 16 taps read, and in which order, depends only on the ring
+//            position (16 cases, the same for t and t+16), which is wave-uniform: the wave branches
+//            once to a fully unrolled variant whose LDS reads are "per-lane base + immediate".  The
+//            lane's 16 window coefficients live in registers with the mirror's sign folded in
+//            (even segments always meet d[0..31], odd ones d[32..63]).  To keep the offsets immediate
+//            across the ring wrap, the first 15 slots are repeated behind the ring, so "the 16 slots
+//            ending at T" are always contiguous.
 //
-// Time slicing: a sub-block depends on the previous 15 only through the V history, and
+// Time slicing: a sub-block depends on the previous 15 only through the history, and
 // every history slot is a pure function of one sub-block's samples.  So the frames of one
 // launch are split into n_chunks slices per stream, one workgroup each; a slice that does not
 // start at frame 0 rebuilds its 15-slot history by re-running the 15 DCTs in front of it
@@ -50,17 +53,16 @@ struct AudioArgs {
 
 constexpr int kAudioWaves = 4;
 constexpr int kAudioThreads = 64 * kAudioWaves;
-constexpr int kStep = 32;                             // sub-blocks per super-step: 64 DCTs = one full wave
-constexpr int kRingSlots = 48;                        // >= kStep + 15 (the window reaches 15 sub-blocks back)
 constexpr int kMirrorSlots = 15;                      // ring slots 0..14 are repeated behind the ring
-constexpr int kSlotStride = 129;                      // floats per slot: [half 2][channel 2][32] + 1 pad
-constexpr int kHistFloats = (kRingSlots + kMirrorSlots) * kSlotStride;
-constexpr int kWinFloats = 1024;                      // window as [segment 16][channel 2][32]
-constexpr int kAudioLdsFloats = kHistFloats + kWinFloats;
+constexpr int kSlotStride = 65;                       // floats per slot: [channel 2][32] + 1 pad
 constexpr int kT0 = 16;                               // local time of the launch's first sub-block
 
-// position of V entry x (0..63) inside a history slot, before the channel offset
-MPG_HD constexpr int hx(int x) { return (x >> 5) * 64 + (x & 31); }
+// DW = waves that run DCTs in phase D
+template <int DW> struct AudioCfg {
+    static constexpr int kStep = 32 * DW;             // sub-blocks per super-step
+    static constexpr int kRing = kStep + 16;          // >= kStep + 15: the window reaches 15 sub-blocks back
+    static constexpr int kLdsFloats = (kRing + kMirrorSlots) * kSlotStride;
+};
 
 // c_N[i] = 0.5 / cos((2i+1)*pi/(2N)); identical float32 values to the decimal
 // literals of audio.go:498-661.
@@ -109,28 +111,8 @@ struct Dct<1> {
     static MPG_HDM void run(float (&)[1]) {}
 };
 
-// scatter with the mirror / sign pattern of audio.go:708-771: X[2k] = e[k], X[2k+1] = o[k]
-MPG_HD void scatter(const float (&e)[16], const float (&o)[16], float *v)
-{
-#pragma unroll
-    for (int k = 0; k <= 31; k++) {
-        const float X = (k & 1) ? o[k >> 1] : e[k >> 1];
-        if (k <= 16)
-            v[hx(48 - k)] = -X;
-        if (k >= 1 && k <= 15)
-            v[hx(48 + k)] = -X;
-        if (k >= 17) {
-            v[hx(48 - k)] = -X;
-            v[hx(k - 16)] = X;
-        }
-        if (k == 16)
-            v[hx(0)] = X;
-    }
-    v[hx(16)] = 0.0f;
-}
-
-// idct36 for one (channel, sub-block): s = 32 sub-band samples, v = the history slot (at this
-// channel's offset) that receives d[dp+0 .. dp+63]; v2 = its mirror or nullptr.
+// idct36 for one (channel, sub-block) up to the mirror: s = 32 sub-band samples, v = the history
+// slot (at this channel's offset) that receives X[0..31]; v2 = its repeat behind the ring or nullptr.
 MPG_HD void matrixing(const int32_t *s, float *v, float *v2)
 {
     float e[16], o[16];
@@ -153,10 +135,26 @@ MPG_HD void matrixing(const int32_t *s, float *v, float *v2)
 #pragma unroll
     for (int k = 0; k < 15; k++)
         o[k] += o[k + 1];
-    scatter(e, o, v);
-    if (v2)
-        scatter(e, o, v2);
+#pragma unroll
+    for (int k = 0; k < 16; k++) { // X[2k] = e[k], X[2k+1] = o[k]
+        v[2 * k] = e[k];
+        v[2 * k + 1] = o[k];
+    }
+    if (v2) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            v2[2 * k] = e[k];
+            v2[2 * k + 1] = o[k];
+        }
+    }
 }
+
+// The mirror (audio.go:708-771): d[x] = sign * X[k]
+//   x = 0: X[16]   1..15: X[x+16]   16: 0   17..48: -X[48-x]   49..63: -X[x-48]
+MPG_HD int mirror_index(int x) { return x < 16 ? x + 16 : (x == 16 ? 0 : (x <= 48 ? 48 - x : x - 48)); }
+MPG_HD float mirror_apply(int x, float X) { return x < 16 ? X : (x == 16 ? 0.0f : -X); }
+// and back: X[k] from d
+MPG_HD float mirror_recover(int k, const float *d) { return k <= 16 ? -d[48 - k] : d[k - 16]; }
 
 template <bool kFma> MPG_HD float tap(float acc, float d, float v)
 {
@@ -166,46 +164,49 @@ template <bool kFma> MPG_HD float tap(float acc, float d, float v)
 // ring position of the slot written at local time T (Audio.vPos after that sub-block, audio.go:383)
 MPG_HD int32_t vpos_at(int32_t vpos0, int32_t T) { return (vpos0 - 64 * (T - kT0 + 1)) & 1023; }
 
-MPG_HD int ring_slot(int32_t T) { return (int)((uint32_t)T % (uint32_t)kRingSlots); }
-MPG_HD int hist_index(int32_t T, int ch, int x) { return ring_slot(T) * kSlotStride + ch * 32 + hx(x); }
+template <int DW> MPG_HD int ring_slot(int32_t T) { return (int)((uint32_t)T % (uint32_t)AudioCfg<DW>::kRing); }
 
-// window table -> LDS, repeated per channel so that a tap's address is segment*64 + lane
-MPG_HD void audio_load_window(const AudioArgs &a, int tid, float *lds)
-{
-    for (int idx = tid; idx < kWinFloats; idx += kAudioThreads)
-        lds[kHistFloats + idx] = a.window[(idx >> 6) * 32 + (idx & 31)];
-}
-
-// ---- state in: Audio.v ring -> time-indexed history
-MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, float *lds)
+// ---- state in: Audio.v ring -> time-indexed X history (item = channel, slot time, k)
+template <int DW> MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, float *lds)
 {
     const float *ring = a.ring + (uint64_t)stream * 2048;
-    for (int idx = tid; idx < 2048; idx += kAudioThreads) {
-        const int ch = idx >> 10, ra = idx & 1023;
-        const int e = (ra - vpos0) & 1023;           // slot vpos0 holds the newest block (time T0-1)
-        const int T = kT0 - 1 - (e >> 6);            // 0..15: no mirror needed, the first reader has T >= 16
-        lds[hist_index(T, ch, e & 63)] = ring[idx];
+    for (int idx = tid; idx < 1024; idx += kAudioThreads) {
+        const int ch = idx >> 9, T = (idx >> 5) & 15, k = idx & 31; // T = 0..15: no repeat needed, the first reader has T >= 16
+        const int e0 = 64 * (kT0 - 1 - T);                           // slot vpos0 holds the newest block (time T0-1)
+        const int x = k <= 16 ? 48 - k : k - 16;
+        const float d = ring[ch * 1024 + ((vpos0 + e0 + x) & 1023)];
+        lds[ring_slot<DW>(T) * kSlotStride + ch * 32 + k] = k <= 16 ? -d : d;
     }
-    audio_load_window(a, tid, lds);
 }
 
-// one DCT: sub-block tg (counted from the launch's first) of channel ch -> its history slot (+ mirror)
-MPG_HD void hist_matrixing(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, float *lds)
+// the lane's 16 window coefficients (synthesisWindow, audio.go:812-899) with the mirror's sign:
+// segment s meets d[(s&1)*32 + i]
+MPG_HD void audio_load_window(const AudioArgs &a, int tid, float (&dreg)[16])
+{
+    const int i = tid & 31;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const float w = a.window[s * 32 + i];
+        dreg[s] = (s & 1) ? -w : mirror_apply(i, w);
+    }
+}
+
+// one DCT: sub-block tg (counted from the launch's first) of channel ch -> its history slot (+ repeat)
+template <int DW> MPG_HD void hist_matrixing(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, float *lds)
 {
     const uint32_t f = tg / 36, t = tg % 36;
-    const int32_t T = kT0 + (int32_t)tg;
-    const int32_t slot = ring_slot(T);
+    const int32_t slot = ring_slot<DW>(kT0 + (int32_t)tg);
     const int32_t *s = a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + t * 32;
     float *v = lds + slot * kSlotStride + ch * 32;
-    matrixing(s, v, slot < kMirrorSlots ? v + kRingSlots * kSlotStride : nullptr);
+    matrixing(s, v, slot < kMirrorSlots ? v + AudioCfg<DW>::kRing * kSlotStride : nullptr);
 }
 
 // ---- history rebuild for a slice that starts at frame f0 > 0: the 15 sub-blocks before it
-MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t f0, int tid, float *lds)
+template <int DW> MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t f0, int tid, float *lds)
 {
     if (tid >= 30)
         return;
-    hist_matrixing(a, stream, f0 * 36 - 15 + (uint32_t)(tid % 15), tid / 15, lds);
+    hist_matrixing<DW>(a, stream, f0 * 36 - 15 + (uint32_t)(tid % 15), tid / 15, lds);
 }
 
 // frames [f0, f1) of time slice `chunk`
@@ -216,103 +217,153 @@ MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, 
     f1 = f0 + per < a.n_frames ? f0 + per : a.n_frames;
 }
 
-// ---- phase D: lane (channel, j) of ONE wave transforms sub-block base + j.  The wave rotates from
-// step to step so that the workgroups resident on a CU do not all load the same SIMD.
+// ---- phase D: DW waves; lane (channel, j) of the q-th of them transforms sub-block base + 32q + j.
+// The DCT waves rotate from step to step so that the workgroups resident on a CU do not all load
+// the same SIMD.
+template <int DW>
 MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t base, uint32_t tg1, int tid, float *lds)
 {
-    if ((uint32_t)(tid >> 6) != (base / kStep) % kAudioWaves)
+    const uint32_t rot = (base / AudioCfg<DW>::kStep * DW) % kAudioWaves;
+    const uint32_t q = ((uint32_t)(tid >> 6) - rot) % kAudioWaves;
+    if (q >= (uint32_t)DW)
         return;
-    const uint32_t tg = base + (uint32_t)(tid & 31);
+    const uint32_t tg = base + 32 * q + (uint32_t)(tid & 31);
     if (tg < tg1)
-        hist_matrixing(a, stream, tg, (tid >> 5) & 1, lds);
+        hist_matrixing<DW>(a, stream, tg, (tid >> 5) & 1, lds);
 }
 
-// The 16 taps of one output sample when the ring position is 64*M (audio_noasm.go:8-38).
-// vb = &history[(top - 15) * kSlotStride + lane] where `top` is the (possibly mirrored) slot of
-// this sub-block; db = &window_lds[lane].  Everything else folds to immediates.
-template <int M, bool kFma> MPG_HD float window_taps(const float *vb, const float *db)
+// The 16 taps of one output sample of two sub-blocks when the ring position is 64*M
+// (audio_noasm.go:8-38).  p0/p1 = the lane's history pointers for d[0..31] / d[32..63] at slot
+// (top - 15), where `top` is the (possibly repeated) slot of the sub-block; A and B are the two
+// sub-blocks.  Everything else folds to immediates.
+template <int M, bool kFma>
+MPG_HD void window_taps(const float *p0A, const float *p1A, const float *p0B, const float *p1B, const float (&d)[16], float &accA,
+                        float &accB)
 {
     constexpr int32_t pos = 64 * M;
     constexpr int32_t v0 = (pos & 127) >> 1;
     constexpr int32_t d0 = 512 - (pos >> 1);
-    float acc = 0.0f;
+    float a = 0.0f, b = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) { // audio_noasm.go:14-24 — first run of 8 taps
         const int32_t e = (v0 - pos + 128 * k) & 1023;
         const int32_t seg = ((d0 + 64 * k) & 511) >> 5;
-        acc = tap<kFma>(acc, db[seg * 64], vb[(15 - (e >> 6)) * kSlotStride + ((e & 63) >> 5) * 64]);
+        const int off = (15 - (e >> 6)) * kSlotStride;
+        a = tap<kFma>(a, d[seg], ((e & 63) >> 5) ? p1A[off] : p0A[off]);
+        b = tap<kFma>(b, d[seg], ((e & 63) >> 5) ? p1B[off] : p0B[off]);
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) { // audio_noasm.go:26-37 — second run
         const int32_t e = (96 - v0 - pos + 128 * k) & 1023;
         const int32_t seg = ((d0 + 32 + 64 * k) & 511) >> 5;
-        acc = tap<kFma>(acc, db[seg * 64], vb[(15 - (e >> 6)) * kSlotStride + ((e & 63) >> 5) * 64]);
+        const int off = (15 - (e >> 6)) * kSlotStride;
+        a = tap<kFma>(a, d[seg], ((e & 63) >> 5) ? p1A[off] : p0A[off]);
+        b = tap<kFma>(b, d[seg], ((e & 63) >> 5) ? p1B[off] : p0B[off]);
     }
-    return acc;
+    accA = a;
+    accB = b;
 }
 
-template <bool kFma> MPG_HD float window_dispatch(int32_t m, const float *vb, const float *db)
+template <bool kFma>
+MPG_HD void window_dispatch(int32_t m, const float *p0A, const float *p1A, const float *p0B, const float *p1B,
+                            const float (&d)[16], float &accA, float &accB)
 {
     switch (m) {
-    case 0: return window_taps<0, kFma>(vb, db);
-    case 1: return window_taps<1, kFma>(vb, db);
-    case 2: return window_taps<2, kFma>(vb, db);
-    case 3: return window_taps<3, kFma>(vb, db);
-    case 4: return window_taps<4, kFma>(vb, db);
-    case 5: return window_taps<5, kFma>(vb, db);
-    case 6: return window_taps<6, kFma>(vb, db);
-    case 7: return window_taps<7, kFma>(vb, db);
-    case 8: return window_taps<8, kFma>(vb, db);
-    case 9: return window_taps<9, kFma>(vb, db);
-    case 10: return window_taps<10, kFma>(vb, db);
-    case 11: return window_taps<11, kFma>(vb, db);
-    case 12: return window_taps<12, kFma>(vb, db);
-    case 13: return window_taps<13, kFma>(vb, db);
-    case 14: return window_taps<14, kFma>(vb, db);
-    default: return window_taps<15, kFma>(vb, db);
+    case 0: return window_taps<0, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 1: return window_taps<1, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 2: return window_taps<2, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 3: return window_taps<3, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 4: return window_taps<4, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 5: return window_taps<5, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 6: return window_taps<6, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 7: return window_taps<7, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 8: return window_taps<8, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 9: return window_taps<9, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 10: return window_taps<10, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 11: return window_taps<11, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 12: return window_taps<12, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 13: return window_taps<13, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    case 14: return window_taps<14, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
+    default: return window_taps<15, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
     }
 }
 
-// ---- phase W: wave w takes sub-blocks base + w + 4n (n = 0..7); lane = channel*32 + sample
-template <bool kFma>
+// x / -1090519040 (audio.go:390), correctly rounded.  The short form is Markstein's sequence
+// q = x*y, r = fma(-q, D, x), q' = fma(r, y, q) with y = RN(1/D); tests/proofs/div_const.c checks
+// all 2^32 inputs: it equals the IEEE quotient for x == 0 and for every finite |x| >= 2^-95 (it
+// differs for some 2^-119 <= |x| < 2^-95, where r underflows).  |x| cannot overflow: |samples| <
+// 2^31, each of the DCT's 5 levels at most doubles twice and scales by < 10.2 (< 2^27 in all), the
+// window sums 16 products with |D| < 2^17: |x| < 2^80.
+constexpr float kScale = -1090519040.0f;
+constexpr float kScaleInv = 1.0f / kScale;
+MPG_HD bool scale_short_ok(float x) { return !(__builtin_fabsf(x) < 0x1p-95f) || x == 0.0f; }
+MPG_HD float scale_short(float x)
+{
+    const float q = x * kScaleInv;
+    const float r = __builtin_fmaf(-q, kScale, x);
+    return __builtin_fmaf(r, kScaleInv, q);
+}
+
+// convert (audio.go:386-418) and store one sample of sub-block tg
+MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, int i, float sv)
+{
+    const uint32_t f = tg / 36, t = tg % 36;
+    const uint64_t fb = ((uint64_t)stream * a.n_frames + f) * 2304;
+    const uint32_t o = t * 32 + (uint32_t)i;
+    switch (a.format) {
+    case MPEGHIP_AUDIO_F32N:
+        reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv;
+        break;
+    case MPEGHIP_AUDIO_F32NLR:
+        reinterpret_cast<float *>(a.out)[fb + (uint32_t)ch * 1152 + o] = sv;
+        break;
+    case MPEGHIP_AUDIO_S16: // audio.go:400-408
+        reinterpret_cast<int16_t *>(a.out)[fb + 2 * o + (uint32_t)ch] = (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f);
+        break;
+    default: // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
+        reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv * 2147483648.0f;
+        break;
+    }
+}
+
+// ---- phase W: per group of 32 sub-blocks, wave w takes the pairs (g + w + 4n, g + w + 4n + 16), n = 0..3;
+// lane = channel*32 + sample
+template <int DW, bool kFma>
 MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t base, uint32_t tg1, int tid,
-                               const float *lds)
+                               const float (&dreg)[16], const float *lds)
 {
     const int wave = uniform(tid >> 6), lane = tid & 63;
     const int ch = lane >> 5, i = lane & 31;
-    const float *db = lds + kHistFloats + lane;
-    for (int n = 0; n < kStep / kAudioWaves; n++) {
-        const uint32_t tg = base + (uint32_t)(wave + kAudioWaves * n); // wave-uniform from here down to the taps
-        if (tg >= tg1)
+    const float *p0 = lds + ch * 32 + mirror_index(i);
+    const float *p1 = lds + ch * 32 + mirror_index(32 + i);
+    for (int n = 0; n < 4 * DW; n++) {
+        const uint32_t tgA = base + (uint32_t)(32 * (n >> 2) + wave + kAudioWaves * (n & 3)); // wave-uniform down to the taps
+        const uint32_t tgB = tgA + 16;
+        if (tgA >= tg1)
             break;
-        const int32_t T = kT0 + (int32_t)tg;
-        const int32_t m = vpos_at(vpos0, T) >> 6;
-        const int32_t slot = ring_slot(T);
-        const int32_t top = slot < kMirrorSlots ? slot + kRingSlots : slot;
-        const float acc = window_dispatch<kFma>(m, lds + (top - 15) * kSlotStride + lane, db);
-        const float sv = acc / -1090519040.0f; // audio.go:390
-        const uint32_t f = tg / 36, t = tg % 36;
-        const uint64_t fb = ((uint64_t)stream * a.n_frames + f) * 2304;
-        const uint32_t o = t * 32 + (uint32_t)i;
-        switch (a.format) {
-        case MPEGHIP_AUDIO_F32N:
-            reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv;
-            break;
-        case MPEGHIP_AUDIO_F32NLR:
-            reinterpret_cast<float *>(a.out)[fb + (uint32_t)ch * 1152 + o] = sv;
-            break;
-        case MPEGHIP_AUDIO_S16: // audio.go:400-408
-            reinterpret_cast<int16_t *>(a.out)[fb + 2 * o + (uint32_t)ch] = (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f);
-            break;
-        default: // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
-            reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv * 2147483648.0f;
-            break;
+        const int32_t TA = kT0 + (int32_t)tgA;
+        const int32_t m = vpos_at(vpos0, TA) >> 6; // == that of TA + 16
+        const int32_t slotA = ring_slot<DW>(TA), slotB = ring_slot<DW>(TA + 16);
+        const int32_t offA = ((slotA < kMirrorSlots ? slotA + AudioCfg<DW>::kRing : slotA) - 15) * kSlotStride;
+        const int32_t offB = ((slotB < kMirrorSlots ? slotB + AudioCfg<DW>::kRing : slotB) - 15) * kSlotStride;
+        float accA, accB;
+        window_dispatch<kFma>(m, p0 + offA, p1 + offA, p0 + offB, p1 + offB, dreg, accA, accB);
+        float svA, svB;
+        if (all_in_wave(scale_short_ok(accA) && scale_short_ok(accB))) {
+            svA = scale_short(accA);
+            svB = scale_short(accB);
+        } else {
+            svA = accA / kScale;
+            svB = accB / kScale;
         }
+        audio_store_sample(a, stream, tgA, ch, i, svA);
+        if (tgB < tg1) // past the slice: B read stale history, drop it
+            audio_store_sample(a, stream, tgB, ch, i, svB);
     }
 }
 
 // ---- state out: last 16 history slots -> Audio.v ring; thread 0 advances vPos
-MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, const float *lds)
+template <int DW> MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, const float *lds)
 {
     float *ring = a.ring_out + (uint64_t)stream * 2048;
     const int32_t Tend = kT0 + (int32_t)a.n_frames * 36; // first time NOT produced
@@ -320,8 +371,8 @@ MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0
     for (int idx = tid; idx < 2048; idx += kAudioThreads) {
         const int ch = idx >> 10, ra = idx & 1023;
         const int e = (ra - vpos1) & 1023;
-        const int T = Tend - 1 - (e >> 6);
-        ring[idx] = lds[hist_index(T, ch, e & 63)];
+        const int T = Tend - 1 - (e >> 6), x = e & 63;
+        ring[idx] = mirror_apply(x, lds[ring_slot<DW>(T) * kSlotStride + ch * 32 + mirror_index(x)]);
     }
 }
 

@@ -199,6 +199,17 @@ MPG_HD bool none_in_wave(bool pred)
 #endif
 }
 
+// true if `pred` holds for every active lane of the wavefront.  The emulator runs one lane at a
+// time and answers for that lane alone: only use it where both branches give the same result.
+MPG_HD bool all_in_wave(bool pred)
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_ballot_w64(!pred) == 0;
+#else
+    return pred;
+#endif
+}
+
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its
 // own L2).  Gives every XCD one contiguous range of work chunks so that
 // neighbouring macroblocks — which share 128-byte destination lines and overlapping

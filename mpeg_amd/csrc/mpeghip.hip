@@ -383,9 +383,10 @@ __global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32
     out[s] = h;
 }
 
-template <bool kFma> __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
+template <int DW, bool kFma> __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[kAudioLdsFloats];
+    using Cfg = AudioCfg<DW>;
+    __shared__ __attribute__((aligned(16))) float lds[Cfg::kLdsFloats];
     const uint32_t stream = blockIdx.x / a.n_chunks, chunk = blockIdx.x % a.n_chunks;
     const int tid = threadIdx.x;
     uint32_t f0, f1;
@@ -393,22 +394,22 @@ template <bool kFma> __global__ __launch_bounds__(kAudioThreads) void audio_kern
     if (f0 >= f1)
         return; // empty slice (wave-uniform, before any barrier)
     const int32_t vpos0 = a.vpos[stream];
-    if (f0 == 0) {
-        audio_load_state(a, stream, vpos0, tid, lds);
-    } else {
-        audio_load_window(a, tid, lds);
-        audio_phase_warmup(a, stream, f0, tid, lds);
-    }
+    float dreg[16];
+    audio_load_window(a, tid, dreg);
+    if (f0 == 0)
+        audio_load_state<DW>(a, stream, vpos0, tid, lds);
+    else
+        audio_phase_warmup<DW>(a, stream, f0, tid, lds);
     __syncthreads();
     const uint32_t tg1 = f1 * 36;
-    for (uint32_t base = f0 * 36; base < tg1; base += kStep) {
-        audio_phase_dct(a, stream, base, tg1, tid, lds);
+    for (uint32_t base = f0 * 36; base < tg1; base += Cfg::kStep) {
+        audio_phase_dct<DW>(a, stream, base, tg1, tid, lds);
         __syncthreads();
-        audio_phase_window<kFma>(a, stream, vpos0, base, tg1, tid, lds);
+        audio_phase_window<DW, kFma>(a, stream, vpos0, base, tg1, tid, dreg, lds);
         __syncthreads();
     }
     if (f1 == a.n_frames) { // the slice that ends the launch owns the state hand-over
-        audio_store_state(a, stream, vpos0, tid, lds);
+        audio_store_state<DW>(a, stream, vpos0, tid, lds);
         if (tid == 0)
             audio_store_vpos(a, stream, vpos0);
     }
@@ -1389,10 +1390,24 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     if (chunks > n_frames)
         chunks = n_frames;
     args.n_chunks = chunks;
-    if (args.fma)
-        hipLaunchKernelGGL(audio_kernel<true>, dim3(a->n_streams * chunks), dim3(kAudioThreads), 0, a->ctx->stream, args);
+    int dw = 2; // DCT waves per workgroup (A/B on MI355X: 2 > 4 > 1)
+    if (const char *e = getenv("MPEGHIP_AUDIO_DW")) // development knob
+        dw = atoi(e);
+    const dim3 grid(a->n_streams * chunks), block(kAudioThreads);
+#define LAUNCH_AUDIO(DW)                                                                      \
+    do {                                                                                      \
+        if (args.fma)                                                                         \
+            hipLaunchKernelGGL((audio_kernel<DW, true>), grid, block, 0, a->ctx->stream, args);  \
+        else                                                                                  \
+            hipLaunchKernelGGL((audio_kernel<DW, false>), grid, block, 0, a->ctx->stream, args); \
+    } while (0)
+    if (dw == 4)
+        LAUNCH_AUDIO(4);
+    else if (dw == 2)
+        LAUNCH_AUDIO(2);
     else
-        hipLaunchKernelGGL(audio_kernel<false>, dim3(a->n_streams * chunks), dim3(kAudioThreads), 0, a->ctx->stream, args);
+        LAUNCH_AUDIO(1);
+#undef LAUNCH_AUDIO
     HIP_TRY(hipGetLastError());
     { // the launch wrote the new state into the alternate buffers
         float *r = a->d_ring;
@@ -1443,6 +1458,19 @@ int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, i
 {
     if (!a || stream >= a->n_streams || vpos < 0 || vpos > 1023 || (vpos & 63))
         return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    if (v) {
+        // Audio.v only ever holds idct36 outputs (or zeros): each 64-entry slot is the signed mirror
+        // of 32 DCT outputs (audio.go:708-771).  The kernel keeps just those 32, so insist on it.
+        for (int ch = 0; ch < 2; ch++)
+            for (int slot = 0; slot < 16; slot++) {
+                const float *d = v + ch * 1024 + slot * 64;
+                bool ok = d[16] == 0.0f && d[0] == -d[32];
+                for (int k = 1; k <= 15 && ok; k++)
+                    ok = d[48 + k] == d[48 - k] && d[16 - k] == -d[16 + k];
+                if (!ok)
+                    return fail(MPEGHIP_ERR_INVALID, "v is not a synthesis state (channel %d slot %d breaks the idct36 mirror)", ch, slot);
+            }
+    }
     HIP_TRY(hipSetDevice(a->ctx->device));
     HIP_TRY(hipStreamSynchronize(a->ctx->stream));
     if (v)

@@ -235,6 +235,12 @@ class OracleSynth:
             lib().orc_synth_frames(C.byref(self.states[i]), _ptr(s[i]), n_frames, fmt, self.fma, _ptr(out[i]))
         return out
 
+    def set_state(self, stream: int, v, vpos: int):
+        st = self.states[stream]
+        if v is not None:
+            np.ctypeslib.as_array(st.v).reshape(2, 1024)[:] = np.asarray(v, np.float32).reshape(2, 1024)
+        st.vpos = vpos
+
     def get_state(self, stream: int):
         st = self.states[stream]
         return np.ctypeslib.as_array(st.v).reshape(2, 1024).copy(), int(st.vpos)

@@ -1,7 +1,7 @@
 // emu.cpp — TEST INFRASTRUCTURE ONLY: a CPU "lane emulator" for the kernels of
 // libmpeghip.  It compiles the very same lane functions the GPU kernels are made
 // of (mpeg_amd/csrc/*_lane.h) with g++ and runs the 64 lanes of a wavefront /
-// the 384 threads of an audio workgroup in plain loops, phase by phase, with LDS
+// the 256 threads of an audio workgroup in plain loops, phase by phase, with LDS
 // as an ordinary array.  Purpose: check lane mapping, addressing and the integer
 // range invariants (MPG_EMU_CHECKS) against the oracle on a machine without a
 // GPU, under ASan/UBSan if wanted.
@@ -335,10 +335,51 @@ void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, ui
             rgba_convert_quad(frame, luma_w, luma_w / 2, luma_w * luma_h, luma_w * luma_h / 4, width, height, x4, y, rgba);
 }
 
-// audio_kernel: n_chunks workgroups (time slices) per stream; ring / vpos are updated in place for the
+// audio_kernel<DW>: n_chunks workgroups (time slices) per stream; ring / vpos are updated in place for the
 // caller (the kernel writes them to the alternate buffers, emulated with a copy).
+} // extern "C"
+template <int DW> static void emu_audio_blocks(const AudioArgs &a)
+{
+    std::vector<float> lds(AudioCfg<DW>::kLdsFloats);
+    for (uint32_t blk = 0; blk < a.n_streams * a.n_chunks; blk++) {
+        const uint32_t stream = blk / a.n_chunks, chunk = blk % a.n_chunks;
+        uint32_t f0, f1;
+        audio_chunk_range(a, chunk, f0, f1);
+        if (f0 >= f1)
+            continue;
+        for (auto &x : lds)
+            x = 1e30f; // poison
+        const int32_t vpos0 = a.vpos[stream];
+        for (int tid = 0; tid < kAudioThreads; tid++) {
+            if (f0 == 0)
+                audio_load_state<DW>(a, stream, vpos0, tid, lds.data());
+            else
+                audio_phase_warmup<DW>(a, stream, f0, tid, lds.data());
+        }
+        const uint32_t tg1 = f1 * 36;
+        for (uint32_t base = f0 * 36; base < tg1; base += AudioCfg<DW>::kStep) {
+            for (int tid = 0; tid < kAudioThreads; tid++)
+                audio_phase_dct<DW>(a, stream, base, tg1, tid, lds.data());
+            for (int tid = 0; tid < kAudioThreads; tid++) {
+                float dreg[16]; // a register array of the thread, loaded once in the kernel
+                audio_load_window(a, tid, dreg);
+                if (a.fma)
+                    audio_phase_window<DW, true>(a, stream, vpos0, base, tg1, tid, dreg, lds.data());
+                else
+                    audio_phase_window<DW, false>(a, stream, vpos0, base, tg1, tid, dreg, lds.data());
+            }
+        }
+        if (f1 == a.n_frames) {
+            for (int tid = 0; tid < kAudioThreads; tid++)
+                audio_store_state<DW>(a, stream, vpos0, tid, lds.data());
+            audio_store_vpos(a, stream, vpos0);
+        }
+    }
+}
+
+extern "C" {
 int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos, const float *window,
-                  uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks)
+                  uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks, int32_t dw)
 {
     if (n_frames == 0)
         return 0;
@@ -357,41 +398,12 @@ int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos,
     a.format = format;
     a.fma = fma;
     a.n_chunks = n_chunks < 1 ? 1 : (n_chunks > n_frames ? n_frames : n_chunks);
-    std::vector<float> lds(kAudioLdsFloats);
-    for (uint32_t blk = 0; blk < n_streams * a.n_chunks; blk++) {
-        const uint32_t stream = blk / a.n_chunks, chunk = blk % a.n_chunks;
-        uint32_t f0, f1;
-        audio_chunk_range(a, chunk, f0, f1);
-        if (f0 >= f1)
-            continue;
-        for (auto &x : lds)
-            x = 1e30f; // poison
-        const int32_t vpos0 = a.vpos[stream];
-        for (int tid = 0; tid < kAudioThreads; tid++) {
-            if (f0 == 0) {
-                audio_load_state(a, stream, vpos0, tid, lds.data());
-            } else {
-                audio_load_window(a, tid, lds.data());
-                audio_phase_warmup(a, stream, f0, tid, lds.data());
-            }
-        }
-        const uint32_t tg1 = f1 * 36;
-        for (uint32_t base = f0 * 36; base < tg1; base += kStep) {
-            for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_dct(a, stream, base, tg1, tid, lds.data());
-            for (int tid = 0; tid < kAudioThreads; tid++) {
-                if (a.fma)
-                    audio_phase_window<true>(a, stream, vpos0, base, tg1, tid, lds.data());
-                else
-                    audio_phase_window<false>(a, stream, vpos0, base, tg1, tid, lds.data());
-            }
-        }
-        if (f1 == a.n_frames) {
-            for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_store_state(a, stream, vpos0, tid, lds.data());
-            audio_store_vpos(a, stream, vpos0);
-        }
-    }
+    if (dw == 4)
+        emu_audio_blocks<4>(a);
+    else if (dw == 2)
+        emu_audio_blocks<2>(a);
+    else
+        emu_audio_blocks<1>(a);
     memcpy(ring, ring_out.data(), ring_out.size() * sizeof(float));
     memcpy(vpos, vpos_out.data(), vpos_out.size() * sizeof(int32_t));
     return 0;

@@ -29,3 +29,21 @@ def run_and_compare(ref_store, dut_store, seq, check_rgba=False, stream=0):
 
 def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+def mirror_ring(X):
+    """Audio.v contents from 32 DCT outputs per slot: X[2, 16, 32] -> v[2, 1024] (audio.go:708-771:
+    d[48-k] = d[48+k] = -X[k], d[k-16] = X[k], d[16] = 0)."""
+    X = np.asarray(X, np.float32)
+    v = np.zeros((2, 16, 64), np.float32)
+    for k in range(32):
+        if k <= 16:
+            v[:, :, 48 - k] = -X[:, :, k]
+        if 1 <= k <= 15:
+            v[:, :, 48 + k] = -X[:, :, k]
+        if k >= 17:
+            v[:, :, 48 - k] = -X[:, :, k]
+            v[:, :, k - 16] = X[:, :, k]
+        if k == 16:
+            v[:, :, 0] = X[:, :, k]
+    return v.reshape(2, 1024)

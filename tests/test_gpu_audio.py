@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from mpeg_amd import abi, desc, synth
-from parity import bits_equal
+from parity import bits_equal, mirror_ring
 
 pytestmark = pytest.mark.gpu
 
@@ -72,12 +72,49 @@ def test_time_slicing_is_bit_identical(oracle, hip_ctx, chunks, monkeypatch):
     dut.close()
 
 
-def test_zero_frames_and_rewind_semantics(hip_ctx):
+def test_zero_frames_and_state_transplant(oracle, hip_ctx):
+    s = synth.audio_frames(1, 4)
+    src = abi.AudioSynth(hip_ctx, 1)
+    src.synth(s[:, :3])
+    v, p = src.get_state(0)          # a genuine Audio.v / vPos
     dut = abi.AudioSynth(hip_ctx, 1)
-    v = np.arange(2048, dtype=np.float32).reshape(2, 1024)
-    dut.set_state(0, v, 192)
+    dut.set_state(0, v, p)
     out = dut.synth(np.zeros((1, 0, 2, 36, 32), np.int32))
     assert out.shape == (1, 0, 2304)
     v2, p2 = dut.get_state(0)
-    assert p2 == 192 and bits_equal(v, v2)
+    assert p2 == p and bits_equal(v, v2)
+    # the transplanted stream continues exactly like the original (and like the oracle)
+    ref = oracle.OracleSynth(1, 0)
+    ref.synth(s[:, :3], desc.AUDIO_F32N)
+    want = ref.synth(s[:, 3:], desc.AUDIO_F32N)
+    assert bits_equal(src.synth(s[:, 3:]), want) and bits_equal(dut.synth(s[:, 3:]), want)
+    src.close()
+    dut.close()
+
+
+def test_set_state_refuses_a_ring_that_is_not_a_synthesis_state(hip_ctx):
+    """Audio.v slots are signed mirrors of 32 DCT outputs; anything else cannot come from the reference."""
+    dut = abi.AudioSynth(hip_ctx, 1)
+    with pytest.raises(abi.MpegHipError) as ei:
+        dut.set_state(0, np.arange(2048, dtype=np.float32).reshape(2, 1024), 192)
+    assert ei.value.code == abi.ERR_INVALID
+    dut.set_state(0, np.zeros((2, 1024), np.float32), 192)  # zeros (a fresh decoder) are fine
+    for bad in (-64, 1024, 100):
+        with pytest.raises(abi.MpegHipError):
+            dut.set_state(0, None, bad)
+    dut.close()
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -125, 2.0 ** -140, 1.0])
+def test_scaling_of_tiny_sums(oracle, hip_ctx, scale):
+    """Outputs whose window sums fall inside 2^-119..2^-95 must take the kernel's IEEE division (the
+    short form is only proven outside, tests/proofs/div_const.c)."""
+    rng = np.random.default_rng(5)
+    v = mirror_ring(rng.integers(-999, 1000, (2, 16, 32)).astype(np.float32) * np.float32(scale))
+    ref, dut = oracle.OracleSynth(1, 0), abi.AudioSynth(hip_ctx, 1)
+    ref.set_state(0, v, 320)
+    dut.set_state(0, v, 320)
+    s = np.zeros((1, 1, 2, 36, 32), np.int32)
+    a, b = ref.synth(s, desc.AUDIO_F32N), dut.synth(s, desc.AUDIO_F32N)
+    assert bits_equal(a, b) and np.count_nonzero(a) > 500
     dut.close()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from mpeg_amd import desc, synth
-from parity import bits_equal, run_and_compare
+from parity import bits_equal, mirror_ring, run_and_compare
 
 
 @pytest.mark.parametrize("w,h,n,profile,raw,rgba", [
@@ -82,16 +82,35 @@ def test_audio_lane_logic_matches_oracle(oracle, emu, fma, fmt):
             assert pa == pb and bits_equal(va, vb)
 
 
-@pytest.mark.parametrize("chunks", [2, 3, 7])
-def test_audio_time_slices_are_bit_identical(oracle, emu, chunks):
-    """Splitting a launch along time (history rebuilt from the samples) must not change a single bit."""
+@pytest.mark.parametrize("dw", [1, 2, 4])
+@pytest.mark.parametrize("chunks", [1, 2, 3, 7])
+def test_audio_time_slices_are_bit_identical(oracle, emu, chunks, dw):
+    """Splitting a launch along time (history rebuilt from the samples) must not change a single bit;
+    neither may the number of DCT waves (super-step 32/64/128 sub-blocks, different ring sizes)."""
     s = synth.audio_frames(2, 9)
-    o, e = oracle.OracleSynth(2, 0), emu.EmuSynth(2, 0, chunks=chunks)
+    o, e = oracle.OracleSynth(2, 0), emu.EmuSynth(2, 0, chunks=chunks, dw=dw)
     for _ in range(2):
         assert bits_equal(o.synth(s, desc.AUDIO_F32N), e.synth(s, desc.AUDIO_F32N))
         for st in range(2):
             (va, pa), (vb, pb) = o.get_state(st), e.get_state(st)
             assert pa == pb and bits_equal(va, vb)
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -125, 2.0 ** -140, 1.0])
+def test_audio_scaling_of_tiny_sums_takes_the_long_division(oracle, emu, scale):
+    """Sums inside 2^-119..2^-95 are where the short division is not proven (tests/proofs); a
+    history of tiny values and silent samples puts every output there."""
+    rng = np.random.default_rng(5)
+    v = mirror_ring(rng.integers(-999, 1000, (2, 16, 32)).astype(np.float32) * np.float32(scale))
+    o, e = oracle.OracleSynth(1, 0), emu.EmuSynth(1, 0)
+    o.set_state(0, v, 320)
+    e.set_state(0, v, 320)
+    s = np.zeros((1, 1, 2, 36, 32), np.int32)
+    a, b = o.synth(s, desc.AUDIO_F32N), e.synth(s, desc.AUDIO_F32N)
+    assert bits_equal(a, b) and np.count_nonzero(a) > 500
+    if scale == 2.0 ** -125:
+        mag = np.abs(a[a != 0]) * 1090519040.0
+        assert ((mag > 2.0 ** -119) & (mag < 2.0 ** -95)).mean() > 0.5
 
 
 @pytest.mark.parametrize("fma,want", [(0, 0xf1b76cdf8e6cdea5), (1, 0x50f3ab75f5fb0fb5)])
