@@ -10,20 +10,26 @@
 // MPEGHIP_AUDIO_FMA_WINDOW mode, taps are accumulated in the reference's ring
 // order (which depends on vPos), the output is a true IEEE division.
 //
-// Data flow per super-step of kStep = 32*DW sub-blocks (both channels; 4 waves per workgroup):
-//   phase D: DW waves run 64 32-point DCTs each, one per lane (channel x 32 sub-blocks), entirely in
-//            registers.  idct36's 64 outputs d[0..63] are a signed mirror of the 32 DCT outputs X[k]
-//            (audio.go:708-771: d[48-k] = d[48+k] = -X[k], d[k-16] = X[k], d[16] = 0), so only X is
-//            kept: a time-indexed history in LDS, slot = [channel][32] (+1 pad).  The reference's
-//            1024-entry ring only ever holds the last 16 slots.
-//   phase W: a wave owns sub-blocks t and t+16 at a time, lane = channel*32 + sample.  Which history
-//            slots and window segments the 16 taps read, and in which order, depends only on the ring
-//            position (16 cases, the same for t and t+16), which is wave-uniform: the wave branches
-//            once to a fully unrolled variant whose LDS reads are "per-lane base + immediate".  The
-//            lane's 16 window coefficients live in registers with the mirror's sign folded in
-//            (even segments always meet d[0..31], odd ones d[32..63]).  To keep the offsets immediate
-//            across the ring wrap, the first 15 slots are repeated behind the ring, so "the 16 slots
-//            ending at T" are always contiguous.
+// Data flow (4 waves per workgroup, steps of 32 sub-blocks, both channels):
+//   DCT:    one wave runs the step's 64 32-point DCTs, one per lane (channel x 32 sub-blocks),
+//           entirely in registers.  idct36's 64 outputs d[0..63] are a signed mirror of the 32 DCT
+//           outputs X[k] (audio.go:708-771: d[48-k] = d[48+k] = -X[k], d[k-16] = X[k], d[16] = 0),
+//           so only X is kept: a time-indexed history in LDS, slot = [channel][32] (+1 pad).  The
+//           reference's 1024-entry ring only ever holds the last 16 slots.
+//   window: a wave owns sub-blocks t and t+16 at a time, lane = channel*32 + sample.  Which history
+//           slots and window segments the 16 taps read, and in which order, depends only on the ring
+//           position (16 cases, the same for t and t+16), which is wave-uniform: the wave branches
+//           once to a fully unrolled variant whose LDS reads are "per-lane base + immediate".  The
+//           lane's 16 window coefficients live in registers with the mirror's sign folded in
+//           (even segments always meet d[0..31], odd ones d[32..63]).  To keep the offsets immediate
+//           across the ring wrap, the first 15 slots are repeated behind the ring, so "the 16 slots
+//           ending at T" are always contiguous.
+//   pipeline: the history ring holds 79 slots, so the DCTs of step s+1 never touch a slot the
+//           windows of step s read.  Iteration s therefore runs, between two barriers, DCT(s+1) on
+//           wave (s+1)%4 (plus one window pair) and window(s) on the other three waves (five pairs
+//           each), while wave (s+2)%4 has the samples of step s+2 in flight from HBM straight into
+//           an LDS staging buffer (global_load_lds, two buffers): one barrier per step, no wave
+//           idles through the DCT or its HBM latency, no registers are held across it.
 //
 // Time slicing: a sub-block depends on the previous 15 only through the history, and
 // every history slot is a pure function of one sub-block's samples.  So the frames of one
@@ -57,12 +63,11 @@ constexpr int kMirrorSlots = 15;                      // ring slots 0..14 are re
 constexpr int kSlotStride = 65;                       // floats per slot: [channel 2][32] + 1 pad
 constexpr int kT0 = 16;                               // local time of the launch's first sub-block
 
-// DW = waves that run DCTs in phase D
-template <int DW> struct AudioCfg {
-    static constexpr int kStep = 32 * DW;             // sub-blocks per super-step
-    static constexpr int kRing = kStep + 16;          // >= kStep + 15: the window reaches 15 sub-blocks back
-    static constexpr int kLdsFloats = (kRing + kMirrorSlots) * kSlotStride;
-};
+constexpr int kStep = 32;                             // sub-blocks per step: 64 DCTs = one full wave
+constexpr int kRing = 2 * kStep + 15;                 // DCT(s+1) writes [b+32, b+64) while window(s) reads [b-15, b+32)
+constexpr int kStageFloats = 64 * 32;                 // one step's samples: [8 x 16 bytes][64 lanes]
+constexpr int kHistBase = 2 * kStageFloats;           // LDS: two staging buffers, then the history
+constexpr int kAudioLdsFloats = kHistBase + (kRing + kMirrorSlots) * kSlotStride; // 40824 bytes: 4 workgroups per CU
 
 // c_N[i] = 0.5 / cos((2i+1)*pi/(2N)); identical float32 values to the decimal
 // literals of audio.go:498-661.
@@ -111,20 +116,25 @@ struct Dct<1> {
     static MPG_HDM void run(float (&)[1]) {}
 };
 
-// idct36 for one (channel, sub-block) up to the mirror: s = 32 sub-band samples, v = the history
-// slot (at this channel's offset) that receives X[0..31]; v2 = its repeat behind the ring or nullptr.
-MPG_HD void matrixing(const int32_t *s, float *v, float *v2)
+// the 32 sub-band samples of one (channel, sub-block), 8 x 16 bytes `stride` ints apart
+MPG_HD void load_samples(const int32_t *s, int stride, int32_t (&in)[32])
 {
-    float e[16], o[16];
-    int32_t in[32];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const i32x4 g = reinterpret_cast<const i32x4 *>(s)[q];
+        i32x4 g;
+        __builtin_memcpy(&g, s + q * stride, 16);
         in[4 * q + 0] = g.v[0];
         in[4 * q + 1] = g.v[1];
         in[4 * q + 2] = g.v[2];
         in[4 * q + 3] = g.v[3];
     }
+}
+
+// idct36 for one (channel, sub-block) up to the mirror: v = the history slot (at this channel's
+// offset) that receives X[0..31]; v2 = its repeat behind the ring or nullptr.
+MPG_HD void matrixing(const int32_t (&in)[32], float *v, float *v2)
+{
+    float e[16], o[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { // audio.go:497-528: integer sum/difference, then float32
         e[i] = (float)(in[i] + in[31 - i]);
@@ -164,10 +174,10 @@ template <bool kFma> MPG_HD float tap(float acc, float d, float v)
 // ring position of the slot written at local time T (Audio.vPos after that sub-block, audio.go:383)
 MPG_HD int32_t vpos_at(int32_t vpos0, int32_t T) { return (vpos0 - 64 * (T - kT0 + 1)) & 1023; }
 
-template <int DW> MPG_HD int ring_slot(int32_t T) { return (int)((uint32_t)T % (uint32_t)AudioCfg<DW>::kRing); }
+MPG_HD int ring_slot(int32_t T) { return (int)((uint32_t)T % (uint32_t)kRing); }
 
 // ---- state in: Audio.v ring -> time-indexed X history (item = channel, slot time, k)
-template <int DW> MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, float *lds)
+MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, float *lds)
 {
     const float *ring = a.ring + (uint64_t)stream * 2048;
     for (int idx = tid; idx < 1024; idx += kAudioThreads) {
@@ -175,7 +185,7 @@ template <int DW> MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stre
         const int e0 = 64 * (kT0 - 1 - T);                           // slot vpos0 holds the newest block (time T0-1)
         const int x = k <= 16 ? 48 - k : k - 16;
         const float d = ring[ch * 1024 + ((vpos0 + e0 + x) & 1023)];
-        lds[ring_slot<DW>(T) * kSlotStride + ch * 32 + k] = k <= 16 ? -d : d;
+        lds[kHistBase + ring_slot(T) * kSlotStride + ch * 32 + k] = k <= 16 ? -d : d;
     }
 }
 
@@ -191,22 +201,30 @@ MPG_HD void audio_load_window(const AudioArgs &a, int tid, float (&dreg)[16])
     }
 }
 
-// one DCT: sub-block tg (counted from the launch's first) of channel ch -> its history slot (+ repeat)
-template <int DW> MPG_HD void hist_matrixing(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, float *lds)
+MPG_HD const int32_t *samples_of(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch)
 {
     const uint32_t f = tg / 36, t = tg % 36;
-    const int32_t slot = ring_slot<DW>(kT0 + (int32_t)tg);
-    const int32_t *s = a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + t * 32;
-    float *v = lds + slot * kSlotStride + ch * 32;
-    matrixing(s, v, slot < kMirrorSlots ? v + AudioCfg<DW>::kRing * kSlotStride : nullptr);
+    return a.samples + (((uint64_t)stream * a.n_frames + f) * 2 + (uint32_t)ch) * 1152 + t * 32;
+}
+
+// one DCT: sub-block tg (counted from the launch's first) of channel ch -> its history slot (+ repeat)
+MPG_HD void hist_matrixing(const int32_t (&in)[32], uint32_t tg, int ch, float *lds)
+{
+    const int32_t slot = ring_slot(kT0 + (int32_t)tg);
+    float *v = lds + kHistBase + slot * kSlotStride + ch * 32;
+    matrixing(in, v, slot < kMirrorSlots ? v + kRing * kSlotStride : nullptr);
 }
 
 // ---- history rebuild for a slice that starts at frame f0 > 0: the 15 sub-blocks before it
-template <int DW> MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t f0, int tid, float *lds)
+MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t f0, int tid, float *lds)
 {
-    if (tid >= 30)
+    if (tid < 128 || tid >= 128 + 30) // wave 2: waves 0 and 1 issue the first two fetches
         return;
-    hist_matrixing<DW>(a, stream, f0 * 36 - 15 + (uint32_t)(tid % 15), tid / 15, lds);
+    const int ch = (tid - 128) / 15;
+    const uint32_t tg = f0 * 36 - 15 + (uint32_t)((tid - 128) % 15);
+    int32_t in[32];
+    load_samples(samples_of(a, stream, tg, ch), 4, in);
+    hist_matrixing(in, tg, ch, lds);
 }
 
 // frames [f0, f1) of time slice `chunk`
@@ -217,19 +235,39 @@ MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, 
     f1 = f0 + per < a.n_frames ? f0 + per : a.n_frames;
 }
 
-// ---- phase D: DW waves; lane (channel, j) of the q-th of them transforms sub-block base + 32q + j.
-// The DCT waves rotate from step to step so that the workgroups resident on a CU do not all load
-// the same SIMD.
-template <int DW>
-MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t base, uint32_t tg1, int tid, float *lds)
+// the wave that runs the DCTs of step `si` (counted from the slice's first): it rotates so that the
+// workgroups resident on a CU do not all load the same SIMD
+MPG_HD uint32_t dct_wave(uint32_t si) { return si % kAudioWaves; }
+
+// ---- samples of step si -> staging buffer si&1, issued by wave si%4 (lane = channel*32 + j); they
+// have landed after the next barrier
+MPG_HD void audio_phase_fetch(const AudioArgs &a, uint32_t stream, uint32_t tg0, uint32_t tg1, uint32_t si, int tid, float *lds)
 {
-    const uint32_t rot = (base / AudioCfg<DW>::kStep * DW) % kAudioWaves;
-    const uint32_t q = ((uint32_t)(tid >> 6) - rot) % kAudioWaves;
-    if (q >= (uint32_t)DW)
+    if ((uint32_t)(tid >> 6) != dct_wave(si))
         return;
-    const uint32_t tg = base + 32 * q + (uint32_t)(tid & 31);
-    if (tg < tg1)
-        hist_matrixing<DW>(a, stream, tg, (tid >> 5) & 1, lds);
+    const int lane = tid & 63;
+    const uint32_t tg = tg0 + si * kStep + (uint32_t)(lane & 31);
+    if (tg >= tg1)
+        return;
+    const int32_t *src = samples_of(a, stream, tg, lane >> 5);
+    float *stage = lds + (si & 1) * kStageFloats;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        copy16_to_lds(src + 4 * q, stage + q * 256, lane);
+}
+
+// ---- DCTs of step si from its staging buffer, on wave si%4
+MPG_HD void audio_phase_dct(uint32_t tg0, uint32_t tg1, uint32_t si, int tid, float *lds)
+{
+    if ((uint32_t)(tid >> 6) != dct_wave(si))
+        return;
+    const int lane = tid & 63;
+    const uint32_t tg = tg0 + si * kStep + (uint32_t)(lane & 31);
+    if (tg >= tg1)
+        return;
+    int32_t in[32];
+    load_samples(reinterpret_cast<const int32_t *>(lds + (si & 1) * kStageFloats) + lane * 4, 256, in);
+    hist_matrixing(in, tg, lane >> 5, lds);
 }
 
 // The 16 taps of one output sample of two sub-blocks when the ring position is 64*M
@@ -305,65 +343,70 @@ MPG_HD float scale_short(float x)
 }
 
 // convert (audio.go:386-418) and store one sample of sub-block tg
+template <int kFormat>
 MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, int i, float sv)
 {
     const uint32_t f = tg / 36, t = tg % 36;
     const uint64_t fb = ((uint64_t)stream * a.n_frames + f) * 2304;
     const uint32_t o = t * 32 + (uint32_t)i;
-    switch (a.format) {
-    case MPEGHIP_AUDIO_F32N:
+    if (kFormat == MPEGHIP_AUDIO_F32N)
         reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv;
-        break;
-    case MPEGHIP_AUDIO_F32NLR:
+    else if (kFormat == MPEGHIP_AUDIO_F32NLR)
         reinterpret_cast<float *>(a.out)[fb + (uint32_t)ch * 1152 + o] = sv;
-        break;
-    case MPEGHIP_AUDIO_S16: // audio.go:400-408
+    else if (kFormat == MPEGHIP_AUDIO_S16) // audio.go:400-408
         reinterpret_cast<int16_t *>(a.out)[fb + 2 * o + (uint32_t)ch] = (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f);
-        break;
-    default: // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
+    else // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
         reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv * 2147483648.0f;
-        break;
-    }
 }
 
-// ---- phase W: per group of 32 sub-blocks, wave w takes the pairs (g + w + 4n, g + w + 4n + 16), n = 0..3;
-// lane = channel*32 + sample
-template <int DW, bool kFma>
-MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t base, uint32_t tg1, int tid,
-                               const float (&dreg)[16], const float *lds)
+// one window pair: sub-blocks tgA and tgA + 16 (same ring position modulo 16 slots, so the same taps)
+template <bool kFma, int kFormat>
+MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t tgA, uint32_t tg1, int ch, int i,
+                              const float *p0, const float *p1, const float (&dreg)[16])
 {
-    const int wave = uniform(tid >> 6), lane = tid & 63;
-    const int ch = lane >> 5, i = lane & 31;
-    const float *p0 = lds + ch * 32 + mirror_index(i);
-    const float *p1 = lds + ch * 32 + mirror_index(32 + i);
-    for (int n = 0; n < 4 * DW; n++) {
-        const uint32_t tgA = base + (uint32_t)(32 * (n >> 2) + wave + kAudioWaves * (n & 3)); // wave-uniform down to the taps
-        const uint32_t tgB = tgA + 16;
-        if (tgA >= tg1)
+    const uint32_t tgB = tgA + 16;
+    const int32_t TA = kT0 + (int32_t)tgA;
+    const int32_t m = vpos_at(vpos0, TA) >> 6; // == that of TA + 16
+    const int32_t slotA = ring_slot(TA), slotB = ring_slot(TA + 16);
+    const int32_t offA = ((slotA < kMirrorSlots ? slotA + kRing : slotA) - 15) * kSlotStride;
+    const int32_t offB = ((slotB < kMirrorSlots ? slotB + kRing : slotB) - 15) * kSlotStride;
+    float accA, accB;
+    window_dispatch<kFma>(m, p0 + offA, p1 + offA, p0 + offB, p1 + offB, dreg, accA, accB);
+    float svA, svB;
+    if (all_in_wave(scale_short_ok(accA) && scale_short_ok(accB))) {
+        svA = scale_short(accA);
+        svB = scale_short(accB);
+    } else {
+        svA = accA / kScale;
+        svB = accB / kScale;
+    }
+    audio_store_sample<kFormat>(a, stream, tgA, ch, i, svA);
+    if (tgB < tg1) // past the slice: B read stale history, drop it
+        audio_store_sample<kFormat>(a, stream, tgB, ch, i, svB);
+}
+
+// ---- windows of step si: 16 pairs (p, p + 16).  The wave that runs DCT(si + 1) in the same
+// iteration takes pair 15 only; the other three take p = rank, rank + 3, ... (five each).
+template <bool kFma, int kFormat>
+MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t tg0, uint32_t tg1, uint32_t si,
+                               int tid, const float (&dreg)[16], const float *lds)
+{
+    const uint32_t wave = (uint32_t)uniform(tid >> 6), busy = dct_wave(si + 1);
+    const int lane = tid & 63, ch = lane >> 5, i = lane & 31;
+    const float *p0 = lds + kHistBase + ch * 32 + mirror_index(i);
+    const float *p1 = lds + kHistBase + ch * 32 + mirror_index(32 + i);
+    const uint32_t base = tg0 + si * kStep;
+    const uint32_t rank = (wave - busy - 1) % kAudioWaves; // 0..2 for the three free waves, 3 for the busy one
+    const uint32_t first = rank == 3 ? 15 : rank, stride = rank == 3 ? 16 : 3, end = rank == 3 ? 16 : 15;
+    for (uint32_t p = first; p < end; p += stride) {
+        if (base + p >= tg1)
             break;
-        const int32_t TA = kT0 + (int32_t)tgA;
-        const int32_t m = vpos_at(vpos0, TA) >> 6; // == that of TA + 16
-        const int32_t slotA = ring_slot<DW>(TA), slotB = ring_slot<DW>(TA + 16);
-        const int32_t offA = ((slotA < kMirrorSlots ? slotA + AudioCfg<DW>::kRing : slotA) - 15) * kSlotStride;
-        const int32_t offB = ((slotB < kMirrorSlots ? slotB + AudioCfg<DW>::kRing : slotB) - 15) * kSlotStride;
-        float accA, accB;
-        window_dispatch<kFma>(m, p0 + offA, p1 + offA, p0 + offB, p1 + offB, dreg, accA, accB);
-        float svA, svB;
-        if (all_in_wave(scale_short_ok(accA) && scale_short_ok(accB))) {
-            svA = scale_short(accA);
-            svB = scale_short(accB);
-        } else {
-            svA = accA / kScale;
-            svB = accB / kScale;
-        }
-        audio_store_sample(a, stream, tgA, ch, i, svA);
-        if (tgB < tg1) // past the slice: B read stale history, drop it
-            audio_store_sample(a, stream, tgB, ch, i, svB);
+        audio_window_pair<kFma, kFormat>(a, stream, vpos0, base + p, tg1, ch, i, p0, p1, dreg);
     }
 }
 
 // ---- state out: last 16 history slots -> Audio.v ring; thread 0 advances vPos
-template <int DW> MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, const float *lds)
+MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0, int tid, const float *lds)
 {
     float *ring = a.ring_out + (uint64_t)stream * 2048;
     const int32_t Tend = kT0 + (int32_t)a.n_frames * 36; // first time NOT produced
@@ -372,7 +415,7 @@ template <int DW> MPG_HD void audio_store_state(const AudioArgs &a, uint32_t str
         const int ch = idx >> 10, ra = idx & 1023;
         const int e = (ra - vpos1) & 1023;
         const int T = Tend - 1 - (e >> 6), x = e & 63;
-        ring[idx] = mirror_apply(x, lds[ring_slot<DW>(T) * kSlotStride + ch * 32 + mirror_index(x)]);
+        ring[idx] = mirror_apply(x, lds[kHistBase + ring_slot(T) * kSlotStride + ch * 32 + mirror_index(x)]);
     }
 }
 

@@ -210,6 +210,20 @@ MPG_HD bool all_in_wave(bool pred)
 #endif
 }
 
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4, no registers in
+// between): lane l of the wave lands at lds_wave_base + 16*l.  The data is only guaranteed to be
+// there after the next __syncthreads() (hipcc drains vmcnt in front of the barrier).
+MPG_HD void copy16_to_lds(const void *g, void *lds_wave_base, int lane)
+{
+#if MPG_ON_DEVICE
+    (void)lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+#else
+    __builtin_memcpy(static_cast<char *>(lds_wave_base) + 16 * lane, g, 16);
+#endif
+}
+
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its
 // own L2).  Gives every XCD one contiguous range of work chunks so that
 // neighbouring macroblocks — which share 128-byte destination lines and overlapping

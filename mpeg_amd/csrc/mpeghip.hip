@@ -383,10 +383,9 @@ __global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32
     out[s] = h;
 }
 
-template <int DW, bool kFma> __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
+template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
 {
-    using Cfg = AudioCfg<DW>;
-    __shared__ __attribute__((aligned(16))) float lds[Cfg::kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kAudioLdsFloats];
     const uint32_t stream = blockIdx.x / a.n_chunks, chunk = blockIdx.x % a.n_chunks;
     const int tid = threadIdx.x;
     uint32_t f0, f1;
@@ -394,22 +393,27 @@ template <int DW, bool kFma> __global__ __launch_bounds__(kAudioThreads) void au
     if (f0 >= f1)
         return; // empty slice (wave-uniform, before any barrier)
     const int32_t vpos0 = a.vpos[stream];
+    const uint32_t tg0 = f0 * 36, tg1 = f1 * 36, n_steps = (tg1 - tg0 + kStep - 1) / kStep;
     float dreg[16];
     audio_load_window(a, tid, dreg);
+    // prologue: samples of steps 0 and 1 in flight, history from the state or rebuilt
+    audio_phase_fetch(a, stream, tg0, tg1, 0, tid, lds);
+    audio_phase_fetch(a, stream, tg0, tg1, 1, tid, lds);
     if (f0 == 0)
-        audio_load_state<DW>(a, stream, vpos0, tid, lds);
+        audio_load_state(a, stream, vpos0, tid, lds);
     else
-        audio_phase_warmup<DW>(a, stream, f0, tid, lds);
+        audio_phase_warmup(a, stream, f0, tid, lds);
     __syncthreads();
-    const uint32_t tg1 = f1 * 36;
-    for (uint32_t base = f0 * 36; base < tg1; base += Cfg::kStep) {
-        audio_phase_dct<DW>(a, stream, base, tg1, tid, lds);
-        __syncthreads();
-        audio_phase_window<DW, kFma>(a, stream, vpos0, base, tg1, tid, dreg, lds);
+    audio_phase_dct(tg0, tg1, 0, tid, lds);
+    __syncthreads();
+    for (uint32_t si = 0; si < n_steps; si++) {
+        audio_phase_fetch(a, stream, tg0, tg1, si + 2, tid, lds); // wave (si+2)%4 -> the buffer DCT(si) has left
+        audio_phase_dct(tg0, tg1, si + 1, tid, lds);               // wave (si+1)%4, fetched an iteration ago
+        audio_phase_window<kFma, kFormat>(a, stream, vpos0, tg0, tg1, si, tid, dreg, lds);
         __syncthreads();
     }
     if (f1 == a.n_frames) { // the slice that ends the launch owns the state hand-over
-        audio_store_state<DW>(a, stream, vpos0, tid, lds);
+        audio_store_state(a, stream, vpos0, tid, lds);
         if (tid == 0)
             audio_store_vpos(a, stream, vpos0);
     }
@@ -1373,14 +1377,14 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     args.n_frames = n_frames;
     args.format = format;
     args.fma = a->fma;
-    // time slices per stream: enough workgroups to fill the GPU (~8 per CU), at least 4 frames per slice
+    // time slices per stream: one full residency of workgroups (4 per CU), at least 4 frames per slice
     uint32_t chunks = 1;
     if (const char *e = getenv("MPEGHIP_AUDIO_CHUNKS")) { // development knob
         chunks = (uint32_t)atoi(e);
     } else {
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, a->ctx->device);
-        const uint32_t want = ((uint32_t)n_cu * 8 + a->n_streams - 1) / a->n_streams;
+        const uint32_t want = ((uint32_t)n_cu * 4 + a->n_streams - 1) / a->n_streams;
         chunks = want < 1 ? 1 : want;
         if (chunks > n_frames / 4)
             chunks = n_frames / 4;
@@ -1390,23 +1394,20 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     if (chunks > n_frames)
         chunks = n_frames;
     args.n_chunks = chunks;
-    int dw = 2; // DCT waves per workgroup (A/B on MI355X: 2 > 4 > 1)
-    if (const char *e = getenv("MPEGHIP_AUDIO_DW")) // development knob
-        dw = atoi(e);
     const dim3 grid(a->n_streams * chunks), block(kAudioThreads);
-#define LAUNCH_AUDIO(DW)                                                                      \
-    do {                                                                                      \
-        if (args.fma)                                                                         \
-            hipLaunchKernelGGL((audio_kernel<DW, true>), grid, block, 0, a->ctx->stream, args);  \
-        else                                                                                  \
-            hipLaunchKernelGGL((audio_kernel<DW, false>), grid, block, 0, a->ctx->stream, args); \
+#define LAUNCH_AUDIO(FMT)                                                                        \
+    do {                                                                                         \
+        if (args.fma)                                                                            \
+            hipLaunchKernelGGL((audio_kernel<true, FMT>), grid, block, 0, a->ctx->stream, args);  \
+        else                                                                                     \
+            hipLaunchKernelGGL((audio_kernel<false, FMT>), grid, block, 0, a->ctx->stream, args); \
     } while (0)
-    if (dw == 4)
-        LAUNCH_AUDIO(4);
-    else if (dw == 2)
-        LAUNCH_AUDIO(2);
-    else
-        LAUNCH_AUDIO(1);
+    switch (format) {
+    case MPEGHIP_AUDIO_F32N: LAUNCH_AUDIO(MPEGHIP_AUDIO_F32N); break;
+    case MPEGHIP_AUDIO_F32NLR: LAUNCH_AUDIO(MPEGHIP_AUDIO_F32NLR); break;
+    case MPEGHIP_AUDIO_S16: LAUNCH_AUDIO(MPEGHIP_AUDIO_S16); break;
+    default: LAUNCH_AUDIO(MPEGHIP_AUDIO_F32); break;
+    }
 #undef LAUNCH_AUDIO
     HIP_TRY(hipGetLastError());
     { // the launch wrote the new state into the alternate buffers

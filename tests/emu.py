@@ -48,7 +48,7 @@ def lib():
         L.emu_rgba_convert.restype = None
         L.emu_rgba_convert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P]
         L.emu_audio_run.restype = C.c_int
-        L.emu_audio_run.argtypes = [P, P, P, P, P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32]
+        L.emu_audio_run.argtypes = [P, P, P, P, P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32]
         for n in ("emu_avg4", "emu_avg2", "emu_xcd_chunk", "emu_ycbcr"):
             getattr(L, n).restype = C.c_uint32
         L.emu_avg4.argtypes = [C.c_uint32] * 4
@@ -161,8 +161,8 @@ class EmuStore:
 
 
 class EmuSynth:
-    def __init__(self, n_streams=1, fma=0, chunks=1, dw=1):
-        self.n_streams, self.fma, self.chunks, self.dw = n_streams, fma, chunks, dw
+    def __init__(self, n_streams=1, fma=0, chunks=1):
+        self.n_streams, self.fma, self.chunks = n_streams, fma, chunks
         self.ring = np.zeros((n_streams, 2, 1024), np.float32)
         self.vpos = np.zeros(n_streams, np.int32)
         self.window = (np.array(_window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
@@ -172,7 +172,7 @@ class EmuSynth:
         n_frames = s.shape[1]
         out = np.zeros((self.n_streams, n_frames, 2304), np.int16 if fmt == desc.AUDIO_S16 else np.float32)
         rc = lib().emu_audio_run(_ptr(s), _ptr(out), _ptr(self.ring), _ptr(self.vpos), _ptr(self.window),
-                                 self.n_streams, n_frames, fmt, self.fma, self.chunks, self.dw)
+                                 self.n_streams, n_frames, fmt, self.fma, self.chunks)
         assert rc == 0
         return out
 

@@ -335,12 +335,17 @@ void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, ui
             rgba_convert_quad(frame, luma_w, luma_w / 2, luma_w * luma_h, luma_w * luma_h / 4, width, height, x4, y, rgba);
 }
 
-// audio_kernel<DW>: n_chunks workgroups (time slices) per stream; ring / vpos are updated in place for the
-// caller (the kernel writes them to the alternate buffers, emulated with a copy).
 } // extern "C"
-template <int DW> static void emu_audio_blocks(const AudioArgs &a)
+
+// audio_kernel: n_chunks workgroups (time slices) per stream; ring / vpos are updated in place for the
+// caller (the kernel writes them to the alternate buffers, emulated with a copy).  Between two
+// barriers the kernel's waves run different phases concurrently; the emulation runs them in the
+// order that would expose a hazard (the DCTs of step s+1 BEFORE the windows of step s).
+template <bool kFma, int kFormat> static void emu_audio_blocks(const AudioArgs &a)
 {
-    std::vector<float> lds(AudioCfg<DW>::kLdsFloats);
+    std::vector<float> lds(kAudioLdsFloats);
+    struct Regs { float dreg[16]; };
+    std::vector<Regs> regs(kAudioThreads);
     for (uint32_t blk = 0; blk < a.n_streams * a.n_chunks; blk++) {
         const uint32_t stream = blk / a.n_chunks, chunk = blk % a.n_chunks;
         uint32_t f0, f1;
@@ -350,36 +355,48 @@ template <int DW> static void emu_audio_blocks(const AudioArgs &a)
         for (auto &x : lds)
             x = 1e30f; // poison
         const int32_t vpos0 = a.vpos[stream];
+        const uint32_t tg0 = f0 * 36, tg1 = f1 * 36, n_steps = (tg1 - tg0 + kStep - 1) / kStep;
         for (int tid = 0; tid < kAudioThreads; tid++) {
+            audio_load_window(a, tid, regs[tid].dreg);
+            audio_phase_fetch(a, stream, tg0, tg1, 0, tid, lds.data());
+            audio_phase_fetch(a, stream, tg0, tg1, 1, tid, lds.data());
             if (f0 == 0)
-                audio_load_state<DW>(a, stream, vpos0, tid, lds.data());
+                audio_load_state(a, stream, vpos0, tid, lds.data());
             else
-                audio_phase_warmup<DW>(a, stream, f0, tid, lds.data());
+                audio_phase_warmup(a, stream, f0, tid, lds.data());
         }
-        const uint32_t tg1 = f1 * 36;
-        for (uint32_t base = f0 * 36; base < tg1; base += AudioCfg<DW>::kStep) {
+        for (int tid = 0; tid < kAudioThreads; tid++)
+            audio_phase_dct(tg0, tg1, 0, tid, lds.data());
+        for (uint32_t si = 0; si < n_steps; si++) {
+            // a fetch only lands at the barrier: emulate by running it AFTER the DCT that shares the iteration
             for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_dct<DW>(a, stream, base, tg1, tid, lds.data());
-            for (int tid = 0; tid < kAudioThreads; tid++) {
-                float dreg[16]; // a register array of the thread, loaded once in the kernel
-                audio_load_window(a, tid, dreg);
-                if (a.fma)
-                    audio_phase_window<DW, true>(a, stream, vpos0, base, tg1, tid, dreg, lds.data());
-                else
-                    audio_phase_window<DW, false>(a, stream, vpos0, base, tg1, tid, dreg, lds.data());
-            }
+                audio_phase_dct(tg0, tg1, si + 1, tid, lds.data());
+            for (int tid = 0; tid < kAudioThreads; tid++)
+                audio_phase_window<kFma, kFormat>(a, stream, vpos0, tg0, tg1, si, tid, regs[tid].dreg, lds.data());
+            for (int tid = 0; tid < kAudioThreads; tid++)
+                audio_phase_fetch(a, stream, tg0, tg1, si + 2, tid, lds.data());
         }
         if (f1 == a.n_frames) {
             for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_store_state<DW>(a, stream, vpos0, tid, lds.data());
+                audio_store_state(a, stream, vpos0, tid, lds.data());
             audio_store_vpos(a, stream, vpos0);
         }
     }
 }
 
+template <bool kFma> static void emu_audio_format(const AudioArgs &a)
+{
+    switch (a.format) {
+    case MPEGHIP_AUDIO_F32N: return emu_audio_blocks<kFma, MPEGHIP_AUDIO_F32N>(a);
+    case MPEGHIP_AUDIO_F32NLR: return emu_audio_blocks<kFma, MPEGHIP_AUDIO_F32NLR>(a);
+    case MPEGHIP_AUDIO_S16: return emu_audio_blocks<kFma, MPEGHIP_AUDIO_S16>(a);
+    default: return emu_audio_blocks<kFma, MPEGHIP_AUDIO_F32>(a);
+    }
+}
+
 extern "C" {
 int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos, const float *window,
-                  uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks, int32_t dw)
+                  uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks)
 {
     if (n_frames == 0)
         return 0;
@@ -398,12 +415,10 @@ int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos,
     a.format = format;
     a.fma = fma;
     a.n_chunks = n_chunks < 1 ? 1 : (n_chunks > n_frames ? n_frames : n_chunks);
-    if (dw == 4)
-        emu_audio_blocks<4>(a);
-    else if (dw == 2)
-        emu_audio_blocks<2>(a);
+    if (fma)
+        emu_audio_format<true>(a);
     else
-        emu_audio_blocks<1>(a);
+        emu_audio_format<false>(a);
     memcpy(ring, ring_out.data(), ring_out.size() * sizeof(float));
     memcpy(vpos, vpos_out.data(), vpos_out.size() * sizeof(int32_t));
     return 0;

@@ -82,13 +82,11 @@ def test_audio_lane_logic_matches_oracle(oracle, emu, fma, fmt):
             assert pa == pb and bits_equal(va, vb)
 
 
-@pytest.mark.parametrize("dw", [1, 2, 4])
 @pytest.mark.parametrize("chunks", [1, 2, 3, 7])
-def test_audio_time_slices_are_bit_identical(oracle, emu, chunks, dw):
-    """Splitting a launch along time (history rebuilt from the samples) must not change a single bit;
-    neither may the number of DCT waves (super-step 32/64/128 sub-blocks, different ring sizes)."""
+def test_audio_time_slices_are_bit_identical(oracle, emu, chunks):
+    """Splitting a launch along time (history rebuilt from the samples) must not change a single bit."""
     s = synth.audio_frames(2, 9)
-    o, e = oracle.OracleSynth(2, 0), emu.EmuSynth(2, 0, chunks=chunks, dw=dw)
+    o, e = oracle.OracleSynth(2, 0), emu.EmuSynth(2, 0, chunks=chunks)
     for _ in range(2):
         assert bits_equal(o.synth(s, desc.AUDIO_F32N), e.synth(s, desc.AUDIO_F32N))
         for st in range(2):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the audio kernel's DCT waves (MPEGHIP_AUDIO_DW) and time slicing (MPEGHIP_AUDIO_CHUNKS) on BASELINE config 4 (256 streams x 100 frames)."""
+"""A/B of the audio kernel's time slicing (MPEGHIP_AUDIO_CHUNKS) on BASELINE config 4 (256 streams x 100 frames)."""
 import os
 import sys
 from pathlib import Path
@@ -17,9 +17,7 @@ smp = synth.audio_frames(streams, frames)
 d_s, d_o = a.device_buffers(frames, desc.AUDIO_F32N)
 a.upload(d_s, smp)
 only = os.environ.get("MPEGHIP_AB_ONLY")
-for dw, chunks in ([(os.environ.get("MPEGHIP_AUDIO_DW", "1"), only)] if only else
-                   [(d, c) for d in ("1", "2", "4") for c in ("1", "4", "8", "auto")]):
-    os.environ["MPEGHIP_AUDIO_DW"] = dw
+for chunks in ([only] if only else ["1", "2", "4", "8", "16", "auto"]):
     if chunks == "auto":
         os.environ.pop("MPEGHIP_AUDIO_CHUNKS", None)
     else:
@@ -35,5 +33,5 @@ for dw, chunks in ([(os.environ.get("MPEGHIP_AUDIO_DW", "1"), only)] if only els
         ts.append(ctx.timer_stop_ms() / 3)
     ms = float(np.median(ts))
     nbytes = streams * frames * 18432
-    print("dw %s chunks %-5s %8.3f ms  %7.1f G pairs/s  %7.1f GB/s alg (%.1f%% of 8 TB/s)" %
-          (dw, chunks, ms, streams * frames * 1152 / ms / 1e6, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80))
+    print("chunks %-5s %8.3f ms  %7.1f G pairs/s  %7.1f GB/s alg (%.1f%% of 8 TB/s)" %
+          (chunks, ms, streams * frames * 1152 / ms / 1e6, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80))
