@@ -181,6 +181,9 @@ typedef struct mpeghip_mb_desc {
 #define MPEGHIP_COEF_UNIT 128u
 
 /* Validate + copy descriptors to the device and reconstruct, stream ordered.
+ * Asynchronous: the arrays are copied into one of two pinned staging buffers and the call returns
+ * with the H2D copy and the kernel in flight, so the caller parses picture N+1 while picture N is
+ * reconstructed (the arrays may be reused at once; a third submit waits for the first).
  * Macroblocks of one submit must not overlap inside one picture (the emitter
  * starts a new submit when a damaged stream addresses a macroblock twice, so
  * "last writer in bitstream order" is kept by stream order).  Pictures of the

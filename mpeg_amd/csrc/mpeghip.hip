@@ -469,7 +469,16 @@ struct mpeghip_video {
     uint8_t *d_dump = nullptr;    // sink for the static-count stores of the pipelined kernel
     size_t dump_bytes = 0;
     uint64_t *d_hash = nullptr;
-    mpeghip_batch transient;
+    // mpeghip_video_submit: two descriptor batches with pinned host staging, used alternately, so
+    // that the caller can parse picture N+1 while picture N's copy and kernel are in flight
+    struct Staging {
+        mpeghip_batch batch;
+        uint8_t *h = nullptr;      // pinned
+        size_t cap_h = 0;
+        hipEvent_t done = nullptr; // recorded after the batch's kernel
+        bool in_flight = false;
+    } staging[2];
+    int next_staging = 0;
 };
 
 struct mpeghip_audio {
@@ -696,7 +705,7 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
         mpeghip_video_close(v);
         return rc;
     }
-    v->transient.owner = v;
+    v->staging[0].batch.owner = v->staging[1].batch.owner = v;
     *out = v;
     return MPEGHIP_OK;
 }
@@ -725,7 +734,13 @@ void mpeghip_video_close(mpeghip_video *v)
         return;
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
-    batch_release(&v->transient);
+    for (auto &sg : v->staging) {
+        batch_release(&sg.batch);
+        if (sg.h)
+            (void)hipHostFree(sg.h);
+        if (sg.done)
+            (void)hipEventDestroy(sg.done);
+    }
     if (v->d_frames)
         (void)hipFree(v->d_frames);
     if (v->d_rgba)
@@ -1027,9 +1042,12 @@ static bool wants_rgba(const mpeghip_pic_desc *pics, uint32_t n_pics)
     return false;
 }
 
+// `sg` != nullptr: b is that staging slot's batch; the host arrays are copied into its pinned buffer
+// and the call returns with the copies still in flight.  Otherwise (resident batches) the copies
+// read the caller's pageable memory and the call waits for them.
 static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_desc *pics, uint32_t n_pics,
                        const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
-                       uint32_t replicas)
+                       uint32_t replicas, mpeghip_video::Staging *sg = nullptr)
 {
     int rc = validate(v, pics, n_pics, mbs, n_mbs, coef_bytes, &b->alg_bytes, &b->dense_partition);
     b->any_rgba = wants_rgba(pics, n_pics);
@@ -1046,9 +1064,34 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
             return rc;
     }
     hipStream_t st = v->ctx->stream;
-    // the transient batch may still be in use by the previous submit
-    if (b == &v->transient)
-        HIP_TRY(hipStreamSynchronize(st));
+    if (sg) {
+        if (sg->in_flight) { // two submits ago: normally long finished
+            HIP_TRY(hipEventSynchronize(sg->done));
+            sg->in_flight = false;
+        }
+        const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics, mb = sizeof(mpeghip_mb_desc) * (size_t)n_mbs;
+        const size_t need = pb + mb + coef_bytes + 64;
+        if (need > sg->cap_h) {
+            if (sg->h)
+                (void)hipHostFree(sg->h);
+            sg->h = nullptr;
+            sg->cap_h = 0;
+            const size_t cap = need + need / 2;
+            HIP_TRY(hipHostMalloc((void **)&sg->h, cap, hipHostMallocDefault));
+            sg->cap_h = cap;
+        }
+        if (!sg->done)
+            HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
+        if (pb)
+            memcpy(sg->h, pics, pb);
+        if (mb)
+            memcpy(sg->h + pb, mbs, mb);
+        if (coef_bytes)
+            memcpy(sg->h + pb + mb, coefs, coef_bytes);
+        pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->h);
+        mbs = reinterpret_cast<const mpeghip_mb_desc *>(sg->h + pb);
+        coefs = sg->h + pb + mb;
+    }
     if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
         (rc = grow((void **)&b->d_mbs, &b->cap_mbs, sizeof(mpeghip_mb_desc) * (size_t)n_mbs * replicas + 32)) != 0 ||
         (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0 ||
@@ -1068,8 +1111,8 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
                            b->d_mbs, n_mbs, (uint32_t)(coef_bytes / MPEGHIP_COEF_UNIT), replicas);
         HIP_TRY(hipGetLastError());
     }
-    // pageable host memory: the copies above may still be reading it
-    HIP_TRY(hipStreamSynchronize(st));
+    if (!sg) // pageable host memory: the copies above may still be reading it
+        HIP_TRY(hipStreamSynchronize(st));
     b->n_pics = (uint64_t)n_pics * replicas;
     b->n_mbs = (uint64_t)n_mbs * replicas;
     b->coef_bytes = (uint64_t)coef_bytes * replicas;
@@ -1082,10 +1125,17 @@ int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_
 {
     if (!v)
         return fail(MPEGHIP_ERR_INVALID, "video is NULL");
-    int rc = upload_into(v, &v->transient, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, 1);
+    mpeghip_video::Staging *sg = &v->staging[v->next_staging];
+    int rc = upload_into(v, &sg->batch, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, 1, sg);
     if (rc != MPEGHIP_OK)
         return rc;
-    return launch_batch(v, &v->transient);
+    v->next_staging ^= 1;
+    rc = launch_batch(v, &sg->batch);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    HIP_TRY(hipEventRecord(sg->done, v->ctx->stream));
+    sg->in_flight = true;
+    return MPEGHIP_OK;
 }
 
 int mpeghip_video_batch_upload_replicated(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
