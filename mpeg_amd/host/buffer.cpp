@@ -34,6 +34,7 @@ std::unique_ptr<Buffer> Buffer::FromMemory(const uint8_t *data, size_t len)
         *pos = p > len ? len : p;
         return true;
     };
+    r.tell = [pos]() { return *pos; };
     r.size = len;
     std::unique_ptr<Buffer> b(new Buffer(std::move(r)));
     Buffer *raw = b.get();
@@ -83,7 +84,12 @@ void Buffer::seek(size_t pos)
     }
 }
 
-size_t Buffer::tell() { return bit_index_ >> 3; } // buffer.go:178-187 (reader offset bookkeeping lives in Demux::Seek, not ported yet)
+size_t Buffer::tell()
+{ // buffer.go:178-187
+    if (has_reader_ && total_size_ > 0 && reader_.tell)
+        return reader_.tell() + (bit_index_ >> 3) - bytes_.size();
+    return bit_index_ >> 3;
+}
 
 void Buffer::discardReadBytes()
 { // buffer.go:189-201

@@ -5,11 +5,15 @@
 #include <string.h>
 
 #include <exception>
+#include <stdexcept>
 #include <string>
 
 #include "mpeg.hpp"
 
 using namespace mpeg;
+
+extern "C" struct mpeghost_frame;
+typedef struct mpeghost_frame mpeghost_frame_t;
 
 namespace {
 thread_local std::string g_err;
@@ -33,6 +37,16 @@ struct AudioHandle {
     std::unique_ptr<Buffer> buf;
     std::unique_ptr<Audio> audio;
 };
+struct MpegHandle {
+    std::unique_ptr<MPEG> m;
+    int video_calls = 0, audio_calls = 0; // callbacks installed by mpeghost_mpeg_count_callbacks
+};
+struct DemuxHandle {
+    std::unique_ptr<Buffer> buf;
+    std::unique_ptr<Demux> demux;
+};
+MPEG *M(void *h) { return static_cast<MpegHandle *>(h)->m.get(); }
+void fill(mpeghost_frame_t *out, const Frame *f);
 } // namespace
 
 extern "C" {
@@ -166,12 +180,28 @@ const void *mpeghost_audio_decode(void *ha, double *time)
 // mpeg.New over a complete program stream
 void *mpeghost_mpeg_open(void *device, const uint8_t *data, size_t len)
 {
-    return guard([&]() -> void * { return new MPEG(data, len, static_cast<Device *>(device)); }, (void *)nullptr);
+    return guard([&]() -> void * {
+        std::unique_ptr<MpegHandle> h(new MpegHandle);
+        h->m.reset(new MPEG(data, len, static_cast<Device *>(device)));
+        return h.release();
+    }, (void *)nullptr);
 }
-void mpeghost_mpeg_close(void *m) { delete static_cast<MPEG *>(m); }
+// same over injected backends (tests): the factories return `new`ed VideoBackend / AudioBackend objects
+void *mpeghost_mpeg_open_backends(void *(*make_video)(void), void *(*make_audio)(int), const uint8_t *data, size_t len)
+{
+    return guard([&]() -> void * {
+        MPEG::Backends b;
+        b.video = [make_video]() { return std::unique_ptr<VideoBackend>(static_cast<VideoBackend *>(make_video())); };
+        b.audio = [make_audio](int fma) { return std::unique_ptr<AudioBackend>(static_cast<AudioBackend *>(make_audio(fma))); };
+        std::unique_ptr<MpegHandle> h(new MpegHandle);
+        h->m.reset(new MPEG(data, len, std::move(b)));
+        return h.release();
+    }, (void *)nullptr);
+}
+void mpeghost_mpeg_close(void *m) { delete static_cast<MpegHandle *>(m); }
 void mpeghost_mpeg_info(void *mv, int out[6])
 {
-    MPEG *m = static_cast<MPEG *>(mv);
+    MPEG *m = M(mv);
     out[0] = m->NumVideoStreams();
     out[1] = m->NumAudioStreams();
     out[2] = m->Width();
@@ -179,37 +209,26 @@ void mpeghost_mpeg_info(void *mv, int out[6])
     out[4] = m->Samplerate();
     out[5] = m->Channels();
 }
-double mpeghost_mpeg_framerate(void *m) { return static_cast<MPEG *>(m)->Framerate(); }
+double mpeghost_mpeg_framerate(void *m) { return M(m)->Framerate(); }
 void mpeghost_mpeg_set_enabled(void *m, int video, int audio)
 {
-    static_cast<MPEG *>(m)->SetVideoEnabled(video != 0);
-    static_cast<MPEG *>(m)->SetAudioEnabled(audio != 0);
+    M(m)->SetVideoEnabled(video != 0);
+    M(m)->SetAudioEnabled(audio != 0);
 }
 int mpeghost_mpeg_decode_video(void *mv, mpeghost_frame *out)
 {
     return guard([&]() -> int {
-        Frame *f = static_cast<MPEG *>(mv)->DecodeVideo();
+        Frame *f = M(mv)->DecodeVideo();
         if (!f)
             return 0;
-        out->time = f->Time;
-        out->width = f->Width;
-        out->height = f->Height;
-        out->luma_w = f->Y.Width;
-        out->luma_h = f->Y.Height;
-        out->chroma_w = f->Cb.Width;
-        out->chroma_h = f->Cb.Height;
-        out->y = f->Y.Data;
-        out->cb = f->Cb.Data;
-        out->cr = f->Cr.Data;
-        out->luma_bytes = f->Y.Len;
-        out->chroma_bytes = f->Cb.Len;
+        fill(out, f);
         return 1;
     }, -1);
 }
 const float *mpeghost_mpeg_decode_audio(void *mv, double *time)
 {
     return guard([&]() -> const float * {
-        Samples *s = static_cast<MPEG *>(mv)->DecodeAudio();
+        Samples *s = M(mv)->DecodeAudio();
         if (!s)
             return nullptr;
         if (time)
@@ -217,6 +236,118 @@ const float *mpeghost_mpeg_decode_audio(void *mv, double *time)
         return s->Interleaved.data();
     }, (const float *)nullptr);
 }
-int mpeghost_mpeg_has_ended(void *m) { return static_cast<MPEG *>(m)->HasEnded() ? 1 : 0; }
+int mpeghost_mpeg_has_ended(void *m) { return M(m)->HasEnded() ? 1 : 0; }
+int mpeghost_mpeg_probe(void *m, size_t probe_size)
+{
+    return guard([&]() -> int { return M(m)->Probe(probe_size) ? 1 : 0; }, -1);
+}
+int mpeghost_mpeg_has_headers(void *m)
+{
+    return guard([&]() -> int { return M(m)->HasHeaders() ? 1 : 0; }, -1);
+}
+double mpeghost_mpeg_duration(void *m) { return guard([&]() -> double { return M(m)->Duration(); }, -1.0); }
+double mpeghost_mpeg_time(void *m) { return M(m)->Time(); }
+double mpeghost_mpeg_audio_time(void *m) { return M(m)->GetAudio() ? M(m)->GetAudio()->Time() : -1.0; }
+double mpeghost_mpeg_video_time(void *m) { return M(m)->GetVideo() ? M(m)->GetVideo()->Time() : -1.0; }
+// install callbacks that only count (SetVideoCallback / SetAudioCallback), or remove them
+void mpeghost_mpeg_count_callbacks(void *mv, int video, int audio)
+{
+    MpegHandle *h = static_cast<MpegHandle *>(mv);
+    h->video_calls = h->audio_calls = 0;
+    if (video)
+        h->m->SetVideoCallback([h](MPEG *, Frame *) { h->video_calls++; });
+    else
+        h->m->SetVideoCallback(VideoFunc());
+    if (audio)
+        h->m->SetAudioCallback([h](MPEG *, Samples *) { h->audio_calls++; });
+    else
+        h->m->SetAudioCallback(AudioFunc());
+}
+void mpeghost_mpeg_callback_counts(void *mv, int out[2])
+{
+    MpegHandle *h = static_cast<MpegHandle *>(mv);
+    out[0] = h->video_calls;
+    out[1] = h->audio_calls;
+}
+void mpeghost_mpeg_decode(void *m, double tick)
+{
+    guard([&]() -> int { M(m)->Decode(tick); return 0; }, -1);
+}
+int mpeghost_mpeg_seek(void *m, double seconds, int exact)
+{
+    return guard([&]() -> int { return M(m)->Seek(seconds, exact != 0) ? 1 : 0; }, -1);
+}
+int mpeghost_mpeg_seek_frame(void *m, double seconds, int exact, mpeghost_frame *out)
+{
+    return guard([&]() -> int {
+        Frame *f = M(m)->SeekFrame(seconds, exact != 0);
+        if (!f)
+            return 0;
+        fill(out, f);
+        return 1;
+    }, -1);
+}
+
+// NewDemux over a complete program stream (mpeg_test.go:88-100)
+void *mpeghost_demux_open(const uint8_t *data, size_t len)
+{
+    return guard([&]() -> void * {
+        std::unique_ptr<DemuxHandle> h(new DemuxHandle);
+        h->buf = Buffer::FromMemory(data, len);
+        h->demux.reset(new Demux(h->buf.get()));
+        if (!h->demux->HasHeaders())
+            throw std::runtime_error("invalid MPEG-PS header"); // ErrInvalidHeader
+        return h.release();
+    }, (void *)nullptr);
+}
+void mpeghost_demux_close(void *h) { delete static_cast<DemuxHandle *>(h); }
+double mpeghost_demux_start_time(void *h, int type) { return static_cast<DemuxHandle *>(h)->demux->StartTime(type); }
+double mpeghost_demux_duration(void *h, int type) { return static_cast<DemuxHandle *>(h)->demux->Duration(type); }
+int mpeghost_demux_probe(void *h, size_t probe_size) { return static_cast<DemuxHandle *>(h)->demux->Probe(probe_size) ? 1 : 0; }
+void mpeghost_demux_streams(void *h, int out[2])
+{
+    out[0] = static_cast<DemuxHandle *>(h)->demux->NumVideoStreams();
+    out[1] = static_cast<DemuxHandle *>(h)->demux->NumAudioStreams();
+}
+void mpeghost_demux_rewind(void *h) { static_cast<DemuxHandle *>(h)->demux->Rewind(); }
+// next packet: returns its type (0 at the end); pts / len / first payload bytes through the pointers
+int mpeghost_demux_decode(void *h, double *pts, size_t *len, const uint8_t **data)
+{
+    Packet *p = static_cast<DemuxHandle *>(h)->demux->Decode();
+    if (!p)
+        return 0;
+    *pts = p->Pts;
+    *len = p->Len;
+    *data = p->Data;
+    return p->Type;
+}
+int mpeghost_demux_seek(void *h, double seconds, int type, int force_intra, double *pts, size_t *len, const uint8_t **data)
+{
+    Packet *p = static_cast<DemuxHandle *>(h)->demux->Seek(seconds, type, force_intra != 0);
+    if (!p)
+        return 0;
+    *pts = p->Pts;
+    *len = p->Len;
+    *data = p->Data;
+    return p->Type;
+}
 
 } // extern "C"
+
+namespace {
+void fill(mpeghost_frame_t *out, const Frame *f)
+{
+    out->time = f->Time;
+    out->width = f->Width;
+    out->height = f->Height;
+    out->luma_w = f->Y.Width;
+    out->luma_h = f->Y.Height;
+    out->chroma_w = f->Cb.Width;
+    out->chroma_h = f->Cb.Height;
+    out->y = f->Y.Data;
+    out->cb = f->Cb.Data;
+    out->cr = f->Cr.Data;
+    out->luma_bytes = f->Y.Len;
+    out->chroma_bytes = f->Cb.Len;
+}
+} // namespace

@@ -6,7 +6,20 @@
 
 namespace mpeg {
 
-MPEG::MPEG(const uint8_t *data, size_t len, Device *dev, int audio_fma_mode) : dev_(dev), audio_fma_mode_(audio_fma_mode)
+MPEG::MPEG(const uint8_t *data, size_t len, Device *dev, int audio_fma_mode) : audio_fma_mode_(audio_fma_mode)
+{
+    backends_.video = [dev]() { return dev->newVideoBackend(); };
+    backends_.audio = [dev](int fma) { return dev->newAudioBackend(fma); };
+    open(data, len);
+}
+
+MPEG::MPEG(const uint8_t *data, size_t len, Backends backends, int audio_fma_mode)
+    : backends_(std::move(backends)), audio_fma_mode_(audio_fma_mode)
+{
+    open(data, len);
+}
+
+void MPEG::open(const uint8_t *data, size_t len)
 { // mpeg.go:85-117
     buf_ = Buffer::FromMemory(data, len);
     static const uint8_t magic[4] = {0x00, 0x00, 0x01, 0xBA};
@@ -69,6 +82,79 @@ void MPEG::Rewind()
     time_ = 0;
 }
 
+bool MPEG::Probe(size_t probe_size)
+{ // mpeg.go:141-152
+    if (!demux_->Probe(probe_size))
+        return false;
+    has_decoders_ = false;
+    video_packet_type_ = 0;
+    audio_packet_type_ = 0;
+    return initDecoders();
+}
+
+Frame *MPEG::SeekFrame(double tm, bool seek_exact)
+{ // mpeg.go:460-522
+    if (!initDecoders() || video_packet_type_ == 0)
+        return nullptr;
+    const int type = video_packet_type_;
+    const double start_time = demux_->StartTime(type);
+    const double duration = demux_->Duration(type);
+    if (tm < 0)
+        tm = 0;
+    else if (tm > duration)
+        tm = duration;
+    Packet *packet = demux_->Seek(tm, type, true);
+    if (!packet)
+        return nullptr;
+    // no audio packets into the audio buffer while decoding video
+    const int prev_audio_packet_type = audio_packet_type_;
+    audio_packet_type_ = 0;
+    video_->Rewind();
+    video_->SetTime(packet->Pts - start_time);
+    video_buf_->Write(packet->Data, packet->Len);
+    Frame *frame = video_->Decode();
+    if (seek_exact)
+        while (frame && frame->Time < tm)
+            frame = video_->Decode();
+    audio_packet_type_ = prev_audio_packet_type;
+    if (frame)
+        time_ = frame->Time;
+    has_ended_ = false;
+    return frame;
+}
+
+bool MPEG::Seek(double tm, bool seek_exact)
+{ // mpeg.go:524-576
+    Frame *frame = SeekFrame(tm, seek_exact);
+    if (!frame)
+        return false;
+    if (video_cb_)
+        video_cb_(this, frame);
+    if (audio_packet_type_ == 0)
+        return true;
+    // demux on until the first audio packet after the new time, then decode up to the lead time
+    const double start_time = demux_->StartTime(video_packet_type_);
+    audio_->Rewind();
+    for (;;) {
+        Packet *p = demux_->Decode();
+        if (!p)
+            break;
+        if (p->Type == video_packet_type_) {
+            video_buf_->Write(p->Data, p->Len);
+        } else if (p->Type == audio_packet_type_ && p->Pts - start_time > time_) {
+            audio_->SetTime(p->Pts - start_time);
+            audio_buf_->Write(p->Data, p->Len);
+            const int prev_audio_packet_type = audio_packet_type_;
+            audio_packet_type_ = 0;
+            Decode(0);
+            audio_packet_type_ = prev_audio_packet_type;
+            Decode(0);
+            break;
+        }
+    }
+    return true;
+}
+
 bool MPEG::initDecoders()
 { // mpeg.go:578-623
     if (has_decoders_)
@@ -81,7 +167,7 @@ bool MPEG::initDecoders()
         if (!video_) {
             video_buf_.reset(new Buffer());
             video_buf_->SetLoadCallback([this](Buffer *) { readPackets(video_packet_type_); });
-            video_.reset(new Video(video_buf_.get(), dev_));
+            video_.reset(new Video(video_buf_.get(), backends_.video()));
         }
     }
     if (demux_->NumAudioStreams() > 0) {
@@ -90,7 +176,7 @@ bool MPEG::initDecoders()
         if (!audio_) {
             audio_buf_.reset(new Buffer());
             audio_buf_->SetLoadCallback([this](Buffer *) { readPackets(audio_packet_type_); });
-            audio_.reset(new Audio(audio_buf_.get(), dev_, audio_fma_mode_));
+            audio_.reset(new Audio(audio_buf_.get(), backends_.audio(audio_fma_mode_)));
             audio_->SetFormat(audio_format_);
         }
     }

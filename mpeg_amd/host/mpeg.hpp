@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include <functional>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -34,6 +35,7 @@ using LoadFunc = std::function<void(Buffer *)>; // buffer.go:14
 struct BufferReader {
     std::function<size_t(uint8_t *, size_t)> read; // returns bytes read, 0 = EOF
     std::function<bool(size_t)> seek;              // absolute; may be empty (not seekable)
+    std::function<size_t()> tell;                  // current offset (io.Seeker's Seek(0, SeekCurrent)); with seek
     size_t size = 0;                               // total size if seekable
 };
 
@@ -303,13 +305,22 @@ public:
     void Rewind();
     bool HasEnded() const { return buf_->HasEnded(); }
     Packet *Decode();                              // demux.go:473-516
+    bool Probe(size_t probe_size);                 // demux.go:158-198: count the streams that really occur
+    // demux.go:208-352: packet of `type` with the PTS just before seek_time (0-based); with
+    // force_intra only packets that start an intra picture.  nullptr if none.
+    Packet *Seek(double seek_time, int type, bool force_intra);
+    double StartTime(int type);                    // demux.go:357-404: lowest PTS of the type, or PacketInvalidTS
+    double Duration(int type);                     // demux.go:406-457: highest - lowest PTS + one frame
 
 private:
     double decodeTime();
     Packet *decodePacket(int type);
     Packet *packet();
+    void bufferSeek(size_t pos);
     Buffer *buf_;
-    double sys_clock_ref_ = 0;
+    double sys_clock_ref_ = 0, last_decoded_pts_ = 0;
+    std::map<int, double> start_time_, duration_, first_pts_, last_pts_;
+    size_t last_file_size_ = 0;
     int start_code_ = -1;
     bool has_pack_header_ = false, has_system_header_ = false, has_headers_ = false;
     int num_audio_streams_ = 0, num_video_streams_ = 0;
@@ -321,12 +332,18 @@ using VideoFunc = std::function<void(class MPEG *, Frame *)>;    // mpeg.go:48
 using AudioFunc = std::function<void(class MPEG *, Samples *)>;  // mpeg.go:51
 
 // High-level player facade (mpeg.go:57-669): demux -> per-stream buffers -> decoders,
-// A/V clocking.  Seek / SeekFrame are not ported yet.
+// A/V clocking, seeking.
 class MPEG {
 public:
     // mpeg.New (mpeg.go:85-117).  Throws std::runtime_error("invalid MPEG-PS") like ErrInvalidMPEG /
     // ErrInvalidHeader.  `data` must outlive the object.
     MPEG(const uint8_t *data, size_t len, Device *dev, int audio_fma_mode = MPEGHIP_AUDIO_FMA_NONE);
+    // same, with injected backends (tests): the factories are called when the decoders are created
+    struct Backends {
+        std::function<std::unique_ptr<VideoBackend>()> video;
+        std::function<std::unique_ptr<AudioBackend>(int fma_mode)> audio;
+    };
+    MPEG(const uint8_t *data, size_t len, Backends backends, int audio_fma_mode = MPEGHIP_AUDIO_FMA_NONE);
     ~MPEG();
     bool HasHeaders();
     bool HasEnded() const { return has_ended_; }
@@ -345,7 +362,14 @@ public:
     int Samplerate() { return initDecoders() && audio_ ? audio_->Samplerate() : 0; }
     int Channels() { return initDecoders() && audio_ ? audio_->Channels() : 0; }
     double Time() const { return time_; }
+    double Duration() { return demux_->Duration(PacketVideo1); }   // mpeg.go:318-320
+    bool Probe(size_t probe_size);      // mpeg.go:141-152
     void Rewind();
+    // mpeg.go:460-522: the intra frame just before `seconds` (clamped to 0..duration), or, with
+    // seek_exact, the frame at that time (decodes forward from the intra frame).  No callbacks.
+    Frame *SeekFrame(double seconds, bool seek_exact);
+    // mpeg.go:524-576: SeekFrame + the video callback exactly once + audio re-synchronised
+    bool Seek(double seconds, bool seek_exact);
     void Decode(double tick_seconds);   // mpeg.go:356-411
     Frame *DecodeVideo();               // mpeg.go:416-433
     Samples *DecodeAudio();             // mpeg.go:438-455
@@ -356,7 +380,8 @@ private:
     bool initDecoders();
     void handleEnd();
     void readPackets(int requested_type);
-    Device *dev_;
+    void open(const uint8_t *data, size_t len);
+    Backends backends_;
     int audio_fma_mode_;
     std::unique_ptr<Buffer> buf_, video_buf_, audio_buf_;
     std::unique_ptr<Demux> demux_;

@@ -100,7 +100,18 @@ private:
 
 } // namespace
 
+static int g_flavour = 0;
+static float g_window[512];
+
 extern "C" {
 void *host_emu_video_backend(int flavour) { return new EmuVideoBackend(flavour); }
 void *host_emu_audio_backend(int fma, const float *window512) { return new EmuAudioBackend(fma, window512); }
+// factories with the signature mpeghost_mpeg_open_backends wants
+void host_emu_configure(int flavour, const float *window512)
+{
+    g_flavour = flavour;
+    memcpy(g_window, window512, sizeof(g_window));
+}
+void *host_emu_make_video(void) { return new EmuVideoBackend(g_flavour); }
+void *host_emu_make_audio(int fma) { return new EmuAudioBackend(fma, g_window); }
 }

@@ -47,6 +47,21 @@ def host():
             "mpeghost_mpeg_set_enabled": (None, [P, C.c_int, C.c_int]),
             "mpeghost_mpeg_decode_video": (C.c_int, [P, C.POINTER(HostFrame)]),
             "mpeghost_mpeg_decode_audio": (P, [P, C.POINTER(C.c_double)]), "mpeghost_mpeg_has_ended": (C.c_int, [P]),
+            "mpeghost_mpeg_open_backends": (P, [P, P, C.c_char_p, C.c_size_t]),
+            "mpeghost_mpeg_probe": (C.c_int, [P, C.c_size_t]), "mpeghost_mpeg_has_headers": (C.c_int, [P]),
+            "mpeghost_mpeg_duration": (C.c_double, [P]), "mpeghost_mpeg_time": (C.c_double, [P]),
+            "mpeghost_mpeg_audio_time": (C.c_double, [P]), "mpeghost_mpeg_video_time": (C.c_double, [P]),
+            "mpeghost_mpeg_count_callbacks": (None, [P, C.c_int, C.c_int]),
+            "mpeghost_mpeg_callback_counts": (None, [P, C.POINTER(C.c_int * 2)]),
+            "mpeghost_mpeg_decode": (None, [P, C.c_double]),
+            "mpeghost_mpeg_seek": (C.c_int, [P, C.c_double, C.c_int]),
+            "mpeghost_mpeg_seek_frame": (C.c_int, [P, C.c_double, C.c_int, C.POINTER(HostFrame)]),
+            "mpeghost_demux_open": (P, [C.c_char_p, C.c_size_t]), "mpeghost_demux_close": (None, [P]),
+            "mpeghost_demux_start_time": (C.c_double, [P, C.c_int]), "mpeghost_demux_duration": (C.c_double, [P, C.c_int]),
+            "mpeghost_demux_probe": (C.c_int, [P, C.c_size_t]), "mpeghost_demux_streams": (None, [P, C.POINTER(C.c_int * 2)]),
+            "mpeghost_demux_rewind": (None, [P]),
+            "mpeghost_demux_decode": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_size_t), C.POINTER(P)]),
+            "mpeghost_demux_seek": (C.c_int, [P, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_size_t), C.POINTER(P)]),
         }
         for n, (r, a) in sig.items():
             f = getattr(L, n)
@@ -75,6 +90,8 @@ def host_emu():
         L.host_emu_video_backend.argtypes = [C.c_int]
         L.host_emu_audio_backend.restype = C.c_void_p
         L.host_emu_audio_backend.argtypes = [C.c_int, C.c_void_p]
+        L.host_emu_configure.restype = None
+        L.host_emu_configure.argtypes = [C.c_int, C.c_void_p]
         _emu = L
     return _emu
 
@@ -152,4 +169,130 @@ class HostAudio:
     def close(self):
         if self.h:
             host().mpeghost_audio_close(self.h)
+            self.h = None
+
+
+PACKET_VIDEO_1, PACKET_AUDIO_1 = 0xE0, 0xC0  # demux.go:11-29
+
+
+class HostDemux:
+    """mpeg.Demux over a whole program stream."""
+
+    def __init__(self, data: bytes):
+        self._data = data
+        self.h = host().mpeghost_demux_open(data, len(data))
+        if not self.h:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+
+    def start_time(self, typ):
+        return host().mpeghost_demux_start_time(self.h, typ)
+
+    def duration(self, typ):
+        return host().mpeghost_demux_duration(self.h, typ)
+
+    def probe(self, size):
+        return bool(host().mpeghost_demux_probe(self.h, size))
+
+    def streams(self):
+        out = (C.c_int * 2)()
+        host().mpeghost_demux_streams(self.h, C.byref(out))
+        return out[0], out[1]
+
+    def rewind(self):
+        host().mpeghost_demux_rewind(self.h)
+
+    def _packet(self, typ, pts, n, data):
+        if typ == 0:
+            return None
+        return typ, pts.value, C.string_at(data.value, n.value)
+
+    def decode(self):
+        pts, n, data = C.c_double(), C.c_size_t(), C.c_void_p()
+        return self._packet(host().mpeghost_demux_decode(self.h, C.byref(pts), C.byref(n), C.byref(data)), pts, n, data)
+
+    def seek(self, seconds, typ, force_intra):
+        pts, n, data = C.c_double(), C.c_size_t(), C.c_void_p()
+        return self._packet(host().mpeghost_demux_seek(self.h, seconds, typ, int(force_intra), C.byref(pts), C.byref(n), C.byref(data)),
+                            pts, n, data)
+
+    def close(self):
+        if self.h:
+            host().mpeghost_demux_close(self.h)
+            self.h = None
+
+
+class HostMpeg:
+    """mpeg.MPEG over a whole program stream; device=None runs the decoders on the test-only lane emulator."""
+
+    def __init__(self, data: bytes, device=None, window=None, flavour=0):
+        self._data = data
+        L = host()
+        if device is not None:
+            self.h = L.mpeghost_mpeg_open(device, data, len(data))
+        else:
+            E = host_emu()
+            self._win = np.ascontiguousarray(window, np.float32)
+            E.host_emu_configure(flavour, self._win.ctypes.data)
+            mk_v = C.cast(E.host_emu_make_video, C.c_void_p)
+            mk_a = C.cast(E.host_emu_make_audio, C.c_void_p)
+            self.h = L.mpeghost_mpeg_open_backends(mk_v, mk_a, data, len(data))
+        if not self.h:
+            raise RuntimeError(L.mpeghost_last_error().decode())
+
+    def info(self):
+        out = (C.c_int * 6)()
+        host().mpeghost_mpeg_info(self.h, C.byref(out))
+        return dict(zip(("video_streams", "audio_streams", "width", "height", "samplerate", "channels"), out))
+
+    def _call(self, name, *a):
+        return getattr(host(), "mpeghost_mpeg_" + name)(self.h, *a)
+
+    def probe(self, size):
+        return self._call("probe", size) == 1
+
+    def has_headers(self):
+        return self._call("has_headers") == 1
+
+    duration = property(lambda s: s._call("duration"))
+    time = property(lambda s: s._call("time"))
+    audio_time = property(lambda s: s._call("audio_time"))
+    video_time = property(lambda s: s._call("video_time"))
+    framerate = property(lambda s: s._call("framerate"))
+    has_ended = property(lambda s: s._call("has_ended") == 1)
+
+    def set_enabled(self, video, audio):
+        self._call("set_enabled", int(video), int(audio))
+
+    def count_callbacks(self, video=True, audio=True):
+        self._call("count_callbacks", int(video), int(audio))
+
+    def callback_counts(self):
+        out = (C.c_int * 2)()
+        self._call("callback_counts", C.byref(out))
+        return out[0], out[1]
+
+    def decode(self, tick):
+        self._call("decode", float(tick))
+
+    def decode_video(self):
+        f = HostFrame()
+        return f if self._call("decode_video", C.byref(f)) == 1 else None
+
+    def decode_audio(self):
+        t = C.c_double()
+        p = self._call("decode_audio", C.byref(t))
+        if not p:
+            return None
+        return t.value, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(2304,)).copy()
+
+    def seek(self, seconds, exact):
+        return self._call("seek", float(seconds), int(exact)) == 1
+
+    def seek_frame(self, seconds, exact):
+        f = HostFrame()
+        return f if self._call("seek_frame", float(seconds), int(exact), C.byref(f)) == 1 else None
+
+    def close(self):
+        if self.h:
+            host().mpeghost_mpeg_close(self.h)
             self.h = None

@@ -99,3 +99,24 @@ def test_program_stream_facade_on_gpu(oracle, golden_dir, device):
         n += 1
     assert (h, n) == (0xf1b76cdf8e6cdea5, 355)
     L.mpeghost_mpeg_close(m)
+
+
+def test_seek_on_gpu_matches_the_lane_emulator(emu, golden_dir, device):
+    """MPEG.Seek / SeekFrame (mpeg.go:460-576) through the HIP backend: same frames, times and callback counts
+    as the CPU run of the same host code on the test-only lane emulator."""
+    ps = (golden_dir / "test.mpg").read_bytes()
+    win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
+    gpu, cpu = hostlib.HostMpeg(ps, device=device), hostlib.HostMpeg(ps, window=win)
+    assert abs(gpu.duration - 9.233333) < 1e-3                      # mpeg_test.go:104
+    for t, exact in ((3.0, True), (1.0, False), (6.25, True), (100.0, True), (0.0, True)):
+        fg, fc = gpu.seek_frame(t, exact), cpu.seek_frame(t, exact)
+        assert fg is not None and fc is not None and fg.time == fc.time
+        for a, b in zip(hostlib.frame_planes(fg), hostlib.frame_planes(fc)):
+            assert np.array_equal(a, b)
+    for m in (gpu, cpu):
+        m.count_callbacks()
+        assert m.seek(3.001, True)
+    assert gpu.callback_counts() == cpu.callback_counts() and gpu.callback_counts()[0] == 1   # mpeg_test.go:442-461
+    assert gpu.time == cpu.time and gpu.audio_time == cpu.audio_time and abs(gpu.audio_time - gpu.time) <= 0.5
+    gpu.close()
+    cpu.close()
