@@ -107,7 +107,8 @@ def test_seek_on_gpu_matches_the_lane_emulator(emu, golden_dir, device):
     ps = (golden_dir / "test.mpg").read_bytes()
     win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
     gpu, cpu = hostlib.HostMpeg(ps, device=device), hostlib.HostMpeg(ps, window=win)
-    assert abs(gpu.duration - 9.233333) < 1e-3                      # mpeg_test.go:104
+    # same call sequence on both: the seek estimator starts from the demuxer's last decoded PTS (demux.go:244)
+    assert abs(gpu.duration - 9.233333) < 1e-3 and cpu.duration == gpu.duration   # mpeg_test.go:104
     for t, exact in ((3.0, True), (1.0, False), (6.25, True), (100.0, True), (0.0, True)):
         fg, fc = gpu.seek_frame(t, exact), cpu.seek_frame(t, exact)
         assert fg is not None and fc is not None and fg.time == fc.time
