@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Host-inclusive rates (NOT bench.py's `value`): what one host thread + PCIe can feed.
+
+ 1. submit path: mpeghip_video_submit of one typical 1080p picture per call from pageable host arrays
+    (validate + copy into pinned staging + H2D + kernel), back to back, 1 stream and 16 streams per call.
+ 2. BASELINE config 1: testdata/test.mpg (160x120, 278 pictures + 355 audio frames) through the product
+    (host parser -> C ABI -> GPU, frames read back) vs the CPU oracle decoding the same file.
+"""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+from mpeg_amd import abi, desc, synth  # noqa: E402
+
+
+def submit_rate(ctx, streams, seconds=2.0):
+    seq = synth.generate_sequence(1920, 1080, 13, profile="typical")
+    store = abi.VideoStore(ctx, 1920, 1080, streams)
+    batches = []
+    for s in seq:
+        pics = np.repeat(s.pics, streams)
+        pics["stream"] = np.arange(streams)
+        pics["mb_first"] = np.arange(streams) * len(s.mbs)
+        mbs = np.tile(s.mbs, streams)
+        mbs["pic"] = np.repeat(np.arange(streams), len(s.mbs))
+        if streams > 1:  # every stream reads its own copy of the coefficients, as a real multi-stream submit would
+            per = s.coefs.nbytes // desc.COEF_UNIT
+            mbs["coef_off"] = mbs["coef_off"] + np.repeat(np.arange(streams, dtype=np.uint32) * per, len(s.mbs))
+            coefs = np.tile(s.coefs, streams)
+        else:
+            coefs = s.coefs
+        batches.append((pics, mbs, coefs))
+    for b in batches:
+        store.submit(*b)
+    ctx.sync()
+    t0, n, nbytes = time.perf_counter(), 0, 0
+    while time.perf_counter() - t0 < seconds:
+        for b in batches:
+            store.submit(*b)
+            n += streams
+            nbytes += b[0].nbytes + b[1].nbytes + b[2].nbytes
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    store.close()
+    return n / dt, nbytes / dt
+
+
+def main():
+    ctx = abi.Context(0)
+    for streams in (1, 16):
+        pps, bps = submit_rate(ctx, streams)
+        print("submit, %2d stream(s)/call: %8.0f pictures/s = %.3f G macroblocks/s, %.2f GB/s of descriptors+coefficients over PCIe"
+              % (streams, pps, pps * 8160 / 1e9, bps / 1e9))
+    ctx.close()
+
+    import hostlib
+    from oracle import pyoracle
+    ps = (ROOT / "tests" / "golden" / "test.mpg").read_bytes()
+    dev = hostlib.host().mpeghost_device_create(0)
+    best = None
+    for _ in range(5):
+        m = hostlib.HostMpeg(ps, device=dev)
+        m.set_enabled(True, False)
+        t0, n = time.perf_counter(), 0
+        while m.decode_video() is not None:
+            n += 1
+        dt = time.perf_counter() - t0
+        m.close()
+        best = dt if best is None or dt < best else best
+    print("config 1, product on the GPU (host parse + per-picture submit + D2H of every frame): %d pictures in %.1f ms = %.0f pictures/s"
+          % (n, best * 1e3, n / best))
+    es = pyoracle.ps_extract(ps, 0xE0)[0]
+    best = None
+    for _ in range(5):
+        d = pyoracle.VideoDecoder(es)
+        t0, n = time.perf_counter(), 0
+        while d.decode() is not None:
+            n += 1
+        dt = time.perf_counter() - t0
+        d.close()
+        best = dt if best is None or dt < best else best
+    print("config 1, CPU oracle (C restatement of the reference, 1 thread): %d pictures in %.1f ms = %.0f pictures/s" % (n, best * 1e3, n / best))
+    hostlib.host().mpeghost_device_destroy(dev)
+
+
+if __name__ == "__main__":
+    main()
