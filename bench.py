@@ -41,7 +41,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--gop", type=int, default=13, help="pictures in the cycled decode-order GOP")
-    ap.add_argument("--profile", default="typical", choices=["typical", "dense"])
+    ap.add_argument("--profile", default="typical", choices=["typical", "dense", "typical_nocoef", "typical_fullpel"],
+                    help="typical / dense are the reported workloads; the other two are diagnostics (no residual / no half-pel)")
     ap.add_argument("--rgba", type=int, default=0, help="1: fuse Frame.RGBA into the reconstruction kernel")
     ap.add_argument("--audio-streams", type=int, default=256)
     ap.add_argument("--audio-frames", type=int, default=100)

@@ -144,6 +144,10 @@ def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", 
             else:
                 mvx[i], mvy[i] = 0, 0
     mvx[intra], mvy[intra] = 0, 0
+    if profile == "typical_fullpel":  # diagnostic: no half-pel interpolation anywhere
+        mvx, mvy = mvx & ~1, mvy & ~1
+        bad = ~mv_in_range(g, mb_x, mb_y, mvx, mvy)
+        mvx[bad], mvy[bad] = 0, 0
 
     # ---- coded block pattern
     if profile == "dense":
@@ -153,6 +157,8 @@ def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", 
         order = np.argsort(rng.random((n, 6)), axis=1)
         bits = (np.argsort(order, axis=1) < pop[:, None])
         cbp = (bits * (0x20 >> np.arange(6))[None, :]).sum(axis=1)
+    if profile in ("typical_nocoef", "typical_fullpel"):  # diagnostic: prediction only (intra stays coded)
+        cbp = np.zeros(n, np.int64)
     cbp = np.where(intra, 0x3f, cbp)
     cbp = np.where(skipped, 0, cbp)
 

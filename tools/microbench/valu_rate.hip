@@ -1,0 +1,89 @@
+// Issue rate of wave64 VALU instructions on gfx950, per instruction kind: a loop of 64 independent
+// instructions of one kind, enough waves to fill every SIMD.  Prints wave-instructions per clock per CU
+// (4.0 = every SIMD issues one per clock; 1.0 = one per 4 clocks, the classic 16-lane SIMD figure).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#define REP8(x) x x x x x x x x
+template <int KIND> __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t seed)
+{
+    uint32_t a[8], b = seed ^ threadIdx.x, c = seed * 3u + threadIdx.x;
+    uint32_t sb = seed * 5u, sc = seed * 7u + 1u; // wave-uniform: scalar registers
+    uint64_t mask = 0x5555555555555555ull * seed, mask2 = 0;
+    for (int i = 0; i < 8; i++) a[i] = seed + i * 7 + threadIdx.x;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (KIND == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 1) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 2) asm volatile("v_lerp_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 3) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                if (KIND == 4) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 5) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 6) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 7) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 8) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 9) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[i]));
+                if (KIND == 10) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 11) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*(uint64_t *)&a[i & 6]) : "v"(*(uint64_t *)&a[(i + 2) & 6]), "v"(*(uint64_t *)&a[(i + 4) & 6]));
+                if (KIND == 12) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sb) : "s"(sc) : "scc");
+                if (KIND == 13) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(sb) : "s"(sc));
+                if (KIND == 14) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
+                if (KIND == 15) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(mask));
+                if (KIND == 16) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 17) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 18) asm volatile("v_sat_pk_u8_i16 %0, %0" : "+v"(a[i]));
+                if (KIND == 19) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 20) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 21) asm volatile("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(mask2) : "v"(a[i]), "v"(b));
+                if (KIND == 22) asm volatile("v_mul_i32_i24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 23) asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(a[i]));
+                if (KIND == 24) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(*(uint64_t *)&a[i & 6]) : "v"(*(uint64_t *)&a[(i + 2) & 6]));
+                if (KIND == 25) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 26) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "s"(sc));
+                if (KIND == 27) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "s"(sc));
+                if (KIND == 28) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 29) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 30) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(a[i]));
+                if (KIND == 31) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            }
+        }
+    }
+    uint32_t s = b ^ sb ^ (uint32_t)mask2;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345) out[threadIdx.x] = s;
+}
+template <int KIND> void run(const char *name, uint32_t *out, int cus, double ghz)
+{
+    const int iters = 2000, blocks = cus * 8; // 8 blocks x 4 waves per CU = 8 waves per SIMD
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 10, 1u);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double winstr = (double)blocks * 4 * iters * 64;
+    printf("%-16s %8.3f ms  %6.3f wave-instr/clk/CU at %.2f GHz (%.2f per SIMD)\n", name, ms, winstr / (ms * 1e-3) / (ghz * 1e9) / cus, ghz,
+           winstr / (ms * 1e-3) / (ghz * 1e9) / cus / 4);
+}
+int main()
+{
+    uint32_t *out; hipMalloc(&out, 4096);
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount; const double ghz = p.clockRate / 1e6;
+    printf("%s: %d CUs, %.2f GHz\n", p.gcnArchName, cus, ghz);
+    run<0>("v_add_u32", out, cus, ghz); run<1>("v_mul_i32_i24", out, cus, ghz); run<2>("v_lerp_u8", out, cus, ghz);
+    run<3>("v_cndmask_b32", out, cus, ghz); run<4>("v_mul_lo_u32", out, cus, ghz); run<5>("v_pk_add_i16", out, cus, ghz);
+    run<6>("v_alignbyte_b32", out, cus, ghz); run<7>("v_fma_f32", out, cus, ghz); run<8>("v_med3_i32", out, cus, ghz);
+    run<9>("v_ashrrev_i32", out, cus, ghz); run<10>("v_mad_i32_i24", out, cus, ghz); run<11>("v_pk_fma_f32", out, cus, ghz);
+    run<12>("s_add_u32", out, cus, ghz); run<13>("s_mul_i32", out, cus, ghz);
+    run<14>("v_mov_b32 v,v", out, cus, ghz); run<26>("v_mov_b32 v,s", out, cus, ghz); run<15>("v_cndmask_e64 sgpr", out, cus, ghz);
+    run<16>("v_and_b32", out, cus, ghz); run<31>("v_xor_b32", out, cus, ghz); run<25>("v_sub_u32", out, cus, ghz);
+    run<27>("v_add_u32 s,v", out, cus, ghz); run<30>("v_lshrrev_b32", out, cus, ghz); run<17>("v_perm_b32", out, cus, ghz);
+    run<18>("v_sat_pk_u8_i16", out, cus, ghz); run<28>("v_cvt_pk_i16_i32", out, cus, ghz); run<19>("v_add3_u32", out, cus, ghz);
+    run<20>("v_lshl_add_u32", out, cus, ghz); run<21>("v_cmp_lt_i32_e64", out, cus, ghz); run<22>("v_mul_i24_sdwa", out, cus, ghz);
+    run<23>("v_bfe_u32", out, cus, ghz); run<24>("v_lshl_add_u64", out, cus, ghz); run<29>("v_bitop3_b32", out, cus, ghz);
+    return 0;
+}
