@@ -58,8 +58,8 @@ def test_no_kernel_uses_scratch():
     moves to scratch memory (measured: 4x slower).  Checked on the compiler's resource-usage remarks."""
     import subprocess
     from mpeg_amd import _build
-    cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-c",
-           "-Rpass-analysis=kernel-resource-usage", "-I", str(_build.INCLUDE), "-I", str(_build.CSRC),
+    flags = [f for f in _build.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]  # the product's own code generation flags
+    cmd = [_build.hipcc_path(), *flags, "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage", "-I", str(_build.INCLUDE), "-I", str(_build.CSRC),
            str(_build.CSRC / "mpeghip.hip"), "-o", "/dev/null"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
