@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void rgba_pics_kernel(const VideoArgs a, uint3
                       a.height, x4, y, a.rgba + fs * a.rgba_stride);
 }
 
-// Frame.RGBA for whole slots: grid (x quads, rows, streams).
+// Frame.RGBA for whole slots: grid (x quads, row pairs / 4, streams).
 __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64_t frame_stride,
                                                   uint8_t *rgba, uint64_t rgba_stride,
                                                   uint32_t luma_w, uint32_t chroma_w,
@@ -940,7 +940,7 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
             const uint32_t quads = (in.width + 3) / 4;
             for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
                 const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 3) / 4, np), dim3(256), 0, st, a,
+                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
                                    (uint32_t)p0);
             }
             HIP_TRY(hipGetLastError());
@@ -956,7 +956,7 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
             const uint32_t quads = (in.width + 3) / 4;
             for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
                 const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 3) / 4, np), dim3(256), 0, st, a,
+                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
                                    (uint32_t)p0);
             }
             HIP_TRY(hipGetLastError());
@@ -991,7 +991,7 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
             const uint32_t quads = (in.width + 3) / 4;
             for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
                 const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 3) / 4, np), dim3(256), 0, st, a,
+                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
                                    (uint32_t)p0);
             }
             HIP_TRY(hipGetLastError());
@@ -1299,7 +1299,7 @@ int mpeghip_video_rgba_convert(mpeghip_video *v, uint32_t slot, uint32_t stream0
     // grid.z is limited to 65535
     for (uint32_t s0 = 0; s0 < n; s0 += 32768) {
         const uint32_t ns = n - s0 < 32768 ? n - s0 : 32768;
-        dim3 grid((quads + 63) / 64, (in.height + 3) / 4, ns);
+        dim3 grid((quads + 63) / 64, (in.height + 7) / 8, ns);
         hipLaunchKernelGGL(rgba_kernel, grid, dim3(256), 0, v->ctx->stream, v->d_frames, in.frame_stride, v->d_rgba,
                            rgba_stride_of(v), in.luma_w, in.chroma_w, (uint32_t)in.luma_bytes, (uint32_t)in.chroma_bytes,
                            in.width, in.height, slot, stream0 + s0);

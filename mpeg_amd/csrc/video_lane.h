@@ -483,32 +483,53 @@ MPG_HD void mb_phase_c_convert(const VideoArgs &a, const MbU &u, int lane, const
 }
 
 // ------------------------------------------------------- stand-alone Frame.RGBA
-// One thread converts 4 horizontally adjacent pixels of one stream's slot.
-MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t luma_w, uint32_t chroma_w,
-                              uint32_t luma_bytes, uint32_t chroma_bytes,
-                              uint32_t width, uint32_t height, uint32_t x4, uint32_t y, uint8_t *rgba)
+// One thread converts a 4x2 block of pixels of one stream's slot (rows 2*yp and 2*yp+1 share their
+// chroma samples: one Cb and one Cr word serve 8 pixels).  Grid rows are therefore row PAIRS.
+MPG_HD void rgba_store4(uint32_t *dst, uint64_t p, const uint32_t (&px)[4], uint32_t n)
 {
-    const uint32_t x0 = x4 * 4;
-    if (y >= height || x0 >= width)
-        return;
-    const uint32_t yy = *reinterpret_cast<const uint32_t *>(frame + (uint64_t)y * luma_w + x0);
-    const uint8_t *cbp = frame + luma_bytes + (uint64_t)(y >> 1) * chroma_w + (x0 >> 1);
-    const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp);
-    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + chroma_bytes);
-    uint32_t px[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        px[k] = ycbcr_to_rgba((yy >> (8 * k)) & 0xff, (cb >> (8 * (k >> 1))) & 0xff, (cr >> (8 * (k >> 1))) & 0xff);
-    const uint64_t p = (uint64_t)y * width + x0;
-    uint32_t *dst = reinterpret_cast<uint32_t *>(rgba) + p;
-    const uint32_t n = width - x0 >= 4 ? 4 : width - x0;
     if (n == 4 && (p & 3) == 0) {
+#if MPG_ON_DEVICE
+        // written once, read by nobody on the device: streaming store
+        typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+        const u32v4 q = {px[0], px[1], px[2], px[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<u32v4 *>(dst));
+#else
         u32x4 q = {{px[0], px[1], px[2], px[3]}};
         *reinterpret_cast<u32x4 *>(dst) = q;
+#endif
     } else {
         for (uint32_t k = 0; k < n; k++)
             dst[k] = px[k];
     }
+}
+
+MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t luma_w, uint32_t chroma_w,
+                              uint32_t luma_bytes, uint32_t chroma_bytes,
+                              uint32_t width, uint32_t height, uint32_t x4, uint32_t yp, uint8_t *rgba)
+{
+    const uint32_t x0 = x4 * 4, y = yp * 2;
+    if (y >= height || x0 >= width)
+        return;
+    const bool two = y + 1 < height;
+    const uint8_t *yrow = frame + (uint64_t)y * luma_w + x0;
+    const uint32_t yy0 = *reinterpret_cast<const uint32_t *>(yrow);
+    const uint32_t yy1 = *reinterpret_cast<const uint32_t *>(yrow + (two ? luma_w : 0));
+    const uint8_t *cbp = frame + luma_bytes + (uint64_t)yp * chroma_w + (x0 >> 1);
+    const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp);
+    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + chroma_bytes);
+    uint32_t px0[4], px1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = (cb >> (8 * (k >> 1))) & 0xff, r = (cr >> (8 * (k >> 1))) & 0xff;
+        px0[k] = ycbcr_to_rgba((yy0 >> (8 * k)) & 0xff, b, r);
+        px1[k] = ycbcr_to_rgba((yy1 >> (8 * k)) & 0xff, b, r);
+    }
+    const uint64_t p = (uint64_t)y * width + x0;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(rgba) + p;
+    const uint32_t n = width - x0 >= 4 ? 4 : width - x0;
+    rgba_store4(dst, p, px0, n);
+    if (two)
+        rgba_store4(dst + width, p + width, px1, n);
 }
 
 } // namespace mpg

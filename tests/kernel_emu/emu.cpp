@@ -163,7 +163,7 @@ int emu_video_run_split(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w,
             continue;
         const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
         const uint32_t quads = (width + 3) / 4;
-        for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+        for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
             for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
                 rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
                                   x4, y, rgba + fs * rgba_stride);
@@ -238,7 +238,7 @@ int emu_video_run_compact(uint8_t *frames, uint64_t frame_stride, uint32_t luma_
             continue;
         const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
         const uint32_t quads = (width + 3) / 4;
-        for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+        for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
             for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
                 rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
                                   x4, y, rgba + fs * rgba_stride);
@@ -318,7 +318,7 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
             continue;
         const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
         const uint32_t quads = (width + 3) / 4;
-        for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+        for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
             for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
                 rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
                                   x4, y, rgba + fs * rgba_stride);
@@ -330,7 +330,7 @@ void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, ui
                       uint8_t *rgba)
 {
     const uint32_t quads = (width + 3) / 4;
-    for (uint32_t y = 0; y < ((height + 3) / 4) * 4; y++)
+    for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
         for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
             rgba_convert_quad(frame, luma_w, luma_w / 2, luma_w * luma_h, luma_w * luma_h / 4, width, height, x4, y, rgba);
 }
