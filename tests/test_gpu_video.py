@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
     (160, 120, 10, "typical", 0.05, True),    # fused Frame.RGBA
     (176, 144, 5, "typical", 0.0, True),
     (24, 40, 4, "typical", 0.0, True),
+    (50, 35, 3, "typical", 0.0, True),        # odd height: the last RGBA row has no partner
     (1920, 1080, 4, "typical", 0.0, True),    # BASELINE config 3: 1080p, fused IDCT+MC+RGBA
     (1920, 1080, 2, "dense", 0.0, False),
 ])
@@ -39,8 +40,8 @@ def test_custom_quant_matrices(oracle, hip_ctx):
     dut.close()
 
 
-def test_standalone_rgba(oracle, hip_ctx):
-    w, h = 100, 60
+@pytest.mark.parametrize("w,h", [(100, 60), (37, 23), (16, 1), (3, 16)])  # odd sizes: partial quads, a last row without a partner
+def test_standalone_rgba(oracle, hip_ctx, w, h):
     ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h, 2)
     rng = np.random.default_rng(3)
     g = desc.geometry(w, h)

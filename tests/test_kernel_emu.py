@@ -16,6 +16,7 @@ from parity import bits_equal, mirror_ring, run_and_compare
     (160, 120, 7, "typical", 0.05, True),    # fused RGBA
     (176, 144, 4, "typical", 0.0, True),     # QCIF: height not a multiple of 16 in RGBA
     (24, 40, 4, "typical", 0.0, True),       # tiny, width not a multiple of 16
+    (50, 35, 3, "typical", 0.0, True),       # odd height: the last RGBA row has no partner
 ])
 @pytest.mark.parametrize("flavour", ["wave_chunk", "compact", "split", "fused", "fused_static"])
 def test_video_lane_logic_matches_oracle(oracle, emu, w, h, n, profile, raw, rgba, flavour):
@@ -34,10 +35,11 @@ def test_video_custom_quant_matrices(oracle, emu):
     run_and_compare(o, e, synth.generate_sequence(64, 48, 6, seed=11))
 
 
-def test_standalone_rgba(oracle, emu):
-    o, e = oracle.OracleStore(100, 60), emu.EmuStore(100, 60)
+@pytest.mark.parametrize("w,h", [(100, 60), (37, 23), (16, 1), (3, 16)])  # odd sizes: partial quads, a last row without a partner
+def test_standalone_rgba(oracle, emu, w, h):
+    o, e = oracle.OracleStore(w, h), emu.EmuStore(w, h)
     rng = np.random.default_rng(3)
-    g = desc.geometry(100, 60)
+    g = desc.geometry(w, h)
     y, cb, cr = (rng.integers(0, 256, n, dtype=np.uint8) for n in (g["luma_bytes"], g["chroma_bytes"], g["chroma_bytes"]))
     o.write_planes(0, 1, y, cb, cr)
     e.write_planes(0, 1, y, cb, cr)
