@@ -27,9 +27,11 @@
 //   pipeline: the history ring holds 79 slots, so the DCTs of step s+1 never touch a slot the
 //           windows of step s read.  Iteration s therefore runs, between two barriers, DCT(s+1) on
 //           wave (s+1)%4 (plus one window pair) and window(s) on the other three waves (five pairs
-//           each), while wave (s+2)%4 has the samples of step s+2 in flight from HBM straight into
-//           an LDS staging buffer (global_load_lds, two buffers): one barrier per step, no wave
-//           idles through the DCT or its HBM latency, no registers are held across it.
+//           each).  The DCT wave takes its samples from an LDS staging buffer and, as soon as it has
+//           them in registers, refills the same buffer with the samples of step s+2 straight from
+//           HBM (global_load_lds: every lane overwrites exactly the 8 x 16 bytes it has just read):
+//           one barrier per step, no wave idles through the DCT or its HBM latency, no registers
+//           are held across it.
 //
 // Time slicing: a sub-block depends on the previous 15 only through the history, and
 // every history slot is a pure function of one sub-block's samples.  So the frames of one
@@ -66,8 +68,8 @@ constexpr int kT0 = 16;                               // local time of the launc
 constexpr int kStep = 32;                             // sub-blocks per step: 64 DCTs = one full wave
 constexpr int kRing = 2 * kStep + 15;                 // DCT(s+1) writes [b+32, b+64) while window(s) reads [b-15, b+32)
 constexpr int kStageFloats = 64 * 32;                 // one step's samples: [8 x 16 bytes][64 lanes]
-constexpr int kHistBase = 2 * kStageFloats;           // LDS: two staging buffers, then the history
-constexpr int kAudioLdsFloats = kHistBase + (kRing + kMirrorSlots) * kSlotStride; // 40824 bytes: 4 workgroups per CU
+constexpr int kHistBase = kStageFloats;               // LDS: the staging buffer, then the history
+constexpr int kAudioLdsFloats = kHistBase + (kRing + kMirrorSlots) * kSlotStride; // 32632 bytes
 
 // c_N[i] = 0.5 / cos((2i+1)*pi/(2N)); identical float32 values to the decimal
 // literals of audio.go:498-661.
@@ -239,7 +241,7 @@ MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, 
 // workgroups resident on a CU do not all load the same SIMD
 MPG_HD uint32_t dct_wave(uint32_t si) { return si % kAudioWaves; }
 
-// ---- samples of step si -> staging buffer si&1, issued by wave si%4 (lane = channel*32 + j); they
+// ---- samples of step si -> the staging buffer, issued by wave si%4 (lane = channel*32 + j); they
 // have landed after the next barrier
 MPG_HD void audio_phase_fetch(const AudioArgs &a, uint32_t stream, uint32_t tg0, uint32_t tg1, uint32_t si, int tid, float *lds)
 {
@@ -250,24 +252,34 @@ MPG_HD void audio_phase_fetch(const AudioArgs &a, uint32_t stream, uint32_t tg0,
     if (tg >= tg1)
         return;
     const int32_t *src = samples_of(a, stream, tg, lane >> 5);
-    float *stage = lds + (si & 1) * kStageFloats;
 #pragma unroll
     for (int q = 0; q < 8; q++)
-        copy16_to_lds(src + 4 * q, stage + q * 256, lane);
+        copy16_to_lds(src + 4 * q, lds + q * 256, lane);
 }
 
-// ---- DCTs of step si from its staging buffer, on wave si%4
-MPG_HD void audio_phase_dct(uint32_t tg0, uint32_t tg1, uint32_t si, int tid, float *lds)
+// ---- DCTs of step si from the staging buffer, on wave si%4; the same lanes refill the buffer for
+// step si+1 (whose DCT wave is the next one) once their own samples are in registers
+MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t tg0, uint32_t tg1, uint32_t si, int tid, float *lds)
 {
     if ((uint32_t)(tid >> 6) != dct_wave(si))
         return;
     const int lane = tid & 63;
     const uint32_t tg = tg0 + si * kStep + (uint32_t)(lane & 31);
-    if (tg >= tg1)
-        return;
     int32_t in[32];
-    load_samples(reinterpret_cast<const int32_t *>(lds + (si & 1) * kStageFloats) + lane * 4, 256, in);
-    hist_matrixing(in, tg, lane >> 5, lds);
+    if (tg < tg1)
+        load_samples(reinterpret_cast<const int32_t *>(lds) + lane * 4, 256, in);
+#if MPG_ON_DEVICE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads above are done before the refill is issued
+#endif
+    const uint32_t tn = tg + kStep; // same lane, next step
+    if (tn < tg1) {
+        const int32_t *src = samples_of(a, stream, tn, lane >> 5);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            copy16_to_lds(src + 4 * q, lds + q * 256, lane);
+    }
+    if (tg < tg1)
+        hist_matrixing(in, tg, lane >> 5, lds);
 }
 
 // The 16 taps of one output sample of two sub-blocks when the ring position is 64*M

@@ -396,19 +396,17 @@ template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) vo
     const uint32_t tg0 = f0 * 36, tg1 = f1 * 36, n_steps = (tg1 - tg0 + kStep - 1) / kStep;
     float dreg[16];
     audio_load_window(a, tid, dreg);
-    // prologue: samples of steps 0 and 1 in flight, history from the state or rebuilt
+    // prologue: samples of step 0 in flight, history from the state or rebuilt
     audio_phase_fetch(a, stream, tg0, tg1, 0, tid, lds);
-    audio_phase_fetch(a, stream, tg0, tg1, 1, tid, lds);
     if (f0 == 0)
         audio_load_state(a, stream, vpos0, tid, lds);
     else
         audio_phase_warmup(a, stream, f0, tid, lds);
     __syncthreads();
-    audio_phase_dct(tg0, tg1, 0, tid, lds);
+    audio_phase_dct(a, stream, tg0, tg1, 0, tid, lds); // (also puts the samples of step 1 in flight)
     __syncthreads();
     for (uint32_t si = 0; si < n_steps; si++) {
-        audio_phase_fetch(a, stream, tg0, tg1, si + 2, tid, lds); // wave (si+2)%4 -> the buffer DCT(si) has left
-        audio_phase_dct(tg0, tg1, si + 1, tid, lds);               // wave (si+1)%4, fetched an iteration ago
+        audio_phase_dct(a, stream, tg0, tg1, si + 1, tid, lds); // wave (si+1)%4; refills the staging buffer for step si+2
         audio_phase_window<kFma, kFormat>(a, stream, vpos0, tg0, tg1, si, tid, dreg, lds);
         __syncthreads();
     }
@@ -1427,7 +1425,8 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     args.n_frames = n_frames;
     args.format = format;
     args.fma = a->fma;
-    // time slices per stream: one full residency of workgroups (4 per CU), at least 4 frames per slice
+    // time slices per stream: one full residency of workgroups (4 per CU are resident in practice: 5 x 32 KB
+    // of LDS do not fit next to the allocation granularity), at least 4 frames per slice
     uint32_t chunks = 1;
     if (const char *e = getenv("MPEGHIP_AUDIO_CHUNKS")) { // development knob
         chunks = (uint32_t)atoi(e);

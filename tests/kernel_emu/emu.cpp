@@ -359,22 +359,18 @@ template <bool kFma, int kFormat> static void emu_audio_blocks(const AudioArgs &
         for (int tid = 0; tid < kAudioThreads; tid++) {
             audio_load_window(a, tid, regs[tid].dreg);
             audio_phase_fetch(a, stream, tg0, tg1, 0, tid, lds.data());
-            audio_phase_fetch(a, stream, tg0, tg1, 1, tid, lds.data());
             if (f0 == 0)
                 audio_load_state(a, stream, vpos0, tid, lds.data());
             else
                 audio_phase_warmup(a, stream, f0, tid, lds.data());
         }
         for (int tid = 0; tid < kAudioThreads; tid++)
-            audio_phase_dct(tg0, tg1, 0, tid, lds.data());
+            audio_phase_dct(a, stream, tg0, tg1, 0, tid, lds.data());
         for (uint32_t si = 0; si < n_steps; si++) {
-            // a fetch only lands at the barrier: emulate by running it AFTER the DCT that shares the iteration
             for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_dct(tg0, tg1, si + 1, tid, lds.data());
+                audio_phase_dct(a, stream, tg0, tg1, si + 1, tid, lds.data());
             for (int tid = 0; tid < kAudioThreads; tid++)
                 audio_phase_window<kFma, kFormat>(a, stream, vpos0, tg0, tg1, si, tid, regs[tid].dreg, lds.data());
-            for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_fetch(a, stream, tg0, tg1, si + 2, tid, lds.data());
         }
         if (f1 == a.n_frames) {
             for (int tid = 0; tid < kAudioThreads; tid++)
