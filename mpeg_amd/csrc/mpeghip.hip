@@ -1350,6 +1350,12 @@ int mpeghip_audio_open(mpeghip_ctx *c, uint32_t n_streams, int fma_mode, mpeghip
         mpeghip_audio_close(a);
         return fail(MPEGHIP_ERR_OOM, "audio state allocation failed");
     }
+    if (getenv("MPEGHIP_DEBUG")) { // development aid: resident workgroups per CU of both kernels
+        int na = 0, nv = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, audio_kernel<false, MPEGHIP_AUDIO_F32N>, kAudioThreads, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nv, recon_wc_kernel<4>, 256, 0);
+        fprintf(stderr, "mpeghip: occupancy audio_kernel %d, recon_wc_kernel<4> %d workgroups per CU\n", na, nv);
+    }
     *out = a;
     return MPEGHIP_OK;
 }
