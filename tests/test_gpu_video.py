@@ -96,6 +96,42 @@ def test_out_of_range_vector_is_rejected(hip_ctx):
     dut.close()
 
 
+def test_malformed_descriptors_are_refused_and_nothing_is_launched(oracle, hip_ctx):
+    """Every field a caller can get wrong: the submit returns an error code (the reference would panic on
+    an out-of-bounds slice), the device is not touched, and the store keeps working afterwards."""
+    w, h = 64, 48
+    seq = synth.generate_sequence(w, h, 3, seed=21)
+    ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h)
+    run_and_compare(ref, dut, seq[:1])
+    good = seq[1]
+    before = [dut.read_planes(0, s) for s in range(3)]
+
+    def corrupt(field, value, which="mbs", index=0):
+        pics, mbs, coefs = good.pics.copy(), good.mbs.copy(), good.coefs.copy()
+        (mbs if which == "mbs" else pics)[field][index] = value
+        return pics, mbs, coefs
+
+    coded = int(np.nonzero(good.mbs["cbp"])[0][0])
+    cases = [
+        corrupt("mb_x", 4), corrupt("mb_y", 3), corrupt("pic", 1), corrupt("cbp", 0x40, index=coded),
+        corrupt("qscale", 0, index=coded), corrupt("qscale", 32, index=coded),
+        corrupt("coef_off", 1 << 20, index=coded), corrupt("flags", desc.MB_REF_FWD | desc.MB_REF_BWD),
+        corrupt("flags", desc.MB_INTRA | desc.MB_REF_FWD), corrupt("flags", 0),
+        corrupt("stream", 1, "pics"), corrupt("cur", 3, "pics"), corrupt("fwd", 7, "pics"), corrupt("bwd", 200, "pics"),
+        corrupt("mb_count", len(good.mbs) + 1, "pics"), corrupt("mb_first", 5, "pics"),
+    ]
+    for pics, mbs, coefs in cases:
+        with pytest.raises(abi.MpegHipError) as ei:
+            dut.submit(pics, mbs, coefs)
+        assert ei.value.code in (abi.ERR_INVALID, abi.ERR_RANGE)
+    with pytest.raises(abi.MpegHipError):  # coefficient buffer not a whole number of 128-byte units
+        dut.submit(good.pics, good.mbs, good.coefs[:-1])
+    for s in range(3):
+        assert_planes_equal(before[s], dut.read_planes(0, s), "slot %d after refused submits" % s)
+    run_and_compare(ref, dut, seq[1:])  # and the stream continues bit-exactly
+    dut.close()
+
+
 def test_overread_into_next_plane_and_pad(oracle, hip_ctx):
     """Legal reads past a plane end: bottom-row macroblocks with downward half-pel vectors
     read the first rows of the next plane / the zero pad, exactly like the reference's shared buffer."""
