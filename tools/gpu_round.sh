@@ -26,6 +26,11 @@ cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $GRAFT_REPO_ROOT
 for f in $(find $OUT/prof_trace -name "*kernel_stats.csv" | head -1); do head -12 $f | cut -c1-220; done
 find $OUT/prof_trace -name "*kernel_trace.csv" -delete
+echo "== rocprofv3 kernel trace: Frame.RGBA"
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_rgba -o trace -- python $GRAFT_REPO_ROOT/tools/bench_rgba.py 512 > $GRAFT_REPO_ROOT/$OUT/bench_rgba.txt 2>&1; echo "rocprof rgba rc=$?"
+cd $GRAFT_REPO_ROOT
+grep rgba_kernel $OUT/bench_rgba.txt; for f in $(find $OUT/prof_rgba -name "*kernel_stats.csv" | head -1); do head -4 $f | cut -c1-220; done
+find $OUT/prof_rgba -name "*kernel_trace.csv" -delete
 echo "== rocprofv3 PMC (HBM traffic; separate passes)"
 cd /tmp
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
