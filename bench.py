@@ -171,6 +171,20 @@ def main():
         smp = synth.audio_frames(args.audio_streams, args.audio_frames)
         d_s, d_o = a.device_buffers(args.audio_frames, desc.AUDIO_F32N)
         a.upload(d_s, smp)
+        a.synth_device(d_s, args.audio_frames, desc.AUDIO_F32N, d_o)  # first launch from the zero state: checked below
+        ctx.sync()
+        aparity = None
+        if args.check:
+            from oracle import pyoracle
+            got = a.download(d_o, args.audio_streams * args.audio_frames * 2304, desc.AUDIO_F32N).reshape(args.audio_streams, -1)
+            probe = sorted({0, args.audio_streams // 2, args.audio_streams - 1})
+            ok = True
+            for st in probe:
+                want = pyoracle.OracleSynth(1, 0).synth(smp[st:st + 1], desc.AUDIO_F32N).reshape(-1)
+                ok &= bool(np.array_equal(want.view(np.uint32), got[st].view(np.uint32)))
+            if not ok:
+                raise SystemExit("bench: audio samples differ from the oracle — result invalid")
+            aparity = "bit-exact vs oracle (no-FMA) on streams %s x %d frames" % (probe, args.audio_frames)
         for _ in range(2):
             a.synth_device(d_s, args.audio_frames, desc.AUDIO_F32N, d_o)
         ctx.sync()
@@ -186,7 +200,9 @@ def main():
             "streams": args.audio_streams, "frames_per_launch": args.audio_frames, "ms_per_launch": ams,
             "realtime_streams_44k1": frames * 1152 / (ams * 1e-3) / 44100.0,
             "roofline": {"bound": "hbm", "achieved": abytes / (ams * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": abytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+                         "frac": abytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "audio_kernel<false, F32N> (DCT-32 + polyphase window, 4 waves per stream slice)"},
+            "parity": aparity,
         }
         a.close()
 
