@@ -1,0 +1,128 @@
+// batch.cpp — mpeg::VideoBatch: many streams, one reconstruction call per tick.
+//
+// Each stream keeps its own, unmodified parser (mpeg::Video); what it would submit to its own device
+// store goes through a Port into the batch's descriptor arrays instead (stream index, macroblock and
+// coefficient offsets rebased).  Pictures of ONE stream depend on each other, so a stream never has two
+// pictures in the same device call: a second one (first reference picture of a stream, which yields
+// no frame; the re-submit after a duplicated macroblock address in a damaged stream) flushes the batch
+// first — launches are stream ordered, so "last writer in bitstream order" is kept.
+#include <stdexcept>
+#include <string.h>
+
+#include "mpeg.hpp"
+
+namespace mpeg {
+
+class VideoBatch::Port : public VideoBackend {
+public:
+    Port(VideoBatch *b, uint32_t stream) : b_(b), stream_(stream) {}
+    void open(int width, int height) override
+    {
+        if (b_->width_ == 0) {
+            b_->width_ = width;
+            b_->height_ = height;
+            b_->store_->open(width, height, b_->capacity_);
+        } else if (b_->width_ != width || b_->height_ != height) {
+            throw std::runtime_error("VideoBatch: all streams must have the same picture size");
+        }
+    }
+    void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override
+    {
+        b_->Flush(); // the table belongs to pictures not yet queued
+        b_->store_->setQuant(stream_, intra, non_intra);
+    }
+    void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
+                size_t coef_bytes) override
+    {
+        b_->queue(stream_, pic, mbs, n_mbs, coefs, coef_bytes);
+    }
+    void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
+    {
+        b_->Flush();
+        b_->store_->readPlanes(stream_, slot, y, cb, cr);
+    }
+    void readRGBA(uint32_t slot, uint8_t *dst) override
+    {
+        b_->Flush();
+        b_->store_->readRGBA(stream_, slot, dst);
+    }
+
+private:
+    VideoBatch *b_;
+    uint32_t stream_;
+};
+
+VideoBatch::VideoBatch(Device *dev, uint32_t n_streams) : VideoBatch(dev->newBatchStore(), n_streams) {}
+
+VideoBatch::VideoBatch(std::unique_ptr<BatchStore> store, uint32_t n_streams) : store_(std::move(store)), capacity_(n_streams)
+{
+    if (n_streams == 0)
+        throw std::runtime_error("VideoBatch: n_streams is 0");
+    pending_.assign(n_streams, 0);
+}
+
+VideoBatch::~VideoBatch() {}
+
+Video *VideoBatch::AddStream(Buffer *buf)
+{
+    if (videos_.size() >= capacity_)
+        throw std::runtime_error("VideoBatch: more streams than the batch was opened for");
+    const uint32_t idx = (uint32_t)videos_.size();
+    videos_.emplace_back(new Video(buf, std::unique_ptr<VideoBackend>(new Port(this, idx))));
+    return videos_.back().get();
+}
+
+void VideoBatch::queue(uint32_t stream, const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                       const uint8_t *coefs, size_t coef_bytes)
+{
+    if (pending_[stream])
+        Flush(); // two pictures of one stream never share a device call
+    const uint32_t pic_index = (uint32_t)pics_.size(), mb_first = (uint32_t)mbs_.size();
+    const uint32_t unit0 = (uint32_t)(coefs_.size() / MPEGHIP_COEF_UNIT);
+    mpeghip_pic_desc p = pic;
+    p.stream = stream;
+    p.mb_first = mb_first;
+    p.mb_count = n_mbs;
+    pics_.push_back(p);
+    mbs_.insert(mbs_.end(), mbs, mbs + n_mbs);
+    for (uint32_t i = mb_first; i < mb_first + n_mbs; i++) {
+        mbs_[i].pic = pic_index;
+        mbs_[i].coef_off += unit0;
+    }
+    coefs_.insert(coefs_.end(), coefs, coefs + coef_bytes);
+    pending_[stream] = 1;
+    queued_pictures_++;
+}
+
+void VideoBatch::Flush()
+{
+    if (pics_.empty())
+        return;
+    store_->submit(pics_.data(), (uint32_t)pics_.size(), mbs_.data(), (uint32_t)mbs_.size(), coefs_.data(), coefs_.size());
+    device_submits_++;
+    pics_.clear();
+    mbs_.clear();
+    coefs_.clear();
+    std::fill(pending_.begin(), pending_.end(), 0);
+}
+
+size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
+{
+    const size_t n = videos_.size();
+    frames.assign(n, nullptr);
+    std::vector<uint32_t> slot(n, 0);
+    std::vector<double> time(n, 0.0);
+    std::vector<uint8_t> got(n, 0);
+    for (size_t i = 0; i < n; i++) // CPU: parse, queue
+        got[i] = videos_[i]->DecodeDeferred(&slot[i], &time[i]) ? 1 : 0;
+    Flush();                       // GPU: one call for all streams
+    size_t produced = 0;
+    for (size_t i = 0; i < n; i++)
+        if (got[i]) {
+            frames[i] = videos_[i]->Fetch(slot[i], time[i], fetch);
+            produced++;
+        }
+    return produced;
+}
+
+} // namespace mpeg

@@ -7,6 +7,7 @@
 #include <exception>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "mpeg.hpp"
 
@@ -40,6 +41,11 @@ struct AudioHandle {
 struct MpegHandle {
     std::unique_ptr<MPEG> m;
     int video_calls = 0, audio_calls = 0; // callbacks installed by mpeghost_mpeg_count_callbacks
+};
+struct BatchHandle {
+    std::vector<std::unique_ptr<Buffer>> bufs;
+    std::unique_ptr<VideoBatch> batch;
+    std::vector<Frame *> frames;
 };
 struct DemuxHandle {
     std::unique_ptr<Buffer> buf;
@@ -286,6 +292,58 @@ int mpeghost_mpeg_seek_frame(void *m, double seconds, int exact, mpeghost_frame 
         fill(out, f);
         return 1;
     }, -1);
+}
+
+// VideoBatch: many elementary streams of one picture size, one device call per tick
+void *mpeghost_batch_open(void *device, uint32_t n_streams)
+{
+    return guard([&]() -> void * {
+        std::unique_ptr<BatchHandle> h(new BatchHandle);
+        h->batch.reset(new VideoBatch(static_cast<Device *>(device), n_streams));
+        return h.release();
+    }, (void *)nullptr);
+}
+// same over an injected BatchStore (tests); ownership of `store` passes to the batch
+void *mpeghost_batch_open_store(void *store, uint32_t n_streams)
+{
+    return guard([&]() -> void * {
+        std::unique_ptr<BatchHandle> h(new BatchHandle);
+        h->batch.reset(new VideoBatch(std::unique_ptr<BatchStore>(static_cast<BatchStore *>(store)), n_streams));
+        return h.release();
+    }, (void *)nullptr);
+}
+void mpeghost_batch_close(void *h) { delete static_cast<BatchHandle *>(h); }
+int mpeghost_batch_add_stream(void *hv, const uint8_t *data, size_t len)
+{
+    return guard([&]() -> int {
+        BatchHandle *h = static_cast<BatchHandle *>(hv);
+        h->bufs.push_back(Buffer::FromMemory(data, len));
+        h->batch->AddStream(h->bufs.back().get());
+        return (int)h->batch->Streams() - 1;
+    }, -1);
+}
+// advance every stream by one frame; returns the number of frames produced (-1 on error)
+int mpeghost_batch_decode_all(void *hv, int fetch)
+{
+    return guard([&]() -> int {
+        BatchHandle *h = static_cast<BatchHandle *>(hv);
+        return (int)h->batch->DecodeAll(h->frames, fetch != 0);
+    }, -1);
+}
+// frame of stream i from the last decode_all: 1 and *out filled, or 0
+int mpeghost_batch_frame(void *hv, uint32_t stream, mpeghost_frame *out)
+{
+    BatchHandle *h = static_cast<BatchHandle *>(hv);
+    if (stream >= h->frames.size() || !h->frames[stream])
+        return 0;
+    fill(out, h->frames[stream]);
+    return 1;
+}
+void mpeghost_batch_counters(void *hv, uint64_t out[2])
+{
+    BatchHandle *h = static_cast<BatchHandle *>(hv);
+    out[0] = h->batch->DeviceSubmits();
+    out[1] = h->batch->QueuedPictures();
 }
 
 // NewDemux over a complete program stream (mpeg_test.go:88-100)

@@ -53,6 +53,45 @@ private:
     mpeghip_video *store_ = nullptr;
 };
 
+class HipBatchStore : public BatchStore {
+public:
+    explicit HipBatchStore(mpeghip_ctx *ctx) : ctx_(ctx) {}
+    ~HipBatchStore() override
+    {
+        if (store_)
+            mpeghip_video_close(store_);
+    }
+    void open(int width, int height, uint32_t n_streams) override
+    {
+        if (store_)
+            mpeghip_video_close(store_);
+        store_ = nullptr;
+        check(mpeghip_video_open(ctx_, (uint32_t)width, (uint32_t)height, n_streams, &store_), "mpeghip_video_open");
+    }
+    void setQuant(uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64]) override
+    {
+        check(mpeghip_video_set_quant(store_, stream, intra, non_intra), "mpeghip_video_set_quant");
+    }
+    void submit(const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
+                size_t coef_bytes) override
+    {
+        check(mpeghip_video_submit(store_, pics, n_pics, mbs, n_mbs, coefs, coef_bytes), "mpeghip_video_submit");
+    }
+    void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
+    {
+        check(mpeghip_video_read_planes(store_, stream, slot, y, cb, cr), "mpeghip_video_read_planes");
+    }
+    void readRGBA(uint32_t stream, uint32_t slot, uint8_t *dst) override
+    {
+        check(mpeghip_video_rgba_convert(store_, slot, stream, 1), "mpeghip_video_rgba_convert");
+        check(mpeghip_video_read_rgba(store_, stream, slot, dst), "mpeghip_video_read_rgba");
+    }
+
+private:
+    mpeghip_ctx *ctx_;
+    mpeghip_video *store_ = nullptr;
+};
+
 class HipAudioBackend : public AudioBackend {
 public:
     HipAudioBackend(mpeghip_ctx *ctx, int fma_mode)
@@ -80,6 +119,7 @@ Device::Device(int ordinal)
 Device::~Device() { mpeghip_ctx_destroy(ctx_); }
 
 std::unique_ptr<VideoBackend> Device::newVideoBackend() { return std::unique_ptr<VideoBackend>(new HipVideoBackend(ctx_)); }
+std::unique_ptr<BatchStore> Device::newBatchStore() { return std::unique_ptr<BatchStore>(new HipBatchStore(ctx_)); }
 std::unique_ptr<AudioBackend> Device::newAudioBackend(int fma_mode)
 {
     return std::unique_ptr<AudioBackend>(new HipAudioBackend(ctx_, fma_mode));

@@ -135,6 +135,20 @@ public:
     virtual void readRGBA(uint32_t slot, uint8_t *dst) = 0;  // Frame.RGBA of the slot
 };
 
+// Frame stores of MANY streams of one picture size behind one reconstruction call (libmpeghip's
+// mpeghip_video with n_streams > 1): what VideoBatch drives.  Same rule as VideoBackend: the product
+// ships one implementation (hip_backend.cpp), tests inject the lane emulator.
+class BatchStore {
+public:
+    virtual ~BatchStore() {}
+    virtual void open(int width, int height, uint32_t n_streams) = 0;
+    virtual void setQuant(uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64]) = 0;
+    virtual void submit(const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                        const uint8_t *coefs, size_t coef_bytes) = 0;
+    virtual void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) = 0;
+    virtual void readRGBA(uint32_t stream, uint32_t slot, uint8_t *dst) = 0;
+};
+
 class AudioBackend {
 public:
     virtual ~AudioBackend() {}
@@ -150,6 +164,7 @@ public:
     mpeghip_ctx *ctx() const { return ctx_; }
     std::unique_ptr<VideoBackend> newVideoBackend();
     std::unique_ptr<AudioBackend> newAudioBackend(int fma_mode);
+    std::unique_ptr<BatchStore> newBatchStore();
 private:
     mpeghip_ctx *ctx_ = nullptr;
 };
@@ -170,6 +185,11 @@ public:
     void Rewind();
     bool HasEnded() const { return buf_->HasEnded(); }
     Frame *Decode();                                 // video.go:209-268
+    // Decode() in two halves, for VideoBatch: DecodeDeferred parses up to and including the picture that
+    // completes the next output frame and hands its work to the backend WITHOUT reading anything back;
+    // Fetch copies that frame's planes to the host (what makes Frame.Y/Cb/Cr.Data valid).
+    bool DecodeDeferred(uint32_t *slot, double *time);
+    Frame *Fetch(uint32_t slot, double time, bool read_back = true);
     const VideoStats &Stats() const { return stats_; }
 
     // used by Frame
@@ -230,6 +250,44 @@ private:
     std::vector<uint8_t> host_planes_[3];
     std::vector<uint8_t> host_rgba_;
     VideoStats stats_;
+};
+
+// Many independent streams of one picture size on one GPU: every DecodeAll() advances each stream by
+// one output frame — the streams are parsed one after the other on the CPU, their pictures are
+// reconstructed by ONE device call (one mpeghip_pic_desc per stream), then the
+// frames are fetched.  This is the shape of the 10 000-stream deployment; a lone Video pays one
+// launch + one read-back per 330-macroblock picture.
+class VideoBatch {
+public:
+    VideoBatch(Device *dev, uint32_t n_streams);
+    VideoBatch(std::unique_ptr<BatchStore> store, uint32_t n_streams); // injected store (tests)
+    ~VideoBatch();
+    // NewVideo over `buf` as stream number Streams(); the Video is owned by the batch.  All streams must
+    // have the same picture size (std::runtime_error from the first Decode otherwise).
+    Video *AddStream(Buffer *buf);
+    uint32_t Streams() const { return (uint32_t)videos_.size(); }
+    Video *Stream(uint32_t i) { return videos_[i].get(); }
+    // frames[i] = the next frame of stream i, or nullptr (ended / no frame yet).  With fetch = false the
+    // planes stay on the device (frames[i]->Y.Data is stale): for consumers that read RGBA / planes there.
+    size_t DecodeAll(std::vector<Frame *> &frames, bool fetch = true);
+    void Flush();                                  // submit whatever is queued
+    uint64_t DeviceSubmits() const { return device_submits_; }
+    uint64_t QueuedPictures() const { return queued_pictures_; }
+
+private:
+    class Port;
+    friend class Port;
+    void queue(uint32_t stream, const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
+               size_t coef_bytes);
+    std::unique_ptr<BatchStore> store_;
+    uint32_t capacity_;
+    int width_ = 0, height_ = 0;
+    std::vector<std::unique_ptr<Video>> videos_;
+    std::vector<mpeghip_pic_desc> pics_;
+    std::vector<mpeghip_mb_desc> mbs_;
+    std::vector<uint8_t> coefs_;
+    std::vector<uint8_t> pending_;                 // stream already has a picture in the open batch
+    uint64_t device_submits_ = 0, queued_pictures_ = 0;
 };
 
 // -------------------------------------------------------------------- audio.go

@@ -195,8 +195,17 @@ const uint8_t *Frame::RGBA() { return owner->fetchRGBA(slot); }
 
 Frame *Video::Decode()
 { // video.go:209-268
-    if (!HasHeader())
+    uint32_t slot;
+    double t;
+    if (!DecodeDeferred(&slot, &t))
         return nullptr;
+    return Fetch(slot, t);
+}
+
+bool Video::DecodeDeferred(uint32_t *slot, double *time)
+{ // video.go:209-268 up to the frame selection
+    if (!HasHeader())
+        return false;
     int out_slot = -1;
     for (;;) {
         if (start_code_ != kStartPicture) {
@@ -208,11 +217,11 @@ Frame *Video::Decode()
                     out_slot = (int)slot_bwd_;
                     break;
                 }
-                return nullptr;
+                return false;
             }
         }
         if (buf_->hasStartCode(kStartPicture) == -1 && !buf_->HasEnded())
-            return nullptr;
+            return false;
         buf_->discardReadBytes();
 
         decodePicture();
@@ -228,10 +237,17 @@ Frame *Video::Decode()
         if (out_slot >= 0)
             break;
     }
-    Frame *frame = frameForSlot((uint32_t)out_slot);
-    frame->Time = time_;
+    *slot = (uint32_t)out_slot;
+    *time = time_;
     frames_decoded_++;
     time_ = (double)frames_decoded_ / frame_rate_;
+    return true;
+}
+
+Frame *Video::Fetch(uint32_t slot, double time, bool read_back)
+{
+    Frame *frame = read_back ? frameForSlot(slot) : &frames_[slot];
+    frame->Time = time;
     return frame;
 }
 

@@ -79,6 +79,58 @@ private:
     uint8_t qt_[256];
 };
 
+// multi-stream store over the wave-chunk lane emulator (what HipBatchStore is over libmpeghip)
+class EmuBatchStore : public mpeg::BatchStore {
+public:
+    void open(int width, int height, uint32_t n_streams) override
+    {
+        w_ = width;
+        h_ = height;
+        n_ = n_streams;
+        lw_ = ((width + 15) >> 4) << 4;
+        lh_ = ((height + 15) >> 4) << 4;
+        luma_ = (size_t)lw_ * lh_;
+        chroma_ = luma_ / 4;
+        stride_ = (luma_ + 2 * chroma_ + (size_t)lw_ * 16 + 64 + 255) / 256 * 256;
+        frames_.assign(stride_ * 3 * n_streams + 4096, 0);
+        rgba_stride_ = ((size_t)w_ * h_ * 4 + 255) / 256 * 256;
+        rgba_.assign(rgba_stride_ * 3 * n_streams, 0);
+        qt_.assign((size_t)256 * n_streams, 0);
+    }
+    void setQuant(uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64]) override
+    {
+        uint8_t *t = qt_.data() + (size_t)stream * 256;
+        for (int cls = 0; cls < 2; cls++)
+            for (int c = 0; c < 8; c++)
+                for (int r = 0; r < 8; r++) {
+                    t[cls * 128 + c * 16 + r] = (cls ? non_intra : intra)[r * 8 + c];
+                    t[cls * 128 + c * 16 + 8 + r] = kPremult[r * 8 + c];
+                }
+    }
+    void submit(const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
+                size_t) override
+    {
+        emu_video_run_wc(frames_.data(), stride_, lw_, lh_, w_, h_, pics, n_pics, mbs, n_mbs, coefs, qt_.data(), rgba_.data(),
+                         rgba_stride_);
+    }
+    void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
+    {
+        const uint8_t *f = frames_.data() + ((size_t)stream * 3 + slot) * stride_;
+        memcpy(y, f, luma_);
+        memcpy(cb, f + luma_, chroma_);
+        memcpy(cr, f + luma_ + chroma_, chroma_);
+    }
+    void readRGBA(uint32_t stream, uint32_t slot, uint8_t *dst) override
+    {
+        emu_rgba_convert(frames_.data() + ((size_t)stream * 3 + slot) * stride_, lw_, lh_, w_, h_, dst);
+    }
+
+private:
+    uint32_t w_ = 0, h_ = 0, lw_ = 0, lh_ = 0, n_ = 0;
+    size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0;
+    std::vector<uint8_t> frames_, rgba_, qt_;
+};
+
 class EmuAudioBackend : public mpeg::AudioBackend {
 public:
     EmuAudioBackend(int fma, const float *window) : fma_(fma)
@@ -113,5 +165,6 @@ void host_emu_configure(int flavour, const float *window512)
     memcpy(g_window, window512, sizeof(g_window));
 }
 void *host_emu_make_video(void) { return new EmuVideoBackend(g_flavour); }
+void *host_emu_batch_store(void) { return new EmuBatchStore(); }
 void *host_emu_make_audio(int fma) { return new EmuAudioBackend(fma, g_window); }
 }

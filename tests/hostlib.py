@@ -56,6 +56,11 @@ def host():
             "mpeghost_mpeg_decode": (None, [P, C.c_double]),
             "mpeghost_mpeg_seek": (C.c_int, [P, C.c_double, C.c_int]),
             "mpeghost_mpeg_seek_frame": (C.c_int, [P, C.c_double, C.c_int, C.POINTER(HostFrame)]),
+            "mpeghost_batch_open": (P, [P, C.c_uint32]), "mpeghost_batch_open_store": (P, [P, C.c_uint32]),
+            "mpeghost_batch_close": (None, [P]), "mpeghost_batch_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
+            "mpeghost_batch_decode_all": (C.c_int, [P, C.c_int]),
+            "mpeghost_batch_frame": (C.c_int, [P, C.c_uint32, C.POINTER(HostFrame)]),
+            "mpeghost_batch_counters": (None, [P, C.POINTER(C.c_uint64 * 2)]),
             "mpeghost_demux_open": (P, [C.c_char_p, C.c_size_t]), "mpeghost_demux_close": (None, [P]),
             "mpeghost_demux_start_time": (C.c_double, [P, C.c_int]), "mpeghost_demux_duration": (C.c_double, [P, C.c_int]),
             "mpeghost_demux_probe": (C.c_int, [P, C.c_size_t]), "mpeghost_demux_streams": (None, [P, C.POINTER(C.c_int * 2)]),
@@ -90,6 +95,8 @@ def host_emu():
         L.host_emu_video_backend.argtypes = [C.c_int]
         L.host_emu_audio_backend.restype = C.c_void_p
         L.host_emu_audio_backend.argtypes = [C.c_int, C.c_void_p]
+        L.host_emu_batch_store.restype = C.c_void_p
+        L.host_emu_batch_store.argtypes = []
         L.host_emu_configure.restype = None
         L.host_emu_configure.argtypes = [C.c_int, C.c_void_p]
         _emu = L
@@ -295,4 +302,45 @@ class HostMpeg:
     def close(self):
         if self.h:
             host().mpeghost_mpeg_close(self.h)
+            self.h = None
+
+
+class HostBatch:
+    """mpeg::VideoBatch: n elementary streams of one picture size, one device call per decode_all()."""
+
+    def __init__(self, n_streams: int, device=None):
+        L = host()
+        if device is not None:
+            self.h = L.mpeghost_batch_open(device, n_streams)
+        else:
+            self.h = L.mpeghost_batch_open_store(host_emu().host_emu_batch_store(), n_streams)
+        if not self.h:
+            raise RuntimeError(L.mpeghost_last_error().decode())
+        self._keep = []
+
+    def add_stream(self, data: bytes) -> int:
+        self._keep.append(data)
+        i = host().mpeghost_batch_add_stream(self.h, data, len(data))
+        if i < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return i
+
+    def decode_all(self, fetch=True) -> int:
+        n = host().mpeghost_batch_decode_all(self.h, int(fetch))
+        if n < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return n
+
+    def frame(self, stream: int):
+        f = HostFrame()
+        return f if host().mpeghost_batch_frame(self.h, stream, C.byref(f)) == 1 else None
+
+    def counters(self):
+        out = (C.c_uint64 * 2)()
+        host().mpeghost_batch_counters(self.h, C.byref(out))
+        return {"device_submits": out[0], "queued_pictures": out[1]}
+
+    def close(self):
+        if self.h:
+            host().mpeghost_batch_close(self.h)
             self.h = None

@@ -121,3 +121,16 @@ def test_seek_on_gpu_matches_the_lane_emulator(emu, golden_dir, device):
     assert gpu.time == cpu.time and gpu.audio_time == cpu.audio_time and abs(gpu.audio_time - gpu.time) <= 0.5
     gpu.close()
     cpu.close()
+
+
+def test_video_batch_on_gpu(oracle, golden_dir, device):
+    """mpeg::VideoBatch over the HIP store: staggered, mixed streams reconstructed by one device call per tick,
+    each bit-identical to its golden hash (tests/test_host_batch.py runs the same on the lane emulator)."""
+    from test_host_batch import TESTMPG_VIDEO_HASH as CLEAN, VIDEO_HASH as DAMAGED, run_batch
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    clean = oracle.ps_extract((golden_dir / "test.mpg").read_bytes(), 0xE0)[0]
+    streams = [es, clean, es, es, clean, es, es, clean]
+    h, n, c = run_batch(oracle, streams, [0, 0, 1, 5, 9, 2, 2, 3], device=device)
+    assert h == [DAMAGED if s is es else CLEAN for s in streams]
+    assert n == [260 if s is es else 278 for s in streams]
+    assert c["device_submits"] < c["queued_pictures"] / 4

@@ -1,0 +1,72 @@
+"""mpeg::VideoBatch (mpeg_amd/host/batch.cpp): many streams parsed on the CPU, ONE reconstruction call per
+tick.  CPU only: the store is the test-only lane emulator; the HIP store runs the same cases in
+test_gpu_golden.py.  Every stream must come out exactly as if it had been decoded alone — the golden
+hash of the reference's TestVideoGolden (mpeg_test.go:205-231) — whatever the others are doing."""
+import numpy as np
+import pytest
+
+import hostlib
+
+VIDEO_HASH = 0xea6d7fcb1340ba3f       # testdata/test.mpeg1video, damaged stream (53 invalid blocks, duplicates)
+TESTMPG_VIDEO_HASH = 0xd00818edcafdc702
+
+
+def run_batch(oracle, streams, delays, device=None):
+    """streams[i] joins the batch after delays[i] ticks; returns per-stream (hash, frames) + counters."""
+    b = hostlib.HostBatch(len(streams), device=device)
+    h = [oracle.FNV_OFFSET] * len(streams)
+    n = [0] * len(streams)
+    added, tick = 0, 0
+    order = sorted(range(len(streams)), key=lambda i: delays[i])
+    index_of = {}
+    while True:
+        while added < len(order) and delays[order[added]] <= tick:
+            index_of[b.add_stream(streams[order[added]])] = order[added]
+            added += 1
+        produced = b.decode_all()
+        for k, i in index_of.items():
+            f = b.frame(k)
+            if f is not None:
+                for p in hostlib.frame_planes(f):
+                    h[i] = oracle.fnv1a64(p, h[i])
+                n[i] += 1
+        tick += 1
+        if produced == 0 and added == len(order):
+            break
+    c = b.counters()
+    b.close()
+    return h, n, c
+
+
+def test_lockstep_streams_share_one_device_call_per_tick(oracle, golden_dir):
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    h, n, c = run_batch(oracle, [es] * 6, [0] * 6)
+    assert h == [VIDEO_HASH] * 6 and n == [260] * 6
+    # 6 streams x ~274 pictures, but close to one device call per tick (a few extra: the first reference
+    # picture of a stream yields no frame, duplicated macroblock addresses re-submit)
+    assert c["queued_pictures"] >= 6 * 260 and c["device_submits"] < c["queued_pictures"] / 4
+
+
+def test_staggered_and_mixed_streams(oracle, golden_dir):
+    """Streams at different positions of their GOPs in every call (I, P and B pictures of different
+    streams side by side in one submit), one of them a different bitstream of the same picture size."""
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    clean = oracle.ps_extract((golden_dir / "test.mpg").read_bytes(), 0xE0)[0]
+    streams = [es, clean, es, es, clean]
+    h, n, c = run_batch(oracle, streams, [0, 0, 1, 5, 9])
+    assert h == [VIDEO_HASH, TESTMPG_VIDEO_HASH, VIDEO_HASH, VIDEO_HASH, TESTMPG_VIDEO_HASH]
+    assert n == [260, 278, 260, 260, 278]
+
+
+def test_different_picture_sizes_are_refused(oracle, golden_dir):
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    # same stream with the 12-bit horizontal size in the sequence header patched from 160 to 176
+    i = es.find(b"\x00\x00\x01\xb3")
+    assert i >= 0 and (es[i + 4] << 4 | es[i + 5] >> 4) == 160
+    other = bytearray(es)
+    other[i + 4], other[i + 5] = 176 >> 4, ((176 & 15) << 4) | (es[i + 5] & 15)
+    b = hostlib.HostBatch(2)
+    b.add_stream(es)
+    with pytest.raises(RuntimeError, match="same picture size"):
+        b.add_stream(bytes(other))
+    b.close()

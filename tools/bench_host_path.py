@@ -86,6 +86,24 @@ def main():
         d.close()
         best = dt if best is None or dt < best else best
     print("config 1, CPU oracle (C restatement of the reference, 1 thread): %d pictures in %.1f ms = %.0f pictures/s" % (n, best * 1e3, n / best))
+    # the same file as N lockstep streams through mpeg::VideoBatch: one device call per tick
+    es = pyoracle.ps_extract(ps, 0xE0)[0]
+    for n_streams, fetch in ((64, True), (64, False), (512, False)):
+        b = hostlib.HostBatch(n_streams, device=dev)
+        for _ in range(n_streams):
+            b.add_stream(es)
+        t0, frames = time.perf_counter(), 0
+        while True:
+            k = b.decode_all(fetch=fetch)
+            if k == 0:
+                break
+            frames += k
+        dt = time.perf_counter() - t0
+        c = b.counters()
+        b.close()
+        print("config 1 x %d streams, VideoBatch (%s): %d pictures in %.1f ms = %.0f pictures/s, %d device calls for %d pictures"
+              % (n_streams, "frames read back" if fetch else "frames stay on the device", frames, dt * 1e3, frames / dt,
+                 c["device_submits"], c["queued_pictures"]))
     hostlib.host().mpeghost_device_destroy(dev)
 
 
