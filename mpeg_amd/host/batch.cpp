@@ -113,9 +113,24 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
     std::vector<uint32_t> slot(n, 0);
     std::vector<double> time(n, 0.0);
     std::vector<uint8_t> got(n, 0);
-    for (size_t i = 0; i < n; i++) // CPU: parse, queue
-        got[i] = videos_[i]->DecodeDeferred(&slot[i], &time[i]) ? 1 : 0;
-    Flush();                       // GPU: one call for all streams
+    // Rounds of "every stream that still owes a frame parses ONE picture, then one device call": a tick
+    // costs as many calls as the neediest stream has pictures in it (1; 2 at a stream's start), not one
+    // per stream.
+    std::vector<uint32_t> todo(n);
+    for (size_t i = 0; i < n; i++)
+        todo[i] = (uint32_t)i;
+    while (!todo.empty()) {
+        std::vector<uint32_t> again;
+        for (uint32_t i : todo) {
+            const int r = videos_[i]->DecodeStep(&slot[i], &time[i]);
+            if (r == 1)
+                got[i] = 1;
+            else if (r == 2)
+                again.push_back(i);
+        }
+        Flush();
+        todo.swap(again);
+    }
     size_t produced = 0;
     for (size_t i = 0; i < n; i++)
         if (got[i]) {

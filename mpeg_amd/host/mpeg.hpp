@@ -189,6 +189,9 @@ public:
     // completes the next output frame and hands its work to the backend WITHOUT reading anything back;
     // Fetch copies that frame's planes to the host (what makes Frame.Y/Cb/Cr.Data valid).
     bool DecodeDeferred(uint32_t *slot, double *time);
+    // one picture of DecodeDeferred: 1 = a frame is complete (*slot, *time), 2 = a picture was consumed but
+    // no frame is due yet (the stream's first reference picture): call again, 0 = nothing to decode now
+    int DecodeStep(uint32_t *slot, double *time);
     Frame *Fetch(uint32_t slot, double time, bool read_back = true);
     const VideoStats &Stats() const { return stats_; }
 

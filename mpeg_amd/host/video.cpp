@@ -203,25 +203,33 @@ Frame *Video::Decode()
 }
 
 bool Video::DecodeDeferred(uint32_t *slot, double *time)
-{ // video.go:209-268 up to the frame selection
+{
+    int r;
+    while ((r = DecodeStep(slot, time)) == 2) {
+    }
+    return r == 1;
+}
+
+int Video::DecodeStep(uint32_t *slot, double *time)
+{ // one iteration of the loop of video.go:209-268
     if (!HasHeader())
-        return false;
+        return 0;
     int out_slot = -1;
-    for (;;) {
-        if (start_code_ != kStartPicture) {
-            start_code_ = buf_->findStartCode(kStartPicture);
-            if (start_code_ == -1) {
-                if (has_reference_frame_ && !assume_no_b_frames_ && buf_->HasEnded() &&
-                    (picture_type_ == kPictureTypeIntra || picture_type_ == kPictureTypePredictive)) {
-                    has_reference_frame_ = false;
-                    out_slot = (int)slot_bwd_;
-                    break;
-                }
-                return false;
+    if (start_code_ != kStartPicture) {
+        start_code_ = buf_->findStartCode(kStartPicture);
+        if (start_code_ == -1) {
+            if (has_reference_frame_ && !assume_no_b_frames_ && buf_->HasEnded() &&
+                (picture_type_ == kPictureTypeIntra || picture_type_ == kPictureTypePredictive)) {
+                has_reference_frame_ = false;
+                out_slot = (int)slot_bwd_;
+            } else {
+                return 0;
             }
         }
+    }
+    if (out_slot < 0) {
         if (buf_->hasStartCode(kStartPicture) == -1 && !buf_->HasEnded())
-            return false;
+            return 0;
         buf_->discardReadBytes();
 
         decodePicture();
@@ -234,14 +242,14 @@ bool Video::DecodeDeferred(uint32_t *slot, double *time)
             out_slot = (int)slot_fwd_;
         else
             has_reference_frame_ = true;
-        if (out_slot >= 0)
-            break;
+        if (out_slot < 0)
+            return 2;
     }
     *slot = (uint32_t)out_slot;
     *time = time_;
     frames_decoded_++;
     time_ = (double)frames_decoded_ / frame_rate_;
-    return true;
+    return 1;
 }
 
 Frame *Video::Fetch(uint32_t slot, double time, bool read_back)

@@ -42,9 +42,9 @@ def test_lockstep_streams_share_one_device_call_per_tick(oracle, golden_dir):
     es = (golden_dir / "test.mpeg1video").read_bytes()
     h, n, c = run_batch(oracle, [es] * 6, [0] * 6)
     assert h == [VIDEO_HASH] * 6 and n == [260] * 6
-    # 6 streams x ~274 pictures, but close to one device call per tick (a few extra: the first reference
-    # picture of a stream yields no frame, duplicated macroblock addresses re-submit)
-    assert c["queued_pictures"] >= 6 * 260 and c["device_submits"] < c["queued_pictures"] / 4
+    # 6 streams x ~274 pictures, but about one device call per tick (extra ones: the first reference picture
+    # of a stream yields no frame -> a second round in that tick; duplicated macroblock addresses re-submit)
+    assert c["queued_pictures"] >= 6 * 260 and c["device_submits"] < 1.5 * 260
 
 
 def test_staggered_and_mixed_streams(oracle, golden_dir):
