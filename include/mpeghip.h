@@ -284,6 +284,11 @@ void mpeghip_audio_close(mpeghip_audio *a);
  * [n_streams][n_frames][2304] elements of the format's type.  Synchronous. */
 int mpeghip_audio_synth(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames,
                         int format, void *out);
+/* Same for a subset of the streams: active[n_streams], streams with 0 sit the call out — their V ring
+ * and vPos are carried over unchanged, their slots in `samples` / `out` are ignored / left alone.  What a
+ * batch of decoders needs when some streams have no frame this tick (NULL = all active). */
+int mpeghip_audio_synth_masked(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames,
+                               int format, void *out, const uint8_t *active);
 /* Same with device-resident input/output (stream ordered, asynchronous). */
 int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples,
                                uint32_t n_frames, int format, void *d_out);

@@ -65,6 +65,7 @@ SYMBOLS = {
     "mpeghip_audio_open": (C.c_int, [_P, C.c_uint32, C.c_int, C.POINTER(_P)]),
     "mpeghip_audio_close": (None, [_P]),
     "mpeghip_audio_synth": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P]),
+    "mpeghip_audio_synth_masked": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, _P]),
     "mpeghip_audio_synth_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P]),
     "mpeghip_audio_device_buffers": (C.c_int, [_P, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(_P)]),
     "mpeghip_audio_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -235,6 +236,20 @@ class AudioSynth:
         n_frames = s.shape[1]
         out = np.empty((self.n_streams, n_frames, 2304), self.out_dtype(fmt))
         _check(self.lib.mpeghip_audio_synth(self.h, _ptr(s), n_frames, fmt, _ptr(out)))
+        return out
+
+    def synth_masked(self, samples: np.ndarray, active, fmt: int = desc.AUDIO_F32N, out=None) -> np.ndarray:
+        """Like synth() for the streams with active[i] != 0; the others keep their state and their rows of `out`."""
+        s = np.ascontiguousarray(samples, dtype=np.int32)
+        assert s.shape[0] == self.n_streams and s.shape[2:] == (2, 36, 32)
+        n_frames = s.shape[1]
+        if out is None:
+            out = np.zeros((self.n_streams, n_frames, 2304), self.out_dtype(fmt))
+        mask = np.ascontiguousarray(active, dtype=np.uint8)
+        assert mask.shape == (self.n_streams,)
+        tmp = np.empty_like(out)
+        _check(self.lib.mpeghip_audio_synth_masked(self.h, _ptr(s), n_frames, fmt, _ptr(tmp), _ptr(mask)))
+        out[mask != 0] = tmp[mask != 0]
         return out
 
     def device_buffers(self, n_frames: int, fmt: int):

@@ -57,6 +57,7 @@ struct AudioArgs {
     const float *window;    // [512]                 (synthesisWindow, audio.go:812-899)
     uint32_t n_streams, n_frames;
     int32_t format, fma;
+    const uint8_t *active;  // [n_streams] or nullptr: streams with 0 sit this launch out (state carried over unchanged)
 };
 
 constexpr int kAudioWaves = 4;
@@ -429,6 +430,15 @@ MPG_HD void audio_store_state(const AudioArgs &a, uint32_t stream, int32_t vpos0
         const int T = Tend - 1 - (e >> 6), x = e & 63;
         ring[idx] = mirror_apply(x, lds[kHistBase + ring_slot(T) * kSlotStride + ch * 32 + mirror_index(x)]);
     }
+}
+
+// ---- a stream that sits the launch out: its state moves to the new buffers untouched
+MPG_HD void audio_carry_state(const AudioArgs &a, uint32_t stream, int tid)
+{
+    for (int idx = tid; idx < 2048; idx += kAudioThreads)
+        a.ring_out[(uint64_t)stream * 2048 + idx] = a.ring[(uint64_t)stream * 2048 + idx];
+    if (tid == 0)
+        a.vpos_out[stream] = a.vpos[stream];
 }
 
 MPG_HD void audio_store_vpos(const AudioArgs &a, uint32_t stream, int32_t vpos0)

@@ -392,6 +392,11 @@ template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) vo
     audio_chunk_range(a, chunk, f0, f1);
     if (f0 >= f1)
         return; // empty slice (wave-uniform, before any barrier)
+    if (a.active && a.active[stream] == 0) { // (workgroup-uniform)
+        if (f1 == a.n_frames)
+            audio_carry_state(a, stream, tid);
+        return;
+    }
     const int32_t vpos0 = a.vpos[stream];
     const uint32_t tg0 = f0 * 36, tg1 = f1 * 36, n_steps = (tg1 - tg0 + kStep - 1) / kStep;
     float dreg[16];
@@ -489,6 +494,7 @@ struct mpeghip_audio {
     int32_t *d_samples = nullptr;
     void *d_out = nullptr;
     size_t cap_samples = 0, cap_out = 0;
+    uint8_t *d_active = nullptr;   // [n_streams] mask of mpeghip_audio_synth_masked
 };
 
 static const uint8_t k_default_intra[64] = { // ISO 11172-2 default intra matrix (video.go:1055-1064)
@@ -1370,6 +1376,8 @@ void mpeghip_audio_close(mpeghip_audio *a)
     for (void *p : ps)
         if (p)
             (void)hipFree(p);
+    if (a->d_active)
+        (void)hipFree(a->d_active);
     delete a;
 }
 
@@ -1412,7 +1420,7 @@ int mpeghip_audio_download(mpeghip_audio *a, void *dst, const void *d_src, size_
     return MPEGHIP_OK;
 }
 
-int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_frames, int format, void *d_out)
+static int audio_launch(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_frames, int format, void *d_out, const uint8_t *d_active)
 {
     if (!a || !d_samples || !d_out || format < 0 || format > MPEGHIP_AUDIO_S16)
         return fail(MPEGHIP_ERR_INVALID, "bad argument");
@@ -1431,6 +1439,7 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     args.n_frames = n_frames;
     args.format = format;
     args.fma = a->fma;
+    args.active = d_active;
     // time slices per stream: one full residency of workgroups (4 per CU are resident in practice: 5 x 32 KB
     // of LDS do not fit next to the allocation granularity), at least 4 frames per slice
     uint32_t chunks = 1;
@@ -1476,7 +1485,18 @@ int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint3
     return MPEGHIP_OK;
 }
 
+int mpeghip_audio_synth_device(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_frames, int format, void *d_out)
+{
+    return audio_launch(a, d_samples, n_frames, format, d_out, nullptr);
+}
+
 int mpeghip_audio_synth(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames, int format, void *out)
+{
+    return mpeghip_audio_synth_masked(a, samples, n_frames, format, out, nullptr);
+}
+
+int mpeghip_audio_synth_masked(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames, int format, void *out,
+                               const uint8_t *active)
 {
     if (!a || !samples || !out)
         return fail(MPEGHIP_ERR_INVALID, "NULL argument");
@@ -1489,7 +1509,12 @@ int mpeghip_audio_synth(mpeghip_audio *a, const int32_t *samples, uint32_t n_fra
         return rc;
     const size_t n = (size_t)a->n_streams * n_frames * MPEGHIP_AUDIO_FRAME_INTS;
     HIP_TRY(hipMemcpy(ds, samples, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    rc = mpeghip_audio_synth_device(a, ds, n_frames, format, dout);
+    if (active) {
+        if (!a->d_active)
+            HIP_TRY(hipMalloc((void **)&a->d_active, a->n_streams));
+        HIP_TRY(hipMemcpy(a->d_active, active, a->n_streams, hipMemcpyHostToDevice));
+    }
+    rc = audio_launch(a, ds, n_frames, format, dout, active ? a->d_active : nullptr);
     if (rc != MPEGHIP_OK)
         return rc;
     HIP_TRY(hipStreamSynchronize(a->ctx->stream));

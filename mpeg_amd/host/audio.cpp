@@ -279,20 +279,16 @@ void Audio::decodeFrame()
     // Synthesis of the whole frame on the device (audio.go:378-422)
     switch (format_) {
     case AudioF32N:
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32N, samples_.Interleaved.data());
+        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32N, samples_.Interleaved.data(), nullptr);
         break;
-    case AudioF32NLR: {
-        float lr[2304];
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32NLR, lr);
-        memcpy(samples_.Left.data(), lr, 1152 * sizeof(float));
-        memcpy(samples_.Right.data(), lr + 1152, 1152 * sizeof(float));
+    case AudioF32NLR:
+        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32NLR, samples_.Left.data(), samples_.Right.data());
         break;
-    }
     case AudioS16:
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_S16, samples_.S16.data());
+        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_S16, samples_.S16.data(), nullptr);
         break;
     case AudioF32:
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32, samples_.F32.data());
+        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32, samples_.F32.data(), nullptr);
         break;
     }
 }

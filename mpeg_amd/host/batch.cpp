@@ -140,4 +140,106 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
     return produced;
 }
 
+// ------------------------------------------------------------------ AudioBatch
+namespace {
+size_t elemSize(AudioFormat f) { return f == AudioS16 ? 2 : 4; }
+int abiFormat(AudioFormat f)
+{
+    switch (f) {
+    case AudioF32NLR: return MPEGHIP_AUDIO_F32NLR;
+    case AudioF32: return MPEGHIP_AUDIO_F32;
+    case AudioS16: return MPEGHIP_AUDIO_S16;
+    default: return MPEGHIP_AUDIO_F32N;
+    }
+}
+} // namespace
+
+// An Audio's synthesis request is only RECORDED (samples copied, destination remembered); the batch's
+// Flush() runs all recorded streams in one call and scatters the results.
+class AudioBatch::Port : public AudioBackend {
+public:
+    Port(AudioBatch *b, uint32_t stream) : b_(b), stream_(stream) {}
+    void synth(const int32_t *samples, int format, void *out, void *out2) override
+    {
+        if (format != abiFormat(b_->format_))
+            throw std::runtime_error("AudioBatch: a stream changed its output format");
+        if (b_->active_[stream_])
+            b_->Flush(); // two frames of one stream never share a device call
+        memcpy(b_->in_.data() + (size_t)stream_ * MPEGHIP_AUDIO_FRAME_INTS, samples, MPEGHIP_AUDIO_FRAME_INTS * sizeof(int32_t));
+        b_->active_[stream_] = 1;
+        b_->dest_[stream_].out = out;
+        b_->dest_[stream_].out2 = out2;
+    }
+
+private:
+    AudioBatch *b_;
+    uint32_t stream_;
+};
+
+AudioBatch::AudioBatch(Device *dev, uint32_t n_streams, AudioFormat format, int fma_mode)
+    : AudioBatch(dev->newAudioBatchStore(), n_streams, format, fma_mode)
+{
+}
+
+AudioBatch::AudioBatch(std::unique_ptr<AudioBatchStore> store, uint32_t n_streams, AudioFormat format, int fma_mode)
+    : store_(std::move(store)), capacity_(n_streams), format_(format)
+{
+    if (n_streams == 0)
+        throw std::runtime_error("AudioBatch: n_streams is 0");
+    store_->open(n_streams, fma_mode);
+    in_.assign((size_t)n_streams * MPEGHIP_AUDIO_FRAME_INTS, 0);
+    out_.assign((size_t)n_streams * 2304 * elemSize(format), 0);
+    active_.assign(n_streams, 0);
+    dest_.assign(n_streams, Dest());
+}
+
+AudioBatch::~AudioBatch() {}
+
+Audio *AudioBatch::AddStream(Buffer *buf)
+{
+    if (audios_.size() >= capacity_)
+        throw std::runtime_error("AudioBatch: more streams than the batch was opened for");
+    const uint32_t idx = (uint32_t)audios_.size();
+    audios_.emplace_back(new Audio(buf, std::unique_ptr<AudioBackend>(new Port(this, idx))));
+    audios_.back()->SetFormat(format_);
+    return audios_.back().get();
+}
+
+void AudioBatch::Flush()
+{
+    bool any = false;
+    for (uint8_t a : active_)
+        any = any || a;
+    if (!any)
+        return;
+    store_->synth(in_.data(), active_.data(), abiFormat(format_), out_.data());
+    device_calls_++;
+    const size_t es = elemSize(format_);
+    for (uint32_t i = 0; i < capacity_; i++) {
+        if (!active_[i])
+            continue;
+        const uint8_t *src = out_.data() + (size_t)i * 2304 * es;
+        if (format_ == AudioF32NLR) {
+            memcpy(dest_[i].out, src, 1152 * es);
+            memcpy(dest_[i].out2, src + 1152 * es, 1152 * es);
+        } else {
+            memcpy(dest_[i].out, src, 2304 * es);
+        }
+        active_[i] = 0;
+    }
+}
+
+size_t AudioBatch::DecodeAll(std::vector<Samples *> &samples)
+{
+    const size_t n = audios_.size();
+    samples.assign(n, nullptr);
+    size_t produced = 0;
+    for (size_t i = 0; i < n; i++) { // CPU: parse, record
+        samples[i] = audios_[i]->Decode();
+        produced += samples[i] ? 1 : 0;
+    }
+    Flush();                         // GPU: one call for all streams
+    return produced;
+}
+
 } // namespace mpeg

@@ -47,6 +47,11 @@ struct BatchHandle {
     std::unique_ptr<VideoBatch> batch;
     std::vector<Frame *> frames;
 };
+struct AudioBatchHandle {
+    std::vector<std::unique_ptr<Buffer>> bufs;
+    std::unique_ptr<AudioBatch> batch;
+    std::vector<Samples *> samples;
+};
 struct DemuxHandle {
     std::unique_ptr<Buffer> buf;
     std::unique_ptr<Demux> demux;
@@ -345,6 +350,61 @@ void mpeghost_batch_counters(void *hv, uint64_t out[2])
     out[0] = h->batch->DeviceSubmits();
     out[1] = h->batch->QueuedPictures();
 }
+
+// AudioBatch: many MP2 streams, one synthesis call per tick (format: 0 F32N, 1 F32NLR, 2 F32, 3 S16)
+void *mpeghost_audio_batch_open(void *device, uint32_t n_streams, int format, int fma_mode)
+{
+    return guard([&]() -> void * {
+        std::unique_ptr<AudioBatchHandle> h(new AudioBatchHandle);
+        h->batch.reset(new AudioBatch(static_cast<Device *>(device), n_streams, (AudioFormat)format, fma_mode));
+        return h.release();
+    }, (void *)nullptr);
+}
+void *mpeghost_audio_batch_open_store(void *store, uint32_t n_streams, int format, int fma_mode)
+{
+    return guard([&]() -> void * {
+        std::unique_ptr<AudioBatchHandle> h(new AudioBatchHandle);
+        h->batch.reset(new AudioBatch(std::unique_ptr<AudioBatchStore>(static_cast<AudioBatchStore *>(store)), n_streams,
+                                      (AudioFormat)format, fma_mode));
+        return h.release();
+    }, (void *)nullptr);
+}
+void mpeghost_audio_batch_close(void *h) { delete static_cast<AudioBatchHandle *>(h); }
+int mpeghost_audio_batch_add_stream(void *hv, const uint8_t *data, size_t len)
+{
+    return guard([&]() -> int {
+        AudioBatchHandle *h = static_cast<AudioBatchHandle *>(hv);
+        h->bufs.push_back(Buffer::FromMemory(data, len));
+        h->batch->AddStream(h->bufs.back().get());
+        return (int)h->batch->Streams() - 1;
+    }, -1);
+}
+int mpeghost_audio_batch_decode_all(void *hv)
+{
+    return guard([&]() -> int {
+        AudioBatchHandle *h = static_cast<AudioBatchHandle *>(hv);
+        return (int)h->batch->DecodeAll(h->samples);
+    }, -1);
+}
+// samples of stream i from the last decode_all (Interleaved / Left / F32 / S16 by format; right = Right for F32NLR)
+const void *mpeghost_audio_batch_samples(void *hv, uint32_t stream, double *time, const void **right)
+{
+    AudioBatchHandle *h = static_cast<AudioBatchHandle *>(hv);
+    if (stream >= h->samples.size() || !h->samples[stream])
+        return nullptr;
+    Samples *s = h->samples[stream];
+    if (time)
+        *time = s->Time;
+    if (right)
+        *right = s->Right.data();
+    switch (s->format) {
+    case AudioF32N: return s->Interleaved.data();
+    case AudioF32: return s->F32.data();
+    case AudioS16: return s->S16.data();
+    default: return s->Left.data();
+    }
+}
+uint64_t mpeghost_audio_batch_device_calls(void *hv) { return static_cast<AudioBatchHandle *>(hv)->batch->DeviceCalls(); }
 
 // NewDemux over a complete program stream (mpeg_test.go:88-100)
 void *mpeghost_demux_open(const uint8_t *data, size_t len)

@@ -1,5 +1,6 @@
 // hip_backend.cpp — the one and only reconstruction backend of the product: libmpeghip.
 #include <stdexcept>
+#include <string.h>
 #include <string>
 
 #include "mpeg.hpp"
@@ -99,12 +100,41 @@ public:
         check(mpeghip_audio_open(ctx, 1, fma_mode, &synth_), "mpeghip_audio_open");
     }
     ~HipAudioBackend() override { mpeghip_audio_close(synth_); }
-    void synth(const int32_t *samples, int format, void *out) override
+    void synth(const int32_t *samples, int format, void *out, void *out2) override
     {
-        check(mpeghip_audio_synth(synth_, samples, 1, format, out), "mpeghip_audio_synth");
+        if (format == MPEGHIP_AUDIO_F32NLR) {
+            float lr[2304];
+            check(mpeghip_audio_synth(synth_, samples, 1, format, lr), "mpeghip_audio_synth");
+            memcpy(out, lr, 1152 * sizeof(float));
+            memcpy(out2, lr + 1152, 1152 * sizeof(float));
+        } else {
+            check(mpeghip_audio_synth(synth_, samples, 1, format, out), "mpeghip_audio_synth");
+        }
     }
 
 private:
+    mpeghip_audio *synth_ = nullptr;
+};
+
+class HipAudioBatchStore : public AudioBatchStore {
+public:
+    explicit HipAudioBatchStore(mpeghip_ctx *ctx) : ctx_(ctx) {}
+    ~HipAudioBatchStore() override
+    {
+        if (synth_)
+            mpeghip_audio_close(synth_);
+    }
+    void open(uint32_t n_streams, int fma_mode) override
+    {
+        check(mpeghip_audio_open(ctx_, n_streams, fma_mode, &synth_), "mpeghip_audio_open");
+    }
+    void synth(const int32_t *samples, const uint8_t *active, int format, void *out) override
+    {
+        check(mpeghip_audio_synth_masked(synth_, samples, 1, format, out, active), "mpeghip_audio_synth_masked");
+    }
+
+private:
+    mpeghip_ctx *ctx_;
     mpeghip_audio *synth_ = nullptr;
 };
 
@@ -119,6 +149,10 @@ Device::Device(int ordinal)
 Device::~Device() { mpeghip_ctx_destroy(ctx_); }
 
 std::unique_ptr<VideoBackend> Device::newVideoBackend() { return std::unique_ptr<VideoBackend>(new HipVideoBackend(ctx_)); }
+std::unique_ptr<AudioBatchStore> Device::newAudioBatchStore()
+{
+    return std::unique_ptr<AudioBatchStore>(new HipAudioBatchStore(ctx_));
+}
 std::unique_ptr<BatchStore> Device::newBatchStore() { return std::unique_ptr<BatchStore>(new HipBatchStore(ctx_)); }
 std::unique_ptr<AudioBackend> Device::newAudioBackend(int fma_mode)
 {

@@ -152,8 +152,19 @@ public:
 class AudioBackend {
 public:
     virtual ~AudioBackend() {}
-    // one frame: samples int32 [2][36][32] -> 2304 elements of the format's type
-    virtual void synth(const int32_t *samples, int format, void *out) = 0;
+    // one frame: samples int32 [2][36][32] -> 2304 elements of the format's type in `out`; for
+    // MPEGHIP_AUDIO_F32NLR the two halves go to `out` (left, 1152 floats) and `out2` (right).  The backend
+    // may complete the writes later, but before anything reads them (AudioBatch: at its Flush()).
+    virtual void synth(const int32_t *samples, int format, void *out, void *out2) = 0;
+};
+
+// Synthesis state of MANY streams behind one call (libmpeghip's mpeghip_audio with n_streams > 1):
+// what AudioBatch drives.  active[i] == 0: stream i has no frame in this call and keeps its state.
+class AudioBatchStore {
+public:
+    virtual ~AudioBatchStore() {}
+    virtual void open(uint32_t n_streams, int fma_mode) = 0;
+    virtual void synth(const int32_t *samples, const uint8_t *active, int format, void *out) = 0; // [n][2][36][32] -> [n][2304]
 };
 
 // Shared device context for decoders (one per GPU).
@@ -165,6 +176,7 @@ public:
     std::unique_ptr<VideoBackend> newVideoBackend();
     std::unique_ptr<AudioBackend> newAudioBackend(int fma_mode);
     std::unique_ptr<BatchStore> newBatchStore();
+    std::unique_ptr<AudioBatchStore> newAudioBatchStore();
 private:
     mpeghip_ctx *ctx_ = nullptr;
 };
@@ -343,6 +355,37 @@ private:
     Samples samples_;
     AudioFormat format_ = AudioF32N;
     static const QuantizerSpec quant_tab_[17];
+};
+
+// Many MP2 streams on one GPU: every DecodeAll() advances each stream by one frame; the streams are
+// parsed one after the other on the CPU, then ONE device call synthesises all of them (streams without a
+// frame in this tick sit it out).  All streams share the output format.
+class AudioBatch {
+public:
+    AudioBatch(Device *dev, uint32_t n_streams, AudioFormat format = AudioF32N, int fma_mode = MPEGHIP_AUDIO_FMA_NONE);
+    AudioBatch(std::unique_ptr<AudioBatchStore> store, uint32_t n_streams, AudioFormat format, int fma_mode);
+    ~AudioBatch();
+    Audio *AddStream(Buffer *buf);                 // NewAudio over `buf`, owned by the batch
+    uint32_t Streams() const { return (uint32_t)audios_.size(); }
+    Audio *Stream(uint32_t i) { return audios_[i].get(); }
+    // samples[i] = the next frame of stream i or nullptr; valid until the next DecodeAll
+    size_t DecodeAll(std::vector<Samples *> &samples);
+    void Flush();
+    uint64_t DeviceCalls() const { return device_calls_; }
+
+private:
+    class Port;
+    friend class Port;
+    std::unique_ptr<AudioBatchStore> store_;
+    uint32_t capacity_;
+    AudioFormat format_;
+    std::vector<std::unique_ptr<Audio>> audios_;
+    std::vector<int32_t> in_;                      // [capacity][2][36][32]
+    std::vector<uint8_t> out_;                     // [capacity][2304] elements of the format
+    std::vector<uint8_t> active_;
+    struct Dest { void *out = nullptr, *out2 = nullptr; };
+    std::vector<Dest> dest_;
+    uint64_t device_calls_ = 0;
 };
 
 // -------------------------------------------------------------------- demux.go

@@ -17,6 +17,8 @@ int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, c
                   const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, uint64_t, int);
 void emu_rgba_convert(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
 int emu_audio_run(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t, uint32_t);
+int emu_audio_run_masked(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t, uint32_t,
+                         const uint8_t *);
 }
 
 namespace {
@@ -138,15 +140,46 @@ public:
         memset(ring_, 0, sizeof(ring_));
         memcpy(window_, window, sizeof(window_));
     }
-    void synth(const int32_t *samples, int format, void *out) override
+    void synth(const int32_t *samples, int format, void *out, void *out2) override
     {
-        emu_audio_run(samples, out, &ring_[0][0], &vpos_, window_, 1, 1, format, fma_, 1);
+        if (format == MPEGHIP_AUDIO_F32NLR) {
+            float lr[2304];
+            emu_audio_run(samples, lr, &ring_[0][0], &vpos_, window_, 1, 1, format, fma_, 1);
+            memcpy(out, lr, 1152 * sizeof(float));
+            memcpy(out2, lr + 1152, 1152 * sizeof(float));
+        } else {
+            emu_audio_run(samples, out, &ring_[0][0], &vpos_, window_, 1, 1, format, fma_, 1);
+        }
     }
 
 private:
     int fma_;
     float ring_[2][1024];
     int32_t vpos_ = 0;
+    float window_[512];
+};
+
+// multi-stream synthesis over the lane emulator (what HipAudioBatchStore is over libmpeghip)
+class EmuAudioBatchStore : public mpeg::AudioBatchStore {
+public:
+    explicit EmuAudioBatchStore(const float *window) { memcpy(window_, window, sizeof(window_)); }
+    void open(uint32_t n_streams, int fma_mode) override
+    {
+        n_ = n_streams;
+        fma_ = fma_mode;
+        ring_.assign((size_t)n_streams * 2048, 0.0f);
+        vpos_.assign(n_streams, 0);
+    }
+    void synth(const int32_t *samples, const uint8_t *active, int format, void *out) override
+    {
+        emu_audio_run_masked(samples, out, ring_.data(), vpos_.data(), window_, n_, 1, format, fma_, 1, active);
+    }
+
+private:
+    uint32_t n_ = 0;
+    int fma_ = 0;
+    std::vector<float> ring_;
+    std::vector<int32_t> vpos_;
     float window_[512];
 };
 
@@ -166,5 +199,6 @@ void host_emu_configure(int flavour, const float *window512)
 }
 void *host_emu_make_video(void) { return new EmuVideoBackend(g_flavour); }
 void *host_emu_batch_store(void) { return new EmuBatchStore(); }
+void *host_emu_audio_batch_store(void) { return new EmuAudioBatchStore(g_window); }
 void *host_emu_make_audio(int fma) { return new EmuAudioBackend(fma, g_window); }
 }

@@ -61,6 +61,12 @@ def host():
             "mpeghost_batch_decode_all": (C.c_int, [P, C.c_int]),
             "mpeghost_batch_frame": (C.c_int, [P, C.c_uint32, C.POINTER(HostFrame)]),
             "mpeghost_batch_counters": (None, [P, C.POINTER(C.c_uint64 * 2)]),
+            "mpeghost_audio_batch_open": (P, [P, C.c_uint32, C.c_int, C.c_int]),
+            "mpeghost_audio_batch_open_store": (P, [P, C.c_uint32, C.c_int, C.c_int]),
+            "mpeghost_audio_batch_close": (None, [P]), "mpeghost_audio_batch_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
+            "mpeghost_audio_batch_decode_all": (C.c_int, [P]),
+            "mpeghost_audio_batch_samples": (P, [P, C.c_uint32, C.POINTER(C.c_double), C.POINTER(P)]),
+            "mpeghost_audio_batch_device_calls": (C.c_uint64, [P]),
             "mpeghost_demux_open": (P, [C.c_char_p, C.c_size_t]), "mpeghost_demux_close": (None, [P]),
             "mpeghost_demux_start_time": (C.c_double, [P, C.c_int]), "mpeghost_demux_duration": (C.c_double, [P, C.c_int]),
             "mpeghost_demux_probe": (C.c_int, [P, C.c_size_t]), "mpeghost_demux_streams": (None, [P, C.POINTER(C.c_int * 2)]),
@@ -97,6 +103,8 @@ def host_emu():
         L.host_emu_audio_backend.argtypes = [C.c_int, C.c_void_p]
         L.host_emu_batch_store.restype = C.c_void_p
         L.host_emu_batch_store.argtypes = []
+        L.host_emu_audio_batch_store.restype = C.c_void_p
+        L.host_emu_audio_batch_store.argtypes = []
         L.host_emu_configure.restype = None
         L.host_emu_configure.argtypes = [C.c_int, C.c_void_p]
         _emu = L
@@ -343,4 +351,56 @@ class HostBatch:
     def close(self):
         if self.h:
             host().mpeghost_batch_close(self.h)
+            self.h = None
+
+
+class HostAudioBatch:
+    """mpeg::AudioBatch: n MP2 streams, one synthesis call per decode_all().  fmt: 0 F32N, 1 F32NLR, 2 F32, 3 S16."""
+
+    def __init__(self, n_streams: int, device=None, fmt=0, fma=0, window=None):
+        L = host()
+        self.fmt = fmt
+        if device is not None:
+            self.h = L.mpeghost_audio_batch_open(device, n_streams, fmt, fma)
+        else:
+            E = host_emu()
+            self._win = np.ascontiguousarray(window, np.float32)
+            E.host_emu_configure(0, self._win.ctypes.data)
+            self.h = L.mpeghost_audio_batch_open_store(E.host_emu_audio_batch_store(), n_streams, fmt, fma)
+        if not self.h:
+            raise RuntimeError(L.mpeghost_last_error().decode())
+        self._keep = []
+
+    def add_stream(self, data: bytes) -> int:
+        self._keep.append(data)
+        i = host().mpeghost_audio_batch_add_stream(self.h, data, len(data))
+        if i < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return i
+
+    def decode_all(self) -> int:
+        n = host().mpeghost_audio_batch_decode_all(self.h)
+        if n < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return n
+
+    def samples(self, stream: int):
+        """The stream's frame as the reference's golden test hashes it: 2304 (or 1152 + 1152) elements."""
+        t, right = C.c_double(), C.c_void_p()
+        p = host().mpeghost_audio_batch_samples(self.h, stream, C.byref(t), C.byref(right))
+        if not p:
+            return None
+        if self.fmt == 3:
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(2304,)).copy()
+        if self.fmt == 1:
+            l = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(1152,))
+            r = np.ctypeslib.as_array(C.cast(right.value, C.POINTER(C.c_float)), shape=(1152,))
+            return np.concatenate([l, r])
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(2304,)).copy()
+
+    device_calls = property(lambda s: host().mpeghost_audio_batch_device_calls(s.h))
+
+    def close(self):
+        if self.h:
+            host().mpeghost_audio_batch_close(self.h)
             self.h = None

@@ -352,6 +352,12 @@ template <bool kFma, int kFormat> static void emu_audio_blocks(const AudioArgs &
         audio_chunk_range(a, chunk, f0, f1);
         if (f0 >= f1)
             continue;
+        if (a.active && a.active[stream] == 0) {
+            if (f1 == a.n_frames)
+                for (int tid = 0; tid < kAudioThreads; tid++)
+                    audio_carry_state(a, stream, tid);
+            continue;
+        }
         for (auto &x : lds)
             x = 1e30f; // poison
         const int32_t vpos0 = a.vpos[stream];
@@ -391,8 +397,15 @@ template <bool kFma> static void emu_audio_format(const AudioArgs &a)
 }
 
 extern "C" {
+int emu_audio_run_masked(const int32_t *samples, void *out, float *ring, int32_t *vpos, const float *window,
+                         uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks, const uint8_t *active);
 int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos, const float *window,
                   uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks)
+{
+    return emu_audio_run_masked(samples, out, ring, vpos, window, n_streams, n_frames, format, fma, n_chunks, nullptr);
+}
+int emu_audio_run_masked(const int32_t *samples, void *out, float *ring, int32_t *vpos, const float *window,
+                         uint32_t n_streams, uint32_t n_frames, int32_t format, int32_t fma, uint32_t n_chunks, const uint8_t *active)
 {
     if (n_frames == 0)
         return 0;
@@ -410,6 +423,7 @@ int emu_audio_run(const int32_t *samples, void *out, float *ring, int32_t *vpos,
     a.n_frames = n_frames;
     a.format = format;
     a.fma = fma;
+    a.active = active;
     a.n_chunks = n_chunks < 1 ? 1 : (n_chunks > n_frames ? n_frames : n_chunks);
     if (fma)
         emu_audio_format<true>(a);

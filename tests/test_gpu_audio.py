@@ -118,3 +118,26 @@ def test_scaling_of_tiny_sums(oracle, hip_ctx, scale):
     a, b = ref.synth(s, desc.AUDIO_F32N), dut.synth(s, desc.AUDIO_F32N)
     assert bits_equal(a, b) and np.count_nonzero(a) > 500
     dut.close()
+
+
+def test_masked_synth_leaves_idle_streams_alone(oracle, hip_ctx):
+    """mpeghip_audio_synth_masked: streams with active == 0 keep their V ring / vPos and their output rows;
+    the others behave exactly like mpeghip_audio_synth (what AudioBatch needs when a stream has no frame)."""
+    n, rng = 6, np.random.default_rng(9)
+    s = synth.audio_frames(n, 7)
+    ref = [oracle.OracleSynth(1, 0) for _ in range(n)]
+    dut = abi.AudioSynth(hip_ctx, n)
+    for step in range(5):
+        mask = (rng.random(n) < 0.6).astype(np.uint8)
+        if step == 2:
+            mask[:] = 0  # nobody: the call must be a no-op
+        frames = s[:, step:step + 1]
+        out = dut.synth_masked(frames, mask, out=np.full((n, 1, 2304), 7.0, np.float32))
+        for i in range(n):
+            if mask[i]:
+                assert bits_equal(out[i], ref[i].synth(frames[i:i + 1], desc.AUDIO_F32N)[0])
+            else:
+                assert (out[i] == 7.0).all()
+            (va, pa), (vb, pb) = ref[i].get_state(0), dut.get_state(i)
+            assert pa == pb and bits_equal(va, vb)
+    dut.close()

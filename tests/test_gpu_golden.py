@@ -134,3 +134,13 @@ def test_video_batch_on_gpu(oracle, golden_dir, device):
     assert h == [DAMAGED if s is es else CLEAN for s in streams]
     assert n == [260 if s is es else 278 for s in streams]
     assert c["device_submits"] < c["queued_pictures"] / 4
+
+
+def test_audio_batch_on_gpu(oracle, device):
+    """mpeg::AudioBatch over the HIP store: staggered MP2 streams, one synthesis call per tick, every stream's
+    samples hash to the reference's golden value (tests/test_host_batch.py runs the same on the lane emulator)."""
+    from test_host_batch import AUDIO_HASH, run_audio_batch
+    h, cnt, calls = run_audio_batch(oracle, 6, [0, 0, 3, 7, 40, 1], device=device)
+    assert h == [AUDIO_HASH] * 6 and cnt == [355] * 6 and calls == 355 + 40
+    h, cnt, _ = run_audio_batch(oracle, 3, [0, 2, 2], fmt=3, device=device)   # S16
+    assert len(set(h)) == 1 and cnt == [355] * 3

@@ -70,3 +70,41 @@ def test_different_picture_sizes_are_refused(oracle, golden_dir):
     with pytest.raises(RuntimeError, match="same picture size"):
         b.add_stream(bytes(other))
     b.close()
+
+
+# ------------------------------------------------------------------------------------------------ audio
+AUDIO_HASH = 0xf1b76cdf8e6cdea5   # TestAudioGolden, no FMA (mpeg_test.go:193-197)
+
+
+def run_audio_batch(oracle, n, delays, fmt=0, device=None, window=None):
+    """n copies of test.mp2; stream i joins after delays[i] ticks.  Returns per-stream (hash, frames), device calls."""
+    from pathlib import Path
+    mp2 = (Path(__file__).resolve().parent / "golden" / "test.mp2").read_bytes()
+    b = hostlib.HostAudioBatch(n, device=device, fmt=fmt, window=window)
+    h, cnt = [oracle.FNV_OFFSET] * n, [0] * n
+    added, tick = 0, 0
+    order = sorted(range(n), key=lambda i: delays[i])
+    index_of = {}
+    while True:
+        while added < n and delays[order[added]] <= tick:
+            index_of[b.add_stream(mp2)] = order[added]
+            added += 1
+        produced = b.decode_all()
+        for k, i in index_of.items():
+            s = b.samples(k)
+            if s is not None:
+                h[i] = oracle.fnv1a64(s, h[i])
+                cnt[i] += 1
+        tick += 1
+        if produced == 0 and added == n:
+            break
+    calls = b.device_calls
+    b.close()
+    return h, cnt, calls
+
+
+def test_audio_batch_streams_share_one_synthesis_call_per_tick(oracle, emu):
+    win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
+    h, cnt, calls = run_audio_batch(oracle, 5, [0, 0, 3, 7, 40], window=win)
+    assert h == [AUDIO_HASH] * 5 and cnt == [355] * 5      # every stream exactly as if decoded alone
+    assert calls == 355 + 40                                # one call per tick while any stream is alive
