@@ -134,3 +134,58 @@ func (a *Audio) Close() { C.mpeghip_audio_close(a.h) }
 func (a *Audio) Synth(samples *[2][36][32]int32, format int, out unsafe.Pointer) error {
 	return lastError(C.mpeghip_audio_synth(a.h, (*C.int32_t)(unsafe.Pointer(samples)), 1, C.int(format), out))
 }
+
+// ---- many streams on one GPU (the shape of mpeg_amd/host/batch.cpp's VideoBatch / AudioBatch)
+
+// OpenVideoStreams is OpenVideo for n independent streams of one picture size: PicDesc.Stream selects
+// the stream, SubmitBatch reconstructs one picture of each of them with a single device call.
+func (c *Context) OpenVideoStreams(width, height, n int) (*Video, error) {
+	v := &Video{}
+	if err := lastError(C.mpeghip_video_open(c.h, C.uint32_t(width), C.uint32_t(height), C.uint32_t(n), &v.h)); err != nil {
+		return nil, err
+	}
+	C.mpeghip_video_info_get(v.h, &v.Info)
+	return v, nil
+}
+
+func (v *Video) SetQuantOf(stream int, intra, nonIntra *[64]byte) error {
+	return lastError(C.mpeghip_video_set_quant(v.h, C.uint32_t(stream), (*C.uint8_t)(&intra[0]), (*C.uint8_t)(&nonIntra[0])))
+}
+
+// SubmitBatch hands pictures of DIFFERENT streams to the GPU (pics[i].MbFirst/MbCount index mbs,
+// mbs[j].Pic indexes pics, coefficient offsets are relative to coefs).
+func (v *Video) SubmitBatch(pics []PicDesc, mbs []MbDesc, coefs []byte) error {
+	if len(pics) == 0 {
+		return nil
+	}
+	var mp, cp unsafe.Pointer
+	if len(mbs) > 0 {
+		mp = unsafe.Pointer(&mbs[0])
+	}
+	if len(coefs) > 0 {
+		cp = unsafe.Pointer(&coefs[0])
+	}
+	return lastError(C.mpeghip_video_submit(v.h, (*C.mpeghip_pic_desc)(unsafe.Pointer(&pics[0])), C.uint32_t(len(pics)),
+		(*C.mpeghip_mb_desc)(mp), C.uint32_t(len(mbs)), cp, C.size_t(len(coefs))))
+}
+
+func (v *Video) ReadPlanesOf(stream, slot int, y, cb, cr []byte) error {
+	return lastError(C.mpeghip_video_read_planes(v.h, C.uint32_t(stream), C.uint32_t(slot),
+		(*C.uint8_t)(&y[0]), (*C.uint8_t)(&cb[0]), (*C.uint8_t)(&cr[0])))
+}
+
+// OpenAudioStreams is OpenAudio for n independent streams.
+func (c *Context) OpenAudioStreams(n, fmaMode int) (*Audio, error) {
+	a := &Audio{}
+	if err := lastError(C.mpeghip_audio_open(c.h, C.uint32_t(n), C.int(fmaMode), &a.h)); err != nil {
+		return nil, err
+	}
+	return a, nil
+}
+
+// SynthMasked synthesises one frame of every stream with active[i] != 0 (samples: n x [2][36][32]int32,
+// out: n x 2304 elements); the other streams keep their V ring and vPos.
+func (a *Audio) SynthMasked(samples []int32, active []byte, format int, out unsafe.Pointer) error {
+	return lastError(C.mpeghip_audio_synth_masked(a.h, (*C.int32_t)(unsafe.Pointer(&samples[0])), 1, C.int(format), out,
+		(*C.uint8_t)(unsafe.Pointer(&active[0]))))
+}
