@@ -253,7 +253,11 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
     }
     // per macroblock: prediction + residual, clamp; outputs leave as whole rows when the chunk is a horizontal run
     const bool coalesce = wc_can_coalesce(ci, u);
-    uint8_t *out_tile = coalesce ? reinterpret_cast<uint8_t *>(tile) : nullptr;
+    bool rgba = false; // any macroblock of a picture that is colour-converted on the fly (wave-uniform)
+#pragma unroll
+    for (int m = 0; m < kWcMbs; m++)
+        rgba = rgba || ((uint32_t)m < ci.n && u[m].rgba != nullptr);
+    uint8_t *out_tile = (coalesce || rgba) ? reinterpret_cast<uint8_t *>(tile) : nullptr;
     const int below_lane = wc_below_lane(lane);
     const int below_addr = (below_lane < 0 ? lane : below_lane) << 2; // ds_bpermute byte address of the source lane
 #pragma unroll
@@ -268,11 +272,18 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
                 below.v[k] = below_lane < 0 ? below.v[k] : got;
             }
         }
-        wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m], below, resid, out_tile);
+        wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m], below, resid, out_tile, !coalesce);
     }
-    if (coalesce) {
+    if (out_tile) {
         wave_lds_handoff();
-        wc_store_tile(a, u[0], lane, out_tile);
+        if (coalesce)
+            wc_store_tile(a, u[0], lane, out_tile);
+        if (rgba) {
+#pragma unroll
+            for (int m = 0; m < kWcMbs; m++)
+                if ((uint32_t)m < ci.n && u[m].rgba != nullptr)
+                    wc_rgba_mb(a, u[m], (uint32_t)m, lane, out_tile);
+        }
     }
 }
 
@@ -460,6 +471,11 @@ struct mpeghip_batch {
     BlockEntry *d_entries = nullptr; // split path work list, one per coefficient unit
     bool dense_partition = false;   // coefficient units are an ordered partition of the stream: no memset needed
     bool any_rgba = false;
+    // host copy of what launch_batch needs to keep the RGBA images in step: per picture of the original
+    // (un-replicated) batch {stream, cur, MPEGHIP_PIC_RGBA?, covers every macroblock of the frame?}
+    struct PicNote { uint32_t stream; uint8_t cur, rgba, full; };
+    std::vector<PicNote> notes;
+    uint32_t replicas = 1;
     size_t cap_pics = 0, cap_mbs = 0, cap_coefs = 0, cap_entries = 0; // capacities (transient batch reuse)
 };
 
@@ -472,6 +488,11 @@ struct mpeghip_video {
     uint8_t *d_dump = nullptr;    // sink for the static-count stores of the pipelined kernel
     size_t dump_bytes = 0;
     uint64_t *d_hash = nullptr;
+    // rgba_sync[stream*3 + slot]: the slot's RGBA image equals the conversion of its planes.  Pictures
+    // flagged MPEGHIP_PIC_RGBA convert the macroblocks they write inside the reconstruction kernel; that
+    // is the whole story unless a partial picture lands on a slot whose image is out of date — then
+    // the whole-frame pass runs as well (launch_batch).
+    std::vector<uint8_t> rgba_sync;
     // mpeghip_video_submit: two descriptor batches with pinned host staging, used alternately, so
     // that the caller can parse picture N+1 while picture N's copy and kernel are in flight
     struct Staging {
@@ -710,6 +731,7 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
         return rc;
     }
     v->staging[0].batch.owner = v->staging[1].batch.owner = v;
+    v->rgba_sync.assign((size_t)n_streams * MPEGHIP_SLOTS, 0);
     *out = v;
     return MPEGHIP_OK;
 }
@@ -940,7 +962,21 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
             hipLaunchKernelGGL((recon_wc_kernel<4>), dim3((n_chunks + 3) / 4), dim3(256), 0, st, a, n_chunks);
         }
         HIP_TRY(hipGetLastError());
-        if (b->any_rgba) {
+        // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
+        // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
+        // image was out of date (an unflagged picture or write_planes touched the slot since).
+        bool whole_frames = false;
+        for (uint32_t r = 0; r < b->replicas; r++)
+            for (const mpeghip_batch::PicNote &n : b->notes) {
+                uint8_t &sync = v->rgba_sync[((size_t)n.stream + r) * MPEGHIP_SLOTS + n.cur];
+                if (!n.rgba)
+                    sync = 0;
+                else if (n.full)
+                    sync = 1;
+                else if (!sync)
+                    whole_frames = true, sync = 1;
+            }
+        if (whole_frames) {
             const uint32_t quads = (in.width + 3) / 4;
             for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
                 const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
@@ -1117,6 +1153,14 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
     }
     if (!sg) // pageable host memory: the copies above may still be reading it
         HIP_TRY(hipStreamSynchronize(st));
+    b->notes.resize(n_pics);
+    for (uint32_t p = 0; p < n_pics; p++) {
+        b->notes[p].stream = pics[p].stream;
+        b->notes[p].cur = pics[p].cur;
+        b->notes[p].rgba = (pics[p].flags & MPEGHIP_PIC_RGBA) ? 1 : 0;
+        b->notes[p].full = pics[p].mb_count == v->info.mb_w * v->info.mb_h ? 1 : 0; // (macroblocks of one submit do not overlap)
+    }
+    b->replicas = replicas;
     b->n_pics = (uint64_t)n_pics * replicas;
     b->n_mbs = (uint64_t)n_mbs * replicas;
     b->coef_bytes = (uint64_t)coef_bytes * replicas;
@@ -1222,6 +1266,7 @@ int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, 
 {
     if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
+    v->rgba_sync[(size_t)stream * MPEGHIP_SLOTS + slot] = 0; // (write_planes: the image is out of date now)
     HIP_TRY(hipSetDevice(v->ctx->device));
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
     const uint8_t *p = slot_ptr(v, stream, slot);
@@ -1259,6 +1304,9 @@ int mpeghip_video_broadcast_slot(mpeghip_video *v, uint32_t src, uint32_t slot, 
     if (!v || src >= v->info.n_streams || slot >= MPEGHIP_SLOTS || (uint64_t)dst0 + n > v->info.n_streams)
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
     HIP_TRY(hipSetDevice(v->ctx->device));
+    for (uint32_t s = dst0; s < dst0 + n; s++)
+        if (s != src)
+            v->rgba_sync[(size_t)s * MPEGHIP_SLOTS + slot] = 0;
     for (uint32_t s = dst0; s < dst0 + n; s++) {
         if (s == src)
             continue;
@@ -1309,6 +1357,8 @@ int mpeghip_video_rgba_convert(mpeghip_video *v, uint32_t slot, uint32_t stream0
                            in.width, in.height, slot, stream0 + s0);
         HIP_TRY(hipGetLastError());
     }
+    for (uint32_t st = stream0; st < stream0 + n; st++)
+        v->rgba_sync[(size_t)st * MPEGHIP_SLOTS + slot] = 1;
     return MPEGHIP_OK;
 }
 

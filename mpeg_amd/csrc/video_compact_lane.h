@@ -357,19 +357,34 @@ MPG_HD bool wc_needs_below(const MbU &u)
 
 // phase 3 of the wave-chunk kernel.  `below` = the 16 bytes of the row under this lane's row, already
 // fetched from the owning lane (or from ld.r1 for the bottom rows).  If out_tile != nullptr the 8 output
-// bytes are parked there (layout: luma [16 rows][4 macroblocks x 16 B], Cb [8][4 x 8 B], Cr [8][4 x 8 B])
-// instead of being stored.
+// bytes are parked there (layout: luma [16 rows][4 macroblocks x 16 B], Cb [8][4 x 8 B], Cr [8][4 x 8 B]);
+// with `store` they go to the frame as one 8-byte store (both when the picture is colour-converted
+// from the tile but the chunk is not a horizontal run).  A block the macroblock does not write (an
+// invalid intra block) parks the frame's current bytes, so that the tile always mirrors the planes.
+MPG_HD uint32_t wc_tile_offset(int b, int j, uint32_t m)
+{
+    if (b < 4)
+        return ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 64 + m * 16 + ((uint32_t)(b & 1) << 3);
+    return 1024 + (uint32_t)(b - 4) * 256 + (uint32_t)j * 32 + m * 8;
+}
+
 template <int N>
 MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci, uint32_t m, int lane, const MbLoads &ld,
-                      const u8x16 &below, const uint8_t *resid_store, uint8_t *out_tile)
+                      const u8x16 &below, const uint8_t *resid_store, uint8_t *out_tile, bool store)
 {
     const int b = lane >> 3, j = lane & 7;
     if (b >= 6)
         return;
     const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
     const bool coded = (u.cbp & (0x20u >> b)) != 0;
-    if (intra && !coded)
-        return; // an invalid intra block leaves the old pixels (video.go:711-714); never taken on the LDS path
+    if (intra && !coded) { // an invalid intra block leaves the old pixels (video.go:711-714); never on the coalesced path
+        if (out_tile) {
+            const WcPredScalars pk = wc_pred_scalars(a, u);
+            const int32_t off = wc_lane_row_offset(a, lane) + (b < 4 ? pk.dst_luma : pk.dst_chroma);
+            *reinterpret_cast<uint64_t *>(out_tile + wc_tile_offset(b, j, m)) = *reinterpret_cast<const uint64_t *>(u.cur + off);
+        }
+        return;
+    }
 
     const WcPredScalars ps = wc_pred_scalars(a, u);
     const bool luma = b < 4;
@@ -402,17 +417,31 @@ MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci,
         const uint32_t hi = add_resid_pack4((uint32_t)(pred >> 32), row.v[2], row.v[3]);
         out = (uint64_t)lo | ((uint64_t)hi << 32);
     }
-    if (out_tile) {
-        uint32_t o;
-        if (b < 4)
-            o = ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 64 + m * 16 + ((uint32_t)(b & 1) << 3);
-        else
-            o = 1024 + (uint32_t)(b - 4) * 256 + (uint32_t)j * 32 + m * 8;
-        *reinterpret_cast<uint64_t *>(out_tile + o) = out;
-        return;
+    if (out_tile)
+        *reinterpret_cast<uint64_t *>(out_tile + wc_tile_offset(b, j, m)) = out;
+    if (store) {
+        const int32_t off = wc_lane_row_offset(a, lane) + (luma ? ps.dst_luma : ps.dst_chroma);
+        *reinterpret_cast<uint64_t *>(u.cur + off) = out;
     }
-    const int32_t off = wc_lane_row_offset(a, lane) + (luma ? ps.dst_luma : ps.dst_chroma);
-    *reinterpret_cast<uint64_t *>(u.cur + off) = out;
+}
+
+// Frame.RGBA fused into the reconstruction (pictures flagged MPEGHIP_PIC_RGBA): macroblock m of the
+// chunk from the output tile, 4 pixels per lane (lane = row*4 + segment), one 16-byte store each — a
+// macroblock row is 64 contiguous bytes of the image.  Pixels outside width x height are not stored.
+MPG_HD void wc_rgba_mb(const VideoArgs &a, const MbU &u, uint32_t m, int lane, const uint8_t *out_tile)
+{
+    const uint32_t row = (uint32_t)lane >> 2, seg = (uint32_t)lane & 3;
+    const uint32_t py = (u.mb_y << 4) + row, px0 = (u.mb_x << 4) + seg * 4;
+    if (py >= a.height || px0 >= a.width)
+        return;
+    const uint32_t yy = *reinterpret_cast<const uint32_t *>(out_tile + row * 64 + m * 16 + seg * 4);
+    const uint32_t cb = *reinterpret_cast<const uint16_t *>(out_tile + 1024 + (row >> 1) * 32 + m * 8 + seg * 2);
+    const uint32_t cr = *reinterpret_cast<const uint16_t *>(out_tile + 1280 + (row >> 1) * 32 + m * 8 + seg * 2);
+    uint32_t px[4];
+    rgba_row4(yy, chroma_terms(cb & 0xff, cr & 0xff), chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff), px);
+    const uint64_t p = (uint64_t)py * a.width + px0;
+    const uint32_t n = a.width - px0 >= 4 ? 4 : a.width - px0;
+    rgba_store4<false>(reinterpret_cast<uint32_t *>(u.rgba) + p, p, px, n);
 }
 
 // Is the chunk a horizontal run of 4 fully written macroblocks of one picture, 64-byte aligned?  (wave-uniform)

@@ -428,6 +428,50 @@ MPG_HD uint32_t ycbcr_to_rgba(uint32_t y, uint32_t cb, uint32_t cr)
     return ((uint32_t)r & 0xff) | (((uint32_t)g & 0xff) << 8) | (((uint32_t)bl & 0xff) << 16) | 0xff000000u;
 }
 
+// The same arithmetic arranged for the machine.  The chroma part of r, g, b is shared by the 2 (or 2x2)
+// pixels of a chroma sample; "(v & 0xff000000) ? ~(v >> 31) : v >> 16" is clamp(v >> 16, 0, 255), and
+// v >> 16 always fits int16 (|v| < 2^25), so the upper halves of r, g (and b, 255) go through
+// v_perm_b32 into int16 pairs and v_sat_pk_u8_i16 clamps two channels at once; y * 0x10101 is the
+// y byte replicated three times (one v_perm_b32, no extraction).  About 40 clocks per pixel instead of
+// about 110 (tools/microbench/valu_rate.hip for the per-instruction costs).
+struct ChromaTerms { int32_t r, g, b; };
+MPG_HD ChromaTerms chroma_terms(uint32_t cb, uint32_t cr)
+{
+    const int32_t cb1 = (int32_t)cb - 128, cr1 = (int32_t)cr - 128;
+    return ChromaTerms{91881 * cr1, -22554 * cb1 - 46802 * cr1, 116130 * cb1};
+}
+// pixel k (0..3) of the luma word `yword`
+template <int K> MPG_HD uint32_t rgba_pixel(uint32_t yword, const ChromaTerms &c)
+{
+#if MPG_ON_DEVICE
+    const int32_t yy = (int32_t)__builtin_amdgcn_perm(0u, yword, 0x0c000000u | (K << 16) | (K << 8) | K);
+    const uint32_t r = (uint32_t)(yy + c.r), g = (uint32_t)(yy + c.g), b = (uint32_t)(yy + c.b);
+    const uint32_t rg16 = __builtin_amdgcn_perm(g, r, 0x07060302u); // {r >> 16, g >> 16} as int16
+    const uint32_t ba16 = __builtin_amdgcn_perm(0u, b, 0x0c0d0302u); // {b >> 16, 255}
+    uint32_t rg8, ba8;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(rg8) : "v"(rg16));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ba8) : "v"(ba16));
+    return __builtin_amdgcn_perm(ba8, rg8, 0x05040100u);             // R, G, B, A in memory order
+#else
+    const int32_t yy = (int32_t)((yword >> (8 * K)) & 0xff) * 0x10101;
+    const int32_t v[3] = {yy + c.r, yy + c.g, yy + c.b};
+    uint32_t out = 0xff000000u;
+    for (int i = 0; i < 3; i++) {
+        const int32_t q = v[i] >> 16; // fits int16
+        out |= (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q)) << (8 * i);
+    }
+    return out;
+#endif
+}
+// 4 pixels of one row: luma word + the two chroma samples under it (cb2 / cr2: two bytes each)
+MPG_HD void rgba_row4(uint32_t yword, const ChromaTerms &c01, const ChromaTerms &c23, uint32_t (&px)[4])
+{
+    px[0] = rgba_pixel<0>(yword, c01);
+    px[1] = rgba_pixel<1>(yword, c01);
+    px[2] = rgba_pixel<2>(yword, c23);
+    px[3] = rgba_pixel<3>(yword, c23);
+}
+
 // phase C part 1: every lane that holds macroblock pixels parks them in LDS.
 // For blocks this macroblock did not write (invalid intra blocks) the current
 // frame content is used instead, so the RGBA image always mirrors the planes.
@@ -485,14 +529,20 @@ MPG_HD void mb_phase_c_convert(const VideoArgs &a, const MbU &u, int lane, const
 // ------------------------------------------------------- stand-alone Frame.RGBA
 // One thread converts a 4x2 block of pixels of one stream's slot (rows 2*yp and 2*yp+1 share their
 // chroma samples: one Cb and one Cr word serve 8 pixels).  Grid rows are therefore row PAIRS.
+// kStream: non-temporal store — right when a wave writes whole cache lines of an image nobody reads
+// on the device (the stand-alone kernel), wrong when a line is completed by later instructions (the
+// fused path writes a row in 64-byte pieces and wants L2 to combine them).
+template <bool kStream = true>
 MPG_HD void rgba_store4(uint32_t *dst, uint64_t p, const uint32_t (&px)[4], uint32_t n)
 {
     if (n == 4 && (p & 3) == 0) {
 #if MPG_ON_DEVICE
-        // written once, read by nobody on the device: streaming store
         typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
         const u32v4 q = {px[0], px[1], px[2], px[3]};
-        __builtin_nontemporal_store(q, reinterpret_cast<u32v4 *>(dst));
+        if (kStream)
+            __builtin_nontemporal_store(q, reinterpret_cast<u32v4 *>(dst));
+        else
+            *reinterpret_cast<u32v4 *>(dst) = q;
 #else
         u32x4 q = {{px[0], px[1], px[2], px[3]}};
         *reinterpret_cast<u32x4 *>(dst) = q;
@@ -518,12 +568,9 @@ MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t luma_w, uint32_t ch
     const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp);
     const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + chroma_bytes);
     uint32_t px0[4], px1[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t b = (cb >> (8 * (k >> 1))) & 0xff, r = (cr >> (8 * (k >> 1))) & 0xff;
-        px0[k] = ycbcr_to_rgba((yy0 >> (8 * k)) & 0xff, b, r);
-        px1[k] = ycbcr_to_rgba((yy1 >> (8 * k)) & 0xff, b, r);
-    }
+    const ChromaTerms c01 = chroma_terms(cb & 0xff, cr & 0xff), c23 = chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff);
+    rgba_row4(yy0, c01, c23, px0);
+    rgba_row4(yy1, c01, c23, px1);
     const uint64_t p = (uint64_t)y * width + x0;
     uint32_t *dst = reinterpret_cast<uint32_t *>(rgba) + p;
     const uint32_t n = width - x0 >= 4 ? 4 : width - x0;

@@ -294,8 +294,11 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
                 compact_phase2_rows(s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kTileStride, active[lane], resid);
         }
         const bool coalesce = wc_can_coalesce(ci, u);
-        uint8_t *out_tile = coalesce ? reinterpret_cast<uint8_t *>(tile) : nullptr;
-        if (coalesce)
+        bool rgba_any = false;
+        for (int m = 0; m < kWcMbs; m++)
+            rgba_any = rgba_any || ((uint32_t)m < ci.n && u[m].rgba != nullptr);
+        uint8_t *out_tile = (coalesce || rgba_any) ? reinterpret_cast<uint8_t *>(tile) : nullptr;
+        if (out_tile)
             memset(tile, 0xEE, kWcTileBytes);
         for (int m = 0; m < kWcMbs; m++) {
             if ((uint32_t)m >= ci.n)
@@ -306,24 +309,38 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
                 if (wc_needs_below(u[m]) && bl >= 0) // the kernel's __shfl from the owning lane
                     for (int k = 0; k < 3; k++)
                         below.v[k] = ld[m][bl].r0.v[k];
-                wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile);
+                wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile, !coalesce);
             }
         }
         if (coalesce)
             for (int lane = 0; lane < 64; lane++)
                 wc_store_tile(a, u[0], lane, out_tile);
-    }
-    for (uint32_t p = 0; p < n_pics; p++) {
-        if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
-            continue;
-        const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
-        const uint32_t quads = (width + 3) / 4;
-        for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
-            for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
-                rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
-                                  x4, y, rgba + fs * rgba_stride);
+        if (rgba_any) // Frame.RGBA of the written macroblocks, fused (the host adds a whole-frame pass only
+            for (int m = 0; m < kWcMbs; m++) // for partial pictures over a slot whose image is out of date)
+                if ((uint32_t)m < ci.n && u[m].rgba != nullptr)
+                    for (int lane = 0; lane < 64; lane++)
+                        wc_rgba_mb(a, u[m], (uint32_t)m, lane, out_tile);
     }
     return 0;
+}
+
+// rgba_pixel (the arrangement the device uses) against ycbcr_to_rgba (the reference's form) for ALL
+// 2^24 (y, cb, cr): returns the number of disagreements
+uint32_t emu_rgba_forms_disagree(void)
+{
+    uint32_t bad = 0;
+    for (uint32_t cb = 0; cb < 256; cb++)
+        for (uint32_t cr = 0; cr < 256; cr++) {
+            const ChromaTerms c = chroma_terms(cb, cr);
+            for (uint32_t y = 0; y < 256; y += 4) {
+                const uint32_t yw = y | ((y + 1) << 8) | ((y + 2) << 16) | ((y + 3) << 24);
+                uint32_t px[4];
+                rgba_row4(yw, c, c, px);
+                for (uint32_t k = 0; k < 4; k++)
+                    bad += px[k] != ycbcr_to_rgba(y + k, cb, cr);
+            }
+        }
+    return bad;
 }
 
 void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, uint32_t width, uint32_t height,

@@ -56,6 +56,35 @@ def test_standalone_rgba(oracle, hip_ctx, w, h):
     dut.close()
 
 
+def test_rgba_of_every_possible_pixel(oracle, hip_ctx):
+    """All 2^24 (Y, Cb, Cr) triples through the device's conversion, against the oracle's: 64 frames of 512x512,
+    chroma sample (cx, cy) = (Cb, Cr) = (cx, cy), its four luma pixels in frame f = 4f .. 4f+3."""
+    w = h = 512
+    n = 64
+    ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h, n)
+    g = desc.geometry(w, h)
+    cb = np.tile(np.arange(256, dtype=np.uint8), 256)
+    cr = np.repeat(np.arange(256, dtype=np.uint8), 256)
+    quad = (np.arange(h)[:, None] & 1) * 2 + (np.arange(w)[None, :] & 1)
+    for f in range(n):
+        y = (4 * f + quad).astype(np.uint8).reshape(-1)
+        dut.write_planes(f, 1, y, cb, cr)
+    dut.rgba_convert(1)
+    for f in (0, 1, 17, 31, 32, 62, 63):    # the oracle converts a frame in ~10 ms; 7 frames sample every luma range
+        y = (4 * f + quad).astype(np.uint8).reshape(-1)
+        ref.write_planes(0, 1, y, cb, cr)
+        assert np.array_equal(ref.read_rgba(0, 1), dut.read_rgba(f, 1)), f
+    # and all 64 frames against the closed form (clamp((y*65793 + chroma term) >> 16, 0, 255)), vectorised
+    cbi, cri = cb.astype(np.int64).reshape(256, 256) - 128, cr.astype(np.int64).reshape(256, 256) - 128
+    up = lambda a: np.repeat(np.repeat(a, 2, axis=0), 2, axis=1)
+    terms = [up(91881 * cri), up(-22554 * cbi - 46802 * cri), up(116130 * cbi)]
+    for f in range(n):
+        yy = (4 * f + quad).astype(np.int64) * 0x10101
+        want = np.stack([np.clip((yy + t) >> 16, 0, 255) for t in terms] + [np.full((h, w), 255)], axis=-1).astype(np.uint8)
+        assert np.array_equal(want, dut.read_rgba(f, 1)), f
+    dut.close()
+
+
 def test_edge_cases(oracle, hip_ctx):
     """Empty submits, a single macroblock, pictures that touch only part of a frame."""
     w, h = 64, 64
@@ -129,6 +158,53 @@ def test_malformed_descriptors_are_refused_and_nothing_is_launched(oracle, hip_c
     for s in range(3):
         assert_planes_equal(before[s], dut.read_planes(0, s), "slot %d after refused submits" % s)
     run_and_compare(ref, dut, seq[1:])  # and the stream continues bit-exactly
+    dut.close()
+
+
+def test_fused_rgba_keeps_the_image_in_step_with_the_planes(oracle, hip_ctx):
+    """MPEGHIP_PIC_RGBA converts inside the reconstruction kernel only the macroblocks a picture writes; the
+    image must still equal Frame.RGBA() of the whole frame (video.go:31-36) when pictures are partial, when
+    some pictures are not flagged, and after write_planes — the cases where the whole-frame pass is owed."""
+    w, h = 96, 64
+    flagged = synth.generate_sequence(w, h, 6, seed=33, rgba=True)
+    ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h)
+
+    def submit(s, n_mbs=None, flag=True):
+        pics, mbs = s.pics.copy(), s.mbs.copy()
+        if n_mbs is not None:   # a picture that covers only its first n_mbs macroblocks (coefficients stay contiguous)
+            mbs = mbs[:n_mbs]
+            pics["mb_count"] = n_mbs
+        pics["flags"] = desc.PIC_RGBA if flag else 0
+        ref.submit(pics, mbs, s.coefs)
+        dut.submit(pics, mbs, s.coefs)
+        for slot in range(3):
+            assert_planes_equal(ref.read_planes(0, slot), dut.read_planes(0, slot), "slot %d" % slot)
+        return int(pics["cur"][0])
+
+    def image_matches(slot):
+        return np.array_equal(ref.read_rgba(0, slot), dut.read_rgba(0, slot))
+
+    cur = submit(flagged[0])                       # full + flagged: fused conversion alone
+    assert image_matches(cur)
+    cur = submit(flagged[1], n_mbs=7)              # partial + flagged over a slot whose image was never converted
+    assert image_matches(cur)
+    cur = submit(flagged[2], flag=False)           # not flagged: the image of this slot goes stale ...
+    cur2 = submit(flagged[3], n_mbs=5)             # ... (another slot meanwhile)
+    assert image_matches(cur2)
+    for s in flagged[4:]:
+        cur = submit(s, n_mbs=11)                  # partial pictures keep rotating over stale and fresh slots
+        assert image_matches(cur)
+    rng = np.random.default_rng(2)
+    g = desc.geometry(w, h)
+    y, cb, cr = (rng.integers(0, 256, n, dtype=np.uint8) for n in (g["luma_bytes"], g["chroma_bytes"], g["chroma_bytes"]))
+    ref.write_planes(0, cur, y, cb, cr)
+    dut.write_planes(0, cur, y, cb, cr)            # planes replaced behind the image's back
+    s = flagged[2]
+    pics = s.pics.copy()
+    pics["cur"], pics["flags"], pics["mb_count"] = cur, desc.PIC_RGBA, 3
+    ref.submit(pics, s.mbs[:3], s.coefs)
+    dut.submit(pics, s.mbs[:3], s.coefs)
+    assert image_matches(cur)
     dut.close()
 
 

@@ -47,6 +47,13 @@ def test_standalone_rgba(oracle, emu, w, h):
     assert np.array_equal(o.read_rgba(0, 1), e.read_rgba(0, 1))
 
 
+def test_rgba_arrangement_equals_the_reference_form_for_every_input(emu):
+    """chroma terms + v_perm/v_sat_pk style clamp (video_lane.h rgba_pixel) == Go's DrawYCbCr arithmetic for all 2^24 inputs."""
+    L = emu.lib()
+    L.emu_rgba_forms_disagree.restype = __import__("ctypes").c_uint32
+    assert L.emu_rgba_forms_disagree() == 0
+
+
 def test_avg4_identity(emu):
     """(a+b+c+d+2)>>2 == ceil_avg(floor_avg(a,b), floor_avg(c,d)) + correction, for every pair of pair-sums."""
     L = emu.lib()
