@@ -170,7 +170,7 @@ typedef struct mpeghip_mb_desc {
     uint8_t  qscale;      /* quantiser_scale 1..31 (ignored for COEF_RAW)            */
     uint8_t  reserved0;
     uint32_t coef_off;    /* first coefficient block, in 128-byte units              */
-    uint32_t reserved[3];
+    uint32_t reserved[3]; /* 0; the library's device copy keeps its picture's fields here  */
 } mpeghip_mb_desc;        /* 32 bytes */
 
 #define MPEGHIP_MB_INTRA    0x01u /* no prediction, coded blocks overwrite           */

@@ -229,16 +229,18 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
         return;
     uint8_t *resid = lds_all + w * kWcLdsBytes;
     int32_t *tile = reinterpret_cast<int32_t *>(resid + kWcResidBytes);
-    const WcInfo ci = load_chunk_t<kWcMbs>(a, chunk);
+    uint32_t n_live;
+    WcRaw raw;
+    wc_load_raw(a, chunk, n_live, raw); // one round of scalar loads for the whole chunk
+    const WcInfo ci = wc_info_from_raw(n_live, raw);
     const int g = lane >> 3, j = lane & 7;
 
-    // descriptors + prediction loads of every macroblock of the chunk, up front
+    // prediction loads of every macroblock of the chunk, up front
     MbU u[kWcMbs];
     MbLoads ld[kWcMbs];
 #pragma unroll
     for (int m = 0; m < kWcMbs; m++) {
-        const uint32_t idx = (uint32_t)m < ci.n ? chunk * kWcMbs + (uint32_t)m : chunk * kWcMbs;
-        u[m] = load_mb(a, idx);
+        u[m] = wc_mb_from_raw(a, raw.d[m]);
         wc_issue_pred(a, u[m], lane, ld[m]);
     }
     // dense residual stage: 8 coded blocks per pass
@@ -348,6 +350,15 @@ __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64
     const uint64_t fs = (uint64_t)(stream0 + blockIdx.z) * MPEGHIP_SLOTS + slot;
     rgba_convert_quad(frames + fs * frame_stride, luma_w, chroma_w, luma_bytes, chroma_bytes,
                       width, height, x4, y, rgba + fs * rgba_stride);
+}
+
+// Copies each macroblock's picture fields into the reserved words of its (device) descriptor: see
+// wc_load_raw.  Runs once per upload, after the replication.
+__global__ void fill_pic_fields_kernel(const mpeghip_pic_desc *pics, mpeghip_mb_desc *mbs, uint64_t n_mbs)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_mbs)
+        fill_pic_fields(pics, mbs, (uint32_t)i);
 }
 
 // Replicate a one-stream descriptor set for streams 1..n-1 (benchmark batches).
@@ -1149,6 +1160,11 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
         const uint64_t work = (uint64_t)(n_mbs > n_pics ? n_mbs : n_pics) * replicas;
         hipLaunchKernelGGL(replicate_desc_kernel, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, st, b->d_pics, n_pics,
                            b->d_mbs, n_mbs, (uint32_t)(coef_bytes / MPEGHIP_COEF_UNIT), replicas);
+        HIP_TRY(hipGetLastError());
+    }
+    if (n_mbs) {
+        const uint64_t total = (uint64_t)n_mbs * replicas;
+        hipLaunchKernelGGL(fill_pic_fields_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, b->d_pics, b->d_mbs, total);
         HIP_TRY(hipGetLastError());
     }
     if (!sg) // pageable host memory: the copies above may still be reading it

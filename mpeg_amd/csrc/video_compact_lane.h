@@ -282,6 +282,86 @@ constexpr int kWcLdsBytes = kWcResidBytes + kWcTileBytes;   // 5376
 constexpr int kWcOutBytes = 16 * 64 + 2 * 8 * 32;           // 1536 <= kWcTileBytes
 using WcInfo = ChunkInfoT<kWcMbs>;
 
+// Everything a wave needs from the descriptor arrays in ONE round of scalar loads: the chunk's four
+// 32-byte macroblock descriptors (contiguous, 128 bytes).  The picture fields a macroblock needs
+// (stream; cur | fwd | bwd | flags) have been copied into the descriptor's reserved words on the
+// DEVICE copy by fill_pic_fields_kernel when the batch was uploaded, so no second, dependent load of
+// mpeghip_pic_desc is needed.  The descriptors are streamed — every load misses all caches — and
+// scalar loads return out of order, so each s_waitcnt waits for all of them: loading per macroblock
+// (descriptor, then its picture) cost a wave ten such round trips, 43 % of its life
+// (profiles/r03o_phase_timing.txt).
+constexpr int kMbPicStream = 5, kMbPicSlots = 6; // dword index of reserved[0], reserved[1]
+
+struct WcRaw {
+    uint32_t d[kWcMbs][7]; // pic | mb_x,mb_y | mv_x,mv_y | flags,cbp,qscale,- | coef_off | stream | cur,fwd,bwd,picflags
+};
+
+MPG_HD void wc_load_raw(const VideoArgs &a, uint32_t chunk, uint32_t &n, WcRaw &r)
+{
+    const uint32_t first = chunk * kWcMbs;
+    n = a.n_mbs - first < (uint32_t)kWcMbs ? a.n_mbs - first : (uint32_t)kWcMbs;
+    const MPG_CONST_AS uint32_t *mb = (const MPG_CONST_AS uint32_t *)(uintptr_t)a.mbs + (uint64_t)first * 8;
+#pragma unroll
+    for (int k = 0; k < kWcMbs; k++) {
+        const uint32_t kk = (uint32_t)k < n ? (uint32_t)k : 0u; // past the end of the batch: macroblock 0 again
+#pragma unroll
+        for (int w = 1; w < 7; w++)
+            r.d[k][w] = mb[kk * 8 + w];
+        r.d[k][0] = 0;
+    }
+}
+
+// the wave-uniform views the phases use, from the raw dwords (pure arithmetic)
+MPG_HD MbU wc_mb_from_raw(const VideoArgs &a, const uint32_t (&d)[7])
+{
+    MbU u;
+    u.flags = d[3] & 0xff;
+    u.cbp = (d[3] >> 8) & 0xff;
+    u.qscale = (d[3] >> 16) & 0xff;
+    u.coef_off = d[4];
+    u.mv_x = (int32_t)(int16_t)(d[2] & 0xffff);
+    u.mv_y = (int32_t)(int16_t)(d[2] >> 16);
+    u.mb_x = d[1] & 0xffff;
+    u.mb_y = d[1] >> 16;
+    const uint32_t slots = d[kMbPicSlots], cur_slot = slots & 0xff;
+    u.pic_flags = slots >> 24;
+    const uint64_t s3 = (uint64_t)d[kMbPicStream] * MPEGHIP_SLOTS;
+    u.cur = a.frames + (s3 + cur_slot) * a.frame_stride;
+    const uint32_t ref_slot = (u.flags & MPEGHIP_MB_REF_BWD) ? (slots >> 16) & 0xff : (slots >> 8) & 0xff;
+    u.ref = a.frames + (s3 + ref_slot) * a.frame_stride;
+    u.qm = a.qmat + (uint64_t)d[kMbPicStream] * 256 + ((u.flags & MPEGHIP_MB_INTRA) ? 0 : 128);
+    u.rgba = (u.pic_flags & MPEGHIP_PIC_RGBA) ? a.rgba + (s3 + cur_slot) * a.rgba_stride : nullptr;
+    return u;
+}
+
+MPG_HD WcInfo wc_info_from_raw(uint32_t n, const WcRaw &r)
+{
+    WcInfo ci;
+    ci.n = n;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kWcMbs; k++) {
+        const uint32_t w3 = r.d[k][3];
+        const uint32_t live = (uint32_t)k < n ? 0x3fu : 0u;
+        ci.cbp[k] = (w3 >> 8) & live;
+        ci.flags[k] = (w3 & 0xffu) | (((w3 >> 16) & 0xffu) << 8);
+        ci.coef_off[k] = r.d[k][4];
+        ci.qtab[k] = r.d[k][kMbPicStream] * 256 + ((w3 & MPEGHIP_MB_INTRA) ? 0u : 128u);
+        ci.base[k] = acc;
+        acc += popc6(ci.cbp[k]);
+    }
+    ci.base[kWcMbs] = acc;
+    return ci;
+}
+
+// what fill_pic_fields_kernel writes into macroblock descriptor i of the device copy
+MPG_HD void fill_pic_fields(const mpeghip_pic_desc *pics, mpeghip_mb_desc *mbs, uint32_t i)
+{
+    const mpeghip_pic_desc &p = pics[mbs[i].pic];
+    mbs[i].reserved[0] = p.stream;
+    mbs[i].reserved[1] = (uint32_t)p.cur | ((uint32_t)p.fwd << 8) | ((uint32_t)p.bwd << 16) | ((uint32_t)p.flags << 24);
+}
+
 // lane that holds the row below this lane's row, or -1 if that row must be loaded
 // (bottom row of the macroblock: luma row 16, chroma row 8)
 MPG_HD int wc_below_lane(int lane)

@@ -261,8 +261,12 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
     a.chroma_h = luma_h / 2;
     a.luma_bytes = luma_w * luma_h;
     a.chroma_bytes = a.luma_bytes / 4;
+    // the library's device copy of the descriptors: picture fields filled into the reserved words
+    std::vector<mpeghip_mb_desc> filled(mbs, mbs + n_mbs);
+    for (uint32_t i = 0; i < n_mbs; i++)
+        fill_pic_fields(pics, filled.data(), i);
     a.pics = pics;
-    a.mbs = mbs;
+    a.mbs = filled.data();
     a.coefs = coefs;
     a.qmat = qtable;
     a.dump = nullptr;
@@ -277,12 +281,14 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
         memset(lds, 0xCD, sizeof(lds));
         uint8_t *resid = lds;
         int32_t *tile = reinterpret_cast<int32_t *>(lds + kWcResidBytes);
-        const WcInfo ci = load_chunk_t<kWcMbs>(a, chunk);
+        uint32_t n_live;
+        WcRaw raw;
+        wc_load_raw(a, chunk, n_live, raw);
+        const WcInfo ci = wc_info_from_raw(n_live, raw);
         MbU u[kWcMbs];
         static MbLoads ld[kWcMbs][64];
         for (int m = 0; m < kWcMbs; m++) {
-            const uint32_t idx = (uint32_t)m < ci.n ? chunk * kWcMbs + (uint32_t)m : chunk * kWcMbs;
-            u[m] = load_mb(a, idx);
+            u[m] = wc_mb_from_raw(a, raw.d[m]);
             for (int lane = 0; lane < 64; lane++)
                 wc_issue_pred(a, u[m], lane, ld[m][lane]);
         }
