@@ -229,11 +229,19 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
         return;
     uint8_t *resid = lds_all + w * kWcLdsBytes;
     int32_t *tile = reinterpret_cast<int32_t *>(resid + kWcResidBytes);
+#ifdef MPG_PHASE_TIMING // instrumented build for tools/phase_timing.py only: s_memtime at the phase boundaries
+#define MPG_STAMP(k) ts[k] = __builtin_readcyclecounter()
+    uint64_t ts[6];
+#else
+#define MPG_STAMP(k)
+#endif
+    MPG_STAMP(0);
     uint32_t n_live;
     WcRaw raw;
     wc_load_raw(a, chunk, n_live, raw); // one round of scalar loads for the whole chunk
     const WcInfo ci = wc_info_from_raw(n_live, raw);
     const int g = lane >> 3, j = lane & 7;
+    MPG_STAMP(1);
 
     // prediction loads of every macroblock of the chunk, up front
     MbU u[kWcMbs];
@@ -243,6 +251,7 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
         u[m] = wc_mb_from_raw(a, raw.d[m]);
         wc_issue_pred(a, u[m], lane, ld[m]);
     }
+    MPG_STAMP(2);
     // dense residual stage: 8 coded blocks per pass
     const uint32_t total = ci.base[kWcMbs];
     for (uint32_t s0 = 0; s0 < total; s0 += 8) {
@@ -253,6 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
         compact_phase2_rows(slot, j, tile + g * kTileStride, active, resid);
         wave_lds_handoff();
     }
+    MPG_STAMP(3);
     // per macroblock: prediction + residual, clamp; outputs leave as whole rows when the chunk is a horizontal run
     const bool coalesce = wc_can_coalesce(ci, u);
     bool rgba = false; // any macroblock of a picture that is colour-converted on the fly (wave-uniform)
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
         }
         wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m], below, resid, out_tile, !coalesce);
     }
+    MPG_STAMP(4);
     if (out_tile) {
         wave_lds_handoff();
         if (coalesce)
@@ -287,6 +298,17 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
                     wc_rgba_mb(a, u[m], (uint32_t)m, lane, out_tile);
         }
     }
+#ifdef MPG_PHASE_TIMING
+    MPG_STAMP(5);
+    if (lane == 0 && chunk < 60000) { // a.dump is 4 MB: 64 bytes per sampled wave
+        uint64_t *d = reinterpret_cast<uint64_t *>(a.dump) + (uint64_t)chunk * 8;
+        for (int k = 0; k < 6; k++)
+            d[k] = ts[k];
+        d[6] = total;
+        d[7] = coalesce;
+    }
+#endif
+#undef MPG_STAMP
 }
 
 // ---- split path (video_split_lane.h): K1 prediction, K2 dense residual
@@ -1625,5 +1647,14 @@ int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, i
     HIP_TRY(hipMemcpy(a->d_vpos + stream, &vpos, sizeof(int32_t), hipMemcpyHostToDevice));
     return MPEGHIP_OK;
 }
+
+#ifdef MPG_PHASE_TIMING
+int mpeghip_debug_read_dump(mpeghip_video *v, void *dst, size_t bytes)
+{
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    HIP_TRY(hipMemcpy(dst, v->d_dump, bytes, hipMemcpyDeviceToHost));
+    return MPEGHIP_OK;
+}
+#endif
 
 } // extern "C"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a wave of recon_wc_kernel spends its wall time (development aid).  Needs the instrumented build
-mpeg_amd/libmpeghip_timing.so (s_memtime stamps per phase, written by lane 0 of the first 60000 chunks):
-swaps it in for this process, runs one typical (or dense) picture for 64 streams, prints per-phase medians."""
+    hipcc <flags of mpeg_amd/_build.py> -DMPG_PHASE_TIMING mpeg_amd/csrc/mpeghip.hip -o mpeg_amd/libmpeghip_timing.so
+(s_memtime stamps per phase, written by lane 0 of the first 60000 chunks; tools/gpu_phase_timing.sh builds it):
+swaps it in for this process, runs pictures for 64 streams, prints per-phase medians."""
 import ctypes as C
 import shutil
 import sys
