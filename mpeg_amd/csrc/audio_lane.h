@@ -315,30 +315,6 @@ MPG_HD void window_taps(const float *p0A, const float *p1A, const float *p0B, co
     accB = b;
 }
 
-template <bool kFma>
-MPG_HD void window_dispatch(int32_t m, const float *p0A, const float *p1A, const float *p0B, const float *p1B,
-                            const float (&d)[16], float &accA, float &accB)
-{
-    switch (m) {
-    case 0: return window_taps<0, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 1: return window_taps<1, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 2: return window_taps<2, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 3: return window_taps<3, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 4: return window_taps<4, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 5: return window_taps<5, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 6: return window_taps<6, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 7: return window_taps<7, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 8: return window_taps<8, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 9: return window_taps<9, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 10: return window_taps<10, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 11: return window_taps<11, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 12: return window_taps<12, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 13: return window_taps<13, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    case 14: return window_taps<14, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    default: return window_taps<15, kFma>(p0A, p1A, p0B, p1B, d, accA, accB);
-    }
-}
-
 // x / -1090519040 (audio.go:390), correctly rounded.  The short form is Markstein's sequence
 // q = x*y, r = fma(-q, D, x), q' = fma(r, y, q) with y = RN(1/D); tests/proofs/div_const.c checks
 // all 2^32 inputs: it equals the IEEE quotient for x == 0 and for every finite |x| >= 2^-95 (it
@@ -372,19 +348,19 @@ MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg,
         reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv * 2147483648.0f;
 }
 
-// one window pair: sub-blocks tgA and tgA + 16 (same ring position modulo 16 slots, so the same taps)
-template <bool kFma, int kFormat>
-MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t tgA, uint32_t tg1, int ch, int i,
-                              const float *p0, const float *p1, const float (&dreg)[16])
+// one window pair: sub-blocks tgA and tgA + 16 (same ring position modulo 16 slots, so the same taps),
+// for the ring position 64*M known at compile time
+template <int M, bool kFma, int kFormat>
+MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, uint32_t tgA, uint32_t tg1, int ch, int i, const float *p0,
+                              const float *p1, const float (&dreg)[16])
 {
     const uint32_t tgB = tgA + 16;
     const int32_t TA = kT0 + (int32_t)tgA;
-    const int32_t m = vpos_at(vpos0, TA) >> 6; // == that of TA + 16
     const int32_t slotA = ring_slot(TA), slotB = ring_slot(TA + 16);
     const int32_t offA = ((slotA < kMirrorSlots ? slotA + kRing : slotA) - 15) * kSlotStride;
     const int32_t offB = ((slotB < kMirrorSlots ? slotB + kRing : slotB) - 15) * kSlotStride;
     float accA, accB;
-    window_dispatch<kFma>(m, p0 + offA, p1 + offA, p0 + offB, p1 + offB, dreg, accA, accB);
+    window_taps<M, kFma>(p0 + offA, p1 + offA, p0 + offB, p1 + offB, dreg, accA, accB);
     float svA, svB;
     if (all_in_wave(scale_short_ok(accA) && scale_short_ok(accB))) {
         svA = scale_short(accA);
@@ -398,8 +374,21 @@ MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, int32_t vpos0
         audio_store_sample<kFormat>(a, stream, tgB, ch, i, svB);
 }
 
-// ---- windows of step si: 16 pairs (p, p + 16).  The wave that runs DCT(si + 1) in the same
-// iteration takes pair 15 only; the other three take p = rank, rank + 3, ... (five each).
+// the pair of this step whose ring position is 64*M: p = (c - M) mod 16 (vpos_at: the position falls by one
+// slot per sub-block), c = the ring slot index one sub-block before the step
+template <int M, bool kFma, int kFormat>
+MPG_HD void audio_window_m(const AudioArgs &a, uint32_t stream, uint32_t c, uint32_t base, uint32_t tg1, int ch, int i,
+                           const float *p0, const float *p1, const float (&dreg)[16])
+{
+    const uint32_t p = (c - (uint32_t)M) & 15u;
+    if (base + p < tg1)
+        audio_window_pair<M, kFma, kFormat>(a, stream, base + p, tg1, ch, i, p0, p1, dreg);
+}
+
+// ---- windows of step si: 16 pairs (p, p + 16), one per ring position M = 0..15.  Which taps a pair
+// reads, and in which order, depends on M alone, so the work is dealt out BY M: the three free waves take
+// M = rank, rank + 3, ... (five each), the wave that runs DCT(si + 1) in the same iteration takes
+// M = 15 — each wave runs straight-line code with immediate offsets, no per-pair dispatch.
 template <bool kFma, int kFormat>
 MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t tg0, uint32_t tg1, uint32_t si,
                                int tid, const float (&dreg)[16], const float *lds)
@@ -409,13 +398,16 @@ MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos
     const float *p0 = lds + kHistBase + ch * 32 + mirror_index(i);
     const float *p1 = lds + kHistBase + ch * 32 + mirror_index(32 + i);
     const uint32_t base = tg0 + si * kStep;
+    const uint32_t c = (uint32_t)(vpos_at(vpos0, kT0 + (int32_t)base) >> 6); // ring slot index of pair 0
     const uint32_t rank = (wave - busy - 1) % kAudioWaves; // 0..2 for the three free waves, 3 for the busy one
-    const uint32_t first = rank == 3 ? 15 : rank, stride = rank == 3 ? 16 : 3, end = rank == 3 ? 16 : 15;
-    for (uint32_t p = first; p < end; p += stride) {
-        if (base + p >= tg1)
-            break;
-        audio_window_pair<kFma, kFormat>(a, stream, vpos0, base + p, tg1, ch, i, p0, p1, dreg);
+#define MPG_WIN(M) audio_window_m<M, kFma, kFormat>(a, stream, c, base, tg1, ch, i, p0, p1, dreg)
+    switch (rank) {
+    case 0: MPG_WIN(0); MPG_WIN(3); MPG_WIN(6); MPG_WIN(9); MPG_WIN(12); break;
+    case 1: MPG_WIN(1); MPG_WIN(4); MPG_WIN(7); MPG_WIN(10); MPG_WIN(13); break;
+    case 2: MPG_WIN(2); MPG_WIN(5); MPG_WIN(8); MPG_WIN(11); MPG_WIN(14); break;
+    default: MPG_WIN(15); break;
     }
+#undef MPG_WIN
 }
 
 // ---- state out: last 16 history slots -> Audio.v ring; thread 0 advances vPos
