@@ -332,33 +332,36 @@ MPG_HD float scale_short(float x)
 }
 
 // convert (audio.go:386-418) and store one sample of sub-block tg
+// The interleaved formats need no frame / sub-block split: frame f, sub-block t, sample i, channel ch sits at
+// element (f*36 + t)*64 + 2i + ch = tg*64 + (2i + ch) of the stream's output.
 template <int kFormat>
 MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, int i, float sv)
 {
-    const uint32_t f = tg / 36, t = tg % 36;
-    const uint64_t fb = ((uint64_t)stream * a.n_frames + f) * 2304;
-    const uint32_t o = t * 32 + (uint32_t)i;
+    const uint64_t sb = (uint64_t)stream * a.n_frames * 2304; // the stream's first output element
+    if (kFormat == MPEGHIP_AUDIO_F32NLR) {
+        const uint32_t f = tg / 36, t = tg % 36;
+        reinterpret_cast<float *>(a.out)[sb + f * 2304 + (uint32_t)ch * 1152 + t * 32 + (uint32_t)i] = sv;
+        return;
+    }
+    const uint32_t e = tg * 64 + 2 * (uint32_t)i + (uint32_t)ch;
     if (kFormat == MPEGHIP_AUDIO_F32N)
-        reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv;
-    else if (kFormat == MPEGHIP_AUDIO_F32NLR)
-        reinterpret_cast<float *>(a.out)[fb + (uint32_t)ch * 1152 + o] = sv;
+        (reinterpret_cast<float *>(a.out) + sb)[e] = sv;
     else if (kFormat == MPEGHIP_AUDIO_S16) // audio.go:400-408
-        reinterpret_cast<int16_t *>(a.out)[fb + 2 * o + (uint32_t)ch] = (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f);
+        (reinterpret_cast<int16_t *>(a.out) + sb)[e] = (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f);
     else // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
-        reinterpret_cast<float *>(a.out)[fb + 2 * o + (uint32_t)ch] = sv * 2147483648.0f;
+        (reinterpret_cast<float *>(a.out) + sb)[e] = sv * 2147483648.0f;
 }
 
 // one window pair: sub-blocks tgA and tgA + 16 (same ring position modulo 16 slots, so the same taps),
 // for the ring position 64*M known at compile time
 template <int M, bool kFma, int kFormat>
-MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, uint32_t tgA, uint32_t tg1, int ch, int i, const float *p0,
-                              const float *p1, const float (&dreg)[16])
+MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, uint32_t tgA, uint32_t tg1, uint32_t slotA, int ch, int i,
+                              const float *p0, const float *p1, const float (&dreg)[16])
 {
     const uint32_t tgB = tgA + 16;
-    const int32_t TA = kT0 + (int32_t)tgA;
-    const int32_t slotA = ring_slot(TA), slotB = ring_slot(TA + 16);
-    const int32_t offA = ((slotA < kMirrorSlots ? slotA + kRing : slotA) - 15) * kSlotStride;
-    const int32_t offB = ((slotB < kMirrorSlots ? slotB + kRing : slotB) - 15) * kSlotStride;
+    const uint32_t slotB = slotA + 16 >= (uint32_t)kRing ? slotA + 16 - kRing : slotA + 16; // ring_slot(TA + 16)
+    const int32_t offA = (int32_t)((slotA < (uint32_t)kMirrorSlots ? slotA + kRing : slotA) - 15) * kSlotStride;
+    const int32_t offB = (int32_t)((slotB < (uint32_t)kMirrorSlots ? slotB + kRing : slotB) - 15) * kSlotStride;
     float accA, accB;
     window_taps<M, kFma>(p0 + offA, p1 + offA, p0 + offB, p1 + offB, dreg, accA, accB);
     float svA, svB;
@@ -377,12 +380,14 @@ MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, uint32_t tgA,
 // the pair of this step whose ring position is 64*M: p = (c - M) mod 16 (vpos_at: the position falls by one
 // slot per sub-block), c = the ring slot index one sub-block before the step
 template <int M, bool kFma, int kFormat>
-MPG_HD void audio_window_m(const AudioArgs &a, uint32_t stream, uint32_t c, uint32_t base, uint32_t tg1, int ch, int i,
-                           const float *p0, const float *p1, const float (&dreg)[16])
+MPG_HD void audio_window_m(const AudioArgs &a, uint32_t stream, uint32_t c, uint32_t slot0, uint32_t base, uint32_t tg1, int ch,
+                           int i, const float *p0, const float *p1, const float (&dreg)[16])
 {
     const uint32_t p = (c - (uint32_t)M) & 15u;
-    if (base + p < tg1)
-        audio_window_pair<M, kFma, kFormat>(a, stream, base + p, tg1, ch, i, p0, p1, dreg);
+    if (base + p < tg1) {
+        const uint32_t slotA = slot0 + p >= (uint32_t)kRing ? slot0 + p - kRing : slot0 + p; // ring_slot(kT0 + base + p)
+        audio_window_pair<M, kFma, kFormat>(a, stream, base + p, tg1, slotA, ch, i, p0, p1, dreg);
+    }
 }
 
 // ---- windows of step si: 16 pairs (p, p + 16), one per ring position M = 0..15.  Which taps a pair
@@ -399,8 +404,9 @@ MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos
     const float *p1 = lds + kHistBase + ch * 32 + mirror_index(32 + i);
     const uint32_t base = tg0 + si * kStep;
     const uint32_t c = (uint32_t)(vpos_at(vpos0, kT0 + (int32_t)base) >> 6); // ring slot index of pair 0
+    const uint32_t slot0 = (uint32_t)ring_slot(kT0 + (int32_t)base);         // one modulo per step, not two per pair
     const uint32_t rank = (wave - busy - 1) % kAudioWaves; // 0..2 for the three free waves, 3 for the busy one
-#define MPG_WIN(M) audio_window_m<M, kFma, kFormat>(a, stream, c, base, tg1, ch, i, p0, p1, dreg)
+#define MPG_WIN(M) audio_window_m<M, kFma, kFormat>(a, stream, c, slot0, base, tg1, ch, i, p0, p1, dreg)
     switch (rank) {
     case 0: MPG_WIN(0); MPG_WIN(3); MPG_WIN(6); MPG_WIN(9); MPG_WIN(12); break;
     case 1: MPG_WIN(1); MPG_WIN(4); MPG_WIN(7); MPG_WIN(10); MPG_WIN(13); break;
