@@ -218,8 +218,9 @@ __global__ __launch_bounds__(kChunkMbs * 64) void recon_compact_kernel(const Vid
 }
 
 // ---- wave-chunk path: one wave = 4 consecutive macroblocks, dense residual stage, no barrier
+// 8 waves per SIMD: 64 VGPRs, and 4 x 5120 bytes of LDS per workgroup let 8 workgroups share a CU
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a, const uint32_t n_chunks)
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_wc_kernel(const VideoArgs a, const uint32_t n_chunks)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kWcLdsBytes];
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -257,9 +258,9 @@ __global__ __launch_bounds__(WAVES * 64) void recon_wc_kernel(const VideoArgs a,
     for (uint32_t s0 = 0; s0 < total; s0 += 8) {
         const uint32_t slot = s0 + (uint32_t)g;
         bool active;
-        compact_phase2(a, ci, slot, j, tile + g * kTileStride, active);
+        compact_phase2(a, ci, slot, j, tile + g * kWcTileStride, active);
         wave_lds_handoff();
-        compact_phase2_rows(slot, j, tile + g * kTileStride, active, resid);
+        compact_phase2_rows(slot, j, tile + g * kWcTileStride, active, resid);
         wave_lds_handoff();
     }
     MPG_STAMP(3);
@@ -374,28 +375,41 @@ __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64
                       width, height, x4, y, rgba + fs * rgba_stride);
 }
 
-// Copies each macroblock's picture fields into the reserved words of its (device) descriptor: see
-// wc_load_raw.  Runs once per upload, after the replication.
-__global__ void fill_pic_fields_kernel(const mpeghip_pic_desc *pics, mpeghip_mb_desc *mbs, uint64_t n_mbs)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_mbs)
-        fill_pic_fields(pics, mbs, (uint32_t)i);
-}
-
-// Replicate a one-stream descriptor set for streams 1..n-1 (benchmark batches).
-__global__ void replicate_desc_kernel(mpeghip_pic_desc *pics, uint32_t n_pics,
-                                      mpeghip_mb_desc *mbs, uint32_t n_mbs,
-                                      uint32_t coef_units, uint32_t n_streams)
+// Replicate a one-stream descriptor set for streams 1..n-1 (benchmark batches): descriptors and pictures
+// for the diagnostic kernels, expanded records (video_compact_lane.h) for the wave-chunk kernel.  Upload-time
+// scaffolding of mpeghip_video_batch_upload_replicated, never inside a timed region.
+struct ReplicateSteps {
+    uint32_t coef_units;  // coefficient units of one stream
+    uint32_t frames256;   // MPEGHIP_SLOTS * frame_stride >> 8
+    uint32_t rgba256;     // MPEGHIP_SLOTS * rgba_stride >> 8
+};
+__global__ void replicate_desc_kernel(mpeghip_pic_desc *pics, uint32_t n_pics, mpeghip_mb_desc *mbs, uint32_t *xmbs,
+                                      uint32_t n_mbs, ReplicateSteps k, uint32_t n_streams)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total_mbs = (uint64_t)n_mbs * n_streams;
     if (gid >= (uint64_t)n_mbs && gid < total_mbs) {
         const uint32_t s = (uint32_t)(gid / n_mbs), i = (uint32_t)(gid % n_mbs);
-        mpeghip_mb_desc d = mbs[i];
-        d.pic += s * n_pics;
-        d.coef_off += s * coef_units;
-        mbs[gid] = d;
+        if (mbs) {
+            mpeghip_mb_desc d = mbs[i];
+            d.pic += s * n_pics;
+            d.coef_off += s * k.coef_units;
+            mbs[gid] = d;
+        }
+        if (xmbs) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(xmbs + (uint64_t)i * kXDwords);
+            u32x4 q0 = src[0], q1 = src[1], q2 = src[2];
+            q0.v[1] += s * k.coef_units;
+            q0.v[2] += s * 256u;
+            q1.v[0] += s * k.frames256;
+            q1.v[1] += s * k.frames256;
+            q2.v[2] += s * k.rgba256;
+            u32x4 *dst = reinterpret_cast<u32x4 *>(xmbs + gid * kXDwords);
+            dst[0] = q0;
+            dst[1] = q1;
+            dst[2] = q2;
+            static_assert(kXDwords == 12, "three 16-byte quarters per record");
+        }
     }
     const uint64_t total_pics = (uint64_t)n_pics * n_streams;
     if (gid >= (uint64_t)n_pics && gid < total_pics) {
@@ -497,7 +511,8 @@ struct mpeghip_ctx {
 struct mpeghip_batch {
     mpeghip_video *owner = nullptr;
     mpeghip_pic_desc *d_pics = nullptr;
-    mpeghip_mb_desc *d_mbs = nullptr;
+    mpeghip_mb_desc *d_mbs = nullptr; // filled only for the diagnostic kernels (MPEGHIP_RECON mode < 6)
+    uint32_t *d_xmbs = nullptr;       // expanded records of the wave-chunk kernel (mode 6)
     uint8_t *d_coefs = nullptr;
     uint64_t n_pics = 0, n_mbs = 0, coef_bytes = 0;
     uint64_t alg_bytes = 0;
@@ -509,7 +524,7 @@ struct mpeghip_batch {
     struct PicNote { uint32_t stream; uint8_t cur, rgba, full; };
     std::vector<PicNote> notes;
     uint32_t replicas = 1;
-    size_t cap_pics = 0, cap_mbs = 0, cap_coefs = 0, cap_entries = 0; // capacities (transient batch reuse)
+    size_t cap_pics = 0, cap_mbs = 0, cap_xmbs = 0, cap_coefs = 0, cap_entries = 0; // capacities (transient batch reuse)
 };
 
 struct mpeghip_video {
@@ -775,6 +790,8 @@ static void batch_release(mpeghip_batch *b)
         (void)hipFree(b->d_pics);
     if (b->d_mbs)
         (void)hipFree(b->d_mbs);
+    if (b->d_xmbs)
+        (void)hipFree(b->d_xmbs);
     if (b->d_coefs)
         (void)hipFree(b->d_coefs);
     if (b->d_entries)
@@ -783,6 +800,7 @@ static void batch_release(mpeghip_batch *b)
     b->cap_entries = 0;
     b->d_pics = nullptr;
     b->d_mbs = nullptr;
+    b->d_xmbs = nullptr;
     b->d_coefs = nullptr;
     b->cap_pics = b->cap_mbs = b->cap_coefs = 0;
 }
@@ -855,9 +873,17 @@ static uint64_t rgba_stride_of(const mpeghip_video *v) { return align_up(v->info
 // Host-side validation of one submit; also totals the algorithmic bytes.
 static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
                     const mpeghip_mb_desc *mbs, uint32_t n_mbs, size_t coef_bytes, uint64_t *alg_bytes,
-                    bool *dense_partition)
+                    bool *dense_partition, uint32_t *xrec = nullptr)
 {
+    // xrec != NULL: also write each macroblock's expanded record (video_compact_lane.h: expand_mb) — the same
+    // pass has just checked every field the record is computed from
     const mpeghip_video_info &in = v->info;
+    XGeom geom;
+    geom.luma_w = in.luma_w;
+    geom.chroma_w = in.chroma_w;
+    geom.frame_stride = in.frame_stride;
+    geom.rgba_stride = rgba_stride_of(v);
+    std::vector<XPic> xpics;
     if (n_pics && !pics)
         return fail(MPEGHIP_ERR_INVALID, "pics is NULL");
     if (n_mbs && !mbs)
@@ -870,6 +896,11 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
             return fail(MPEGHIP_ERR_INVALID, "picture %u: bad stream/slot", p);
         if ((uint64_t)pd.mb_first + pd.mb_count > n_mbs)
             return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock range out of bounds", p);
+    }
+    if (xrec) {
+        xpics.resize(n_pics);
+        for (uint32_t p = 0; p < n_pics; p++)
+            xpics[p] = expand_pic(geom, pics[p]);
     }
     const int64_t cap_y = (int64_t)in.frame_bytes;
     const int64_t cap_c0 = (int64_t)(in.frame_bytes - in.luma_bytes);
@@ -924,6 +955,8 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
         alg += 32 + units * MPEGHIP_COEF_UNIT + ref_bytes + (intra ? 64ull * nb : 384);
         if (pics[m.pic].flags & MPEGHIP_PIC_RGBA)
             alg += 1024;
+        if (xrec)
+            expand_mb(geom, xpics[m.pic], m, xrec + (size_t)i * kXDwords);
     }
     if (alg_bytes)
         *alg_bytes = alg;
@@ -947,6 +980,27 @@ static int grow(void **p, size_t *cap, size_t need)
     return MPEGHIP_OK;
 }
 
+// Development knob (not part of the ABI): MPEGHIP_RECON="mode,waves,blocks_per_cu".
+//   mode 6 (default): wave-chunk kernel: one wave = 4 macroblocks, dense residual stage, no barrier
+//                     ("waves" = 4 -> 4 waves/block, 8 -> 8, 16 -> 2)
+//   mode 5: compact fused kernel (dense residual stage inside the workgroup) (+ RGBA pass)
+//   mode 4: split path, K1 prediction + K2 dense residual (+ RGBA pass)
+//   mode 0: fused one-wave-per-macroblock kernel;  1-3: its persistent / pipelined variants
+struct ReconKnob {
+    int mode = 6, waves = 4, bpc = 4;
+};
+static ReconKnob recon_knob()
+{
+    ReconKnob r;
+    if (const char *e = getenv("MPEGHIP_RECON"))
+        sscanf(e, "%d,%d,%d", &r.mode, &r.waves, &r.bpc);
+    if (r.waves != 4 && r.waves != 8 && r.waves != 16)
+        r.waves = 8;
+    if (r.mode < 0 || r.mode > 6)
+        r.mode = 6;
+    return r;
+}
+
 static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
 {
     if (b->n_mbs == 0)
@@ -963,6 +1017,7 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.chroma_bytes = (uint32_t)in.chroma_bytes;
     a.pics = b->d_pics;
     a.mbs = b->d_mbs;
+    a.xmbs = b->d_xmbs;
     a.coefs = b->d_coefs;
     a.qmat = v->d_qmat;
     a.dump = v->d_dump;
@@ -971,19 +1026,8 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.height = in.height;
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
-    // Development knob (not part of the ABI): MPEGHIP_RECON="mode,waves,blocks_per_cu".
-    //   mode 6 (default): wave-chunk kernel: one wave = 4 macroblocks, dense residual stage, no barrier
-    //                     ("waves" = 4 -> 4 waves/block, 8 -> 8, 16 -> 2)
-    //   mode 5: compact fused kernel (dense residual stage inside the workgroup) (+ RGBA pass)
-    //   mode 4: split path, K1 prediction + K2 dense residual (+ RGBA pass)
-    //   mode 0: fused one-wave-per-macroblock kernel;  1-3: its persistent / pipelined variants
-    int mode = 6, waves = 4, bpc = 4;
-    if (const char *e = getenv("MPEGHIP_RECON"))
-        sscanf(e, "%d,%d,%d", &mode, &waves, &bpc);
-    if (waves != 4 && waves != 8 && waves != 16)
-        waves = 8;
-    if (mode < 0 || mode > 6)
-        mode = 6;
+    const ReconKnob knob = recon_knob();
+    const int mode = knob.mode, waves = knob.waves, bpc = knob.bpc;
     if (mode == 6) {
         hipStream_t st = v->ctx->stream;
         const uint32_t n_chunks = (uint32_t)((b->n_mbs + kWcMbs - 1) / kWcMbs);
@@ -1122,28 +1166,28 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
                        const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
                        uint32_t replicas, mpeghip_video::Staging *sg = nullptr)
 {
-    int rc = validate(v, pics, n_pics, mbs, n_mbs, coef_bytes, &b->alg_bytes, &b->dense_partition);
-    b->any_rgba = wants_rgba(pics, n_pics);
-    if (rc != MPEGHIP_OK)
-        return rc;
     if (n_mbs > 0 && coef_bytes > 0 && !coefs)
         return fail(MPEGHIP_ERR_INVALID, "coefs is NULL");
     if ((uint64_t)n_mbs * replicas > 0xffffffffull || (uint64_t)(coef_bytes / MPEGHIP_COEF_UNIT) * replicas > 0xffffffffull)
         return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit descriptor indices");
     HIP_TRY(hipSetDevice(v->ctx->device));
-    if (wants_rgba(pics, n_pics)) {
-        rc = ensure_rgba(v);
-        if (rc != MPEGHIP_OK)
-            return rc;
-    }
+    // The wave-chunk kernel (mode 6) reads expanded records, which the validation pass below writes straight
+    // into the buffer the H2D copy reads; the ABI descriptors go to the device only for the diagnostic
+    // kernels.  A submit carries one of the two; a resident batch both (it may be run under either knob).
+    const bool records = !sg || recon_knob().mode == 6, descs = !sg || !records;
+    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics;
+    const size_t mb = descs ? sizeof(mpeghip_mb_desc) * (size_t)n_mbs : 0;
+    const size_t xb = records ? sizeof(uint32_t) * kXDwords * (size_t)n_mbs : 0;
+    const size_t x_at = (pb + mb + 63) & ~(size_t)63, coef_at = (x_at + xb + 63) & ~(size_t)63;
+    std::vector<uint32_t> xhost; // (resident batches: pageable, this call waits for the copies anyway)
+    uint32_t *xrec = nullptr;
     hipStream_t st = v->ctx->stream;
     if (sg) {
         if (sg->in_flight) { // two submits ago: normally long finished
             HIP_TRY(hipEventSynchronize(sg->done));
             sg->in_flight = false;
         }
-        const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics, mb = sizeof(mpeghip_mb_desc) * (size_t)n_mbs;
-        const size_t need = pb + mb + coef_bytes + 64;
+        const size_t need = coef_at + coef_bytes + 64;
         if (need > sg->cap_h) {
             if (sg->h)
                 (void)hipHostFree(sg->h);
@@ -1155,38 +1199,56 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
         }
         if (!sg->done)
             HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
+        if (records)
+            xrec = reinterpret_cast<uint32_t *>(sg->h + x_at);
+    } else if (records) {
+        xhost.resize((size_t)n_mbs * kXDwords);
+        xrec = xhost.data();
+    }
+    int rc = validate(v, pics, n_pics, mbs, n_mbs, coef_bytes, &b->alg_bytes, &b->dense_partition, xrec);
+    b->any_rgba = wants_rgba(pics, n_pics);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    if (b->any_rgba) {
+        rc = ensure_rgba(v);
+        if (rc != MPEGHIP_OK)
+            return rc;
+    }
+    if (sg) {
         if (pb)
             memcpy(sg->h, pics, pb);
         if (mb)
             memcpy(sg->h + pb, mbs, mb);
         if (coef_bytes)
-            memcpy(sg->h + pb + mb, coefs, coef_bytes);
+            memcpy(sg->h + coef_at, coefs, coef_bytes);
         pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->h);
         mbs = reinterpret_cast<const mpeghip_mb_desc *>(sg->h + pb);
-        coefs = sg->h + pb + mb;
+        coefs = sg->h + coef_at;
     }
     if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
-        (rc = grow((void **)&b->d_mbs, &b->cap_mbs, sizeof(mpeghip_mb_desc) * (size_t)n_mbs * replicas + 32)) != 0 ||
+        (rc = grow((void **)&b->d_mbs, &b->cap_mbs, mb * replicas + 32)) != 0 ||
+        (rc = grow((void **)&b->d_xmbs, &b->cap_xmbs, xb * replicas + 64 * kWcMbs)) != 0 ||
         (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0 ||
         (rc = grow((void **)&b->d_entries, &b->cap_entries, (coef_bytes / MPEGHIP_COEF_UNIT) * replicas * sizeof(BlockEntry) + 64)) != 0)
         return rc;
-    if (n_pics)
-        HIP_TRY(hipMemcpyAsync(b->d_pics, pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics, hipMemcpyHostToDevice, st));
-    if (n_mbs)
-        HIP_TRY(hipMemcpyAsync(b->d_mbs, mbs, sizeof(mpeghip_mb_desc) * (size_t)n_mbs, hipMemcpyHostToDevice, st));
+    if (pb)
+        HIP_TRY(hipMemcpyAsync(b->d_pics, pics, pb, hipMemcpyHostToDevice, st));
+    if (mb)
+        HIP_TRY(hipMemcpyAsync(b->d_mbs, mbs, mb, hipMemcpyHostToDevice, st));
+    if (xb)
+        HIP_TRY(hipMemcpyAsync(b->d_xmbs, xrec, xb, hipMemcpyHostToDevice, st));
     if (coef_bytes)
         HIP_TRY(hipMemcpyAsync(b->d_coefs, coefs, coef_bytes, hipMemcpyHostToDevice, st));
     if (replicas > 1) {
         for (uint32_t s = 1; s < replicas && coef_bytes; s++)
             HIP_TRY(hipMemcpyAsync(b->d_coefs + (size_t)s * coef_bytes, b->d_coefs, coef_bytes, hipMemcpyDeviceToDevice, st));
         const uint64_t work = (uint64_t)(n_mbs > n_pics ? n_mbs : n_pics) * replicas;
+        ReplicateSteps k;
+        k.coef_units = (uint32_t)(coef_bytes / MPEGHIP_COEF_UNIT);
+        k.frames256 = (uint32_t)((MPEGHIP_SLOTS * v->info.frame_stride) >> 8);
+        k.rgba256 = (uint32_t)((MPEGHIP_SLOTS * rgba_stride_of(v)) >> 8);
         hipLaunchKernelGGL(replicate_desc_kernel, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, st, b->d_pics, n_pics,
-                           b->d_mbs, n_mbs, (uint32_t)(coef_bytes / MPEGHIP_COEF_UNIT), replicas);
-        HIP_TRY(hipGetLastError());
-    }
-    if (n_mbs) {
-        const uint64_t total = (uint64_t)n_mbs * replicas;
-        hipLaunchKernelGGL(fill_pic_fields_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, b->d_pics, b->d_mbs, total);
+                           descs ? b->d_mbs : nullptr, records ? b->d_xmbs : nullptr, n_mbs, k, replicas);
         HIP_TRY(hipGetLastError());
     }
     if (!sg) // pageable host memory: the copies above may still be reading it

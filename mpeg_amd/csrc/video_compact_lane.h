@@ -277,60 +277,130 @@ MPG_HD void compact_phase1(const VideoArgs &a, const MbU &u, int lane, MbLoads &
 constexpr int kWcMbs = 4;
 constexpr int kWcMaxBlocks = 6 * kWcMbs;                   // 24
 constexpr int kWcResidBytes = kWcMaxBlocks * 128;           // 3072
-constexpr int kWcTileBytes = 8 * kTileStride * 4;           // 2304: IDCT transpose tile, later the output tile
+// 8 blocks x 64 dwords, no padding: the column writes take 8-way bank conflicts, but the 256 bytes the
+// padding would cost per wave are what separates 7 from 8 resident workgroups per CU (20 480 bytes each),
+// and the kernel is short of waves, not of LDS bandwidth (4 % of its issue).
+constexpr int kWcTileStride = 64;
+constexpr int kWcTileBytes = 8 * kWcTileStride * 4;         // 2048: IDCT transpose tile, later the output tile
 constexpr int kWcLdsBytes = kWcResidBytes + kWcTileBytes;   // 5376
 constexpr int kWcOutBytes = 16 * 64 + 2 * 8 * 32;           // 1536 <= kWcTileBytes
 using WcInfo = ChunkInfoT<kWcMbs>;
 
-// Everything a wave needs from the descriptor arrays in ONE round of scalar loads: the chunk's four
-// 32-byte macroblock descriptors (contiguous, 128 bytes).  The picture fields a macroblock needs
-// (stream; cur | fwd | bwd | flags) have been copied into the descriptor's reserved words on the
-// DEVICE copy by fill_pic_fields_kernel when the batch was uploaded, so no second, dependent load of
-// mpeghip_pic_desc is needed.  The descriptors are streamed — every load misses all caches — and
-// scalar loads return out of order, so each s_waitcnt waits for all of them: loading per macroblock
-// (descriptor, then its picture) cost a wave ten such round trips, 43 % of its life
-// (profiles/r03o_phase_timing.txt).
-constexpr int kMbPicStream = 5, kMbPicSlots = 6; // dword index of reserved[0], reserved[1]
+// The wave-chunk kernel does not read mpeghip_mb_desc / mpeghip_pic_desc.  The HOST half of the library turns
+// every macroblock descriptor (+ its picture's) into a 48-byte record while it stages a batch (expand_mb,
+// called from the validation loop of mpeghip.hip) and uploads the records; they hold what the kernel
+// would otherwise work out per wave on the scalar unit — frame offsets of the block origins and of the
+// prediction source, the frames' byte offsets, half-pel flags, table offset.  Why:
+//   * the descriptors are streamed (every load misses all caches) and scalar loads return out of
+//     order, so each s_waitcnt waits for all of them: descriptor -> picture -> ... cost a wave ten
+//     round trips; one round of loads of 4 x 44 bytes is left;
+//   * scalar instructions are not free on this path: +20 per macroblock inside phase 3 cost 4 % of the
+//     typical workload (more than 20 vector instructions), and two thirds of the kernel's 145 scalar
+//     instructions per macroblock were this arithmetic (profiles/r03y_sensitivity_phase3.txt);
+//   * with the registers that frees, 8 instead of 7 waves fit a SIMD.
+// The C ABI is unchanged: records are the library's device format.  They cost 16 B of descriptor
+// traffic per macroblock more than the ABI's 32-byte descriptor, which the HBM has to spare.
+constexpr int kXDwords = 12;
+constexpr uint32_t kXOhLuma = 1u << 24, kXOvLuma = 1u << 25, kXOhChroma = 1u << 26, kXOvChroma = 1u << 27,
+                   kXNeedsBelow = 1u << 28, kXRgba = 1u << 29;
+// dword 0: flags | cbp << 8 | qscale << 16 | kX* bits     1: coef_off      2: qtab (byte offset into qmat)
+//       3: mb_x | mb_y << 16     4: cur frame offset >> 8     5: reference frame offset >> 8
+//       6..9: src_luma, src_chroma, dst_luma, dst_chroma (bytes inside the frame)   10: RGBA image offset >> 8
+// Per stream s of a replicated batch, dwords 1, 2, 4, 5, 10 move by s times kXStep* (replicate_desc_kernel).
 
-struct WcRaw {
-    uint32_t d[kWcMbs][7]; // pic | mb_x,mb_y | mv_x,mv_y | flags,cbp,qscale,- | coef_off | stream | cur,fwd,bwd,picflags
+// geometry the expansion needs (a subset of VideoArgs, so that host code can call it too)
+struct XGeom {
+    uint32_t luma_w, chroma_w;
+    uint64_t frame_stride, rgba_stride;
 };
 
+// the picture's share of a record, worked out once per picture
+struct XPic {
+    uint32_t cur256, fwd256, bwd256, rgba256, qtab, bits;
+};
+
+MPG_HD XPic expand_pic(const XGeom &g, const mpeghip_pic_desc &p)
+{
+    const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
+    XPic xp;
+    xp.cur256 = (uint32_t)(((s3 + p.cur) * g.frame_stride) >> 8); // strides are multiples of 256
+    xp.fwd256 = (uint32_t)(((s3 + p.fwd) * g.frame_stride) >> 8);
+    xp.bwd256 = (uint32_t)(((s3 + p.bwd) * g.frame_stride) >> 8);
+    xp.rgba256 = (uint32_t)(((s3 + p.cur) * g.rgba_stride) >> 8);
+    xp.qtab = p.stream * 256;
+    xp.bits = (p.flags & MPEGHIP_PIC_RGBA) ? kXRgba : 0;
+    return xp;
+}
+
+MPG_HD void expand_mb(const XGeom &g, const XPic &xp, const mpeghip_mb_desc &d, uint32_t *x /* [kXDwords] */)
+{
+    const bool intra = (d.flags & MPEGHIP_MB_INTRA) != 0;
+    const int32_t mvx = d.mv_x, mvy = d.mv_y;
+    const int32_t cmx = mvx / 2, cmy = mvy / 2; // toward zero, video_noasm.go:35-36
+    uint32_t w0 = (uint32_t)d.flags | ((uint32_t)d.cbp << 8) | ((uint32_t)d.qscale << 16) | xp.bits;
+    w0 |= (mvx & 1) ? kXOhLuma : 0;
+    w0 |= (mvy & 1) ? kXOvLuma : 0;
+    w0 |= (cmx & 1) ? kXOhChroma : 0;
+    w0 |= (cmy & 1) ? kXOvChroma : 0;
+    w0 |= (!intra && ((mvy & 1) || (cmy & 1))) ? kXNeedsBelow : 0;
+    const int32_t dst_luma = (int32_t)((uint32_t)d.mb_y << 4) * (int32_t)g.luma_w + (int32_t)((uint32_t)d.mb_x << 4);
+    const int32_t dst_chroma = (int32_t)((uint32_t)d.mb_y << 3) * (int32_t)g.chroma_w + (int32_t)((uint32_t)d.mb_x << 3);
+    x[0] = w0;
+    x[1] = d.coef_off;
+    x[2] = xp.qtab + (intra ? 0u : 128u);
+    x[3] = (uint32_t)d.mb_x | ((uint32_t)d.mb_y << 16);
+    x[4] = xp.cur256;
+    x[5] = (d.flags & MPEGHIP_MB_REF_BWD) ? xp.bwd256 : xp.fwd256;
+    x[6] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
+    x[7] = (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)g.chroma_w + (cmx >> 1));
+    x[8] = (uint32_t)dst_luma;
+    x[9] = (uint32_t)dst_chroma;
+    x[10] = xp.rgba256;
+    x[11] = 0;
+    static_assert(kXDwords == 12, "record layout");
+}
+
+struct WcRaw {
+    uint32_t d[kWcMbs][11];
+};
+
+// ONE round of scalar loads for the whole chunk
 MPG_HD void wc_load_raw(const VideoArgs &a, uint32_t chunk, uint32_t &n, WcRaw &r)
 {
     const uint32_t first = chunk * kWcMbs;
     n = a.n_mbs - first < (uint32_t)kWcMbs ? a.n_mbs - first : (uint32_t)kWcMbs;
-    const MPG_CONST_AS uint32_t *mb = (const MPG_CONST_AS uint32_t *)(uintptr_t)a.mbs + (uint64_t)first * 8;
+    const MPG_CONST_AS uint32_t *x = (const MPG_CONST_AS uint32_t *)(uintptr_t)a.xmbs + (uint64_t)first * kXDwords;
 #pragma unroll
     for (int k = 0; k < kWcMbs; k++) {
         const uint32_t kk = (uint32_t)k < n ? (uint32_t)k : 0u; // past the end of the batch: macroblock 0 again
 #pragma unroll
-        for (int w = 1; w < 7; w++)
-            r.d[k][w] = mb[kk * 8 + w];
-        r.d[k][0] = 0;
+        for (int w = 0; w < 11; w++)
+            r.d[k][w] = x[kk * kXDwords + w];
     }
 }
 
-// the wave-uniform views the phases use, from the raw dwords (pure arithmetic)
-MPG_HD MbU wc_mb_from_raw(const VideoArgs &a, const uint32_t (&d)[7])
+// the wave-uniform view the phases use (no arithmetic left beyond two 64-bit adds)
+MPG_HD MbU wc_mb_from_raw(const VideoArgs &a, const uint32_t (&d)[11])
 {
     MbU u;
-    u.flags = d[3] & 0xff;
-    u.cbp = (d[3] >> 8) & 0xff;
-    u.qscale = (d[3] >> 16) & 0xff;
-    u.coef_off = d[4];
-    u.mv_x = (int32_t)(int16_t)(d[2] & 0xffff);
-    u.mv_y = (int32_t)(int16_t)(d[2] >> 16);
-    u.mb_x = d[1] & 0xffff;
-    u.mb_y = d[1] >> 16;
-    const uint32_t slots = d[kMbPicSlots], cur_slot = slots & 0xff;
-    u.pic_flags = slots >> 24;
-    const uint64_t s3 = (uint64_t)d[kMbPicStream] * MPEGHIP_SLOTS;
-    u.cur = a.frames + (s3 + cur_slot) * a.frame_stride;
-    const uint32_t ref_slot = (u.flags & MPEGHIP_MB_REF_BWD) ? (slots >> 16) & 0xff : (slots >> 8) & 0xff;
-    u.ref = a.frames + (s3 + ref_slot) * a.frame_stride;
-    u.qm = a.qmat + (uint64_t)d[kMbPicStream] * 256 + ((u.flags & MPEGHIP_MB_INTRA) ? 0 : 128);
-    u.rgba = (u.pic_flags & MPEGHIP_PIC_RGBA) ? a.rgba + (s3 + cur_slot) * a.rgba_stride : nullptr;
+    u.flags = d[0] & 0xff;
+    u.cbp = (d[0] >> 8) & 0xff;
+    u.qscale = (d[0] >> 16) & 0xff;
+    u.bits = d[0];
+    u.coef_off = d[1];
+    u.mv_x = u.mv_y = 0; // (not used by the wave-chunk phases)
+    u.mb_x = d[3] & 0xffff;
+    u.mb_y = d[3] >> 16;
+    u.pic_flags = (d[0] & kXRgba) ? MPEGHIP_PIC_RGBA : 0;
+    u.cur_off256 = d[4];
+    u.cur = a.frames + ((uint64_t)d[4] << 8);
+    u.ref = a.frames + ((uint64_t)d[5] << 8);
+    u.qm = a.qmat + d[2];
+    u.rgba = (d[0] & kXRgba) ? a.rgba + ((uint64_t)d[10] << 8) : nullptr;
+    u.src_luma = (int32_t)d[6];
+    u.src_chroma = (int32_t)d[7];
+    u.dst_luma = (int32_t)d[8];
+    u.dst_chroma = (int32_t)d[9];
     return u;
 }
 
@@ -341,25 +411,17 @@ MPG_HD WcInfo wc_info_from_raw(uint32_t n, const WcRaw &r)
     uint32_t acc = 0;
 #pragma unroll
     for (int k = 0; k < kWcMbs; k++) {
-        const uint32_t w3 = r.d[k][3];
+        const uint32_t w0 = r.d[k][0];
         const uint32_t live = (uint32_t)k < n ? 0x3fu : 0u;
-        ci.cbp[k] = (w3 >> 8) & live;
-        ci.flags[k] = (w3 & 0xffu) | (((w3 >> 16) & 0xffu) << 8);
-        ci.coef_off[k] = r.d[k][4];
-        ci.qtab[k] = r.d[k][kMbPicStream] * 256 + ((w3 & MPEGHIP_MB_INTRA) ? 0u : 128u);
+        ci.cbp[k] = (w0 >> 8) & live;
+        ci.flags[k] = (w0 & 0xffu) | (((w0 >> 16) & 0xffu) << 8);
+        ci.coef_off[k] = r.d[k][1];
+        ci.qtab[k] = r.d[k][2];
         ci.base[k] = acc;
         acc += popc6(ci.cbp[k]);
     }
     ci.base[kWcMbs] = acc;
     return ci;
-}
-
-// what fill_pic_fields_kernel writes into macroblock descriptor i of the device copy
-MPG_HD void fill_pic_fields(const mpeghip_pic_desc *pics, mpeghip_mb_desc *mbs, uint32_t i)
-{
-    const mpeghip_pic_desc &p = pics[mbs[i].pic];
-    mbs[i].reserved[0] = p.stream;
-    mbs[i].reserved[1] = (uint32_t)p.cur | ((uint32_t)p.fwd << 8) | ((uint32_t)p.bwd << 16) | ((uint32_t)p.flags << 24);
 }
 
 // lane that holds the row below this lane's row, or -1 if that row must be loaded
@@ -393,18 +455,17 @@ struct WcPredScalars {
     bool oh_luma, ov_luma, oh_chroma, ov_chroma;
 };
 
-MPG_HD WcPredScalars wc_pred_scalars(const VideoArgs &a, const MbU &u)
+MPG_HD WcPredScalars wc_pred_scalars(const VideoArgs &, const MbU &u)
 {
-    WcPredScalars p;
-    const int32_t cmx = u.mv_x / 2, cmy = u.mv_y / 2; // toward zero, video_noasm.go:35-36
-    p.dst_luma = uniform((int32_t)(u.mb_y << 4) * (int32_t)a.luma_w + (int32_t)(u.mb_x << 4));
-    p.dst_chroma = uniform((int32_t)(u.mb_y << 3) * (int32_t)a.chroma_w + (int32_t)(u.mb_x << 3));
-    p.src_luma = uniform(p.dst_luma + (u.mv_y >> 1) * (int32_t)a.luma_w + (u.mv_x >> 1));
-    p.src_chroma = uniform(p.dst_chroma + (cmy >> 1) * (int32_t)a.chroma_w + (cmx >> 1));
-    p.oh_luma = (u.mv_x & 1) != 0;
-    p.ov_luma = (u.mv_y & 1) != 0;
-    p.oh_chroma = (cmx & 1) != 0;
-    p.ov_chroma = (cmy & 1) != 0;
+    WcPredScalars p; // all of it was worked out by expand_mb
+    p.dst_luma = u.dst_luma;
+    p.dst_chroma = u.dst_chroma;
+    p.src_luma = u.src_luma;
+    p.src_chroma = u.src_chroma;
+    p.oh_luma = (u.bits & kXOhLuma) != 0;
+    p.ov_luma = (u.bits & kXOvLuma) != 0;
+    p.oh_chroma = (u.bits & kXOhChroma) != 0;
+    p.ov_chroma = (u.bits & kXOvChroma) != 0;
     return p;
 }
 
@@ -430,10 +491,7 @@ MPG_HD void wc_issue_pred(const VideoArgs &a, const MbU &u, int lane, MbLoads &l
 }
 
 // does any lane of this macroblock need the row below?  (wave-uniform)
-MPG_HD bool wc_needs_below(const MbU &u)
-{
-    return !(u.flags & MPEGHIP_MB_INTRA) && (((u.mv_y & 1) != 0) || (((u.mv_y / 2) & 1) != 0));
-}
+MPG_HD bool wc_needs_below(const MbU &u) { return (u.bits & kXNeedsBelow) != 0; }
 
 // phase 3 of the wave-chunk kernel.  `below` = the 16 bytes of the row under this lane's row, already
 // fetched from the owning lane (or from ld.r1 for the bottom rows).  If out_tile != nullptr the 8 output
@@ -532,7 +590,7 @@ MPG_HD bool wc_can_coalesce(const WcInfo &ci, const MbU (&u)[kWcMbs])
     bool ok = true;
 #pragma unroll
     for (int m = 0; m < kWcMbs; m++) {
-        ok = ok && u[m].cur == u[0].cur && u[m].mb_y == u[0].mb_y && u[m].mb_x == u[0].mb_x + (uint32_t)m;
+        ok = ok && u[m].cur_off256 == u[0].cur_off256 && u[m].mb_y == u[0].mb_y && u[m].mb_x == u[0].mb_x + (uint32_t)m;
         ok = ok && (!(u[m].flags & MPEGHIP_MB_INTRA) || u[m].cbp == 0x3f);
     }
     return ok;

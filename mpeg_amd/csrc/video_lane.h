@@ -40,6 +40,7 @@ struct VideoArgs {
     uint32_t width, height;       // display size (RGBA image)
     uint8_t *rgba;                // base of RGBA images, same (stream, slot) indexing
     uint64_t rgba_stride;
+    const uint32_t *xmbs;         // wave-chunk kernel: 48-byte expanded macroblock records (video_compact_lane.h)
 };
 
 constexpr int kTileStride = 72;               // dwords per 8x8 block in LDS (64 + 8 pad)
@@ -56,6 +57,11 @@ struct MbU {
     const uint8_t *ref;
     const uint8_t *qm;   // 128-byte column table {matrix column, premultiplier column} of this macroblock's class
     uint8_t *rgba;       // RGBA image of the cur slot (or nullptr)
+    // wave-chunk kernel only (from the expanded record): frame byte offsets of the block origins / of the
+    // prediction source, half-pel flags
+    int32_t src_luma, src_chroma, dst_luma, dst_chroma;
+    uint32_t bits;       // kXOhLuma ...
+    uint32_t cur_off256; // byte offset of the destination frame >> 8 (names the frame)
 };
 
 // Descriptors are read-only for the whole launch.  On the device they are read

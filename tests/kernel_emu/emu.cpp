@@ -261,12 +261,20 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
     a.chroma_h = luma_h / 2;
     a.luma_bytes = luma_w * luma_h;
     a.chroma_bytes = a.luma_bytes / 4;
-    // the library's device copy of the descriptors: picture fields filled into the reserved words
-    std::vector<mpeghip_mb_desc> filled(mbs, mbs + n_mbs);
+    // the library's expanded records (built by the host half of the product during validation)
+    XGeom geom;
+    geom.luma_w = a.luma_w;
+    geom.chroma_w = a.chroma_w;
+    geom.frame_stride = frame_stride;
+    geom.rgba_stride = rgba_stride;
+    if (frame_stride % 256 || rgba_stride % 256)
+        abort(); // the records name frames in units of 256 bytes
+    std::vector<uint32_t> xrec((size_t)n_mbs * kXDwords + 16);
     for (uint32_t i = 0; i < n_mbs; i++)
-        fill_pic_fields(pics, filled.data(), i);
+        expand_mb(geom, expand_pic(geom, pics[mbs[i].pic]), mbs[i], xrec.data() + (size_t)i * kXDwords);
     a.pics = pics;
-    a.mbs = filled.data();
+    a.mbs = mbs;
+    a.xmbs = xrec.data();
     a.coefs = coefs;
     a.qmat = qtable;
     a.dump = nullptr;
@@ -295,9 +303,9 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
         for (uint32_t s0 = 0; s0 < ci.base[kWcMbs]; s0 += 8) {
             bool active[64];
             for (int lane = 0; lane < 64; lane++)
-                compact_phase2(a, ci, s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kTileStride, active[lane]);
+                compact_phase2(a, ci, s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kWcTileStride, active[lane]);
             for (int lane = 0; lane < 64; lane++)
-                compact_phase2_rows(s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kTileStride, active[lane], resid);
+                compact_phase2_rows(s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kWcTileStride, active[lane], resid);
         }
         const bool coalesce = wc_can_coalesce(ci, u);
         bool rgba_any = false;
