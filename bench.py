@@ -13,6 +13,7 @@ Prints ONE JSON line (rank 0): metric/value/... plus
   roofline     — algorithmic HBM bytes per launch / average launch time vs 8 TB/s
   cpu_baseline — the CPU oracle (restated reference algorithm) on a bounded sample
   audio        — the MP2 synthesis kernel on 256 stereo streams (BASELINE config 4)
+  rgba_fused   — the same GOP with Frame.RGBA() of every picture fused into the kernel (BASELINE config 3's kernel)
 """
 from __future__ import annotations
 
@@ -44,6 +45,8 @@ def parse_args():
     ap.add_argument("--profile", default="typical", choices=["typical", "dense", "typical_nocoef", "typical_fullpel"],
                     help="typical / dense are the reported workloads; the other two are diagnostics (no residual / no half-pel)")
     ap.add_argument("--rgba", type=int, default=0, help="1: fuse Frame.RGBA into the reconstruction kernel")
+    ap.add_argument("--rgba-streams", type=int, default=512,
+                    help="streams of the secondary fused-RGBA leg (BASELINE config 3's kernel; 0 = skip; N=1 only)")
     ap.add_argument("--audio-streams", type=int, default=256)
     ap.add_argument("--audio-frames", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -206,6 +209,63 @@ def main():
         }
         a.close()
 
+    # ---- fused IDCT + MC + YCbCr->RGBA (BASELINE config 3's kernel), secondary: the same GOP with every picture
+    # flagged MPEGHIP_PIC_RGBA, i.e. Frame.RGBA() of every decoded picture done inside the reconstruction kernel
+    fused = None
+    if args.rgba_streams > 0 and not args.rgba and rank == 0 and world == 1:
+        for b in batches:
+            b.free()
+        batches = []
+        n2 = args.rgba_streams
+        store2 = abi.VideoStore(ctx, args.width, args.height, n2)
+        seq2 = []
+        for s_ in seq:
+            pics = s_.pics.copy()
+            pics["flags"] |= desc.PIC_RGBA
+            seq2.append(pics)
+        b2 = [store2.upload(p_, s_.mbs, s_.coefs, replicate=n2) for p_, s_ in zip(seq2, seq)]
+        ctx.sync()
+        order2 = []
+        for i in range(args.warmup):
+            b2[i % len(b2)].run()
+            order2.append(i % len(b2))
+        ctx.sync()
+        mbs2 = alg2 = 0
+        ctx.timer_start()
+        for i in range(args.warmup, args.warmup + args.steps):
+            b = b2[i % len(b2)]
+            b.run()
+            order2.append(i % len(b2))
+            mbs2 += b.n_mbs
+            alg2 += b.alg_bytes
+        ms2 = ctx.timer_stop_ms()
+        fparity = None
+        if args.check:
+            from oracle import pyoracle
+            ref = pyoracle.OracleStore(args.width, args.height, 1, threads=1)
+            for i in order2:
+                ref.submit(seq2[i], seq[i].mbs, seq[i].coefs)
+            ok = True
+            for slot in range(3):
+                want = ref.read_rgba(0, slot)
+                for st in sorted({0, n2 - 1}):
+                    ok &= bool(np.array_equal(np.asarray(store2.read_rgba(st, slot)).reshape(-1), want.reshape(-1)))
+            ref.close()
+            if not ok:
+                raise SystemExit("bench: fused RGBA images differ from the oracle — result invalid")
+            fparity = "RGBA images bit-exact vs oracle on streams %s x 3 slots after %d pictures" % (sorted({0, n2 - 1}), len(order2))
+        fused = {
+            "metric": "1080p macroblocks/sec, Frame.RGBA() of every picture fused into the reconstruction kernel",
+            "value": mbs2 / (ms2 * 1e-3), "streams": n2, "steps": args.steps, "ms_per_step": ms2 / args.steps,
+            "roofline": {"bound": "hbm", "achieved": alg2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "recon_wc_kernel<4>, pictures flagged MPEGHIP_PIC_RGBA"},
+            "parity": fparity,
+        }
+        for b in b2:
+            b.free()
+        store2.close()
+
     cpu = None
     if args.cpu_seconds > 0 and rank == 0 and world == 1:
         cpu = cpu_baseline(args, seq, geom)
@@ -240,6 +300,7 @@ def main():
                          "avg_launch_ms": launch_ms},
             "cpu_baseline": cpu,
             "audio": audio,
+            "rgba_fused": fused,
             "parity": check,
         }
         print(json.dumps(line))

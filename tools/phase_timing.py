@@ -13,8 +13,16 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 lib = ROOT / "mpeg_amd" / "libmpeghip.so"
+import os
+
+
+def swap_in(src):  # via rename: the library may be mapped by this process, its inode must not be rewritten
+    shutil.copy(src, str(lib) + ".tmp")
+    os.replace(str(lib) + ".tmp", lib)
+
+
 shutil.copy(lib, "/tmp/libmpeghip_keep.so")
-shutil.copy(ROOT / "mpeg_amd" / "libmpeghip_timing.so", lib)
+swap_in(ROOT / "mpeg_amd" / "libmpeghip_timing.so")
 try:
     from mpeg_amd import abi, desc, synth
     profile = sys.argv[1] if len(sys.argv) > 1 else "typical"
@@ -50,4 +58,4 @@ try:
         if m.sum() > 50:
             print("  coded blocks = %2d: %6d waves, phase 2 mean %7.0f, lifetime mean %7.0f" % (nb, m.sum(), d[m, 2].mean(), life[m].mean()))
 finally:
-    shutil.copy("/tmp/libmpeghip_keep.so", lib)
+    swap_in("/tmp/libmpeghip_keep.so")
