@@ -259,7 +259,7 @@ def main():
             "value": mbs2 / (ms2 * 1e-3), "streams": n2, "steps": args.steps, "ms_per_step": ms2 / args.steps,
             "roofline": {"bound": "hbm", "achieved": alg2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "recon_wc_kernel<4>, pictures flagged MPEGHIP_PIC_RGBA"},
+                         "kernel": "recon_wc_kernel<4, true> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"},
             "parity": fparity,
         }
         for b in b2:
@@ -296,7 +296,7 @@ def main():
             "realtime_1080p30_streams": value / MB_PER_1080P30_STREAM,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "recon_wc_kernel<4> (one wave = 4 macroblocks, dense residual stage)", "alg_bytes_per_launch": alg_done // args.steps,
+                         "kernel": "recon_wc_kernel<4, %s> (one wave = 4 macroblocks, dense residual stage)" % ("true" if args.rgba else "false"), "alg_bytes_per_launch": alg_done // args.steps,
                          "avg_launch_ms": launch_ms},
             "cpu_baseline": cpu,
             "audio": audio,

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(kChunkMbs * 64) void recon_compact_kernel(const Vid
 
 // ---- wave-chunk path: one wave = 4 consecutive macroblocks, dense residual stage, no barrier
 // 8 waves per SIMD: 64 VGPRs, and 4 x 5120 bytes of LDS per workgroup let 8 workgroups share a CU
-template <int WAVES>
+// kRgba: the instance for batches with MPEGHIP_PIC_RGBA pictures (Frame.RGBA() fused); the other one carries
+// none of that code
+template <int WAVES, bool kRgba>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_wc_kernel(const VideoArgs a, const uint32_t n_chunks)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kWcLdsBytes];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     MPG_STAMP(0);
     uint32_t n_live;
     WcRaw raw;
-    wc_load_raw(a, chunk, n_live, raw); // one round of scalar loads for the whole chunk
+    wc_load_raw<kRgba>(a, chunk, n_live, raw); // one round of scalar loads for the whole chunk
     const WcInfo ci = wc_info_from_raw(n_live, raw);
     const int g = lane >> 3, j = lane & 7;
     MPG_STAMP(1);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     MbLoads ld[kWcMbs];
 #pragma unroll
     for (int m = 0; m < kWcMbs; m++) {
-        u[m] = wc_mb_from_raw(a, raw.d[m]);
+        u[m] = wc_mb_from_raw<kRgba>(a, raw.d[m]);
         wc_issue_pred(a, u[m], lane, ld[m]);
     }
     MPG_STAMP(2);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     bool rgba = false; // any macroblock of a picture that is colour-converted on the fly (wave-uniform)
 #pragma unroll
     for (int m = 0; m < kWcMbs; m++)
-        rgba = rgba || ((uint32_t)m < ci.n && u[m].rgba != nullptr);
+        rgba = rgba || (kRgba && (uint32_t)m < ci.n && u[m].rgba != nullptr);
     uint8_t *out_tile = (coalesce || rgba) ? reinterpret_cast<uint8_t *>(tile) : nullptr;
     const int below_lane = wc_below_lane(lane);
     const int below_addr = (below_lane < 0 ? lane : below_lane) << 2; // ds_bpermute byte address of the source lane
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         wave_lds_handoff();
         if (coalesce)
             wc_store_tile(a, u[0], lane, out_tile);
-        if (rgba) {
+        if (kRgba && rgba) {
 #pragma unroll
             for (int m = 0; m < kWcMbs; m++)
                 if ((uint32_t)m < ci.n && u[m].rgba != nullptr)
@@ -1031,13 +1033,20 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     if (mode == 6) {
         hipStream_t st = v->ctx->stream;
         const uint32_t n_chunks = (uint32_t)((b->n_mbs + kWcMbs - 1) / kWcMbs);
-        if (waves == 8) {
-            hipLaunchKernelGGL((recon_wc_kernel<8>), dim3((n_chunks + 7) / 8), dim3(512), 0, st, a, n_chunks);
-        } else if (waves == 16) {
-            hipLaunchKernelGGL((recon_wc_kernel<2>), dim3((n_chunks + 1) / 2), dim3(128), 0, st, a, n_chunks);
-        } else {
-            hipLaunchKernelGGL((recon_wc_kernel<4>), dim3((n_chunks + 3) / 4), dim3(256), 0, st, a, n_chunks);
-        }
+#define LAUNCH_WC(W)                                                                                                   \
+    do {                                                                                                               \
+        if (b->any_rgba)                                                                                               \
+            hipLaunchKernelGGL((recon_wc_kernel<W, true>), dim3((n_chunks + W - 1) / W), dim3(W * 64), 0, st, a, n_chunks);  \
+        else                                                                                                           \
+            hipLaunchKernelGGL((recon_wc_kernel<W, false>), dim3((n_chunks + W - 1) / W), dim3(W * 64), 0, st, a, n_chunks); \
+    } while (0)
+        if (waves == 8)
+            LAUNCH_WC(8);
+        else if (waves == 16)
+            LAUNCH_WC(2);
+        else
+            LAUNCH_WC(4);
+#undef LAUNCH_WC
         HIP_TRY(hipGetLastError());
         // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
         // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
@@ -1509,7 +1518,7 @@ int mpeghip_audio_open(mpeghip_ctx *c, uint32_t n_streams, int fma_mode, mpeghip
     if (getenv("MPEGHIP_DEBUG")) { // development aid: resident workgroups per CU of both kernels
         int na = 0, nv = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, audio_kernel<false, MPEGHIP_AUDIO_F32N>, kAudioThreads, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nv, recon_wc_kernel<4>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nv, recon_wc_kernel<4, false>, 256, 0);
         fprintf(stderr, "mpeghip: occupancy audio_kernel %d, recon_wc_kernel<4> %d workgroups per CU\n", na, nv);
     }
     *out = a;

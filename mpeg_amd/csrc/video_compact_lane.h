@@ -364,7 +364,9 @@ struct WcRaw {
     uint32_t d[kWcMbs][11];
 };
 
-// ONE round of scalar loads for the whole chunk
+// ONE round of scalar loads for the whole chunk (kRgba = false: the instance for batches without
+// colour conversion, which neither loads nor keeps anything of the RGBA images)
+template <bool kRgba>
 MPG_HD void wc_load_raw(const VideoArgs &a, uint32_t chunk, uint32_t &n, WcRaw &r)
 {
     const uint32_t first = chunk * kWcMbs;
@@ -374,12 +376,15 @@ MPG_HD void wc_load_raw(const VideoArgs &a, uint32_t chunk, uint32_t &n, WcRaw &
     for (int k = 0; k < kWcMbs; k++) {
         const uint32_t kk = (uint32_t)k < n ? (uint32_t)k : 0u; // past the end of the batch: macroblock 0 again
 #pragma unroll
-        for (int w = 0; w < 11; w++)
+        for (int w = 0; w < (kRgba ? 11 : 10); w++)
             r.d[k][w] = x[kk * kXDwords + w];
+        if (!kRgba)
+            r.d[k][10] = 0;
     }
 }
 
 // the wave-uniform view the phases use (no arithmetic left beyond two 64-bit adds)
+template <bool kRgba>
 MPG_HD MbU wc_mb_from_raw(const VideoArgs &a, const uint32_t (&d)[11])
 {
     MbU u;
@@ -391,12 +396,12 @@ MPG_HD MbU wc_mb_from_raw(const VideoArgs &a, const uint32_t (&d)[11])
     u.mv_x = u.mv_y = 0; // (not used by the wave-chunk phases)
     u.mb_x = d[3] & 0xffff;
     u.mb_y = d[3] >> 16;
-    u.pic_flags = (d[0] & kXRgba) ? MPEGHIP_PIC_RGBA : 0;
+    u.pic_flags = (kRgba && (d[0] & kXRgba)) ? MPEGHIP_PIC_RGBA : 0;
     u.cur_off256 = d[4];
     u.cur = a.frames + ((uint64_t)d[4] << 8);
     u.ref = a.frames + ((uint64_t)d[5] << 8);
     u.qm = a.qmat + d[2];
-    u.rgba = (d[0] & kXRgba) ? a.rgba + ((uint64_t)d[10] << 8) : nullptr;
+    u.rgba = (kRgba && (d[0] & kXRgba)) ? a.rgba + ((uint64_t)d[10] << 8) : nullptr;
     u.src_luma = (int32_t)d[6];
     u.src_chroma = (int32_t)d[7];
     u.dst_luma = (int32_t)d[8];

@@ -267,6 +267,9 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
     geom.chroma_w = a.chroma_w;
     geom.frame_stride = frame_stride;
     geom.rgba_stride = rgba_stride;
+    bool any_rgba = false; // the product picks the kernel instance by this (mpeghip.hip: launch_batch)
+    for (uint32_t p = 0; p < n_pics; p++)
+        any_rgba = any_rgba || (pics[p].flags & MPEGHIP_PIC_RGBA);
     if (frame_stride % 256 || rgba_stride % 256)
         abort(); // the records name frames in units of 256 bytes
     std::vector<uint32_t> xrec((size_t)n_mbs * kXDwords + 16);
@@ -291,12 +294,15 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
         int32_t *tile = reinterpret_cast<int32_t *>(lds + kWcResidBytes);
         uint32_t n_live;
         WcRaw raw;
-        wc_load_raw(a, chunk, n_live, raw);
+        if (any_rgba)
+            wc_load_raw<true>(a, chunk, n_live, raw);
+        else
+            wc_load_raw<false>(a, chunk, n_live, raw);
         const WcInfo ci = wc_info_from_raw(n_live, raw);
         MbU u[kWcMbs];
         static MbLoads ld[kWcMbs][64];
         for (int m = 0; m < kWcMbs; m++) {
-            u[m] = wc_mb_from_raw(a, raw.d[m]);
+            u[m] = any_rgba ? wc_mb_from_raw<true>(a, raw.d[m]) : wc_mb_from_raw<false>(a, raw.d[m]);
             for (int lane = 0; lane < 64; lane++)
                 wc_issue_pred(a, u[m], lane, ld[m][lane]);
         }

@@ -35,7 +35,7 @@ echo "== rocprofv3 PMC (HBM traffic; separate passes)"
 cd /tmp
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $SET | tr ' ' '_' | cut -c1-40)
-  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-seconds 0 --check 0 --audio-streams 0 "$@" > $GRAFT_REPO_ROOT/$OUT/pmc_$N.log 2>&1
+  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-seconds 0 --check 0 --audio-streams 0 --rgba-streams 0 "$@" > $GRAFT_REPO_ROOT/$OUT/pmc_$N.log 2>&1
   echo "pmc [$SET] rc=$?"
 done
 cd $GRAFT_REPO_ROOT
