@@ -122,6 +122,7 @@ def main():
         seq = seq[:1] + [s for s in seq[1:] if s.picture_type == desc.PIC_P]
     store = abi.VideoStore(ctx, args.width, args.height, args.streams)
     batches = [store.upload(s.pics, s.mbs, s.coefs, replicate=args.streams) for s in seq]
+    gop_len = len(batches)
     ctx.sync()
 
     order = []
@@ -289,7 +290,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": "%d independent %dx%d MPEG-1 streams per GPU, one picture each per step, decode-order "
                                    "GOP of %d pictures (%s macroblock mix%s), descriptors resident in HBM" %
-                                   (args.streams, args.width, args.height, len(batches), args.profile,
+                                   (args.streams, args.width, args.height, gop_len, args.profile,
                                     ", fused RGBA" if args.rgba else ""),
                        "streams_per_gpu": args.streams, "macroblocks_per_step_per_gpu": mbs_done // args.steps,
                        "profile": args.profile, "rgba_fused": bool(args.rgba), "sharding": "by stream, no collective"},
