@@ -275,19 +275,28 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     uint8_t *out_tile = (coalesce || rgba) ? reinterpret_cast<uint8_t *>(tile) : nullptr;
     const int below_lane = wc_below_lane(lane);
     const int below_addr = (below_lane < 0 ? lane : below_lane) << 2; // ds_bpermute byte address of the source lane
-#pragma unroll
-    for (int m = 0; m < kWcMbs; m++) {
-        if ((uint32_t)m >= ci.n)
-            continue;
+    auto row_below = [&](int m) { // the row under this lane's row: from the lane that loaded it, or ld.r1
         u8x16 below = ld[m].r1;
-        if (wc_needs_below(u[m])) { // wave-uniform: fetch the row below from the lane that loaded it
+        if (wc_needs_below(u[m])) { // wave-uniform
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(below_addr, (int)ld[m].r0.v[k]);
                 below.v[k] = below_lane < 0 ? below.v[k] : got;
             }
         }
-        wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m], below, resid, out_tile, !coalesce);
+        return below;
+    };
+    if (coalesce) { // the normal case, without the rare paths
+#pragma unroll
+        for (int m = 0; m < kWcMbs; m++)
+            wc_phase3<kWcMbs, true>(a, u[m], ci, (uint32_t)m, lane, ld[m], row_below(m), resid, out_tile, false);
+    } else {
+#pragma unroll
+        for (int m = 0; m < kWcMbs; m++) {
+            if ((uint32_t)m >= ci.n)
+                continue;
+            wc_phase3<kWcMbs, false>(a, u[m], ci, (uint32_t)m, lane, ld[m], row_below(m), resid, out_tile, true);
+        }
     }
     MPG_STAMP(4);
     if (out_tile) {
@@ -960,6 +969,8 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
         if (xrec)
             expand_mb(geom, xpics[m.pic], m, xrec + (size_t)i * kXDwords);
     }
+    if (xrec)
+        mark_chunk_runs(xrec, n_mbs);
     if (alg_bytes)
         *alg_bytes = alg;
     if (dense_partition)

@@ -302,7 +302,8 @@ using WcInfo = ChunkInfoT<kWcMbs>;
 // traffic per macroblock more than the ABI's 32-byte descriptor, which the HBM has to spare.
 constexpr int kXDwords = 12;
 constexpr uint32_t kXOhLuma = 1u << 24, kXOvLuma = 1u << 25, kXOhChroma = 1u << 26, kXOvChroma = 1u << 27,
-                   kXNeedsBelow = 1u << 28, kXRgba = 1u << 29;
+                   kXNeedsBelow = 1u << 28, kXRgba = 1u << 29,
+                   kXRun = 1u << 30; // (first record of a chunk) the chunk is a horizontal run: mark_chunk_runs
 // dword 0: flags | cbp << 8 | qscale << 16 | kX* bits     1: coef_off      2: qtab (byte offset into qmat)
 //       3: mb_x | mb_y << 16     4: cur frame offset >> 8     5: reference frame offset >> 8
 //       6..9: src_luma, src_chroma, dst_luma, dst_chroma (bytes inside the frame)   10: RGBA image offset >> 8
@@ -358,6 +359,25 @@ MPG_HD void expand_mb(const XGeom &g, const XPic &xp, const mpeghip_mb_desc &d, 
     x[10] = xp.rgba256;
     x[11] = 0;
     static_assert(kXDwords == 12, "record layout");
+}
+
+// Is chunk c (records 4c .. 4c+3) a horizontal run of 4 fully written macroblocks of one frame, 64-byte aligned?
+// Then its outputs leave as whole rows (wc_store_tile).  Worked out on the host for every chunk, after all
+// records of the batch are written; kept in the chunk's first record.
+MPG_HD void mark_chunk_runs(uint32_t *xrec, uint32_t n_mbs)
+{
+    for (uint32_t first = 0; first + kWcMbs <= n_mbs; first += kWcMbs) {
+        uint32_t *x0 = xrec + (size_t)first * kXDwords;
+        bool ok = ((x0[3] & 0xffff) & 3) == 0;
+        for (int m = 0; m < kWcMbs && ok; m++) {
+            const uint32_t *x = x0 + m * kXDwords;
+            ok = x[4] == x0[4] && x[3] == x0[3] + (uint32_t)m; // same frame, same row, next column
+            const uint32_t flags = x[0] & 0xff, cbp = (x[0] >> 8) & 0xff;
+            ok = ok && (!(flags & MPEGHIP_MB_INTRA) || cbp == 0x3f); // an invalid intra block keeps old pixels
+        }
+        if (ok)
+            x0[0] |= kXRun;
+    }
 }
 
 struct WcRaw {
@@ -511,7 +531,9 @@ MPG_HD uint32_t wc_tile_offset(int b, int j, uint32_t m)
     return 1024 + (uint32_t)(b - 4) * 256 + (uint32_t)j * 32 + m * 8;
 }
 
-template <int N>
+// kRun: the chunk is a horizontal run (wc_can_coalesce) — every block is written, the outputs go to the tile
+// only; the instance without the rare paths.
+template <int N, bool kRun>
 MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci, uint32_t m, int lane, const MbLoads &ld,
                       const u8x16 &below, const uint8_t *resid_store, uint8_t *out_tile, bool store)
 {
@@ -520,7 +542,7 @@ MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci,
         return;
     const bool intra = (u.flags & MPEGHIP_MB_INTRA) != 0;
     const bool coded = (u.cbp & (0x20u >> b)) != 0;
-    if (intra && !coded) { // an invalid intra block leaves the old pixels (video.go:711-714); never on the coalesced path
+    if (!kRun && intra && !coded) { // an invalid intra block leaves the old pixels (video.go:711-714); never on the coalesced path
         if (out_tile) {
             const WcPredScalars pk = wc_pred_scalars(a, u);
             const int32_t off = wc_lane_row_offset(a, lane) + (b < 4 ? pk.dst_luma : pk.dst_chroma);
@@ -560,9 +582,9 @@ MPG_HD void wc_phase3(const VideoArgs &a, const MbU &u, const ChunkInfoT<N> &ci,
         const uint32_t hi = add_resid_pack4((uint32_t)(pred >> 32), row.v[2], row.v[3]);
         out = (uint64_t)lo | ((uint64_t)hi << 32);
     }
-    if (out_tile)
+    if (kRun || out_tile)
         *reinterpret_cast<uint64_t *>(out_tile + wc_tile_offset(b, j, m)) = out;
-    if (store) {
+    if (!kRun && store) {
         const int32_t off = wc_lane_row_offset(a, lane) + (luma ? ps.dst_luma : ps.dst_chroma);
         *reinterpret_cast<uint64_t *>(u.cur + off) = out;
     }
@@ -587,18 +609,11 @@ MPG_HD void wc_rgba_mb(const VideoArgs &a, const MbU &u, uint32_t m, int lane, c
     rgba_store4<false>(reinterpret_cast<uint32_t *>(u.rgba) + p, p, px, n);
 }
 
-// Is the chunk a horizontal run of 4 fully written macroblocks of one picture, 64-byte aligned?  (wave-uniform)
+// Is the chunk a horizontal run of 4 fully written macroblocks of one picture, 64-byte aligned?  (wave-uniform;
+// decided by the host: mark_chunk_runs)
 MPG_HD bool wc_can_coalesce(const WcInfo &ci, const MbU (&u)[kWcMbs])
 {
-    if (ci.n != (uint32_t)kWcMbs || (u[0].mb_x & 3) != 0)
-        return false;
-    bool ok = true;
-#pragma unroll
-    for (int m = 0; m < kWcMbs; m++) {
-        ok = ok && u[m].cur_off256 == u[0].cur_off256 && u[m].mb_y == u[0].mb_y && u[m].mb_x == u[0].mb_x + (uint32_t)m;
-        ok = ok && (!(u[m].flags & MPEGHIP_MB_INTRA) || u[m].cbp == 0x3f);
-    }
-    return ok;
+    return ci.n == (uint32_t)kWcMbs && (u[0].bits & kXRun) != 0;
 }
 
 // Cooperative store of the chunk's output tile: luma 16 rows x 64 B by all 64 lanes, chroma 2 x 8 rows x 32 B by lanes 0-31.

@@ -275,6 +275,7 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
     std::vector<uint32_t> xrec((size_t)n_mbs * kXDwords + 16);
     for (uint32_t i = 0; i < n_mbs; i++)
         expand_mb(geom, expand_pic(geom, pics[mbs[i].pic]), mbs[i], xrec.data() + (size_t)i * kXDwords);
+    mark_chunk_runs(xrec.data(), n_mbs);
     a.pics = pics;
     a.mbs = mbs;
     a.xmbs = xrec.data();
@@ -329,7 +330,10 @@ int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, ui
                 if (wc_needs_below(u[m]) && bl >= 0) // the kernel's __shfl from the owning lane
                     for (int k = 0; k < 3; k++)
                         below.v[k] = ld[m][bl].r0.v[k];
-                wc_phase3(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile, !coalesce);
+                if (coalesce)
+                    wc_phase3<kWcMbs, true>(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile, false);
+                else
+                    wc_phase3<kWcMbs, false>(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile, true);
             }
         }
         if (coalesce)
