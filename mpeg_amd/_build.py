@@ -61,7 +61,7 @@ def build_libmpeghost(force: bool = False) -> Path:
     if not force and _newer(LIBMPEGHOST, srcs + [LIBMPEGHIP]):
         return LIBMPEGHOST
     build_libmpeghip()
-    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-I", HOST, *cpps,
+    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", "-I", INCLUDE, "-I", HOST, *cpps,
           "-o", LIBMPEGHOST, "-L", LIBMPEGHIP.parent, "-lmpeghip", "-Wl,-rpath,$ORIGIN"])
     return LIBMPEGHOST
 

@@ -6,50 +6,187 @@
 // pictures in the same device call: a second one (first reference picture of a stream, which yields
 // no frame; the re-submit after a duplicated macroblock address in a damaged stream) flushes the batch
 // first — launches are stream ordered, so "last writer in bitstream order" is kept.
+#include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string.h>
+#include <thread>
 
 #include "mpeg.hpp"
 
 namespace mpeg {
 
+// A stream's parser talks to the batch through its Port.  Normally a request acts at once; while the
+// stream is being parsed on a pool thread (`recording`), requests are only recorded — nothing shared is
+// touched — and VideoBatch::DecodeAll replays them on its own thread afterwards.
 class VideoBatch::Port : public VideoBackend {
 public:
+    struct Event {
+        enum Kind { Open, Quant, Submit } kind;
+        int width = 0, height = 0;
+        uint8_t quant[128];
+        mpeghip_pic_desc pic;
+        std::vector<mpeghip_mb_desc> mbs;
+        std::vector<uint8_t> coefs;
+    };
     Port(VideoBatch *b, uint32_t stream) : b_(b), stream_(stream) {}
     void open(int width, int height) override
     {
-        if (b_->width_ == 0) {
-            b_->width_ = width;
-            b_->height_ = height;
-            b_->store_->open(width, height, b_->capacity_);
-        } else if (b_->width_ != width || b_->height_ != height) {
-            throw std::runtime_error("VideoBatch: all streams must have the same picture size");
+        if (recording) {
+            events.emplace_back();
+            events.back().kind = Event::Open;
+            events.back().width = width;
+            events.back().height = height;
+            return;
         }
+        b_->openStore(width, height);
     }
     void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override
     {
+        if (recording) {
+            events.emplace_back();
+            events.back().kind = Event::Quant;
+            memcpy(events.back().quant, intra, 64);
+            memcpy(events.back().quant + 64, non_intra, 64);
+            return;
+        }
         b_->Flush(); // the table belongs to pictures not yet queued
         b_->store_->setQuant(stream_, intra, non_intra);
     }
     void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
                 size_t coef_bytes) override
     {
+        if (recording) {
+            events.emplace_back();
+            Event &e = events.back();
+            e.kind = Event::Submit;
+            e.pic = pic;
+            e.mbs.assign(mbs, mbs + n_mbs);
+            e.coefs.assign(coefs, coefs + coef_bytes);
+            return;
+        }
         b_->queue(stream_, pic, mbs, n_mbs, coefs, coef_bytes);
     }
     void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
+        if (recording)
+            throw std::logic_error("VideoBatch: frame read during a parallel parse");
         b_->Flush();
         b_->store_->readPlanes(stream_, slot, y, cb, cr);
     }
     void readRGBA(uint32_t slot, uint8_t *dst) override
     {
+        if (recording)
+            throw std::logic_error("VideoBatch: frame read during a parallel parse");
         b_->Flush();
         b_->store_->readRGBA(stream_, slot, dst);
     }
+    void replay(const Event &e) // on the batch's thread
+    {
+        switch (e.kind) {
+        case Event::Open: b_->openStore(e.width, e.height); break;
+        case Event::Quant:
+            b_->Flush();
+            b_->store_->setQuant(stream_, e.quant, e.quant + 64);
+            break;
+        case Event::Submit:
+            b_->queue(stream_, e.pic, e.mbs.data(), (uint32_t)e.mbs.size(), e.coefs.data(), e.coefs.size());
+            break;
+        }
+    }
+    bool recording = false;
+    std::vector<Event> events;
 
 private:
     VideoBatch *b_;
     uint32_t stream_;
+};
+
+// n - 1 parked threads + the caller share the items of one run() at a time.
+class VideoBatch::Pool {
+public:
+    explicit Pool(unsigned n)
+    {
+        for (unsigned i = 1; i < n; i++)
+            workers_.emplace_back([this] { work(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread &t : workers_)
+            t.join();
+    }
+    // fn(k) for k in [0, n), each exactly once; returns when all are done; the first exception is rethrown
+    void run(size_t n, const std::function<void(size_t)> &fn)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            busy_ = workers_.size();
+            error_ = nullptr;
+            generation_++;
+        }
+        wake_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> l(m_);
+        idle_.wait(l, [this] { return busy_ == 0; });
+        fn_ = nullptr;
+        if (error_)
+            std::rethrow_exception(error_);
+    }
+
+private:
+    void drain()
+    {
+        for (;;) {
+            const size_t k = next_.fetch_add(1);
+            if (k >= n_)
+                return;
+            try {
+                (*fn_)(k);
+            } catch (...) {
+                std::lock_guard<std::mutex> l(m_);
+                if (!error_)
+                    error_ = std::current_exception();
+            }
+        }
+    }
+    void work()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                wake_.wait(l, [&] { return stop_ || generation_ != seen; });
+                if (stop_)
+                    return;
+                seen = generation_;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                busy_--;
+            }
+            idle_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, idle_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_ = 0, busy_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+    std::exception_ptr error_;
 };
 
 VideoBatch::VideoBatch(Device *dev, uint32_t n_streams) : VideoBatch(dev->newBatchStore(), n_streams) {}
@@ -63,12 +200,34 @@ VideoBatch::VideoBatch(std::unique_ptr<BatchStore> store, uint32_t n_streams) : 
 
 VideoBatch::~VideoBatch() {}
 
+void VideoBatch::SetThreads(unsigned n)
+{
+    n = n < 1 ? 1 : n;
+    if (n == threads_)
+        return;
+    pool_.reset(n > 1 ? new Pool(n) : nullptr);
+    threads_ = n;
+}
+
+void VideoBatch::openStore(int width, int height)
+{
+    if (width_ == 0) {
+        width_ = width;
+        height_ = height;
+        store_->open(width, height, capacity_);
+    } else if (width_ != width || height_ != height) {
+        throw std::runtime_error("VideoBatch: all streams must have the same picture size");
+    }
+}
+
 Video *VideoBatch::AddStream(Buffer *buf)
 {
     if (videos_.size() >= capacity_)
         throw std::runtime_error("VideoBatch: more streams than the batch was opened for");
     const uint32_t idx = (uint32_t)videos_.size();
-    videos_.emplace_back(new Video(buf, std::unique_ptr<VideoBackend>(new Port(this, idx))));
+    Port *port = new Port(this, idx);
+    ports_.push_back(port);
+    videos_.emplace_back(new Video(buf, std::unique_ptr<VideoBackend>(port)));
     return videos_.back().get();
 }
 
@@ -119,13 +278,54 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
     std::vector<uint32_t> todo(n);
     for (size_t i = 0; i < n; i++)
         todo[i] = (uint32_t)i;
+    std::vector<int> result(n, 0);
     while (!todo.empty()) {
         std::vector<uint32_t> again;
+        if (pool_ && todo.size() > 1) {
+            // parse on the pool, every stream recording its own device requests ...
+            for (uint32_t i : todo)
+                ports_[i]->recording = true;
+            std::exception_ptr failed;
+            try {
+                pool_->run(todo.size(), [&](size_t k) {
+                    const uint32_t i = todo[k];
+                    result[i] = videos_[i]->DecodeStep(&slot[i], &time[i]);
+                });
+            } catch (...) {
+                failed = std::current_exception();
+            }
+            for (uint32_t i : todo)
+                ports_[i]->recording = false;
+            if (failed) {
+                for (uint32_t i : todo)
+                    ports_[i]->events.clear();
+                std::rethrow_exception(failed);
+            }
+            // ... then replay them here: the k-th request of every stream, in stream order (requests of
+            // different streams commute; queue() keeps two pictures of one stream in separate calls)
+            size_t most = 0;
+            for (uint32_t i : todo)
+                most = ports_[i]->events.size() > most ? ports_[i]->events.size() : most;
+            try {
+                for (size_t k = 0; k < most; k++)
+                    for (uint32_t i : todo)
+                        if (k < ports_[i]->events.size())
+                            ports_[i]->replay(ports_[i]->events[k]);
+            } catch (...) {
+                for (uint32_t i : todo)
+                    ports_[i]->events.clear();
+                throw;
+            }
+            for (uint32_t i : todo)
+                ports_[i]->events.clear();
+        } else {
+            for (uint32_t i : todo)
+                result[i] = videos_[i]->DecodeStep(&slot[i], &time[i]);
+        }
         for (uint32_t i : todo) {
-            const int r = videos_[i]->DecodeStep(&slot[i], &time[i]);
-            if (r == 1)
+            if (result[i] == 1)
                 got[i] = 1;
-            else if (r == 2)
+            else if (result[i] == 2)
                 again.push_back(i);
         }
         Flush();

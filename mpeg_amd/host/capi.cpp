@@ -335,6 +335,14 @@ int mpeghost_batch_decode_all(void *hv, int fetch)
         return (int)h->batch->DecodeAll(h->frames, fetch != 0);
     }, -1);
 }
+// host threads of the parse (VideoBatch::SetThreads)
+void mpeghost_batch_set_threads(void *hv, uint32_t n)
+{
+    guard([&]() -> int {
+        static_cast<BatchHandle *>(hv)->batch->SetThreads(n);
+        return 0;
+    }, -1);
+}
 // frame of stream i from the last decode_all: 1 and *out filled, or 0
 int mpeghost_batch_frame(void *hv, uint32_t stream, mpeghost_frame *out)
 {

@@ -285,6 +285,13 @@ public:
     // frames[i] = the next frame of stream i, or nullptr (ended / no frame yet).  With fetch = false the
     // planes stay on the device (frames[i]->Y.Data is stale): for consumers that read RGBA / planes there.
     size_t DecodeAll(std::vector<Frame *> &frames, bool fetch = true);
+    // Parse with n host threads (default 1).  The bitstream parse is the serial part of a stream but streams
+    // are independent: with n > 1 every round of DecodeAll parses its streams on a pool of n threads (each
+    // stream's device requests are recorded privately), then replays the recorded requests in stream order on
+    // the calling thread — the device sees an equivalent sequence of calls (same pictures, same order per stream).  Load callbacks of different
+    // streams' Buffers may then run concurrently.
+    void SetThreads(unsigned n);
+    unsigned Threads() const { return threads_; }
     void Flush();                                  // submit whatever is queued
     uint64_t DeviceSubmits() const { return device_submits_; }
     uint64_t QueuedPictures() const { return queued_pictures_; }
@@ -292,9 +299,14 @@ public:
 private:
     class Port;
     friend class Port;
+    class Pool;
     void queue(uint32_t stream, const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
                size_t coef_bytes);
+    void openStore(int width, int height);
     std::unique_ptr<BatchStore> store_;
+    std::vector<Port *> ports_;                    // (owned by the Videos)
+    std::unique_ptr<Pool> pool_;
+    unsigned threads_ = 1;
     uint32_t capacity_;
     int width_ = 0, height_ = 0;
     std::vector<std::unique_ptr<Video>> videos_;

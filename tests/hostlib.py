@@ -58,7 +58,7 @@ def host():
             "mpeghost_mpeg_seek_frame": (C.c_int, [P, C.c_double, C.c_int, C.POINTER(HostFrame)]),
             "mpeghost_batch_open": (P, [P, C.c_uint32]), "mpeghost_batch_open_store": (P, [P, C.c_uint32]),
             "mpeghost_batch_close": (None, [P]), "mpeghost_batch_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
-            "mpeghost_batch_decode_all": (C.c_int, [P, C.c_int]),
+            "mpeghost_batch_decode_all": (C.c_int, [P, C.c_int]), "mpeghost_batch_set_threads": (None, [P, C.c_uint32]),
             "mpeghost_batch_frame": (C.c_int, [P, C.c_uint32, C.POINTER(HostFrame)]),
             "mpeghost_batch_counters": (None, [P, C.POINTER(C.c_uint64 * 2)]),
             "mpeghost_audio_batch_open": (P, [P, C.c_uint32, C.c_int, C.c_int]),
@@ -316,7 +316,7 @@ class HostMpeg:
 class HostBatch:
     """mpeg::VideoBatch: n elementary streams of one picture size, one device call per decode_all()."""
 
-    def __init__(self, n_streams: int, device=None):
+    def __init__(self, n_streams: int, device=None, threads: int = 1):
         L = host()
         if device is not None:
             self.h = L.mpeghost_batch_open(device, n_streams)
@@ -324,6 +324,8 @@ class HostBatch:
             self.h = L.mpeghost_batch_open_store(host_emu().host_emu_batch_store(), n_streams)
         if not self.h:
             raise RuntimeError(L.mpeghost_last_error().decode())
+        if threads > 1:
+            L.mpeghost_batch_set_threads(self.h, threads)
         self._keep = []
 
     def add_stream(self, data: bytes) -> int:

@@ -134,6 +134,9 @@ def test_video_batch_on_gpu(oracle, golden_dir, device):
     assert h == [DAMAGED if s is es else CLEAN for s in streams]
     assert n == [260 if s is es else 278 for s in streams]
     assert c["device_submits"] < c["queued_pictures"] / 4
+    # the same with the streams parsed on 4 host threads (VideoBatch::SetThreads)
+    h4, n4, c4 = run_batch(oracle, streams, [0, 0, 1, 5, 9, 2, 2, 3], device=device, threads=4)
+    assert (h4, n4) == (h, n) and c4["device_submits"] <= c["device_submits"]
 
 
 def test_audio_batch_on_gpu(oracle, device):

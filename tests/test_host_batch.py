@@ -11,9 +11,9 @@ VIDEO_HASH = 0xea6d7fcb1340ba3f       # testdata/test.mpeg1video, damaged stream
 TESTMPG_VIDEO_HASH = 0xd00818edcafdc702
 
 
-def run_batch(oracle, streams, delays, device=None):
+def run_batch(oracle, streams, delays, device=None, threads=1):
     """streams[i] joins the batch after delays[i] ticks; returns per-stream (hash, frames) + counters."""
-    b = hostlib.HostBatch(len(streams), device=device)
+    b = hostlib.HostBatch(len(streams), device=device, threads=threads)
     h = [oracle.FNV_OFFSET] * len(streams)
     n = [0] * len(streams)
     added, tick = 0, 0
@@ -56,6 +56,23 @@ def test_staggered_and_mixed_streams(oracle, golden_dir):
     h, n, c = run_batch(oracle, streams, [0, 0, 1, 5, 9])
     assert h == [VIDEO_HASH, TESTMPG_VIDEO_HASH, VIDEO_HASH, VIDEO_HASH, TESTMPG_VIDEO_HASH]
     assert n == [260, 278, 260, 260, 278]
+
+
+@pytest.mark.parametrize("threads", [2, 5])
+def test_threaded_parse_gives_the_same_frames_and_device_calls(oracle, golden_dir, threads):
+    """VideoBatch::SetThreads: streams parsed on a pool, their device requests recorded and replayed in stream
+    order — same frames; no more device calls than with one thread (replaying the k-th request of every
+    stream together groups re-submits of damaged streams better than stream-after-stream does)."""
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    clean = oracle.ps_extract((golden_dir / "test.mpg").read_bytes(), 0xE0)[0]
+    streams = [es, clean, es, es, clean, es, es]
+    delays = [0, 0, 1, 5, 9, 0, 2]
+    h1, n1, c1 = run_batch(oracle, streams, delays)
+    h, n, c = run_batch(oracle, streams, delays, threads=threads)
+    want = {id(es): (VIDEO_HASH, 260), id(clean): (TESTMPG_VIDEO_HASH, 278)}
+    assert h == [want[id(s)][0] for s in streams] and n == [want[id(s)][1] for s in streams]
+    assert (h, n) == (h1, n1) and c["queued_pictures"] == c1["queued_pictures"]
+    assert c["device_submits"] <= c1["device_submits"]
 
 
 def test_different_picture_sizes_are_refused(oracle, golden_dir):

@@ -88,8 +88,11 @@ def main():
     print("config 1, CPU oracle (C restatement of the reference, 1 thread): %d pictures in %.1f ms = %.0f pictures/s" % (n, best * 1e3, n / best))
     # the same file as N lockstep streams through mpeg::VideoBatch: one device call per tick
     es = pyoracle.ps_extract(ps, 0xE0)[0]
-    for n_streams, fetch in ((64, True), (64, False), (512, False)):
-        b = hostlib.HostBatch(n_streams, device=dev)
+    import os
+    many = min(32, os.cpu_count() or 1)
+    for n_streams, fetch, threads in ((64, True, 1), (64, False, 1), (512, False, 1), (512, False, 8), (512, False, many),
+                                      (2048, False, many)):
+        b = hostlib.HostBatch(n_streams, device=dev, threads=threads)
         for _ in range(n_streams):
             b.add_stream(es)
         t0, frames = time.perf_counter(), 0
@@ -101,8 +104,8 @@ def main():
         dt = time.perf_counter() - t0
         c = b.counters()
         b.close()
-        print("config 1 x %d streams, VideoBatch (%s): %d pictures in %.1f ms = %.0f pictures/s, %d device calls for %d pictures"
-              % (n_streams, "frames read back" if fetch else "frames stay on the device", frames, dt * 1e3, frames / dt,
+        print("config 1 x %d streams, VideoBatch, %d parse thread(s) (%s): %d pictures in %.1f ms = %.0f pictures/s, %d device calls for %d pictures"
+              % (n_streams, threads, "frames read back" if fetch else "frames stay on the device", frames, dt * 1e3, frames / dt,
                  c["device_submits"], c["queued_pictures"]))
     hostlib.host().mpeghost_device_destroy(dev)
 
