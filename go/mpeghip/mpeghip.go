@@ -51,6 +51,9 @@ const (
 	PicRGBA   = C.MPEGHIP_PIC_RGBA
 )
 
+// lastError: mpeghip_last_error is per OS thread; goroutines that call into the library keep theirs with
+// runtime.LockOSThread (the one that owns a Context does so anyway: a HIP context is bound to its thread's
+// device selection), otherwise the text may belong to another call — the code is always right.
 func lastError(rc C.int) error {
 	if rc == C.MPEGHIP_OK {
 		return nil
@@ -167,6 +170,48 @@ func (v *Video) SubmitBatch(pics []PicDesc, mbs []MbDesc, coefs []byte) error {
 	}
 	return lastError(C.mpeghip_video_submit(v.h, (*C.mpeghip_pic_desc)(unsafe.Pointer(&pics[0])), C.uint32_t(len(pics)),
 		(*C.mpeghip_mb_desc)(mp), C.uint32_t(len(mbs)), cp, C.size_t(len(coefs))))
+}
+
+// Stage is one submit assembled picture by picture; Put may be called from several goroutines for
+// distinct i (one parser goroutine per stream), Commit from the goroutine that owns the context.
+type Stage struct{ h *C.mpeghip_stage }
+
+// StageBegin reserves room for len(nMbs) pictures of the given sizes in the next pinned staging buffer.
+func (v *Video) StageBegin(nMbs []uint32, coefBytes []uint64) (*Stage, error) {
+	s := &Stage{}
+	if len(nMbs) == 0 || len(nMbs) != len(coefBytes) {
+		return nil, errors.New("mpeghip: StageBegin: nMbs and coefBytes must have the same, non-zero length")
+	}
+	sizes := make([]C.size_t, len(coefBytes))
+	for i, b := range coefBytes {
+		sizes[i] = C.size_t(b)
+	}
+	if err := lastError(C.mpeghip_video_stage_begin(v.h, C.uint32_t(len(nMbs)), (*C.uint32_t)(unsafe.Pointer(&nMbs[0])),
+		&sizes[0], &s.h)); err != nil {
+		return nil, err
+	}
+	return s, nil
+}
+
+// Put validates picture i and writes it into the staging buffer (mbs[].Pic is ignored, CoefOff is relative
+// to coefs).  The slices are not retained.
+func (s *Stage) Put(i int, pic *PicDesc, mbs []MbDesc, coefs []byte) error {
+	var mp, cp unsafe.Pointer
+	if len(mbs) > 0 {
+		mp = unsafe.Pointer(&mbs[0])
+	}
+	if len(coefs) > 0 {
+		cp = unsafe.Pointer(&coefs[0])
+	}
+	return lastError(C.mpeghip_video_stage_put(s.h, C.uint32_t(i), (*C.mpeghip_pic_desc)(unsafe.Pointer(pic)),
+		(*C.mpeghip_mb_desc)(mp), cp))
+}
+
+// Commit sends the staged pictures and reconstructs them (asynchronous, like Submit); the Stage is over.
+func (s *Stage) Commit() error {
+	h := s.h
+	s.h = nil
+	return lastError(C.mpeghip_video_stage_commit(h))
 }
 
 func (v *Video) ReadPlanesOf(stream, slot int, y, cb, cr []byte) error {

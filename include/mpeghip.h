@@ -195,6 +195,21 @@ int mpeghip_video_submit(mpeghip_video *v,
                          const mpeghip_mb_desc *mbs, uint32_t n_mbs,
                          const void *coefs, size_t coef_bytes);
 
+/* The same submit, staged picture by picture from several host threads (the many-stream emitter:
+ * one parser thread per stream, mpeg_amd/host/batch.cpp).  `begin` reserves room for n_pics pictures of
+ * the given sizes in the next pinned staging buffer; `put` validates picture i and writes it there —
+ * thread-safe for distinct i, no device access, mbs[].pic is ignored (all belong to picture i), coef_off is
+ * relative to the picture's own `coefs`; `commit` (the thread that owns the context) sends the buffer and
+ * reconstructs, asynchronous like mpeghip_video_submit, and ends the stage.  A failed `put` makes `commit`
+ * fail with that error and launch nothing.  One stage per video at a time; no other submit in between.
+ * The rules of mpeghip_video_submit about overlapping macroblocks and dependent pictures apply. */
+typedef struct mpeghip_stage mpeghip_stage;
+int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
+                              mpeghip_stage **out);
+int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic,
+                            const mpeghip_mb_desc *mbs, const void *coefs);
+int mpeghip_video_stage_commit(mpeghip_stage *s);
+
 /* Device-resident batches: validate + upload once, replay many times
  * (synthetic benchmark batches; a real decoder double-buffers two). */
 int  mpeghip_video_batch_upload(mpeghip_video *v,

@@ -48,6 +48,9 @@ SYMBOLS = {
     "mpeghip_video_info_get": (C.c_int, [_P, C.POINTER(VideoInfo)]),
     "mpeghip_video_set_quant": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "mpeghip_video_submit": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t]),
+    "mpeghip_video_stage_begin": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_void_p)]),
+    "mpeghip_video_stage_put": (C.c_int, [_P, C.c_uint32, _P, _P, _P]),
+    "mpeghip_video_stage_commit": (C.c_int, [_P]),
     "mpeghip_video_batch_upload": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.POINTER(_P)]),
     "mpeghip_video_batch_upload_replicated": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     "mpeghip_video_batch_run": (C.c_int, [_P, _P]),
@@ -174,6 +177,33 @@ class VideoStore:
     def submit(self, pics, mbs, coefs):
         pics, mbs, coefs = self._args(pics, mbs, coefs)
         _check(self.lib.mpeghip_video_submit(self.h, _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs), coefs.nbytes))
+
+    def submit_staged(self, pictures, threads: int = 1):
+        """One submit assembled picture by picture (mpeghip_video_stage_*): pictures = [(pic, mbs, coefs)], each
+        with coef_off relative to its own coefs; the puts run on `threads` host threads."""
+        parts = []
+        for pic, mbs, coefs in pictures:
+            p, m, c = self._args(np.asarray(pic).reshape(1), mbs, coefs)
+            parts.append((p, m, c))
+        n_mbs = np.array([len(m) for _, m, _ in parts], np.uint32)
+        nbytes = np.array([c.nbytes for _, _, c in parts], np.uint64)  # size_t
+        st = C.c_void_p()
+        _check(self.lib.mpeghip_video_stage_begin(self.h, len(parts), _ptr(n_mbs), _ptr(nbytes), C.byref(st)))
+        rcs = [0] * len(parts)
+
+        def put(i):
+            p, m, c = parts[i]
+            rcs[i] = self.lib.mpeghip_video_stage_put(st, i, _ptr(p), _ptr(m), _ptr(c))
+
+        if threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(put, range(len(parts))))
+        else:
+            for i in range(len(parts)):
+                put(i)
+        _check(self.lib.mpeghip_video_stage_commit(st))  # reports the first failed put, launches nothing then
+        return rcs
 
     def upload(self, pics, mbs, coefs, replicate: int = 1) -> Batch:
         pics, mbs, coefs = self._args(pics, mbs, coefs)

@@ -12,7 +12,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <memory>
 #include <new>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "audio_lane.h"
@@ -562,6 +566,23 @@ struct mpeghip_video {
         bool in_flight = false;
     } staging[2];
     int next_staging = 0;
+    struct mpeghip_stage *stage = nullptr; // the open mpeghip_video_stage_begin, if any
+};
+
+// mpeghip_video_stage_*: one submit assembled in a staging buffer by several host threads
+struct mpeghip_stage {
+    mpeghip_video *v = nullptr;
+    mpeghip_video::Staging *sg = nullptr;
+    uint32_t n_pics = 0, n_mbs = 0;
+    uint64_t coef_units = 0;
+    std::vector<uint32_t> mb_first, mb_count;   // per picture: its records [mb_first, mb_first + mb_count)
+    std::vector<uint64_t> unit_first, units;    // per picture: its coefficient units
+    std::vector<uint64_t> alg;                  // per picture, written by its put
+    std::vector<uint8_t> done;                  // per picture: put succeeded
+    size_t x_at = 0, coef_at = 0;
+    std::atomic<int> error{MPEGHIP_OK};         // first failed put
+    std::mutex error_lock;
+    std::string error_text;
 };
 
 struct mpeghip_audio {
@@ -822,6 +843,8 @@ void mpeghip_video_close(mpeghip_video *v)
         return;
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
+    delete v->stage; // a stage that was begun and never committed
+    v->stage = nullptr;
     for (auto &sg : v->staging) {
         batch_release(&sg.batch);
         if (sg.h)
@@ -882,6 +905,71 @@ static bool wants_rgba(const mpeghip_pic_desc *pics, uint32_t n_pics);
 static uint64_t rgba_stride_of(const mpeghip_video *v) { return align_up(v->info.rgba_bytes, 256); }
 
 // Host-side validation of one submit; also totals the algorithmic bytes.
+static int validate_pic(const mpeghip_video_info &in, const mpeghip_pic_desc &pd, uint32_t p)
+{
+    if (pd.stream >= in.n_streams || pd.cur >= MPEGHIP_SLOTS || pd.fwd >= MPEGHIP_SLOTS || pd.bwd >= MPEGHIP_SLOTS)
+        return fail(MPEGHIP_ERR_INVALID, "picture %u: bad stream/slot", p);
+    return MPEGHIP_OK;
+}
+
+// One macroblock of picture `pd`: field ranges, coefficient extent inside [0, coef_units), prediction
+// reads inside the frame buffer.  *units = coefficient units it owns; adds its algorithmic bytes to *alg.
+static int validate_mb(const mpeghip_video_info &in, const mpeghip_pic_desc &pd, const mpeghip_mb_desc &m, uint32_t i,
+                       uint64_t coef_units, uint64_t *units_out, uint64_t *alg)
+{
+    if (m.mb_x >= in.mb_w || m.mb_y >= in.mb_h)
+        return fail(MPEGHIP_ERR_INVALID, "macroblock %u: position (%u,%u) outside %ux%u", i, m.mb_x, m.mb_y, in.mb_w,
+                    in.mb_h);
+    const bool intra = m.flags & MPEGHIP_MB_INTRA;
+    const uint32_t nref = ((m.flags & MPEGHIP_MB_REF_FWD) ? 1 : 0) + ((m.flags & MPEGHIP_MB_REF_BWD) ? 1 : 0);
+    if ((intra && nref != 0) || (!intra && nref != 1))
+        return fail(MPEGHIP_ERR_INVALID, "macroblock %u: flags 0x%x name %u references", i, m.flags, nref);
+    if (m.cbp > 0x3f)
+        return fail(MPEGHIP_ERR_INVALID, "macroblock %u: cbp 0x%x", i, m.cbp);
+    const uint32_t nb = (uint32_t)__builtin_popcount(m.cbp);
+    const bool raw = m.flags & MPEGHIP_MB_COEF_RAW;
+    const uint64_t units = (uint64_t)nb * (raw ? 2 : 1);
+    if (nb && (uint64_t)m.coef_off + units > coef_units)
+        return fail(MPEGHIP_ERR_INVALID, "macroblock %u: coefficient blocks beyond the buffer", i);
+    if (!raw && nb && (m.qscale == 0 || m.qscale > 31))
+        return fail(MPEGHIP_ERR_INVALID, "macroblock %u: quantiser_scale %u", i, m.qscale);
+    uint64_t ref_bytes = 0;
+    if (!intra) {
+        // extents of the reference's copyBlock reads (video_noasm.go:48-80): Go
+        // indexes src[:cap(src)], i.e. [plane start, end of base); anything else panics.
+        const int64_t cap_y = (int64_t)in.frame_bytes;
+        const int64_t cap_c0 = (int64_t)(in.frame_bytes - in.luma_bytes);
+        const int64_t cap_c1 = (int64_t)(in.frame_bytes - in.luma_bytes - in.chroma_bytes);
+        const int mh = m.mv_x, mv = m.mv_y;
+        const int64_t lsi = ((int64_t)(m.mb_y << 4) + (mv >> 1)) * in.luma_w + (m.mb_x << 4) + (mh >> 1);
+        const int loh = mh & 1, lov = mv & 1;
+        const int64_t llast = lsi + (int64_t)(15 + lov) * in.luma_w + 15 + loh;
+        const int cmh = mh / 2, cmv = mv / 2;
+        const int64_t csi = ((int64_t)(m.mb_y << 3) + (cmv >> 1)) * in.chroma_w + (m.mb_x << 3) + (cmh >> 1);
+        const int coh = cmh & 1, cov = cmv & 1;
+        const int64_t clast = csi + (int64_t)(7 + cov) * in.chroma_w + 7 + coh;
+        if (lsi < 0 || llast >= cap_y || csi < 0 || clast >= cap_c1 || clast >= cap_c0)
+            return fail(MPEGHIP_ERR_RANGE, "macroblock %u at (%u,%u): motion vector (%d,%d) reads outside the frame buffer",
+                        i, m.mb_x, m.mb_y, mh, mv);
+        ref_bytes = (uint64_t)(16 + lov) * (16 + loh) + 2ull * (8 + cov) * (8 + coh);
+    }
+    *units_out = units;
+    *alg += 32 + units * MPEGHIP_COEF_UNIT + ref_bytes + (intra ? 64ull * nb : 384);
+    if (pd.flags & MPEGHIP_PIC_RGBA)
+        *alg += 1024;
+    return MPEGHIP_OK;
+}
+
+static XGeom record_geometry(const mpeghip_video *v)
+{
+    XGeom geom;
+    geom.luma_w = v->info.luma_w;
+    geom.chroma_w = v->info.chroma_w;
+    geom.frame_stride = v->info.frame_stride;
+    geom.rgba_stride = rgba_stride_of(v);
+    return geom;
+}
+
 static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
                     const mpeghip_mb_desc *mbs, uint32_t n_mbs, size_t coef_bytes, uint64_t *alg_bytes,
                     bool *dense_partition, uint32_t *xrec = nullptr)
@@ -889,11 +977,7 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
     // xrec != NULL: also write each macroblock's expanded record (video_compact_lane.h: expand_mb) — the same
     // pass has just checked every field the record is computed from
     const mpeghip_video_info &in = v->info;
-    XGeom geom;
-    geom.luma_w = in.luma_w;
-    geom.chroma_w = in.chroma_w;
-    geom.frame_stride = in.frame_stride;
-    geom.rgba_stride = rgba_stride_of(v);
+    const XGeom geom = record_geometry(v);
     std::vector<XPic> xpics;
     if (n_pics && !pics)
         return fail(MPEGHIP_ERR_INVALID, "pics is NULL");
@@ -902,10 +986,10 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
     if (coef_bytes % MPEGHIP_COEF_UNIT)
         return fail(MPEGHIP_ERR_INVALID, "coef_bytes %zu is not a multiple of 128", coef_bytes);
     for (uint32_t p = 0; p < n_pics; p++) {
-        const mpeghip_pic_desc &pd = pics[p];
-        if (pd.stream >= in.n_streams || pd.cur >= MPEGHIP_SLOTS || pd.fwd >= MPEGHIP_SLOTS || pd.bwd >= MPEGHIP_SLOTS)
-            return fail(MPEGHIP_ERR_INVALID, "picture %u: bad stream/slot", p);
-        if ((uint64_t)pd.mb_first + pd.mb_count > n_mbs)
+        const int rc = validate_pic(in, pics[p], p);
+        if (rc != MPEGHIP_OK)
+            return rc;
+        if ((uint64_t)pics[p].mb_first + pics[p].mb_count > n_mbs)
             return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock range out of bounds", p);
     }
     if (xrec) {
@@ -913,9 +997,6 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
         for (uint32_t p = 0; p < n_pics; p++)
             xpics[p] = expand_pic(geom, pics[p]);
     }
-    const int64_t cap_y = (int64_t)in.frame_bytes;
-    const int64_t cap_c0 = (int64_t)(in.frame_bytes - in.luma_bytes);
-    const int64_t cap_c1 = (int64_t)(in.frame_bytes - in.luma_bytes - in.chroma_bytes);
     uint64_t alg = 0;
     const uint64_t coef_units = coef_bytes / MPEGHIP_COEF_UNIT;
     uint64_t next_unit = 0;
@@ -924,48 +1005,15 @@ static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32
         const mpeghip_mb_desc &m = mbs[i];
         if (m.pic >= n_pics)
             return fail(MPEGHIP_ERR_INVALID, "macroblock %u: picture index %u out of range", i, m.pic);
-        if (m.mb_x >= in.mb_w || m.mb_y >= in.mb_h)
-            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: position (%u,%u) outside %ux%u", i, m.mb_x, m.mb_y,
-                        in.mb_w, in.mb_h);
-        const bool intra = m.flags & MPEGHIP_MB_INTRA;
-        const uint32_t nref = ((m.flags & MPEGHIP_MB_REF_FWD) ? 1 : 0) + ((m.flags & MPEGHIP_MB_REF_BWD) ? 1 : 0);
-        if ((intra && nref != 0) || (!intra && nref != 1))
-            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: flags 0x%x name %u references", i, m.flags, nref);
-        if (m.cbp > 0x3f)
-            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: cbp 0x%x", i, m.cbp);
-        const uint32_t nb = (uint32_t)__builtin_popcount(m.cbp);
-        const bool raw = m.flags & MPEGHIP_MB_COEF_RAW;
-        const uint64_t units = (uint64_t)nb * (raw ? 2 : 1);
-        if (nb && (uint64_t)m.coef_off + units > coef_units)
-            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: coefficient blocks beyond the buffer", i);
-        if (!raw && nb && (m.qscale == 0 || m.qscale > 31))
-            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: quantiser_scale %u", i, m.qscale);
-        if (nb) {
+        uint64_t units = 0;
+        const int rc = validate_mb(in, pics[m.pic], m, i, coef_units, &units, &alg);
+        if (rc != MPEGHIP_OK)
+            return rc;
+        if (units) {
             if (m.coef_off != next_unit)
                 dense = false;
             next_unit = (uint64_t)m.coef_off + units;
         }
-        uint64_t ref_bytes = 0;
-        if (!intra) {
-            // extents of the reference's copyBlock reads (video_noasm.go:48-80): Go
-            // indexes src[:cap(src)], i.e. [plane start, end of base); anything else panics.
-            const int mh = m.mv_x, mv = m.mv_y;
-            const int64_t lsi = ((int64_t)(m.mb_y << 4) + (mv >> 1)) * in.luma_w + (m.mb_x << 4) + (mh >> 1);
-            const int loh = mh & 1, lov = mv & 1;
-            const int64_t llast = lsi + (int64_t)(15 + lov) * in.luma_w + 15 + loh;
-            const int cmh = mh / 2, cmv = mv / 2;
-            const int64_t csi = ((int64_t)(m.mb_y << 3) + (cmv >> 1)) * in.chroma_w + (m.mb_x << 3) + (cmh >> 1);
-            const int coh = cmh & 1, cov = cmv & 1;
-            const int64_t clast = csi + (int64_t)(7 + cov) * in.chroma_w + 7 + coh;
-            if (lsi < 0 || llast >= cap_y || csi < 0 || clast >= cap_c1 || clast >= cap_c0)
-                return fail(MPEGHIP_ERR_RANGE,
-                            "macroblock %u at (%u,%u): motion vector (%d,%d) reads outside the frame buffer", i, m.mb_x,
-                            m.mb_y, mh, mv);
-            ref_bytes = (uint64_t)(16 + lov) * (16 + loh) + 2ull * (8 + cov) * (8 + coh);
-        }
-        alg += 32 + units * MPEGHIP_COEF_UNIT + ref_bytes + (intra ? 64ull * nb : 384);
-        if (pics[m.pic].flags & MPEGHIP_PIC_RGBA)
-            alg += 1024;
         if (xrec)
             expand_mb(geom, xpics[m.pic], m, xrec + (size_t)i * kXDwords);
     }
@@ -1293,6 +1341,8 @@ int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_
 {
     if (!v)
         return fail(MPEGHIP_ERR_INVALID, "video is NULL");
+    if (v->stage)
+        return fail(MPEGHIP_ERR_INVALID, "submit while a stage is open (mpeghip_video_stage_commit ends it)");
     mpeghip_video::Staging *sg = &v->staging[v->next_staging];
     int rc = upload_into(v, &sg->batch, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, 1, sg);
     if (rc != MPEGHIP_OK)
@@ -1302,6 +1352,186 @@ int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_
     if (rc != MPEGHIP_OK)
         return rc;
     HIP_TRY(hipEventRecord(sg->done, v->ctx->stream));
+    sg->in_flight = true;
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
+                              mpeghip_stage **out)
+{
+    if (!v || !out || (n_pics && (!n_mbs || !coef_bytes)))
+        return fail(MPEGHIP_ERR_INVALID, "stage_begin: NULL argument");
+    if (v->stage)
+        return fail(MPEGHIP_ERR_INVALID, "stage_begin: the previous stage is still open");
+    if (recon_knob().mode != 6)
+        return fail(MPEGHIP_ERR_INVALID, "stage_begin: staged submits feed the wave-chunk kernel only (MPEGHIP_RECON mode 6)");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    std::unique_ptr<mpeghip_stage> s(new mpeghip_stage);
+    s->v = v;
+    s->n_pics = n_pics;
+    s->mb_first.resize(n_pics);
+    s->mb_count.assign(n_mbs, n_mbs + n_pics);
+    s->unit_first.resize(n_pics);
+    s->units.resize(n_pics);
+    s->alg.assign(n_pics, 0);
+    s->done.assign(n_pics, 0);
+    uint64_t mbs = 0, units = 0;
+    for (uint32_t i = 0; i < n_pics; i++) {
+        if (coef_bytes[i] % MPEGHIP_COEF_UNIT)
+            return fail(MPEGHIP_ERR_INVALID, "stage_begin: picture %u: coef_bytes %zu is not a multiple of 128", i, coef_bytes[i]);
+        s->mb_first[i] = (uint32_t)mbs;
+        s->unit_first[i] = units;
+        s->units[i] = coef_bytes[i] / MPEGHIP_COEF_UNIT;
+        mbs += n_mbs[i];
+        units += s->units[i];
+        if (mbs > 0xffffffffull || units > 0xffffffffull)
+            return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit descriptor indices");
+    }
+    s->n_mbs = (uint32_t)mbs;
+    s->coef_units = units;
+    mpeghip_video::Staging *sg = &v->staging[v->next_staging];
+    if (sg->in_flight) { // two submits ago: normally long finished
+        HIP_TRY(hipEventSynchronize(sg->done));
+        sg->in_flight = false;
+    }
+    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics, xb = sizeof(uint32_t) * kXDwords * (size_t)mbs;
+    s->x_at = (pb + 63) & ~(size_t)63;
+    s->coef_at = (s->x_at + xb + 63) & ~(size_t)63;
+    const size_t need = s->coef_at + units * MPEGHIP_COEF_UNIT + 64;
+    if (need > sg->cap_h) {
+        if (sg->h)
+            (void)hipHostFree(sg->h);
+        sg->h = nullptr;
+        sg->cap_h = 0;
+        const size_t cap = need + need / 2;
+        HIP_TRY(hipHostMalloc((void **)&sg->h, cap, hipHostMallocDefault));
+        sg->cap_h = cap;
+    }
+    if (!sg->done)
+        HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
+    s->sg = sg;
+    v->stage = s.get();
+    *out = s.release();
+    return MPEGHIP_OK;
+}
+
+// Thread-safe for distinct i: touches only picture i's part of the staging buffer and of the stage's arrays.
+int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
+                            const void *coefs)
+{
+    if (!s || !pic)
+        return fail(MPEGHIP_ERR_INVALID, "stage_put: NULL argument");
+    int rc = MPEGHIP_OK;
+    do {
+        if (i >= s->n_pics) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u of %u", i, s->n_pics);
+            break;
+        }
+        const mpeghip_video *v = s->v;
+        const uint32_t n = s->mb_count[i], first = s->mb_first[i];
+        if ((n && !mbs) || (n && s->units[i] && !coefs)) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: NULL array", i);
+            break;
+        }
+        if ((rc = validate_pic(v->info, *pic, i)) != MPEGHIP_OK)
+            break;
+        uint8_t *h = s->sg->h;
+        mpeghip_pic_desc pd = *pic;
+        pd.mb_first = first;
+        pd.mb_count = n;
+        reinterpret_cast<mpeghip_pic_desc *>(h)[i] = pd;
+        const XGeom geom = record_geometry(v);
+        const XPic xp = expand_pic(geom, pd);
+        uint32_t *xrec = reinterpret_cast<uint32_t *>(h + s->x_at);
+        const uint32_t unit0 = (uint32_t)s->unit_first[i];
+        uint64_t alg = 0;
+        for (uint32_t k = 0; k < n && rc == MPEGHIP_OK; k++) {
+            uint64_t units = 0;
+            rc = validate_mb(v->info, pd, mbs[k], k, s->units[i], &units, &alg);
+            if (rc != MPEGHIP_OK)
+                break;
+            uint32_t *x = xrec + (size_t)(first + k) * kXDwords;
+            expand_mb(geom, xp, mbs[k], x);
+            x[1] += unit0; // coef_off: relative to the picture's coefficients -> to the batch's
+        }
+        if (rc != MPEGHIP_OK)
+            break;
+        // horizontal runs of the chunks that lie inside this picture (commit looks at the straddling ones)
+        for (uint32_t c = (first + kWcMbs - 1) / kWcMbs * kWcMbs; c + kWcMbs <= first + n; c += kWcMbs)
+            mark_chunk_run(xrec, c);
+        if (s->units[i])
+            memcpy(h + s->coef_at + s->unit_first[i] * MPEGHIP_COEF_UNIT, coefs, s->units[i] * MPEGHIP_COEF_UNIT);
+        s->alg[i] = alg;
+        s->done[i] = 1;
+    } while (0);
+    if (rc != MPEGHIP_OK) {
+        std::lock_guard<std::mutex> l(s->error_lock);
+        if (s->error.load() == MPEGHIP_OK) {
+            s->error_text = mpeghip_last_error();
+            s->error.store(rc);
+        }
+    }
+    return rc;
+}
+
+int mpeghip_video_stage_commit(mpeghip_stage *sp)
+{
+    if (!sp)
+        return fail(MPEGHIP_ERR_INVALID, "stage_commit: NULL stage");
+    std::unique_ptr<mpeghip_stage> s(sp); // the stage ends here, whatever happens
+    mpeghip_video *v = s->v;
+    v->stage = nullptr;
+    if (s->error.load() != MPEGHIP_OK)
+        return fail(s->error.load(), "%s", s->error_text.c_str());
+    for (uint32_t i = 0; i < s->n_pics; i++)
+        if (!s->done[i])
+            return fail(MPEGHIP_ERR_INVALID, "stage_commit: picture %u was never put", i);
+    if (s->n_mbs == 0)
+        return MPEGHIP_OK;
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    mpeghip_video::Staging *sg = s->sg;
+    mpeghip_batch *b = &sg->batch;
+    const mpeghip_pic_desc *pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->h);
+    uint32_t *xrec = reinterpret_cast<uint32_t *>(sg->h + s->x_at);
+    for (uint32_t i = 1; i < s->n_pics; i++) { // chunks that straddle two pictures
+        const uint32_t c = s->mb_first[i] / kWcMbs * kWcMbs;
+        if (c != s->mb_first[i] && c + kWcMbs <= s->n_mbs)
+            mark_chunk_run(xrec, c);
+    }
+    b->any_rgba = wants_rgba(pics, s->n_pics);
+    int rc;
+    if (b->any_rgba && (rc = ensure_rgba(v)) != MPEGHIP_OK)
+        return rc;
+    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)s->n_pics, xb = sizeof(uint32_t) * kXDwords * (size_t)s->n_mbs;
+    const size_t cb = s->coef_units * MPEGHIP_COEF_UNIT;
+    if ((rc = grow((void **)&b->d_pics, &b->cap_pics, pb + 16)) != 0 ||
+        (rc = grow((void **)&b->d_xmbs, &b->cap_xmbs, xb + 64 * kWcMbs)) != 0 ||
+        (rc = grow((void **)&b->d_coefs, &b->cap_coefs, cb + 256)) != 0)
+        return rc;
+    hipStream_t st = v->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(b->d_pics, pics, pb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_xmbs, xrec, xb, hipMemcpyHostToDevice, st));
+    if (cb)
+        HIP_TRY(hipMemcpyAsync(b->d_coefs, sg->h + s->coef_at, cb, hipMemcpyHostToDevice, st));
+    b->notes.resize(s->n_pics);
+    b->alg_bytes = 0;
+    for (uint32_t p = 0; p < s->n_pics; p++) {
+        b->notes[p].stream = pics[p].stream;
+        b->notes[p].cur = pics[p].cur;
+        b->notes[p].rgba = (pics[p].flags & MPEGHIP_PIC_RGBA) ? 1 : 0;
+        b->notes[p].full = pics[p].mb_count == v->info.mb_w * v->info.mb_h ? 1 : 0;
+        b->alg_bytes += s->alg[p];
+    }
+    b->replicas = 1;
+    b->n_pics = s->n_pics;
+    b->n_mbs = s->n_mbs;
+    b->coef_bytes = cb;
+    b->dense_partition = false;
+    v->next_staging ^= 1;
+    rc = launch_batch(v, b);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    HIP_TRY(hipEventRecord(sg->done, st));
     sg->in_flight = true;
     return MPEGHIP_OK;
 }

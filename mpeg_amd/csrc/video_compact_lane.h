@@ -364,20 +364,24 @@ MPG_HD void expand_mb(const XGeom &g, const XPic &xp, const mpeghip_mb_desc &d, 
 // Is chunk c (records 4c .. 4c+3) a horizontal run of 4 fully written macroblocks of one frame, 64-byte aligned?
 // Then its outputs leave as whole rows (wc_store_tile).  Worked out on the host for every chunk, after all
 // records of the batch are written; kept in the chunk's first record.
+MPG_HD void mark_chunk_run(uint32_t *xrec, uint32_t first) // records first .. first+3 exist
+{
+    uint32_t *x0 = xrec + (size_t)first * kXDwords;
+    bool ok = ((x0[3] & 0xffff) & 3) == 0;
+    for (int m = 0; m < kWcMbs && ok; m++) {
+        const uint32_t *x = x0 + m * kXDwords;
+        ok = x[4] == x0[4] && x[3] == x0[3] + (uint32_t)m; // same frame, same row, next column
+        const uint32_t flags = x[0] & 0xff, cbp = (x[0] >> 8) & 0xff;
+        ok = ok && (!(flags & MPEGHIP_MB_INTRA) || cbp == 0x3f); // an invalid intra block keeps old pixels
+    }
+    if (ok)
+        x0[0] |= kXRun;
+}
+
 MPG_HD void mark_chunk_runs(uint32_t *xrec, uint32_t n_mbs)
 {
-    for (uint32_t first = 0; first + kWcMbs <= n_mbs; first += kWcMbs) {
-        uint32_t *x0 = xrec + (size_t)first * kXDwords;
-        bool ok = ((x0[3] & 0xffff) & 3) == 0;
-        for (int m = 0; m < kWcMbs && ok; m++) {
-            const uint32_t *x = x0 + m * kXDwords;
-            ok = x[4] == x0[4] && x[3] == x0[3] + (uint32_t)m; // same frame, same row, next column
-            const uint32_t flags = x[0] & 0xff, cbp = (x[0] >> 8) & 0xff;
-            ok = ok && (!(flags & MPEGHIP_MB_INTRA) || cbp == 0x3f); // an invalid intra block keeps old pixels
-        }
-        if (ok)
-            x0[0] |= kXRun;
-    }
+    for (uint32_t first = 0; first + kWcMbs <= n_mbs; first += kWcMbs)
+        mark_chunk_run(xrec, first);
 }
 
 struct WcRaw {

@@ -302,15 +302,77 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                 std::rethrow_exception(failed);
             }
             // ... then replay them here: the k-th request of every stream, in stream order (requests of
-            // different streams commute; queue() keeps two pictures of one stream in separate calls)
+            // different streams commute; two pictures of one stream never share a device call).  Pictures go
+            // to the device as one staged submit per step, put into the pinned staging buffer by the pool
+            // (validation, record expansion and the copies run in parallel); stores without staging get
+            // them merged through queue().
             size_t most = 0;
             for (uint32_t i : todo)
                 most = ports_[i]->events.size() > most ? ports_[i]->events.size() : most;
+            std::vector<const Port::Event *> group;
+            std::vector<uint32_t> group_stream;
+            std::vector<uint8_t> in_group(videos_.size(), 0);
+            auto run_group = [&]() {
+                if (group.empty())
+                    return;
+                Flush(); // pictures queued the other way come first
+                if (group.size() == 1 || !store_->canStage()) {
+                    for (size_t g = 0; g < group.size(); g++)
+                        queue(group_stream[g], group[g]->pic, group[g]->mbs.data(), (uint32_t)group[g]->mbs.size(),
+                              group[g]->coefs.data(), group[g]->coefs.size());
+                    Flush();
+                } else {
+                    std::vector<uint32_t> n_mbs(group.size());
+                    std::vector<size_t> bytes(group.size());
+                    for (size_t g = 0; g < group.size(); g++) {
+                        n_mbs[g] = (uint32_t)group[g]->mbs.size();
+                        bytes[g] = group[g]->coefs.size();
+                    }
+                    store_->stageBegin(n_mbs, bytes);
+                    std::exception_ptr put_failed;
+                    try {
+                        pool_->run(group.size(), [&](size_t g) {
+                            mpeghip_pic_desc p = group[g]->pic;
+                            p.stream = group_stream[g];
+                            store_->stagePut((uint32_t)g, p, group[g]->mbs.data(), group[g]->coefs.data());
+                        });
+                    } catch (...) {
+                        put_failed = std::current_exception();
+                    }
+                    try {
+                        store_->stageCommit(); // ends the stage; fails (launching nothing) if a put failed
+                    } catch (...) {
+                        if (!put_failed)
+                            put_failed = std::current_exception();
+                    }
+                    if (put_failed)
+                        std::rethrow_exception(put_failed);
+                    device_submits_++;
+                    queued_pictures_ += group.size();
+                }
+                for (uint32_t st : group_stream)
+                    in_group[st] = 0;
+                group.clear();
+                group_stream.clear();
+            };
             try {
                 for (size_t k = 0; k < most; k++)
-                    for (uint32_t i : todo)
-                        if (k < ports_[i]->events.size())
-                            ports_[i]->replay(ports_[i]->events[k]);
+                    for (uint32_t i : todo) {
+                        if (k >= ports_[i]->events.size())
+                            continue;
+                        const Port::Event &e = ports_[i]->events[k];
+                        if (e.kind != Port::Event::Submit) {
+                            run_group(); // (a quantiser table belongs to pictures not yet on the device)
+                            ports_[i]->replay(e);
+                            continue;
+                        }
+                        if (in_group[i])
+                            run_group();
+                        group.push_back(&e);
+                        group_stream.push_back(i);
+                        in_group[i] = 1;
+                    }
+                run_group();
             } catch (...) {
                 for (uint32_t i : todo)
                     ports_[i]->events.clear();

@@ -87,10 +87,27 @@ public:
         check(mpeghip_video_rgba_convert(store_, slot, stream, 1), "mpeghip_video_rgba_convert");
         check(mpeghip_video_read_rgba(store_, stream, slot, dst), "mpeghip_video_read_rgba");
     }
+    bool canStage() const override { return true; }
+    void stageBegin(const std::vector<uint32_t> &n_mbs, const std::vector<size_t> &coef_bytes) override
+    {
+        check(mpeghip_video_stage_begin(store_, (uint32_t)n_mbs.size(), n_mbs.data(), coef_bytes.data(), &stage_),
+              "mpeghip_video_stage_begin");
+    }
+    void stagePut(uint32_t i, const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, const uint8_t *coefs) override
+    {
+        check(mpeghip_video_stage_put(stage_, i, &pic, mbs, coefs), "mpeghip_video_stage_put");
+    }
+    void stageCommit() override
+    {
+        mpeghip_stage *s = stage_;
+        stage_ = nullptr; // the commit ends the stage whatever it returns
+        check(mpeghip_video_stage_commit(s), "mpeghip_video_stage_commit");
+    }
 
 private:
     mpeghip_ctx *ctx_;
     mpeghip_video *store_ = nullptr;
+    mpeghip_stage *stage_ = nullptr;
 };
 
 class HipAudioBackend : public AudioBackend {

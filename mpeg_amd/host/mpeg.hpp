@@ -147,6 +147,13 @@ public:
                         const uint8_t *coefs, size_t coef_bytes) = 0;
     virtual void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) = 0;
     virtual void readRGBA(uint32_t stream, uint32_t slot, uint8_t *dst) = 0;
+    // One submit assembled picture by picture (mpeghip_video_stage_*): stagePut may be called from several
+    // threads for distinct i; each picture brings its own arrays (coef_off relative to its coefs, pic.stream
+    // set).  Stores without it return false from canStage() and get one merged submit() instead.
+    virtual bool canStage() const { return false; }
+    virtual void stageBegin(const std::vector<uint32_t> &, const std::vector<size_t> &) {}
+    virtual void stagePut(uint32_t, const mpeghip_pic_desc &, const mpeghip_mb_desc *, const uint8_t *) {}
+    virtual void stageCommit() {}
 };
 
 class AudioBackend {

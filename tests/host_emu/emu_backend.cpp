@@ -4,7 +4,10 @@
 // reference's golden hashes on a machine without a GPU.  Never part of the product:
 // libmpeghost itself only knows the HIP backend.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
 
 #include <vector>
 
@@ -115,6 +118,51 @@ public:
         emu_video_run_wc(frames_.data(), stride_, lw_, lh_, w_, h_, pics, n_pics, mbs, n_mbs, coefs, qt_.data(), rgba_.data(),
                          rgba_stride_);
     }
+    // staged submit (the product's mpeghip_video_stage_*): pictures put from several threads into one merged submit
+    bool canStage() const override { return true; }
+    void stageBegin(const std::vector<uint32_t> &n_mbs, const std::vector<size_t> &coef_bytes) override
+    {
+        const size_t n = n_mbs.size();
+        st_first_.assign(n, 0);
+        st_unit_.assign(n, 0);
+        st_count_ = n_mbs;
+        st_bytes_ = coef_bytes;
+        size_t mbs = 0, bytes = 0;
+        for (size_t i = 0; i < n; i++) {
+            st_first_[i] = (uint32_t)mbs;
+            st_unit_[i] = (uint32_t)(bytes / MPEGHIP_COEF_UNIT);
+            mbs += n_mbs[i];
+            bytes += coef_bytes[i];
+        }
+        st_pics_.assign(n, mpeghip_pic_desc{});
+        st_mbs_.assign(mbs, mpeghip_mb_desc{});
+        st_coefs_.assign(bytes, 0);
+        stage_puts_ = 0;
+    }
+    void stagePut(uint32_t i, const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, const uint8_t *coefs) override
+    {
+        mpeghip_pic_desc p = pic;
+        p.mb_first = st_first_[i];
+        p.mb_count = st_count_[i];
+        st_pics_[i] = p;
+        for (uint32_t k = 0; k < st_count_[i]; k++) {
+            mpeghip_mb_desc m = mbs[k];
+            m.pic = i;
+            m.coef_off += st_unit_[i];
+            st_mbs_[st_first_[i] + k] = m;
+        }
+        if (st_bytes_[i])
+            memcpy(st_coefs_.data() + (size_t)st_unit_[i] * MPEGHIP_COEF_UNIT, coefs, st_bytes_[i]);
+        stage_puts_++;
+    }
+    void stageCommit() override
+    {
+        if (stage_puts_.load() != st_pics_.size())
+            abort();
+        submit(st_pics_.data(), (uint32_t)st_pics_.size(), st_mbs_.data(), (uint32_t)st_mbs_.size(), st_coefs_.data(),
+               st_coefs_.size());
+        staged_commits_++;
+    }
     void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
         const uint8_t *f = frames_.data() + ((size_t)stream * 3 + slot) * stride_;
@@ -131,6 +179,15 @@ private:
     uint32_t w_ = 0, h_ = 0, lw_ = 0, lh_ = 0, n_ = 0;
     size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0;
     std::vector<uint8_t> frames_, rgba_, qt_;
+    std::vector<uint32_t> st_first_, st_unit_, st_count_;
+    std::vector<size_t> st_bytes_;
+    std::vector<mpeghip_pic_desc> st_pics_;
+    std::vector<mpeghip_mb_desc> st_mbs_;
+    std::vector<uint8_t> st_coefs_;
+    std::atomic<size_t> stage_puts_{0};
+
+public:
+    uint64_t staged_commits_ = 0;
 };
 
 class EmuAudioBackend : public mpeg::AudioBackend {
@@ -199,6 +256,8 @@ void host_emu_configure(int flavour, const float *window512)
 }
 void *host_emu_make_video(void) { return new EmuVideoBackend(g_flavour); }
 void *host_emu_batch_store(void) { return new EmuBatchStore(); }
+// staged submits the store has seen (valid while the batch that owns the store is open)
+uint64_t host_emu_batch_store_staged_commits(void *store) { return static_cast<EmuBatchStore *>(static_cast<mpeg::BatchStore *>(store))->staged_commits_; }
 void *host_emu_audio_batch_store(void) { return new EmuAudioBatchStore(g_window); }
 void *host_emu_make_audio(int fma) { return new EmuAudioBackend(fma, g_window); }
 }

@@ -103,6 +103,8 @@ def host_emu():
         L.host_emu_audio_backend.argtypes = [C.c_int, C.c_void_p]
         L.host_emu_batch_store.restype = C.c_void_p
         L.host_emu_batch_store.argtypes = []
+        L.host_emu_batch_store_staged_commits.restype = C.c_uint64
+        L.host_emu_batch_store_staged_commits.argtypes = [C.c_void_p]
         L.host_emu_audio_batch_store.restype = C.c_void_p
         L.host_emu_audio_batch_store.argtypes = []
         L.host_emu_configure.restype = None
@@ -321,7 +323,8 @@ class HostBatch:
         if device is not None:
             self.h = L.mpeghost_batch_open(device, n_streams)
         else:
-            self.h = L.mpeghost_batch_open_store(host_emu().host_emu_batch_store(), n_streams)
+            self.emu_store = host_emu().host_emu_batch_store()
+            self.h = L.mpeghost_batch_open_store(self.emu_store, n_streams)
         if not self.h:
             raise RuntimeError(L.mpeghost_last_error().decode())
         if threads > 1:
@@ -348,7 +351,10 @@ class HostBatch:
     def counters(self):
         out = (C.c_uint64 * 2)()
         host().mpeghost_batch_counters(self.h, C.byref(out))
-        return {"device_submits": out[0], "queued_pictures": out[1]}
+        c = {"device_submits": out[0], "queued_pictures": out[1]}
+        if getattr(self, "emu_store", None):
+            c["staged_commits"] = int(host_emu().host_emu_batch_store_staged_commits(self.emu_store))
+        return c
 
     def close(self):
         if self.h:

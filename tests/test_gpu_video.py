@@ -257,6 +257,58 @@ def test_many_streams_replicated_batch(oracle, hip_ctx):
     dut.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 4])
+def test_staged_submit_equals_plain_submit(oracle, hip_ctx, threads):
+    """mpeghip_video_stage_begin / _put / _commit: one submit assembled picture by picture (puts from several
+    host threads, each picture with its own coefficient array) reconstructs exactly what one plain submit of
+    the merged arrays does; pictures of odd macroblock counts make chunks straddle picture boundaries."""
+    w, h = 96, 80   # 6 x 5 = 30 macroblocks per picture: not a multiple of the 4-macroblock chunk
+    n = 5
+    seqs = [synth.generate_sequence(w, h, 4, seed=300 + i, rgba=(i == 1)) for i in range(n)]
+    ref, dut = oracle.OracleStore(w, h, n), abi.VideoStore(hip_ctx, w, h, n)
+    for step in range(4):
+        pictures = []
+        for sidx, seq in enumerate(seqs):
+            s = seq[step]
+            p = s.pics.copy()
+            p["stream"] = sidx
+            pictures.append((p[0], s.mbs, s.coefs))
+            q = p.copy()
+            q["mb_first"] = 0
+            ref.submit(q, s.mbs, s.coefs)
+        assert dut.submit_staged(pictures, threads=threads) == [0] * n
+        for sidx in range(n):
+            for slot in range(3):
+                assert_planes_equal(ref.read_planes(sidx, slot), dut.read_planes(sidx, slot), "stream %d slot %d" % (sidx, slot))
+        cur = int(seqs[1][step].pics[0]["cur"])
+        assert np.array_equal(np.asarray(dut.read_rgba(1, cur)).reshape(-1), ref.read_rgba(1, cur).reshape(-1))
+    dut.close()
+
+
+@pytest.mark.gpu
+def test_staged_submit_refuses_a_bad_picture(hip_ctx):
+    """A put that fails validation makes the commit fail with that error and launch nothing; the stage is over
+    and the store accepts the next submit."""
+    w, h = 96, 80
+    s = synth.generate_sequence(w, h, 2, seed=7)[0]
+    dut = abi.VideoStore(hip_ctx, w, h, 2)
+    good = s.pics.copy()
+    bad_mbs = s.mbs.copy()
+    bad_mbs["mb_x"][3] = 99
+    p1 = good.copy()
+    p1["stream"] = 1
+    before = [dut.read_planes(st, int(good[0]["cur"])) for st in range(2)]
+    with pytest.raises(abi.MpegHipError, match="position"):
+        dut.submit_staged([(good[0], s.mbs, s.coefs), (p1[0], bad_mbs, s.coefs)])
+    for st in range(2):
+        assert_planes_equal(before[st], dut.read_planes(st, int(good[0]["cur"])), "stream %d untouched" % st)
+    dut.submit_staged([(good[0], s.mbs, s.coefs), (p1[0], s.mbs, s.coefs)])
+    a, b = dut.read_planes(0, int(good[0]["cur"])), dut.read_planes(1, int(good[0]["cur"]))
+    assert_planes_equal(a, b, "both streams decoded the same picture")
+    dut.close()
+
+
 def test_streams_are_independent(oracle, hip_ctx):
     """Different streams decode different pictures in ONE submit without interfering."""
     w, h = 96, 80

@@ -73,6 +73,8 @@ def test_threaded_parse_gives_the_same_frames_and_device_calls(oracle, golden_di
     assert h == [want[id(s)][0] for s in streams] and n == [want[id(s)][1] for s in streams]
     assert (h, n) == (h1, n1) and c["queued_pictures"] == c1["queued_pictures"]
     assert c["device_submits"] <= c1["device_submits"]
+    # and the pictures went through staged submits (put from the pool), not through the merged path
+    assert c1["staged_commits"] == 0 and c["staged_commits"] > 0.8 * c["device_submits"]
 
 
 def test_different_picture_sizes_are_refused(oracle, golden_dir):

@@ -51,12 +51,65 @@ def submit_rate(ctx, streams, seconds=2.0):
     return n / dt, nbytes / dt
 
 
+def staged_rate(ctx, streams, threads, seconds=2.0):
+    """mpeghip_video_stage_*: `streams` typical 1080p pictures per device call, each put (validation, record
+    expansion, copy into pinned staging) from one of `threads` host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    seq = synth.generate_sequence(1920, 1080, 13, profile="typical")
+    store = abi.VideoStore(ctx, 1920, 1080, streams)
+    L = store.lib
+    steps = []
+    for s in seq:
+        pics = np.repeat(s.pics, streams)
+        pics["stream"] = np.arange(streams)
+        mbs = np.ascontiguousarray(s.mbs)
+        coefs = [np.array(s.coefs, copy=True) for _ in range(streams)]  # every stream its own coefficient array
+        n_mbs = np.full(streams, len(mbs), np.uint32)
+        nbytes = np.full(streams, s.coefs.nbytes, np.uint64)
+        steps.append((pics, mbs, coefs, n_mbs, nbytes))
+    ex = ThreadPoolExecutor(threads)
+
+    def run(step):
+        pics, mbs, coefs, n_mbs, nbytes = step
+        st = C.c_void_p()
+        abi._check(L.mpeghip_video_stage_begin(store.h, streams, n_mbs.ctypes.data, nbytes.ctypes.data, C.byref(st)))
+        base, item = pics.ctypes.data, pics.dtype.itemsize
+
+        def put(i):
+            return L.mpeghip_video_stage_put(st, i, base + i * item, mbs.ctypes.data, coefs[i].ctypes.data)
+
+        rcs = list(ex.map(put, range(streams)))
+        abi._check(L.mpeghip_video_stage_commit(st))
+        assert not any(rcs)
+
+    for step in steps:
+        run(step)
+    ctx.sync()
+    t0, n, nb = time.perf_counter(), 0, 0
+    while time.perf_counter() - t0 < seconds:
+        for step in steps:
+            run(step)
+            n += streams
+            nb += streams * (16 + step[1].nbytes + step[2][0].nbytes)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ex.shutdown()
+    store.close()
+    return n / dt, nb / dt
+
+
 def main():
+    import os
     ctx = abi.Context(0)
     for streams in (1, 16):
         pps, bps = submit_rate(ctx, streams)
         print("submit, %2d stream(s)/call: %8.0f pictures/s = %.3f G macroblocks/s, %.2f GB/s of descriptors+coefficients over PCIe"
               % (streams, pps, pps * 8160 / 1e9, bps / 1e9))
+    for streams, threads in ((64, 1), (64, 8), (64, 32), (256, 32)):
+        threads = min(threads, os.cpu_count() or 1)
+        pps, bps = staged_rate(ctx, streams, threads)
+        print("staged submit, %3d pictures/call put by %2d host thread(s): %8.0f pictures/s = %.3f G macroblocks/s, %.2f GB/s of "
+              "descriptors+coefficients" % (streams, threads, pps, pps * 8160 / 1e9, bps / 1e9))
     ctx.close()
 
     import hostlib
