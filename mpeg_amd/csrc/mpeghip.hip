@@ -25,6 +25,7 @@
 #include "video_lane.h"
 #include "video_split_lane.h"
 #include "video_compact_lane.h"
+#include "video_wire_lane.h"
 
 using namespace mpg;
 
@@ -436,6 +437,38 @@ __global__ void replicate_desc_kernel(mpeghip_pic_desc *pics, uint32_t n_pics, m
     }
 }
 
+// Staged submits: rebuild the dense coefficient units from their wire form (video_wire_lane.h).  Grid:
+// x = groups of 8 units (4 per workgroup), y = pictures; one wave = 8 units of one picture.
+struct WireTab {
+    uint32_t unit_first; // first dense unit of the picture in the batch's coefficient array (a multiple of 8)
+    uint32_t units;
+    uint32_t region;     // dword offset of the picture's wire region: `units` headers, then the payload
+    uint32_t reserved;
+};
+__global__ __launch_bounds__(256) void wire_expand_kernel(const uint32_t *wire, const WireTab *tab, uint32_t pic0,
+                                                            uint8_t *coefs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[4 * 1024];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const WireTab t = tab[pic0 + blockIdx.y];
+    const uint32_t group = blockIdx.x * 4 + wave;
+    if (group * 8 >= t.units)
+        return;
+    const uint32_t unit = group * 8 + ((uint32_t)lane >> 3);
+    const uint32_t *region = wire + t.region;
+    WireLane w;
+    w.live = unit < t.units;
+    w.header = w.live ? region[unit] : 0;
+    w.payload = region + t.units;
+    uint8_t *tile = tiles + wave * 1024;
+    wire_phase_zero(tile, lane);
+    wave_lds_handoff();
+    wire_phase_scatter(w, tile, lane);
+    wave_lds_handoff();
+    wire_phase_store(w, tile, lane, coefs + ((uint64_t)t.unit_first + unit) * MPEGHIP_COEF_UNIT);
+}
+
 // FNV-1a-64 over Y||Cb||Cr of one slot per stream (mpeg_test.go:221-223); one
 // thread per stream — a test aid, not a hot path.
 __global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32_t slot,
@@ -528,6 +561,10 @@ struct mpeghip_batch {
     mpeghip_pic_desc *d_pics = nullptr;
     mpeghip_mb_desc *d_mbs = nullptr; // filled only for the diagnostic kernels (MPEGHIP_RECON mode < 6)
     uint32_t *d_xmbs = nullptr;       // expanded records of the wave-chunk kernel (mode 6)
+    uint32_t *d_wire = nullptr;       // staged submits: coefficient units in wire form (video_wire_lane.h)
+    void *d_wtab = nullptr;           //                 one WireTab per picture
+    uint8_t *d_blob = nullptr;        // staged submits: d_pics, d_wtab, d_xmbs, d_wire are parts of this one allocation
+    size_t cap_blob = 0;              //                 (the image of the staging buffer: one H2D copy per commit)
     uint8_t *d_coefs = nullptr;
     uint64_t n_pics = 0, n_mbs = 0, coef_bytes = 0;
     uint64_t alg_bytes = 0;
@@ -540,6 +577,7 @@ struct mpeghip_batch {
     std::vector<PicNote> notes;
     uint32_t replicas = 1;
     size_t cap_pics = 0, cap_mbs = 0, cap_xmbs = 0, cap_coefs = 0, cap_entries = 0; // capacities (transient batch reuse)
+
 };
 
 struct mpeghip_video {
@@ -576,10 +614,14 @@ struct mpeghip_stage {
     uint32_t n_pics = 0, n_mbs = 0;
     uint64_t coef_units = 0;
     std::vector<uint32_t> mb_first, mb_count;   // per picture: its records [mb_first, mb_first + mb_count)
-    std::vector<uint64_t> unit_first, units;    // per picture: its coefficient units
+    std::vector<uint64_t> unit_first, units;    // per picture: its coefficient units (unit_first: multiples of 8)
     std::vector<uint64_t> alg;                  // per picture, written by its put
     std::vector<uint8_t> done;                  // per picture: put succeeded
-    size_t x_at = 0, coef_at = 0;
+    size_t x_at = 0, tab_at = 0, wire0 = 0;     // staging layout: pictures | WireTab | records | wire regions
+    uint64_t wire_cap_dwords = 0;               // room for all regions if every unit travelled dense
+    std::atomic<uint64_t> wire_used{0};         // dwords handed out so far: a put packs its picture into scratch
+                                                // memory of its thread, then takes exactly the room it needs, so
+                                                // that the regions form one contiguous block = one H2D copy
     std::atomic<int> error{MPEGHIP_OK};         // first failed put
     std::mutex error_lock;
     std::string error_text;
@@ -816,14 +858,32 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
     return MPEGHIP_OK;
 }
 
+// d_pics / d_xmbs (+ d_wtab, d_wire) are either allocations of their own (plain submits, resident batches) or parts
+// of d_blob (staged submits); a staging batch may change from one form to the other between submits.
+static void batch_drop_descriptors(mpeghip_batch *b)
+{
+    if (b->d_blob) {
+        (void)hipFree(b->d_blob);
+    } else {
+        if (b->d_pics)
+            (void)hipFree(b->d_pics);
+        if (b->d_xmbs)
+            (void)hipFree(b->d_xmbs);
+    }
+    b->d_blob = nullptr;
+    b->cap_blob = 0;
+    b->d_pics = nullptr;
+    b->d_xmbs = nullptr;
+    b->d_wire = nullptr;
+    b->d_wtab = nullptr;
+    b->cap_pics = b->cap_xmbs = 0;
+}
+
 static void batch_release(mpeghip_batch *b)
 {
-    if (b->d_pics)
-        (void)hipFree(b->d_pics);
+    batch_drop_descriptors(b);
     if (b->d_mbs)
         (void)hipFree(b->d_mbs);
-    if (b->d_xmbs)
-        (void)hipFree(b->d_xmbs);
     if (b->d_coefs)
         (void)hipFree(b->d_coefs);
     if (b->d_entries)
@@ -833,6 +893,8 @@ static void batch_release(mpeghip_batch *b)
     b->d_pics = nullptr;
     b->d_mbs = nullptr;
     b->d_xmbs = nullptr;
+    b->d_wire = nullptr;
+    b->d_wtab = nullptr;
     b->d_coefs = nullptr;
     b->cap_pics = b->cap_mbs = b->cap_coefs = 0;
 }
@@ -1293,6 +1355,8 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
         mbs = reinterpret_cast<const mpeghip_mb_desc *>(sg->h + pb);
         coefs = sg->h + coef_at;
     }
+    if (b->d_blob) // (a staging batch last used by a staged submit)
+        batch_drop_descriptors(b);
     if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
         (rc = grow((void **)&b->d_mbs, &b->cap_mbs, mb * replicas + 32)) != 0 ||
         (rc = grow((void **)&b->d_xmbs, &b->cap_xmbs, xb * replicas + 64 * kWcMbs)) != 0 ||
@@ -1375,7 +1439,8 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
     s->units.resize(n_pics);
     s->alg.assign(n_pics, 0);
     s->done.assign(n_pics, 0);
-    uint64_t mbs = 0, units = 0;
+    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics;
+    uint64_t mbs = 0, units = 0, wire = 0; // wire: dwords, worst case (every unit dense) + headers
     for (uint32_t i = 0; i < n_pics; i++) {
         if (coef_bytes[i] % MPEGHIP_COEF_UNIT)
             return fail(MPEGHIP_ERR_INVALID, "stage_begin: picture %u: coef_bytes %zu is not a multiple of 128", i, coef_bytes[i]);
@@ -1383,21 +1448,24 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
         s->unit_first[i] = units;
         s->units[i] = coef_bytes[i] / MPEGHIP_COEF_UNIT;
         mbs += n_mbs[i];
-        units += s->units[i];
-        if (mbs > 0xffffffffull || units > 0xffffffffull)
+        units += (s->units[i] + 7) & ~7ull; // a wave of wire_expand_kernel = 8 units of ONE picture
+        wire += (s->units[i] * (1 + kWireUnitDwords) + 15) & ~15ull;
+        if (mbs > 0xffffffffull || units > 0xffffffffull || wire > 0xffffffffull)
             return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit descriptor indices");
     }
     s->n_mbs = (uint32_t)mbs;
     s->coef_units = units;
+    s->wire_cap_dwords = wire;
     mpeghip_video::Staging *sg = &v->staging[v->next_staging];
     if (sg->in_flight) { // two submits ago: normally long finished
         HIP_TRY(hipEventSynchronize(sg->done));
         sg->in_flight = false;
     }
-    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics, xb = sizeof(uint32_t) * kXDwords * (size_t)mbs;
-    s->x_at = (pb + 63) & ~(size_t)63;
-    s->coef_at = (s->x_at + xb + 63) & ~(size_t)63;
-    const size_t need = s->coef_at + units * MPEGHIP_COEF_UNIT + 64;
+    const size_t xb = sizeof(uint32_t) * kXDwords * (size_t)mbs;
+    s->tab_at = (pb + 63) & ~(size_t)63;
+    s->x_at = (s->tab_at + sizeof(WireTab) * (size_t)n_pics + 63) & ~(size_t)63;
+    s->wire0 = (s->x_at + xb + 63) & ~(size_t)63;
+    const size_t need = s->wire0 + (size_t)wire * 4 + 64;
     if (need > sg->cap_h) {
         if (sg->h)
             (void)hipHostFree(sg->h);
@@ -1459,8 +1527,27 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         // horizontal runs of the chunks that lie inside this picture (commit looks at the straddling ones)
         for (uint32_t c = (first + kWcMbs - 1) / kWcMbs * kWcMbs; c + kWcMbs <= first + n; c += kWcMbs)
             mark_chunk_run(xrec, c);
-        if (s->units[i])
-            memcpy(h + s->coef_at + s->unit_first[i] * MPEGHIP_COEF_UNIT, coefs, s->units[i] * MPEGHIP_COEF_UNIT);
+        // the coefficient units, in wire form (video_wire_lane.h): headers, then the payload — packed in this
+        // thread's scratch memory first, because the room a picture needs is only known afterwards
+        const uint32_t units = (uint32_t)s->units[i];
+        static thread_local std::vector<uint32_t> scratch;
+        const size_t worst = (size_t)units * (1 + kWireUnitDwords);
+        if (scratch.size() < worst)
+            scratch.resize(worst + worst / 4 + 1024);
+        uint32_t *hdr = scratch.data(), *payload = scratch.data() + units;
+        uint32_t used = 0;
+        const uint8_t *src = static_cast<const uint8_t *>(coefs);
+        for (uint32_t u = 0; u < units; u++)
+            hdr[u] = wire_pack_unit(src + (size_t)u * MPEGHIP_COEF_UNIT, payload, used);
+        const uint32_t dwords = (units + used + 3) & ~3u; // regions stay 16-byte aligned
+        const uint64_t at = s->wire_used.fetch_add(dwords);
+        memcpy(h + s->wire0 + at * 4, scratch.data(), (size_t)(units + used) * 4);
+        WireTab t;
+        t.unit_first = unit0;
+        t.units = units;
+        t.region = (uint32_t)at;
+        t.reserved = 0;
+        reinterpret_cast<WireTab *>(h + s->tab_at)[i] = t;
         s->alg[i] = alg;
         s->done[i] = 1;
     } while (0);
@@ -1502,17 +1589,37 @@ int mpeghip_video_stage_commit(mpeghip_stage *sp)
     int rc;
     if (b->any_rgba && (rc = ensure_rgba(v)) != MPEGHIP_OK)
         return rc;
-    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)s->n_pics, xb = sizeof(uint32_t) * kXDwords * (size_t)s->n_mbs;
+    // the device image of the staging buffer: pictures | WireTab | records | wire regions, sent in ONE copy
+    // (a copy costs the better part of a millisecond of stream time whatever its size)
     const size_t cb = s->coef_units * MPEGHIP_COEF_UNIT;
-    if ((rc = grow((void **)&b->d_pics, &b->cap_pics, pb + 16)) != 0 ||
-        (rc = grow((void **)&b->d_xmbs, &b->cap_xmbs, xb + 64 * kWcMbs)) != 0 ||
+    if (!b->d_blob)
+        batch_drop_descriptors(b); // (the batch was last used by a plain submit)
+    if ((rc = grow((void **)&b->d_blob, &b->cap_blob, s->wire0 + (size_t)s->wire_cap_dwords * 4 + 256)) != 0 ||
         (rc = grow((void **)&b->d_coefs, &b->cap_coefs, cb + 256)) != 0)
         return rc;
+    b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
+    b->d_wtab = b->d_blob + s->tab_at;
+    b->d_xmbs = reinterpret_cast<uint32_t *>(b->d_blob + s->x_at);
+    b->d_wire = reinterpret_cast<uint32_t *>(b->d_blob + s->wire0);
     hipStream_t st = v->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(b->d_pics, pics, pb, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b->d_xmbs, xrec, xb, hipMemcpyHostToDevice, st));
-    if (cb)
-        HIP_TRY(hipMemcpyAsync(b->d_coefs, sg->h + s->coef_at, cb, hipMemcpyHostToDevice, st));
+    {
+        // in pieces: one copy of a gigabyte ran at a quarter of the rate of the same bytes in 32-128 MB pieces
+        const size_t total = s->wire0 + (size_t)s->wire_used.load() * 4, piece = (size_t)64 << 20;
+        for (size_t at = 0; at < total; at += piece)
+            HIP_TRY(hipMemcpyAsync(b->d_blob + at, sg->h + at, total - at < piece ? total - at : piece, hipMemcpyHostToDevice, st));
+    }
+    uint32_t max_units = 0;
+    for (uint32_t i = 0; i < s->n_pics; i++)
+        max_units = s->units[i] > max_units ? (uint32_t)s->units[i] : max_units;
+    if (max_units) {
+        const uint32_t gx = ((max_units + 7) / 8 + 3) / 4;
+        for (uint32_t p0 = 0; p0 < s->n_pics; p0 += 32768) {
+            const uint32_t np = s->n_pics - p0 < 32768 ? s->n_pics - p0 : 32768;
+            hipLaunchKernelGGL(wire_expand_kernel, dim3(gx, np), dim3(256), 0, st, b->d_wire,
+                               static_cast<const WireTab *>(b->d_wtab), p0, b->d_coefs);
+        }
+        HIP_TRY(hipGetLastError());
+    }
     b->notes.resize(s->n_pics);
     b->alg_bytes = 0;
     for (uint32_t p = 0; p < s->n_pics; p++) {

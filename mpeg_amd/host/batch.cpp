@@ -322,33 +322,42 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                               group[g]->coefs.data(), group[g]->coefs.size());
                     Flush();
                 } else {
-                    std::vector<uint32_t> n_mbs(group.size());
-                    std::vector<size_t> bytes(group.size());
-                    for (size_t g = 0; g < group.size(); g++) {
-                        n_mbs[g] = (uint32_t)group[g]->mbs.size();
-                        bytes[g] = group[g]->coefs.size();
-                    }
-                    store_->stageBegin(n_mbs, bytes);
-                    std::exception_ptr put_failed;
-                    try {
-                        pool_->run(group.size(), [&](size_t g) {
-                            mpeghip_pic_desc p = group[g]->pic;
-                            p.stream = group_stream[g];
-                            store_->stagePut((uint32_t)g, p, group[g]->mbs.data(), group[g]->coefs.data());
-                        });
-                    } catch (...) {
-                        put_failed = std::current_exception();
-                    }
-                    try {
-                        store_->stageCommit(); // ends the stage; fails (launching nothing) if a put failed
-                    } catch (...) {
-                        if (!put_failed)
+                    // about kStageSliceBytes of coefficients per staged submit: the device starts on the first slice
+                    // while the pool packs the next, and staging buffers stay in the size range that copies fastest
+                    constexpr size_t kStageSliceBytes = (size_t)128 << 20;
+                    for (size_t g0 = 0, gn = 0; g0 < group.size(); g0 += gn) {
+                        size_t sum = 0;
+                        for (gn = 0; g0 + gn < group.size() && (gn == 0 || sum < kStageSliceBytes); gn++)
+                            sum += group[g0 + gn]->coefs.size() + group[g0 + gn]->mbs.size() * sizeof(mpeghip_mb_desc);
+                        std::vector<uint32_t> n_mbs(gn);
+                        std::vector<size_t> bytes(gn);
+                        for (size_t g = 0; g < gn; g++) {
+                            n_mbs[g] = (uint32_t)group[g0 + g]->mbs.size();
+                            bytes[g] = group[g0 + g]->coefs.size();
+                        }
+                        store_->stageBegin(n_mbs, bytes);
+                        std::exception_ptr put_failed;
+                        try {
+                            pool_->run(gn, [&](size_t g) {
+                                const Port::Event *e = group[g0 + g];
+                                mpeghip_pic_desc p = e->pic;
+                                p.stream = group_stream[g0 + g];
+                                store_->stagePut((uint32_t)g, p, e->mbs.data(), e->coefs.data());
+                            });
+                        } catch (...) {
                             put_failed = std::current_exception();
+                        }
+                        try {
+                            store_->stageCommit(); // ends the stage; fails (launching nothing) if a put failed
+                        } catch (...) {
+                            if (!put_failed)
+                                put_failed = std::current_exception();
+                        }
+                        if (put_failed)
+                            std::rethrow_exception(put_failed);
+                        device_submits_++;
+                        queued_pictures_ += gn;
                     }
-                    if (put_failed)
-                        std::rethrow_exception(put_failed);
-                    device_submits_++;
-                    queued_pictures_ += group.size();
                 }
                 for (uint32_t st : group_stream)
                     in_group[st] = 0;

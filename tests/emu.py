@@ -55,6 +55,8 @@ def lib():
         L.emu_avg2.argtypes = [C.c_uint32] * 2
         L.emu_xcd_chunk.argtypes = [C.c_uint32] * 2
         L.emu_ycbcr.argtypes = [C.c_uint32] * 3
+        L.emu_wire_roundtrip.restype = C.c_uint32
+        L.emu_wire_roundtrip.argtypes = [P, C.c_uint32, P]
         _lib = L
     return _lib
 

@@ -18,6 +18,7 @@
 #include "video_lane.h"
 #include "video_split_lane.h"
 #include "video_compact_lane.h"
+#include "video_wire_lane.h"
 
 using namespace mpg;
 
@@ -480,4 +481,32 @@ uint32_t emu_avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return avg4_
 uint32_t emu_avg2(uint32_t a, uint32_t b) { return avg_ceil_u8x4(a, b); }
 uint32_t emu_xcd_chunk(uint32_t b, uint32_t n) { return xcd_chunk(b, n); }
 uint32_t emu_ycbcr(uint32_t y, uint32_t cb, uint32_t cr) { return ycbcr_to_rgba(y, cb, cr); }
+
+// video_wire_lane.h: pack n dense units the way mpeghip_video_stage_put does, then rebuild them the way
+// wire_expand_kernel's lanes do.  Returns the dwords on the wire (headers + payload); out = n * 128 bytes.
+uint32_t emu_wire_roundtrip(const uint8_t *units, uint32_t n, uint8_t *out)
+{
+    std::vector<uint32_t> region((size_t)n * (1 + kWireUnitDwords) + 16);
+    uint32_t *hdr = region.data(), *payload = region.data() + n;
+    uint32_t used = 0;
+    for (uint32_t u = 0; u < n; u++)
+        hdr[u] = wire_pack_unit(units + (size_t)u * 128, payload, used);
+    alignas(16) uint8_t tile[1024];
+    for (uint32_t group = 0; group * 8 < n; group++) {
+        WireLane w[64];
+        memset(tile, 0xCD, sizeof(tile));
+        for (int lane = 0; lane < 64; lane++) {
+            const uint32_t unit = group * 8 + (uint32_t)(lane >> 3);
+            w[lane].live = unit < n;
+            w[lane].header = w[lane].live ? hdr[unit] : 0;
+            w[lane].payload = payload;
+            wire_phase_zero(tile, lane);
+        }
+        for (int lane = 0; lane < 64; lane++)
+            wire_phase_scatter(w[lane], tile, lane);
+        for (int lane = 0; lane < 64; lane++)
+            wire_phase_store(w[lane], tile, lane, out + (size_t)(group * 8 + (uint32_t)(lane >> 3)) * 128);
+    }
+    return n + used;
+}
 }

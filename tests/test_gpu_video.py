@@ -265,7 +265,8 @@ def test_staged_submit_equals_plain_submit(oracle, hip_ctx, threads):
     the merged arrays does; pictures of odd macroblock counts make chunks straddle picture boundaries."""
     w, h = 96, 80   # 6 x 5 = 30 macroblocks per picture: not a multiple of the 4-macroblock chunk
     n = 5
-    seqs = [synth.generate_sequence(w, h, 4, seed=300 + i, rgba=(i == 1)) for i in range(n)]
+    # stream 3: every block full (its units travel as they are, not as sparse entries: video_wire_lane.h)
+    seqs = [synth.generate_sequence(w, h, 4, seed=300 + i, rgba=(i == 1), profile="dense" if i == 3 else "typical") for i in range(n)]
     ref, dut = oracle.OracleStore(w, h, n), abi.VideoStore(hip_ctx, w, h, n)
     for step in range(4):
         pictures = []

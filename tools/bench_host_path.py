@@ -51,51 +51,33 @@ def submit_rate(ctx, streams, seconds=2.0):
     return n / dt, nbytes / dt
 
 
-def staged_rate(ctx, streams, threads, seconds=2.0):
+def staged_rate(dev, streams, threads, seconds=2.0):
     """mpeghip_video_stage_*: `streams` typical 1080p pictures per device call, each put (validation, record
-    expansion, copy into pinned staging) from one of `threads` host threads."""
-    from concurrent.futures import ThreadPoolExecutor
+    expansion, packing of the coefficient units into pinned staging) from one of `threads` host threads —
+    driven natively (mpeghost_staged_submit_rate in mpeg_amd/host/capi.cpp): a Python thread pool would be
+    the bottleneck."""
+    import hostlib
+    H = hostlib.host()
     seq = synth.generate_sequence(1920, 1080, 13, profile="typical")
-    store = abi.VideoStore(ctx, 1920, 1080, streams)
-    L = store.lib
-    steps = []
-    for s in seq:
-        pics = np.repeat(s.pics, streams)
-        pics["stream"] = np.arange(streams)
-        mbs = np.ascontiguousarray(s.mbs)
-        coefs = [np.array(s.coefs, copy=True) for _ in range(streams)]  # every stream its own coefficient array
-        n_mbs = np.full(streams, len(mbs), np.uint32)
-        nbytes = np.full(streams, s.coefs.nbytes, np.uint64)
-        steps.append((pics, mbs, coefs, n_mbs, nbytes))
-    ex = ThreadPoolExecutor(threads)
-
-    def run(step):
-        pics, mbs, coefs, n_mbs, nbytes = step
-        st = C.c_void_p()
-        abi._check(L.mpeghip_video_stage_begin(store.h, streams, n_mbs.ctypes.data, nbytes.ctypes.data, C.byref(st)))
-        base, item = pics.ctypes.data, pics.dtype.itemsize
-
-        def put(i):
-            return L.mpeghip_video_stage_put(st, i, base + i * item, mbs.ctypes.data, coefs[i].ctypes.data)
-
-        rcs = list(ex.map(put, range(streams)))
-        abi._check(L.mpeghip_video_stage_commit(st))
-        assert not any(rcs)
-
-    for step in steps:
-        run(step)
-    ctx.sync()
-    t0, n, nb = time.perf_counter(), 0, 0
-    while time.perf_counter() - t0 < seconds:
-        for step in steps:
-            run(step)
-            n += streams
-            nb += streams * (16 + step[1].nbytes + step[2][0].nbytes)
-    ctx.sync()
-    dt = time.perf_counter() - t0
-    ex.shutdown()
-    store.close()
-    return n / dt, nb / dt
+    n = len(seq)
+    pics = np.concatenate([s.pics[:1] for s in seq])
+    mbs = [np.ascontiguousarray(s.mbs) for s in seq]
+    coefs = [np.ascontiguousarray(s.coefs).view(np.uint8).reshape(-1) for s in seq]
+    mbs_p = (C.c_void_p * n)(*[m.ctypes.data for m in mbs])
+    coefs_p = (C.c_void_p * n)(*[c.ctypes.data for c in coefs])
+    n_mbs = np.array([len(m) for m in mbs], np.uint32)
+    nbytes = np.array([c.nbytes for c in coefs], np.uint64)
+    H.mpeghost_staged_submit_rate.restype = C.c_double
+    H.mpeghost_staged_submit_rate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    pps = H.mpeghost_staged_submit_rate(dev, 1920, 1080, streams, threads, seconds, n, pics.ctypes.data, mbs_p,
+                                        n_mbs.ctypes.data, coefs_p, nbytes.ctypes.data)
+    if pps < 0:
+        raise RuntimeError(H.mpeghost_last_error().decode())
+    dense = float(np.mean([16 + m.nbytes + c.nbytes for m, c in zip(mbs, coefs)]))
+    nz = [np.count_nonzero(c.view(np.int16).reshape(-1, 64), axis=1) for c in coefs]
+    wire = float(np.mean([16 + 16 + len(m) * 48 + 4 * len(k) + 4 * np.where(k <= 31, k, 32).sum() for m, k in zip(mbs, nz)]))
+    return pps, dense, wire
 
 
 def main():
@@ -105,14 +87,17 @@ def main():
         pps, bps = submit_rate(ctx, streams)
         print("submit, %2d stream(s)/call: %8.0f pictures/s = %.3f G macroblocks/s, %.2f GB/s of descriptors+coefficients over PCIe"
               % (streams, pps, pps * 8160 / 1e9, bps / 1e9))
-    for streams, threads in ((64, 1), (64, 8), (64, 32), (256, 32)):
-        threads = min(threads, os.cpu_count() or 1)
-        pps, bps = staged_rate(ctx, streams, threads)
-        print("staged submit, %3d pictures/call put by %2d host thread(s): %8.0f pictures/s = %.3f G macroblocks/s, %.2f GB/s of "
-              "descriptors+coefficients" % (streams, threads, pps, pps * 8160 / 1e9, bps / 1e9))
     ctx.close()
 
     import hostlib
+    dev = hostlib.host().mpeghost_device_create(0)
+    for streams, threads in ((64, 1), (64, 8), (64, 32), (256, 32), (512, 32)):
+        threads = min(threads, os.cpu_count() or 1)
+        pps, dense, wire = staged_rate(dev, streams, threads)
+        print("staged submit, %4d pictures/call put by %2d host thread(s): %8.0f pictures/s = %.3f G macroblocks/s; per picture "
+              "%.2f MB as the ABI hands it over, %.2f MB on the wire (records + packed units) = %.1f GB/s over PCIe"
+              % (streams, threads, pps, pps * 8160 / 1e9, dense / 1e6, wire / 1e6, pps * wire / 1e9))
+    hostlib.host().mpeghost_device_destroy(dev)
     from oracle import pyoracle
     ps = (ROOT / "tests" / "golden" / "test.mpg").read_bytes()
     dev = hostlib.host().mpeghost_device_create(0)
