@@ -42,3 +42,6 @@ cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $OUT 2>&1 | tee $OUT/pmc_summary.txt
 find $OUT -name "*.csv" -size +5M -delete
 du -sh $OUT
+echo "== bench with the host-fed leg (separate run: it launches the kernel on small batches)"
+timeout 600 python bench.py --cpu-seconds 0 --audio-streams 0 --rgba-streams 0 --host-fed-seconds 2 "$@" > $OUT/bench_host_fed.json 2> $OUT/bench_host_fed.err; echo "bench host-fed rc=$?"
+python -c "import json,sys; d=json.loads(open('$OUT/bench_host_fed.json').read().strip().splitlines()[-1]); print(d['host_fed'])"
