@@ -563,8 +563,12 @@ struct mpeghip_batch {
     uint32_t *d_xmbs = nullptr;       // expanded records of the wave-chunk kernel (mode 6)
     uint32_t *d_wire = nullptr;       // staged submits: coefficient units in wire form (video_wire_lane.h)
     void *d_wtab = nullptr;           //                 one WireTab per picture
-    uint8_t *d_blob = nullptr;        // staged submits: d_pics, d_wtab, d_xmbs, d_wire are parts of this one allocation
-    size_t cap_blob = 0;              //                 (the image of the staging buffer: one H2D copy per commit)
+    // Submits that come through a pinned staging buffer keep its device image in ONE allocation, filled by one
+    // H2D copy: staged submits pictures | WireTab | records | wire regions (d_coefs is separate: the units
+    // rebuilt by wire_expand_kernel), plain submits pictures | descriptors | records | coefficients.
+    enum Form { Separate, StageBlob, SubmitBlob } form = Separate;
+    uint8_t *d_blob = nullptr;
+    size_t cap_blob = 0;
     uint8_t *d_coefs = nullptr;
     uint64_t n_pics = 0, n_mbs = 0, coef_bytes = 0;
     uint64_t alg_bytes = 0;
@@ -605,6 +609,8 @@ struct mpeghip_video {
     } staging[2];
     int next_staging = 0;
     struct mpeghip_stage *stage = nullptr; // the open mpeghip_video_stage_begin, if any
+    uint8_t *bounce = nullptr;             // pinned: read_planes / read_rgba land here first
+    size_t bounce_cap = 0;
 };
 
 // mpeghip_video_stage_*: one submit assembled in a staging buffer by several host threads
@@ -858,18 +864,25 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
     return MPEGHIP_OK;
 }
 
-// d_pics / d_xmbs (+ d_wtab, d_wire) are either allocations of their own (plain submits, resident batches) or parts
-// of d_blob (staged submits); a staging batch may change from one form to the other between submits.
+// The descriptor arrays are either allocations of their own (resident batches) or parts of d_blob; a staging
+// batch may change from one blob form to the other between submits.
 static void batch_drop_descriptors(mpeghip_batch *b)
 {
-    if (b->d_blob) {
-        (void)hipFree(b->d_blob);
-    } else {
+    if (b->form == mpeghip_batch::Separate) {
         if (b->d_pics)
             (void)hipFree(b->d_pics);
         if (b->d_xmbs)
             (void)hipFree(b->d_xmbs);
+    } else {
+        if (b->d_blob)
+            (void)hipFree(b->d_blob);
+        if (b->form == mpeghip_batch::SubmitBlob) { // these were parts of the blob as well
+            b->d_mbs = nullptr;
+            b->d_coefs = nullptr;
+            b->cap_mbs = b->cap_coefs = 0;
+        }
     }
+    b->form = mpeghip_batch::Separate;
     b->d_blob = nullptr;
     b->cap_blob = 0;
     b->d_pics = nullptr;
@@ -907,6 +920,8 @@ void mpeghip_video_close(mpeghip_video *v)
     (void)hipStreamSynchronize(v->ctx->stream);
     delete v->stage; // a stage that was begun and never committed
     v->stage = nullptr;
+    if (v->bounce)
+        (void)hipHostFree(v->bounce);
     for (auto &sg : v->staging) {
         batch_release(&sg.batch);
         if (sg.h)
@@ -1355,22 +1370,46 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
         mbs = reinterpret_cast<const mpeghip_mb_desc *>(sg->h + pb);
         coefs = sg->h + coef_at;
     }
-    if (b->d_blob) // (a staging batch last used by a staged submit)
-        batch_drop_descriptors(b);
-    if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
-        (rc = grow((void **)&b->d_mbs, &b->cap_mbs, mb * replicas + 32)) != 0 ||
-        (rc = grow((void **)&b->d_xmbs, &b->cap_xmbs, xb * replicas + 64 * kWcMbs)) != 0 ||
-        (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0 ||
-        (rc = grow((void **)&b->d_entries, &b->cap_entries, (coef_bytes / MPEGHIP_COEF_UNIT) * replicas * sizeof(BlockEntry) + 64)) != 0)
-        return rc;
-    if (pb)
-        HIP_TRY(hipMemcpyAsync(b->d_pics, pics, pb, hipMemcpyHostToDevice, st));
-    if (mb)
-        HIP_TRY(hipMemcpyAsync(b->d_mbs, mbs, mb, hipMemcpyHostToDevice, st));
-    if (xb)
-        HIP_TRY(hipMemcpyAsync(b->d_xmbs, xrec, xb, hipMemcpyHostToDevice, st));
-    if (coef_bytes)
-        HIP_TRY(hipMemcpyAsync(b->d_coefs, coefs, coef_bytes, hipMemcpyHostToDevice, st));
+    if (sg) {
+        // one allocation = the image of the staging buffer, one copy
+        if (b->form != mpeghip_batch::SubmitBlob) {
+            batch_drop_descriptors(b);
+            if (b->d_mbs) // allocations of their own so far; parts of the blob from now on
+                (void)hipFree(b->d_mbs);
+            if (b->d_coefs)
+                (void)hipFree(b->d_coefs);
+            b->d_mbs = nullptr;
+            b->d_coefs = nullptr;
+            b->cap_mbs = b->cap_coefs = 0;
+        }
+        b->form = mpeghip_batch::SubmitBlob;
+        const size_t total = coef_at + coef_bytes;
+        if ((rc = grow((void **)&b->d_blob, &b->cap_blob, total + 256)) != 0 ||
+            (rc = grow((void **)&b->d_entries, &b->cap_entries, (coef_bytes / MPEGHIP_COEF_UNIT) * sizeof(BlockEntry) + 64)) != 0)
+            return rc;
+        b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
+        b->d_mbs = reinterpret_cast<mpeghip_mb_desc *>(b->d_blob + pb);
+        b->d_xmbs = reinterpret_cast<uint32_t *>(b->d_blob + x_at);
+        b->d_coefs = b->d_blob + coef_at;
+        HIP_TRY(hipMemcpyAsync(b->d_blob, sg->h, total, hipMemcpyHostToDevice, st));
+    } else {
+        if (b->form != mpeghip_batch::Separate)
+            batch_drop_descriptors(b);
+        if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
+            (rc = grow((void **)&b->d_mbs, &b->cap_mbs, mb * replicas + 32)) != 0 ||
+            (rc = grow((void **)&b->d_xmbs, &b->cap_xmbs, xb * replicas + 64 * kWcMbs)) != 0 ||
+            (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0 ||
+            (rc = grow((void **)&b->d_entries, &b->cap_entries, (coef_bytes / MPEGHIP_COEF_UNIT) * replicas * sizeof(BlockEntry) + 64)) != 0)
+            return rc;
+        if (pb)
+            HIP_TRY(hipMemcpyAsync(b->d_pics, pics, pb, hipMemcpyHostToDevice, st));
+        if (mb)
+            HIP_TRY(hipMemcpyAsync(b->d_mbs, mbs, mb, hipMemcpyHostToDevice, st));
+        if (xb)
+            HIP_TRY(hipMemcpyAsync(b->d_xmbs, xrec, xb, hipMemcpyHostToDevice, st));
+        if (coef_bytes)
+            HIP_TRY(hipMemcpyAsync(b->d_coefs, coefs, coef_bytes, hipMemcpyHostToDevice, st));
+    }
     if (replicas > 1) {
         for (uint32_t s = 1; s < replicas && coef_bytes; s++)
             HIP_TRY(hipMemcpyAsync(b->d_coefs + (size_t)s * coef_bytes, b->d_coefs, coef_bytes, hipMemcpyDeviceToDevice, st));
@@ -1592,8 +1631,9 @@ int mpeghip_video_stage_commit(mpeghip_stage *sp)
     // the device image of the staging buffer: pictures | WireTab | records | wire regions, sent in ONE copy
     // (a copy costs the better part of a millisecond of stream time whatever its size)
     const size_t cb = s->coef_units * MPEGHIP_COEF_UNIT;
-    if (!b->d_blob)
+    if (b->form != mpeghip_batch::StageBlob)
         batch_drop_descriptors(b); // (the batch was last used by a plain submit)
+    b->form = mpeghip_batch::StageBlob;
     if ((rc = grow((void **)&b->d_blob, &b->cap_blob, s->wire0 + (size_t)s->wire_cap_dwords * 4 + 256)) != 0 ||
         (rc = grow((void **)&b->d_coefs, &b->cap_coefs, cb + 256)) != 0)
         return rc;
@@ -1723,16 +1763,28 @@ int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, 
 {
     if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
-    v->rgba_sync[(size_t)stream * MPEGHIP_SLOTS + slot] = 0; // (write_planes: the image is out of date now)
     HIP_TRY(hipSetDevice(v->ctx->device));
-    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
-    const uint8_t *p = slot_ptr(v, stream, slot);
+    // Y, Cb, Cr are one contiguous range of the slot: ONE copy into a pinned bounce buffer behind everything
+    // queued on the stream, then plain memcpys (three synchronous copies into pageable memory cost three
+    // round trips — most of a small picture's turnaround)
+    const size_t bytes = v->info.luma_bytes + 2 * v->info.chroma_bytes;
+    if (v->bounce_cap < bytes) {
+        if (v->bounce)
+            (void)hipHostFree(v->bounce);
+        v->bounce = nullptr;
+        v->bounce_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&v->bounce, bytes, hipHostMallocDefault));
+        v->bounce_cap = bytes;
+    }
+    hipStream_t st = v->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(v->bounce, slot_ptr(v, stream, slot), bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (y)
-        HIP_TRY(hipMemcpy(y, p, v->info.luma_bytes, hipMemcpyDeviceToHost));
+        memcpy(y, v->bounce, v->info.luma_bytes);
     if (cb)
-        HIP_TRY(hipMemcpy(cb, p + v->info.luma_bytes, v->info.chroma_bytes, hipMemcpyDeviceToHost));
+        memcpy(cb, v->bounce + v->info.luma_bytes, v->info.chroma_bytes);
     if (cr)
-        HIP_TRY(hipMemcpy(cr, p + v->info.luma_bytes + v->info.chroma_bytes, v->info.chroma_bytes, hipMemcpyDeviceToHost));
+        memcpy(cr, v->bounce + v->info.luma_bytes + v->info.chroma_bytes, v->info.chroma_bytes);
     return MPEGHIP_OK;
 }
 
@@ -1741,6 +1793,7 @@ int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
 {
     if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
+    v->rgba_sync[(size_t)stream * MPEGHIP_SLOTS + slot] = 0; // the slot's RGBA image is out of date now
     HIP_TRY(hipSetDevice(v->ctx->device));
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
     uint8_t *p = slot_ptr(v, stream, slot);

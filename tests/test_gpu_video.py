@@ -310,6 +310,41 @@ def test_staged_submit_refuses_a_bad_picture(hip_ctx):
     dut.close()
 
 
+@pytest.mark.gpu
+def test_stage_protocol_errors(hip_ctx):
+    """One stage at a time; no plain submit while it is open; a commit with a picture missing launches nothing;
+    every error leaves the store usable."""
+    import ctypes as C
+    w, h = 96, 80
+    s = synth.generate_sequence(w, h, 2, seed=11)[0]
+    dut = abi.VideoStore(hip_ctx, w, h, 2)
+    L = dut.lib
+    pics, mbs, coefs = dut._args(s.pics, s.mbs, s.coefs)
+    n_mbs = np.array([len(mbs)] * 2, np.uint32)
+    nbytes = np.array([coefs.nbytes] * 2, np.uint64)
+    st = C.c_void_p()
+    assert L.mpeghip_video_stage_begin(dut.h, 2, n_mbs.ctypes.data, nbytes.ctypes.data, C.byref(st)) == 0
+    st2 = C.c_void_p()
+    assert L.mpeghip_video_stage_begin(dut.h, 2, n_mbs.ctypes.data, nbytes.ctypes.data, C.byref(st2)) != 0
+    assert b"still open" in L.mpeghip_last_error()
+    with pytest.raises(abi.MpegHipError, match="stage is open"):
+        dut.submit(s.pics, s.mbs, s.coefs)
+    assert L.mpeghip_video_stage_put(st, 5, pics.ctypes.data, mbs.ctypes.data, coefs.ctypes.data) != 0   # no such picture
+    st_err = L.mpeghip_video_stage_commit(st)
+    assert st_err != 0 and b"picture 5 of 2" in L.mpeghip_last_error()
+    assert L.mpeghip_video_stage_begin(dut.h, 2, n_mbs.ctypes.data, nbytes.ctypes.data, C.byref(st)) == 0
+    assert L.mpeghip_video_stage_put(st, 0, pics.ctypes.data, mbs.ctypes.data, coefs.ctypes.data) == 0
+    assert L.mpeghip_video_stage_commit(st) != 0 and b"never put" in L.mpeghip_last_error()
+    cur = int(s.pics[0]["cur"])
+    assert not dut.read_planes(0, cur)[0].any()          # nothing was launched
+    dut.submit(s.pics, s.mbs, s.coefs)                    # and the store goes on working
+    assert dut.read_planes(0, cur)[0].any()
+    # an empty stage is legal
+    assert L.mpeghip_video_stage_begin(dut.h, 0, None, None, C.byref(st)) == 0
+    assert L.mpeghip_video_stage_commit(st) == 0
+    dut.close()
+
+
 def test_streams_are_independent(oracle, hip_ctx):
     """Different streams decode different pictures in ONE submit without interfering."""
     w, h = 96, 80
