@@ -139,6 +139,39 @@ def test_video_batch_on_gpu(oracle, golden_dir, device):
     assert (h4, n4) == (h, n) and c4["device_submits"] <= c["device_submits"]
 
 
+def test_written_1080p_stream_through_the_parser_and_the_gpu(oracle, device):
+    """A 1920x1080 stream (tests/mpeg1_writer.py over the seeded descriptor generator: I P B B, the typical mix) through
+    the PRODUCT PATH — bitstream parser -> descriptors -> C ABI -> kernels — frame by frame against the oracle's
+    reconstruction of the descriptors the stream was written from; then six copies of it through mpeg::VideoBatch
+    with three parse threads (staged submits)."""
+    import mpeg1_writer
+    from mpeg_amd import synth
+    from test_written_streams import decode_all, expected_frames
+    w, h = 1920, 1080
+    seq = synth.generate_sequence(w, h, 4, seed=0x1080)
+    es = mpeg1_writer.write_sequence(w, h, seq)
+    want = expected_frames(oracle, w, h, seq)
+    assert len(want) == 3                      # I, B, B (the P picture is still held when the stream ends on a B)
+    dut = hostlib.HostVideo(es, device=device)
+    got = decode_all(dut, hostlib.frame_planes)
+    st = dut.stats()
+    dut.close()
+    assert len(got) == len(want) and st["pictures"] == 4 and st["invalid_blocks"] == 0 and st["range_skips"] == 0
+    for i, (a, b) in enumerate(zip(want, got)):
+        for pa, pb in zip(a, b):
+            assert np.array_equal(pa, pb), "frame %d" % i
+    b = hostlib.HostBatch(6, device=device, threads=3)
+    for _ in range(6):
+        b.add_stream(es)
+    for i in range(len(want)):
+        assert b.decode_all() == 6
+        for k in range(6):
+            for pa, pb in zip(want[i], hostlib.frame_planes(b.frame(k))):
+                assert np.array_equal(pa, pb), "batch: stream %d frame %d" % (k, i)
+    assert b.decode_all() == 0
+    b.close()
+
+
 def test_audio_batch_on_gpu(oracle, device):
     """mpeg::AudioBatch over the HIP store: staggered MP2 streams, one synthesis call per tick, every stream's
     samples hash to the reference's golden value (tests/test_host_batch.py runs the same on the lane emulator)."""

@@ -145,6 +145,30 @@ def main():
         print("config 1 x %d streams, VideoBatch, %d parse thread(s) (%s): %d pictures in %.1f ms = %.0f pictures/s, %d device calls for %d pictures"
               % (n_streams, threads, "frames read back" if fetch else "frames stay on the device", frames, dt * 1e3, frames / dt,
                  c["device_submits"], c["queued_pictures"]))
+    # a 1080p stream (tests/mpeg1_writer.py over the bench's own descriptor generator) through the whole product
+    # path — parse included — as N streams of mpeg::VideoBatch
+    import mpeg1_writer
+    seq = synth.generate_sequence(1920, 1080, 13, profile="typical")
+    es = mpeg1_writer.write_sequence(1920, 1080, seq)
+    print("1080p written stream: %d pictures, %.2f MB (%.0f kB per picture: every AC coefficient an escape code)"
+          % (len(seq), len(es) / 1e6, len(es) / len(seq) / 1e3))
+    for n_streams, threads in ((1, 1), (32, 1), (32, 8), (64, many), (128, many)):
+        b = hostlib.HostBatch(n_streams, device=dev, threads=threads)
+        for _ in range(n_streams):
+            b.add_stream(es)
+        t0, frames = time.perf_counter(), 0
+        while True:
+            k = b.decode_all(fetch=False)
+            if k == 0:
+                break
+            frames += k
+        dt = time.perf_counter() - t0
+        c = b.counters()
+        b.close()
+        print("1080p stream x %d streams, VideoBatch, %d parse thread(s), frames stay on the device: %d pictures parsed + "
+              "reconstructed in %.1f ms = %.0f pictures/s = %.3f G macroblocks/s (%d device calls)"
+              % (n_streams, threads, c["queued_pictures"], dt * 1e3, c["queued_pictures"] / dt,
+                 c["queued_pictures"] / dt * 8160 / 1e9, c["device_submits"]))
     hostlib.host().mpeghost_device_destroy(dev)
 
 

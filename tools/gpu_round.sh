@@ -38,8 +38,16 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_I
   timeout 600 rocprofv3 --pmc $SET --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-seconds 0 --check 0 --audio-streams 0 --rgba-streams 0 "$@" > $GRAFT_REPO_ROOT/$OUT/pmc_$N.log 2>&1
   echo "pmc [$SET] rc=$?"
 done
+mkdir -p $GRAFT_REPO_ROOT/$OUT/dense
+for SET in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $GRAFT_REPO_ROOT/$OUT/dense/pmc_$SET -o pmc -- python $GRAFT_REPO_ROOT/bench.py --profile dense --steps 4 --warmup 2 --cpu-seconds 0 --check 0 --audio-streams 0 --rgba-streams 0 "$@" > $GRAFT_REPO_ROOT/$OUT/dense/pmc_$SET.log 2>&1
+  echo "pmc dense [$SET] rc=$?"
+done
 cd $GRAFT_REPO_ROOT
+mv $OUT/dense /tmp/dense_pmc_$TAG
 python tools/pmc_summary.py $OUT 2>&1 | tee $OUT/pmc_summary.txt
+echo "#### dense profile" | tee -a $OUT/pmc_summary.txt
+python tools/pmc_summary.py /tmp/dense_pmc_$TAG 2>&1 | tee -a $OUT/pmc_summary.txt
 find $OUT -name "*.csv" -size +5M -delete
 du -sh $OUT
 echo "== bench with the host-fed leg (separate run: it launches the kernel on small batches)"
