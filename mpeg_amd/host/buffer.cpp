@@ -117,37 +117,6 @@ bool Buffer::has(size_t count)
     return false;
 }
 
-uint32_t Buffer::peek(int count)
-{
-    // up to 24 bits starting at the cursor, zero-padded past the end (the reference
-    // would index out of range and panic there)
-    const size_t byte = bit_index_ >> 3, n = bytes_.size();
-    uint32_t w = 0;
-    for (size_t k = 0; k < 4; k++)
-        w = (w << 8) | (byte + k < n ? bytes_[byte + k] : 0u);
-    w <<= (bit_index_ & 7);
-    return count ? w >> (32 - count) : 0;
-}
-
-int Buffer::read(int count)
-{ // buffer.go:223-244
-    int value = 0;
-    while (count > 0) {
-        int take = count > 16 ? 16 : count;
-        value = (value << take) | (int)peek(take);
-        bit_index_ += (size_t)take;
-        count -= take;
-    }
-    return value;
-}
-
-int Buffer::read1()
-{ // buffer.go:246-255
-    int v = (int)peek(1);
-    bit_index_++;
-    return v;
-}
-
 void Buffer::skip(size_t count)
 { // buffer.go:261-265
     if (has(count))
@@ -166,18 +135,29 @@ int Buffer::skipBytes(uint8_t v)
 }
 
 int Buffer::nextStartCode()
-{ // buffer.go:279-302
+{ // buffer.go:279-302: the first byte position i at or after the cursor with 00 00 01 xx inside the
+  // buffered bytes (i + 5 <= size); same result and same final cursor as the reference's byte-by-byte
+  // walk, found by looking for the 01 bytes (memchr) — this scan runs over every picture twice
+  // (hasStartCode's look-ahead, then the slices), a third of the parser's time when done bytewise.
     align();
     for (;;) {
-        while ((bytes_.size() << 3) >= bit_index_ + (5 << 3)) {
-            const size_t i = bit_index_ >> 3;
-            const uint8_t *d = bytes_.data();
-            if (d[i] == 0 && d[i + 1] == 0 && d[i + 2] == 1) {
-                bit_index_ = (i + 4) << 3;
-                return d[i + 3];
+        const uint8_t *d = bytes_.data();
+        const size_t n = bytes_.size();
+        size_t i = bit_index_ >> 3;
+        while (i + 5 <= n) {
+            const uint8_t *p = static_cast<const uint8_t *>(memchr(d + i + 2, 1, (n - 2) - (i + 2)));
+            if (!p) {
+                i = n - 4; // where the bytewise walk stops: fewer than 5 bytes left
+                break;
             }
-            bit_index_ += 8;
+            const size_t k = (size_t)(p - d);
+            if (d[k - 1] == 0 && d[k - 2] == 0) {
+                bit_index_ = (k + 2) << 3;
+                return d[k + 1];
+            }
+            i = k - 1; // the next candidate has its 01 byte behind this one
         }
+        bit_index_ = i << 3;
         if (!has(5 << 3))
             return -1;
     }

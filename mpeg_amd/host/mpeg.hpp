@@ -16,6 +16,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <functional>
 #include <map>
@@ -68,9 +69,40 @@ public:
     size_t tell();
     void discardReadBytes();
     bool has(size_t count);
-    int read(int count);
-    int read1();
-    uint32_t peek(int count);            // next `count` (<= 24) bits, zero-padded past the end
+    // next `count` (<= 24) bits, zero-padded past the end (the reference would index out of range and panic
+    // there).  Inline: the parser spends its time here.
+    uint32_t peek(int count) const
+    {
+        const size_t byte = bit_index_ >> 3, n = bytes_.size();
+        uint32_t w;
+        if (byte + 4 <= n) {
+            memcpy(&w, bytes_.data() + byte, 4);
+            w = __builtin_bswap32(w);
+        } else {
+            w = 0;
+            for (size_t k = 0; k < 4; k++)
+                w = (w << 8) | (byte + k < n ? bytes_[byte + k] : 0u);
+        }
+        w <<= (bit_index_ & 7);
+        return count ? w >> (32 - count) : 0;
+    }
+    int read(int count)
+    { // buffer.go:223-244
+        int value = 0;
+        while (count > 0) {
+            const int take = count > 16 ? 16 : count;
+            value = (value << take) | (int)peek(take);
+            bit_index_ += (size_t)take;
+            count -= take;
+        }
+        return value;
+    }
+    int read1()
+    { // buffer.go:246-255
+        const int v = (int)peek(1);
+        bit_index_++;
+        return v;
+    }
     void drop(int count) { bit_index_ += (size_t)count; }
     void align() { bit_index_ = ((bit_index_ + 7) >> 3) << 3; }
     void skip(size_t count);

@@ -354,7 +354,11 @@ void Video::beginMacroblockRecord(bool intra)
         stats_.duplicate_splits++;
     }
     written_[addr] = 1;
-    rec_ = MbRec();
+    // (not `rec_ = MbRec()`: that clears 2.3 KB of block storage per macroblock; a block is reset by its own
+    // decodeBlock, and endMacroblockRecord only looks at the blocks of this macroblock's pattern)
+    rec_.has_pred = rec_.backward = rec_.any_raw = false;
+    rec_.mv_x = rec_.mv_y = 0;
+    rec_.cbp = 0;
     rec_.active = true;
     rec_.intra = intra;
     rec_.mb_x = mb_col_;

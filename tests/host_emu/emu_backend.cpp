@@ -255,6 +255,16 @@ void host_emu_configure(int flavour, const float *window512)
     memcpy(g_window, window512, sizeof(g_window));
 }
 void *host_emu_make_video(void) { return new EmuVideoBackend(g_flavour); }
+// A store that swallows everything: what is left of a decode is the parser's own time (tools/bench_parse.py)
+class NullBatchStore : public mpeg::BatchStore {
+public:
+    void open(int, int, uint32_t) override {}
+    void setQuant(uint32_t, const uint8_t[64], const uint8_t[64]) override {}
+    void submit(const mpeghip_pic_desc *, uint32_t, const mpeghip_mb_desc *, uint32_t, const uint8_t *, size_t) override {}
+    void readPlanes(uint32_t, uint32_t, uint8_t *, uint8_t *, uint8_t *) override {}
+    void readRGBA(uint32_t, uint32_t, uint8_t *) override {}
+};
+void *host_emu_null_batch_store(void) { return new NullBatchStore(); }
 void *host_emu_batch_store(void) { return new EmuBatchStore(); }
 // staged submits the store has seen (valid while the batch that owns the store is open)
 uint64_t host_emu_batch_store_staged_commits(void *store) { return static_cast<EmuBatchStore *>(static_cast<mpeg::BatchStore *>(store))->staged_commits_; }
