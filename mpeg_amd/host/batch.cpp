@@ -32,13 +32,21 @@ public:
         std::vector<uint8_t> coefs;
     };
     Port(VideoBatch *b, uint32_t stream) : b_(b), stream_(stream) {}
+    // events[0 .. n_events) are this round's; the objects (and the capacity of their vectors: a 1080p picture is
+    // 2.5 MB, and fresh allocations of that size are mmap + page faults, which serialise the pool) are reused
+    Event &nextEvent()
+    {
+        if (n_events == events.size())
+            events.emplace_back();
+        return events[n_events++];
+    }
     void open(int width, int height) override
     {
         if (recording) {
-            events.emplace_back();
-            events.back().kind = Event::Open;
-            events.back().width = width;
-            events.back().height = height;
+            Event &e = nextEvent();
+            e.kind = Event::Open;
+            e.width = width;
+            e.height = height;
             return;
         }
         b_->openStore(width, height);
@@ -46,10 +54,10 @@ public:
     void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override
     {
         if (recording) {
-            events.emplace_back();
-            events.back().kind = Event::Quant;
-            memcpy(events.back().quant, intra, 64);
-            memcpy(events.back().quant + 64, non_intra, 64);
+            Event &e = nextEvent();
+            e.kind = Event::Quant;
+            memcpy(e.quant, intra, 64);
+            memcpy(e.quant + 64, non_intra, 64);
             return;
         }
         b_->Flush(); // the table belongs to pictures not yet queued
@@ -59,8 +67,7 @@ public:
                 size_t coef_bytes) override
     {
         if (recording) {
-            events.emplace_back();
-            Event &e = events.back();
+            Event &e = nextEvent();
             e.kind = Event::Submit;
             e.pic = pic;
             e.mbs.assign(mbs, mbs + n_mbs);
@@ -98,6 +105,7 @@ public:
     }
     bool recording = false;
     std::vector<Event> events;
+    size_t n_events = 0;
 
 private:
     VideoBatch *b_;
@@ -298,7 +306,7 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                 ports_[i]->recording = false;
             if (failed) {
                 for (uint32_t i : todo)
-                    ports_[i]->events.clear();
+                    ports_[i]->n_events = 0;
                 std::rethrow_exception(failed);
             }
             // ... then replay them here: the k-th request of every stream, in stream order (requests of
@@ -308,7 +316,7 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
             // them merged through queue().
             size_t most = 0;
             for (uint32_t i : todo)
-                most = ports_[i]->events.size() > most ? ports_[i]->events.size() : most;
+                most = ports_[i]->n_events > most ? ports_[i]->n_events : most;
             std::vector<const Port::Event *> group;
             std::vector<uint32_t> group_stream;
             std::vector<uint8_t> in_group(videos_.size(), 0);
@@ -367,7 +375,7 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
             try {
                 for (size_t k = 0; k < most; k++)
                     for (uint32_t i : todo) {
-                        if (k >= ports_[i]->events.size())
+                        if (k >= ports_[i]->n_events)
                             continue;
                         const Port::Event &e = ports_[i]->events[k];
                         if (e.kind != Port::Event::Submit) {
@@ -384,11 +392,11 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                 run_group();
             } catch (...) {
                 for (uint32_t i : todo)
-                    ports_[i]->events.clear();
+                    ports_[i]->n_events = 0;
                 throw;
             }
             for (uint32_t i : todo)
-                ports_[i]->events.clear();
+                ports_[i]->n_events = 0;
         } else {
             for (uint32_t i : todo)
                 result[i] = videos_[i]->DecodeStep(&slot[i], &time[i]);
