@@ -450,10 +450,14 @@ void Video::endMacroblockRecord()
         } else {
             const size_t at = coefs_.size();
             coefs_.resize(at + MPEGHIP_COEF_UNIT);
+            // column-major (the resize zero-filled the unit): only the positions the block's levels went to
             int16_t *dst = reinterpret_cast<int16_t *>(coefs_.data() + at);
-            for (int r = 0; r < 8; r++)
-                for (int c = 0; c < 8; c++)
-                    dst[c * 8 + r] = br.q[r * 8 + c];
+            if (rec_.intra)
+                dst[0] = br.q[0];
+            for (int k = 0; k < br.n_touched; k++) {
+                const int i = br.touched[k];
+                dst[(i & 7) * 8 + (i >> 3)] = br.q[i];
+            }
         }
     }
     if (raw)
@@ -646,23 +650,32 @@ void Video::decodeBlock(int block)
         quant_matrix = non_intra_quant_;
     }
 
-    int touched[64], n_touched = 0; // natural indices written by this block, in scan order
+    uint8_t *touched = br.touched; // natural indices written by this block, in scan order
+    int n_touched = 0;
+    br.n_touched = 0;
     int level = 0;
     bool invalid = false;
+    const VlcTable &coeff_table = tabCoeff();
     for (;;) {
         int run;
-        const int coeff = tabCoeff().read(buf_);
+        const int coeff = coeff_table.read(buf_);
         if (coeff == 0x0001 && n > 0 && buf_->read1() == 0)
             break; // end_of_block
-        if (coeff == 0xffff) { // escape
-            run = buf_->read(6);
-            level = buf_->read(8);
-            if (level == 0)
-                level = buf_->read(8);
-            else if (level == 128)
-                level = buf_->read(8) - 256;
-            else if (level > 128)
+        if (coeff == 0xffff) { // escape: run (6 bits), level (8 bits, or 8 + 8) — one look at the next 22 bits
+            const uint32_t w = buf_->peek(22);
+            run = (int)(w >> 16);
+            level = (int)((w >> 8) & 0xff);
+            int used = 14;
+            if (level == 0) {
+                level = (int)(w & 0xff);
+                used = 22;
+            } else if (level == 128) {
+                level = (int)(w & 0xff) - 256;
+                used = 22;
+            } else if (level > 128) {
                 level -= 256;
+            }
+            buf_->drop(used);
         } else {
             run = coeff >> 8;
             level = coeff & 0xff;
@@ -679,7 +692,8 @@ void Video::decodeBlock(int block)
         if (level == 0)
             explicit_zero = true; // dequantises to +-1, which "0 = absent" cannot express
         br.q[dz] = (int16_t)level;
-        touched[n_touched++] = dz;
+        touched[n_touched++] = (uint8_t)dz;
+        br.n_touched = n_touched;
         if (dirty_at_start)
             block_data_[dz] = dequantPremult(level, macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
     }
