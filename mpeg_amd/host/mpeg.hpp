@@ -86,6 +86,21 @@ public:
         w <<= (bit_index_ & 7);
         return count ? w >> (32 - count) : 0;
     }
+    // the next 57+ bits, left-aligned in 64, zero-padded past the end: several fields per look
+    uint64_t window() const
+    {
+        const size_t byte = bit_index_ >> 3, n = bytes_.size();
+        uint64_t w;
+        if (byte + 8 <= n) {
+            memcpy(&w, bytes_.data() + byte, 8);
+            w = __builtin_bswap64(w);
+        } else {
+            w = 0;
+            for (size_t k = 0; k < 8; k++)
+                w = (w << 8) | (byte + k < n ? bytes_[byte + k] : 0u);
+        }
+        return w << (bit_index_ & 7);
+    }
     int read(int count)
     { // buffer.go:223-244
         int value = 0;

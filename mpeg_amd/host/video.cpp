@@ -657,30 +657,40 @@ void Video::decodeBlock(int block)
     bool invalid = false;
     const VlcTable &coeff_table = tabCoeff();
     for (;;) {
+        // One 64-bit look at the stream per coefficient: the code (<= 17 bits), then either its sign bit or the
+        // escape's run and level (<= 22 bits) — same fields, same order, same consumption as video.go:685-707
+        // reads them one by one; the dependent chain cursor -> load -> table -> cursor is walked once, not thrice.
         int run;
-        const int coeff = coeff_table.read(buf_);
-        if (coeff == 0x0001 && n > 0 && buf_->read1() == 0)
-            break; // end_of_block
-        if (coeff == 0xffff) { // escape: run (6 bits), level (8 bits, or 8 + 8) — one look at the next 22 bits
-            const uint32_t w = buf_->peek(22);
-            run = (int)(w >> 16);
-            level = (int)((w >> 8) & 0xff);
-            int used = 14;
-            if (level == 0) {
-                level = (int)(w & 0xff);
-                used = 22;
-            } else if (level == 128) {
-                level = (int)(w & 0xff) - 256;
-                used = 22;
-            } else if (level > 128) {
-                level -= 256;
+        const uint64_t w = buf_->window();
+        const VlcTable::Symbol sym = coeff_table.at(w);
+        const int coeff = sym.value;
+        uint64_t rest = w << sym.len; // what follows the code
+        int taken = sym.len;
+        if (coeff == 0x0001 && n > 0) { // '1' after the first coefficient: '10' = end_of_block, '11s' = run 0, level 1
+            taken++;
+            if ((rest >> 63) == 0) {
+                buf_->drop(taken);
+                break;
             }
-            buf_->drop(used);
+            rest <<= 1;
+        }
+        if (coeff == 0xffff) { // escape: run (6 bits), level (8 bits, or 8 + 8)
+            const uint32_t f = (uint32_t)(rest >> (64 - 22));
+            run = (int)(f >> 16);
+            const int b = (int)((f >> 8) & 0xff);
+            int used = 14;
+            if (b & 0x7f) {
+                level = (int8_t)b; // -127 .. 127, without a branch on the sign (it is a coin flip)
+            } else {               // 0x00 / 0x80: the level is in the next 8 bits (128 .. 255 / -255 .. -129)
+                level = (int)(f & 0xff) - (b ? 256 : 0);
+                used = 22;
+            }
+            buf_->drop(taken + used);
         } else {
             run = coeff >> 8;
-            level = coeff & 0xff;
-            if (buf_->read1())
-                level = -level;
+            const int neg = (int)(rest >> 63); // sign bit, applied without a branch
+            level = ((coeff & 0xff) ^ -neg) + neg;
+            buf_->drop(taken + 1);
         }
         n += run;
         if (n < 0 || n >= 64) {

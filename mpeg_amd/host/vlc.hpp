@@ -49,6 +49,14 @@ public:
         return e.value;
     }
     int bits() const { return bits_; }
+    // for callers that decode several fields from one 64-bit look at the stream (Buffer::window): the symbol
+    // whose code starts at the window's top bit
+    struct Symbol { int32_t value, len; };
+    Symbol at(uint64_t window) const
+    {
+        const Entry &e = lut_[(size_t)(window >> (64 - bits_))];
+        return Symbol{e.value, e.len};
+    }
 
 private:
     struct Entry { int32_t value, len; };
