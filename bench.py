@@ -295,8 +295,10 @@ def main():
         traffic = None
         tp = ROOT / "profiles" / "pmc_traffic.json"
         if tp.exists():
-            try:
-                traffic = json.loads(tp.read_text()).get(args.profile, {}).get("hbm_bytes_per_launch")
+            try:  # measured for the default workload only: same streams, same picture size, no fused RGBA
+                t = json.loads(tp.read_text()).get(args.profile, {})
+                if t.get("streams") == args.streams and (args.width, args.height) == (1920, 1080) and not args.rgba:
+                    traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
