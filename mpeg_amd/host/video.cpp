@@ -656,12 +656,31 @@ void Video::decodeBlock(int block)
     int level = 0;
     bool invalid = false;
     const VlcTable &coeff_table = tabCoeff();
+    // The cursor lives in locals for the length of the block (nothing in here refills the buffer): the
+    // byte stores below may alias anything, and would otherwise force the Buffer's members through memory
+    // once per coefficient.
+    const uint8_t *const data = buf_->Bytes();
+    const size_t data_len = buf_->Len();
+    size_t bit = buf_->bitIndex();
+    auto window = [&]() -> uint64_t { // the next 57+ bits, left-aligned, zero-padded past the end
+        const size_t byte = bit >> 3;
+        uint64_t w;
+        if (byte + 8 <= data_len) {
+            memcpy(&w, data + byte, 8);
+            w = __builtin_bswap64(w);
+        } else {
+            w = 0;
+            for (size_t k = 0; k < 8; k++)
+                w = (w << 8) | (byte + k < data_len ? data[byte + k] : 0u);
+        }
+        return w << (bit & 7);
+    };
     for (;;) {
         // One 64-bit look at the stream per coefficient: the code (<= 17 bits), then either its sign bit or the
         // escape's run and level (<= 22 bits) — same fields, same order, same consumption as video.go:685-707
         // reads them one by one; the dependent chain cursor -> load -> table -> cursor is walked once, not thrice.
         int run;
-        const uint64_t w = buf_->window();
+        const uint64_t w = window();
         const VlcTable::Symbol sym = coeff_table.at(w);
         const int coeff = sym.value;
         uint64_t rest = w << sym.len; // what follows the code
@@ -669,7 +688,7 @@ void Video::decodeBlock(int block)
         if (coeff == 0x0001 && n > 0) { // '1' after the first coefficient: '10' = end_of_block, '11s' = run 0, level 1
             taken++;
             if ((rest >> 63) == 0) {
-                buf_->drop(taken);
+                bit += (size_t)taken;
                 break;
             }
             rest <<= 1;
@@ -685,12 +704,12 @@ void Video::decodeBlock(int block)
                 level = (int)(f & 0xff) - (b ? 256 : 0);
                 used = 22;
             }
-            buf_->drop(taken + used);
+            bit += (size_t)(taken + used);
         } else {
             run = coeff >> 8;
             const int neg = (int)(rest >> 63); // sign bit, applied without a branch
             level = ((coeff & 0xff) ^ -neg) + neg;
-            buf_->drop(taken + 1);
+            bit += (size_t)(taken + 1);
         }
         n += run;
         if (n < 0 || n >= 64) {
@@ -703,10 +722,12 @@ void Video::decodeBlock(int block)
             explicit_zero = true; // dequantises to +-1, which "0 = absent" cannot express
         br.q[dz] = (int16_t)level;
         touched[n_touched++] = (uint8_t)dz;
-        br.n_touched = n_touched;
         if (dirty_at_start)
             block_data_[dz] = dequantPremult(level, macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
     }
+
+    buf_->setBitIndex(bit);
+    br.n_touched = n_touched;
 
     // bring block_data_ up to date when it was not maintained on the fly
     auto materialize = [&]() {
