@@ -288,6 +288,40 @@ def test_staged_submit_equals_plain_submit(oracle, hip_ctx, threads):
 
 
 @pytest.mark.gpu
+def test_staged_submit_of_ragged_pictures(oracle, hip_ctx):
+    """Pictures of different sizes in one staged submit: a full picture, an empty one (no macroblocks), one with a
+    few macroblocks and no coefficients, one whose macroblock count is not a multiple of the 4-macroblock chunk —
+    chunks straddle picture boundaries in every way; int32 snapshot blocks (two units each) travel too."""
+    w, h = 96, 80
+    rng = np.random.default_rng(5)
+    full = [synth.generate_sequence(w, h, 3, seed=40 + i, raw_fraction=0.2 if i == 2 else 0.0) for i in range(4)]
+    ref, dut = oracle.OracleStore(w, h, 4), abi.VideoStore(hip_ctx, w, h, 4)
+    for step in range(3):
+        pictures = []
+        for sidx in range(4):
+            s = full[sidx][step]
+            p = s.pics.copy()
+            p["stream"] = sidx
+            mbs, coefs = s.mbs, s.coefs
+            if sidx == 1:                      # nothing at all
+                mbs, coefs = mbs[:0], coefs[:0]
+            elif sidx == 3:                    # the first 7 macroblocks only, prediction / intra as they are
+                mbs = mbs[:7].copy()
+                units = int(mbs["coef_off"][-1]) + bin(int(mbs["cbp"][-1])).count("1")
+                coefs = coefs[:units * desc.COEF_UNIT]
+            pictures.append((p[0], mbs, coefs))
+            q = p.copy()
+            q["mb_first"], q["mb_count"] = 0, len(mbs)
+            if len(mbs):
+                ref.submit(q, mbs, coefs)
+        assert dut.submit_staged(pictures, threads=2) == [0] * 4
+        for sidx in range(4):
+            for slot in range(3):
+                assert_planes_equal(ref.read_planes(sidx, slot), dut.read_planes(sidx, slot), "step %d stream %d slot %d" % (step, sidx, slot))
+    dut.close()
+
+
+@pytest.mark.gpu
 def test_staged_submit_refuses_a_bad_picture(hip_ctx):
     """A put that fails validation makes the commit fail with that error and launch nothing; the stage is over
     and the store accepts the next submit."""
