@@ -345,6 +345,57 @@ def test_staged_submit_refuses_a_bad_picture(hip_ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometries_plain_and_staged(oracle, hip_ctx, seed):
+    """Seeded sweep over picture sizes (also not multiples of 16, also one macroblock wide or high), stream
+    counts, macroblock mixes, snapshot blocks and fused RGBA: every picture goes to one store by plain submit and to
+    another by staged submit; both must equal the oracle after every picture, planes and RGBA images."""
+    rng = np.random.default_rng(1000 + seed)
+    w = int(rng.choice([16, 17, 48, 100, 176, 250, 352]))
+    h = int(rng.choice([16, 31, 64, 90, 144, 240]))
+    n = int(rng.integers(1, 4))
+    rgba = bool(rng.integers(0, 2))
+    seqs = [synth.generate_sequence(w, h, 5, seed=int(rng.integers(1 << 30)), rgba=rgba,
+                                    profile=str(rng.choice(["typical", "dense"])), raw_fraction=float(rng.choice([0.0, 0.3])))
+            for _ in range(n)]
+    ref = oracle.OracleStore(w, h, n)
+    plain, staged = abi.VideoStore(hip_ctx, w, h, n), abi.VideoStore(hip_ctx, w, h, n)
+    for step in range(5):
+        pictures, merged = [], ([], [], [])
+        mb0 = c0 = 0
+        for sidx, seq in enumerate(seqs):
+            s = seq[step]
+            p, m = s.pics.copy(), s.mbs.copy()
+            p["stream"] = sidx
+            pictures.append((p[0], s.mbs, s.coefs))
+            q = p.copy()
+            q["mb_first"] = 0
+            ref.submit(q, s.mbs, s.coefs)
+            p["mb_first"] = mb0
+            m["pic"] = sidx
+            m["coef_off"] += c0
+            merged[0].append(p)
+            merged[1].append(m)
+            merged[2].append(s.coefs)
+            mb0 += len(m)
+            c0 += len(s.coefs) // desc.COEF_UNIT
+        plain.submit(np.concatenate(merged[0]), np.concatenate(merged[1]), np.concatenate(merged[2]))
+        staged.submit_staged(pictures, threads=2)
+        for sidx in range(n):
+            for slot in range(3):
+                want = ref.read_planes(sidx, slot)
+                assert_planes_equal(want, plain.read_planes(sidx, slot), "plain: step %d stream %d slot %d" % (step, sidx, slot))
+                assert_planes_equal(want, staged.read_planes(sidx, slot), "staged: step %d stream %d slot %d" % (step, sidx, slot))
+            if rgba:
+                cur = int(seqs[sidx][step].pics[0]["cur"])
+                want = ref.read_rgba(sidx, cur).reshape(-1)
+                assert np.array_equal(np.asarray(plain.read_rgba(sidx, cur)).reshape(-1), want)
+                assert np.array_equal(np.asarray(staged.read_rgba(sidx, cur)).reshape(-1), want)
+    plain.close()
+    staged.close()
+
+
+@pytest.mark.gpu
 def test_stage_protocol_errors(hip_ctx):
     """One stage at a time; no plain submit while it is open; a commit with a picture missing launches nothing;
     every error leaves the store usable."""
