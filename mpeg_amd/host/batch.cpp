@@ -76,6 +76,19 @@ public:
         }
         b_->queue(stream_, pic, mbs, n_mbs, coefs, coef_bytes);
     }
+    void submitOwned(const mpeghip_pic_desc &pic, std::vector<mpeghip_mb_desc> &mbs, std::vector<uint8_t> &coefs) override
+    {
+        if (recording) { // keep the parser's arrays, give it the event's old ones: no copy of a 2.5 MB picture
+            Event &e = nextEvent();
+            e.kind = Event::Submit;
+            e.pic = pic;
+            e.pic.mb_count = (uint32_t)mbs.size();
+            e.mbs.swap(mbs);
+            e.coefs.swap(coefs);
+            return;
+        }
+        b_->queue(stream_, pic, mbs.data(), (uint32_t)mbs.size(), coefs.data(), coefs.size());
+    }
     void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
         if (recording)

@@ -178,6 +178,12 @@ public:
     virtual void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) = 0;
     virtual void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
                         const uint8_t *coefs, size_t coef_bytes) = 0;
+    // The same submit, with the parser's own arrays handed over: a backend that keeps the picture for later may
+    // swap them for arrays of its own instead of copying (the parser clears whatever it gets back).
+    virtual void submitOwned(const mpeghip_pic_desc &pic, std::vector<mpeghip_mb_desc> &mbs, std::vector<uint8_t> &coefs)
+    {
+        submit(pic, mbs.data(), (uint32_t)mbs.size(), coefs.data(), coefs.size());
+    }
     virtual void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) = 0;
     virtual void readRGBA(uint32_t slot, uint8_t *dst) = 0;  // Frame.RGBA of the slot
 };

@@ -320,9 +320,10 @@ void Video::flushSubmit()
     pic.bwd = (uint8_t)slot_bwd_;
     pic.mb_first = 0;
     pic.mb_count = (uint32_t)mbs_.size();
-    backend_->submit(pic, mbs_.data(), (uint32_t)mbs_.size(), coefs_.data(), coefs_.size());
+    const size_t n_mbs = mbs_.size();
+    backend_->submitOwned(pic, mbs_, coefs_); // (may swap the arrays for others)
     stats_.submits++;
-    stats_.macroblocks += mbs_.size();
+    stats_.macroblocks += n_mbs;
     mbs_.clear();
     coefs_.clear();
     std::fill(written_.begin(), written_.end(), 0);
