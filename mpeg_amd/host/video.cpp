@@ -63,7 +63,7 @@ const uint8_t kPremultiplier[64] = { // video.go:1077-1086
 // that must reproduce the reference's blockData bit for bit (video.go:719-744)
 int32_t dequantPremult(int level, bool intra, int qscale, int qm, int idx)
 {
-    level <<= 1;
+    level *= 2; // (the reference shifts; a negative level shifted is undefined before C++20)
     if (!intra)
         level += level < 0 ? -1 : 1;
     level = (level * qscale * qm) >> 4;
@@ -572,7 +572,7 @@ int Video::decodeMotionVector(int rSize, int motion)
     motion += d;
     if (motion > (fscale << 4) - 1)
         motion -= fscale << 5;
-    else if (motion < ((-fscale) << 4))
+    else if (motion < -(fscale << 4))
         motion += fscale << 5;
     return motion;
 }
@@ -581,14 +581,14 @@ void Video::predictMacroblock()
 { // video.go:608-637
     int fw_h = motion_forward_.H, fw_v = motion_forward_.V;
     if (motion_forward_.FullPx) {
-        fw_h <<= 1;
-        fw_v <<= 1;
+        fw_h *= 2; // (full-pel vectors; may be negative)
+        fw_v *= 2;
     }
     if (picture_type_ == kPictureTypeB) {
         int bw_h = motion_backward_.H, bw_v = motion_backward_.V;
         if (motion_backward_.FullPx) {
-            bw_h <<= 1;
-            bw_v <<= 1;
+            bw_h *= 2;
+            bw_v *= 2;
         }
         if (motion_forward_.IsSet) {
             emitPrediction(fw_h, fw_v, false);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # ThreadSanitizer over mpeg::VideoBatch's parallel parse + staged replay (no GPU: the lane-emulator store stands in
-# for the device).  Prints the frame count; any data race is reported by TSan on stderr.
+# for the device).  Prints the frame count; any data race is reported by TSan on stderr.  The same sources build with
+# -fsanitize=address,undefined (replace the flag): clean on both golden streams, lane functions included.
 set -e
 cd "$(dirname "$0")/../.."
 g++ -O1 -g -fsanitize=thread -std=c++17 -pthread -DMPG_EMU=1 -Iinclude -Impeg_amd/host -Impeg_amd/csrc \
