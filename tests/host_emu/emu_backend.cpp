@@ -81,7 +81,7 @@ private:
     uint32_t w_ = 0, h_ = 0, lw_ = 0, lh_ = 0;
     size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0;
     std::vector<uint8_t> frames_, rgba_, dump_;
-    uint8_t qt_[256];
+    alignas(16) uint8_t qt_[256]; // (the lanes read it in 16-byte pieces, as the device does from its 256-byte aligned table)
 };
 
 // multi-stream store over the wave-chunk lane emulator (what HipBatchStore is over libmpeghip)
@@ -100,11 +100,12 @@ public:
         frames_.assign(stride_ * 3 * n_streams + 4096, 0);
         rgba_stride_ = ((size_t)w_ * h_ * 4 + 255) / 256 * 256;
         rgba_.assign(rgba_stride_ * 3 * n_streams, 0);
-        qt_.assign((size_t)256 * n_streams, 0);
+        qt_store_.assign((size_t)256 * n_streams + 16, 0);
+        qt_ = qt_store_.data() + (16 - reinterpret_cast<uintptr_t>(qt_store_.data()) % 16) % 16; // 16-byte aligned, as on the device
     }
     void setQuant(uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64]) override
     {
-        uint8_t *t = qt_.data() + (size_t)stream * 256;
+        uint8_t *t = qt_ + (size_t)stream * 256;
         for (int cls = 0; cls < 2; cls++)
             for (int c = 0; c < 8; c++)
                 for (int r = 0; r < 8; r++) {
@@ -115,7 +116,7 @@ public:
     void submit(const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
                 size_t) override
     {
-        emu_video_run_wc(frames_.data(), stride_, lw_, lh_, w_, h_, pics, n_pics, mbs, n_mbs, coefs, qt_.data(), rgba_.data(),
+        emu_video_run_wc(frames_.data(), stride_, lw_, lh_, w_, h_, pics, n_pics, mbs, n_mbs, coefs, qt_, rgba_.data(),
                          rgba_stride_);
     }
     // staged submit (the product's mpeghip_video_stage_*): pictures put from several threads into one merged submit
@@ -178,7 +179,8 @@ public:
 private:
     uint32_t w_ = 0, h_ = 0, lw_ = 0, lh_ = 0, n_ = 0;
     size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0;
-    std::vector<uint8_t> frames_, rgba_, qt_;
+    std::vector<uint8_t> frames_, rgba_, qt_store_;
+    uint8_t *qt_ = nullptr;
     std::vector<uint32_t> st_first_, st_unit_, st_count_;
     std::vector<size_t> st_bytes_;
     std::vector<mpeghip_pic_desc> st_pics_;

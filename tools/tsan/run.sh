@@ -1,10 +1,17 @@
 #!/bin/bash
-# ThreadSanitizer over mpeg::VideoBatch's parallel parse + staged replay (no GPU: the lane-emulator store stands in
-# for the device).  Prints the frame count; any data race is reported by TSan on stderr.  The same sources build with
-# -fsanitize=address,undefined (replace the flag): clean on both golden streams, lane functions included.
+# Sanitizer runs of the host stack (no GPU: the lane-emulator backends stand in for the device, so the kernels'
+# lane functions run under the sanitizers too).
+#   videobatch_threads: mpeg::VideoBatch's thread pool + staged replay on the damaged golden stream
+#   mpeg_facade:        Demux, MPEG (Decode with callbacks, Seek, SeekFrame, Rewind), Video and Audio on test.mpg
+# usage: tools/tsan/run.sh [thread|address,undefined]      (default: both; the emulator translation unit takes minutes
+# to compile under a sanitizer — this is a tool, not part of the test suite)
 set -e
 cd "$(dirname "$0")/../.."
-g++ -O1 -g -fsanitize=thread -std=c++17 -pthread -DMPG_EMU=1 -Iinclude -Impeg_amd/host -Impeg_amd/csrc \
-    tools/tsan/videobatch_threads.cpp tools/tsan/device_stubs.cpp mpeg_amd/host/{buffer,video,audio,demux,batch}.cpp \
-    tests/host_emu/emu_backend.cpp tests/kernel_emu/emu.cpp -o /tmp/tsan_videobatch 2>&1 | grep -v "warning\|note" || true
-/tmp/tsan_videobatch tests/golden/test.mpeg1video
+SRC="tools/tsan/device_stubs.cpp mpeg_amd/host/buffer.cpp mpeg_amd/host/video.cpp mpeg_amd/host/audio.cpp mpeg_amd/host/demux.cpp mpeg_amd/host/batch.cpp mpeg_amd/host/mpeg.cpp tests/host_emu/emu_backend.cpp tests/kernel_emu/emu.cpp"
+for SAN in ${1:-thread address,undefined}; do
+  for H in videobatch_threads mpeg_facade; do
+    g++ -O1 -g1 -fno-var-tracking-assignments -fsanitize=$SAN -std=c++17 -pthread -w -DMPG_EMU=1 -Iinclude -Impeg_amd/host -Impeg_amd/csrc tools/tsan/$H.cpp $SRC -o /tmp/san_$H
+    echo "== $SAN / $H"
+    if [ $H = videobatch_threads ]; then /tmp/san_$H tests/golden/test.mpeg1video; else /tmp/san_$H tests/golden/test.mpg; fi
+  done
+done
