@@ -295,10 +295,13 @@ def main():
         traffic = None
         tp = ROOT / "profiles" / "pmc_traffic.json"
         if tp.exists():
-            try:  # measured for the default workload only: same streams, same picture size, no fused RGBA
-                t = json.loads(tp.read_text()).get(args.profile, {})
-                if t.get("streams") == args.streams and (args.width, args.height) == (1920, 1080) and not args.rgba:
+            try:  # measured for the default workloads only: same streams, same picture size
+                t = json.loads(tp.read_text()).get(args.profile + ("_rgba" if args.rgba else ""), {})
+                if t.get("streams") == args.streams and (args.width, args.height) == (1920, 1080):
                     traffic = t.get("hbm_bytes_per_launch")
+                t2 = json.loads(tp.read_text()).get(args.profile + "_rgba", {})
+                if fused and t2.get("streams") == args.rgba_streams and (args.width, args.height) == (1920, 1080):
+                    fused["roofline"]["traffic"] = t2.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
