@@ -7,10 +7,13 @@
 // no frame; the re-submit after a duplicated macroblock address in a damaged stream) flushes the batch
 // first — launches are stream ordered, so "last writer in bitstream order" is kept.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <exception>
 #include <mutex>
 #include <stdexcept>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 
@@ -219,7 +222,16 @@ VideoBatch::VideoBatch(std::unique_ptr<BatchStore> store, uint32_t n_streams) : 
     pending_.assign(n_streams, 0);
 }
 
-VideoBatch::~VideoBatch() {}
+VideoBatch::~VideoBatch()
+{
+    if (getenv("MPEGHOST_BENCH_VERBOSE") && threads_ > 1)
+        fprintf(stderr, "VideoBatch(%u streams, %u threads): parse rounds %.3f s, stage begin %.3f s, puts %.3f s, commits %.3f s\n",
+                (unsigned)videos_.size(), threads_, t_parse_, t_begin_, t_put_, t_commit_);
+}
+
+namespace {
+double nowSeconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} // namespace
 
 void VideoBatch::SetThreads(unsigned n)
 {
@@ -307,6 +319,7 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
             for (uint32_t i : todo)
                 ports_[i]->recording = true;
             std::exception_ptr failed;
+            const double p0 = nowSeconds();
             try {
                 pool_->run(todo.size(), [&](size_t k) {
                     const uint32_t i = todo[k];
@@ -315,6 +328,7 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
             } catch (...) {
                 failed = std::current_exception();
             }
+            t_parse_ += nowSeconds() - p0;
             for (uint32_t i : todo)
                 ports_[i]->recording = false;
             if (failed) {
@@ -356,7 +370,10 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                             n_mbs[g] = (uint32_t)group[g0 + g]->mbs.size();
                             bytes[g] = group[g0 + g]->coefs.size();
                         }
+                        const double s0 = nowSeconds();
                         store_->stageBegin(n_mbs, bytes);
+                        const double s1 = nowSeconds();
+                        t_begin_ += s1 - s0;
                         std::exception_ptr put_failed;
                         try {
                             pool_->run(gn, [&](size_t g) {
@@ -368,12 +385,15 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                         } catch (...) {
                             put_failed = std::current_exception();
                         }
+                        const double s2 = nowSeconds();
+                        t_put_ += s2 - s1;
                         try {
                             store_->stageCommit(); // ends the stage; fails (launching nothing) if a put failed
                         } catch (...) {
                             if (!put_failed)
                                 put_failed = std::current_exception();
                         }
+                        t_commit_ += nowSeconds() - s2;
                         if (put_failed)
                             std::rethrow_exception(put_failed);
                         device_submits_++;

@@ -376,6 +376,7 @@ private:
     std::vector<uint8_t> coefs_;
     std::vector<uint8_t> pending_;                 // stream already has a picture in the open batch
     uint64_t device_submits_ = 0, queued_pictures_ = 0;
+    double t_parse_ = 0, t_put_ = 0, t_commit_ = 0, t_begin_ = 0; // wall time per phase (printed with MPEGHOST_BENCH_VERBOSE)
 };
 
 // -------------------------------------------------------------------- audio.go
