@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <new>
@@ -23,9 +24,7 @@
 #include "iso11172_synth_window.h"
 #include "mpeghip.h"
 #include "video_lane.h"
-#include "video_split_lane.h"
-#include "video_compact_lane.h"
-#include "video_wire_lane.h"
+#include "video_recon_lane.h"
 
 using namespace mpg;
 
@@ -41,326 +40,157 @@ static __device__ __forceinline__ void wave_lds_handoff()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kWaveLdsBytes = kTileDwords * 4 + kRgbaBytes; // 1728 + 384
-
-// One wavefront per macroblock at a time, WAVES macroblocks (consecutive
-// descriptors, i.e. normally consecutive macroblocks of one row) per workgroup
-// so that the 8-byte row stores of neighbouring macroblocks combine into full
-// lines in one L2.
-//
-// MODE 0: one chunk (WAVES macroblocks) per workgroup, grid = all chunks.
-// MODE 1: persistent workgroups; every XCD walks one contiguous range of chunks.
-// MODE 2: MODE 1 + software pipeline: while macroblock i is computed, the global
-//         loads of macroblock i+1 are in flight and the (scalar) descriptor of
-//         macroblock i+2 is being fetched.  The kernel is latency-bound without
-//         it: a wave's life is a chain of dependent round trips (descriptor ->
-//         picture -> pixels/coefficients -> store).
-template <int MODE>
-static __device__ __forceinline__ void chunk_range(uint32_t n_chunks, uint32_t &first, uint32_t &last, uint32_t &step)
-{
-    if (MODE == 0) {
-        first = xcd_chunk(blockIdx.x, gridDim.x);
-        last = first + 1;
-        step = 1;
-    } else {
-        const uint32_t nx = 8; // gridDim.x is a multiple of 8
-        const uint32_t xcd = blockIdx.x % nx, k = blockIdx.x / nx, K = gridDim.x / nx;
-        const uint32_t lo = (uint32_t)(((uint64_t)n_chunks * xcd) / nx);
-        const uint32_t hi = (uint32_t)(((uint64_t)n_chunks * (xcd + 1)) / nx);
-        first = lo + k;
-        last = hi;
-        step = K;
-    }
-}
-
-static __device__ __forceinline__ void finish_mb(const VideoArgs &a, const MbU &u, int lane, const MbLane &st,
-                                                 int32_t *tile, uint8_t *stage)
-{
-    wave_lds_handoff();
-    bool wrote;
-    const uint64_t out = mb_phase_b(a, u, lane, st, tile, wrote);
-    if (u.rgba) { // wave-uniform
-        mb_phase_c_stage(a, u, lane, out, wrote, stage);
-        wave_lds_handoff();
-        mb_phase_c_convert(a, u, lane, stage);
-    }
-    wave_lds_handoff(); // the tile is rewritten by this wave's next macroblock
-}
-
-template <int WAVES, int MODE>
-__global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a, const uint32_t n_chunks)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES * kWaveLdsBytes];
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int32_t *tile = reinterpret_cast<int32_t *>(lds + wave * kWaveLdsBytes);
-    uint8_t *stage = lds + wave * kWaveLdsBytes + kTileDwords * 4;
-    uint32_t first, last, step;
-    chunk_range<MODE>(n_chunks, first, last, step);
-
-    if (MODE == 3) {
-        // Software pipeline with compile-time load / store counts (see mb_issue_loads_static):
-        // two macroblocks' worth of loads are in flight per wave, the descriptor of a third
-        // is being fetched by scalar loads.  Unrolled by two so the load registers ping-pong
-        // without moves (a move would have to wait for the data).
-        const uint32_t S = step * WAVES;
-        uint32_t i = __builtin_amdgcn_readfirstlane(first * WAVES + wave);
-        const uint64_t chunk_limit = (uint64_t)last * WAVES;
-        const uint32_t limit = (uint32_t)(chunk_limit < a.n_mbs ? chunk_limit : a.n_mbs);
-        if (i >= limit)
-            return;
-        uint8_t *sink = a.dump + ((uint64_t)blockIdx.x * WAVES + wave) * 512 + (uint32_t)lane * 8;
-        auto clampi = [&](uint64_t x) { return __builtin_amdgcn_readfirstlane((uint32_t)(x < limit ? x : limit - 1)); };
-        auto finish = [&](const MbU &u, const MbLane &st) {
-            wave_lds_handoff();
-            bool wrote;
-            const uint64_t out = mb_phase_b_t<true>(a, u, lane, st, tile, wrote, sink);
-            if (u.rgba) {
-                mb_phase_c_stage(a, u, lane, out, wrote, stage);
-                wave_lds_handoff();
-                mb_phase_c_convert(a, u, lane, stage);
-            }
-            wave_lds_handoff();
-        };
-        MbU ua = load_mb(a, i);
-        MbLoads la, lb;
-        mb_issue_loads_static(a, ua, lane, la);
-        MbU ub = load_mb(a, clampi((uint64_t)i + S));
-        for (;;) {
-            // even step: compute A while B's loads fly
-            MbU uc = load_mb(a, clampi((uint64_t)i + 2ull * S));
-            mb_issue_loads_static(a, ub, lane, lb);
-            {
-                MbLane st;
-                mb_phase_a_compute_static(a, ua, lane, la, st, tile);
-                finish(ua, st);
-            }
-            if ((uint64_t)i + S >= limit)
-                break;
-            // odd step: compute B while C's loads fly (C's loads land in A's registers)
-            MbU ud = load_mb(a, clampi((uint64_t)i + 3ull * S));
-            mb_issue_loads_static(a, uc, lane, la);
-            {
-                MbLane st;
-                mb_phase_a_compute_static(a, ub, lane, lb, st, tile);
-                finish(ub, st);
-            }
-            if ((uint64_t)i + 2ull * S >= limit)
-                break;
-            ua = uc;
-            ub = ud;
-            i += 2 * S;
-        }
-    } else if (MODE < 2) {
-        for (uint32_t c = first; c < last; c += step) {
-            const uint32_t mb_index = c * WAVES + wave;
-            if (mb_index >= a.n_mbs)
-                break;
-            const MbU u = load_mb(a, mb_index);
-            MbLane st;
-            mb_phase_a(a, u, lane, st, tile);
-            finish_mb(a, u, lane, st, tile, stage);
-        }
-    } else {
-        // indices of this wave's macroblocks: i0, i0+S, i0+2S, ... while < limit (all wave-uniform)
-        const uint32_t S = step * WAVES;
-        uint32_t i = __builtin_amdgcn_readfirstlane(first * WAVES + wave);
-        const uint64_t chunk_limit = (uint64_t)last * WAVES;
-        const uint32_t limit = (uint32_t)(chunk_limit < a.n_mbs ? chunk_limit : a.n_mbs);
-        if (i >= limit)
-            return;
-        MbU u0 = load_mb(a, i);
-        MbLoads l0;
-        mb_issue_loads(a, u0, lane, l0);
-        // look-ahead indices are clamped instead of branched on: the descriptor loads stay scalar and unconditional
-        MbU u1 = load_mb(a, __builtin_amdgcn_readfirstlane(i + S < limit ? i + S : i));
-        for (;;) {
-            const bool has1 = i + S < limit;
-            const uint32_t i2 = (uint64_t)i + 2ull * S < limit ? i + 2 * S : i;
-            const MbU u2 = load_mb(a, __builtin_amdgcn_readfirstlane(i2)); // scalar loads, two macroblocks ahead
-            MbLoads l1;
-            mb_issue_loads(a, u1, lane, l1); // vector loads of the next macroblock: in flight during the compute below
-            MbLane st;
-            mb_phase_a_compute(a, u0, lane, l0, st, tile);
-            finish_mb(a, u0, lane, st, tile, stage);
-            if (!has1)
-                break;
-            u0 = u1;
-            l0 = l1;
-            u1 = u2;
-            i += S;
-        }
-    }
-}
-
-// ---- compact path (video_compact_lane.h): fused, single pass over the pixels, dense residual stage
-__global__ __launch_bounds__(kChunkMbs * 64) void recon_compact_kernel(const VideoArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kCompactLdsBytes];
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const ChunkInfo ci = load_chunk(a, chunk);   // scalar loads of the chunk's 8 descriptors
-    const bool have_mb = w < ci.n;
-    MbU u;
-    MbLoads ld;
-    if (have_mb) {
-        u = load_mb(a, chunk * kChunkMbs + w);
-        compact_phase1(a, u, lane, ld);          // prediction loads: in flight during phase 2
-    }
-    if (8 * w < ci.base[kChunkMbs]) {            // wave-uniform: this wave has coded blocks to transform
-        const int g = lane >> 3, j = lane & 7;
-        const uint32_t slot = 8 * w + (uint32_t)g;
-        int32_t *tile_g = reinterpret_cast<int32_t *>(lds + kResidStoreBytes) + (w * 8 + (uint32_t)g) * kTileStride;
-        bool active;
-        compact_phase2(a, ci, slot, j, tile_g, active);
-        wave_lds_handoff();
-        compact_phase2_rows(slot, j, tile_g, active, lds);
-    }
-    __syncthreads();
-    if (have_mb)
-        compact_phase3(a, u, ci, w, lane, ld, lds);
-}
-
-// ---- wave-chunk path: one wave = 4 consecutive macroblocks, dense residual stage, no barrier
-// 8 waves per SIMD: 64 VGPRs, and 4 x 5120 bytes of LDS per workgroup let 8 workgroups share a CU
-// kRgba: the instance for batches with MPEGHIP_PIC_RGBA pictures (Frame.RGBA() fused); the other one carries
-// none of that code
+// ---- reconstruction (video_recon_lane.h has the whole story): one wave = one chunk of 4 macroblocks,
+// wave-private LDS, no barrier.  kRgba: the instance for batches with MPEGHIP_PIC_RGBA pictures
+// (Frame.RGBA() fused); the other one carries none of that code.
 template <int WAVES, bool kRgba>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_wc_kernel(const VideoArgs a, const uint32_t n_chunks)
+__global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kWcLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kRcLdsBytes];
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t chunk = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w);
-    if (chunk >= n_chunks)
+    if (chunk >= a.n_chunks)
         return;
-    uint8_t *resid = lds_all + w * kWcLdsBytes;
-    int32_t *tile = reinterpret_cast<int32_t *>(resid + kWcResidBytes);
-#ifdef MPG_PHASE_TIMING // instrumented build for tools/phase_timing.py only: s_memtime at the phase boundaries
-#define MPG_STAMP(k) ts[k] = __builtin_readcyclecounter()
-    uint64_t ts[6];
-#else
-#define MPG_STAMP(k)
-#endif
-    MPG_STAMP(0);
-    uint32_t n_live;
-    WcRaw raw;
-    wc_load_raw<kRgba>(a, chunk, n_live, raw); // one round of scalar loads for the whole chunk
-    const WcInfo ci = wc_info_from_raw(n_live, raw);
-    const int g = lane >> 3, j = lane & 7;
-    MPG_STAMP(1);
+    uint8_t *lds = lds_all + w * kRcLdsBytes;
+    int32_t *T = reinterpret_cast<int32_t *>(lds);
+    uint8_t *O = lds + kRcTileBytes;
+    uint8_t *Q = O + kRcOutBytes;
 
-    // prediction loads of every macroblock of the chunk, up front
-    MbU u[kWcMbs];
-    MbLoads ld[kWcMbs];
+    // step 1: one round of scalar loads, then every vector load of the chunk
+    const RcChunk c = rc_load_chunk(a, chunk);
+    const RcLane k = rc_lane(a, lane);
+    const uint32_t n_blocks = rc_n_blocks(c);
+    const uint32_t qdw = rc_load_qtab(a, c, lane);
+    uint32_t bw = rc_load_blk(a, c, 0, lane);
+    uint32_t e = rc_load_ent(a, c, 0, lane);
+    RcPred p[kRcMbs];
 #pragma unroll
-    for (int m = 0; m < kWcMbs; m++) {
-        u[m] = wc_mb_from_raw<kRgba>(a, raw.d[m]);
-        wc_issue_pred(a, u[m], lane, ld[m]);
+    for (int m = 0; m < kRcMbs; m++)
+        p[m].lx0 = p[m].lx1 = p[m].cx0 = p[m].cx1 = p[m].c0 = p[m].c1 = 0;
+    const bool last_l = rc_luma_last_row(lane), last_c = rc_chroma_last_row(lane);
+    if (last_l) { // the windows' extra rows first: few lanes, and the loads behind them can be counted
+#pragma unroll
+        for (int m = 0; m < kRcMbs; m++)
+            if (c.r[m][0] & kROvL)
+                rc_pred_luma_extra(a, c, m, k, p[m]);
     }
-    MPG_STAMP(2);
-    // dense residual stage: 8 coded blocks per pass
-    const uint32_t total = ci.base[kWcMbs];
-    for (uint32_t s0 = 0; s0 < total; s0 += 8) {
-        const uint32_t slot = s0 + (uint32_t)g;
-        bool active;
-        compact_phase2(a, ci, slot, j, tile + g * kWcTileStride, active);
-        wave_lds_handoff();
-        compact_phase2_rows(slot, j, tile + g * kWcTileStride, active, resid);
-        wave_lds_handoff();
+    if (lane < 32 && last_c) {
+#pragma unroll
+        for (int m = 0; m < kRcMbs; m++)
+            if (c.r[m][0] & kROvC)
+                rc_pred_chroma_extra(a, c, m, k, p[m]);
     }
-    MPG_STAMP(3);
-    // per macroblock: prediction + residual, clamp; outputs leave as whole rows when the chunk is a horizontal run
-    const bool coalesce = wc_can_coalesce(ci, u);
-    bool rgba = false; // any macroblock of a picture that is colour-converted on the fly (wave-uniform)
 #pragma unroll
-    for (int m = 0; m < kWcMbs; m++)
-        rgba = rgba || (kRgba && (uint32_t)m < ci.n && u[m].rgba != nullptr);
-    uint8_t *out_tile = (coalesce || rgba) ? reinterpret_cast<uint8_t *>(tile) : nullptr;
-    const int below_lane = wc_below_lane(lane);
-    const int below_addr = (below_lane < 0 ? lane : below_lane) << 2; // ds_bpermute byte address of the source lane
-    auto row_below = [&](int m) { // the row under this lane's row: from the lane that loaded it, or ld.r1
-        u8x16 below = ld[m].r1;
-        if (wc_needs_below(u[m])) { // wave-uniform
+    for (int m = 0; m < kRcMbs; m++)
+        rc_pred_luma(a, c, m, k, p[m]);
+    if (lane < 32) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(below_addr, (int)ld[m].r0.v[k]);
-                below.v[k] = below_lane < 0 ? below.v[k] : got;
+        for (int m = 0; m < kRcMbs; m++)
+            rc_pred_chroma(a, c, m, k, p[m]);
+    }
+    *reinterpret_cast<uint32_t *>(Q + lane * 4) = qdw;
+
+    const int below_l = ((lane + 4) & 63) << 2, below_c = ((lane + 2) & 63) << 2; // ds_bpermute addresses of the row below
+    int32_t v[8];
+    uint32_t ent_at = 0;
+    for (uint32_t pass = 0;; pass++) {
+        const bool work = pass * 8 < n_blocks; // (wave-uniform)
+        if (work) {
+            // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7
+            const uint32_t np = rc_pass_entries(c, pass);
+            rc_zero_tile(T, lane);
+            if (pass > 0)
+                bw = rc_load_blk(a, c, pass, lane);
+            wave_lds_handoff();
+            for (uint32_t r = 0; r < np; r += 64) {
+                if (pass > 0 || r > 0)
+                    e = rc_load_ent(a, c, ent_at + r, lane);
+                if (r + (uint32_t)lane < np)
+                    rc_scatter(T, Q, e);
+            }
+            ent_at += np;
+            if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
+#pragma unroll
+                for (uint32_t g = 0; g < 8; g++) {
+                    const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
+                    if (pass * 8 + g < n_blocks && (bwg & kBRaw))
+                        rc_raw_fill(a, c, T, g, bwg, lane);
+                }
+            }
+            wave_lds_handoff();
+            rc_cols_load(T, lane, v);
+            idct8<false>(v);
+            rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now
+            wave_lds_handoff();
+            rc_rows_load(T, lane, v);
+            idct8<true>(v);
+        }
+        if (pass == 0) {
+            // step 3: motion compensation into O, half-pel modes wave-uniform per macroblock
+#pragma unroll
+            for (int m = 0; m < kRcMbs; m++) {
+                const uint32_t d0 = c.r[m][0];
+                if (d0 & kRDead)
+                    continue;
+                uint32_t yl = 0, yc = 0;
+                if (!(d0 & kRIntra)) {
+                    uint32_t b0 = p[m].lx0, b1 = p[m].lx1;
+                    if (d0 & kROvL) {
+                        const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l0);
+                        b0 = last_l ? b0 : g0;
+                        if (d0 & kROhL) {
+                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l1);
+                            b1 = last_l ? b1 : g1;
+                        }
+                    }
+                    yl = rc_mc4(p[m].l0, p[m].l1, b0, b1, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
+                    uint32_t q0 = p[m].cx0, q1 = p[m].cx1;
+                    if (d0 & kROvC) {
+                        const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c0);
+                        q0 = last_c ? q0 : g0;
+                        if (d0 & kROhC) {
+                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c1);
+                            q1 = last_c ? q1 : g1;
+                        }
+                    }
+                    yc = rc_mc4(p[m].c0, p[m].c1, q0, q1, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+                }
+                *reinterpret_cast<uint32_t *>(O + k.tile_luma + m * 16) = yl;
+                if (lane < 32)
+                    *reinterpret_cast<uint32_t *>(O + k.tile_chroma + m * 8) = yc;
             }
         }
-        return below;
-    };
-    if (coalesce) { // the normal case, without the rare paths
-#pragma unroll
-        for (int m = 0; m < kWcMbs; m++)
-            wc_phase3<kWcMbs, true>(a, u[m], ci, (uint32_t)m, lane, ld[m], row_below(m), resid, out_tile, false);
+        if (!work)
+            break;
+        // step 4: residual rows onto the prediction
+        wave_lds_handoff();
+        if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks)
+            rc_rmw(O, bw, lane, v);
+        if ((pass + 1) * 8 >= n_blocks)
+            break;
+    }
+    wave_lds_handoff();
+    // step 5
+    const bool run = (c.h[5] & kCRun) != 0;
+    const bool rgba = kRgba && (c.h[5] & kCRgba) != 0;
+    const uint32_t n_live = rc_n_live(c);
+    if (run) {
+        rc_store_run(a, c, lane, k, O);
     } else {
 #pragma unroll
-        for (int m = 0; m < kWcMbs; m++) {
-            if ((uint32_t)m >= ci.n)
-                continue;
-            wc_phase3<kWcMbs, false>(a, u[m], ci, (uint32_t)m, lane, ld[m], row_below(m), resid, out_tile, true);
-        }
+        for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
+            if (m < n_live)
+                rc_store_mb(a, c, m, lane, O, rgba);
     }
-    MPG_STAMP(4);
-    if (out_tile) {
-        wave_lds_handoff();
-        if (coalesce)
-            wc_store_tile(a, u[0], lane, out_tile);
-        if (kRgba && rgba) {
+    if (kRgba && rgba) {
+        if (!run)
+            wave_lds_handoff();
 #pragma unroll
-            for (int m = 0; m < kWcMbs; m++)
-                if ((uint32_t)m < ci.n && u[m].rgba != nullptr)
-                    wc_rgba_mb(a, u[m], (uint32_t)m, lane, out_tile);
-        }
+        for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
+            if (m < n_live)
+                rc_rgba_mb(a, c, m, lane, O);
     }
-#ifdef MPG_PHASE_TIMING
-    MPG_STAMP(5);
-    if (lane == 0 && chunk < 60000) { // a.dump is 4 MB: 64 bytes per sampled wave
-        uint64_t *d = reinterpret_cast<uint64_t *>(a.dump) + (uint64_t)chunk * 8;
-        for (int k = 0; k < 6; k++)
-            d[k] = ts[k];
-        d[6] = total;
-        d[7] = coalesce;
-    }
-#endif
-#undef MPG_STAMP
-}
-
-// ---- split path (video_split_lane.h): K1 prediction, K2 dense residual
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void pred_kernel(const SplitArgs s)
-{
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const uint32_t first = (chunk * WAVES + wave) * 2; // wave-uniform
-    if (first >= s.v.n_mbs)
-        return;
-    const uint32_t second = first + 1 < s.v.n_mbs ? first + 1 : first;
-    const PredMb m0 = load_pred_mb(s.v, first);   // scalar loads
-    const PredMb m1 = load_pred_mb(s.v, second);
-    const bool hi = lane >= 32;
-    if (hi && first + 1 >= s.v.n_mbs)
-        return;
-    pred_lane(s, select_pred_mb(hi, m0, m1), lane & 31);
-}
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void resid_kernel(const SplitArgs s)
-{
-    __shared__ __attribute__((aligned(16))) int32_t tiles[WAVES * kResidTileDwords];
-    const uint32_t wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, j = lane & 7;
-    const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
-    const uint32_t unit = (chunk * WAVES + wave) * 8 + (uint32_t)g;
-    int32_t *tile_g = tiles + wave * kResidTileDwords + g * kTileStride;
-    ResidLane st;
-    resid_phase_a(s, unit, j, tile_g, st);
-    wave_lds_handoff();
-    resid_phase_b(s, j, tile_g, st);
 }
 
 // Frame.RGBA of the cur slot of every picture flagged MPEGHIP_PIC_RGBA: grid (x quads, rows, pictures).
@@ -391,82 +221,46 @@ __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64
                       width, height, x4, y, rgba + fs * rgba_stride);
 }
 
-// Replicate a one-stream descriptor set for streams 1..n-1 (benchmark batches): descriptors and pictures
-// for the diagnostic kernels, expanded records (video_compact_lane.h) for the wave-chunk kernel.  Upload-time
-// scaffolding of mpeghip_video_batch_upload_replicated, never inside a timed region.
+// Replicate a one-stream batch for streams 1..n-1 (benchmark batches): stream s gets its own copy of the
+// chunks, shifted to its frames, its table and its own copy of the words.  Upload-time scaffolding of
+// mpeghip_video_batch_upload_replicated, never inside a timed region.
 struct ReplicateSteps {
-    uint32_t coef_units;  // coefficient units of one stream
+    uint32_t words;       // words of one stream
     uint32_t frames256;   // MPEGHIP_SLOTS * frame_stride >> 8
     uint32_t rgba256;     // MPEGHIP_SLOTS * rgba_stride >> 8
 };
-__global__ void replicate_desc_kernel(mpeghip_pic_desc *pics, uint32_t n_pics, mpeghip_mb_desc *mbs, uint32_t *xmbs,
-                                      uint32_t n_mbs, ReplicateSteps k, uint32_t n_streams)
+__global__ void replicate_kernel(mpeghip_pic_desc *pics, uint32_t n_pics, uint32_t *chunks, uint32_t n_chunks,
+                                 uint32_t mbs_per_stream, ReplicateSteps k, uint32_t n_streams)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total_mbs = (uint64_t)n_mbs * n_streams;
-    if (gid >= (uint64_t)n_mbs && gid < total_mbs) {
-        const uint32_t s = (uint32_t)(gid / n_mbs), i = (uint32_t)(gid % n_mbs);
-        if (mbs) {
-            mpeghip_mb_desc d = mbs[i];
-            d.pic += s * n_pics;
-            d.coef_off += s * k.coef_units;
-            mbs[gid] = d;
+    const uint64_t total_chunks = (uint64_t)n_chunks * n_streams;
+    if (gid >= (uint64_t)n_chunks && gid < total_chunks) {
+        const uint32_t s = (uint32_t)(gid / n_chunks), i = (uint32_t)(gid % n_chunks);
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(chunks + (uint64_t)i * kRcChunkDwords);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(chunks + gid * kRcChunkDwords);
+        u32x4 h0 = src[0], h1 = src[1];
+        h0.v[0] += s * k.frames256;
+        h0.v[1] += s * k.rgba256;
+        h0.v[2] += s * 256u;
+        h0.v[3] += s * k.words;
+        h1.v[0] += s * k.words;
+        dst[0] = h0;
+        dst[1] = h1;
+        for (int m = 0; m < kRcMbs; m++) {
+            u32x4 r = src[2 + m];
+            r.v[1] += s * k.frames256; // (intra / dead records read the head of their own stream's frames instead)
+            dst[2 + m] = r;
         }
-        if (xmbs) {
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(xmbs + (uint64_t)i * kXDwords);
-            u32x4 q0 = src[0], q1 = src[1], q2 = src[2];
-            q0.v[1] += s * k.coef_units;
-            q0.v[2] += s * 256u;
-            q1.v[0] += s * k.frames256;
-            q1.v[1] += s * k.frames256;
-            q2.v[2] += s * k.rgba256;
-            u32x4 *dst = reinterpret_cast<u32x4 *>(xmbs + gid * kXDwords);
-            dst[0] = q0;
-            dst[1] = q1;
-            dst[2] = q2;
-            static_assert(kXDwords == 12, "three 16-byte quarters per record");
-        }
+        static_assert(kRcChunkDwords == 24, "six 16-byte quarters per chunk");
     }
     const uint64_t total_pics = (uint64_t)n_pics * n_streams;
     if (gid >= (uint64_t)n_pics && gid < total_pics) {
         const uint32_t s = (uint32_t)(gid / n_pics), i = (uint32_t)(gid % n_pics);
         mpeghip_pic_desc p = pics[i];
         p.stream = s;
-        p.mb_first += s * n_mbs;
+        p.mb_first += s * mbs_per_stream;
         pics[gid] = p;
     }
-}
-
-// Staged submits: rebuild the dense coefficient units from their wire form (video_wire_lane.h).  Grid:
-// x = groups of 8 units (4 per workgroup), y = pictures; one wave = 8 units of one picture.
-struct WireTab {
-    uint32_t unit_first; // first dense unit of the picture in the batch's coefficient array (a multiple of 8)
-    uint32_t units;
-    uint32_t region;     // dword offset of the picture's wire region: `units` headers, then the payload
-    uint32_t reserved;
-};
-__global__ __launch_bounds__(256) void wire_expand_kernel(const uint32_t *wire, const WireTab *tab, uint32_t pic0,
-                                                            uint8_t *coefs)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[4 * 1024];
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const WireTab t = tab[pic0 + blockIdx.y];
-    const uint32_t group = blockIdx.x * 4 + wave;
-    if (group * 8 >= t.units)
-        return;
-    const uint32_t unit = group * 8 + ((uint32_t)lane >> 3);
-    const uint32_t *region = wire + t.region;
-    WireLane w;
-    w.live = unit < t.units;
-    w.header = w.live ? region[unit] : 0;
-    w.payload = region + t.units;
-    uint8_t *tile = tiles + wave * 1024;
-    wire_phase_zero(tile, lane);
-    wave_lds_handoff();
-    wire_phase_scatter(w, tile, lane);
-    wave_lds_handoff();
-    wire_phase_store(w, tile, lane, coefs + ((uint64_t)t.unit_first + unit) * MPEGHIP_COEF_UNIT);
 }
 
 // FNV-1a-64 over Y||Cb||Cr of one slot per stream (mpeg_test.go:221-223); one
@@ -528,6 +322,7 @@ template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) vo
     }
 }
 
+
 // ================================================================ host side
 
 static thread_local char g_err[512] = "";
@@ -556,32 +351,22 @@ struct mpeghip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+// A batch on the device is ONE allocation: pictures | chunks | words (video_recon_lane.h), each region
+// 64-byte aligned; resident batches hold `replicas` copies of every region.
 struct mpeghip_batch {
     mpeghip_video *owner = nullptr;
-    mpeghip_pic_desc *d_pics = nullptr;
-    mpeghip_mb_desc *d_mbs = nullptr; // filled only for the diagnostic kernels (MPEGHIP_RECON mode < 6)
-    uint32_t *d_xmbs = nullptr;       // expanded records of the wave-chunk kernel (mode 6)
-    uint32_t *d_wire = nullptr;       // staged submits: coefficient units in wire form (video_wire_lane.h)
-    void *d_wtab = nullptr;           //                 one WireTab per picture
-    // Submits that come through a pinned staging buffer keep its device image in ONE allocation, filled by one
-    // H2D copy: staged submits pictures | WireTab | records | wire regions (d_coefs is separate: the units
-    // rebuilt by wire_expand_kernel), plain submits pictures | descriptors | records | coefficients.
-    enum Form { Separate, StageBlob, SubmitBlob } form = Separate;
     uint8_t *d_blob = nullptr;
     size_t cap_blob = 0;
-    uint8_t *d_coefs = nullptr;
-    uint64_t n_pics = 0, n_mbs = 0, coef_bytes = 0;
+    mpeghip_pic_desc *d_pics = nullptr;
+    uint32_t *d_chunks = nullptr, *d_words = nullptr;
+    uint64_t n_pics = 0, n_mbs = 0, n_chunks = 0;
     uint64_t alg_bytes = 0;
-    BlockEntry *d_entries = nullptr; // split path work list, one per coefficient unit
-    bool dense_partition = false;   // coefficient units are an ordered partition of the stream: no memset needed
     bool any_rgba = false;
     // host copy of what launch_batch needs to keep the RGBA images in step: per picture of the original
     // (un-replicated) batch {stream, cur, MPEGHIP_PIC_RGBA?, covers every macroblock of the frame?}
     struct PicNote { uint32_t stream; uint8_t cur, rgba, full; };
     std::vector<PicNote> notes;
     uint32_t replicas = 1;
-    size_t cap_pics = 0, cap_mbs = 0, cap_xmbs = 0, cap_coefs = 0, cap_entries = 0; // capacities (transient batch reuse)
-
 };
 
 struct mpeghip_video {
@@ -589,17 +374,15 @@ struct mpeghip_video {
     mpeghip_video_info info{};
     uint8_t *d_frames = nullptr;
     uint8_t *d_rgba = nullptr;
-    uint8_t *d_qmat = nullptr;    // [n_streams][2][8][16]: per column {8 matrix bytes, 8 premultiplier bytes}
-    uint8_t *d_dump = nullptr;    // sink for the static-count stores of the pipelined kernel
-    size_t dump_bytes = 0;
+    uint8_t *d_qmat = nullptr;    // [n_streams][64 positions][2 classes]{matrix entry, premultiplier}
     uint64_t *d_hash = nullptr;
     // rgba_sync[stream*3 + slot]: the slot's RGBA image equals the conversion of its planes.  Pictures
     // flagged MPEGHIP_PIC_RGBA convert the macroblocks they write inside the reconstruction kernel; that
     // is the whole story unless a partial picture lands on a slot whose image is out of date — then
     // the whole-frame pass runs as well (launch_batch).
     std::vector<uint8_t> rgba_sync;
-    // mpeghip_video_submit: two descriptor batches with pinned host staging, used alternately, so
-    // that the caller can parse picture N+1 while picture N's copy and kernel are in flight
+    // mpeghip_video_submit: two batches with pinned host staging, used alternately, so that the caller
+    // can parse picture N+1 while picture N's copy and kernel are in flight
     struct Staging {
         mpeghip_batch batch;
         uint8_t *h = nullptr;      // pinned
@@ -613,21 +396,27 @@ struct mpeghip_video {
     size_t bounce_cap = 0;
 };
 
+// what validation learns about a picture (the dependency check across pictures needs it)
+struct PicUse {
+    uint8_t fwd = 0, bwd = 0; // some macroblock predicts from pic.fwd / pic.bwd
+};
+
 // mpeghip_video_stage_*: one submit assembled in a staging buffer by several host threads
 struct mpeghip_stage {
     mpeghip_video *v = nullptr;
     mpeghip_video::Staging *sg = nullptr;
-    uint32_t n_pics = 0, n_mbs = 0;
-    uint64_t coef_units = 0;
-    std::vector<uint32_t> mb_first, mb_count;   // per picture: its records [mb_first, mb_first + mb_count)
-    std::vector<uint64_t> unit_first, units;    // per picture: its coefficient units (unit_first: multiples of 8)
+    uint32_t n_pics = 0, n_mbs = 0, n_chunks = 0;
+    std::vector<uint32_t> mb_first, mb_count;   // per picture: its macroblocks [mb_first, mb_first + mb_count)
+    std::vector<uint32_t> chunk_first;          // per picture: its first chunk
+    std::vector<uint64_t> units;                // per picture: its coefficient units
     std::vector<uint64_t> alg;                  // per picture, written by its put
+    std::vector<PicUse> use;                    // per picture, written by its put
     std::vector<uint8_t> done;                  // per picture: put succeeded
-    size_t x_at = 0, tab_at = 0, wire0 = 0;     // staging layout: pictures | WireTab | records | wire regions
-    uint64_t wire_cap_dwords = 0;               // room for all regions if every unit travelled dense
-    std::atomic<uint64_t> wire_used{0};         // dwords handed out so far: a put packs its picture into scratch
+    size_t c_at = 0, w_at = 0;                  // staging layout: pictures | chunks | words
+    uint64_t words_cap = 0;                     // room for every picture's worst case
+    std::atomic<uint64_t> words_used{0};        // dwords handed out so far: a put packs its picture into scratch
                                                 // memory of its thread, then takes exactly the room it needs, so
-                                                // that the regions form one contiguous block = one H2D copy
+                                                // that the words form one contiguous block = one H2D copy
     std::atomic<int> error{MPEGHIP_OK};         // first failed put
     std::mutex error_lock;
     std::string error_text;
@@ -659,18 +448,6 @@ static const uint8_t k_premult[64] = {
     42, 58, 55, 49, 42, 33, 23, 12, 38, 52, 49, 44, 38, 30, 20, 10,
     32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30, 25, 20, 14, 7,
     17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
-
-// One stream's device table: for each class (intra, non-intra) and column c, the 8
-// matrix entries of that column (rows 0..7) followed by the 8 premultipliers.
-static void make_qtable(uint8_t out[256], const uint8_t intra[64], const uint8_t non_intra[64])
-{
-    for (int cls = 0; cls < 2; cls++)
-        for (int c = 0; c < 8; c++)
-            for (int r = 0; r < 8; r++) {
-                out[cls * 128 + c * 16 + r] = (cls ? non_intra : intra)[r * 8 + c];
-                out[cls * 128 + c * 16 + 8 + r] = k_premult[r * 8 + c];
-            }
-}
 
 extern "C" {
 
@@ -827,11 +604,7 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
             rc = fail(MPEGHIP_ERR_OOM, "hipMalloc(%llu) for the frame store failed", (unsigned long long)total);
             break;
         }
-        int n_cu = 256;
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-        v->dump_bytes = (size_t)(n_cu + 8) * 32 /* waves per CU */ * 512;
         if (hipMalloc((void **)&v->d_qmat, (size_t)n_streams * 256) != hipSuccess ||
-            hipMalloc((void **)&v->d_dump, v->dump_bytes) != hipSuccess ||
             hipMalloc((void **)&v->d_hash, (size_t)n_streams * 8) != hipSuccess) {
             rc = fail(MPEGHIP_ERR_OOM, "hipMalloc for tables failed");
             break;
@@ -844,7 +617,7 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
         uint8_t non_intra[64];
         memset(non_intra, 16, 64); // video.go:1066-1075
         for (uint32_t s = 0; s < n_streams; s++)
-            make_qtable(&qm[(size_t)s * 256], k_default_intra, non_intra);
+            rc_make_qtable(&qm[(size_t)s * 256], k_default_intra, non_intra, k_premult);
         if (hipMemcpy(v->d_qmat, qm.data(), qm.size(), hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(MPEGHIP_ERR_HIP, "table upload failed");
             break;
@@ -864,52 +637,14 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
     return MPEGHIP_OK;
 }
 
-// The descriptor arrays are either allocations of their own (resident batches) or parts of d_blob; a staging
-// batch may change from one blob form to the other between submits.
-static void batch_drop_descriptors(mpeghip_batch *b)
+static void batch_release(mpeghip_batch *b)
 {
-    if (b->form == mpeghip_batch::Separate) {
-        if (b->d_pics)
-            (void)hipFree(b->d_pics);
-        if (b->d_xmbs)
-            (void)hipFree(b->d_xmbs);
-    } else {
-        if (b->d_blob)
-            (void)hipFree(b->d_blob);
-        if (b->form == mpeghip_batch::SubmitBlob) { // these were parts of the blob as well
-            b->d_mbs = nullptr;
-            b->d_coefs = nullptr;
-            b->cap_mbs = b->cap_coefs = 0;
-        }
-    }
-    b->form = mpeghip_batch::Separate;
+    if (b->d_blob)
+        (void)hipFree(b->d_blob);
     b->d_blob = nullptr;
     b->cap_blob = 0;
     b->d_pics = nullptr;
-    b->d_xmbs = nullptr;
-    b->d_wire = nullptr;
-    b->d_wtab = nullptr;
-    b->cap_pics = b->cap_xmbs = 0;
-}
-
-static void batch_release(mpeghip_batch *b)
-{
-    batch_drop_descriptors(b);
-    if (b->d_mbs)
-        (void)hipFree(b->d_mbs);
-    if (b->d_coefs)
-        (void)hipFree(b->d_coefs);
-    if (b->d_entries)
-        (void)hipFree(b->d_entries);
-    b->d_entries = nullptr;
-    b->cap_entries = 0;
-    b->d_pics = nullptr;
-    b->d_mbs = nullptr;
-    b->d_xmbs = nullptr;
-    b->d_wire = nullptr;
-    b->d_wtab = nullptr;
-    b->d_coefs = nullptr;
-    b->cap_pics = b->cap_mbs = b->cap_coefs = 0;
+    b->d_chunks = b->d_words = nullptr;
 }
 
 void mpeghip_video_close(mpeghip_video *v)
@@ -935,8 +670,6 @@ void mpeghip_video_close(mpeghip_video *v)
         (void)hipFree(v->d_rgba);
     if (v->d_qmat)
         (void)hipFree(v->d_qmat);
-    if (v->d_dump)
-        (void)hipFree(v->d_dump);
     if (v->d_hash)
         (void)hipFree(v->d_hash);
     delete v;
@@ -955,7 +688,7 @@ int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream, const uint8_t int
     if (!v || !intra || !non_intra || stream >= v->info.n_streams)
         return fail(MPEGHIP_ERR_INVALID, "bad argument");
     uint8_t t[256];
-    make_qtable(t, intra, non_intra);
+    rc_make_qtable(t, intra, non_intra, k_premult);
     HIP_TRY(hipSetDevice(v->ctx->device));
     HIP_TRY(hipStreamSynchronize(v->ctx->stream)); // earlier pictures may still read the old matrices
     HIP_TRY(hipMemcpy(v->d_qmat + (size_t)stream * 256, t, 256, hipMemcpyHostToDevice));
@@ -978,10 +711,9 @@ static int ensure_rgba(mpeghip_video *v)
     return MPEGHIP_OK;
 }
 
-static bool wants_rgba(const mpeghip_pic_desc *pics, uint32_t n_pics);
 static uint64_t rgba_stride_of(const mpeghip_video *v) { return align_up(v->info.rgba_bytes, 256); }
 
-// Host-side validation of one submit; also totals the algorithmic bytes.
+// ---- host-side validation of a submit; also totals the algorithmic bytes
 static int validate_pic(const mpeghip_video_info &in, const mpeghip_pic_desc &pd, uint32_t p)
 {
     if (pd.stream >= in.n_streams || pd.cur >= MPEGHIP_SLOTS || pd.fwd >= MPEGHIP_SLOTS || pd.bwd >= MPEGHIP_SLOTS)
@@ -990,9 +722,9 @@ static int validate_pic(const mpeghip_video_info &in, const mpeghip_pic_desc &pd
 }
 
 // One macroblock of picture `pd`: field ranges, coefficient extent inside [0, coef_units), prediction
-// reads inside the frame buffer.  *units = coefficient units it owns; adds its algorithmic bytes to *alg.
+// reads inside the frame buffer.  Adds its algorithmic bytes to *alg.
 static int validate_mb(const mpeghip_video_info &in, const mpeghip_pic_desc &pd, const mpeghip_mb_desc &m, uint32_t i,
-                       uint64_t coef_units, uint64_t *units_out, uint64_t *alg)
+                       uint64_t coef_units, uint64_t *alg)
 {
     if (m.mb_x >= in.mb_w || m.mb_y >= in.mb_h)
         return fail(MPEGHIP_ERR_INVALID, "macroblock %u: position (%u,%u) outside %ux%u", i, m.mb_x, m.mb_y, in.mb_w,
@@ -1012,6 +744,9 @@ static int validate_mb(const mpeghip_video_info &in, const mpeghip_pic_desc &pd,
         return fail(MPEGHIP_ERR_INVALID, "macroblock %u: quantiser_scale %u", i, m.qscale);
     uint64_t ref_bytes = 0;
     if (!intra) {
+        const uint8_t ref = (m.flags & MPEGHIP_MB_REF_BWD) ? pd.bwd : pd.fwd;
+        if (ref == pd.cur)
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: predicts from the slot its picture writes (%u)", i, ref);
         // extents of the reference's copyBlock reads (video_noasm.go:48-80): Go
         // indexes src[:cap(src)], i.e. [plane start, end of base); anything else panics.
         const int64_t cap_y = (int64_t)in.frame_bytes;
@@ -1030,76 +765,144 @@ static int validate_mb(const mpeghip_video_info &in, const mpeghip_pic_desc &pd,
                         i, m.mb_x, m.mb_y, mh, mv);
         ref_bytes = (uint64_t)(16 + lov) * (16 + loh) + 2ull * (8 + cov) * (8 + coh);
     }
-    *units_out = units;
     *alg += 32 + units * MPEGHIP_COEF_UNIT + ref_bytes + (intra ? 64ull * nb : 384);
     if (pd.flags & MPEGHIP_PIC_RGBA)
         *alg += 1024;
     return MPEGHIP_OK;
 }
 
-static XGeom record_geometry(const mpeghip_video *v)
+// All macroblocks of ONE picture.  Macroblocks of one submit run concurrently, so a position may be named once
+// only (the reference lets a damaged stream address a macroblock twice, video.go:462-486: the emitter starts a
+// new submit there); `seen` is scratch of at least mb_w * mb_h bits.
+static int validate_picture(const mpeghip_video_info &in, const mpeghip_pic_desc &pd, uint32_t p, const mpeghip_mb_desc *mbs,
+                            uint32_t n, uint32_t first_index, uint64_t coef_units, uint64_t *alg, PicUse *use,
+                            std::vector<uint64_t> &seen)
 {
-    XGeom geom;
-    geom.luma_w = v->info.luma_w;
-    geom.chroma_w = v->info.chroma_w;
-    geom.frame_stride = v->info.frame_stride;
-    geom.rgba_stride = rgba_stride_of(v);
-    return geom;
+    seen.assign(((size_t)in.mb_w * in.mb_h + 63) / 64, 0);
+    PicUse u;
+    for (uint32_t k = 0; k < n; k++) {
+        const mpeghip_mb_desc &m = mbs[k];
+        const int rc = validate_mb(in, pd, m, first_index + k, coef_units, alg);
+        if (rc != MPEGHIP_OK)
+            return rc;
+        const uint32_t at = (uint32_t)m.mb_y * in.mb_w + m.mb_x;
+        if (seen[at >> 6] & (1ull << (at & 63)))
+            return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock (%u,%u) is addressed twice in one submit", p, m.mb_x, m.mb_y);
+        seen[at >> 6] |= 1ull << (at & 63);
+        u.fwd |= (m.flags & MPEGHIP_MB_REF_FWD) ? 1 : 0;
+        u.bwd |= (m.flags & MPEGHIP_MB_REF_BWD) ? 1 : 0;
+    }
+    *use = u;
+    return MPEGHIP_OK;
 }
 
-static int validate(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
-                    const mpeghip_mb_desc *mbs, uint32_t n_mbs, size_t coef_bytes, uint64_t *alg_bytes,
-                    bool *dense_partition, uint32_t *xrec = nullptr)
+// Pictures of one stream inside one submit run concurrently too: none may write a slot another one writes or
+// predicts from.
+static int check_dependencies(const mpeghip_pic_desc *pics, const PicUse *use, uint32_t n_pics)
 {
-    // xrec != NULL: also write each macroblock's expanded record (video_compact_lane.h: expand_mb) — the same
-    // pass has just checked every field the record is computed from
+    if (n_pics < 2)
+        return MPEGHIP_OK;
+    std::vector<uint32_t> order(n_pics);
+    for (uint32_t p = 0; p < n_pics; p++)
+        order[p] = p;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return pics[x].stream != pics[y].stream ? pics[x].stream < pics[y].stream : x < y;
+    });
+    for (uint32_t i = 0; i < n_pics;) {
+        uint32_t j = i + 1;
+        while (j < n_pics && pics[order[j]].stream == pics[order[i]].stream)
+            j++;
+        for (uint32_t x = i; x < j; x++)
+            for (uint32_t y = i; y < j; y++) {
+                if (x == y)
+                    continue;
+                const mpeghip_pic_desc &w = pics[order[x]], &r = pics[order[y]];
+                if ((x < y && w.cur == r.cur) || (use[order[y]].fwd && r.fwd == w.cur) || (use[order[y]].bwd && r.bwd == w.cur))
+                    return fail(MPEGHIP_ERR_INVALID, "pictures %u and %u of stream %u depend on each other (slot %u): they need "
+                                "separate submits", order[x], order[y], w.stream, w.cur);
+            }
+        i = j;
+    }
+    return MPEGHIP_OK;
+}
+
+static RcGeom record_geometry(const mpeghip_video *v)
+{
+    RcGeom g;
+    g.luma_w = v->info.luma_w;
+    g.chroma_w = v->info.chroma_w;
+    g.luma_bytes = (uint32_t)v->info.luma_bytes;
+    g.frame_stride = v->info.frame_stride;
+    g.rgba_stride = rgba_stride_of(v);
+    return g;
+}
+
+// chunks a submit needs: every picture's macroblocks are padded to whole chunks
+static uint64_t chunks_of(const mpeghip_pic_desc *pics, uint32_t n_pics)
+{
+    uint64_t n = 0;
+    for (uint32_t p = 0; p < n_pics; p++)
+        n += rc_max_chunks(pics[p].mb_count);
+    return n;
+}
+
+// Validate a whole submit and (chunks_out != NULL) pack it into the device format.  The macroblocks of picture p
+// are mbs[mb_first .. mb_first + mb_count); every macroblock belongs to exactly one picture's range.
+static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                             const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
+                             uint64_t *alg_bytes, uint32_t *chunks_out, uint32_t *words_out, uint64_t *n_words)
+{
     const mpeghip_video_info &in = v->info;
-    const XGeom geom = record_geometry(v);
-    std::vector<XPic> xpics;
     if (n_pics && !pics)
         return fail(MPEGHIP_ERR_INVALID, "pics is NULL");
     if (n_mbs && !mbs)
         return fail(MPEGHIP_ERR_INVALID, "mbs is NULL");
+    if (n_mbs > 0 && coef_bytes > 0 && !coefs)
+        return fail(MPEGHIP_ERR_INVALID, "coefs is NULL");
     if (coef_bytes % MPEGHIP_COEF_UNIT)
         return fail(MPEGHIP_ERR_INVALID, "coef_bytes %zu is not a multiple of 128", coef_bytes);
+    uint64_t covered = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
         const int rc = validate_pic(in, pics[p], p);
         if (rc != MPEGHIP_OK)
             return rc;
         if ((uint64_t)pics[p].mb_first + pics[p].mb_count > n_mbs)
             return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock range out of bounds", p);
+        covered += pics[p].mb_count;
     }
-    if (xrec) {
-        xpics.resize(n_pics);
-        for (uint32_t p = 0; p < n_pics; p++)
-            xpics[p] = expand_pic(geom, pics[p]);
-    }
-    uint64_t alg = 0;
+    if (covered != n_mbs)
+        return fail(MPEGHIP_ERR_INVALID, "the pictures' macroblock ranges cover %llu of %u macroblocks",
+                    (unsigned long long)covered, n_mbs);
+    const RcGeom geom = record_geometry(v);
     const uint64_t coef_units = coef_bytes / MPEGHIP_COEF_UNIT;
-    uint64_t next_unit = 0;
-    bool dense = true;
-    for (uint32_t i = 0; i < n_mbs; i++) {
-        const mpeghip_mb_desc &m = mbs[i];
-        if (m.pic >= n_pics)
-            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: picture index %u out of range", i, m.pic);
-        uint64_t units = 0;
-        const int rc = validate_mb(in, pics[m.pic], m, i, coef_units, &units, &alg);
+    std::vector<PicUse> use(n_pics);
+    std::vector<uint64_t> seen;
+    uint64_t alg = 0, words = 0, chunk = 0;
+    for (uint32_t p = 0; p < n_pics; p++) {
+        const mpeghip_mb_desc *pm = mbs + pics[p].mb_first;
+        for (uint32_t k = 0; k < pics[p].mb_count; k++)
+            if (pm[k].pic != p)
+                return fail(MPEGHIP_ERR_INVALID, "macroblock %u: names picture %u but lies in picture %u's range",
+                            pics[p].mb_first + k, pm[k].pic, p);
+        const int rc = validate_picture(in, pics[p], p, pm, pics[p].mb_count, pics[p].mb_first, coef_units, &alg, &use[p], seen);
         if (rc != MPEGHIP_OK)
             return rc;
-        if (units) {
-            if (m.coef_off != next_unit)
-                dense = false;
-            next_unit = (uint64_t)m.coef_off + units;
+        if (chunks_out) {
+            if (words > 0xffffffffull - rc_max_words(coef_units))
+                return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
+            const RcPacked got = rc_pack_picture(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
+                                                 (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words);
+            chunk += got.chunks;
+            words += got.words;
         }
-        if (xrec)
-            expand_mb(geom, xpics[m.pic], m, xrec + (size_t)i * kXDwords);
     }
-    if (xrec)
-        mark_chunk_runs(xrec, n_mbs);
+    const int rc = check_dependencies(pics, use.data(), n_pics);
+    if (rc != MPEGHIP_OK)
+        return rc;
     if (alg_bytes)
         *alg_bytes = alg;
-    if (dense_partition)
-        *dense_partition = dense && next_unit == coef_units;
+    if (n_words)
+        *n_words = words;
     return MPEGHIP_OK;
 }
 
@@ -1118,30 +921,25 @@ static int grow(void **p, size_t *cap, size_t need)
     return MPEGHIP_OK;
 }
 
-// Development knob (not part of the ABI): MPEGHIP_RECON="mode,waves,blocks_per_cu".
-//   mode 6 (default): wave-chunk kernel: one wave = 4 macroblocks, dense residual stage, no barrier
-//                     ("waves" = 4 -> 4 waves/block, 8 -> 8, 16 -> 2)
-//   mode 5: compact fused kernel (dense residual stage inside the workgroup) (+ RGBA pass)
-//   mode 4: split path, K1 prediction + K2 dense residual (+ RGBA pass)
-//   mode 0: fused one-wave-per-macroblock kernel;  1-3: its persistent / pipelined variants
-struct ReconKnob {
-    int mode = 6, waves = 4, bpc = 4;
-};
-static ReconKnob recon_knob()
+static int grow_pinned(mpeghip_video::Staging *sg, size_t need)
 {
-    ReconKnob r;
-    if (const char *e = getenv("MPEGHIP_RECON"))
-        sscanf(e, "%d,%d,%d", &r.mode, &r.waves, &r.bpc);
-    if (r.waves != 4 && r.waves != 8 && r.waves != 16)
-        r.waves = 8;
-    if (r.mode < 0 || r.mode > 6)
-        r.mode = 6;
-    return r;
+    if (need <= sg->cap_h)
+        return MPEGHIP_OK;
+    if (sg->h)
+        (void)hipHostFree(sg->h);
+    sg->h = nullptr;
+    sg->cap_h = 0;
+    const size_t cap = need + need / 2;
+    HIP_TRY(hipHostMalloc((void **)&sg->h, cap, hipHostMallocDefault));
+    sg->cap_h = cap;
+    return MPEGHIP_OK;
 }
+
+constexpr int kReconWaves = 4; // waves (= chunks) per workgroup
 
 static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
 {
-    if (b->n_mbs == 0)
+    if (b->n_chunks == 0)
         return MPEGHIP_OK;
     const mpeghip_video_info &in = v->info;
     VideoArgs a;
@@ -1154,145 +952,44 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.luma_bytes = (uint32_t)in.luma_bytes;
     a.chroma_bytes = (uint32_t)in.chroma_bytes;
     a.pics = b->d_pics;
-    a.mbs = b->d_mbs;
-    a.xmbs = b->d_xmbs;
-    a.coefs = b->d_coefs;
+    a.chunks = b->d_chunks;
+    a.words = b->d_words;
     a.qmat = v->d_qmat;
-    a.dump = v->d_dump;
-    a.n_mbs = (uint32_t)b->n_mbs;
+    a.n_chunks = (uint32_t)b->n_chunks;
     a.width = in.width;
     a.height = in.height;
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
-    const ReconKnob knob = recon_knob();
-    const int mode = knob.mode, waves = knob.waves, bpc = knob.bpc;
-    if (mode == 6) {
-        hipStream_t st = v->ctx->stream;
-        const uint32_t n_chunks = (uint32_t)((b->n_mbs + kWcMbs - 1) / kWcMbs);
-#define LAUNCH_WC(W)                                                                                                   \
-    do {                                                                                                               \
-        if (b->any_rgba)                                                                                               \
-            hipLaunchKernelGGL((recon_wc_kernel<W, true>), dim3((n_chunks + W - 1) / W), dim3(W * 64), 0, st, a, n_chunks);  \
-        else                                                                                                           \
-            hipLaunchKernelGGL((recon_wc_kernel<W, false>), dim3((n_chunks + W - 1) / W), dim3(W * 64), 0, st, a, n_chunks); \
-    } while (0)
-        if (waves == 8)
-            LAUNCH_WC(8);
-        else if (waves == 16)
-            LAUNCH_WC(2);
-        else
-            LAUNCH_WC(4);
-#undef LAUNCH_WC
-        HIP_TRY(hipGetLastError());
-        // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
-        // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
-        // image was out of date (an unflagged picture or write_planes touched the slot since).
-        bool whole_frames = false;
-        for (uint32_t r = 0; r < b->replicas; r++)
-            for (const mpeghip_batch::PicNote &n : b->notes) {
-                uint8_t &sync = v->rgba_sync[((size_t)n.stream + r) * MPEGHIP_SLOTS + n.cur];
-                if (!n.rgba)
-                    sync = 0;
-                else if (n.full)
-                    sync = 1;
-                else if (!sync)
-                    whole_frames = true, sync = 1;
-            }
-        if (whole_frames) {
-            const uint32_t quads = (in.width + 3) / 4;
-            for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
-                const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
-                                   (uint32_t)p0);
-            }
-            HIP_TRY(hipGetLastError());
-        }
-        return MPEGHIP_OK;
-    }
-    if (mode == 5) {
-        hipStream_t st = v->ctx->stream;
-        const uint32_t blocks = (uint32_t)((b->n_mbs + kChunkMbs - 1) / kChunkMbs);
-        hipLaunchKernelGGL(recon_compact_kernel, dim3(blocks), dim3(kChunkMbs * 64), 0, st, a);
-        HIP_TRY(hipGetLastError());
-        if (b->any_rgba) {
-            const uint32_t quads = (in.width + 3) / 4;
-            for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
-                const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
-                                   (uint32_t)p0);
-            }
-            HIP_TRY(hipGetLastError());
-        }
-        return MPEGHIP_OK;
-    }
-    if (mode == 4) {
-        hipStream_t st = v->ctx->stream;
-        SplitArgs s;
-        s.v = a;
-        s.entries = b->d_entries;
-        s.n_units = (uint32_t)(b->coef_bytes / MPEGHIP_COEF_UNIT);
-        if (!b->dense_partition && s.n_units)
-            HIP_TRY(hipMemsetAsync(b->d_entries, 0xff, (size_t)s.n_units * sizeof(BlockEntry), st));
-        const uint32_t pred_blocks = (uint32_t)((b->n_mbs + 2 * waves - 1) / (2 * waves));
-        const uint32_t resid_blocks = (s.n_units + 8 * waves - 1) / (8 * waves);
-#define LAUNCH_SPLIT(W)                                                                                                \
-    do {                                                                                                               \
-        hipLaunchKernelGGL((pred_kernel<W>), dim3(pred_blocks), dim3(W * 64), 0, st, s);                               \
-        if (resid_blocks)                                                                                              \
-            hipLaunchKernelGGL((resid_kernel<W>), dim3(resid_blocks), dim3(W * 64), 0, st, s);                         \
-    } while (0)
-        if (waves == 4)
-            LAUNCH_SPLIT(4);
-        else if (waves == 16)
-            LAUNCH_SPLIT(16);
-        else
-            LAUNCH_SPLIT(8);
-#undef LAUNCH_SPLIT
-        HIP_TRY(hipGetLastError());
-        if (b->any_rgba) {
-            const uint32_t quads = (in.width + 3) / 4;
-            for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
-                const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-                hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
-                                   (uint32_t)p0);
-            }
-            HIP_TRY(hipGetLastError());
-        }
-        return MPEGHIP_OK;
-    }
-    const uint32_t n_chunks = (uint32_t)((b->n_mbs + waves - 1) / waves);
-    uint32_t blocks = n_chunks;
-    if (mode != 0) {
-        int n_cu = 256;
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, v->ctx->device);
-        uint32_t want = (uint32_t)n_cu * (uint32_t)(bpc < 1 ? 1 : bpc);
-        want = (want + 7) / 8 * 8;
-        while ((size_t)want * (size_t)waves * 512 > v->dump_bytes && want > 8)
-            want -= 8;
-        blocks = want;
-    }
     hipStream_t st = v->ctx->stream;
-#define LAUNCH(W, M) hipLaunchKernelGGL((recon_kernel<W, M>), dim3(blocks), dim3(W * 64), 0, st, a, n_chunks)
-#define LAUNCH_W(W)                                                                                                    \
-    do {                                                                                                               \
-        if (mode == 0)                                                                                                 \
-            LAUNCH(W, 0);                                                                                              \
-        else if (mode == 1)                                                                                            \
-            LAUNCH(W, 1);                                                                                              \
-        else if (mode == 3)                                                                                            \
-            LAUNCH(W, 3);                                                                                              \
-        else                                                                                                           \
-            LAUNCH(W, 2);                                                                                              \
-    } while (0)
-    if (waves == 4)
-        LAUNCH_W(4);
-    else if (waves == 16)
-        LAUNCH_W(16);
+    const uint32_t grid = (a.n_chunks + kReconWaves - 1) / kReconWaves;
+    if (b->any_rgba)
+        hipLaunchKernelGGL((recon_kernel<kReconWaves, true>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
     else
-        LAUNCH_W(8);
-#undef LAUNCH_W
-#undef LAUNCH
+        hipLaunchKernelGGL((recon_kernel<kReconWaves, false>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
     HIP_TRY(hipGetLastError());
+    // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
+    // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
+    // image was out of date (an unflagged picture or write_planes touched the slot since).
+    bool whole_frames = false;
+    for (uint32_t r = 0; r < b->replicas; r++)
+        for (const mpeghip_batch::PicNote &n : b->notes) {
+            uint8_t &sync = v->rgba_sync[((size_t)n.stream + r) * MPEGHIP_SLOTS + n.cur];
+            if (!n.rgba)
+                sync = 0;
+            else if (n.full)
+                sync = 1;
+            else if (!sync)
+                whole_frames = true, sync = 1;
+        }
+    if (whole_frames) {
+        const uint32_t quads = (in.width + 3) / 4;
+        for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
+            const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
+            hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
+                               (uint32_t)p0);
+        }
+        HIP_TRY(hipGetLastError());
+    }
     return MPEGHIP_OK;
 }
 
@@ -1304,137 +1001,123 @@ static bool wants_rgba(const mpeghip_pic_desc *pics, uint32_t n_pics)
     return false;
 }
 
-// `sg` != nullptr: b is that staging slot's batch; the host arrays are copied into its pinned buffer
-// and the call returns with the copies still in flight.  Otherwise (resident batches) the copies
-// read the caller's pageable memory and the call waits for them.
-static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_desc *pics, uint32_t n_pics,
-                       const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
-                       uint32_t replicas, mpeghip_video::Staging *sg = nullptr)
+static void fill_notes(const mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_desc *pics, uint32_t n_pics)
 {
-    if (n_mbs > 0 && coef_bytes > 0 && !coefs)
-        return fail(MPEGHIP_ERR_INVALID, "coefs is NULL");
-    if ((uint64_t)n_mbs * replicas > 0xffffffffull || (uint64_t)(coef_bytes / MPEGHIP_COEF_UNIT) * replicas > 0xffffffffull)
-        return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit descriptor indices");
-    HIP_TRY(hipSetDevice(v->ctx->device));
-    // The wave-chunk kernel (mode 6) reads expanded records, which the validation pass below writes straight
-    // into the buffer the H2D copy reads; the ABI descriptors go to the device only for the diagnostic
-    // kernels.  A submit carries one of the two; a resident batch both (it may be run under either knob).
-    const bool records = !sg || recon_knob().mode == 6, descs = !sg || !records;
-    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics;
-    const size_t mb = descs ? sizeof(mpeghip_mb_desc) * (size_t)n_mbs : 0;
-    const size_t xb = records ? sizeof(uint32_t) * kXDwords * (size_t)n_mbs : 0;
-    const size_t x_at = (pb + mb + 63) & ~(size_t)63, coef_at = (x_at + xb + 63) & ~(size_t)63;
-    std::vector<uint32_t> xhost; // (resident batches: pageable, this call waits for the copies anyway)
-    uint32_t *xrec = nullptr;
-    hipStream_t st = v->ctx->stream;
-    if (sg) {
-        if (sg->in_flight) { // two submits ago: normally long finished
-            HIP_TRY(hipEventSynchronize(sg->done));
-            sg->in_flight = false;
-        }
-        const size_t need = coef_at + coef_bytes + 64;
-        if (need > sg->cap_h) {
-            if (sg->h)
-                (void)hipHostFree(sg->h);
-            sg->h = nullptr;
-            sg->cap_h = 0;
-            const size_t cap = need + need / 2;
-            HIP_TRY(hipHostMalloc((void **)&sg->h, cap, hipHostMallocDefault));
-            sg->cap_h = cap;
-        }
-        if (!sg->done)
-            HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
-        if (records)
-            xrec = reinterpret_cast<uint32_t *>(sg->h + x_at);
-    } else if (records) {
-        xhost.resize((size_t)n_mbs * kXDwords);
-        xrec = xhost.data();
-    }
-    int rc = validate(v, pics, n_pics, mbs, n_mbs, coef_bytes, &b->alg_bytes, &b->dense_partition, xrec);
-    b->any_rgba = wants_rgba(pics, n_pics);
-    if (rc != MPEGHIP_OK)
-        return rc;
-    if (b->any_rgba) {
-        rc = ensure_rgba(v);
-        if (rc != MPEGHIP_OK)
-            return rc;
-    }
-    if (sg) {
-        if (pb)
-            memcpy(sg->h, pics, pb);
-        if (mb)
-            memcpy(sg->h + pb, mbs, mb);
-        if (coef_bytes)
-            memcpy(sg->h + coef_at, coefs, coef_bytes);
-        pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->h);
-        mbs = reinterpret_cast<const mpeghip_mb_desc *>(sg->h + pb);
-        coefs = sg->h + coef_at;
-    }
-    if (sg) {
-        // one allocation = the image of the staging buffer, one copy
-        if (b->form != mpeghip_batch::SubmitBlob) {
-            batch_drop_descriptors(b);
-            if (b->d_mbs) // allocations of their own so far; parts of the blob from now on
-                (void)hipFree(b->d_mbs);
-            if (b->d_coefs)
-                (void)hipFree(b->d_coefs);
-            b->d_mbs = nullptr;
-            b->d_coefs = nullptr;
-            b->cap_mbs = b->cap_coefs = 0;
-        }
-        b->form = mpeghip_batch::SubmitBlob;
-        const size_t total = coef_at + coef_bytes;
-        if ((rc = grow((void **)&b->d_blob, &b->cap_blob, total + 256)) != 0 ||
-            (rc = grow((void **)&b->d_entries, &b->cap_entries, (coef_bytes / MPEGHIP_COEF_UNIT) * sizeof(BlockEntry) + 64)) != 0)
-            return rc;
-        b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
-        b->d_mbs = reinterpret_cast<mpeghip_mb_desc *>(b->d_blob + pb);
-        b->d_xmbs = reinterpret_cast<uint32_t *>(b->d_blob + x_at);
-        b->d_coefs = b->d_blob + coef_at;
-        HIP_TRY(hipMemcpyAsync(b->d_blob, sg->h, total, hipMemcpyHostToDevice, st));
-    } else {
-        if (b->form != mpeghip_batch::Separate)
-            batch_drop_descriptors(b);
-        if ((rc = grow((void **)&b->d_pics, &b->cap_pics, sizeof(mpeghip_pic_desc) * (size_t)n_pics * replicas + 16)) != 0 ||
-            (rc = grow((void **)&b->d_mbs, &b->cap_mbs, mb * replicas + 32)) != 0 ||
-            (rc = grow((void **)&b->d_xmbs, &b->cap_xmbs, xb * replicas + 64 * kWcMbs)) != 0 ||
-            (rc = grow((void **)&b->d_coefs, &b->cap_coefs, coef_bytes * replicas + 256)) != 0 ||
-            (rc = grow((void **)&b->d_entries, &b->cap_entries, (coef_bytes / MPEGHIP_COEF_UNIT) * replicas * sizeof(BlockEntry) + 64)) != 0)
-            return rc;
-        if (pb)
-            HIP_TRY(hipMemcpyAsync(b->d_pics, pics, pb, hipMemcpyHostToDevice, st));
-        if (mb)
-            HIP_TRY(hipMemcpyAsync(b->d_mbs, mbs, mb, hipMemcpyHostToDevice, st));
-        if (xb)
-            HIP_TRY(hipMemcpyAsync(b->d_xmbs, xrec, xb, hipMemcpyHostToDevice, st));
-        if (coef_bytes)
-            HIP_TRY(hipMemcpyAsync(b->d_coefs, coefs, coef_bytes, hipMemcpyHostToDevice, st));
-    }
-    if (replicas > 1) {
-        for (uint32_t s = 1; s < replicas && coef_bytes; s++)
-            HIP_TRY(hipMemcpyAsync(b->d_coefs + (size_t)s * coef_bytes, b->d_coefs, coef_bytes, hipMemcpyDeviceToDevice, st));
-        const uint64_t work = (uint64_t)(n_mbs > n_pics ? n_mbs : n_pics) * replicas;
-        ReplicateSteps k;
-        k.coef_units = (uint32_t)(coef_bytes / MPEGHIP_COEF_UNIT);
-        k.frames256 = (uint32_t)((MPEGHIP_SLOTS * v->info.frame_stride) >> 8);
-        k.rgba256 = (uint32_t)((MPEGHIP_SLOTS * rgba_stride_of(v)) >> 8);
-        hipLaunchKernelGGL(replicate_desc_kernel, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, st, b->d_pics, n_pics,
-                           descs ? b->d_mbs : nullptr, records ? b->d_xmbs : nullptr, n_mbs, k, replicas);
-        HIP_TRY(hipGetLastError());
-    }
-    if (!sg) // pageable host memory: the copies above may still be reading it
-        HIP_TRY(hipStreamSynchronize(st));
     b->notes.resize(n_pics);
     for (uint32_t p = 0; p < n_pics; p++) {
         b->notes[p].stream = pics[p].stream;
         b->notes[p].cur = pics[p].cur;
         b->notes[p].rgba = (pics[p].flags & MPEGHIP_PIC_RGBA) ? 1 : 0;
-        b->notes[p].full = pics[p].mb_count == v->info.mb_w * v->info.mb_h ? 1 : 0; // (macroblocks of one submit do not overlap)
+        // (validation has seen every position at most once: as many macroblocks as the frame has = all of them)
+        b->notes[p].full = pics[p].mb_count == v->info.mb_w * v->info.mb_h ? 1 : 0;
     }
+}
+
+// region offsets of a batch image: pictures | chunks | words
+struct BlobLayout {
+    size_t c_at, w_at;
+};
+static BlobLayout blob_layout(uint64_t n_pics, uint64_t n_chunks)
+{
+    BlobLayout l;
+    l.c_at = (sizeof(mpeghip_pic_desc) * (size_t)n_pics + 63) & ~(size_t)63;
+    l.w_at = (l.c_at + (size_t)n_chunks * kRcChunkDwords * 4 + 63) & ~(size_t)63;
+    return l;
+}
+
+// `sg` != nullptr: b is that staging slot's batch; the submit is packed into its pinned buffer and the call
+// returns with the copy still in flight.  Otherwise (resident batches) the image is packed in pageable memory,
+// copied, replicated on the device, and the call waits.
+static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                       const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
+                       uint32_t replicas, mpeghip_video::Staging *sg = nullptr)
+{
+    if ((uint64_t)n_mbs * replicas > 0xffffffffull)
+        return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
+    if (n_pics && !pics)
+        return fail(MPEGHIP_ERR_INVALID, "pics is NULL");
+    for (uint32_t p = 0; p < n_pics; p++)
+        if ((uint64_t)pics[p].mb_first + pics[p].mb_count > n_mbs)
+            return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock range out of bounds", p);
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    const uint64_t n_chunks = chunks_of(pics, n_pics);
+    const BlobLayout l = blob_layout(n_pics, n_chunks);
+    const size_t words_cap = rc_max_words(coef_bytes / MPEGHIP_COEF_UNIT) + kRcWordsPad;
+    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics;
+    hipStream_t st = v->ctx->stream;
+    std::vector<uint8_t> pageable;
+    uint8_t *h;
+    int rc;
+    if (sg) {
+        if (sg->in_flight) { // two submits ago: normally long finished
+            HIP_TRY(hipEventSynchronize(sg->done));
+            sg->in_flight = false;
+        }
+        if ((rc = grow_pinned(sg, l.w_at + words_cap * 4 + 64)) != MPEGHIP_OK)
+            return rc;
+        if (!sg->done)
+            HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
+        h = sg->h;
+    } else {
+        pageable.resize(l.w_at + words_cap * 4 + 64);
+        h = pageable.data();
+    }
+    uint64_t n_words = 0;
+    rc = validate_and_pack(v, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, &b->alg_bytes,
+                           reinterpret_cast<uint32_t *>(h + l.c_at), reinterpret_cast<uint32_t *>(h + l.w_at), &n_words);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    if (n_words * replicas > 0xffffffffull - kRcWordsPad)
+        return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
+    b->any_rgba = wants_rgba(pics, n_pics);
+    if (b->any_rgba && (rc = ensure_rgba(v)) != MPEGHIP_OK)
+        return rc;
+    if (pb)
+        memcpy(h, pics, pb);
+    if (replicas == 1) {
+        // the device image is the host image: one copy
+        const size_t total = l.w_at + (size_t)n_words * 4;
+        if ((rc = grow((void **)&b->d_blob, &b->cap_blob, total + kRcWordsPad * 4)) != 0)
+            return rc;
+        b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
+        b->d_chunks = reinterpret_cast<uint32_t *>(b->d_blob + l.c_at);
+        b->d_words = reinterpret_cast<uint32_t *>(b->d_blob + l.w_at);
+        if (total)
+            HIP_TRY(hipMemcpyAsync(b->d_blob, h, total, hipMemcpyHostToDevice, st));
+    } else {
+        const BlobLayout lr = blob_layout((uint64_t)n_pics * replicas, n_chunks * replicas);
+        const size_t total = lr.w_at + (size_t)n_words * 4 * replicas;
+        if ((rc = grow((void **)&b->d_blob, &b->cap_blob, total + kRcWordsPad * 4)) != 0)
+            return rc;
+        b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
+        b->d_chunks = reinterpret_cast<uint32_t *>(b->d_blob + lr.c_at);
+        b->d_words = reinterpret_cast<uint32_t *>(b->d_blob + lr.w_at);
+        if (pb)
+            HIP_TRY(hipMemcpyAsync(b->d_pics, h, pb, hipMemcpyHostToDevice, st));
+        if (n_chunks)
+            HIP_TRY(hipMemcpyAsync(b->d_chunks, h + l.c_at, (size_t)n_chunks * kRcChunkDwords * 4, hipMemcpyHostToDevice, st));
+        if (n_words)
+            HIP_TRY(hipMemcpyAsync(b->d_words, h + l.w_at, (size_t)n_words * 4, hipMemcpyHostToDevice, st));
+        for (uint32_t s = 1; s < replicas && n_words; s++)
+            HIP_TRY(hipMemcpyAsync(b->d_words + (size_t)s * n_words, b->d_words, (size_t)n_words * 4, hipMemcpyDeviceToDevice, st));
+        const uint64_t work = (n_chunks > n_pics ? n_chunks : (uint64_t)n_pics) * replicas;
+        ReplicateSteps k;
+        k.words = (uint32_t)n_words;
+        k.frames256 = (uint32_t)((MPEGHIP_SLOTS * v->info.frame_stride) >> 8);
+        k.rgba256 = (uint32_t)((MPEGHIP_SLOTS * rgba_stride_of(v)) >> 8);
+        if (work) {
+            hipLaunchKernelGGL(replicate_kernel, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, st, b->d_pics, n_pics,
+                               b->d_chunks, (uint32_t)n_chunks, n_mbs, k, replicas);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (!sg) // pageable host memory: the copies above may still be reading it
+        HIP_TRY(hipStreamSynchronize(st));
+    fill_notes(v, b, pics, n_pics);
     b->replicas = replicas;
     b->n_pics = (uint64_t)n_pics * replicas;
     b->n_mbs = (uint64_t)n_mbs * replicas;
-    b->coef_bytes = (uint64_t)coef_bytes * replicas;
+    b->n_chunks = n_chunks * replicas;
     b->alg_bytes *= replicas;
     return MPEGHIP_OK;
 }
@@ -1466,54 +1149,44 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
         return fail(MPEGHIP_ERR_INVALID, "stage_begin: NULL argument");
     if (v->stage)
         return fail(MPEGHIP_ERR_INVALID, "stage_begin: the previous stage is still open");
-    if (recon_knob().mode != 6)
-        return fail(MPEGHIP_ERR_INVALID, "stage_begin: staged submits feed the wave-chunk kernel only (MPEGHIP_RECON mode 6)");
     HIP_TRY(hipSetDevice(v->ctx->device));
     std::unique_ptr<mpeghip_stage> s(new mpeghip_stage);
     s->v = v;
     s->n_pics = n_pics;
     s->mb_first.resize(n_pics);
     s->mb_count.assign(n_mbs, n_mbs + n_pics);
-    s->unit_first.resize(n_pics);
+    s->chunk_first.resize(n_pics);
     s->units.resize(n_pics);
     s->alg.assign(n_pics, 0);
+    s->use.assign(n_pics, PicUse());
     s->done.assign(n_pics, 0);
-    const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics;
-    uint64_t mbs = 0, units = 0, wire = 0; // wire: dwords, worst case (every unit dense) + headers
+    uint64_t mbs = 0, chunks = 0, words = 0; // words: worst case (every coefficient of every unit non-zero)
     for (uint32_t i = 0; i < n_pics; i++) {
         if (coef_bytes[i] % MPEGHIP_COEF_UNIT)
             return fail(MPEGHIP_ERR_INVALID, "stage_begin: picture %u: coef_bytes %zu is not a multiple of 128", i, coef_bytes[i]);
         s->mb_first[i] = (uint32_t)mbs;
-        s->unit_first[i] = units;
+        s->chunk_first[i] = (uint32_t)chunks;
         s->units[i] = coef_bytes[i] / MPEGHIP_COEF_UNIT;
         mbs += n_mbs[i];
-        units += (s->units[i] + 7) & ~7ull; // a wave of wire_expand_kernel = 8 units of ONE picture
-        wire += (s->units[i] * (1 + kWireUnitDwords) + 15) & ~15ull;
-        if (mbs > 0xffffffffull || units > 0xffffffffull || wire > 0xffffffffull)
-            return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit descriptor indices");
+        chunks += rc_max_chunks(n_mbs[i]);
+        words += rc_max_words(s->units[i]);
+        if (mbs > 0xffffffffull || words > 0xffffffffull - kRcWordsPad)
+            return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
     }
     s->n_mbs = (uint32_t)mbs;
-    s->coef_units = units;
-    s->wire_cap_dwords = wire;
+    s->n_chunks = (uint32_t)chunks;
+    s->words_cap = words;
     mpeghip_video::Staging *sg = &v->staging[v->next_staging];
     if (sg->in_flight) { // two submits ago: normally long finished
         HIP_TRY(hipEventSynchronize(sg->done));
         sg->in_flight = false;
     }
-    const size_t xb = sizeof(uint32_t) * kXDwords * (size_t)mbs;
-    s->tab_at = (pb + 63) & ~(size_t)63;
-    s->x_at = (s->tab_at + sizeof(WireTab) * (size_t)n_pics + 63) & ~(size_t)63;
-    s->wire0 = (s->x_at + xb + 63) & ~(size_t)63;
-    const size_t need = s->wire0 + (size_t)wire * 4 + 64;
-    if (need > sg->cap_h) {
-        if (sg->h)
-            (void)hipHostFree(sg->h);
-        sg->h = nullptr;
-        sg->cap_h = 0;
-        const size_t cap = need + need / 2;
-        HIP_TRY(hipHostMalloc((void **)&sg->h, cap, hipHostMallocDefault));
-        sg->cap_h = cap;
-    }
+    const BlobLayout l = blob_layout(n_pics, chunks);
+    s->c_at = l.c_at;
+    s->w_at = l.w_at;
+    int rc = grow_pinned(sg, l.w_at + (size_t)(words + kRcWordsPad) * 4 + 64);
+    if (rc != MPEGHIP_OK)
+        return rc;
     if (!sg->done)
         HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
     s->sg = sg;
@@ -1547,46 +1220,22 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         pd.mb_first = first;
         pd.mb_count = n;
         reinterpret_cast<mpeghip_pic_desc *>(h)[i] = pd;
-        const XGeom geom = record_geometry(v);
-        const XPic xp = expand_pic(geom, pd);
-        uint32_t *xrec = reinterpret_cast<uint32_t *>(h + s->x_at);
-        const uint32_t unit0 = (uint32_t)s->unit_first[i];
         uint64_t alg = 0;
-        for (uint32_t k = 0; k < n && rc == MPEGHIP_OK; k++) {
-            uint64_t units = 0;
-            rc = validate_mb(v->info, pd, mbs[k], k, s->units[i], &units, &alg);
-            if (rc != MPEGHIP_OK)
-                break;
-            uint32_t *x = xrec + (size_t)(first + k) * kXDwords;
-            expand_mb(geom, xp, mbs[k], x);
-            x[1] += unit0; // coef_off: relative to the picture's coefficients -> to the batch's
-        }
-        if (rc != MPEGHIP_OK)
+        static thread_local std::vector<uint64_t> seen;
+        if ((rc = validate_picture(v->info, pd, i, mbs, n, 0, s->units[i], &alg, &s->use[i], seen)) != MPEGHIP_OK)
             break;
-        // horizontal runs of the chunks that lie inside this picture (commit looks at the straddling ones)
-        for (uint32_t c = (first + kWcMbs - 1) / kWcMbs * kWcMbs; c + kWcMbs <= first + n; c += kWcMbs)
-            mark_chunk_run(xrec, c);
-        // the coefficient units, in wire form (video_wire_lane.h): headers, then the payload — packed in this
-        // thread's scratch memory first, because the room a picture needs is only known afterwards
-        const uint32_t units = (uint32_t)s->units[i];
+        // the picture in the device format: its chunks go where they belong; its words are packed in this thread's
+        // scratch memory first, because the room they need is only known afterwards
         static thread_local std::vector<uint32_t> scratch;
-        const size_t worst = (size_t)units * (1 + kWireUnitDwords);
+        const size_t worst = rc_max_words(s->units[i]) + 64;
         if (scratch.size() < worst)
             scratch.resize(worst + worst / 4 + 1024);
-        uint32_t *hdr = scratch.data(), *payload = scratch.data() + units;
-        uint32_t used = 0;
-        const uint8_t *src = static_cast<const uint8_t *>(coefs);
-        for (uint32_t u = 0; u < units; u++)
-            hdr[u] = wire_pack_unit(src + (size_t)u * MPEGHIP_COEF_UNIT, payload, used);
-        const uint32_t dwords = (units + used + 3) & ~3u; // regions stay 16-byte aligned
-        const uint64_t at = s->wire_used.fetch_add(dwords);
-        memcpy(h + s->wire0 + at * 4, scratch.data(), (size_t)(units + used) * 4);
-        WireTab t;
-        t.unit_first = unit0;
-        t.units = units;
-        t.region = (uint32_t)at;
-        t.reserved = 0;
-        reinterpret_cast<WireTab *>(h + s->tab_at)[i] = t;
+        uint32_t *chunks = reinterpret_cast<uint32_t *>(h + s->c_at) + (size_t)s->chunk_first[i] * kRcChunkDwords;
+        const RcPacked got = rc_pack_picture(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0, chunks,
+                                             scratch.data());
+        const uint64_t at = s->words_used.fetch_add(got.words);
+        memcpy(h + s->w_at + at * 4, scratch.data(), (size_t)got.words * 4);
+        rc_rebase(chunks, got.chunks, (uint32_t)at);
         s->alg[i] = alg;
         s->done[i] = 1;
     } while (0);
@@ -1618,62 +1267,35 @@ int mpeghip_video_stage_commit(mpeghip_stage *sp)
     mpeghip_video::Staging *sg = s->sg;
     mpeghip_batch *b = &sg->batch;
     const mpeghip_pic_desc *pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->h);
-    uint32_t *xrec = reinterpret_cast<uint32_t *>(sg->h + s->x_at);
-    for (uint32_t i = 1; i < s->n_pics; i++) { // chunks that straddle two pictures
-        const uint32_t c = s->mb_first[i] / kWcMbs * kWcMbs;
-        if (c != s->mb_first[i] && c + kWcMbs <= s->n_mbs)
-            mark_chunk_run(xrec, c);
-    }
+    int rc = check_dependencies(pics, s->use.data(), s->n_pics);
+    if (rc != MPEGHIP_OK)
+        return rc;
     b->any_rgba = wants_rgba(pics, s->n_pics);
-    int rc;
     if (b->any_rgba && (rc = ensure_rgba(v)) != MPEGHIP_OK)
         return rc;
-    // the device image of the staging buffer: pictures | WireTab | records | wire regions, sent in ONE copy
+    // the device image of the staging buffer: pictures | chunks | words, sent as ONE range
     // (a copy costs the better part of a millisecond of stream time whatever its size)
-    const size_t cb = s->coef_units * MPEGHIP_COEF_UNIT;
-    if (b->form != mpeghip_batch::StageBlob)
-        batch_drop_descriptors(b); // (the batch was last used by a plain submit)
-    b->form = mpeghip_batch::StageBlob;
-    if ((rc = grow((void **)&b->d_blob, &b->cap_blob, s->wire0 + (size_t)s->wire_cap_dwords * 4 + 256)) != 0 ||
-        (rc = grow((void **)&b->d_coefs, &b->cap_coefs, cb + 256)) != 0)
+    const size_t total = s->w_at + (size_t)s->words_used.load() * 4;
+    if ((rc = grow((void **)&b->d_blob, &b->cap_blob, total + kRcWordsPad * 4)) != 0)
         return rc;
     b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
-    b->d_wtab = b->d_blob + s->tab_at;
-    b->d_xmbs = reinterpret_cast<uint32_t *>(b->d_blob + s->x_at);
-    b->d_wire = reinterpret_cast<uint32_t *>(b->d_blob + s->wire0);
+    b->d_chunks = reinterpret_cast<uint32_t *>(b->d_blob + s->c_at);
+    b->d_words = reinterpret_cast<uint32_t *>(b->d_blob + s->w_at);
     hipStream_t st = v->ctx->stream;
     {
         // in pieces: one copy of a gigabyte ran at a quarter of the rate of the same bytes in 32-128 MB pieces
-        const size_t total = s->wire0 + (size_t)s->wire_used.load() * 4, piece = (size_t)64 << 20;
+        const size_t piece = (size_t)64 << 20;
         for (size_t at = 0; at < total; at += piece)
             HIP_TRY(hipMemcpyAsync(b->d_blob + at, sg->h + at, total - at < piece ? total - at : piece, hipMemcpyHostToDevice, st));
     }
-    uint32_t max_units = 0;
-    for (uint32_t i = 0; i < s->n_pics; i++)
-        max_units = s->units[i] > max_units ? (uint32_t)s->units[i] : max_units;
-    if (max_units) {
-        const uint32_t gx = ((max_units + 7) / 8 + 3) / 4;
-        for (uint32_t p0 = 0; p0 < s->n_pics; p0 += 32768) {
-            const uint32_t np = s->n_pics - p0 < 32768 ? s->n_pics - p0 : 32768;
-            hipLaunchKernelGGL(wire_expand_kernel, dim3(gx, np), dim3(256), 0, st, b->d_wire,
-                               static_cast<const WireTab *>(b->d_wtab), p0, b->d_coefs);
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    b->notes.resize(s->n_pics);
+    fill_notes(v, b, pics, s->n_pics);
     b->alg_bytes = 0;
-    for (uint32_t p = 0; p < s->n_pics; p++) {
-        b->notes[p].stream = pics[p].stream;
-        b->notes[p].cur = pics[p].cur;
-        b->notes[p].rgba = (pics[p].flags & MPEGHIP_PIC_RGBA) ? 1 : 0;
-        b->notes[p].full = pics[p].mb_count == v->info.mb_w * v->info.mb_h ? 1 : 0;
+    for (uint32_t p = 0; p < s->n_pics; p++)
         b->alg_bytes += s->alg[p];
-    }
     b->replicas = 1;
     b->n_pics = s->n_pics;
     b->n_mbs = s->n_mbs;
-    b->coef_bytes = cb;
-    b->dense_partition = false;
+    b->n_chunks = s->n_chunks;
     v->next_staging ^= 1;
     rc = launch_batch(v, b);
     if (rc != MPEGHIP_OK)
@@ -1916,12 +1538,6 @@ int mpeghip_audio_open(mpeghip_ctx *c, uint32_t n_streams, int fma_mode, mpeghip
         mpeghip_audio_close(a);
         return fail(MPEGHIP_ERR_OOM, "audio state allocation failed");
     }
-    if (getenv("MPEGHIP_DEBUG")) { // development aid: resident workgroups per CU of both kernels
-        int na = 0, nv = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&na, audio_kernel<false, MPEGHIP_AUDIO_F32N>, kAudioThreads, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nv, recon_wc_kernel<4, false>, 256, 0);
-        fprintf(stderr, "mpeghip: occupancy audio_kernel %d, recon_wc_kernel<4> %d workgroups per CU\n", na, nv);
-    }
     *out = a;
     return MPEGHIP_OK;
 }
@@ -2119,14 +1735,5 @@ int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, i
     HIP_TRY(hipMemcpy(a->d_vpos + stream, &vpos, sizeof(int32_t), hipMemcpyHostToDevice));
     return MPEGHIP_OK;
 }
-
-#ifdef MPG_PHASE_TIMING
-int mpeghip_debug_read_dump(mpeghip_video *v, void *dst, size_t bytes)
-{
-    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
-    HIP_TRY(hipMemcpy(dst, v->d_dump, bytes, hipMemcpyDeviceToHost));
-    return MPEGHIP_OK;
-}
-#endif
 
 } // extern "C"

@@ -1,0 +1,480 @@
+// video_recon_lane.h — the reconstruction kernel: device format, host-side packer, lane functions.
+//
+// One WAVE reconstructs one CHUNK = 4 consecutive macroblocks of one picture (normally 4 horizontal
+// neighbours), with wave-private LDS and no barrier.  What the kernel reads is not the C ABI's arrays but
+// the library's own device format, which the host half of the library (rc_pack_picture, called from the
+// validation pass of every submit / upload) writes straight into the buffer the H2D copy reads:
+//
+//   chunks  24 dwords per chunk: 8 header dwords + 4 records of 4 dwords — ONE round of scalar loads
+//           header  h0 destination frame offset >> 8        h1 RGBA image offset >> 8
+//                   h2 byte offset of the stream's dequantisation table
+//                   h3 index (into words) of the chunk's first block word     h4 of its first coefficient entry
+//                   h5 entries of pass 0 | pass 1 << 10 | pass 2 << 20 | kCRun | kCRgba
+//                   h6 coded blocks (0..24) | live macroblocks << 8 | any int32 snapshot block << 16
+//           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24     d1 reference frame offset >> 8
+//                   d2 byte offset (inside the frame) of the luma prediction window: origin + integer vector
+//                   d3 the same for Cb (plane offset included; Cr = + chroma_bytes)
+//   words   per chunk, one after the other (a wave's loads share cache lines):
+//           block words, one per coded block, in (macroblock, block) order = "slot" order:
+//                   output-tile byte offset of the block's row 0 | chroma << 11 | snapshot << 12
+//                   | (snapshot: dword offset of its 64 int32 values behind the chunk's first entry) << 13
+//           entries, one per NON-ZERO quantised coefficient, grouped by pass (slots 0-7, 8-15, 16-23):
+//                   level << 16 | quantiser_scale << 11 | (slot & 7) << 8 | position << 2 | non-intra << 1
+//                   | "intra DC" ; position = column * 8 + row, the order of the ABI's coefficient units
+//           then the chunk's int32 snapshot blocks (MPEGHIP_MB_COEF_RAW), 64 dwords each
+//
+// The reference's VLC loop produces exactly such (position, level) pairs (video.go:680-745); the ABI hands
+// them over as dense 128-byte units, the packer drops the zeros again.  Dequantisation, premultiply, IDCT,
+// prediction and write-back all happen on the device:
+//
+//   1  scalar loads: header + 4 records.  Vector loads, all issued before the first use: the stream's
+//      256-byte dequantisation table (-> LDS), the pass's block words, the first 64 entries, and the
+//      prediction windows of the 4 macroblocks — luma as 64 lanes x 8 bytes (lane = row, quarter: bytes
+//      4q .. 4q+7 of the row cover both horizontal taps of its 4 pixels), chroma as 32 lanes x 8 bytes.
+//      The row below (vertical tap) comes from the lane that holds it (ds_bpermute); only the window's
+//      last row is loaded separately, by 4 lanes.
+//   2  residual pass (8 coded blocks at a time): zero the wave's int32 tile T[8][64]; one entry per lane:
+//      dequantise (video.go:719-744) and scatter to T[slot & 7][position]; lane (g, j): column j of block
+//      g (two 16-byte LDS reads), column pass, transposed write-back, row j, row pass (+128 >> 8).
+//   3  motion compensation, per macroblock with WAVE-UNIFORM half-pel modes (video_noasm.go:48-80): luma
+//      by 64 lanes x 4 pixels, chroma by 32 lanes x 4 pixels, into the output tile O (the chunk's 4 x 384
+//      bytes laid out as frame rows).  Intra macroblocks put zeros.
+//   4  lane (g, j) adds its residual row to the 8 prediction bytes in O and clamps (video.go:943-971).
+//      (Passes 1, 2 of a chunk with more than 8 coded blocks repeat steps 2 and 4.)
+//   5  O leaves as whole 64-byte luma / 32-byte chroma rows when the chunk is a horizontal run (kCRun),
+//      else as 8-byte rows per block; pictures flagged MPEGHIP_PIC_RGBA are colour-converted from O.
+#pragma once
+
+#include "video_lane.h"
+
+#if !MPG_ON_DEVICE && defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+namespace mpg {
+
+constexpr int kRcMbs = 4;                     // macroblocks per chunk = per wave
+constexpr int kRcMaxBlocks = 6 * kRcMbs;      // 24 slots, 3 passes of 8
+constexpr int kRcChunkDwords = 8 + 4 * kRcMbs;
+constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                                    // header h5
+constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32;  // record d0
+constexpr uint32_t kBChroma = 1u << 11, kBRaw = 1u << 12;                                  // block word
+constexpr uint32_t kEDc = 1, kENonIntra = 2;                                               // entry
+
+// wave-private LDS
+constexpr int kRcTileBytes = 8 * 64 * 4;      // T: int32 [8 blocks][64]
+constexpr int kRcOutBytes = 16 * 64 + 2 * 8 * 32; // O: luma [16 rows][4 x 16] | Cb [8][4 x 8] | Cr [8][4 x 8]
+constexpr int kRcQtabBytes = 256;             // Q: the stream's {matrix, premultiplier} table
+constexpr int kRcLdsBytes = kRcTileBytes + kRcOutBytes + kRcQtabBytes; // 3840
+
+// byte offset inside O of row j of block b of macroblock m
+MPG_HD uint32_t rc_tile_offset(int b, int j, uint32_t m)
+{
+    if (b < 4)
+        return ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 64 + m * 16 + ((uint32_t)(b & 1) << 3);
+    return 1024 + (uint32_t)(b - 4) * 256 + (uint32_t)j * 32 + m * 8;
+}
+
+// ===================================================================== host half: the packer
+struct RcGeom {
+    uint32_t luma_w, chroma_w, luma_bytes;
+    uint64_t frame_stride, rgba_stride;
+};
+
+// One stream's device table: [position = col*8+row][class: 0 intra, 1 non-intra]{matrix entry, premultiplier}
+static inline void rc_make_qtable(uint8_t out[256], const uint8_t intra[64], const uint8_t non_intra[64], const uint8_t premult[64])
+{
+    for (int c = 0; c < 8; c++)
+        for (int r = 0; r < 8; r++)
+            for (int cls = 0; cls < 2; cls++) {
+                uint8_t *e = out + ((c * 8 + r) * 2 + cls) * 2;
+                e[0] = (cls ? non_intra : intra)[r * 8 + c];
+                e[1] = premult[r * 8 + c];
+            }
+}
+
+// Which of a unit's 64 int16 words are non-zero (bit k <=> word k).
+static inline uint64_t rc_nonzero_mask(const uint8_t *unit)
+{
+#if !MPG_ON_DEVICE && defined(__SSE2__)
+    const __m128i zero = _mm_setzero_si128();
+    uint64_t mask = 0;
+    for (int k = 0; k < 4; k++) { // 16 words per step
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(unit + k * 32));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(unit + k * 32 + 16));
+        const __m128i z = _mm_packs_epi16(_mm_cmpeq_epi16(a, zero), _mm_cmpeq_epi16(b, zero)); // 0xff where zero
+        mask |= (uint64_t)(uint16_t)~_mm_movemask_epi8(z) << (k * 16);
+    }
+    return mask;
+#else
+    uint64_t mask = 0;
+    for (uint32_t k = 0; k < 64; k++) {
+        uint16_t w;
+        memcpy(&w, unit + k * 2, 2);
+        mask |= (uint64_t)(w != 0) << k;
+    }
+    return mask;
+#endif
+}
+
+// Room one picture of n macroblocks with `units` coefficient units can need (dwords).
+static inline size_t rc_max_chunks(uint32_t n) { return ((size_t)n + kRcMbs - 1) / kRcMbs; }
+static inline size_t rc_max_words(uint64_t units) { return (size_t)units * 65; }
+constexpr size_t kRcWordsPad = 128; // dwords behind the last chunk's words that a wave may read (and ignore)
+
+struct RcPacked {
+    uint32_t chunks = 0, words = 0; // what the picture took
+};
+
+// Pack ONE picture: macroblocks mbs[0..n) (already validated), whose coef_off index 128-byte units behind
+// `coefs`.  Chunk headers name their words by index: this picture's first word is word_base (callers that
+// only learn the base afterwards pass 0 and add it with rc_rebase).
+static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &p, const mpeghip_mb_desc *mbs, uint32_t n,
+                                       const uint8_t *coefs, uint32_t word_base, uint32_t *chunks_out, uint32_t *words_out)
+{
+    RcPacked out;
+    const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
+    const uint32_t cur256 = (uint32_t)(((s3 + p.cur) * g.frame_stride) >> 8); // strides are multiples of 256
+    const uint32_t fwd256 = (uint32_t)(((s3 + p.fwd) * g.frame_stride) >> 8);
+    const uint32_t bwd256 = (uint32_t)(((s3 + p.bwd) * g.frame_stride) >> 8);
+    const uint32_t rgba256 = (uint32_t)(((s3 + p.cur) * g.rgba_stride) >> 8);
+    const bool rgba = (p.flags & MPEGHIP_PIC_RGBA) != 0;
+    for (uint32_t k0 = 0; k0 < n; k0 += kRcMbs) {
+        const uint32_t live = n - k0 < (uint32_t)kRcMbs ? n - k0 : (uint32_t)kRcMbs;
+        uint32_t *h = chunks_out + (size_t)out.chunks * kRcChunkDwords;
+        struct Slot {
+            const uint8_t *unit;
+            uint32_t bits; // quantiser_scale << 11 | non-intra << 1
+            bool intra, raw;
+        } slot[kRcMaxBlocks];
+        uint32_t n_slots = 0;
+        uint32_t *bw = words_out + out.words;
+        bool run = live == (uint32_t)kRcMbs && (mbs[k0].mb_x & 3) == 0;
+        for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++) {
+            uint32_t *d = h + 8 + m * 4;
+            if (m >= live) { // padding behind the picture's last macroblock
+                d[0] = kRDead;
+                d[1] = d[2] = d[3] = 0;
+                continue;
+            }
+            const mpeghip_mb_desc &mb = mbs[k0 + m];
+            const bool intra = (mb.flags & MPEGHIP_MB_INTRA) != 0, raw = (mb.flags & MPEGHIP_MB_COEF_RAW) != 0;
+            const int32_t mvx = mb.mv_x, mvy = mb.mv_y;
+            const int32_t cmx = mvx / 2, cmy = mvy / 2; // toward zero, video_noasm.go:35-36
+            uint32_t d0 = ((uint32_t)mb.cbp << 8) | ((uint32_t)mb.mb_x << 16) | ((uint32_t)mb.mb_y << 24);
+            if (intra) {
+                d[0] = d0 | kRIntra;
+                d[1] = d[2] = d[3] = 0; // its (unused) prediction loads read the head of the frame store
+            } else {
+                d0 |= (mvx & 1) ? kROhL : 0;
+                d0 |= (mvy & 1) ? kROvL : 0;
+                d0 |= (cmx & 1) ? kROhC : 0;
+                d0 |= (cmy & 1) ? kROvC : 0;
+                const int32_t dst_luma = (int32_t)((uint32_t)mb.mb_y << 4) * (int32_t)g.luma_w + (int32_t)((uint32_t)mb.mb_x << 4);
+                const int32_t dst_chroma = (int32_t)((uint32_t)mb.mb_y << 3) * (int32_t)g.chroma_w + (int32_t)((uint32_t)mb.mb_x << 3);
+                d[0] = d0;
+                d[1] = (mb.flags & MPEGHIP_MB_REF_BWD) ? bwd256 : fwd256;
+                d[2] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
+                d[3] = g.luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)g.chroma_w + (cmx >> 1));
+            }
+            run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
+                  (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
+            uint32_t unit = mb.coef_off;
+            for (int b = 0; b < 6; b++) {
+                if (!(mb.cbp & (0x20u >> b)))
+                    continue;
+                Slot &s = slot[n_slots];
+                s.unit = coefs + (size_t)unit * MPEGHIP_COEF_UNIT;
+                s.bits = ((uint32_t)(mb.qscale & 31) << 11) | (intra ? 0u : kENonIntra);
+                s.intra = intra;
+                s.raw = raw;
+                bw[n_slots] = rc_tile_offset(b, 0, m) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
+                unit += raw ? 2 : 1;
+                n_slots++;
+            }
+        }
+        uint32_t *e0 = bw + n_slots, ne = 0, counts = 0;
+        bool any_raw = false;
+        for (uint32_t pass = 0; pass * 8 < n_slots; pass++) {
+            const uint32_t before = ne;
+            for (uint32_t s = pass * 8; s < n_slots && s < pass * 8 + 8; s++) {
+                const Slot &sl = slot[s];
+                if (sl.raw) {
+                    any_raw = true;
+                    continue;
+                }
+                uint64_t mask = rc_nonzero_mask(sl.unit);
+                const uint32_t bits = sl.bits | ((s & 7) << 8);
+                while (mask) {
+                    const uint32_t pos = (uint32_t)__builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    uint16_t w;
+                    memcpy(&w, sl.unit + pos * 2, 2);
+                    e0[ne++] = ((uint32_t)w << 16) | bits | (pos << 2) | ((sl.intra && pos == 0) ? kEDc : 0u);
+                }
+            }
+            counts |= (ne - before) << (10 * pass);
+        }
+        if (any_raw)
+            for (uint32_t s = 0; s < n_slots; s++)
+                if (slot[s].raw) { // the 64 int32 values as they are (position order = the unit's order)
+                    bw[s] |= ne << 13;
+                    memcpy(e0 + ne, slot[s].unit, 256);
+                    ne += 64;
+                }
+        h[0] = cur256;
+        h[1] = rgba256;
+        h[2] = p.stream * 256;
+        h[3] = word_base + out.words;
+        h[4] = word_base + out.words + n_slots;
+        h[5] = counts | (run ? kCRun : 0u) | (rgba ? kCRgba : 0u);
+        h[6] = n_slots | (live << 8) | (any_raw ? 1u << 16 : 0u);
+        h[7] = 0;
+        out.chunks++;
+        out.words += n_slots + ne;
+    }
+    return out;
+}
+
+// add the base a picture's chunks were packed without
+static inline void rc_rebase(uint32_t *chunks, uint32_t n_chunks, uint32_t word_base)
+{
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        chunks[(size_t)c * kRcChunkDwords + 3] += word_base;
+        chunks[(size_t)c * kRcChunkDwords + 4] += word_base;
+    }
+}
+
+// ===================================================================== device half: lane functions
+// (also compiled by g++ into tests/kernel_emu, which runs the 64 lanes of a wave in a loop, phase by phase)
+
+struct RcChunk {
+    uint32_t h[8];
+    uint32_t r[kRcMbs][4];
+};
+
+MPG_HD RcChunk rc_load_chunk(const VideoArgs &a, uint32_t chunk)
+{
+    const MPG_CONST_AS uint32_t *p = (const MPG_CONST_AS uint32_t *)(uintptr_t)a.chunks + (uint64_t)chunk * kRcChunkDwords;
+    RcChunk c;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        c.h[i] = p[i];
+#pragma unroll
+    for (int m = 0; m < kRcMbs; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            c.r[m][i] = p[8 + m * 4 + i];
+    return c;
+}
+
+MPG_HD uint32_t rc_n_blocks(const RcChunk &c) { return c.h[6] & 0xff; }
+MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[6] >> 8) & 0xff; }
+MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[6] >> 16) & 1; }
+MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[5] >> (10 * pass)) & 0x3ff; }
+
+// what depends on the lane only (worked out once per wave)
+struct RcLane {
+    uint32_t luma_off;    // prediction / MC lane (row lane>>2, quarter lane&3): byte offset inside a 16-row luma window
+    uint32_t chroma_off;  // lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1): offset from the Cb window
+    uint32_t tile_luma;   // where the lane's 4 luma bytes of macroblock 0 sit in O (+ 16 per macroblock)
+    uint32_t tile_chroma; //                  4 chroma bytes                       (+ 8 per macroblock)
+};
+
+MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
+{
+    const uint32_t l = (uint32_t)lane;
+    RcLane k;
+    k.luma_off = (l >> 2) * a.luma_w + (l & 3) * 4;
+    k.chroma_off = ((l >> 4) & 1) * a.chroma_bytes + ((l >> 1) & 7) * a.chroma_w + (l & 1) * 4;
+    k.tile_luma = (l >> 2) * 64 + (l & 3) * 4;
+    k.tile_chroma = 1024 + ((l >> 4) & 1) * 256 + ((l >> 1) & 7) * 32 + (l & 1) * 4;
+    return k;
+}
+
+MPG_HD bool rc_luma_last_row(int lane) { return lane >= 60; }
+MPG_HD bool rc_chroma_last_row(int lane) { return (((uint32_t)lane >> 1) & 7) == 7; }
+
+// ---- step 1: the vector loads
+MPG_HD uint32_t rc_load_qtab(const VideoArgs &a, const RcChunk &c, int lane)
+{
+    return *reinterpret_cast<const uint32_t *>(a.qmat + c.h[2] + (uint32_t)lane * 4);
+}
+MPG_HD uint32_t rc_load_blk(const VideoArgs &a, const RcChunk &c, uint32_t pass, int lane)
+{
+    return a.words[c.h[3] + pass * 8 + ((uint32_t)lane >> 3)]; // (beyond the chunk's blocks: ignored; the array is padded)
+}
+MPG_HD uint32_t rc_load_ent(const VideoArgs &a, const RcChunk &c, uint32_t at, int lane)
+{
+    return a.words[c.h[4] + at + (uint32_t)lane]; // (beyond the pass's entries: ignored; the array is padded)
+}
+
+struct RcPred {
+    uint32_t l0, l1;   // luma: bytes 4q .. 4q+7 of the lane's row
+    uint32_t lx0, lx1; // row 16 of the luma window (lanes 60..63, vertically odd vectors only)
+    uint32_t c0, c1;   // chroma: 8 bytes (lanes 0..31)
+    uint32_t cx0, cx1; // row 8 of the chroma windows (the lanes of row 7)
+};
+
+MPG_HD const uint8_t *rc_ref(const VideoArgs &a, const RcChunk &c, int m) { return a.frames + ((uint64_t)c.r[m][1] << 8); }
+
+MPG_HD void rc_pred_luma(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p)
+{
+    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][2] + k.luma_off);
+    p.l0 = (uint32_t)v;
+    p.l1 = (uint32_t)(v >> 32);
+}
+MPG_HD void rc_pred_chroma(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p) // lanes 0..31
+{
+    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][3] + k.chroma_off);
+    p.c0 = (uint32_t)v;
+    p.c1 = (uint32_t)(v >> 32);
+}
+MPG_HD void rc_pred_luma_extra(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p) // lanes 60..63, kROvL
+{
+    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][2] + k.luma_off + a.luma_w);
+    p.lx0 = (uint32_t)v;
+    p.lx1 = (uint32_t)(v >> 32);
+}
+MPG_HD void rc_pred_chroma_extra(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p) // row-7 lanes, kROvC
+{
+    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][3] + k.chroma_off + a.chroma_w);
+    p.cx0 = (uint32_t)v;
+    p.cx1 = (uint32_t)(v >> 32);
+}
+
+// ---- step 2: the residual pass
+MPG_HD void rc_zero_tile(int32_t *T, int lane)
+{
+    const i32x4 z = {{0, 0, 0, 0}};
+    i32x4 *t = reinterpret_cast<i32x4 *>(T + lane * 8);
+    t[0] = z;
+    t[1] = z;
+}
+
+// one entry: dequantise + premultiply (video.go:719-744; intra DC video.go:672), scatter to T[slot & 7][position]
+MPG_HD void rc_scatter(int32_t *T, const uint8_t *Q, uint32_t e)
+{
+    const uint32_t tq = *reinterpret_cast<const uint16_t *>(Q + (e & 0xfeu)); // [position][class]{matrix, premultiplier}
+    const int32_t level = (int32_t)e >> 16;
+    const int32_t qs = (int32_t)((e >> 11) & 31);
+    const int32_t dq = dequant(level, !(e & kENonIntra), qs * (int32_t)(tq & 0xff), (int32_t)(tq >> 8));
+    T[(e & 0x7fcu) >> 2] = (e & kEDc) ? level * 256 : dq;
+}
+
+// an int32 snapshot block: its 64 values as they are, lane = position
+MPG_HD void rc_raw_fill(const VideoArgs &a, const RcChunk &c, int32_t *T, uint32_t g, uint32_t bw, int lane)
+{
+    T[g * 64 + (uint32_t)lane] = (int32_t)a.words[c.h[4] + (bw >> 13) + (uint32_t)lane];
+}
+
+// lane (g, j) = column j of the pass's block g, then row j
+MPG_HD void rc_cols_load(const int32_t *T, int lane, int32_t (&v)[8])
+{
+    const i32x4 *t = reinterpret_cast<const i32x4 *>(T + lane * 8); // T[g][j * 8 + r]: rows 0..7 of column j
+    const i32x4 t0 = t[0], t1 = t[1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        v[r] = t0.v[r];
+        v[r + 4] = t1.v[r];
+    }
+}
+MPG_HD void rc_cols_store(int32_t *T, int lane, const int32_t (&v)[8])
+{
+    int32_t *t = T + (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        t[r * 8] = v[r];
+}
+MPG_HD void rc_rows_load(const int32_t *T, int lane, int32_t (&v)[8]) { rc_cols_load(T, lane, v); } // T[g][j * 8 + c] now
+
+// ---- step 3: motion compensation of 4 pixels (video_noasm.go:48-80); oh / ov are wave-uniform
+// a0 a1: the 8 bytes at the pixels' position, b0 b1: the 8 bytes one row below
+MPG_HD uint32_t rc_mc4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, bool oh, bool ov)
+{
+    if (!oh && !ov)
+        return a0;
+    if (!oh)
+        return avg_ceil_u8x4(a0, b0);
+    const uint32_t as = shift_in_byte(a1, a0);
+    if (!ov)
+        return avg_ceil_u8x4(a0, as);
+    return avg4_u8x4(a0, as, b0, shift_in_byte(b1, b0));
+}
+
+// ---- step 4: residual row + the 8 prediction bytes in O -> clamped bytes (video.go:943-971)
+MPG_HD void rc_rmw(uint8_t *O, uint32_t bw, int lane, const int32_t (&v)[8])
+{
+    uint8_t *p = O + (bw & 0x7ffu) + ((uint32_t)lane & 7) * ((bw & kBChroma) ? 32u : 64u);
+    const uint64_t pred = *reinterpret_cast<const uint64_t *>(p);
+    *reinterpret_cast<uint64_t *>(p) = add_clamp_pack8(pred, v);
+}
+
+// ---- step 5: stores
+// frame byte offset of macroblock (mb_x, mb_y)'s origin: luma / Cb plane
+MPG_HD uint32_t rc_dst_luma(const VideoArgs &a, uint32_t d0) { return ((d0 >> 24) << 4) * a.luma_w + (((d0 >> 16) & 0xff) << 4); }
+MPG_HD uint32_t rc_dst_chroma(const VideoArgs &a, uint32_t d0)
+{
+    return a.luma_bytes + ((d0 >> 24) << 3) * a.chroma_w + (((d0 >> 16) & 0xff) << 3);
+}
+
+// horizontal run: luma 16 rows x 64 bytes by all 64 lanes, chroma 2 x 8 rows x 32 bytes by lanes 0..31
+MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const RcLane &k, const uint8_t *O)
+{
+    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8);
+    const uint32_t l = (uint32_t)lane;
+    {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(O + l * 16); // row l>>2, 16-byte segment l&3
+        *reinterpret_cast<u32x4 *>(cur + rc_dst_luma(a, c.r[0][0]) + k.luma_off + (l & 3) * 12) = v;
+    }
+    if (lane < 32) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(O + 1024 + l * 16); // plane l>>4, row (l>>1)&7, segment l&1
+        *reinterpret_cast<u32x4 *>(cur + rc_dst_chroma(a, c.r[0][0]) + k.chroma_off + (l & 1) * 12) = v;
+    }
+}
+
+// any other chunk: macroblock m by lanes (block b = lane>>3, row j = lane&7), 8 bytes each.  An invalid intra
+// block keeps the frame's pixels (video.go:711-714); with `mirror` its bytes are parked in O instead, so that
+// the colour conversion sees what the planes hold.
+MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, uint8_t *O, bool mirror)
+{
+    const int b = lane >> 3, j = lane & 7;
+    if (b >= 6)
+        return;
+    const uint32_t d0 = c.r[m][0];
+    const bool written = !(d0 & kRIntra) || ((d0 >> 8) & (0x20u >> b)) != 0;
+    uint32_t off;
+    if (b < 4)
+        off = rc_dst_luma(a, d0) + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * a.luma_w + ((uint32_t)(b & 1) << 3);
+    else
+        off = rc_dst_chroma(a, d0) + (uint32_t)(b - 4) * a.chroma_bytes + (uint32_t)j * a.chroma_w;
+    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + off;
+    uint8_t *t = O + rc_tile_offset(b, j, m);
+    if (written)
+        *reinterpret_cast<uint64_t *>(cur) = *reinterpret_cast<const uint64_t *>(t);
+    else if (mirror)
+        *reinterpret_cast<uint64_t *>(t) = *reinterpret_cast<const uint64_t *>(cur);
+}
+
+// Frame.RGBA fused (pictures flagged MPEGHIP_PIC_RGBA): macroblock m from O, 4 pixels per lane (lane = row*4 +
+// segment), one 16-byte store each — a macroblock row is 64 contiguous bytes of the image.  Pixels outside
+// width x height are not stored.
+MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *O)
+{
+    const uint32_t d0 = c.r[m][0];
+    const uint32_t row = (uint32_t)lane >> 2, seg = (uint32_t)lane & 3;
+    const uint32_t py = ((d0 >> 24) << 4) + row, px0 = (((d0 >> 16) & 0xff) << 4) + seg * 4;
+    if (py >= a.height || px0 >= a.width)
+        return;
+    const uint32_t yy = *reinterpret_cast<const uint32_t *>(O + row * 64 + m * 16 + seg * 4);
+    const uint32_t cb = *reinterpret_cast<const uint16_t *>(O + 1024 + (row >> 1) * 32 + m * 8 + seg * 2);
+    const uint32_t cr = *reinterpret_cast<const uint16_t *>(O + 1280 + (row >> 1) * 32 + m * 8 + seg * 2);
+    uint32_t px[4];
+    rgba_row4(yy, chroma_terms(cb & 0xff, cr & 0xff), chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff), px);
+    const uint64_t p = (uint64_t)py * a.width + px0;
+    const uint32_t n = a.width - px0 >= 4 ? 4 : a.width - px0;
+    uint8_t *img = a.rgba + ((uint64_t)c.h[1] << 8);
+    rgba_store4<false>(reinterpret_cast<uint32_t *>(img) + p, p, px, n);
+}
+
+} // namespace mpg

@@ -38,13 +38,11 @@ def lib():
         L = C.CDLL(str(LIB))
         P = C.c_void_p
         L.emu_video_run.restype = C.c_int
-        L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, P, C.c_uint32, P, P, P, P, C.c_uint64, C.c_int]
-        L.emu_video_run_split.restype = C.c_int
-        L.emu_video_run_split.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, C.c_uint64]
-        L.emu_video_run_wc.restype = C.c_int
-        L.emu_video_run_wc.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
-        L.emu_video_run_compact.restype = C.c_int
-        L.emu_video_run_compact.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
+        L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
+        L.emu_make_qtable.restype = None
+        L.emu_make_qtable.argtypes = [P, P, P]
+        L.emu_pack.restype = C.c_uint32
+        L.emu_pack.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, P, P, P]
         L.emu_rgba_convert.restype = None
         L.emu_rgba_convert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P]
         L.emu_audio_run.restype = C.c_int
@@ -55,8 +53,6 @@ def lib():
         L.emu_avg2.argtypes = [C.c_uint32] * 2
         L.emu_xcd_chunk.argtypes = [C.c_uint32] * 2
         L.emu_ycbcr.argtypes = [C.c_uint32] * 3
-        L.emu_wire_roundtrip.restype = C.c_uint32
-        L.emu_wire_roundtrip.argtypes = [P, C.c_uint32, P]
         _lib = L
     return _lib
 
@@ -66,23 +62,15 @@ def _ptr(a):
 
 
 def _qtable(intra, non_intra):
-    """[2 classes][8 columns][16]: 8 matrix bytes of the column (rows 0-7), then its 8 premultipliers."""
-    t = np.zeros((2, 8, 16), np.uint8)
-    pm = np.asarray(synth.PREMULT, np.uint8).reshape(8, 8)
-    for cls, m in enumerate((intra, non_intra)):
-        m = np.asarray(m, np.uint8).reshape(8, 8)
-        t[cls, :, :8] = m.T
-        t[cls, :, 8:] = pm.T
-    return t.reshape(256)
+    """One stream's dequantisation table in the device layout (video_recon_lane.h: rc_make_qtable)."""
+    t = np.zeros(256, np.uint8)
+    i, n = np.ascontiguousarray(intra, np.uint8), np.ascontiguousarray(non_intra, np.uint8)
+    lib().emu_make_qtable(_ptr(t), _ptr(i), _ptr(n))
+    return t
 
 
 class EmuStore:
-    def __init__(self, width, height, n_streams=1, static_pipeline=False, split=False, compact=False, wc=False):
-        self.wc = wc
-        self.static_pipeline = int(static_pipeline)
-        self.split = split
-        self.compact = compact
-        self.dump = np.zeros(512, np.uint8)
+    def __init__(self, width, height, n_streams=1):
         self.g = desc.geometry(width, height)
         self.n_streams = n_streams
         self.stride = (self.g["frame_bytes"] + 64 + 255) // 256 * 256
@@ -111,27 +99,9 @@ class EmuStore:
                     self.rgba_convert(slot, s, 1)
             self._rgba_init = True
         g = self.g
-        if self.wc:
-            rc = lib().emu_video_run_wc(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
-                                        _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs),
-                                        _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
-            assert rc == 0
-            return
-        if self.compact:
-            rc = lib().emu_video_run_compact(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
-                                             _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs),
-                                             _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
-            assert rc == 0
-            return
-        if self.split:
-            rc = lib().emu_video_run_split(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
-                                           _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs), len(coefs) // 128,
-                                           _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
-            assert rc == 0
-            return
         rc = lib().emu_video_run(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
-                                 _ptr(pics), _ptr(mbs), len(mbs), _ptr(coefs), _ptr(self.qmat), _ptr(self.dump),
-                                 _ptr(self.rgba), self.rgba_stride, self.static_pipeline)
+                                 _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs),
+                                 _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
         assert rc == 0
 
     def read_planes(self, stream, slot):

@@ -14,10 +14,9 @@
 #include "mpeg.hpp"
 
 extern "C" {
-int emu_video_run_wc(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *, uint32_t,
-                     const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint64_t);
-int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *,
-                  const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *, uint64_t, int);
+int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *, uint32_t,
+                  const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint64_t);
+void emu_make_qtable(uint8_t *, const uint8_t *, const uint8_t *);
 void emu_rgba_convert(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
 int emu_audio_run(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t, uint32_t);
 int emu_audio_run_masked(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t, uint32_t,
@@ -25,10 +24,6 @@ int emu_audio_run_masked(const int32_t *, void *, float *, int32_t *, const floa
 }
 
 namespace {
-
-const uint8_t kPremult[64] = {32, 44, 42, 38, 32, 25, 17, 9,  44, 62, 58, 52, 44, 35, 24, 12, 42, 58, 55, 49, 42, 33,
-                              23, 12, 38, 52, 49, 44, 38, 30, 20, 10, 32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30,
-                              25, 20, 14, 7,  17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
 
 class EmuVideoBackend : public mpeg::VideoBackend {
 public:
@@ -47,22 +42,13 @@ public:
         rgba_.assign(rgba_stride_ * 3, 0);
         dump_.assign(512, 0);
     }
-    void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override
-    {
-        for (int cls = 0; cls < 2; cls++)
-            for (int c = 0; c < 8; c++)
-                for (int r = 0; r < 8; r++) {
-                    qt_[cls * 128 + c * 16 + r] = (cls ? non_intra : intra)[r * 8 + c];
-                    qt_[cls * 128 + c * 16 + 8 + r] = kPremult[r * 8 + c];
-                }
-    }
+    void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override { emu_make_qtable(qt_, intra, non_intra); }
     void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs, size_t) override
     {
-        if (flavour_ == 0)
-            emu_video_run_wc(frames_.data(), stride_, lw_, lh_, w_, h_, &pic, 1, mbs, n_mbs, coefs, qt_, rgba_.data(), rgba_stride_);
-        else
-            emu_video_run(frames_.data(), stride_, lw_, lh_, w_, h_, &pic, mbs, n_mbs, coefs, qt_, dump_.data(), rgba_.data(),
-                          rgba_stride_, 0);
+        mpeghip_pic_desc p = pic; // (the emulator packs each picture's own range)
+        p.mb_first = 0;
+        p.mb_count = n_mbs;
+        emu_video_run(frames_.data(), stride_, lw_, lh_, w_, h_, &p, 1, mbs, n_mbs, coefs, qt_, rgba_.data(), rgba_stride_);
     }
     void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
@@ -105,18 +91,12 @@ public:
     }
     void setQuant(uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64]) override
     {
-        uint8_t *t = qt_ + (size_t)stream * 256;
-        for (int cls = 0; cls < 2; cls++)
-            for (int c = 0; c < 8; c++)
-                for (int r = 0; r < 8; r++) {
-                    t[cls * 128 + c * 16 + r] = (cls ? non_intra : intra)[r * 8 + c];
-                    t[cls * 128 + c * 16 + 8 + r] = kPremult[r * 8 + c];
-                }
+        emu_make_qtable(qt_ + (size_t)stream * 256, intra, non_intra);
     }
     void submit(const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
                 size_t) override
     {
-        emu_video_run_wc(frames_.data(), stride_, lw_, lh_, w_, h_, pics, n_pics, mbs, n_mbs, coefs, qt_, rgba_.data(),
+        emu_video_run(frames_.data(), stride_, lw_, lh_, w_, h_, pics, n_pics, mbs, n_mbs, coefs, qt_, rgba_.data(),
                          rgba_stride_);
     }
     // staged submit (the product's mpeghip_video_stage_*): pictures put from several threads into one merged submit

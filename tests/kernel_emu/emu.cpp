@@ -16,20 +16,25 @@
 
 #include "audio_lane.h"
 #include "video_lane.h"
-#include "video_split_lane.h"
-#include "video_compact_lane.h"
-#include "video_wire_lane.h"
+#include "video_recon_lane.h"
 
 using namespace mpg;
 
+static const uint8_t kPremult[64] = {32, 44, 42, 38, 32, 25, 17, 9,  44, 62, 58, 52, 44, 35, 24, 12, 42, 58, 55, 49, 42, 33,
+                                     23, 12, 38, 52, 49, 44, 38, 30, 20, 10, 32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30,
+                                     25, 20, 14, 7,  17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
+
 extern "C" {
 
-// Reconstruct n_mbs macroblocks exactly as recon_kernel<W> does, one "wave" at a time.
+// one stream's dequantisation table in the device layout (what mpeghip_video_open / _set_quant upload)
+void emu_make_qtable(uint8_t *out, const uint8_t *intra, const uint8_t *non_intra) { rc_make_qtable(out, intra, non_intra, kPremult); }
+
+// recon_kernel, wave by wave: the library's packer (rc_pack_picture) turns the ABI arrays into the device
+// format, then every chunk runs through the kernel's lane functions in the kernel's order, LDS = an array.
 int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
                   uint32_t width, uint32_t height,
-                  const mpeghip_pic_desc *pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
-                  const uint8_t *coefs, const uint8_t *qtable, uint8_t *dump,
-                  uint8_t *rgba, uint64_t rgba_stride, int static_pipeline)
+                  const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                  const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
 {
     VideoArgs a;
     a.frames = frames;
@@ -40,313 +45,165 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     a.chroma_h = luma_h / 2;
     a.luma_bytes = luma_w * luma_h;
     a.chroma_bytes = a.luma_bytes / 4;
-    a.pics = pics;
-    a.mbs = mbs;
-    a.coefs = coefs;
-    a.qmat = qtable;
-    a.dump = dump;
-    a.n_mbs = n_mbs;
-    a.width = width;
-    a.height = height;
-    a.rgba = rgba;
-    a.rgba_stride = rgba_stride;
-
-    alignas(16) int32_t tile[kTileDwords];
-    alignas(16) uint8_t stage[kRgbaBytes];
-    // walk the grid the way the kernel does (8 waves per block, XCD remap) so the
-    // chunk mapping is exercised too; the result must not depend on the order
-    const uint32_t WAVES = 8;
-    const uint32_t blocks = (n_mbs + WAVES - 1) / WAVES;
-    for (uint32_t blk = 0; blk < blocks; blk++) {
-        const uint32_t chunk = xcd_chunk(blk, blocks);
-        for (uint32_t wave = 0; wave < WAVES; wave++) {
-            const uint32_t mb_index = chunk * WAVES + wave;
-            if (mb_index >= n_mbs)
-                continue;
-            const MbU u = load_mb(a, mb_index);
-            MbLane st[64];
-            memset(tile, 0xCD, sizeof(tile)); // poison: reads of unwritten LDS must not matter
-            uint64_t out[64];
-            bool wrote[64];
-            if (static_pipeline) { // the lane functions of recon_kernel<W, 3>
-                MbLoads ld[64];
-                for (int lane = 0; lane < 64; lane++)
-                    mb_issue_loads_static(a, u, lane, ld[lane]);
-                for (int lane = 0; lane < 64; lane++)
-                    mb_phase_a_compute_static(a, u, lane, ld[lane], st[lane], tile);
-                for (int lane = 0; lane < 64; lane++)
-                    out[lane] = mb_phase_b_t<true>(a, u, lane, st[lane], tile, wrote[lane], dump + lane * 8);
-            } else {
-                for (int lane = 0; lane < 64; lane++)
-                    mb_phase_a(a, u, lane, st[lane], tile);
-                for (int lane = 0; lane < 64; lane++)
-                    out[lane] = mb_phase_b(a, u, lane, st[lane], tile, wrote[lane]);
-            }
-            if (u.rgba) {
-                for (int lane = 0; lane < 64; lane++)
-                    mb_phase_c_stage(a, u, lane, out[lane], wrote[lane], stage);
-                for (int lane = 0; lane < 64; lane++)
-                    mb_phase_c_convert(a, u, lane, stage);
-            }
-        }
-    }
-    return 0;
-}
-
-// The split path: pred_kernel<W> then resid_kernel<W> (then the RGBA pass for flagged pictures).
-int emu_video_run_split(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
-                        uint32_t width, uint32_t height,
-                        const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
-                        const uint8_t *coefs, uint32_t n_units, const uint8_t *qtable,
-                        uint8_t *rgba, uint64_t rgba_stride)
-{
-    SplitArgs s;
-    VideoArgs &a = s.v;
-    a.frames = frames;
-    a.frame_stride = frame_stride;
-    a.luma_w = luma_w;
-    a.luma_h = luma_h;
-    a.chroma_w = luma_w / 2;
-    a.chroma_h = luma_h / 2;
-    a.luma_bytes = luma_w * luma_h;
-    a.chroma_bytes = a.luma_bytes / 4;
-    a.pics = pics;
-    a.mbs = mbs;
-    a.coefs = coefs;
-    a.qmat = qtable;
-    a.dump = nullptr;
-    a.n_mbs = n_mbs;
-    a.width = width;
-    a.height = height;
-    a.rgba = rgba;
-    a.rgba_stride = rgba_stride;
-    std::vector<BlockEntry> entries(n_units ? n_units : 1);
-    memset(entries.data(), 0xff, entries.size() * sizeof(BlockEntry));
-    s.entries = entries.data();
-    s.n_units = n_units;
-    const uint32_t WAVES = 8;
-    // K1
-    {
-        const uint32_t blocks = (n_mbs + 2 * WAVES - 1) / (2 * WAVES);
-        for (uint32_t blk = 0; blk < blocks; blk++) {
-            const uint32_t chunk = xcd_chunk(blk, blocks);
-            for (uint32_t wave = 0; wave < WAVES; wave++)
-                for (int lane = 0; lane < 64; lane++) {
-                    const uint32_t mb_index = (chunk * WAVES + wave) * 2 + (uint32_t)(lane >> 5);
-                    if (mb_index < n_mbs)
-                        pred_lane(s, load_pred_mb(s.v, mb_index), lane & 31);
-                }
-        }
-    }
-    // K2
-    {
-        const uint32_t blocks = (n_units + 8 * WAVES - 1) / (8 * WAVES);
-        alignas(16) int32_t tile[kResidTileDwords];
-        for (uint32_t blk = 0; blk < blocks; blk++) {
-            const uint32_t chunk = xcd_chunk(blk, blocks);
-            for (uint32_t wave = 0; wave < WAVES; wave++) {
-                ResidLane st[64];
-                memset(tile, 0xCD, sizeof(tile));
-                for (int lane = 0; lane < 64; lane++) {
-                    const int g = lane >> 3, j = lane & 7;
-                    resid_phase_a(s, (chunk * WAVES + wave) * 8 + (uint32_t)g, j, tile + g * kTileStride, st[lane]);
-                }
-                for (int lane = 0; lane < 64; lane++) {
-                    const int g = lane >> 3, j = lane & 7;
-                    resid_phase_b(s, j, tile + g * kTileStride, st[lane]);
-                }
-            }
-        }
-    }
-    // RGBA pass
-    for (uint32_t p = 0; p < n_pics; p++) {
-        if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
-            continue;
-        const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
-        const uint32_t quads = (width + 3) / 4;
-        for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
-            for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
-                rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
-                                  x4, y, rgba + fs * rgba_stride);
-    }
-    return 0;
-}
-
-// recon_compact_kernel: one workgroup (8 waves) per chunk of 8 macroblocks (+ the RGBA pass).
-int emu_video_run_compact(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
-                          uint32_t width, uint32_t height,
-                          const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
-                          const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
-{
-    VideoArgs a;
-    a.frames = frames;
-    a.frame_stride = frame_stride;
-    a.luma_w = luma_w;
-    a.luma_h = luma_h;
-    a.chroma_w = luma_w / 2;
-    a.chroma_h = luma_h / 2;
-    a.luma_bytes = luma_w * luma_h;
-    a.chroma_bytes = a.luma_bytes / 4;
-    a.pics = pics;
-    a.mbs = mbs;
-    a.coefs = coefs;
-    a.qmat = qtable;
-    a.dump = nullptr;
-    a.n_mbs = n_mbs;
-    a.width = width;
-    a.height = height;
-    a.rgba = rgba;
-    a.rgba_stride = rgba_stride;
-    alignas(16) static uint8_t lds[kCompactLdsBytes];
-    const uint32_t blocks = (n_mbs + kChunkMbs - 1) / kChunkMbs;
-    for (uint32_t blk = 0; blk < blocks; blk++) {
-        const uint32_t chunk = xcd_chunk(blk, blocks);
-        const ChunkInfo ci = load_chunk(a, chunk);
-        memset(lds, 0xCD, sizeof(lds));
-        MbU u[kChunkMbs];
-        static MbLoads ld[kChunkMbs][64];
-        for (uint32_t w = 0; w < (uint32_t)kChunkMbs; w++) {
-            if (w >= ci.n)
-                continue;
-            u[w] = load_mb(a, chunk * kChunkMbs + w);
-            for (int lane = 0; lane < 64; lane++)
-                compact_phase1(a, u[w], lane, ld[w][lane]);
-        }
-        for (uint32_t w = 0; w < (uint32_t)kChunkMbs; w++) {
-            if (8 * w >= ci.base[kChunkMbs])
-                continue;
-            bool active[64];
-            for (int lane = 0; lane < 64; lane++) {
-                const int g = lane >> 3, j = lane & 7;
-                int32_t *tile_g = reinterpret_cast<int32_t *>(lds + kResidStoreBytes) + (w * 8 + (uint32_t)g) * kTileStride;
-                compact_phase2(a, ci, 8 * w + (uint32_t)g, j, tile_g, active[lane]);
-            }
-            for (int lane = 0; lane < 64; lane++) {
-                const int g = lane >> 3, j = lane & 7;
-                const int32_t *tile_g = reinterpret_cast<const int32_t *>(lds + kResidStoreBytes) + (w * 8 + (uint32_t)g) * kTileStride;
-                compact_phase2_rows(8 * w + (uint32_t)g, j, tile_g, active[lane], lds);
-            }
-        }
-        for (uint32_t w = 0; w < (uint32_t)kChunkMbs; w++) {
-            if (w >= ci.n)
-                continue;
-            for (int lane = 0; lane < 64; lane++)
-                compact_phase3(a, u[w], ci, w, lane, ld[w][lane], lds);
-        }
-    }
-    for (uint32_t p = 0; p < n_pics; p++) {
-        if (!(pics[p].flags & MPEGHIP_PIC_RGBA))
-            continue;
-        const uint64_t fs = (uint64_t)pics[p].stream * MPEGHIP_SLOTS + pics[p].cur;
-        const uint32_t quads = (width + 3) / 4;
-        for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
-            for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
-                rgba_convert_quad(frames + fs * frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, width, height,
-                                  x4, y, rgba + fs * rgba_stride);
-    }
-    return 0;
-}
-
-// recon_wc_kernel: one wave per chunk of 4 macroblocks (+ the RGBA pass).
-int emu_video_run_wc(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
-                     uint32_t width, uint32_t height,
-                     const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
-                     const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
-{
-    VideoArgs a;
-    a.frames = frames;
-    a.frame_stride = frame_stride;
-    a.luma_w = luma_w;
-    a.luma_h = luma_h;
-    a.chroma_w = luma_w / 2;
-    a.chroma_h = luma_h / 2;
-    a.luma_bytes = luma_w * luma_h;
-    a.chroma_bytes = a.luma_bytes / 4;
-    // the library's expanded records (built by the host half of the product during validation)
-    XGeom geom;
+    if (frame_stride % 256 || rgba_stride % 256)
+        abort(); // the chunks name frames in units of 256 bytes
+    RcGeom geom;
     geom.luma_w = a.luma_w;
     geom.chroma_w = a.chroma_w;
+    geom.luma_bytes = a.luma_bytes;
     geom.frame_stride = frame_stride;
     geom.rgba_stride = rgba_stride;
     bool any_rgba = false; // the product picks the kernel instance by this (mpeghip.hip: launch_batch)
-    for (uint32_t p = 0; p < n_pics; p++)
+    uint64_t units = 0, n_chunks = 0;
+    for (uint32_t p = 0; p < n_pics; p++) {
         any_rgba = any_rgba || (pics[p].flags & MPEGHIP_PIC_RGBA);
-    if (frame_stride % 256 || rgba_stride % 256)
-        abort(); // the records name frames in units of 256 bytes
-    std::vector<uint32_t> xrec((size_t)n_mbs * kXDwords + 16);
-    for (uint32_t i = 0; i < n_mbs; i++)
-        expand_mb(geom, expand_pic(geom, pics[mbs[i].pic]), mbs[i], xrec.data() + (size_t)i * kXDwords);
-    mark_chunk_runs(xrec.data(), n_mbs);
+        n_chunks += rc_max_chunks(pics[p].mb_count);
+    }
+    for (uint32_t i = 0; i < n_mbs; i++) {
+        const uint64_t end = (uint64_t)mbs[i].coef_off + (uint64_t)__builtin_popcount(mbs[i].cbp) * ((mbs[i].flags & MPEGHIP_MB_COEF_RAW) ? 2 : 1);
+        units = mbs[i].cbp && end > units ? end : units;
+    }
+    std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1), words(rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
+    uint32_t nc = 0, nw = 0;
+    for (uint32_t p = 0; p < n_pics; p++) {
+        const RcPacked got = rc_pack_picture(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
+                                             chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw);
+        nc += got.chunks;
+        nw += got.words;
+    }
     a.pics = pics;
-    a.mbs = mbs;
-    a.xmbs = xrec.data();
-    a.coefs = coefs;
+    a.chunks = chunks.data();
+    a.words = words.data();
     a.qmat = qtable;
-    a.dump = nullptr;
-    a.n_mbs = n_mbs;
+    a.n_chunks = nc;
     a.width = width;
     a.height = height;
     a.rgba = rgba;
     a.rgba_stride = rgba_stride;
-    alignas(16) static uint8_t lds[kWcLdsBytes];
-    const uint32_t n_chunks = (n_mbs + kWcMbs - 1) / kWcMbs;
-    for (uint32_t chunk = 0; chunk < n_chunks; chunk++) {
-        memset(lds, 0xCD, sizeof(lds));
-        uint8_t *resid = lds;
-        int32_t *tile = reinterpret_cast<int32_t *>(lds + kWcResidBytes);
-        uint32_t n_live;
-        WcRaw raw;
-        if (any_rgba)
-            wc_load_raw<true>(a, chunk, n_live, raw);
-        else
-            wc_load_raw<false>(a, chunk, n_live, raw);
-        const WcInfo ci = wc_info_from_raw(n_live, raw);
-        MbU u[kWcMbs];
-        static MbLoads ld[kWcMbs][64];
-        for (int m = 0; m < kWcMbs; m++) {
-            u[m] = any_rgba ? wc_mb_from_raw<true>(a, raw.d[m]) : wc_mb_from_raw<false>(a, raw.d[m]);
-            for (int lane = 0; lane < 64; lane++)
-                wc_issue_pred(a, u[m], lane, ld[m][lane]);
-        }
-        for (uint32_t s0 = 0; s0 < ci.base[kWcMbs]; s0 += 8) {
-            bool active[64];
-            for (int lane = 0; lane < 64; lane++)
-                compact_phase2(a, ci, s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kWcTileStride, active[lane]);
-            for (int lane = 0; lane < 64; lane++)
-                compact_phase2_rows(s0 + (uint32_t)(lane >> 3), lane & 7, tile + (lane >> 3) * kWcTileStride, active[lane], resid);
-        }
-        const bool coalesce = wc_can_coalesce(ci, u);
-        bool rgba_any = false;
-        for (int m = 0; m < kWcMbs; m++)
-            rgba_any = rgba_any || ((uint32_t)m < ci.n && u[m].rgba != nullptr);
-        uint8_t *out_tile = (coalesce || rgba_any) ? reinterpret_cast<uint8_t *>(tile) : nullptr;
-        if (out_tile)
-            memset(tile, 0xEE, kWcTileBytes);
-        for (int m = 0; m < kWcMbs; m++) {
-            if ((uint32_t)m >= ci.n)
-                continue;
-            for (int lane = 0; lane < 64; lane++) {
-                u8x16 below = ld[m][lane].r1;
-                const int bl = wc_below_lane(lane);
-                if (wc_needs_below(u[m]) && bl >= 0) // the kernel's __shfl from the owning lane
-                    for (int k = 0; k < 3; k++)
-                        below.v[k] = ld[m][bl].r0.v[k];
-                if (coalesce)
-                    wc_phase3<kWcMbs, true>(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile, false);
-                else
-                    wc_phase3<kWcMbs, false>(a, u[m], ci, (uint32_t)m, lane, ld[m][lane], below, resid, out_tile, true);
+
+    alignas(16) static uint8_t lds[kRcLdsBytes];
+    for (uint32_t chunk = 0; chunk < nc; chunk++) {
+        memset(lds, 0xCD, sizeof(lds)); // poison: reads of unwritten LDS must not matter
+        int32_t *T = reinterpret_cast<int32_t *>(lds);
+        uint8_t *O = lds + kRcTileBytes, *Q = O + kRcOutBytes;
+        const RcChunk c = rc_load_chunk(a, chunk);
+        const uint32_t n_blocks = rc_n_blocks(c);
+        RcLane k[64];
+        uint32_t qdw[64], bw[64], e[64];
+        static RcPred p[kRcMbs][64];
+        memset(p, 0, sizeof(p));
+        for (int lane = 0; lane < 64; lane++) {
+            k[lane] = rc_lane(a, lane);
+            qdw[lane] = rc_load_qtab(a, c, lane);
+            bw[lane] = rc_load_blk(a, c, 0, lane);
+            e[lane] = rc_load_ent(a, c, 0, lane);
+            for (int m = 0; m < kRcMbs; m++) {
+                if (rc_luma_last_row(lane) && (c.r[m][0] & kROvL))
+                    rc_pred_luma_extra(a, c, m, k[lane], p[m][lane]);
+                if (lane < 32 && rc_chroma_last_row(lane) && (c.r[m][0] & kROvC))
+                    rc_pred_chroma_extra(a, c, m, k[lane], p[m][lane]);
+                rc_pred_luma(a, c, m, k[lane], p[m][lane]);
+                if (lane < 32)
+                    rc_pred_chroma(a, c, m, k[lane], p[m][lane]);
             }
         }
-        if (coalesce)
+        for (int lane = 0; lane < 64; lane++)
+            memcpy(Q + lane * 4, &qdw[lane], 4);
+        static int32_t v[64][8];
+        uint32_t ent_at = 0;
+        for (uint32_t pass = 0;; pass++) {
+            const bool work = pass * 8 < n_blocks;
+            if (work) {
+                const uint32_t np = rc_pass_entries(c, pass);
+                for (int lane = 0; lane < 64; lane++) {
+                    rc_zero_tile(T, lane);
+                    if (pass > 0)
+                        bw[lane] = rc_load_blk(a, c, pass, lane);
+                }
+                for (uint32_t r = 0; r < np; r += 64)
+                    for (int lane = 0; lane < 64; lane++) {
+                        if (pass > 0 || r > 0)
+                            e[lane] = rc_load_ent(a, c, ent_at + r, lane);
+                        if (r + (uint32_t)lane < np)
+                            rc_scatter(T, Q, e[lane]);
+                    }
+                ent_at += np;
+                if (rc_any_raw(c))
+                    for (uint32_t g = 0; g < 8; g++) {
+                        const uint32_t bwg = bw[g * 8]; // the kernel's v_readlane
+                        if (pass * 8 + g < n_blocks && (bwg & kBRaw))
+                            for (int lane = 0; lane < 64; lane++)
+                                rc_raw_fill(a, c, T, g, bwg, lane);
+                    }
+                for (int lane = 0; lane < 64; lane++) {
+                    rc_cols_load(T, lane, v[lane]);
+                    idct8<false>(v[lane]);
+                }
+                for (int lane = 0; lane < 64; lane++) // (in place: only after every lane has read its column)
+                    rc_cols_store(T, lane, v[lane]);
+                for (int lane = 0; lane < 64; lane++) {
+                    rc_rows_load(T, lane, v[lane]);
+                    idct8<true>(v[lane]);
+                }
+            }
+            if (pass == 0) {
+                for (int m = 0; m < kRcMbs; m++) {
+                    const uint32_t d0 = c.r[m][0];
+                    if (d0 & kRDead)
+                        continue;
+                    for (int lane = 0; lane < 64; lane++) {
+                        uint32_t yl = 0, yc = 0;
+                        if (!(d0 & kRIntra)) {
+                            const RcPred &me = p[m][lane], &bl = p[m][(lane + 4) & 63], &bc = p[m][(lane + 2) & 63]; // ds_bpermute
+                            const bool last_l = rc_luma_last_row(lane), last_c = rc_chroma_last_row(lane);
+                            yl = rc_mc4(me.l0, me.l1, last_l ? me.lx0 : bl.l0, last_l ? me.lx1 : bl.l1, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
+                            yc = rc_mc4(me.c0, me.c1, last_c ? me.cx0 : bc.c0, last_c ? me.cx1 : bc.c1, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+                        }
+                        memcpy(O + k[lane].tile_luma + m * 16, &yl, 4);
+                        if (lane < 32)
+                            memcpy(O + k[lane].tile_chroma + m * 8, &yc, 4);
+                    }
+                }
+            }
+            if (!work)
+                break;
             for (int lane = 0; lane < 64; lane++)
-                wc_store_tile(a, u[0], lane, out_tile);
-        if (rgba_any) // Frame.RGBA of the written macroblocks, fused (the host adds a whole-frame pass only
-            for (int m = 0; m < kWcMbs; m++) // for partial pictures over a slot whose image is out of date)
-                if ((uint32_t)m < ci.n && u[m].rgba != nullptr)
-                    for (int lane = 0; lane < 64; lane++)
-                        wc_rgba_mb(a, u[m], (uint32_t)m, lane, out_tile);
+                if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks)
+                    rc_rmw(O, bw[lane], lane, v[lane]);
+            if ((pass + 1) * 8 >= n_blocks)
+                break;
+        }
+        const bool run = (c.h[5] & kCRun) != 0, rgba_on = any_rgba && (c.h[5] & kCRgba) != 0;
+        const uint32_t n_live = rc_n_live(c);
+        if (run) {
+            for (int lane = 0; lane < 64; lane++)
+                rc_store_run(a, c, lane, k[lane], O);
+        } else {
+            for (uint32_t m = 0; m < n_live; m++)
+                for (int lane = 0; lane < 64; lane++)
+                    rc_store_mb(a, c, m, lane, O, rgba_on);
+        }
+        if (rgba_on)
+            for (uint32_t m = 0; m < n_live; m++)
+                for (int lane = 0; lane < 64; lane++)
+                    rc_rgba_mb(a, c, m, lane, O);
     }
     return 0;
+}
+
+// the packer alone, for tests that look at the device format: returns chunks, *n_words
+uint32_t emu_pack(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride, uint64_t rgba_stride, const mpeghip_pic_desc *pic,
+                  const mpeghip_mb_desc *mbs, const uint8_t *coefs, uint32_t *chunks_out, uint32_t *words_out, uint32_t *n_words)
+{
+    RcGeom geom;
+    geom.luma_w = luma_w;
+    geom.chroma_w = luma_w / 2;
+    geom.luma_bytes = luma_w * luma_h;
+    geom.frame_stride = frame_stride;
+    geom.rgba_stride = rgba_stride;
+    const RcPacked got = rc_pack_picture(geom, *pic, mbs, pic->mb_count, coefs, 0, chunks_out, words_out);
+    *n_words = got.words;
+    return got.chunks;
 }
 
 // rgba_pixel (the arrangement the device uses) against ycbcr_to_rgba (the reference's form) for ALL
@@ -482,31 +339,4 @@ uint32_t emu_avg2(uint32_t a, uint32_t b) { return avg_ceil_u8x4(a, b); }
 uint32_t emu_xcd_chunk(uint32_t b, uint32_t n) { return xcd_chunk(b, n); }
 uint32_t emu_ycbcr(uint32_t y, uint32_t cb, uint32_t cr) { return ycbcr_to_rgba(y, cb, cr); }
 
-// video_wire_lane.h: pack n dense units the way mpeghip_video_stage_put does, then rebuild them the way
-// wire_expand_kernel's lanes do.  Returns the dwords on the wire (headers + payload); out = n * 128 bytes.
-uint32_t emu_wire_roundtrip(const uint8_t *units, uint32_t n, uint8_t *out)
-{
-    std::vector<uint32_t> region((size_t)n * (1 + kWireUnitDwords) + 16);
-    uint32_t *hdr = region.data(), *payload = region.data() + n;
-    uint32_t used = 0;
-    for (uint32_t u = 0; u < n; u++)
-        hdr[u] = wire_pack_unit(units + (size_t)u * 128, payload, used);
-    alignas(16) uint8_t tile[1024];
-    for (uint32_t group = 0; group * 8 < n; group++) {
-        WireLane w[64];
-        memset(tile, 0xCD, sizeof(tile));
-        for (int lane = 0; lane < 64; lane++) {
-            const uint32_t unit = group * 8 + (uint32_t)(lane >> 3);
-            w[lane].live = unit < n;
-            w[lane].header = w[lane].live ? hdr[unit] : 0;
-            w[lane].payload = payload;
-            wire_phase_zero(tile, lane);
-        }
-        for (int lane = 0; lane < 64; lane++)
-            wire_phase_scatter(w[lane], tile, lane);
-        for (int lane = 0; lane < 64; lane++)
-            wire_phase_store(w[lane], tile, lane, out + (size_t)(group * 8 + (uint32_t)(lane >> 3)) * 128);
-    }
-    return n + used;
-}
 }

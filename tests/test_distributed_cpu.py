@@ -31,7 +31,7 @@ def _worker(rank, world, port, out):
     mine = shard_streams(6, world, rank)                        # 6 independent streams over 2 ranks
     w, h = 64, 48
     seqs = {s: synth.generate_sequence(w, h, 3, seed=1000 + s) for s in mine}
-    stores = {s: emu.EmuStore(w, h, wc=True) for s in mine}     # stand-in for this rank's device (test-only emulator)
+    stores = {s: emu.EmuStore(w, h) for s in mine}     # stand-in for this rank's device (test-only emulator)
     units = [0]
 
     def body():

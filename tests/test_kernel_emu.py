@@ -18,18 +18,15 @@ from parity import bits_equal, mirror_ring, run_and_compare
     (24, 40, 4, "typical", 0.0, True),       # tiny, width not a multiple of 16
     (50, 35, 3, "typical", 0.0, True),       # odd height: the last RGBA row has no partner
 ])
-@pytest.mark.parametrize("flavour", ["wave_chunk", "compact", "split", "fused", "fused_static"])
-def test_video_lane_logic_matches_oracle(oracle, emu, w, h, n, profile, raw, rgba, flavour):
+def test_video_lane_logic_matches_oracle(oracle, emu, w, h, n, profile, raw, rgba):
     seq = synth.generate_sequence(w, h, n, profile=profile, raw_fraction=raw, rgba=rgba)
-    dut = emu.EmuStore(w, h, static_pipeline=(flavour == "fused_static"), split=(flavour == "split"),
-                       compact=(flavour == "compact"), wc=(flavour == "wave_chunk"))
-    run_and_compare(oracle.OracleStore(w, h), dut, seq, check_rgba=rgba)
+    run_and_compare(oracle.OracleStore(w, h), emu.EmuStore(w, h), seq, check_rgba=rgba)
 
 
 def test_video_custom_quant_matrices(oracle, emu):
     rng = np.random.default_rng(5)
     iq, nq = rng.integers(1, 256, 64), rng.integers(1, 256, 64)
-    o, e = oracle.OracleStore(64, 48), emu.EmuStore(64, 48, wc=True)
+    o, e = oracle.OracleStore(64, 48), emu.EmuStore(64, 48)
     o.set_quant(0, iq, nq)
     e.set_quant(0, iq, nq)
     run_and_compare(o, e, synth.generate_sequence(64, 48, 6, seed=11))
@@ -71,31 +68,6 @@ def test_avg4_identity(emu):
         for k in range(4):
             s = sum((v >> (8 * k)) & 0xff for v in (a, b, c, d))
             assert (got >> (8 * k)) & 0xff == (s + 2) >> 2
-
-
-def test_coefficient_wire_form_round_trips(emu):
-    """video_wire_lane.h: dense 128-byte units -> (header, entries | dense copy) on the host -> dense units on the
-    device, bit for bit: empty units, 1 .. 31 non-zero words (sparse), 32 .. 64 (sent as they are), extreme
-    values, int32 snapshot halves, and a unit count that is not a multiple of the 8 units a wave rebuilds."""
-    rng = np.random.default_rng(0x77697265)
-    units = []
-    for nz in list(range(0, 65)) + [0, 1, 31, 32, 64] * 3:
-        u = np.zeros(64, np.int16)
-        pos = rng.permutation(64)[:nz]
-        u[pos] = rng.choice([-32768, -2048, -255, -1, 1, 2, 255, 2047, 32767], nz) if nz else 0
-        units.append(u)
-    snap = rng.integers(-2**31, 2**31 - 1, 64, dtype=np.int64).astype(np.int32)  # two units of an int32 snapshot block
-    snap[rng.permutation(64)[:50]] = 0
-    units += [snap.view(np.int16)[:64].copy(), snap.view(np.int16)[64:].copy()]
-    dense = np.ascontiguousarray(np.concatenate(units)).view(np.uint8)
-    n = len(units)
-    assert n % 8 != 0
-    out = np.full(n * 128, 0xA5, np.uint8)
-    L = emu.lib()
-    words = L.emu_wire_roundtrip(dense.ctypes.data, n, out.ctypes.data)
-    assert np.array_equal(out, dense)
-    nz = np.array([int(np.count_nonzero(u)) for u in units])
-    assert words == n + int(np.where(nz <= 31, nz, 32).sum())   # one header each + entries, or the unit as it is
 
 
 def test_xcd_chunk_is_a_permutation(emu):
