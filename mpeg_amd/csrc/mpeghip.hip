@@ -44,7 +44,7 @@ static __device__ __forceinline__ void wave_lds_handoff()
 // wave-private LDS, no barrier.  kRgba: the instance for batches with MPEGHIP_PIC_RGBA pictures
 // (Frame.RGBA() fused); the other one carries none of that code.
 template <int WAVES, bool kRgba>
-__global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a)
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_kernel(const VideoArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kRcLdsBytes];
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -94,81 +94,87 @@ __global__ __launch_bounds__(WAVES * 64) void recon_kernel(const VideoArgs a)
     const int below_l = ((lane + 4) & 63) << 2, below_c = ((lane + 2) & 63) << 2; // ds_bpermute addresses of the row below
     int32_t v[8];
     uint32_t ent_at = 0;
-    for (uint32_t pass = 0;; pass++) {
-        const bool work = pass * 8 < n_blocks; // (wave-uniform)
-        if (work) {
-            // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7
-            const uint32_t np = rc_pass_entries(c, pass);
-            rc_zero_tile(T, lane);
-            if (pass > 0)
-                bw = rc_load_blk(a, c, pass, lane);
-            wave_lds_handoff();
-            for (uint32_t r = 0; r < np; r += 64) {
-                if (pass > 0 || r > 0)
-                    e = rc_load_ent(a, c, ent_at + r, lane);
-                if (r + (uint32_t)lane < np)
-                    rc_scatter(T, Q, e);
-            }
-            ent_at += np;
-            if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
-#pragma unroll
-                for (uint32_t g = 0; g < 8; g++) {
-                    const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
-                    if (pass * 8 + g < n_blocks && (bwg & kBRaw))
-                        rc_raw_fill(a, c, T, g, bwg, lane);
-                }
-            }
-            wave_lds_handoff();
-            rc_cols_load(T, lane, v);
-            idct8<false>(v);
-            rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now
-            wave_lds_handoff();
-            rc_rows_load(T, lane, v);
-            idct8<true>(v);
+    // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7; leaves lane (g, j) with row j of block g
+    auto residual_pass = [&](uint32_t pass) {
+        const uint32_t np = rc_pass_entries(c, pass);
+        rc_zero_tile(T, lane);
+        if (pass > 0)
+            bw = rc_load_blk(a, c, pass, lane);
+        wave_lds_handoff();
+        for (uint32_t r = 0; r < np; r += 64) {
+            if (pass > 0 || r > 0)
+                e = rc_load_ent(a, c, ent_at + r, lane);
+            if (r + (uint32_t)lane < np)
+                rc_scatter(T, Q, e);
         }
-        if (pass == 0) {
-            // step 3: motion compensation into O, half-pel modes wave-uniform per macroblock
+        ent_at += np;
+        if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
 #pragma unroll
-            for (int m = 0; m < kRcMbs; m++) {
-                const uint32_t d0 = c.r[m][0];
-                if (d0 & kRDead)
-                    continue;
-                uint32_t yl = 0, yc = 0;
-                if (!(d0 & kRIntra)) {
-                    uint32_t b0 = p[m].lx0, b1 = p[m].lx1;
-                    if (d0 & kROvL) {
-                        const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l0);
-                        b0 = last_l ? b0 : g0;
-                        if (d0 & kROhL) {
-                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l1);
-                            b1 = last_l ? b1 : g1;
-                        }
-                    }
-                    yl = rc_mc4(p[m].l0, p[m].l1, b0, b1, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
-                    uint32_t q0 = p[m].cx0, q1 = p[m].cx1;
-                    if (d0 & kROvC) {
-                        const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c0);
-                        q0 = last_c ? q0 : g0;
-                        if (d0 & kROhC) {
-                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c1);
-                            q1 = last_c ? q1 : g1;
-                        }
-                    }
-                    yc = rc_mc4(p[m].c0, p[m].c1, q0, q1, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
-                }
-                *reinterpret_cast<uint32_t *>(O + k.tile_luma + m * 16) = yl;
-                if (lane < 32)
-                    *reinterpret_cast<uint32_t *>(O + k.tile_chroma + m * 8) = yc;
+            for (uint32_t g = 0; g < 8; g++) {
+                const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
+                if (pass * 8 + g < n_blocks && (bwg & kBRaw))
+                    rc_raw_fill(a, c, T, g, bwg, lane);
             }
         }
-        if (!work)
-            break;
-        // step 4: residual rows onto the prediction
+        wave_lds_handoff();
+        rc_cols_load(T, lane, v);
+        if (rc_any_dense(c)) { // blocks that travel as dense units: their columns come straight from the unit
+            if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw & kBDense))
+                rc_dense_cols(a, c, Q, bw, lane, v);
+        }
+        idct8<false>(v);
+        rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now
+        wave_lds_handoff();
+        rc_rows_load(T, lane, v);
+        idct8<true>(v);
+    };
+    // step 4: residual rows onto the prediction
+    auto add_residual = [&](uint32_t pass) {
         wave_lds_handoff();
         if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks)
             rc_rmw(O, bw, lane, v);
-        if ((pass + 1) * 8 >= n_blocks)
-            break;
+    };
+    if (n_blocks)
+        residual_pass(0);
+    // step 3: motion compensation into O, half-pel modes wave-uniform per macroblock
+#pragma unroll
+    for (int m = 0; m < kRcMbs; m++) {
+        const uint32_t d0 = c.r[m][0];
+        if (d0 & kRDead)
+            continue;
+        uint32_t yl = 0, yc = 0;
+        if (!(d0 & kRIntra)) {
+            uint32_t b0 = p[m].lx0, b1 = p[m].lx1;
+            if (d0 & kROvL) {
+                const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l0);
+                b0 = last_l ? b0 : g0;
+                if (d0 & kROhL) {
+                    const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l1);
+                    b1 = last_l ? b1 : g1;
+                }
+            }
+            yl = rc_mc4(p[m].l0, p[m].l1, b0, b1, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
+            uint32_t q0 = p[m].cx0, q1 = p[m].cx1;
+            if (d0 & kROvC) {
+                const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c0);
+                q0 = last_c ? q0 : g0;
+                if (d0 & kROhC) {
+                    const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c1);
+                    q1 = last_c ? q1 : g1;
+                }
+            }
+            yc = rc_mc4(p[m].c0, p[m].c1, q0, q1, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+        }
+        *reinterpret_cast<uint32_t *>(O + k.tile_luma + m * 16) = yl;
+        if (lane < 32)
+            *reinterpret_cast<uint32_t *>(O + k.tile_chroma + m * 8) = yc;
+    }
+    if (n_blocks) {
+        add_residual(0);
+        for (uint32_t pass = 1; pass * 8 < n_blocks; pass++) {
+            residual_pass(pass);
+            add_residual(pass);
+        }
     }
     wave_lds_handoff();
     // step 5

@@ -10,18 +10,22 @@
 //                   h2 byte offset of the stream's dequantisation table
 //                   h3 index (into words) of the chunk's first block word     h4 of its first coefficient entry
 //                   h5 entries of pass 0 | pass 1 << 10 | pass 2 << 20 | kCRun | kCRgba
-//                   h6 coded blocks (0..24) | live macroblocks << 8 | any int32 snapshot block << 16
+//                   h6 coded blocks (0..24) | live macroblocks << 8 | any snapshot block << 16 | any dense block << 17
 //           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24     d1 reference frame offset >> 8
 //                   d2 byte offset (inside the frame) of the luma prediction window: origin + integer vector
 //                   d3 the same for Cb (plane offset included; Cr = + chroma_bytes)
 //   words   per chunk, one after the other (a wave's loads share cache lines):
 //           block words, one per coded block, in (macroblock, block) order = "slot" order:
-//                   output-tile byte offset of the block's row 0 | chroma << 11 | snapshot << 12
-//                   | (snapshot: dword offset of its 64 int32 values behind the chunk's first entry) << 13
-//           entries, one per NON-ZERO quantised coefficient, grouped by pass (slots 0-7, 8-15, 16-23):
+//                   output-tile byte offset of the block's row 0 | chroma << 11 | snapshot << 12 | dense << 13
+//                   | (snapshot / dense: dword offset of its data behind the chunk's first entry) << 14
+//                   | (dense: quantiser_scale << 26 | non-intra << 31)
+//           entries, one per NON-ZERO quantised coefficient of the sparse blocks, grouped by pass (slots 0-7,
+//           8-15, 16-23):
 //                   level << 16 | quantiser_scale << 11 | (slot & 7) << 8 | position << 2 | non-intra << 1
 //                   | "intra DC" ; position = column * 8 + row, the order of the ABI's coefficient units
-//           then the chunk's int32 snapshot blocks (MPEGHIP_MB_COEF_RAW), 64 dwords each
+//           then the data of the chunk's other blocks: int32 snapshot blocks (MPEGHIP_MB_COEF_RAW), 64 dwords
+//           each, and DENSE blocks — more than 32 non-zero levels, where a unit as the ABI hands it over
+//           (64 int16 levels, 32 dwords) is the shorter form
 //
 // The reference's VLC loop produces exactly such (position, level) pairs (video.go:680-745); the ABI hands
 // them over as dense 128-byte units, the packer drops the zeros again.  Dequantisation, premultiply, IDCT,
@@ -58,7 +62,8 @@ constexpr int kRcMaxBlocks = 6 * kRcMbs;      // 24 slots, 3 passes of 8
 constexpr int kRcChunkDwords = 8 + 4 * kRcMbs;
 constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                                    // header h5
 constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32;  // record d0
-constexpr uint32_t kBChroma = 1u << 11, kBRaw = 1u << 12;                                  // block word
+constexpr uint32_t kBChroma = 1u << 11, kBRaw = 1u << 12, kBDense = 1u << 13;              // block word
+constexpr uint32_t kDenseAbove = 32; // non-zero levels beyond which a block travels as a dense unit
 constexpr uint32_t kEDc = 1, kENonIntra = 2;                                               // entry
 
 // wave-private LDS
@@ -145,7 +150,8 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         struct Slot {
             const uint8_t *unit;
             uint32_t bits; // quantiser_scale << 11 | non-intra << 1
-            bool intra, raw;
+            uint64_t mask; // non-zero levels
+            bool intra, raw, dense;
         } slot[kRcMaxBlocks];
         uint32_t n_slots = 0;
         uint32_t *bw = words_out + out.words;
@@ -188,22 +194,27 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 s.bits = ((uint32_t)(mb.qscale & 31) << 11) | (intra ? 0u : kENonIntra);
                 s.intra = intra;
                 s.raw = raw;
+                s.mask = raw ? 0 : rc_nonzero_mask(s.unit);
+                s.dense = !raw && (uint32_t)__builtin_popcountll(s.mask) > kDenseAbove;
                 bw[n_slots] = rc_tile_offset(b, 0, m) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
+                if (s.dense)
+                    bw[n_slots] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
                 unit += raw ? 2 : 1;
                 n_slots++;
             }
         }
         uint32_t *e0 = bw + n_slots, ne = 0, counts = 0;
-        bool any_raw = false;
+        bool any_raw = false, any_dense = false;
         for (uint32_t pass = 0; pass * 8 < n_slots; pass++) {
             const uint32_t before = ne;
             for (uint32_t s = pass * 8; s < n_slots && s < pass * 8 + 8; s++) {
                 const Slot &sl = slot[s];
-                if (sl.raw) {
-                    any_raw = true;
+                if (sl.raw || sl.dense) {
+                    any_raw = any_raw || sl.raw;
+                    any_dense = any_dense || sl.dense;
                     continue;
                 }
-                uint64_t mask = rc_nonzero_mask(sl.unit);
+                uint64_t mask = sl.mask;
                 const uint32_t bits = sl.bits | ((s & 7) << 8);
                 while (mask) {
                     const uint32_t pos = (uint32_t)__builtin_ctzll(mask);
@@ -215,12 +226,13 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             }
             counts |= (ne - before) << (10 * pass);
         }
-        if (any_raw)
+        if (any_raw || any_dense)
             for (uint32_t s = 0; s < n_slots; s++)
-                if (slot[s].raw) { // the 64 int32 values as they are (position order = the unit's order)
-                    bw[s] |= ne << 13;
-                    memcpy(e0 + ne, slot[s].unit, 256);
-                    ne += 64;
+                if (slot[s].raw || slot[s].dense) { // the unit(s) as they are (position order = the unit's order)
+                    const uint32_t dwords = slot[s].raw ? 64 : 32;
+                    bw[s] |= ne << 14;
+                    memcpy(e0 + ne, slot[s].unit, dwords * 4);
+                    ne += dwords;
                 }
         h[0] = cur256;
         h[1] = rgba256;
@@ -228,7 +240,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         h[3] = word_base + out.words;
         h[4] = word_base + out.words + n_slots;
         h[5] = counts | (run ? kCRun : 0u) | (rgba ? kCRgba : 0u);
-        h[6] = n_slots | (live << 8) | (any_raw ? 1u << 16 : 0u);
+        h[6] = n_slots | (live << 8) | (any_raw ? 1u << 16 : 0u) | (any_dense ? 1u << 17 : 0u);
         h[7] = 0;
         out.chunks++;
         out.words += n_slots + ne;
@@ -271,6 +283,7 @@ MPG_HD RcChunk rc_load_chunk(const VideoArgs &a, uint32_t chunk)
 MPG_HD uint32_t rc_n_blocks(const RcChunk &c) { return c.h[6] & 0xff; }
 MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[6] >> 8) & 0xff; }
 MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[6] >> 16) & 1; }
+MPG_HD bool rc_any_dense(const RcChunk &c) { return (c.h[6] >> 17) & 1; }
 MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[5] >> (10 * pass)) & 0x3ff; }
 
 // what depends on the lane only (worked out once per wave)
@@ -365,7 +378,7 @@ MPG_HD void rc_scatter(int32_t *T, const uint8_t *Q, uint32_t e)
 // an int32 snapshot block: its 64 values as they are, lane = position
 MPG_HD void rc_raw_fill(const VideoArgs &a, const RcChunk &c, int32_t *T, uint32_t g, uint32_t bw, int lane)
 {
-    T[g * 64 + (uint32_t)lane] = (int32_t)a.words[c.h[4] + (bw >> 13) + (uint32_t)lane];
+    T[g * 64 + (uint32_t)lane] = (int32_t)a.words[c.h[4] + ((bw >> 14) & 0xfffu) + (uint32_t)lane];
 }
 
 // lane (g, j) = column j of the pass's block g, then row j
@@ -379,6 +392,32 @@ MPG_HD void rc_cols_load(const int32_t *T, int lane, int32_t (&v)[8])
         v[r + 4] = t1.v[r];
     }
 }
+// a dense block: lane (g, j) takes column j straight from the unit — one 16-byte load, 8 levels dequantised in
+// place of the tile read.  Rows that are empty in every dense lane of the wave are skipped wave-wide.
+struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; };
+MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *Q, uint32_t bw, int lane, int32_t (&v)[8])
+{
+    const uint32_t j = (uint32_t)lane & 7;
+    const i32x4_a4 lv = *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 14) & 0xfffu) + j * 4);
+    const int32_t qs = (int32_t)((bw >> 26) & 31);
+    const bool intra = !(bw >> 31);
+    const uint8_t *q = Q + j * 32 + (intra ? 0 : 2); // [position = j * 8 + r][class]{matrix, premultiplier}
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int32_t w = lv.v[r >> 1];
+        const int32_t level = (r & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
+        if (none_in_wave(level != 0)) {
+            v[r] = 0;
+            continue;
+        }
+        const uint32_t tq = *reinterpret_cast<const uint16_t *>(q + r * 4);
+        const int32_t d = dequant(level, intra, qs * (int32_t)(tq & 0xff), (int32_t)(tq >> 8));
+        v[r] = level ? d : 0;
+    }
+    if (intra && j == 0)
+        v[0] = (int32_t)(int16_t)(lv.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
+}
+
 MPG_HD void rc_cols_store(int32_t *T, int lane, const int32_t (&v)[8])
 {
     int32_t *t = T + (lane >> 3) * 64 + (lane & 7);
