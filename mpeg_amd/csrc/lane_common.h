@@ -224,6 +224,74 @@ MPG_HD void copy16_to_lds(const void *g, void *lds_wave_base, int lane)
 #endif
 }
 
+// ---- loads whose completion the KERNEL waits for (s_waitcnt vmcnt(N) placed by hand, wait_loads below), not the
+// compiler: it forces vmcnt(0) in front of the first LDS access that follows a direct-to-LDS load, and it counts
+// conservatively across branches; the reconstruction kernel wants "the two oldest loads are back" instead.
+// They are inline assembly, so the compiler neither counts them nor waits for them.
+//
+// SIX direct-to-LDS loads (global_load_lds_dwordx4: 16 bytes per lane from global memory straight into LDS, no
+// registers in between).  Load i: lane l fetches base[i] + off[i] (wave-uniform base, 32-bit per-lane byte offset)
+// and lands at lds_wave_base + kAt_i + 16 l.  One asm statement: M0 (the LDS base) is written once, and the target
+// offset of each load travels in the instruction's offset field, which the hardware adds to the LDS address AND to
+// the global address (tools/microbench/lds_dma_probe4.hip) — the scalar base is moved back by the same amount.
+// Loads complete in order, also mixed with register loads, and their data is in LDS as soon as s_waitcnt vmcnt lets
+// the wave go (lds_dma_probe3.hip: 800 000 waves on cold lines).  (dwordx3 keeps the 16-byte lane stride and
+// leaves holes: lds_dma_probe.hip.)
+template <int kAt0, int kAt1, int kAt2, int kAt3, int kAt4, int kAt5>
+MPG_HD void dma16x6_to_lds(const uint8_t *const (&g_base)[6], const uint32_t (&off)[6], void *lds_wave_base, int lane)
+{
+    static_assert(kAt0 >= 0 && kAt5 < 4096 && kAt1 < 4096 && kAt2 < 4096 && kAt3 < 4096 && kAt4 < 4096, "13-bit signed offset field");
+#if MPG_ON_DEVICE
+    (void)lane;
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base); // LDS aperture: low 32 bits = offset
+    asm volatile("s_mov_b32 m0, %12\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %6 offset:%13\n\t"
+                 "global_load_lds_dwordx4 %1, %7 offset:%14\n\t"
+                 "global_load_lds_dwordx4 %2, %8 offset:%15\n\t"
+                 "global_load_lds_dwordx4 %3, %9 offset:%16\n\t"
+                 "global_load_lds_dwordx4 %4, %10 offset:%17\n\t"
+                 "global_load_lds_dwordx4 %5, %11 offset:%18"
+                 :
+                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(g_base[0] - kAt0),
+                   "s"(g_base[1] - kAt1), "s"(g_base[2] - kAt2), "s"(g_base[3] - kAt3), "s"(g_base[4] - kAt4), "s"(g_base[5] - kAt5),
+                   "s"(base), "n"(kAt0), "n"(kAt1), "n"(kAt2), "n"(kAt3), "n"(kAt4), "n"(kAt5)
+                 : "memory");
+#else
+    const int at[6] = {kAt0, kAt1, kAt2, kAt3, kAt4, kAt5};
+    for (int i = 0; i < 6; i++)
+        __builtin_memcpy(static_cast<char *>(lds_wave_base) + at[i] + 16 * lane, g_base[i] + off[i], 16);
+#endif
+}
+// one dword per lane into a register; only valid after wait_loads + settle() — and settle() it on EVERY path, used or
+// not: until then the register belongs to the load, and the compiler must not hand it to something else
+MPG_HD uint32_t load32_uncounted(const uint32_t *g)
+{
+#if MPG_ON_DEVICE
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(g) : "memory");
+    return v;
+#else
+    return *g;
+#endif
+}
+// wait until at most `newer` of the loads above are still in flight (they complete in order)
+template <int kNewer> MPG_HD void wait_loads()
+{
+#if MPG_ON_DEVICE
+    static_assert(kNewer >= 0 && kNewer < 16, "vmcnt");
+    __builtin_amdgcn_s_waitcnt(0x0f70 | kNewer); // gfx9 encoding: vmcnt[3:0], expcnt 7, lgkmcnt 15 = no wait on those
+#endif
+}
+// ties a register loaded by load32_uncounted to the wait in front of it: its uses cannot move above this point
+MPG_HD void settle(uint32_t &v)
+{
+#if MPG_ON_DEVICE
+    asm volatile("" : "+v"(v)::"memory");
+#else
+    (void)v;
+#endif
+}
+
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its
 // own L2).  Gives every XCD one contiguous range of work chunks so that
 // neighbouring macroblocks — which share 128-byte destination lines and overlapping

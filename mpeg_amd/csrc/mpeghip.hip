@@ -43,9 +43,20 @@ static __device__ __forceinline__ void wave_lds_handoff()
 // ---- reconstruction (video_recon_lane.h has the whole story): one wave = one chunk of 4 macroblocks,
 // wave-private LDS, no barrier.  kRgba: the instance for batches with MPEGHIP_PIC_RGBA pictures
 // (Frame.RGBA() fused); the other one carries none of that code.
+#ifdef MPG_PHASE_TIMING // instrumented build for tools/phase_timing.py only: s_memtime at the phase boundaries
+__device__ uint64_t g_phase_dump[60000 * 8];
+#define MPG_STAMP(k) ts[k] = __builtin_readcyclecounter()
+#else
+#define MPG_STAMP(k)
+#endif
+
 template <int WAVES, bool kRgba>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_kernel(const VideoArgs a)
 {
+#ifdef MPG_PHASE_TIMING
+    uint64_t ts[8];
+#endif
+    MPG_STAMP(0);
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kRcLdsBytes];
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -53,59 +64,41 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     if (chunk >= a.n_chunks)
         return;
     uint8_t *lds = lds_all + w * kRcLdsBytes;
-    int32_t *T = reinterpret_cast<int32_t *>(lds);
-    uint8_t *O = lds + kRcTileBytes;
-    uint8_t *Q = O + kRcOutBytes;
+    int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
 
-    // step 1: one round of scalar loads, then every vector load of the chunk
+    // step 1: one round of scalar loads, then the five vector loads of the chunk
     const RcChunk c = rc_load_chunk(a, chunk);
     const RcLane k = rc_lane(a, lane);
     const uint32_t n_blocks = rc_n_blocks(c);
-    const uint32_t qdw = rc_load_qtab(a, c, lane);
-    uint32_t bw = rc_load_blk(a, c, 0, lane);
-    uint32_t e = rc_load_ent(a, c, 0, lane);
-    RcPred p[kRcMbs];
-#pragma unroll
-    for (int m = 0; m < kRcMbs; m++)
-        p[m].lx0 = p[m].lx1 = p[m].cx0 = p[m].cx1 = p[m].c0 = p[m].c1 = 0;
-    const bool last_l = rc_luma_last_row(lane), last_c = rc_chroma_last_row(lane);
-    if (last_l) { // the windows' extra rows first: few lanes, and the loads behind them can be counted
-#pragma unroll
-        for (int m = 0; m < kRcMbs; m++)
-            if (c.r[m][0] & kROvL)
-                rc_pred_luma_extra(a, c, m, k, p[m]);
+#ifdef MPG_PHASE_TIMING
+    if (n_blocks > 24) // (never: makes the stamp wait for the chunk)
+        return;
+#endif
+    MPG_STAMP(1);
+    uint32_t e = load32_uncounted(rc_ent_src(a, c, 0, lane));
+    if (lane < kRcWinLanes) {
+        const uint8_t *const src[6] = {rc_table_src(a, c), rc_blk_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1),
+                                       rc_win_base(a, c, 2), rc_win_base(a, c, 3)};
+        const uint32_t off[6] = {(uint32_t)lane * 16, (uint32_t)lane * 16, rc_win_offset(c, 0, k), rc_win_offset(c, 1, k),
+                                 rc_win_offset(c, 2, k), rc_win_offset(c, 3, k)};
+        dma16x6_to_lds<kRcQtabAt, kRcBlkAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes>(
+            src, off, lds, lane);
     }
-    if (lane < 32 && last_c) {
-#pragma unroll
-        for (int m = 0; m < kRcMbs; m++)
-            if (c.r[m][0] & kROvC)
-                rc_pred_chroma_extra(a, c, m, k, p[m]);
-    }
-#pragma unroll
-    for (int m = 0; m < kRcMbs; m++)
-        rc_pred_luma(a, c, m, k, p[m]);
-    if (lane < 32) {
-#pragma unroll
-        for (int m = 0; m < kRcMbs; m++)
-            rc_pred_chroma(a, c, m, k, p[m]);
-    }
-    *reinterpret_cast<uint32_t *>(Q + lane * 4) = qdw;
+    MPG_STAMP(2);
 
-    const int below_l = ((lane + 4) & 63) << 2, below_c = ((lane + 2) & 63) << 2; // ds_bpermute addresses of the row below
     int32_t v[8];
-    uint32_t ent_at = 0;
+    uint32_t bw = 0, ent_at = 0;
     // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7; leaves lane (g, j) with row j of block g
     auto residual_pass = [&](uint32_t pass) {
         const uint32_t np = rc_pass_entries(c, pass);
         rc_zero_tile(T, lane);
-        if (pass > 0)
-            bw = rc_load_blk(a, c, pass, lane);
+        bw = rc_blk_word(lds, pass, lane);
         wave_lds_handoff();
         for (uint32_t r = 0; r < np; r += 64) {
             if (pass > 0 || r > 0)
-                e = rc_load_ent(a, c, ent_at + r, lane);
+                e = *rc_ent_src(a, c, ent_at + r, lane);
             if (r + (uint32_t)lane < np)
-                rc_scatter(T, Q, e);
+                rc_scatter(T, lds, e);
         }
         ent_at += np;
         if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
@@ -120,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         rc_cols_load(T, lane, v);
         if (rc_any_dense(c)) { // blocks that travel as dense units: their columns come straight from the unit
             if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw & kBDense))
-                rc_dense_cols(a, c, Q, bw, lane, v);
+                rc_dense_cols(a, c, lds, bw, lane, v);
         }
         idct8<false>(v);
         rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now
@@ -132,43 +125,37 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     auto add_residual = [&](uint32_t pass) {
         wave_lds_handoff();
         if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks)
-            rc_rmw(O, bw, lane, v);
+            rc_rmw(lds, bw, lane, v);
     };
-    if (n_blocks)
+    if (n_blocks) {
+        wait_loads<4>(); // the entries, the table and the block words are there; the four windows may still be on their way
+        settle(e);
+        wave_lds_handoff();
         residual_pass(0);
-    // step 3: motion compensation into O, half-pel modes wave-uniform per macroblock
+    }
+    MPG_STAMP(3);
+    // step 3: motion compensation, half-pel modes wave-uniform per macroblock: window in LDS -> O_m over it
+    wait_loads<0>(); // all four windows are there
+    settle(e);       // (on every path: until here the entries' register belongs to a load in flight)
+    wave_lds_handoff();
 #pragma unroll
     for (int m = 0; m < kRcMbs; m++) {
         const uint32_t d0 = c.r[m][0];
         if (d0 & kRDead)
             continue;
+        uint8_t *win = lds + rc_win_at(m);
         uint32_t yl = 0, yc = 0;
         if (!(d0 & kRIntra)) {
-            uint32_t b0 = p[m].lx0, b1 = p[m].lx1;
-            if (d0 & kROvL) {
-                const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l0);
-                b0 = last_l ? b0 : g0;
-                if (d0 & kROhL) {
-                    const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_l, (int)p[m].l1);
-                    b1 = last_l ? b1 : g1;
-                }
-            }
-            yl = rc_mc4(p[m].l0, p[m].l1, b0, b1, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
-            uint32_t q0 = p[m].cx0, q1 = p[m].cx1;
-            if (d0 & kROvC) {
-                const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c0);
-                q0 = last_c ? q0 : g0;
-                if (d0 & kROhC) {
-                    const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_bpermute(below_c, (int)p[m].c1);
-                    q1 = last_c ? q1 : g1;
-                }
-            }
-            yc = rc_mc4(p[m].c0, p[m].c1, q0, q1, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+            yl = rc_mc4(win + k.mc_luma, 2 * kRcPiece, rc_shift_luma(d0), (d0 & kROhL) != 0, (d0 & kROvL) != 0);
+            if (lane < 32)
+                yc = rc_mc4(win + k.mc_chroma, kRcPiece, rc_shift_chroma(d0), (d0 & kROhC) != 0, (d0 & kROvC) != 0);
         }
-        *reinterpret_cast<uint32_t *>(O + k.tile_luma + m * 16) = yl;
+        wave_lds_handoff(); // every lane has its taps
+        *reinterpret_cast<uint32_t *>(win + k.out_luma) = yl;
         if (lane < 32)
-            *reinterpret_cast<uint32_t *>(O + k.tile_chroma + m * 8) = yc;
+            *reinterpret_cast<uint32_t *>(win + k.out_chroma) = yc;
     }
+    MPG_STAMP(4);
     if (n_blocks) {
         add_residual(0);
         for (uint32_t pass = 1; pass * 8 < n_blocks; pass++) {
@@ -176,18 +163,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
             add_residual(pass);
         }
     }
+    MPG_STAMP(5);
     wave_lds_handoff();
     // step 5
     const bool run = (c.h[5] & kCRun) != 0;
     const bool rgba = kRgba && (c.h[5] & kCRgba) != 0;
     const uint32_t n_live = rc_n_live(c);
     if (run) {
-        rc_store_run(a, c, lane, k, O);
+        rc_store_run(a, c, lane, lds);
     } else {
 #pragma unroll
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
             if (m < n_live)
-                rc_store_mb(a, c, m, lane, O, rgba);
+                rc_store_mb(a, c, m, lane, lds, rgba);
     }
     if (kRgba && rgba) {
         if (!run)
@@ -195,9 +183,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
             if (m < n_live)
-                rc_rgba_mb(a, c, m, lane, O);
+                rc_rgba_mb(a, c, m, lane, lds);
     }
+#ifdef MPG_PHASE_TIMING
+    MPG_STAMP(6);
+    if (lane == 0 && chunk < 60000) {
+        for (int i = 0; i < 7; i++)
+            g_phase_dump[(uint64_t)chunk * 8 + i] = ts[i];
+        g_phase_dump[(uint64_t)chunk * 8 + 7] = n_blocks;
+    }
+#endif
 }
+#undef MPG_STAMP
 
 // Frame.RGBA of the cur slot of every picture flagged MPEGHIP_PIC_RGBA: grid (x quads, rows, pictures).
 __global__ __launch_bounds__(256) void rgba_pics_kernel(const VideoArgs a, uint32_t pic0)
@@ -610,7 +607,7 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
             rc = fail(MPEGHIP_ERR_OOM, "hipMalloc(%llu) for the frame store failed", (unsigned long long)total);
             break;
         }
-        if (hipMalloc((void **)&v->d_qmat, (size_t)n_streams * 256) != hipSuccess ||
+        if (hipMalloc((void **)&v->d_qmat, (size_t)n_streams * kRcQtabStride + kRcQtabPad) != hipSuccess ||
             hipMalloc((void **)&v->d_hash, (size_t)n_streams * 8) != hipSuccess) {
             rc = fail(MPEGHIP_ERR_OOM, "hipMalloc for tables failed");
             break;
@@ -1741,5 +1738,14 @@ int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, i
     HIP_TRY(hipMemcpy(a->d_vpos + stream, &vpos, sizeof(int32_t), hipMemcpyHostToDevice));
     return MPEGHIP_OK;
 }
+
+#ifdef MPG_PHASE_TIMING
+int mpeghip_debug_read_dump(mpeghip_video *v, void *dst, size_t bytes)
+{
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase_dump), bytes));
+    return MPEGHIP_OK;
+}
+#endif
 
 } // extern "C"

@@ -7,17 +7,19 @@
 //
 //   chunks  24 dwords per chunk: 8 header dwords + 4 records of 4 dwords — ONE round of scalar loads
 //           header  h0 destination frame offset >> 8        h1 RGBA image offset >> 8
-//                   h2 byte offset of the stream's dequantisation table
+//                   h2 byte offset of the stream's dequantisation table (stream * kRcQtabStride)
 //                   h3 index (into words) of the chunk's first block word     h4 of its first coefficient entry
 //                   h5 entries of pass 0 | pass 1 << 10 | pass 2 << 20 | kCRun | kCRgba
 //                   h6 coded blocks (0..24) | live macroblocks << 8 | any snapshot block << 16 | any dense block << 17
-//           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24     d1 reference frame offset >> 8
-//                   d2 byte offset (inside the frame) of the luma prediction window: origin + integer vector
+//           record  d0 kR* flags | luma shift << 6 | cbp << 8 | chroma shift << 14 | mb_x << 16 | mb_y << 24
+//                   d1 reference frame offset >> 8
+//                   d2 byte offset (inside the frame) of the luma prediction window (origin + integer vector),
+//                      rounded DOWN to a dword; the 0..3 bytes it lost are the "shift"
 //                   d3 the same for Cb (plane offset included; Cr = + chroma_bytes)
 //   words   per chunk, one after the other (a wave's loads share cache lines):
 //           block words, one per coded block, in (macroblock, block) order = "slot" order:
-//                   output-tile byte offset of the block's row 0 | chroma << 11 | snapshot << 12 | dense << 13
-//                   | (snapshot / dense: dword offset of its data behind the chunk's first entry) << 14
+//                   LDS byte offset / 8 of the block's row 0 in the output bytes | chroma << 9 | snapshot << 10
+//                   | dense << 11 | (snapshot / dense: dword offset of its data behind the chunk's first entry) << 12
 //                   | (dense: quantiser_scale << 26 | non-intra << 31)
 //           entries, one per NON-ZERO quantised coefficient of the sparse blocks, grouped by pass (slots 0-7,
 //           8-15, 16-23):
@@ -31,22 +33,28 @@
 // them over as dense 128-byte units, the packer drops the zeros again.  Dequantisation, premultiply, IDCT,
 // prediction and write-back all happen on the device:
 //
-//   1  scalar loads: header + 4 records.  Vector loads, all issued before the first use: the stream's
-//      256-byte dequantisation table (-> LDS), the pass's block words, the first 64 entries, and the
-//      prediction windows of the 4 macroblocks — luma as 64 lanes x 8 bytes (lane = row, quarter: bytes
-//      4q .. 4q+7 of the row cover both horizontal taps of its 4 pixels), chroma as 32 lanes x 8 bytes.
-//      The row below (vertical tap) comes from the lane that holds it (ds_bpermute); only the window's
-//      last row is loaded separately, by 4 lanes.
+//   1  scalar loads: header + 4 records.  Then SEVEN vector loads per wave, all issued before the first use:
+//      the first 64 entries (one dword per lane), and six direct-to-LDS loads (global_load_lds_dwordx4: lane
+//      l's 16 bytes land at LDS base + 16 l, no registers in between, scalar base + 32-bit lane offset): the
+//      stream's dequantisation table (12 lanes), the chunk's block words (6 lanes), and per macroblock its
+//      whole prediction window as 52 PIECES: 17 luma rows x 2 pieces + 2 x 9 chroma rows x 1 piece.
+//      Pieces start on DWORD boundaries (the window's byte offset, wave-uniform, is applied when the taps are
+//      read).  No registers hold prediction data (the first version of this kernel kept 32 of them and needed
+//      19 load instructions per wave, with ds_bpermute for the row below).
 //   2  residual pass (8 coded blocks at a time): zero the wave's int32 tile T[8][64]; one entry per lane:
 //      dequantise (video.go:719-744) and scatter to T[slot & 7][position]; lane (g, j): column j of block
 //      g (two 16-byte LDS reads), column pass, transposed write-back, row j, row pass (+128 >> 8).
 //   3  motion compensation, per macroblock with WAVE-UNIFORM half-pel modes (video_noasm.go:48-80): luma
-//      by 64 lanes x 4 pixels, chroma by 32 lanes x 4 pixels, into the output tile O (the chunk's 4 x 384
-//      bytes laid out as frame rows).  Intra macroblocks put zeros.
+//      by 64 lanes x 4 pixels, chroma by 32 lanes x 4 pixels, taps read from the window in LDS, result written
+//      over it (every lane has its taps before any lane writes): the macroblock's 384 output bytes O_m.
+//      Intra macroblocks put zeros.
 //   4  lane (g, j) adds its residual row to the 8 prediction bytes in O and clamps (video.go:943-971).
 //      (Passes 1, 2 of a chunk with more than 8 coded blocks repeat steps 2 and 4.)
-//   5  O leaves as whole 64-byte luma / 32-byte chroma rows when the chunk is a horizontal run (kCRun),
-//      else as 8-byte rows per block; pictures flagged MPEGHIP_PIC_RGBA are colour-converted from O.
+//   5  the four O_m leave as whole 64-byte luma / 32-byte chroma rows when the chunk is a horizontal run
+//      (kCRun), else as 8-byte rows per block; pictures flagged MPEGHIP_PIC_RGBA are colour-converted from them.
+//
+// Wave-private LDS, 5664 bytes (7 waves per SIMD):
+//      [   0,  192) table    [ 192,  288) 24 block words    [ 288 + 832 m, + 832) window m -> O_m    [3616, 5664) T
 #pragma once
 
 #include "video_lane.h"
@@ -62,22 +70,33 @@ constexpr int kRcMaxBlocks = 6 * kRcMbs;      // 24 slots, 3 passes of 8
 constexpr int kRcChunkDwords = 8 + 4 * kRcMbs;
 constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                                    // header h5
 constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32;  // record d0
-constexpr uint32_t kBChroma = 1u << 11, kBRaw = 1u << 12, kBDense = 1u << 13;              // block word
+constexpr uint32_t kBChroma = 1u << 9, kBRaw = 1u << 10, kBDense = 1u << 11;               // block word
 constexpr uint32_t kDenseAbove = 32; // non-zero levels beyond which a block travels as a dense unit
 constexpr uint32_t kEDc = 1, kENonIntra = 2;                                               // entry
 
 // wave-private LDS
+constexpr int kRcPiece = 16;                  // bytes per lane of a direct-to-LDS load
+constexpr int kRcWinLuma = 17 * 2 * kRcPiece; // 544: 17 rows x 32 bytes
+constexpr int kRcWinLanes = 52;               // + 2 planes x 9 rows x 1 piece
+constexpr int kRcWinBytes = kRcWinLanes * kRcPiece; // 832
+constexpr int kRcQtabBytes = 192;             // [64 positions][{intra, non-intra} matrix entry] + [64] premultiplier
+constexpr int kRcQtabStride = 256;            // per stream in HBM
+constexpr int kRcQtabAt = 0;
+constexpr int kRcBlkAt = kRcQtabBytes;        // 192: 24 block words = 6 pieces
+constexpr int kRcWinAt = kRcBlkAt + 96;       // 288
+constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3616
 constexpr int kRcTileBytes = 8 * 64 * 4;      // T: int32 [8 blocks][64]
-constexpr int kRcOutBytes = 16 * 64 + 2 * 8 * 32; // O: luma [16 rows][4 x 16] | Cb [8][4 x 8] | Cr [8][4 x 8]
-constexpr int kRcQtabBytes = 256;             // Q: the stream's {matrix, premultiplier} table
-constexpr int kRcLdsBytes = kRcTileBytes + kRcOutBytes + kRcQtabBytes; // 3840
+constexpr int kRcLdsBytes = kRcTileAt + kRcTileBytes; // 5664
 
-// byte offset inside O of row j of block b of macroblock m
+// LDS byte offset of macroblock m's window, later its output bytes O_m: luma [16 rows][16] | Cb [8][8] | Cr [8][8]
+MPG_HD uint32_t rc_win_at(uint32_t m) { return kRcWinAt + m * kRcWinBytes; }
+
+// LDS byte offset of row j of block b of macroblock m (inside O_m)
 MPG_HD uint32_t rc_tile_offset(int b, int j, uint32_t m)
 {
     if (b < 4)
-        return ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 64 + m * 16 + ((uint32_t)(b & 1) << 3);
-    return 1024 + (uint32_t)(b - 4) * 256 + (uint32_t)j * 32 + m * 8;
+        return rc_win_at(m) + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 16 + ((uint32_t)(b & 1) << 3);
+    return rc_win_at(m) + 256 + (uint32_t)(b - 4) * 64 + (uint32_t)j * 8;
 }
 
 // ===================================================================== host half: the packer
@@ -86,16 +105,17 @@ struct RcGeom {
     uint64_t frame_stride, rgba_stride;
 };
 
-// One stream's device table: [position = col*8+row][class: 0 intra, 1 non-intra]{matrix entry, premultiplier}
+// One stream's device table (kRcQtabStride bytes, kRcQtabBytes used): [position = col*8+row]{intra, non-intra matrix
+// entry}, then [position] premultiplier
 static inline void rc_make_qtable(uint8_t out[256], const uint8_t intra[64], const uint8_t non_intra[64], const uint8_t premult[64])
 {
+    memset(out, 0, kRcQtabStride);
     for (int c = 0; c < 8; c++)
-        for (int r = 0; r < 8; r++)
-            for (int cls = 0; cls < 2; cls++) {
-                uint8_t *e = out + ((c * 8 + r) * 2 + cls) * 2;
-                e[0] = (cls ? non_intra : intra)[r * 8 + c];
-                e[1] = premult[r * 8 + c];
-            }
+        for (int r = 0; r < 8; r++) {
+            out[(c * 8 + r) * 2 + 0] = intra[r * 8 + c];
+            out[(c * 8 + r) * 2 + 1] = non_intra[r * 8 + c];
+            out[128 + c * 8 + r] = premult[r * 8 + c];
+        }
 }
 
 // Which of a unit's 64 int16 words are non-zero (bit k <=> word k).
@@ -125,7 +145,8 @@ static inline uint64_t rc_nonzero_mask(const uint8_t *unit)
 // Room one picture of n macroblocks with `units` coefficient units can need (dwords).
 static inline size_t rc_max_chunks(uint32_t n) { return ((size_t)n + kRcMbs - 1) / kRcMbs; }
 static inline size_t rc_max_words(uint64_t units) { return (size_t)units * 65; }
-constexpr size_t kRcWordsPad = 128; // dwords behind the last chunk's words that a wave may read (and ignore)
+constexpr size_t kRcWordsPad = 256; // dwords behind the last chunk's words that a wave may read (and ignore)
+constexpr size_t kRcQtabPad = 1024;  // bytes behind the last stream's table that a wave may read (and ignore)
 
 struct RcPacked {
     uint32_t chunks = 0, words = 0; // what the picture took
@@ -178,10 +199,12 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 d0 |= (cmy & 1) ? kROvC : 0;
                 const int32_t dst_luma = (int32_t)((uint32_t)mb.mb_y << 4) * (int32_t)g.luma_w + (int32_t)((uint32_t)mb.mb_x << 4);
                 const int32_t dst_chroma = (int32_t)((uint32_t)mb.mb_y << 3) * (int32_t)g.chroma_w + (int32_t)((uint32_t)mb.mb_x << 3);
-                d[0] = d0;
+                const uint32_t src_luma = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
+                const uint32_t src_chroma = g.luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)g.chroma_w + (cmx >> 1));
+                d[0] = d0 | ((src_luma & 3) << 6) | ((src_chroma & 3) << 14); // (frames and planes start on 64-byte boundaries)
                 d[1] = (mb.flags & MPEGHIP_MB_REF_BWD) ? bwd256 : fwd256;
-                d[2] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
-                d[3] = g.luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)g.chroma_w + (cmx >> 1));
+                d[2] = src_luma & ~3u;
+                d[3] = src_chroma & ~3u;
             }
             run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
                   (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
@@ -196,7 +219,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 s.raw = raw;
                 s.mask = raw ? 0 : rc_nonzero_mask(s.unit);
                 s.dense = !raw && (uint32_t)__builtin_popcountll(s.mask) > kDenseAbove;
-                bw[n_slots] = rc_tile_offset(b, 0, m) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
+                bw[n_slots] = (rc_tile_offset(b, 0, m) >> 3) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
                 if (s.dense)
                     bw[n_slots] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
                 unit += raw ? 2 : 1;
@@ -230,13 +253,13 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             for (uint32_t s = 0; s < n_slots; s++)
                 if (slot[s].raw || slot[s].dense) { // the unit(s) as they are (position order = the unit's order)
                     const uint32_t dwords = slot[s].raw ? 64 : 32;
-                    bw[s] |= ne << 14;
+                    bw[s] |= ne << 12;
                     memcpy(e0 + ne, slot[s].unit, dwords * 4);
                     ne += dwords;
                 }
         h[0] = cur256;
         h[1] = rgba256;
-        h[2] = p.stream * 256;
+        h[2] = p.stream * kRcQtabStride;
         h[3] = word_base + out.words;
         h[4] = word_base + out.words + n_slots;
         h[5] = counts | (run ? kCRun : 0u) | (rgba ? kCRgba : 0u);
@@ -285,75 +308,55 @@ MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[6] >> 8) & 0xff; }
 MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[6] >> 16) & 1; }
 MPG_HD bool rc_any_dense(const RcChunk &c) { return (c.h[6] >> 17) & 1; }
 MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[5] >> (10 * pass)) & 0x3ff; }
+MPG_HD uint32_t rc_shift_luma(uint32_t d0) { return (d0 >> 6) & 3; }
+MPG_HD uint32_t rc_shift_chroma(uint32_t d0) { return (d0 >> 14) & 3; }
 
 // what depends on the lane only (worked out once per wave)
 struct RcLane {
-    uint32_t luma_off;    // prediction / MC lane (row lane>>2, quarter lane&3): byte offset inside a 16-row luma window
-    uint32_t chroma_off;  // lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1): offset from the Cb window
-    uint32_t tile_luma;   // where the lane's 4 luma bytes of macroblock 0 sit in O (+ 16 per macroblock)
-    uint32_t tile_chroma; //                  4 chroma bytes                       (+ 8 per macroblock)
+    uint32_t piece_off;   // as lane of a window load (piece `lane` < 52): byte offset from the luma / Cb window origin
+    uint32_t piece_chroma; // all ones if that piece is chroma, else 0
+    uint32_t mc_luma;     // as MC lane (row lane>>2, quarter lane&3): LDS offset of its taps inside a window = (lane>>2)*32 + (lane&3)*4
+    uint32_t mc_chroma;   // lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1): kRcWinLuma + (plane*9 + row)*16 + half*4
+    uint32_t out_luma;    // where the lane's 4 luma bytes go inside O_m: lane * 4
+    uint32_t out_chroma;  // 4 chroma bytes: 256 + lane * 4
 };
 
 MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
 {
     const uint32_t l = (uint32_t)lane;
     RcLane k;
-    k.luma_off = (l >> 2) * a.luma_w + (l & 3) * 4;
-    k.chroma_off = ((l >> 4) & 1) * a.chroma_bytes + ((l >> 1) & 7) * a.chroma_w + (l & 1) * 4;
-    k.tile_luma = (l >> 2) * 64 + (l & 3) * 4;
-    k.tile_chroma = 1024 + ((l >> 4) & 1) * 256 + ((l >> 1) & 7) * 32 + (l & 1) * 4;
+    // piece l of a window: luma 17 rows x 2 pieces, then Cb, Cr with 9 rows x 1 piece each
+    const bool chroma = l >= 34;
+    const uint32_t ci = l - 34, plane = ci >= 9 ? 1u : 0u;
+    k.piece_chroma = chroma ? ~0u : 0u;
+    k.piece_off = chroma ? plane * a.chroma_bytes + (ci - plane * 9) * a.chroma_w : (l >> 1) * a.luma_w + (l & 1) * kRcPiece;
+    k.mc_luma = (l >> 2) * 32 + (l & 3) * 4;
+    k.mc_chroma = kRcWinLuma + (((l >> 4) & 1) * 9 + ((l >> 1) & 7)) * kRcPiece + (l & 1) * 4;
+    k.out_luma = l * 4;
+    k.out_chroma = 256 + l * 4;
     return k;
 }
 
-MPG_HD bool rc_luma_last_row(int lane) { return lane >= 60; }
-MPG_HD bool rc_chroma_last_row(int lane) { return (((uint32_t)lane >> 1) & 7) == 7; }
-
 // ---- step 1: the vector loads
-MPG_HD uint32_t rc_load_qtab(const VideoArgs &a, const RcChunk &c, int lane)
+MPG_HD const uint32_t *rc_ent_src(const VideoArgs &a, const RcChunk &c, uint32_t at, int lane)
 {
-    return *reinterpret_cast<const uint32_t *>(a.qmat + c.h[2] + (uint32_t)lane * 4);
+    return a.words + c.h[4] + at + (uint32_t)lane; // (beyond the pass's entries: ignored; the array is padded)
 }
-MPG_HD uint32_t rc_load_blk(const VideoArgs &a, const RcChunk &c, uint32_t pass, int lane)
+// The six direct-to-LDS loads of a wave, issued by lanes 0..51 in this order: the table (12 pieces), the chunk's 24
+// block words (6 pieces), windows 0..3 (52 pieces each).  All 52 lanes take part in every one of them (one asm
+// statement, one EXEC): the table's and the block words' surplus lanes fetch 16 bytes that a LATER load of the same
+// wave overwrites — loads complete in order (tools/microbench/lds_dma_probe3.hip) and the
+// windows cover [kRcWinAt, kRcTileAt) completely.  Surplus lanes read valid memory: the table's run on into the
+// next streams' tables (the table array is padded by 1 KB), the block words' into the words array (padded).
+MPG_HD const uint8_t *rc_table_src(const VideoArgs &a, const RcChunk &c) { return a.qmat + c.h[2]; }
+MPG_HD const uint8_t *rc_blk_src(const VideoArgs &a, const RcChunk &c) { return reinterpret_cast<const uint8_t *>(a.words + c.h[3]); }
+// window m (lanes 0..51): scalar base = the reference frame, lane offset = window origin (luma or Cb) + piece.
+// (Intra / dead macroblocks name the head of the frame store as their window: valid memory, never used.)
+// No select between the two scalars: the compiler turns those into indexed loads from scratch.
+MPG_HD const uint8_t *rc_win_base(const VideoArgs &a, const RcChunk &c, int m) { return a.frames + ((uint64_t)c.r[m][1] << 8); }
+MPG_HD uint32_t rc_win_offset(const RcChunk &c, int m, const RcLane &k)
 {
-    return a.words[c.h[3] + pass * 8 + ((uint32_t)lane >> 3)]; // (beyond the chunk's blocks: ignored; the array is padded)
-}
-MPG_HD uint32_t rc_load_ent(const VideoArgs &a, const RcChunk &c, uint32_t at, int lane)
-{
-    return a.words[c.h[4] + at + (uint32_t)lane]; // (beyond the pass's entries: ignored; the array is padded)
-}
-
-struct RcPred {
-    uint32_t l0, l1;   // luma: bytes 4q .. 4q+7 of the lane's row
-    uint32_t lx0, lx1; // row 16 of the luma window (lanes 60..63, vertically odd vectors only)
-    uint32_t c0, c1;   // chroma: 8 bytes (lanes 0..31)
-    uint32_t cx0, cx1; // row 8 of the chroma windows (the lanes of row 7)
-};
-
-MPG_HD const uint8_t *rc_ref(const VideoArgs &a, const RcChunk &c, int m) { return a.frames + ((uint64_t)c.r[m][1] << 8); }
-
-MPG_HD void rc_pred_luma(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p)
-{
-    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][2] + k.luma_off);
-    p.l0 = (uint32_t)v;
-    p.l1 = (uint32_t)(v >> 32);
-}
-MPG_HD void rc_pred_chroma(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p) // lanes 0..31
-{
-    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][3] + k.chroma_off);
-    p.c0 = (uint32_t)v;
-    p.c1 = (uint32_t)(v >> 32);
-}
-MPG_HD void rc_pred_luma_extra(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p) // lanes 60..63, kROvL
-{
-    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][2] + k.luma_off + a.luma_w);
-    p.lx0 = (uint32_t)v;
-    p.lx1 = (uint32_t)(v >> 32);
-}
-MPG_HD void rc_pred_chroma_extra(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, RcPred &p) // row-7 lanes, kROvC
-{
-    const uint64_t v = ld64u(rc_ref(a, c, m) + c.r[m][3] + k.chroma_off + a.chroma_w);
-    p.cx0 = (uint32_t)v;
-    p.cx1 = (uint32_t)(v >> 32);
+    return c.r[m][2] + (k.piece_chroma & (c.r[m][3] - c.r[m][2])) + k.piece_off;
 }
 
 // ---- step 2: the residual pass
@@ -365,20 +368,27 @@ MPG_HD void rc_zero_tile(int32_t *T, int lane)
     t[1] = z;
 }
 
-// one entry: dequantise + premultiply (video.go:719-744; intra DC video.go:672), scatter to T[slot & 7][position]
-MPG_HD void rc_scatter(int32_t *T, const uint8_t *Q, uint32_t e)
+MPG_HD uint32_t rc_blk_word(const uint8_t *lds, uint32_t pass, int lane) // lane (g, j): the word of the pass's block g
 {
-    const uint32_t tq = *reinterpret_cast<const uint16_t *>(Q + (e & 0xfeu)); // [position][class]{matrix, premultiplier}
+    return *reinterpret_cast<const uint32_t *>(lds + kRcBlkAt + (pass * 8 + ((uint32_t)lane >> 3)) * 4);
+}
+
+// one entry: dequantise + premultiply (video.go:719-744; intra DC video.go:672), scatter to T[slot & 7][position]
+MPG_HD void rc_scatter(int32_t *T, const uint8_t *lds, uint32_t e)
+{
+    const uint8_t *Q = lds + kRcQtabAt;
+    const int32_t qm = Q[(e & 0xfeu) >> 1];         // [position][class]
+    const int32_t pm = Q[128 + ((e >> 2) & 63)];    // [position]
     const int32_t level = (int32_t)e >> 16;
     const int32_t qs = (int32_t)((e >> 11) & 31);
-    const int32_t dq = dequant(level, !(e & kENonIntra), qs * (int32_t)(tq & 0xff), (int32_t)(tq >> 8));
+    const int32_t dq = dequant(level, !(e & kENonIntra), qs * qm, pm);
     T[(e & 0x7fcu) >> 2] = (e & kEDc) ? level * 256 : dq;
 }
 
 // an int32 snapshot block: its 64 values as they are, lane = position
 MPG_HD void rc_raw_fill(const VideoArgs &a, const RcChunk &c, int32_t *T, uint32_t g, uint32_t bw, int lane)
 {
-    T[g * 64 + (uint32_t)lane] = (int32_t)a.words[c.h[4] + ((bw >> 14) & 0xfffu) + (uint32_t)lane];
+    T[g * 64 + (uint32_t)lane] = (int32_t)a.words[c.h[4] + ((bw >> 12) & 0xfffu) + (uint32_t)lane];
 }
 
 // lane (g, j) = column j of the pass's block g, then row j
@@ -392,16 +402,18 @@ MPG_HD void rc_cols_load(const int32_t *T, int lane, int32_t (&v)[8])
         v[r + 4] = t1.v[r];
     }
 }
+
 // a dense block: lane (g, j) takes column j straight from the unit — one 16-byte load, 8 levels dequantised in
 // place of the tile read.  Rows that are empty in every dense lane of the wave are skipped wave-wide.
 struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; };
-MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *Q, uint32_t bw, int lane, int32_t (&v)[8])
+MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *lds, uint32_t bw, int lane, int32_t (&v)[8])
 {
     const uint32_t j = (uint32_t)lane & 7;
-    const i32x4_a4 lv = *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 14) & 0xfffu) + j * 4);
+    const i32x4_a4 lv = *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + j * 4);
     const int32_t qs = (int32_t)((bw >> 26) & 31);
     const bool intra = !(bw >> 31);
-    const uint8_t *q = Q + j * 32 + (intra ? 0 : 2); // [position = j * 8 + r][class]{matrix, premultiplier}
+    const uint8_t *Q = lds + kRcQtabAt;
+    const uint8_t *qm = Q + j * 16 + (intra ? 0 : 1), *pm = Q + 128 + j * 8; // position = j * 8 + r
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int32_t w = lv.v[r >> 1];
@@ -410,8 +422,7 @@ MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *Q
             v[r] = 0;
             continue;
         }
-        const uint32_t tq = *reinterpret_cast<const uint16_t *>(q + r * 4);
-        const int32_t d = dequant(level, intra, qs * (int32_t)(tq & 0xff), (int32_t)(tq >> 8));
+        const int32_t d = dequant(level, intra, qs * (int32_t)qm[r * 2], (int32_t)pm[r]);
         v[r] = level ? d : 0;
     }
     if (intra && j == 0)
@@ -427,24 +438,29 @@ MPG_HD void rc_cols_store(int32_t *T, int lane, const int32_t (&v)[8])
 }
 MPG_HD void rc_rows_load(const int32_t *T, int lane, int32_t (&v)[8]) { rc_cols_load(T, lane, v); } // T[g][j * 8 + c] now
 
-// ---- step 3: motion compensation of 4 pixels (video_noasm.go:48-80); oh / ov are wave-uniform
-// a0 a1: the 8 bytes at the pixels' position, b0 b1: the 8 bytes one row below
-MPG_HD uint32_t rc_mc4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, bool oh, bool ov)
+// ---- step 3: motion compensation of 4 pixels (video_noasm.go:48-80); shift / oh / ov are wave-uniform.
+// `taps` -> the two aligned dwords that hold the pixels (they start `shift` bytes in) and their right neighbour;
+// the same one row below is `below` bytes further on.
+MPG_HD uint32_t rc_mc4(const uint8_t *taps, uint32_t below, uint32_t shift, bool oh, bool ov)
 {
+    const uint32_t *t = reinterpret_cast<const uint32_t *>(taps);
+    const uint64_t a = (uint64_t)t[0] | ((uint64_t)t[1] << 32); // (dword-aligned, not 8-byte aligned: two 4-byte reads)
+    const uint32_t p00 = (uint32_t)(a >> (8 * shift));
     if (!oh && !ov)
-        return a0;
-    if (!oh)
-        return avg_ceil_u8x4(a0, b0);
-    const uint32_t as = shift_in_byte(a1, a0);
+        return p00;
     if (!ov)
-        return avg_ceil_u8x4(a0, as);
-    return avg4_u8x4(a0, as, b0, shift_in_byte(b1, b0));
+        return avg_ceil_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)));
+    const uint32_t *u = reinterpret_cast<const uint32_t *>(taps + below);
+    const uint64_t b = (uint64_t)u[0] | ((uint64_t)u[1] << 32);
+    if (!oh)
+        return avg_ceil_u8x4(p00, (uint32_t)(b >> (8 * shift)));
+    return avg4_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)), (uint32_t)(b >> (8 * shift)), (uint32_t)(b >> (8 * shift + 8)));
 }
 
-// ---- step 4: residual row + the 8 prediction bytes in O -> clamped bytes (video.go:943-971)
-MPG_HD void rc_rmw(uint8_t *O, uint32_t bw, int lane, const int32_t (&v)[8])
+// ---- step 4: residual row + the 8 prediction bytes in O_m -> clamped bytes (video.go:943-971)
+MPG_HD void rc_rmw(uint8_t *lds, uint32_t bw, int lane, const int32_t (&v)[8])
 {
-    uint8_t *p = O + (bw & 0x7ffu) + ((uint32_t)lane & 7) * ((bw & kBChroma) ? 32u : 64u);
+    uint8_t *p = lds + ((bw << 3) & 0xff8u) + ((uint32_t)lane & 7) * ((bw & kBChroma) ? 8u : 16u);
     const uint64_t pred = *reinterpret_cast<const uint64_t *>(p);
     *reinterpret_cast<uint64_t *>(p) = add_clamp_pack8(pred, v);
 }
@@ -457,57 +473,62 @@ MPG_HD uint32_t rc_dst_chroma(const VideoArgs &a, uint32_t d0)
     return a.luma_bytes + ((d0 >> 24) << 3) * a.chroma_w + (((d0 >> 16) & 0xff) << 3);
 }
 
-// horizontal run: luma 16 rows x 64 bytes by all 64 lanes, chroma 2 x 8 rows x 32 bytes by lanes 0..31
-MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const RcLane &k, const uint8_t *O)
+// horizontal run: luma 16 rows x 64 bytes by all 64 lanes (row lane>>2, macroblock lane&3), chroma 2 x 8 rows x
+// 32 bytes by lanes 0..31 (plane lane>>4, row (lane>>1)&7, macroblocks 2*(lane&1) and 2*(lane&1)+1)
+MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
 {
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8);
     const uint32_t l = (uint32_t)lane;
     {
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(O + l * 16); // row l>>2, 16-byte segment l&3
-        *reinterpret_cast<u32x4 *>(cur + rc_dst_luma(a, c.r[0][0]) + k.luma_off + (l & 3) * 12) = v;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l & 3) + (l >> 2) * 16);
+        *reinterpret_cast<u32x4 *>(cur + rc_dst_luma(a, c.r[0][0]) + (l >> 2) * a.luma_w + (l & 3) * 16) = v;
     }
     if (lane < 32) {
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(O + 1024 + l * 16); // plane l>>4, row (l>>1)&7, segment l&1
-        *reinterpret_cast<u32x4 *>(cur + rc_dst_chroma(a, c.r[0][0]) + k.chroma_off + (l & 1) * 12) = v;
+        const uint32_t plane = l >> 4, row = (l >> 1) & 7, m = (l & 1) * 2;
+        const uint64_t lo = *reinterpret_cast<const uint64_t *>(lds + rc_win_at(m) + 256 + plane * 64 + row * 8);
+        const uint64_t hi = *reinterpret_cast<const uint64_t *>(lds + rc_win_at(m + 1) + 256 + plane * 64 + row * 8);
+        const u32x4 v = {{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)}};
+        *reinterpret_cast<u32x4 *>(cur + rc_dst_chroma(a, c.r[0][0]) + plane * a.chroma_bytes + row * a.chroma_w + (l & 1) * 16) = v;
     }
 }
 
 // any other chunk: macroblock m by lanes (block b = lane>>3, row j = lane&7), 8 bytes each.  An invalid intra
-// block keeps the frame's pixels (video.go:711-714); with `mirror` its bytes are parked in O instead, so that
+// block keeps the frame's pixels (video.go:711-714); with `mirror` its bytes are parked in O_m instead, so that
 // the colour conversion sees what the planes hold.
-MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, uint8_t *O, bool mirror)
+MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, uint8_t *lds, bool mirror)
 {
     const int b = lane >> 3, j = lane & 7;
     if (b >= 6)
         return;
     const uint32_t d0 = c.r[m][0];
-    const bool written = !(d0 & kRIntra) || ((d0 >> 8) & (0x20u >> b)) != 0;
+    const bool written = !(d0 & kRIntra) || ((d0 >> 8) & 0x3f & (0x20u >> b)) != 0;
     uint32_t off;
     if (b < 4)
         off = rc_dst_luma(a, d0) + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * a.luma_w + ((uint32_t)(b & 1) << 3);
     else
         off = rc_dst_chroma(a, d0) + (uint32_t)(b - 4) * a.chroma_bytes + (uint32_t)j * a.chroma_w;
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + off;
-    uint8_t *t = O + rc_tile_offset(b, j, m);
+    uint8_t *t = lds + rc_tile_offset(b, j, m);
     if (written)
         *reinterpret_cast<uint64_t *>(cur) = *reinterpret_cast<const uint64_t *>(t);
     else if (mirror)
         *reinterpret_cast<uint64_t *>(t) = *reinterpret_cast<const uint64_t *>(cur);
 }
 
-// Frame.RGBA fused (pictures flagged MPEGHIP_PIC_RGBA): macroblock m from O, 4 pixels per lane (lane = row*4 +
+// Frame.RGBA fused (pictures flagged MPEGHIP_PIC_RGBA): macroblock m from O_m, 4 pixels per lane (lane = row*4 +
 // segment), one 16-byte store each — a macroblock row is 64 contiguous bytes of the image.  Pixels outside
 // width x height are not stored.
-MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *O)
+MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *lds)
 {
     const uint32_t d0 = c.r[m][0];
     const uint32_t row = (uint32_t)lane >> 2, seg = (uint32_t)lane & 3;
     const uint32_t py = ((d0 >> 24) << 4) + row, px0 = (((d0 >> 16) & 0xff) << 4) + seg * 4;
     if (py >= a.height || px0 >= a.width)
         return;
-    const uint32_t yy = *reinterpret_cast<const uint32_t *>(O + row * 64 + m * 16 + seg * 4);
-    const uint32_t cb = *reinterpret_cast<const uint16_t *>(O + 1024 + (row >> 1) * 32 + m * 8 + seg * 2);
-    const uint32_t cr = *reinterpret_cast<const uint16_t *>(O + 1280 + (row >> 1) * 32 + m * 8 + seg * 2);
+    const uint8_t *O = lds + rc_win_at(m);
+    const uint32_t yy = *reinterpret_cast<const uint32_t *>(O + row * 16 + seg * 4);
+    const uint32_t cb = *reinterpret_cast<const uint16_t *>(O + 256 + (row >> 1) * 8 + seg * 2);
+    const uint32_t cr = *reinterpret_cast<const uint16_t *>(O + 320 + (row >> 1) * 8 + seg * 2);
     uint32_t px[4];
     rgba_row4(yy, chroma_terms(cb & 0xff, cr & 0xff), chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff), px);
     const uint64_t p = (uint64_t)py * a.width + px0;

@@ -77,7 +77,7 @@ class EmuStore:
         self.frames = np.zeros(self.stride * 3 * n_streams, np.uint8)
         self.rgba_stride = (width * height * 4 + 255) // 256 * 256
         self.rgba = np.zeros(self.rgba_stride * 3 * n_streams, np.uint8)
-        self.qmat = np.zeros((n_streams, 256), np.uint8)
+        self.qmat = np.zeros((n_streams + 4, 256), np.uint8)   # (+ the padding the lanes may read, as on the device)
         for s in range(n_streams):
             self.qmat[s] = _qtable(synth.INTRA_Q, synth.NON_INTRA_Q)
         self._rgba_init = False

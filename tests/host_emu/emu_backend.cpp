@@ -67,7 +67,7 @@ private:
     uint32_t w_ = 0, h_ = 0, lw_ = 0, lh_ = 0;
     size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0;
     std::vector<uint8_t> frames_, rgba_, dump_;
-    alignas(16) uint8_t qt_[256]; // (the lanes read it in 16-byte pieces, as the device does from its 256-byte aligned table)
+    alignas(16) uint8_t qt_[256 + 1024] = {}; // (+ the padding surplus lanes of the table load may read, as on the device)
 };
 
 // multi-stream store over the wave-chunk lane emulator (what HipBatchStore is over libmpeghip)
@@ -86,7 +86,7 @@ public:
         frames_.assign(stride_ * 3 * n_streams + 4096, 0);
         rgba_stride_ = ((size_t)w_ * h_ * 4 + 255) / 256 * 256;
         rgba_.assign(rgba_stride_ * 3 * n_streams, 0);
-        qt_store_.assign((size_t)256 * n_streams + 16, 0);
+        qt_store_.assign((size_t)256 * n_streams + 16 + 1024, 0);
         qt_ = qt_store_.data() + (16 - reinterpret_cast<uintptr_t>(qt_store_.data()) % 16) % 16; // 16-byte aligned, as on the device
     }
     void setQuant(uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64]) override

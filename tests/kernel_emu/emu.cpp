@@ -84,111 +84,108 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     alignas(16) static uint8_t lds[kRcLdsBytes];
     for (uint32_t chunk = 0; chunk < nc; chunk++) {
         memset(lds, 0xCD, sizeof(lds)); // poison: reads of unwritten LDS must not matter
-        int32_t *T = reinterpret_cast<int32_t *>(lds);
-        uint8_t *O = lds + kRcTileBytes, *Q = O + kRcOutBytes;
+        int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
         const RcChunk c = rc_load_chunk(a, chunk);
         const uint32_t n_blocks = rc_n_blocks(c);
         RcLane k[64];
-        uint32_t qdw[64], bw[64], e[64];
-        static RcPred p[kRcMbs][64];
-        memset(p, 0, sizeof(p));
+        uint32_t bw[64], e[64];
         for (int lane = 0; lane < 64; lane++) {
             k[lane] = rc_lane(a, lane);
-            qdw[lane] = rc_load_qtab(a, c, lane);
-            bw[lane] = rc_load_blk(a, c, 0, lane);
-            e[lane] = rc_load_ent(a, c, 0, lane);
-            for (int m = 0; m < kRcMbs; m++) {
-                if (rc_luma_last_row(lane) && (c.r[m][0] & kROvL))
-                    rc_pred_luma_extra(a, c, m, k[lane], p[m][lane]);
-                if (lane < 32 && rc_chroma_last_row(lane) && (c.r[m][0] & kROvC))
-                    rc_pred_chroma_extra(a, c, m, k[lane], p[m][lane]);
-                rc_pred_luma(a, c, m, k[lane], p[m][lane]);
-                if (lane < 32)
-                    rc_pred_chroma(a, c, m, k[lane], p[m][lane]);
-            }
+            e[lane] = load32_uncounted(rc_ent_src(a, c, 0, lane));
         }
-        for (int lane = 0; lane < 64; lane++)
-            memcpy(Q + lane * 4, &qdw[lane], 4);
+        for (int i = 0; i < 6; i++) // (load by load, as they complete on the device: later loads overwrite the surplus lanes)
+            for (int lane = 0; lane < kRcWinLanes; lane++) {
+                const uint8_t *const src[6] = {rc_table_src(a, c), rc_blk_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1),
+                                               rc_win_base(a, c, 2), rc_win_base(a, c, 3)};
+                const uint32_t off[6] = {(uint32_t)lane * 16, (uint32_t)lane * 16, rc_win_offset(c, 0, k[lane]),
+                                         rc_win_offset(c, 1, k[lane]), rc_win_offset(c, 2, k[lane]), rc_win_offset(c, 3, k[lane])};
+                const int at[6] = {kRcQtabAt, kRcBlkAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes};
+                memcpy(lds + at[i] + 16 * lane, src[i] + off[i], 16);
+            }
         static int32_t v[64][8];
         uint32_t ent_at = 0;
-        for (uint32_t pass = 0;; pass++) {
-            const bool work = pass * 8 < n_blocks;
-            if (work) {
-                const uint32_t np = rc_pass_entries(c, pass);
-                for (int lane = 0; lane < 64; lane++) {
-                    rc_zero_tile(T, lane);
-                    if (pass > 0)
-                        bw[lane] = rc_load_blk(a, c, pass, lane);
-                }
-                for (uint32_t r = 0; r < np; r += 64)
-                    for (int lane = 0; lane < 64; lane++) {
-                        if (pass > 0 || r > 0)
-                            e[lane] = rc_load_ent(a, c, ent_at + r, lane);
-                        if (r + (uint32_t)lane < np)
-                            rc_scatter(T, Q, e[lane]);
-                    }
-                ent_at += np;
-                if (rc_any_raw(c))
-                    for (uint32_t g = 0; g < 8; g++) {
-                        const uint32_t bwg = bw[g * 8]; // the kernel's v_readlane
-                        if (pass * 8 + g < n_blocks && (bwg & kBRaw))
-                            for (int lane = 0; lane < 64; lane++)
-                                rc_raw_fill(a, c, T, g, bwg, lane);
-                    }
-                for (int lane = 0; lane < 64; lane++) {
-                    rc_cols_load(T, lane, v[lane]);
-                    if (rc_any_dense(c) && pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw[lane] & kBDense))
-                        rc_dense_cols(a, c, Q, bw[lane], lane, v[lane]);
-                    idct8<false>(v[lane]);
-                }
-                for (int lane = 0; lane < 64; lane++) // (in place: only after every lane has read its column)
-                    rc_cols_store(T, lane, v[lane]);
-                for (int lane = 0; lane < 64; lane++) {
-                    rc_rows_load(T, lane, v[lane]);
-                    idct8<true>(v[lane]);
-                }
+        auto residual_pass = [&](uint32_t pass) {
+            const uint32_t np = rc_pass_entries(c, pass);
+            for (int lane = 0; lane < 64; lane++) {
+                rc_zero_tile(T, lane);
+                bw[lane] = rc_blk_word(lds, pass, lane);
             }
-            if (pass == 0) {
-                for (int m = 0; m < kRcMbs; m++) {
-                    const uint32_t d0 = c.r[m][0];
-                    if (d0 & kRDead)
-                        continue;
-                    for (int lane = 0; lane < 64; lane++) {
-                        uint32_t yl = 0, yc = 0;
-                        if (!(d0 & kRIntra)) {
-                            const RcPred &me = p[m][lane], &bl = p[m][(lane + 4) & 63], &bc = p[m][(lane + 2) & 63]; // ds_bpermute
-                            const bool last_l = rc_luma_last_row(lane), last_c = rc_chroma_last_row(lane);
-                            yl = rc_mc4(me.l0, me.l1, last_l ? me.lx0 : bl.l0, last_l ? me.lx1 : bl.l1, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
-                            yc = rc_mc4(me.c0, me.c1, last_c ? me.cx0 : bc.c0, last_c ? me.cx1 : bc.c1, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
-                        }
-                        memcpy(O + k[lane].tile_luma + m * 16, &yl, 4);
-                        if (lane < 32)
-                            memcpy(O + k[lane].tile_chroma + m * 8, &yc, 4);
-                    }
+            for (uint32_t r = 0; r < np; r += 64)
+                for (int lane = 0; lane < 64; lane++) {
+                    if (pass > 0 || r > 0)
+                        e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
+                    if (r + (uint32_t)lane < np)
+                        rc_scatter(T, lds, e[lane]);
                 }
+            ent_at += np;
+            if (rc_any_raw(c))
+                for (uint32_t g = 0; g < 8; g++) {
+                    const uint32_t bwg = bw[g * 8]; // the kernel's v_readlane
+                    if (pass * 8 + g < n_blocks && (bwg & kBRaw))
+                        for (int lane = 0; lane < 64; lane++)
+                            rc_raw_fill(a, c, T, g, bwg, lane);
+                }
+            for (int lane = 0; lane < 64; lane++) {
+                rc_cols_load(T, lane, v[lane]);
+                if (rc_any_dense(c) && pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw[lane] & kBDense))
+                    rc_dense_cols(a, c, lds, bw[lane], lane, v[lane]);
+                idct8<false>(v[lane]);
             }
-            if (!work)
-                break;
+            for (int lane = 0; lane < 64; lane++) // (in place: only after every lane has read its column)
+                rc_cols_store(T, lane, v[lane]);
+            for (int lane = 0; lane < 64; lane++) {
+                rc_rows_load(T, lane, v[lane]);
+                idct8<true>(v[lane]);
+            }
+        };
+        auto add_residual = [&](uint32_t pass) {
             for (int lane = 0; lane < 64; lane++)
                 if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks)
-                    rc_rmw(O, bw[lane], lane, v[lane]);
-            if ((pass + 1) * 8 >= n_blocks)
-                break;
+                    rc_rmw(lds, bw[lane], lane, v[lane]);
+        };
+        if (n_blocks)
+            residual_pass(0);
+        for (int m = 0; m < kRcMbs; m++) {
+            const uint32_t d0 = c.r[m][0];
+            if (d0 & kRDead)
+                continue;
+            uint8_t *win = lds + rc_win_at(m);
+            uint32_t yl[64], yc[64];
+            for (int lane = 0; lane < 64; lane++) {
+                yl[lane] = yc[lane] = 0;
+                if (!(d0 & kRIntra)) {
+                    yl[lane] = rc_mc4(win + k[lane].mc_luma, 2 * kRcPiece, rc_shift_luma(d0), (d0 & kROhL) != 0, (d0 & kROvL) != 0);
+                    if (lane < 32)
+                        yc[lane] = rc_mc4(win + k[lane].mc_chroma, kRcPiece, rc_shift_chroma(d0), (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+                }
+            }
+            for (int lane = 0; lane < 64; lane++) { // (over the window: only after every lane has its taps)
+                memcpy(win + k[lane].out_luma, &yl[lane], 4);
+                if (lane < 32)
+                    memcpy(win + k[lane].out_chroma, &yc[lane], 4);
+            }
+        }
+        if (n_blocks) {
+            add_residual(0);
+            for (uint32_t pass = 1; pass * 8 < n_blocks; pass++) {
+                residual_pass(pass);
+                add_residual(pass);
+            }
         }
         const bool run = (c.h[5] & kCRun) != 0, rgba_on = any_rgba && (c.h[5] & kCRgba) != 0;
         const uint32_t n_live = rc_n_live(c);
         if (run) {
             for (int lane = 0; lane < 64; lane++)
-                rc_store_run(a, c, lane, k[lane], O);
+                rc_store_run(a, c, lane, lds);
         } else {
             for (uint32_t m = 0; m < n_live; m++)
                 for (int lane = 0; lane < 64; lane++)
-                    rc_store_mb(a, c, m, lane, O, rgba_on);
+                    rc_store_mb(a, c, m, lane, lds, rgba_on);
         }
         if (rgba_on)
             for (uint32_t m = 0; m < n_live; m++)
                 for (int lane = 0; lane < 64; lane++)
-                    rc_rgba_mb(a, c, m, lane, O);
+                    rc_rgba_mb(a, c, m, lane, lds);
     }
     return 0;
 }

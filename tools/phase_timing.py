@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a wave of recon_wc_kernel spends its wall time (development aid).  Needs the instrumented build
+"""Where a wave of recon_kernel spends its wall time (development aid).  Needs the instrumented build
     hipcc <flags of mpeg_amd/_build.py> -DMPG_PHASE_TIMING mpeg_amd/csrc/mpeghip.hip -o mpeg_amd/libmpeghip_timing.so
 (s_memtime stamps per phase, written by lane 0 of the first 60000 chunks; tools/gpu_phase_timing.sh builds it):
 swaps it in for this process, runs pictures for 64 streams, prints per-phase medians."""
@@ -42,20 +42,21 @@ try:
     n = 60000
     buf = np.zeros((n, 8), np.uint64)
     L.mpeghip_debug_read_dump(store.h, buf.ctypes.data, buf.nbytes)
-    t = buf[:, :6].astype(np.int64)
-    ok = (t[:, 5] > t[:, 0]) & (t[:, 0] > 0)
-    t, total = t[ok], buf[ok, 6]
+    t = buf[:, :7].astype(np.int64)
+    ok = (t[:, 6] > t[:, 0]) & (t[:, 0] > 0)
+    t, total = t[ok], buf[ok, 7]
     d = np.diff(t, axis=1)
-    names = ["chunk descriptors (scalar loads + prefix sums)", "macroblock descriptors + prediction load issue",
-             "phase 2: dequant + IDCT passes", "phase 3: prediction + residual, 4 macroblocks", "tile hand-off + stores"]
+    names = ["kernel arguments + chunk (scalar loads) arrived", "lane constants + every vector load issued",
+             "residual pass 0 (waits for the entries)", "motion compensation (waits for the prediction loads)",
+             "residual add (+ passes 1, 2)", "stores"]
     print("%s: %d waves sampled (last picture), s_memtime ticks (= shader clocks here: the median lifetime matches SQ_WAVE_CYCLES / SQ_WAVES)" % (profile, len(t)))
-    life = t[:, 5] - t[:, 0]
+    life = t[:, 6] - t[:, 0]
     print("  wave lifetime            median %7.0f  mean %7.0f" % (np.median(life), life.mean()))
     for k, nme in enumerate(names):
         print("  %-52s median %7.0f  mean %7.0f  (%4.1f %%)" % (nme, np.median(d[:, k]), d[:, k].mean(), 100 * d[:, k].mean() / life.mean()))
     for nb in (0, 4, 8, 9, 12, 16, 24):
         m = total == nb
         if m.sum() > 50:
-            print("  coded blocks = %2d: %6d waves, phase 2 mean %7.0f, lifetime mean %7.0f" % (nb, m.sum(), d[m, 2].mean(), life[m].mean()))
+            print("  coded blocks = %2d: %6d waves, residual pass 0 mean %7.0f, lifetime mean %7.0f" % (nb, m.sum(), d[m, 2].mean(), life[m].mean()))
 finally:
     swap_in("/tmp/libmpeghip_keep.so")
