@@ -2,7 +2,8 @@
 
 Streams share nothing: rank r decodes its own streams into its own frame store.
 torch.distributed is used only for the barrier around the timed region and for reducing the
-timings / unit counts to rank 0 (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+timings / unit counts to rank 0.  The backend is "gloo" everywhere — the north star asks for no RCCL, and a
+control plane of three scalars per run has no use for it ("nccl" still works if a caller asks for it)."""
 from __future__ import annotations
 
 import os
@@ -19,7 +20,7 @@ def shard_streams(total_streams: int, world: int, rank: int) -> range:
 class Ranks:
     """RANK / LOCAL_RANK / WORLD_SIZE from the launcher's environment; process group only if world > 1."""
 
-    def __init__(self, backend: str = "nccl", device_id=None):
+    def __init__(self, backend: str = "gloo", device_id=None):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -30,6 +31,7 @@ class Ranks:
             dist.init_process_group(backend, **kw)
             self.dist = dist
         self.backend = backend
+        self.last_local = 0.0   # this rank's own elapsed time of the last timed() body
 
     def barrier(self):
         if self.dist is not None:
@@ -61,8 +63,19 @@ class Ranks:
         t0 = time.perf_counter()
         body()
         device_sync()
+        self.last_local = time.perf_counter() - t0
         self.barrier()
         return self.max(time.perf_counter() - t0)
+
+    def gather(self, value: float) -> list:
+        """Every rank's `value`, in rank order (on every rank)."""
+        if self.dist is None:
+            return [value]
+        import torch
+        mine = self._tensor(value)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [float(t.item()) for t in out]
 
     def close(self):
         if self.dist is not None:

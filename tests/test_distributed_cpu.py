@@ -50,6 +50,8 @@ def _worker(rank, world, port, out):
         for slot in range(3):
             ok &= all(np.array_equal(a, b) for a, b in zip(ref.read_planes(0, slot), stores[s].read_planes(0, slot)))
     all_ok = ranks.sum(1.0 if ok else 0.0)
+    rates = ranks.gather(100.0 + rank)                          # per-rank values in rank order, as bench.py's per_rank_value
+    assert rates == [100.0, 101.0] and 0 < ranks.last_local <= elapsed
     out.put((rank, list(mine), elapsed, total_units, all_ok))
     ranks.close()
 
