@@ -300,7 +300,8 @@ def main():
     if args.host_fed_seconds > 0 and alone:
         threads = min(32, os.cpu_count() or 1)
         seq = prim["seq"]
-        pps = abi.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds)
+        from tools import hostbench
+        pps = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds)
         mb_per_pic = float(np.mean([len(s.mbs) for s in seq]))
         host_fed = {"metric": "1080p macroblocks/sec handed over by host threads (mpeghip_video_stage_*), PCIe inclusive",
                     "value": pps * mb_per_pic, "pictures_per_s": pps, "host_threads": threads, "pictures_per_call": 64,

@@ -1,0 +1,131 @@
+/*
+ * mpeghost.h — flat C API of libmpeghost, the host-side mirror of gen2brain/mpeg's Go API
+ * (bitstream parse on the CPU, reconstruction on the MI355X through libmpeghip, see mpeghip.h).
+ *
+ * The C++ classes of mpeg_amd/host/mpeg.hpp carry the reference's names (mpeg.MPEG, Video, Audio,
+ * Demux, Buffer: mpeg.go, video.go, audio.go, demux.go, buffer.go); this header is the same surface
+ * for callers that cannot include C++ — ctypes tests (tests/hostlib.py), cgo, other FFIs.
+ *
+ * Conventions: handles are opaque void *; functions that can fail return NULL / 0 / -1 and leave a
+ * message for the calling thread in mpeghost_last_error(); nothing throws across this boundary.
+ * Pointers returned by decode calls alias decoder-owned storage and stay valid until the next decode
+ * call on the same handle (as in the reference, mpeg.go:413-415, 435-437).
+ */
+#ifndef MPEGHOST_H
+#define MPEGHOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Frame (video.go:11-24): planes are host memory filled on demand from the device. */
+typedef struct mpeghost_frame {
+    double time;
+    int width, height;
+    int luma_w, luma_h, chroma_w, chroma_h;
+    const uint8_t *y, *cb, *cr;
+    size_t luma_bytes, chroma_bytes;
+} mpeghost_frame;
+
+const char *mpeghost_last_error(void);
+
+/* one GPU: a libmpeghip context (mpeghip_ctx_create) + what the decoders share on it */
+void *mpeghost_device_create(int ordinal);
+void mpeghost_device_destroy(void *device);
+
+/* ---- Video (video.go:110 NewVideo over a complete elementary stream, :209 Decode) */
+void *mpeghost_video_open(void *device, const uint8_t *data, size_t len);
+void *mpeghost_video_open_backend(void *backend, const uint8_t *data, size_t len); /* test backends; takes ownership */
+void mpeghost_video_close(void *video);
+int mpeghost_video_width(void *video);
+int mpeghost_video_height(void *video);
+double mpeghost_video_framerate(void *video);
+void mpeghost_video_set_no_delay(void *video, int no_delay);        /* video.go:178 */
+int mpeghost_video_decode(void *video, mpeghost_frame *out);         /* 1 frame, 0 none / end, -1 error */
+const uint8_t *mpeghost_video_rgba(void *video);                     /* Frame.RGBA() of the last decoded frame */
+void mpeghost_video_stats(void *video, uint64_t out[8]);
+
+/* ---- Audio (audio.go:83 NewAudio, :163 Decode); format: 0 F32N, 1 F32NLR, 2 F32, 3 S16 (audio.go:12-23) */
+void *mpeghost_audio_open(void *device, const uint8_t *data, size_t len, int fma_mode, int format);
+void *mpeghost_audio_open_backend(void *backend, const uint8_t *data, size_t len, int format);
+void mpeghost_audio_close(void *audio);
+int mpeghost_audio_samplerate(void *audio);
+int mpeghost_audio_channels(void *audio);
+const void *mpeghost_audio_decode(void *audio, double *time);        /* 2304 samples of the format, or NULL at the end */
+
+/* ---- MPEG (mpeg.go:85 New over a program stream, :356 Decode, :416 DecodeVideo, :438 DecodeAudio, :460/:524 seeks) */
+void *mpeghost_mpeg_open(void *device, const uint8_t *data, size_t len);
+void *mpeghost_mpeg_open_backends(void *(*make_video)(void), void *(*make_audio)(int), const uint8_t *data, size_t len);
+void mpeghost_mpeg_close(void *mpeg);
+void mpeghost_mpeg_info(void *mpeg, int out[6]); /* video streams, audio streams, width, height, samplerate, channels */
+double mpeghost_mpeg_framerate(void *mpeg);
+void mpeghost_mpeg_set_enabled(void *mpeg, int video, int audio);    /* mpeg.go:175, :250 */
+void mpeghost_mpeg_get_enabled(void *mpeg, int out[2]);              /* mpeg.go:170, :245 */
+void mpeghost_mpeg_set_audio_stream(void *mpeg, int stream_index);   /* mpeg.go:271: 0..3, others ignored */
+void mpeghost_mpeg_set_loop(void *mpeg, int loop);                   /* mpeg.go:343 */
+int mpeghost_mpeg_loop(void *mpeg);                                  /* mpeg.go:338 */
+void mpeghost_mpeg_rewind(void *mpeg);                               /* mpeg.go:323 */
+int mpeghost_mpeg_decode_video(void *mpeg, mpeghost_frame *out);
+const float *mpeghost_mpeg_decode_audio(void *mpeg, double *time);
+int mpeghost_mpeg_has_ended(void *mpeg);
+int mpeghost_mpeg_probe(void *mpeg, size_t probe_size);
+int mpeghost_mpeg_has_headers(void *mpeg);
+double mpeghost_mpeg_duration(void *mpeg);
+double mpeghost_mpeg_time(void *mpeg);
+double mpeghost_mpeg_audio_time(void *mpeg);
+double mpeghost_mpeg_video_time(void *mpeg);
+void mpeghost_mpeg_count_callbacks(void *mpeg, int video, int audio); /* SetVideoCallback / SetAudioCallback that count */
+void mpeghost_mpeg_callback_counts(void *mpeg, int out[2]);
+void mpeghost_mpeg_decode(void *mpeg, double tick);
+int mpeghost_mpeg_seek(void *mpeg, double seconds, int exact);
+int mpeghost_mpeg_seek_frame(void *mpeg, double seconds, int exact, mpeghost_frame *out);
+
+/* ---- VideoBatch: many independent video streams on ONE device, one device call per tick */
+void *mpeghost_batch_open(void *device, uint32_t n_streams);
+void *mpeghost_batch_open_store(void *store, uint32_t n_streams);    /* test stores; takes ownership */
+void mpeghost_batch_close(void *batch);
+int mpeghost_batch_add_stream(void *batch, const uint8_t *data, size_t len);
+int mpeghost_batch_decode_all(void *batch, int fetch);               /* frames produced this tick, -1 error */
+void mpeghost_batch_set_threads(void *batch, uint32_t n);
+int mpeghost_batch_frame(void *batch, uint32_t stream, mpeghost_frame *out);
+void mpeghost_batch_counters(void *batch, uint64_t out[2]);          /* device submits, pictures queued */
+void mpeghost_batch_phase_seconds(void *batch, double out[4]);       /* parse rounds, stage begin, puts, commits */
+
+/* ---- ShardedVideoBatch: streams sharded over SEVERAL devices (stream s -> device s mod G), one host thread and one
+ * VideoBatch per device, no collective */
+void *mpeghost_sharded_open(void *const *devices, uint32_t n_devices, uint32_t n_streams);
+void *mpeghost_sharded_open_stores(void *const *stores, uint32_t n_stores, uint32_t n_streams); /* test stores; takes ownership */
+void mpeghost_sharded_close(void *sharded);
+int mpeghost_sharded_add_stream(void *sharded, const uint8_t *data, size_t len);
+int mpeghost_sharded_decode_all(void *sharded, int fetch);
+int mpeghost_sharded_frame(void *sharded, uint32_t stream, mpeghost_frame *out);
+uint32_t mpeghost_sharded_device_of(void *sharded, uint32_t stream);
+void mpeghost_sharded_counters(void *sharded, uint32_t shard, uint64_t out[2]);
+
+/* ---- AudioBatch: many MP2 streams, one synthesis call per tick */
+void *mpeghost_audio_batch_open(void *device, uint32_t n_streams, int format, int fma_mode);
+void *mpeghost_audio_batch_open_store(void *store, uint32_t n_streams, int format, int fma_mode);
+void mpeghost_audio_batch_close(void *batch);
+int mpeghost_audio_batch_add_stream(void *batch, const uint8_t *data, size_t len);
+int mpeghost_audio_batch_decode_all(void *batch);
+const void *mpeghost_audio_batch_samples(void *batch, uint32_t stream, double *time, const void **right);
+uint64_t mpeghost_audio_batch_device_calls(void *batch);
+
+/* ---- Demux (demux.go:61 NewDemux, :216 Seek) */
+void *mpeghost_demux_open(const uint8_t *data, size_t len);
+void mpeghost_demux_close(void *demux);
+double mpeghost_demux_start_time(void *demux, int type);
+double mpeghost_demux_duration(void *demux, int type);
+int mpeghost_demux_probe(void *demux, size_t probe_size);
+void mpeghost_demux_streams(void *demux, int out[2]);
+void mpeghost_demux_rewind(void *demux);
+int mpeghost_demux_decode(void *demux, double *pts, size_t *len, const uint8_t **data);
+int mpeghost_demux_seek(void *demux, double seconds, int type, int force_intra, double *pts, size_t *len, const uint8_t **data);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPEGHOST_H */

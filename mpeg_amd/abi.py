@@ -98,44 +98,6 @@ def load_library(path: Path | None = None) -> C.CDLL:
     return lib
 
 
-def staged_submit_rate(device: int, width: int, height: int, seq, streams: int, threads: int, seconds: float = 2.0) -> float:
-    """Pictures per second that `threads` host threads push through mpeghip_video_stage_* when every device call
-    carries one picture of `seq` (cycled) for each of `streams` streams: validation, record expansion and wire
-    packing of every picture on the host, one H2D copy, expansion + reconstruction on the device.  Driven
-    natively by libmpeghost (mpeg_amd/host/capi.cpp: mpeghost_staged_submit_rate)."""
-    from ._build import LIBMPEGHOST
-    if not LIBMPEGHOST.exists():
-        raise MpegHipError(ERR_NO_DEVICE, "%s is not built (run __graft_entry__.build())" % LIBMPEGHOST)
-    load_library()  # libmpeghost links libmpeghip
-    H = C.CDLL(str(LIBMPEGHOST))
-    H.mpeghost_device_create.restype = C.c_void_p
-    H.mpeghost_device_create.argtypes = [C.c_int]
-    H.mpeghost_device_destroy.argtypes = [C.c_void_p]
-    H.mpeghost_last_error.restype = C.c_char_p
-    H.mpeghost_staged_submit_rate.restype = C.c_double
-    H.mpeghost_staged_submit_rate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    n = len(seq)
-    pics = np.ascontiguousarray(np.concatenate([s.pics[:1] for s in seq]))
-    mbs = [np.ascontiguousarray(s.mbs) for s in seq]
-    coefs = [np.ascontiguousarray(s.coefs).view(np.uint8).reshape(-1) for s in seq]
-    mbs_p = (C.c_void_p * n)(*[m.ctypes.data for m in mbs])
-    coefs_p = (C.c_void_p * n)(*[c.ctypes.data for c in coefs])
-    n_mbs = np.array([len(m) for m in mbs], np.uint32)
-    nbytes = np.array([c.nbytes for c in coefs], np.uint64)
-    dev = H.mpeghost_device_create(device)
-    if not dev:
-        raise MpegHipError(ERR_NO_DEVICE, H.mpeghost_last_error().decode(errors="replace"))
-    try:
-        pps = H.mpeghost_staged_submit_rate(dev, width, height, streams, threads, seconds, n, pics.ctypes.data, mbs_p,
-                                            n_mbs.ctypes.data, coefs_p, nbytes.ctypes.data)
-        if pps < 0:
-            raise MpegHipError(-1, H.mpeghost_last_error().decode(errors="replace"))
-    finally:
-        H.mpeghost_device_destroy(dev)
-    return pps
-
-
 def _check(rc: int):
     if rc != OK:
         raise MpegHipError(rc, load_library().mpeghip_last_error().decode(errors="replace"))

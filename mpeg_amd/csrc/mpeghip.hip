@@ -436,6 +436,7 @@ struct mpeghip_audio {
     void *d_out = nullptr;
     size_t cap_samples = 0, cap_out = 0;
     uint8_t *d_active = nullptr;   // [n_streams] mask of mpeghip_audio_synth_masked
+    int n_cu = 256;                // compute units of the device (asked once, at open)
 };
 
 static const uint8_t k_default_intra[64] = { // ISO 11172-2 default intra matrix (video.go:1055-1064)
@@ -1527,6 +1528,7 @@ int mpeghip_audio_open(mpeghip_ctx *c, uint32_t n_streams, int fma_mode, mpeghip
     a->ctx = c;
     a->n_streams = n_streams;
     a->fma = fma_mode;
+    (void)hipDeviceGetAttribute(&a->n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     float win[512];
     for (int i = 0; i < 512; i++)
         win[i] = (float)mpg_synth_window_x2[i] * 0.5f; // exact: entries are multiples of 0.5
@@ -1622,12 +1624,8 @@ static int audio_launch(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_f
     // time slices per stream: one full residency of workgroups (4 per CU are resident in practice: 5 x 32 KB
     // of LDS do not fit next to the allocation granularity), at least 4 frames per slice
     uint32_t chunks = 1;
-    if (const char *e = getenv("MPEGHIP_AUDIO_CHUNKS")) { // development knob
-        chunks = (uint32_t)atoi(e);
-    } else {
-        int n_cu = 256;
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, a->ctx->device);
-        const uint32_t want = ((uint32_t)n_cu * 4 + a->n_streams - 1) / a->n_streams;
+    {
+        const uint32_t want = ((uint32_t)a->n_cu * 4 + a->n_streams - 1) / a->n_streams;
         chunks = want < 1 ? 1 : want;
         if (chunks > n_frames / 4)
             chunks = n_frames / 4;

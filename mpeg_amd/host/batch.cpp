@@ -222,12 +222,7 @@ VideoBatch::VideoBatch(std::unique_ptr<BatchStore> store, uint32_t n_streams) : 
     pending_.assign(n_streams, 0);
 }
 
-VideoBatch::~VideoBatch()
-{
-    if (getenv("MPEGHOST_BENCH_VERBOSE") && threads_ > 1)
-        fprintf(stderr, "VideoBatch(%u streams, %u threads): parse rounds %.3f s, stage begin %.3f s, puts %.3f s, commits %.3f s\n",
-                (unsigned)videos_.size(), threads_, t_parse_, t_begin_, t_put_, t_commit_);
-}
+VideoBatch::~VideoBatch() = default;
 
 namespace {
 double nowSeconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -259,8 +254,11 @@ Video *VideoBatch::AddStream(Buffer *buf)
         throw std::runtime_error("VideoBatch: more streams than the batch was opened for");
     const uint32_t idx = (uint32_t)videos_.size();
     Port *port = new Port(this, idx);
+    // the Video owns the port; ports_ only learns about it once the Video exists (its constructor may throw:
+    // geometry that does not match the store, a backend error — the port dies with the unique_ptr then)
+    std::unique_ptr<Video> v(new Video(buf, std::unique_ptr<VideoBackend>(port)));
     ports_.push_back(port);
-    videos_.emplace_back(new Video(buf, std::unique_ptr<VideoBackend>(port)));
+    videos_.push_back(std::move(v));
     return videos_.back().get();
 }
 
@@ -551,6 +549,140 @@ size_t AudioBatch::DecodeAll(std::vector<Samples *> &samples)
         produced += samples[i] ? 1 : 0;
     }
     Flush();                         // GPU: one call for all streams
+    return produced;
+}
+
+// -------------------------------------------------------------------- ShardedVideoBatch
+struct ShardedVideoBatch::ShardState {
+    std::unique_ptr<VideoBatch> batch;
+    std::vector<Frame *> frames;      // the shard's last tick, local stream order
+    size_t produced = 0;
+    std::exception_ptr error;
+    // the shard's host thread: sleeps until a tick is posted
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t posted = 0, done = 0;
+    bool fetch = true, quit = false;
+};
+
+ShardedVideoBatch::ShardedVideoBatch(const std::vector<Device *> &devices, uint32_t n_streams)
+{
+    if (devices.empty())
+        throw std::runtime_error("ShardedVideoBatch: no devices");
+    const uint32_t per = (n_streams + (uint32_t)devices.size() - 1) / (uint32_t)devices.size();
+    for (Device *d : devices) {
+        shards_.emplace_back(new ShardState);
+        shards_.back()->batch.reset(new VideoBatch(d, per ? per : 1));
+    }
+    start(n_streams);
+}
+
+ShardedVideoBatch::ShardedVideoBatch(std::vector<std::unique_ptr<BatchStore>> stores, uint32_t n_streams)
+{
+    if (stores.empty())
+        throw std::runtime_error("ShardedVideoBatch: no stores");
+    const uint32_t per = (n_streams + (uint32_t)stores.size() - 1) / (uint32_t)stores.size();
+    for (auto &st : stores) {
+        shards_.emplace_back(new ShardState);
+        shards_.back()->batch.reset(new VideoBatch(std::move(st), per ? per : 1));
+    }
+    start(n_streams);
+}
+
+void ShardedVideoBatch::start(uint32_t n_streams)
+{
+    if (n_streams == 0)
+        throw std::runtime_error("ShardedVideoBatch: n_streams is 0");
+    capacity_ = n_streams;
+    for (auto &sp : shards_) {
+        ShardState *sh = sp.get();
+        sh->worker = std::thread([sh]() {
+            uint64_t seen = 0;
+            for (;;) {
+                bool fetch;
+                {
+                    std::unique_lock<std::mutex> l(sh->m);
+                    sh->cv.wait(l, [&] { return sh->quit || sh->posted != seen; });
+                    if (sh->quit)
+                        return;
+                    seen = sh->posted;
+                    fetch = sh->fetch;
+                }
+                try { // every libmpeghip call selects its context's device itself: nothing else binds the thread
+                    sh->produced = sh->batch->DecodeAll(sh->frames, fetch);
+                } catch (...) {
+                    sh->error = std::current_exception();
+                    sh->produced = 0;
+                }
+                {
+                    std::lock_guard<std::mutex> l(sh->m);
+                    sh->done = seen;
+                }
+                sh->cv.notify_all();
+            }
+        });
+    }
+}
+
+ShardedVideoBatch::~ShardedVideoBatch()
+{
+    for (auto &sh : shards_) {
+        {
+            std::lock_guard<std::mutex> l(sh->m);
+            sh->quit = true;
+        }
+        sh->cv.notify_all();
+        if (sh->worker.joinable())
+            sh->worker.join();
+    }
+}
+
+VideoBatch &ShardedVideoBatch::Shard(uint32_t g) { return *shards_.at(g)->batch; }
+
+Video *ShardedVideoBatch::AddStream(Buffer *buf)
+{
+    if (n_added_ >= capacity_)
+        throw std::runtime_error("ShardedVideoBatch: more streams than the batch was opened for");
+    Video *v = shards_[n_added_ % Shards()]->batch->AddStream(buf);
+    n_added_++;
+    return v;
+}
+
+void ShardedVideoBatch::SetThreads(unsigned n)
+{
+    for (auto &sh : shards_)
+        sh->batch->SetThreads(n);
+}
+
+size_t ShardedVideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
+{
+    for (auto &sh : shards_) {
+        {
+            std::lock_guard<std::mutex> l(sh->m);
+            sh->fetch = fetch;
+            sh->error = nullptr;
+            sh->posted++;
+        }
+        sh->cv.notify_all();
+    }
+    size_t produced = 0;
+    std::exception_ptr failed;
+    for (auto &sh : shards_) {
+        std::unique_lock<std::mutex> l(sh->m);
+        sh->cv.wait(l, [&] { return sh->done == sh->posted; });
+        produced += sh->produced;
+        if (sh->error && !failed)
+            failed = sh->error;
+    }
+    if (failed)
+        std::rethrow_exception(failed);
+    frames.assign(n_added_, nullptr);
+    const uint32_t G = Shards();
+    for (uint32_t s = 0; s < n_added_; s++) {
+        const std::vector<Frame *> &f = shards_[s % G]->frames;
+        frames[s] = s / G < f.size() ? f[s / G] : nullptr;
+    }
     return produced;
 }
 

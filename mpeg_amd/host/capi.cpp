@@ -20,8 +20,8 @@
 
 using namespace mpeg;
 
-extern "C" struct mpeghost_frame;
-typedef struct mpeghost_frame mpeghost_frame_t;
+#include "mpeghost.h"
+typedef mpeghost_frame mpeghost_frame_t;
 
 namespace {
 thread_local std::string g_err;
@@ -59,6 +59,11 @@ struct AudioBatchHandle {
     std::unique_ptr<AudioBatch> batch;
     std::vector<Samples *> samples;
 };
+struct ShardedHandle {
+    std::vector<std::unique_ptr<Buffer>> bufs;
+    std::unique_ptr<ShardedVideoBatch> batch;
+    std::vector<Frame *> frames;
+};
 struct DemuxHandle {
     std::unique_ptr<Buffer> buf;
     std::unique_ptr<Demux> demux;
@@ -68,14 +73,6 @@ void fill(mpeghost_frame_t *out, const Frame *f);
 } // namespace
 
 extern "C" {
-
-struct mpeghost_frame {
-    double time;
-    int width, height;
-    int luma_w, luma_h, chroma_w, chroma_h;
-    const uint8_t *y, *cb, *cr;
-    size_t luma_bytes, chroma_bytes;
-};
 
 const char *mpeghost_last_error(void) { return g_err.c_str(); }
 
@@ -89,20 +86,21 @@ void mpeghost_device_destroy(void *d) { delete static_cast<Device *>(d); }
 void *mpeghost_video_open(void *device, const uint8_t *data, size_t len)
 {
     return guard([&]() -> void * {
-        auto *h = new VideoHandle();
+        std::unique_ptr<VideoHandle> h(new VideoHandle());
         h->buf = Buffer::FromMemory(data, len);
         h->video.reset(new Video(h->buf.get(), static_cast<Device *>(device)));
-        return h;
+        return h.release();
     }, (void *)nullptr);
 }
 // same, with a caller-supplied backend (ownership passes to the decoder) — used by tests/host_emu
 void *mpeghost_video_open_backend(void *backend, const uint8_t *data, size_t len)
 {
     return guard([&]() -> void * {
-        auto *h = new VideoHandle();
+        std::unique_ptr<VideoBackend> be(static_cast<VideoBackend *>(backend)); // ours from here on, whatever throws
+        std::unique_ptr<VideoHandle> h(new VideoHandle());
         h->buf = Buffer::FromMemory(data, len);
-        h->video.reset(new Video(h->buf.get(), std::unique_ptr<VideoBackend>(static_cast<VideoBackend *>(backend))));
-        return h;
+        h->video.reset(new Video(h->buf.get(), std::move(be)));
+        return h.release();
     }, (void *)nullptr);
 }
 void mpeghost_video_close(void *h) { delete static_cast<VideoHandle *>(h); }
@@ -157,21 +155,22 @@ void mpeghost_video_stats(void *hv, uint64_t out[8])
 void *mpeghost_audio_open(void *device, const uint8_t *data, size_t len, int fma_mode, int format)
 {
     return guard([&]() -> void * {
-        auto *h = new AudioHandle();
+        std::unique_ptr<AudioHandle> h(new AudioHandle());
         h->buf = Buffer::FromMemory(data, len);
         h->audio.reset(new Audio(h->buf.get(), static_cast<Device *>(device), fma_mode));
         h->audio->SetFormat((AudioFormat)format);
-        return h;
+        return h.release();
     }, (void *)nullptr);
 }
 void *mpeghost_audio_open_backend(void *backend, const uint8_t *data, size_t len, int format)
 {
     return guard([&]() -> void * {
-        auto *h = new AudioHandle();
+        std::unique_ptr<AudioBackend> be(static_cast<AudioBackend *>(backend)); // ours from here on, whatever throws
+        std::unique_ptr<AudioHandle> h(new AudioHandle());
         h->buf = Buffer::FromMemory(data, len);
-        h->audio.reset(new Audio(h->buf.get(), std::unique_ptr<AudioBackend>(static_cast<AudioBackend *>(backend))));
+        h->audio.reset(new Audio(h->buf.get(), std::move(be)));
         h->audio->SetFormat((AudioFormat)format);
-        return h;
+        return h.release();
     }, (void *)nullptr);
 }
 void mpeghost_audio_close(void *h) { delete static_cast<AudioHandle *>(h); }
@@ -232,6 +231,21 @@ void mpeghost_mpeg_set_enabled(void *m, int video, int audio)
 {
     M(m)->SetVideoEnabled(video != 0);
     M(m)->SetAudioEnabled(audio != 0);
+}
+void mpeghost_mpeg_get_enabled(void *m, int out[2])
+{
+    out[0] = M(m)->VideoEnabled() ? 1 : 0;
+    out[1] = M(m)->AudioEnabled() ? 1 : 0;
+}
+void mpeghost_mpeg_set_audio_stream(void *m, int stream_index)
+{
+    guard([&]() -> int { M(m)->SetAudioStream(stream_index); return 0; }, -1);
+}
+void mpeghost_mpeg_set_loop(void *m, int loop) { M(m)->SetLoop(loop != 0); }
+int mpeghost_mpeg_loop(void *m) { return M(m)->Loop() ? 1 : 0; }
+void mpeghost_mpeg_rewind(void *m)
+{
+    guard([&]() -> int { M(m)->Rewind(); return 0; }, -1);
 }
 int mpeghost_mpeg_decode_video(void *mv, mpeghost_frame *out)
 {
@@ -366,139 +380,62 @@ void mpeghost_batch_counters(void *hv, uint64_t out[2])
     out[1] = h->batch->QueuedPictures();
 }
 
-// Measurement aid (tools/bench_host_path.py): how many pictures per second `threads` host threads can push
-// through mpeghip_video_stage_* when every call carries one picture for each of n_streams streams.  The
-// pictures are the caller's n_steps synthetic ones (arrays of arrays), the same for every stream — each stream
-// still gets its own put (validation, record expansion, wire packing into pinned staging).  Returns
-// pictures/s, < 0 on error; *wire_bytes_per_s = bytes that crossed to the device per second.
-double mpeghost_staged_submit_rate(void *device, uint32_t width, uint32_t height, uint32_t n_streams, uint32_t threads,
-                                   double seconds, uint32_t n_steps, const mpeghip_pic_desc *pics,
-                                   const mpeghip_mb_desc *const *mbs, const uint32_t *n_mbs, const uint8_t *const *coefs,
-                                   const size_t *coef_bytes)
+void mpeghost_batch_phase_seconds(void *hv, double out[4]) { static_cast<BatchHandle *>(hv)->batch->PhaseSeconds(out); }
+
+// ShardedVideoBatch: streams sharded over several devices (stream s -> device s mod G), one host thread per device
+void *mpeghost_sharded_open(void *const *devices, uint32_t n_devices, uint32_t n_streams)
 {
-    return guard([&]() -> double {
-        Device *dev = static_cast<Device *>(device);
-        mpeghip_video *v = nullptr;
-        if (mpeghip_video_open(dev->ctx(), width, height, n_streams, &v) != MPEGHIP_OK)
-            throw std::runtime_error(mpeghip_last_error());
-        struct Shared {
-            std::mutex m;
-            std::condition_variable go, done;
-            uint64_t generation = 0;
-            uint32_t busy = 0;
-            bool stop = false;
-            std::atomic<uint32_t> next{0};
-            std::atomic<int> failed{0};
-            mpeghip_stage *stage = nullptr;
-            uint32_t step = 0;
-        } sh;
-        threads = threads < 1 ? 1 : threads;
-        auto drain = [&]() {
-            for (;;) {
-                const uint32_t i = sh.next.fetch_add(1);
-                if (i >= n_streams)
-                    return;
-                mpeghip_pic_desc p = pics[sh.step];
-                p.stream = i;
-                if (mpeghip_video_stage_put(sh.stage, i, &p, mbs[sh.step], coefs[sh.step]) != MPEGHIP_OK)
-                    sh.failed.store(1);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < threads; t++)
-            pool.emplace_back([&]() {
-                uint64_t seen = 0;
-                for (;;) {
-                    {
-                        std::unique_lock<std::mutex> l(sh.m);
-                        sh.go.wait(l, [&] { return sh.stop || sh.generation != seen; });
-                        if (sh.stop)
-                            return;
-                        seen = sh.generation;
-                    }
-                    drain();
-                    {
-                        std::lock_guard<std::mutex> l(sh.m);
-                        sh.busy--;
-                    }
-                    sh.done.notify_one();
-                }
-            });
-        std::vector<uint32_t> counts(n_streams);
-        std::vector<size_t> bytes(n_streams);
-        double t_begin = 0, t_put = 0, t_commit = 0;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-            return std::chrono::duration<double>(b - a).count();
-        };
-        auto one_call = [&](uint32_t step) {
-            std::fill(counts.begin(), counts.end(), n_mbs[step]);
-            std::fill(bytes.begin(), bytes.end(), coef_bytes[step]);
-            mpeghip_stage *st = nullptr;
-            const auto c0 = now();
-            if (mpeghip_video_stage_begin(v, n_streams, counts.data(), bytes.data(), &st) != MPEGHIP_OK)
-                throw std::runtime_error(mpeghip_last_error());
-            const auto c1 = now();
-            {
-                std::lock_guard<std::mutex> l(sh.m);
-                sh.stage = st;
-                sh.step = step;
-                sh.next.store(0);
-                sh.busy = (uint32_t)pool.size();
-                sh.generation++;
-            }
-            sh.go.notify_all();
-            drain();
-            {
-                std::unique_lock<std::mutex> l(sh.m);
-                sh.done.wait(l, [&] { return sh.busy == 0; });
-            }
-            const auto c2 = now();
-            if (mpeghip_video_stage_commit(st) != MPEGHIP_OK || sh.failed.load())
-                throw std::runtime_error(mpeghip_last_error());
-            const auto c3 = now();
-            t_begin += secs(c0, c1);
-            t_put += secs(c1, c2);
-            t_commit += secs(c2, c3);
-        };
-        double rate = -1;
-        std::exception_ptr err;
-        try {
-            for (uint32_t s = 0; s < n_steps; s++)
-                one_call(s);
-            mpeghip_ctx_sync(dev->ctx());
-            t_begin = t_put = t_commit = 0;
-            const auto t0 = std::chrono::steady_clock::now();
-            uint64_t n = 0;
-            double dt = 0;
-            do {
-                for (uint32_t s = 0; s < n_steps; s++) {
-                    one_call(s);
-                    n += n_streams;
-                }
-                dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            } while (dt < seconds);
-            mpeghip_ctx_sync(dev->ctx());
-            dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            rate = (double)n / dt;
-            if (getenv("MPEGHOST_BENCH_VERBOSE"))
-                fprintf(stderr, "staged rate: %u pictures/call, %u threads: of %.3f s, begin (waits for the staging buffer's "
-                                "previous use) %.3f, puts %.3f, commit %.3f\n", n_streams, threads, dt, t_begin, t_put, t_commit);
-        } catch (...) {
-            err = std::current_exception();
-        }
-        {
-            std::lock_guard<std::mutex> l(sh.m);
-            sh.stop = true;
-        }
-        sh.go.notify_all();
-        for (std::thread &t : pool)
-            t.join();
-        mpeghip_video_close(v);
-        if (err)
-            std::rethrow_exception(err);
-        return rate;
-    }, -1.0);
+    return guard([&]() -> void * {
+        std::vector<Device *> devs;
+        for (uint32_t i = 0; i < n_devices; i++)
+            devs.push_back(static_cast<Device *>(devices[i]));
+        std::unique_ptr<ShardedHandle> h(new ShardedHandle);
+        h->batch.reset(new ShardedVideoBatch(devs, n_streams));
+        return h.release();
+    }, (void *)nullptr);
+}
+void *mpeghost_sharded_open_stores(void *const *stores, uint32_t n_stores, uint32_t n_streams)
+{
+    return guard([&]() -> void * {
+        std::vector<std::unique_ptr<BatchStore>> st; // ours from here on, whatever throws
+        for (uint32_t i = 0; i < n_stores; i++)
+            st.emplace_back(static_cast<BatchStore *>(stores[i]));
+        std::unique_ptr<ShardedHandle> h(new ShardedHandle);
+        h->batch.reset(new ShardedVideoBatch(std::move(st), n_streams));
+        return h.release();
+    }, (void *)nullptr);
+}
+void mpeghost_sharded_close(void *h) { delete static_cast<ShardedHandle *>(h); }
+int mpeghost_sharded_add_stream(void *hv, const uint8_t *data, size_t len)
+{
+    return guard([&]() -> int {
+        ShardedHandle *h = static_cast<ShardedHandle *>(hv);
+        h->bufs.push_back(Buffer::FromMemory(data, len));
+        h->batch->AddStream(h->bufs.back().get());
+        return (int)h->batch->Streams() - 1;
+    }, -1);
+}
+int mpeghost_sharded_decode_all(void *hv, int fetch)
+{
+    return guard([&]() -> int {
+        ShardedHandle *h = static_cast<ShardedHandle *>(hv);
+        return (int)h->batch->DecodeAll(h->frames, fetch != 0);
+    }, -1);
+}
+int mpeghost_sharded_frame(void *hv, uint32_t stream, mpeghost_frame *out)
+{
+    ShardedHandle *h = static_cast<ShardedHandle *>(hv);
+    if (stream >= h->frames.size() || !h->frames[stream])
+        return 0;
+    fill(out, h->frames[stream]);
+    return 1;
+}
+uint32_t mpeghost_sharded_device_of(void *hv, uint32_t stream) { return static_cast<ShardedHandle *>(hv)->batch->ShardOf(stream); }
+void mpeghost_sharded_counters(void *hv, uint32_t shard, uint64_t out[2])
+{
+    VideoBatch &b = static_cast<ShardedHandle *>(hv)->batch->Shard(shard);
+    out[0] = b.DeviceSubmits();
+    out[1] = b.QueuedPictures();
 }
 
 // AudioBatch: many MP2 streams, one synthesis call per tick (format: 0 F32N, 1 F32NLR, 2 F32, 3 S16)

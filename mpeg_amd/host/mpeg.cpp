@@ -80,6 +80,15 @@ void MPEG::Rewind()
         audio_->Rewind();
     demux_->Rewind();
     time_ = 0;
+    has_ended_ = false; // mpeg.go:336
+}
+
+void MPEG::SetAudioStream(int stream_index)
+{ // mpeg.go:270-279
+    if (stream_index < 0 || stream_index > 3)
+        return;
+    audio_stream_index_ = stream_index;
+    SetAudioEnabled(audio_enabled_); // sets the matching packet type
 }
 
 bool MPEG::Probe(size_t probe_size)

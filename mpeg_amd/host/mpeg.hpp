@@ -23,6 +23,10 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <exception>
 
 #include "mpeghip.h"
 
@@ -356,6 +360,8 @@ public:
     void Flush();                                  // submit whatever is queued
     uint64_t DeviceSubmits() const { return device_submits_; }
     uint64_t QueuedPictures() const { return queued_pictures_; }
+    // wall seconds spent so far in {parse rounds, stage begin, puts, commits} (pooled DecodeAll only)
+    void PhaseSeconds(double out[4]) const { out[0] = t_parse_; out[1] = t_begin_; out[2] = t_put_; out[3] = t_commit_; }
 
 private:
     class Port;
@@ -376,7 +382,33 @@ private:
     std::vector<uint8_t> coefs_;
     std::vector<uint8_t> pending_;                 // stream already has a picture in the open batch
     uint64_t device_submits_ = 0, queued_pictures_ = 0;
-    double t_parse_ = 0, t_put_ = 0, t_commit_ = 0, t_begin_ = 0; // wall time per phase (printed with MPEGHOST_BENCH_VERBOSE)
+    double t_parse_ = 0, t_put_ = 0, t_commit_ = 0, t_begin_ = 0; // wall time per phase (PhaseSeconds)
+};
+
+// Streams sharded over SEVERAL devices ("stream s -> GPU s mod G ... host driver = G threads, one
+// HIP stream each; collective: none").  Every shard is a VideoBatch of its own on its own Device (its own libmpeghip
+// context, HIP stream and frame store), driven by its own host thread: a tick wakes the G threads, each advances its
+// streams by one frame with one device call, and the caller gets the frames back in global stream order.  Shards
+// share nothing — no collective, no peer access, no lock on the data path.
+class ShardedVideoBatch {
+public:
+    ShardedVideoBatch(const std::vector<Device *> &devices, uint32_t n_streams);
+    ShardedVideoBatch(std::vector<std::unique_ptr<BatchStore>> stores, uint32_t n_streams); // injected stores (tests)
+    ~ShardedVideoBatch();
+    Video *AddStream(Buffer *buf);                 // becomes stream number Streams(), on shard Streams() % Shards()
+    uint32_t Streams() const { return n_added_; }
+    uint32_t Shards() const { return (uint32_t)shards_.size(); }
+    uint32_t ShardOf(uint32_t stream) const { return stream % Shards(); }
+    VideoBatch &Shard(uint32_t g);
+    void SetThreads(unsigned n);                   // parse threads of every shard
+    // one tick of every shard, concurrently; frames[s] = the next frame of global stream s (or nullptr)
+    size_t DecodeAll(std::vector<Frame *> &frames, bool fetch = true);
+
+private:
+    struct ShardState;
+    void start(uint32_t n_streams);
+    std::vector<std::unique_ptr<ShardState>> shards_;
+    uint32_t n_added_ = 0, capacity_ = 0;
 };
 
 // -------------------------------------------------------------------- audio.go
@@ -528,6 +560,10 @@ public:
     void SetVideoEnabled(bool e);
     void SetAudioEnabled(bool e);
     void SetLoop(bool l) { loop_ = l; }
+    bool Loop() const { return loop_; }                   // mpeg.go:338
+    bool VideoEnabled() const { return video_enabled_; }  // mpeg.go:170
+    bool AudioEnabled() const { return audio_enabled_; }  // mpeg.go:245
+    void SetAudioStream(int stream_index);                // 0..3, default 0 (mpeg.go:270-279)
     void SetAudioLeadTime(double s) { audio_lead_time_ = s; }
     void SetAudioFormat(AudioFormat f);
     void SetVideoCallback(VideoFunc f) { video_cb_ = std::move(f); }

@@ -45,6 +45,10 @@ def host():
             "mpeghost_mpeg_open": (P, [P, C.c_char_p, C.c_size_t]), "mpeghost_mpeg_close": (None, [P]),
             "mpeghost_mpeg_info": (None, [P, C.POINTER(C.c_int * 6)]), "mpeghost_mpeg_framerate": (C.c_double, [P]),
             "mpeghost_mpeg_set_enabled": (None, [P, C.c_int, C.c_int]),
+            "mpeghost_mpeg_get_enabled": (None, [P, C.POINTER(C.c_int * 2)]),
+            "mpeghost_mpeg_set_audio_stream": (None, [P, C.c_int]),
+            "mpeghost_mpeg_set_loop": (None, [P, C.c_int]), "mpeghost_mpeg_loop": (C.c_int, [P]),
+            "mpeghost_mpeg_rewind": (None, [P]),
             "mpeghost_mpeg_decode_video": (C.c_int, [P, C.POINTER(HostFrame)]),
             "mpeghost_mpeg_decode_audio": (P, [P, C.POINTER(C.c_double)]), "mpeghost_mpeg_has_ended": (C.c_int, [P]),
             "mpeghost_mpeg_open_backends": (P, [P, P, C.c_char_p, C.c_size_t]),
@@ -61,6 +65,14 @@ def host():
             "mpeghost_batch_decode_all": (C.c_int, [P, C.c_int]), "mpeghost_batch_set_threads": (None, [P, C.c_uint32]),
             "mpeghost_batch_frame": (C.c_int, [P, C.c_uint32, C.POINTER(HostFrame)]),
             "mpeghost_batch_counters": (None, [P, C.POINTER(C.c_uint64 * 2)]),
+            "mpeghost_batch_phase_seconds": (None, [P, C.POINTER(C.c_double * 4)]),
+            "mpeghost_sharded_open": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
+            "mpeghost_sharded_open_stores": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
+            "mpeghost_sharded_close": (None, [P]), "mpeghost_sharded_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
+            "mpeghost_sharded_decode_all": (C.c_int, [P, C.c_int]),
+            "mpeghost_sharded_frame": (C.c_int, [P, C.c_uint32, C.POINTER(HostFrame)]),
+            "mpeghost_sharded_device_of": (C.c_uint32, [P, C.c_uint32]),
+            "mpeghost_sharded_counters": (None, [P, C.c_uint32, C.POINTER(C.c_uint64 * 2)]),
             "mpeghost_audio_batch_open": (P, [P, C.c_uint32, C.c_int, C.c_int]),
             "mpeghost_audio_batch_open_store": (P, [P, C.c_uint32, C.c_int, C.c_int]),
             "mpeghost_audio_batch_close": (None, [P]), "mpeghost_audio_batch_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
@@ -77,6 +89,7 @@ def host():
         for n, (r, a) in sig.items():
             f = getattr(L, n)
             f.restype, f.argtypes = r, a
+        L.bound_names = sorted(sig)
         _host = L
     return _host
 
@@ -280,6 +293,22 @@ class HostMpeg:
     def set_enabled(self, video, audio):
         self._call("set_enabled", int(video), int(audio))
 
+    def get_enabled(self):
+        out = (C.c_int * 2)()
+        self._call("get_enabled", C.byref(out))
+        return bool(out[0]), bool(out[1])
+
+    def set_audio_stream(self, index):
+        self._call("set_audio_stream", int(index))
+
+    def set_loop(self, loop):
+        self._call("set_loop", int(loop))
+
+    loop = property(lambda s: s._call("loop") == 1)
+
+    def rewind(self):
+        self._call("rewind")
+
     def count_callbacks(self, video=True, audio=True):
         self._call("count_callbacks", int(video), int(audio))
 
@@ -359,6 +388,56 @@ class HostBatch:
     def close(self):
         if self.h:
             host().mpeghost_batch_close(self.h)
+            self.h = None
+
+
+class HostSharded:
+    """mpeg::ShardedVideoBatch: streams sharded over several devices (stream s -> device s mod G), one host thread and
+    one VideoBatch per device.  devices: a list of mpeghost devices, or an int = that many test-only emulator stores."""
+
+    def __init__(self, n_streams: int, devices):
+        L = host()
+        if isinstance(devices, int):
+            E = host_emu()
+            arr = (C.c_void_p * devices)(*[E.host_emu_batch_store() for _ in range(devices)])
+            self.h = L.mpeghost_sharded_open_stores(arr, devices, n_streams)
+            self.shards = devices
+        else:
+            arr = (C.c_void_p * len(devices))(*devices)
+            self.h = L.mpeghost_sharded_open(arr, len(devices), n_streams)
+            self.shards = len(devices)
+        if not self.h:
+            raise RuntimeError(L.mpeghost_last_error().decode())
+        self._keep = []
+
+    def add_stream(self, data: bytes) -> int:
+        self._keep.append(data)
+        i = host().mpeghost_sharded_add_stream(self.h, data, len(data))
+        if i < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return i
+
+    def decode_all(self, fetch=True) -> int:
+        n = host().mpeghost_sharded_decode_all(self.h, int(fetch))
+        if n < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return n
+
+    def frame(self, stream: int):
+        f = HostFrame()
+        return f if host().mpeghost_sharded_frame(self.h, stream, C.byref(f)) == 1 else None
+
+    def device_of(self, stream: int) -> int:
+        return host().mpeghost_sharded_device_of(self.h, stream)
+
+    def counters(self, shard: int):
+        out = (C.c_uint64 * 2)()
+        host().mpeghost_sharded_counters(self.h, shard, C.byref(out))
+        return {"device_submits": out[0], "queued_pictures": out[1]}
+
+    def close(self):
+        if self.h:
+            host().mpeghost_sharded_close(self.h)
             self.h = None
 
 

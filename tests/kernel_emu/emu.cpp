@@ -81,7 +81,7 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     a.rgba = rgba;
     a.rgba_stride = rgba_stride;
 
-    alignas(16) static uint8_t lds[kRcLdsBytes];
+    alignas(16) uint8_t lds[kRcLdsBytes]; // (no statics: ShardedVideoBatch tests run two emulator stores on two threads)
     for (uint32_t chunk = 0; chunk < nc; chunk++) {
         memset(lds, 0xCD, sizeof(lds)); // poison: reads of unwritten LDS must not matter
         int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
@@ -102,7 +102,7 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                 const int at[6] = {kRcQtabAt, kRcBlkAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes};
                 memcpy(lds + at[i] + 16 * lane, src[i] + off[i], 16);
             }
-        static int32_t v[64][8];
+        int32_t v[64][8];
         uint32_t ent_at = 0;
         auto residual_pass = [&](uint32_t pass) {
             const uint32_t np = rc_pass_entries(c, pass);

@@ -26,6 +26,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.mpeghip_abi_version() == 1
 
 
+def test_host_library_exports_exactly_what_its_header_declares():
+    """include/mpeghost.h (the flat C API of libmpeghost) vs the library's dynamic symbol table vs the ctypes
+    bindings the tests use: the three lists are the same."""
+    import subprocess
+    import sys
+    sys.path.insert(0, str(ROOT / "tests"))
+    import hostlib
+    from mpeg_amd import _build
+    txt = (ROOT / "include" / "mpeghost.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mpeghost_[a-z0-9_]+)\s*\(", txt)))
+    L = hostlib.host()
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(_build.LIBMPEGHOST)], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\b(mpeghost_[a-z0-9_]+)\b", nm)))
+    assert len(declared) >= 70
+    assert declared == exported, (sorted(set(declared) - set(exported)), sorted(set(exported) - set(declared)))
+    assert L.bound_names == declared, (sorted(set(declared) - set(L.bound_names)), sorted(set(L.bound_names) - set(declared)))
+
+
 def test_descriptor_layouts_match_header():
     from mpeg_amd import desc
     assert desc.PIC_DTYPE.itemsize == 16 and desc.MB_DTYPE.itemsize == 32

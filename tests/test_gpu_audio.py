@@ -59,15 +59,15 @@ def test_config4_256_streams(oracle, hip_ctx):
     dut.close()
 
 
-@pytest.mark.parametrize("chunks", ["1", "3", "16"])
-def test_time_slicing_is_bit_identical(oracle, hip_ctx, chunks, monkeypatch):
-    """The launch is split along time (MPEGHIP_AUDIO_CHUNKS slices per stream, history rebuilt from the samples)."""
-    monkeypatch.setenv("MPEGHIP_AUDIO_CHUNKS", chunks)
-    s = synth.audio_frames(5, 33)
-    ref, dut = oracle.OracleSynth(5, 0), abi.AudioSynth(hip_ctx, 5, 0)
+@pytest.mark.parametrize("n_streams,n_frames", [(5, 33), (300, 16), (1100, 9), (3, 2)])
+def test_time_slicing_is_bit_identical(oracle, hip_ctx, n_streams, n_frames):
+    """A launch is split along time so that the GPU is full (slices = workgroups per CU x CUs / streams, at least 4 frames
+    each; the history is rebuilt from the samples): 8, 4, 1 and 1 slices here."""
+    s = synth.audio_frames(n_streams, n_frames)
+    ref, dut = oracle.OracleSynth(n_streams, 0), abi.AudioSynth(hip_ctx, n_streams, 0)
     for _ in range(2):
         assert bits_equal(ref.synth(s), dut.synth(s))
-        (va, pa), (vb, pb) = ref.get_state(4), dut.get_state(4)
+        (va, pa), (vb, pb) = ref.get_state(n_streams - 1), dut.get_state(n_streams - 1)
         assert pa == pb and bits_equal(va, vb)
     dut.close()
 

@@ -127,3 +127,30 @@ def test_audio_batch_streams_share_one_synthesis_call_per_tick(oracle, emu):
     h, cnt, calls = run_audio_batch(oracle, 5, [0, 0, 3, 7, 40], window=win)
     assert h == [AUDIO_HASH] * 5 and cnt == [355] * 5      # every stream exactly as if decoded alone
     assert calls == 355 + 40                                # one call per tick while any stream is alive
+
+
+def test_streams_sharded_over_two_stores(oracle, golden_dir):
+    """mpeg::ShardedVideoBatch over two (emulator) stores: stream s lives on store s mod 2, each shard is driven by its
+    own host thread with its own device calls, every stream still comes out as if decoded alone, and no shard sees
+    another one's pictures (no collective)."""
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    clean = oracle.ps_extract((golden_dir / "test.mpg").read_bytes(), 0xE0)[0]
+    streams = [es, clean, es, clean, es]
+    b = hostlib.HostSharded(len(streams), 2)
+    for s in streams:
+        b.add_stream(s)
+    assert [b.device_of(i) for i in range(5)] == [0, 1, 0, 1, 0]
+    h, n = [oracle.FNV_OFFSET] * 5, [0] * 5
+    while b.decode_all():
+        for i in range(5):
+            f = b.frame(i)
+            if f is not None:
+                for p in hostlib.frame_planes(f):
+                    h[i] = oracle.fnv1a64(p, h[i])
+                n[i] += 1
+    assert h == [VIDEO_HASH, TESTMPG_VIDEO_HASH, VIDEO_HASH, TESTMPG_VIDEO_HASH, VIDEO_HASH]
+    assert n == [260, 278, 260, 278, 260]
+    c0, c1 = b.counters(0), b.counters(1)
+    assert c0["queued_pictures"] >= 3 * 260 and c1["queued_pictures"] >= 2 * 278   # each shard queued its own streams only
+    assert c0["queued_pictures"] + c1["queued_pictures"] < 5 * 300
+    b.close()

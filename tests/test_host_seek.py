@@ -101,6 +101,51 @@ def test_mpeg_facade_numbers(test_mpg, window):
     m.close()
 
 
+def test_rewind_after_the_end_clears_has_ended(test_mpg, window):
+    """mpeg.go:323-337: Rewind resets time AND hasEnded — `for !m.HasEnded() { m.Decode(dt) }` must run again."""
+    m = hostlib.HostMpeg(test_mpg, window=window)
+    m.count_callbacks()
+    ticks = 0
+    while not m.has_ended and ticks < 400:
+        m.decode(0.1)
+        ticks += 1
+    assert m.has_ended and 90 <= ticks < 400
+    first = m.callback_counts()
+    assert first[0] >= 270 and first[1] >= 350
+    m.rewind()
+    assert not m.has_ended and m.time == 0.0
+    ticks = 0
+    while not m.has_ended and ticks < 400:
+        m.decode(0.1)
+        ticks += 1
+    second = m.callback_counts()
+    assert m.has_ended and second[0] - first[0] == first[0] and second[1] - first[1] == first[1]   # the whole file once more
+    m.close()
+
+
+def test_loop_enabled_and_audio_stream_accessors(test_mpg, window):
+    """mpeg.go:170-279, 338-345: getters mirror the setters; SetAudioStream takes 0..3 and re-selects the packet type."""
+    m = hostlib.HostMpeg(test_mpg, window=window)
+    assert m.get_enabled() == (True, True) and not m.loop
+    m.set_loop(True)
+    m.set_enabled(False, True)
+    assert m.loop and m.get_enabled() == (False, True)
+    def frames_left():
+        n = 0
+        while m.decode_audio() is not None:
+            n += 1
+        return n
+    m.set_audio_stream(1)                      # a stream the file does not have: only what was buffered before comes out
+    assert frames_left() < 40
+    m.set_audio_stream(7)                      # out of range: ignored (still stream 1)
+    m.rewind()
+    assert frames_left() == 0
+    m.set_audio_stream(0)
+    m.rewind()
+    assert frames_left() == 355                # the whole of testdata/test.mpg (mpeg_test.go:164)
+    m.close()
+
+
 def test_seek_keeps_audio_time_in_step(test_mpg, window):
     """mpeg_test.go:402-438: an exact seek (also off a frame boundary) leaves Audio.Time within one packet."""
     times = []

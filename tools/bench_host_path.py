@@ -51,32 +51,19 @@ def submit_rate(ctx, streams, seconds=2.0):
     return n / dt, nbytes / dt
 
 
-def staged_rate(dev, streams, threads, seconds=2.0):
-    """mpeghip_video_stage_*: `streams` typical 1080p pictures per device call, each put (validation, record
-    expansion, packing of the coefficient units into pinned staging) from one of `threads` host threads —
-    driven natively (mpeghost_staged_submit_rate in mpeg_amd/host/capi.cpp): a Python thread pool would be
-    the bottleneck."""
-    import hostlib
-    H = hostlib.host()
+def staged_rate(device, streams, threads, seconds=2.0):
+    """mpeghip_video_stage_*: `streams` typical 1080p pictures per device call, each put (validation + packing into
+    the device format, into pinned staging) from one of `threads` host threads — driven natively
+    (tools/hostbench/staged_rate.cpp): a Python thread pool would be the bottleneck."""
+    from tools import hostbench
     seq = synth.generate_sequence(1920, 1080, 13, profile="typical")
-    n = len(seq)
-    pics = np.concatenate([s.pics[:1] for s in seq])
+    pps = hostbench.staged_submit_rate(device, 1920, 1080, seq, streams, threads, seconds, verbose=True)
     mbs = [np.ascontiguousarray(s.mbs) for s in seq]
     coefs = [np.ascontiguousarray(s.coefs).view(np.uint8).reshape(-1) for s in seq]
-    mbs_p = (C.c_void_p * n)(*[m.ctypes.data for m in mbs])
-    coefs_p = (C.c_void_p * n)(*[c.ctypes.data for c in coefs])
-    n_mbs = np.array([len(m) for m in mbs], np.uint32)
-    nbytes = np.array([c.nbytes for c in coefs], np.uint64)
-    H.mpeghost_staged_submit_rate.restype = C.c_double
-    H.mpeghost_staged_submit_rate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    pps = H.mpeghost_staged_submit_rate(dev, 1920, 1080, streams, threads, seconds, n, pics.ctypes.data, mbs_p,
-                                        n_mbs.ctypes.data, coefs_p, nbytes.ctypes.data)
-    if pps < 0:
-        raise RuntimeError(H.mpeghost_last_error().decode())
     dense = float(np.mean([16 + m.nbytes + c.nbytes for m, c in zip(mbs, coefs)]))
     nz = [np.count_nonzero(c.view(np.int16).reshape(-1, 64), axis=1) for c in coefs]
-    wire = float(np.mean([16 + 16 + len(m) * 48 + 4 * len(k) + 4 * np.where(k <= 31, k, 32).sum() for m, k in zip(mbs, nz)]))
+    # the device format: 16-byte picture, 24 bytes per macroblock (chunk of 4 = 96), one word per block + one per non-zero level
+    wire = float(np.mean([16 + len(m) * 24 + 4 * len(k) + 4 * np.where(k <= 32, k, 32).sum() for m, k in zip(mbs, nz)]))
     return pps, dense, wire
 
 
@@ -90,14 +77,12 @@ def main():
     ctx.close()
 
     import hostlib
-    dev = hostlib.host().mpeghost_device_create(0)
     for streams, threads in ((64, 1), (64, 8), (64, 32), (256, 32), (512, 32)):
         threads = min(threads, os.cpu_count() or 1)
-        pps, dense, wire = staged_rate(dev, streams, threads)
+        pps, dense, wire = staged_rate(0, streams, threads)
         print("staged submit, %4d pictures/call put by %2d host thread(s): %8.0f pictures/s = %.3f G macroblocks/s; per picture "
-              "%.2f MB as the ABI hands it over, %.2f MB on the wire (records + packed units) = %.1f GB/s over PCIe"
+              "%.2f MB as the ABI hands it over, %.2f MB in the device format (chunks + words) = %.1f GB/s over PCIe"
               % (streams, threads, pps, pps * 8160 / 1e9, dense / 1e6, wire / 1e6, pps * wire / 1e9))
-    hostlib.host().mpeghost_device_destroy(dev)
     from oracle import pyoracle
     ps = (ROOT / "tests" / "golden" / "test.mpg").read_bytes()
     dev = hostlib.host().mpeghost_device_create(0)
