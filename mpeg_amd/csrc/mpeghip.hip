@@ -146,9 +146,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         uint8_t *win = lds + rc_win_at(m);
         uint32_t yl = 0, yc = 0;
         if (!(d0 & kRIntra)) {
-            yl = rc_mc4(win + k.mc_luma, 2 * kRcPiece, rc_shift_luma(d0), (d0 & kROhL) != 0, (d0 & kROvL) != 0);
+            if (d0 & kRSlow) { // the window leaves its plane: the reference's linear reads, gathered (rare)
+                if (lane < 52)
+                    *reinterpret_cast<u32x4 *>(win + lane * 16) = rc_gather_piece(a, c, m, k);
+                wave_lds_handoff();
+            }
+            const RcTaps t = rc_taps(d0, c.r[m][2], c.r[m][3]);
+            yl = rc_mc_luma(win, k, t, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
             if (lane < 32)
-                yc = rc_mc4(win + k.mc_chroma, kRcPiece, rc_shift_chroma(d0), (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+                yc = rc_mc_chroma(win, k, t, lane, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
         }
         wave_lds_handoff(); // every lane has its taps
         *reinterpret_cast<uint32_t *>(win + k.out_luma) = yl;
@@ -205,23 +211,21 @@ __global__ __launch_bounds__(256) void rgba_pics_kernel(const VideoArgs a, uint3
     const uint32_t x4 = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const uint64_t fs = (uint64_t)p.stream * MPEGHIP_SLOTS + p.cur;
-    rgba_convert_quad(a.frames + fs * a.frame_stride, a.luma_w, a.chroma_w, a.luma_bytes, a.chroma_bytes, a.width,
-                      a.height, x4, y, a.rgba + fs * a.rgba_stride);
+    rgba_convert_quad(a.frames + fs * a.frame_stride, a.mb_w, a.luma_bytes, a.chroma_bytes, a.width, a.height, x4, y,
+                      a.rgba + fs * a.rgba_stride);
 }
 
 // Frame.RGBA for whole slots: grid (x quads, row pairs / 4, streams).
 __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64_t frame_stride,
                                                   uint8_t *rgba, uint64_t rgba_stride,
-                                                  uint32_t luma_w, uint32_t chroma_w,
-                                                  uint32_t luma_bytes, uint32_t chroma_bytes,
+                                                  uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_bytes,
                                                   uint32_t width, uint32_t height,
                                                   uint32_t slot, uint32_t stream0)
 {
     const uint32_t x4 = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const uint64_t fs = (uint64_t)(stream0 + blockIdx.z) * MPEGHIP_SLOTS + slot;
-    rgba_convert_quad(frames + fs * frame_stride, luma_w, chroma_w, luma_bytes, chroma_bytes,
-                      width, height, x4, y, rgba + fs * rgba_stride);
+    rgba_convert_quad(frames + fs * frame_stride, mb_w, luma_bytes, chroma_bytes, width, height, x4, y, rgba + fs * rgba_stride);
 }
 
 // Replicate a one-stream batch for streams 1..n-1 (benchmark batches): stream s gets its own copy of the
@@ -266,18 +270,35 @@ __global__ void replicate_kernel(mpeghip_pic_desc *pics, uint32_t n_pics, uint32
     }
 }
 
+// The reference's linear view of one slot's planes <-> the tiled frame (video_lane.h): one dword per thread.
+// to_linear: buf[i] = slot[linear_to_tiled(i)]; else slot[linear_to_tiled(i)] = buf[i], for the byte range [first, first + n).
+__global__ __launch_bounds__(256) void relayout_kernel(uint8_t *slot, uint8_t *buf, uint32_t first, uint32_t n_bytes, uint32_t mb_w,
+                                                       uint32_t luma_bytes, uint32_t chroma_bytes, int to_linear)
+{
+    const uint32_t i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n_bytes)
+        return;
+    uint32_t *t = reinterpret_cast<uint32_t *>(slot + linear_to_tiled(mb_w, luma_bytes, chroma_bytes, first + i));
+    uint32_t *l = reinterpret_cast<uint32_t *>(buf + i);
+    if (to_linear)
+        *l = *t;
+    else
+        *t = *l;
+}
+
 // FNV-1a-64 over Y||Cb||Cr of one slot per stream (mpeg_test.go:221-223); one
 // thread per stream — a test aid, not a hot path.
-__global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32_t slot,
-                            uint64_t n_bytes, uint32_t n_streams, uint64_t *out)
+__global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32_t slot, uint32_t mb_w, uint32_t luma_bytes,
+                            uint32_t chroma_bytes, uint32_t n_streams, uint64_t *out)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams)
         return;
     const uint8_t *p = frames + ((uint64_t)s * MPEGHIP_SLOTS + slot) * frame_stride;
+    const uint32_t n_bytes = luma_bytes + 2 * chroma_bytes; // in the reference's order; 8 linear bytes stay together in a tile row
     uint64_t h = 0xcbf29ce484222325ull;
-    for (uint64_t i = 0; i < n_bytes; i += 8) {
-        uint64_t w = *reinterpret_cast<const uint64_t *>(p + i);
+    for (uint32_t i = 0; i < n_bytes; i += 8) {
+        uint64_t w = *reinterpret_cast<const uint64_t *>(p + linear_to_tiled(mb_w, luma_bytes, chroma_bytes, i));
         for (int k = 0; k < 8; k++) {
             h ^= (w >> (8 * k)) & 0xff;
             h *= 0x100000001b3ull;
@@ -397,6 +418,7 @@ struct mpeghip_video {
     struct mpeghip_stage *stage = nullptr; // the open mpeghip_video_stage_begin, if any
     uint8_t *bounce = nullptr;             // pinned: read_planes / read_rgba land here first
     size_t bounce_cap = 0;
+    uint8_t *d_linear = nullptr;           // one slot's planes in the reference's linear layout (read / write_planes)
 };
 
 // what validation learns about a picture (the dependency check across pictures needs it)
@@ -661,6 +683,8 @@ void mpeghip_video_close(mpeghip_video *v)
     v->stage = nullptr;
     if (v->bounce)
         (void)hipHostFree(v->bounce);
+    if (v->d_linear)
+        (void)hipFree(v->d_linear);
     for (auto &sg : v->staging) {
         batch_release(&sg.batch);
         if (sg.h)
@@ -833,6 +857,8 @@ static int check_dependencies(const mpeghip_pic_desc *pics, const PicUse *use, u
 static RcGeom record_geometry(const mpeghip_video *v)
 {
     RcGeom g;
+    g.mb_w = v->info.mb_w;
+    g.mb_h = v->info.mb_h;
     g.luma_w = v->info.luma_w;
     g.chroma_w = v->info.chroma_w;
     g.luma_bytes = (uint32_t)v->info.luma_bytes;
@@ -949,6 +975,8 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     VideoArgs a;
     a.frames = v->d_frames;
     a.frame_stride = in.frame_stride;
+    a.mb_w = in.mb_w;
+    a.mb_h = in.mb_h;
     a.luma_w = in.luma_w;
     a.luma_h = in.luma_h;
     a.chroma_w = in.chroma_w;
@@ -1385,14 +1413,31 @@ void *mpeghip_video_rgba_devptr(mpeghip_video *v, uint32_t stream, uint32_t slot
     return v->d_rgba + ((uint64_t)stream * MPEGHIP_SLOTS + slot) * rgba_stride_of(v);
 }
 
+static int ensure_linear(mpeghip_video *v)
+{
+    if (!v->d_linear)
+        HIP_TRY(hipMalloc((void **)&v->d_linear, v->info.frame_bytes + 64));
+    return MPEGHIP_OK;
+}
+
+static void launch_relayout(mpeghip_video *v, uint8_t *slot, uint32_t first, uint32_t n_bytes, int to_linear)
+{
+    if (n_bytes)
+        hipLaunchKernelGGL(relayout_kernel, dim3((n_bytes / 4 + 255) / 256), dim3(256), 0, v->ctx->stream, slot, v->d_linear + first, first,
+                           n_bytes, v->info.mb_w, (uint32_t)v->info.luma_bytes, (uint32_t)v->info.chroma_bytes, to_linear);
+}
+
 int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr)
 {
     if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
     HIP_TRY(hipSetDevice(v->ctx->device));
-    // Y, Cb, Cr are one contiguous range of the slot: ONE copy into a pinned bounce buffer behind everything
-    // queued on the stream, then plain memcpys (three synchronous copies into pageable memory cost three
-    // round trips — most of a small picture's turnaround)
+    int rc = ensure_linear(v);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    // the planes are tiled in HBM (video_lane.h): untile into the linear scratch, then ONE copy of Y, Cb, Cr into a
+    // pinned bounce buffer behind everything queued on the stream, then plain memcpys (three synchronous copies
+    // into pageable memory cost three round trips — most of a small picture's turnaround)
     const size_t bytes = v->info.luma_bytes + 2 * v->info.chroma_bytes;
     if (v->bounce_cap < bytes) {
         if (v->bounce)
@@ -1403,7 +1448,9 @@ int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, 
         v->bounce_cap = bytes;
     }
     hipStream_t st = v->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(v->bounce, slot_ptr(v, stream, slot), bytes, hipMemcpyDeviceToHost, st));
+    launch_relayout(v, slot_ptr(v, stream, slot), 0, (uint32_t)bytes, 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(v->bounce, v->d_linear, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (y)
         memcpy(y, v->bounce, v->info.luma_bytes);
@@ -1421,17 +1468,29 @@ int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
     v->rgba_sync[(size_t)stream * MPEGHIP_SLOTS + slot] = 0; // the slot's RGBA image is out of date now
     HIP_TRY(hipSetDevice(v->ctx->device));
-    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    int rc = ensure_linear(v);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    hipStream_t st = v->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(st));
     uint8_t *p = slot_ptr(v, stream, slot);
-    if (y)
-        HIP_TRY(hipMemcpy(p, y, v->info.luma_bytes, hipMemcpyHostToDevice));
-    if (cb)
-        HIP_TRY(hipMemcpy(p + v->info.luma_bytes, cb, v->info.chroma_bytes, hipMemcpyHostToDevice));
-    if (cr)
-        HIP_TRY(hipMemcpy(p + v->info.luma_bytes + v->info.chroma_bytes, cr, v->info.chroma_bytes, hipMemcpyHostToDevice));
-    if (pad)
-        HIP_TRY(hipMemcpy(p + v->info.luma_bytes + 2 * v->info.chroma_bytes, pad, (size_t)v->info.luma_w * 16,
-                          hipMemcpyHostToDevice));
+    const uint32_t L = (uint32_t)v->info.luma_bytes, Cb = (uint32_t)v->info.chroma_bytes;
+    if (y) {
+        HIP_TRY(hipMemcpy(v->d_linear, y, L, hipMemcpyHostToDevice));
+        launch_relayout(v, p, 0, L, 0);
+    }
+    if (cb) {
+        HIP_TRY(hipMemcpy(v->d_linear + L, cb, Cb, hipMemcpyHostToDevice));
+        launch_relayout(v, p, L, Cb, 0);
+    }
+    if (cr) {
+        HIP_TRY(hipMemcpy(v->d_linear + L + Cb, cr, Cb, hipMemcpyHostToDevice));
+        launch_relayout(v, p, L + Cb, Cb, 0);
+    }
+    HIP_TRY(hipGetLastError());
+    if (pad) // (the pad stays linear)
+        HIP_TRY(hipMemcpyAsync(p + L + 2 * Cb, pad, (size_t)v->info.luma_w * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return MPEGHIP_OK;
 }
 
@@ -1457,9 +1516,9 @@ int mpeghip_video_hash_slots(mpeghip_video *v, uint32_t slot, uint64_t *out)
     if (!v || !out || slot >= MPEGHIP_SLOTS)
         return fail(MPEGHIP_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(v->ctx->device));
-    const uint64_t n_bytes = v->info.luma_bytes + 2 * v->info.chroma_bytes; // multiple of 128
     hipLaunchKernelGGL(hash_kernel, dim3((v->info.n_streams + 63) / 64), dim3(64), 0, v->ctx->stream, v->d_frames,
-                       v->info.frame_stride, slot, n_bytes, v->info.n_streams, v->d_hash);
+                       v->info.frame_stride, slot, v->info.mb_w, (uint32_t)v->info.luma_bytes, (uint32_t)v->info.chroma_bytes,
+                       v->info.n_streams, v->d_hash);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
     HIP_TRY(hipMemcpy(out, v->d_hash, (size_t)v->info.n_streams * 8, hipMemcpyDeviceToHost));
@@ -1489,7 +1548,7 @@ int mpeghip_video_rgba_convert(mpeghip_video *v, uint32_t slot, uint32_t stream0
         const uint32_t ns = n - s0 < 32768 ? n - s0 : 32768;
         dim3 grid((quads + 63) / 64, (in.height + 7) / 8, ns);
         hipLaunchKernelGGL(rgba_kernel, grid, dim3(256), 0, v->ctx->stream, v->d_frames, in.frame_stride, v->d_rgba,
-                           rgba_stride_of(v), in.luma_w, in.chroma_w, (uint32_t)in.luma_bytes, (uint32_t)in.chroma_bytes,
+                           rgba_stride_of(v), in.mb_w, (uint32_t)in.luma_bytes, (uint32_t)in.chroma_bytes,
                            in.width, in.height, slot, stream0 + s0);
         HIP_TRY(hipGetLastError());
     }

@@ -16,7 +16,8 @@ namespace mpg {
 struct VideoArgs {
     uint8_t *frames;              // base of the frame store
     uint64_t frame_stride;        // bytes between consecutive (stream, slot) frames
-    uint32_t luma_w, luma_h;      // padded plane sizes
+    uint32_t mb_w, mb_h;          // macroblocks per row / column
+    uint32_t luma_w, luma_h;      // padded plane sizes = 16 mb_w, 16 mb_h
     uint32_t chroma_w, chroma_h;
     uint32_t luma_bytes, chroma_bytes;
     const mpeghip_pic_desc *pics; // (whole-frame RGBA pass only)
@@ -28,6 +29,34 @@ struct VideoArgs {
     uint8_t *rgba;                // base of RGBA images, same (stream, slot) indexing
     uint64_t rgba_stride;
 };
+
+// ---- frame layout in HBM.  A slot holds the reference's `base` slice (video.go:338-355: Y | Cb | Cr | pad), but the
+// planes are TILED in macroblock order: luma as 16x16 tiles of 256 bytes (row-major inside, 16 bytes per row), Cb and
+// Cr as 8x8 blocks of 64 bytes (8 bytes per row); the pad (luma_w * 16 zero bytes) and the slack stay as they are.
+// Why: motion compensation reads a 17 x 17 (9 x 9) window at an arbitrary position per macroblock.  In a row-major
+// plane that is one cache line PER ROW (35 rows -> ~39 lines, 11 useful bytes per line requested), and the number of
+// lines a wave requests is what bounded the kernel (profiles/r2t_ab_tiled_access_pattern.txt: the same kernel with a
+// tile-like access pattern ran 30 % faster).  Tiled, a window touches 2 x 3 luma lines and ~2 x 3 chroma lines; a
+// macroblock's output is 256 + 64 + 64 CONTIGUOUS bytes.  The linear view of the reference (plane reads, hashes,
+// Frame.RGBA, and its reads past a plane's edge) is kept exactly: see linear_to_tiled and the kernel's slow path.
+MPG_HD uint32_t tiled_luma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 4) * mb_w + (x >> 4)) * 256 + (y & 15) * 16 + (x & 15); }
+MPG_HD uint32_t tiled_chroma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 3) * mb_w + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7); }
+// byte offset inside a slot in the reference's (linear) layout -> where that byte lives.  A dword-aligned linear dword
+// stays one dword (tile rows are 16 / 8 bytes and plane widths multiples of them).
+MPG_HD uint32_t linear_to_tiled(uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_bytes, uint32_t L)
+{
+    const uint32_t luma_w = mb_w * 16, chroma_w = mb_w * 8;
+    if (L < luma_bytes)
+        return tiled_luma(mb_w, L % luma_w, L / luma_w);
+    uint32_t c = L - luma_bytes, plane = luma_bytes;
+    if (c >= chroma_bytes) {
+        c -= chroma_bytes;
+        plane += chroma_bytes;
+        if (c >= chroma_bytes)
+            return L; // pad / slack: linear
+    }
+    return plane + tiled_chroma(mb_w, c % chroma_w, c / chroma_w);
+}
 
 // Descriptors are read-only for the whole launch.  On the device they are read through the constant
 // address space so that the compiler keeps them as scalar (s_load) instructions.
@@ -183,18 +212,17 @@ MPG_HD void rgba_store4(uint32_t *dst, uint64_t p, const uint32_t (&px)[4], uint
     }
 }
 
-MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t luma_w, uint32_t chroma_w,
-                              uint32_t luma_bytes, uint32_t chroma_bytes,
+MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_bytes,
                               uint32_t width, uint32_t height, uint32_t x4, uint32_t yp, uint8_t *rgba)
 {
     const uint32_t x0 = x4 * 4, y = yp * 2;
     if (y >= height || x0 >= width)
         return;
     const bool two = y + 1 < height;
-    const uint8_t *yrow = frame + (uint64_t)y * luma_w + x0;
-    const uint32_t yy0 = *reinterpret_cast<const uint32_t *>(yrow);
-    const uint32_t yy1 = *reinterpret_cast<const uint32_t *>(yrow + (two ? luma_w : 0));
-    const uint8_t *cbp = frame + luma_bytes + (uint64_t)yp * chroma_w + (x0 >> 1);
+    // (a quad of 4 luma pixels lies inside one tile row, its 2 chroma samples inside one block row)
+    const uint32_t yy0 = *reinterpret_cast<const uint32_t *>(frame + tiled_luma(mb_w, x0, y));
+    const uint32_t yy1 = *reinterpret_cast<const uint32_t *>(frame + tiled_luma(mb_w, x0, two ? y + 1 : y));
+    const uint8_t *cbp = frame + luma_bytes + tiled_chroma(mb_w, x0 >> 1, yp);
     const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp);
     const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + chroma_bytes);
     uint32_t px0[4], px1[4];

@@ -11,11 +11,14 @@
 //                   h3 index (into words) of the chunk's first block word     h4 of its first coefficient entry
 //                   h5 entries of pass 0 | pass 1 << 10 | pass 2 << 20 | kCRun | kCRgba
 //                   h6 coded blocks (0..24) | live macroblocks << 8 | any snapshot block << 16 | any dense block << 17
-//           record  d0 kR* flags | luma shift << 6 | cbp << 8 | chroma shift << 14 | mb_x << 16 | mb_y << 24
-//                   d1 reference frame offset >> 8
-//                   d2 byte offset (inside the frame) of the luma prediction window (origin + integer vector),
-//                      rounded DOWN to a dword; the 0..3 bytes it lost are the "shift"
-//                   d3 the same for Cb (plane offset included; Cr = + chroma_bytes)
+//           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24        d1 reference frame offset >> 8
+//                   d2 the luma prediction window, origin (x0, y0) = macroblock origin + integer vector:
+//                      byte offset (inside the frame) of the 16x16 TILE that holds (x0, y0) | (y0 & 15) << 4 | x0 & 15
+//                   d3 the same for Cb: offset of the 8x8 block (plane offset included; Cr = + chroma_bytes)
+//                      | (cy0 & 7) << 3 | cx0 & 7
+//                   kRSlow records (a window that leaves its plane: the reference reads on, linearly, into the next
+//                   row / plane / the pad, video_noasm.go:48-80) carry the window origins as LINEAR byte offsets
+//                   of the reference's layout instead; the kernel gathers those windows dword by dword
 //   words   per chunk, one after the other (a wave's loads share cache lines):
 //           block words, one per coded block, in (macroblock, block) order = "slot" order:
 //                   LDS byte offset / 8 of the block's row 0 in the output bytes | chroma << 9 | snapshot << 10
@@ -37,9 +40,9 @@
 //      the first 64 entries (one dword per lane), and six direct-to-LDS loads (global_load_lds_dwordx4: lane
 //      l's 16 bytes land at LDS base + 16 l, no registers in between, scalar base + 32-bit lane offset): the
 //      stream's dequantisation table (12 lanes), the chunk's block words (6 lanes), and per macroblock its
-//      whole prediction window as 52 PIECES: 17 luma rows x 2 pieces + 2 x 9 chroma rows x 1 piece.
-//      Pieces start on DWORD boundaries (the window's byte offset, wave-uniform, is applied when the taps are
-//      read).  No registers hold prediction data (the first version of this kernel kept 32 of them and needed
+//      whole prediction window as 54 PIECES: 17 luma rows x 2 tile rows (16 bytes each) + per chroma plane 5 row
+//      PAIRS x 2 blocks (a 16-byte piece = 2 rows of an 8x8 block).  Pieces are whole tile rows; the window's byte
+//      offset inside them (wave-uniform) is applied when the taps are read.  No registers hold prediction data (the first version of this kernel kept 32 of them and needed
 //      19 load instructions per wave, with ds_bpermute for the row below).
 //   2  residual pass (8 coded blocks at a time): zero the wave's int32 tile T[8][64]; one entry per lane:
 //      dequantise (video.go:719-744) and scatter to T[slot & 7][position]; lane (g, j): column j of block
@@ -53,8 +56,8 @@
 //   5  the four O_m leave as whole 64-byte luma / 32-byte chroma rows when the chunk is a horizontal run
 //      (kCRun), else as 8-byte rows per block; pictures flagged MPEGHIP_PIC_RGBA are colour-converted from them.
 //
-// Wave-private LDS, 5664 bytes (7 waves per SIMD):
-//      [   0,  192) table    [ 192,  288) 24 block words    [ 288 + 832 m, + 832) window m -> O_m    [3616, 5664) T
+// Wave-private LDS, 5792 bytes (7 waves per SIMD):
+//      [   0,  192) table    [ 192,  288) 24 block words    [ 288 + 864 m, + 864) window m -> O_m    [3744, 5792) T
 #pragma once
 
 #include "video_lane.h"
@@ -69,7 +72,7 @@ constexpr int kRcMbs = 4;                     // macroblocks per chunk = per wav
 constexpr int kRcMaxBlocks = 6 * kRcMbs;      // 24 slots, 3 passes of 8
 constexpr int kRcChunkDwords = 8 + 4 * kRcMbs;
 constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                                    // header h5
-constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32;  // record d0
+constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32, kRSlow = 64; // record d0
 constexpr uint32_t kBChroma = 1u << 9, kBRaw = 1u << 10, kBDense = 1u << 11;               // block word
 constexpr uint32_t kDenseAbove = 32; // non-zero levels beyond which a block travels as a dense unit
 constexpr uint32_t kEDc = 1, kENonIntra = 2;                                               // entry
@@ -77,16 +80,16 @@ constexpr uint32_t kEDc = 1, kENonIntra = 2;                                    
 // wave-private LDS
 constexpr int kRcPiece = 16;                  // bytes per lane of a direct-to-LDS load
 constexpr int kRcWinLuma = 17 * 2 * kRcPiece; // 544: 17 rows x 32 bytes
-constexpr int kRcWinLanes = 52;               // + 2 planes x 9 rows x 1 piece
-constexpr int kRcWinBytes = kRcWinLanes * kRcPiece; // 832
+constexpr int kRcWinLanes = 54;               // + 2 planes x 5 row pairs x 2 blocks
+constexpr int kRcWinBytes = kRcWinLanes * kRcPiece; // 864
 constexpr int kRcQtabBytes = 192;             // [64 positions][{intra, non-intra} matrix entry] + [64] premultiplier
 constexpr int kRcQtabStride = 256;            // per stream in HBM
 constexpr int kRcQtabAt = 0;
 constexpr int kRcBlkAt = kRcQtabBytes;        // 192: 24 block words = 6 pieces
 constexpr int kRcWinAt = kRcBlkAt + 96;       // 288
-constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3616
+constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3744
 constexpr int kRcTileBytes = 8 * 64 * 4;      // T: int32 [8 blocks][64]
-constexpr int kRcLdsBytes = kRcTileAt + kRcTileBytes; // 5664
+constexpr int kRcLdsBytes = kRcTileAt + kRcTileBytes; // 5792
 
 // LDS byte offset of macroblock m's window, later its output bytes O_m: luma [16 rows][16] | Cb [8][8] | Cr [8][8]
 MPG_HD uint32_t rc_win_at(uint32_t m) { return kRcWinAt + m * kRcWinBytes; }
@@ -101,7 +104,7 @@ MPG_HD uint32_t rc_tile_offset(int b, int j, uint32_t m)
 
 // ===================================================================== host half: the packer
 struct RcGeom {
-    uint32_t luma_w, chroma_w, luma_bytes;
+    uint32_t mb_w, mb_h, luma_w, chroma_w, luma_bytes;
     uint64_t frame_stride, rgba_stride;
 };
 
@@ -176,7 +179,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         } slot[kRcMaxBlocks];
         uint32_t n_slots = 0;
         uint32_t *bw = words_out + out.words;
-        bool run = live == (uint32_t)kRcMbs && (mbs[k0].mb_x & 3) == 0;
+        bool run = live == (uint32_t)kRcMbs; // 4 consecutive macroblocks of one row = 4 consecutive tiles
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++) {
             uint32_t *d = h + 8 + m * 4;
             if (m >= live) { // padding behind the picture's last macroblock
@@ -199,12 +202,21 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 d0 |= (cmy & 1) ? kROvC : 0;
                 const int32_t dst_luma = (int32_t)((uint32_t)mb.mb_y << 4) * (int32_t)g.luma_w + (int32_t)((uint32_t)mb.mb_x << 4);
                 const int32_t dst_chroma = (int32_t)((uint32_t)mb.mb_y << 3) * (int32_t)g.chroma_w + (int32_t)((uint32_t)mb.mb_x << 3);
-                const uint32_t src_luma = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
-                const uint32_t src_chroma = g.luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)g.chroma_w + (cmx >> 1));
-                d[0] = d0 | ((src_luma & 3) << 6) | ((src_chroma & 3) << 14); // (frames and planes start on 64-byte boundaries)
+                // window origins in pixels; inside their planes (the normal case) the tiles are addressed directly
+                const int32_t x0 = (int32_t)((uint32_t)mb.mb_x << 4) + (mvx >> 1), y0 = (int32_t)((uint32_t)mb.mb_y << 4) + (mvy >> 1);
+                const int32_t cx0 = (int32_t)((uint32_t)mb.mb_x << 3) + (cmx >> 1), cy0 = (int32_t)((uint32_t)mb.mb_y << 3) + (cmy >> 1);
+                const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (mvx & 1) <= (int32_t)g.luma_w && y0 + 16 + (mvy & 1) <= (int32_t)(g.mb_h << 4) &&
+                                    cx0 >= 0 && cy0 >= 0 && cx0 + 8 + (cmx & 1) <= (int32_t)g.chroma_w && cy0 + 8 + (cmy & 1) <= (int32_t)(g.mb_h << 3);
                 d[1] = (mb.flags & MPEGHIP_MB_REF_BWD) ? bwd256 : fwd256;
-                d[2] = src_luma & ~3u;
-                d[3] = src_chroma & ~3u;
+                if (inside) {
+                    d[0] = d0;
+                    d[2] = (((uint32_t)y0 >> 4) * g.mb_w + ((uint32_t)x0 >> 4)) * 256 | (((uint32_t)y0 & 15) << 4) | ((uint32_t)x0 & 15);
+                    d[3] = (g.luma_bytes + (((uint32_t)cy0 >> 3) * g.mb_w + ((uint32_t)cx0 >> 3)) * 64) | (((uint32_t)cy0 & 7) << 3) | ((uint32_t)cx0 & 7);
+                } else { // the reference's linear reads (validated: inside [plane start, end of base))
+                    d[0] = d0 | kRSlow;
+                    d[2] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
+                    d[3] = g.luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)g.chroma_w + (cmx >> 1));
+                }
             }
             run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
                   (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
@@ -308,30 +320,50 @@ MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[6] >> 8) & 0xff; }
 MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[6] >> 16) & 1; }
 MPG_HD bool rc_any_dense(const RcChunk &c) { return (c.h[6] >> 17) & 1; }
 MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[5] >> (10 * pass)) & 0x3ff; }
-MPG_HD uint32_t rc_shift_luma(uint32_t d0) { return (d0 >> 6) & 3; }
-MPG_HD uint32_t rc_shift_chroma(uint32_t d0) { return (d0 >> 14) & 3; }
 
 // what depends on the lane only (worked out once per wave)
 struct RcLane {
-    uint32_t piece_off;   // as lane of a window load (piece `lane` < 52): byte offset from the luma / Cb window origin
-    uint32_t piece_chroma; // all ones if that piece is chroma, else 0
-    uint32_t mc_luma;     // as MC lane (row lane>>2, quarter lane&3): LDS offset of its taps inside a window = (lane>>2)*32 + (lane&3)*4
-    uint32_t mc_chroma;   // lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1): kRcWinLuma + (plane*9 + row)*16 + half*4
-    uint32_t out_luma;    // where the lane's 4 luma bytes go inside O_m: lane * 4
-    uint32_t out_chroma;  // 4 chroma bytes: 256 + lane * 4
+    // as lane of a window load (piece `lane` < 54): luma pieces (lane < 34) are (row lane>>1, tile column lane&1),
+    // chroma pieces (plane, row pair, block column); frame offset of a piece = base + (t >> sh) * stride + (t & msk) * 16
+    // + cterm with t = (window origin's row / row pair inside its tile) + rj
+    uint32_t piece_chroma; // all ones if the piece is chroma, else 0
+    uint32_t rj;           // luma: row 0..16; chroma: row pair 0..4
+    uint32_t sh, msk;      // 4, 15 (16 rows per tile) / 2, 3 (4 row pairs per block)
+    uint32_t stride;       // bytes from a tile (block) to the one below: mb_w * 256 / mb_w * 64
+    uint32_t cterm;        // tile column * 256 / plane * chroma_bytes + block column * 64
+    uint32_t lin_off;      // the same piece of a LINEAR window (kRSlow; lanes < 52): luma row * luma_w + column * 16 /
+                           // plane * chroma_bytes + row * chroma_w (17 rows x 2, then 9 rows per plane)
+    uint32_t lin_chroma;
+    uint32_t mc_luma;      // as MC lane (row lane>>2, quarter lane&3): LDS offset of its taps inside a window = (lane>>2)*32 + (lane&3)*4
+    uint32_t mc_plane;     // lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1): plane * 160 — tiled chroma pieces
+    uint32_t mc_lin;       // linear chroma rows: kRcWinLuma + (plane*9 + row)*16 + half*4
+    uint32_t out_luma;     // where the lane's 4 luma bytes go inside O_m: lane * 4
+    uint32_t out_chroma;   // 4 chroma bytes: 256 + lane * 4
 };
 
 MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
 {
     const uint32_t l = (uint32_t)lane;
     RcLane k;
-    // piece l of a window: luma 17 rows x 2 pieces, then Cb, Cr with 9 rows x 1 piece each
-    const bool chroma = l >= 34;
-    const uint32_t ci = l - 34, plane = ci >= 9 ? 1u : 0u;
-    k.piece_chroma = chroma ? ~0u : 0u;
-    k.piece_off = chroma ? plane * a.chroma_bytes + (ci - plane * 9) * a.chroma_w : (l >> 1) * a.luma_w + (l & 1) * kRcPiece;
+    {
+        const bool chroma = l >= 34;
+        const uint32_t ci = l - 34, plane = ci >= 10 ? 1u : 0u, cj = ci - plane * 10;
+        k.piece_chroma = chroma ? ~0u : 0u;
+        k.rj = chroma ? cj >> 1 : l >> 1;
+        k.sh = chroma ? 2 : 4;
+        k.msk = chroma ? 3 : 15;
+        k.stride = chroma ? a.mb_w * 64 : a.mb_w * 256;
+        k.cterm = chroma ? plane * a.chroma_bytes + (cj & 1) * 64 : (l & 1) * 256;
+    }
+    {
+        const bool chroma = l >= 34;
+        const uint32_t ci = l - 34, plane = ci >= 9 ? 1u : 0u;
+        k.lin_chroma = chroma ? ~0u : 0u;
+        k.lin_off = chroma ? plane * a.chroma_bytes + (ci - plane * 9) * a.chroma_w : (l >> 1) * a.luma_w + (l & 1) * kRcPiece;
+    }
     k.mc_luma = (l >> 2) * 32 + (l & 3) * 4;
-    k.mc_chroma = kRcWinLuma + (((l >> 4) & 1) * 9 + ((l >> 1) & 7)) * kRcPiece + (l & 1) * 4;
+    k.mc_plane = ((l >> 4) & 1) * 160;
+    k.mc_lin = kRcWinLuma + (((l >> 4) & 1) * 9 + ((l >> 1) & 7)) * kRcPiece + (l & 1) * 4;
     k.out_luma = l * 4;
     k.out_chroma = 256 + l * 4;
     return k;
@@ -342,21 +374,41 @@ MPG_HD const uint32_t *rc_ent_src(const VideoArgs &a, const RcChunk &c, uint32_t
 {
     return a.words + c.h[4] + at + (uint32_t)lane; // (beyond the pass's entries: ignored; the array is padded)
 }
-// The six direct-to-LDS loads of a wave, issued by lanes 0..51 in this order: the table (12 pieces), the chunk's 24
-// block words (6 pieces), windows 0..3 (52 pieces each).  All 52 lanes take part in every one of them (one asm
+// The six direct-to-LDS loads of a wave, issued by lanes 0..53 in this order: the table (12 pieces), the chunk's 24
+// block words (6 pieces), windows 0..3 (54 pieces each).  All 54 lanes take part in every one of them (one asm
 // statement, one EXEC): the table's and the block words' surplus lanes fetch 16 bytes that a LATER load of the same
-// wave overwrites — loads complete in order (tools/microbench/lds_dma_probe3.hip) and the
-// windows cover [kRcWinAt, kRcTileAt) completely.  Surplus lanes read valid memory: the table's run on into the
-// next streams' tables (the table array is padded by 1 KB), the block words' into the words array (padded).
+// wave overwrites — loads complete in order (tools/microbench/lds_dma_probe3.hip) and the windows cover
+// [kRcWinAt, kRcTileAt) completely.  Surplus lanes read valid memory: the table's run on into the next streams' tables
+// (the table array is padded by 1 KB), the block words' into the words array (padded).
 MPG_HD const uint8_t *rc_table_src(const VideoArgs &a, const RcChunk &c) { return a.qmat + c.h[2]; }
 MPG_HD const uint8_t *rc_blk_src(const VideoArgs &a, const RcChunk &c) { return reinterpret_cast<const uint8_t *>(a.words + c.h[3]); }
-// window m (lanes 0..51): scalar base = the reference frame, lane offset = window origin (luma or Cb) + piece.
-// (Intra / dead macroblocks name the head of the frame store as their window: valid memory, never used.)
-// No select between the two scalars: the compiler turns those into indexed loads from scratch.
+// window m: scalar base = the reference frame, lane offset = the piece's tile row.  Intra, dead and kRSlow macroblocks
+// fetch the head of the frame store instead: valid memory, never used (a kRSlow window is gathered afterwards).
+// No selects between scalars: the compiler turns those into indexed loads from scratch.
 MPG_HD const uint8_t *rc_win_base(const VideoArgs &a, const RcChunk &c, int m) { return a.frames + ((uint64_t)c.r[m][1] << 8); }
 MPG_HD uint32_t rc_win_offset(const RcChunk &c, int m, const RcLane &k)
 {
-    return c.r[m][2] + (k.piece_chroma & (c.r[m][3] - c.r[m][2])) + k.piece_off;
+    const uint32_t tiled = (c.r[m][0] & (kRIntra | kRDead | kRSlow)) ? 0u : ~0u; // (wave-uniform)
+    const uint32_t d2 = c.r[m][2] & tiled, d3 = c.r[m][3] & tiled;
+    const uint32_t base_l = d2 & ~255u, sub_l = (d2 >> 4) & 15;     // tile of the window origin, its row inside the tile
+    const uint32_t base_c = d3 & ~63u, sub_c = (d3 >> 4) & 3;      // block of the origin, its row PAIR inside the block
+    const uint32_t base = base_l + (k.piece_chroma & (base_c - base_l));
+    const uint32_t t = sub_l + (k.piece_chroma & (sub_c - sub_l)) + k.rj;
+    return base + (t >> k.sh) * k.stride + (t & k.msk) * 16 + k.cterm;
+}
+
+// a kRSlow window (it leaves its plane): the reference's LINEAR reads, gathered dword by dword through
+// linear_to_tiled.  Lane < 52 = piece of the linear window layout: luma 17 rows x 32 bytes from the dword below the
+// origin, then per chroma plane 9 rows x 16 bytes.  Returns the piece's 16 bytes.
+MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k)
+{
+    const uint8_t *ref = rc_win_base(a, c, m);
+    const uint32_t origin = ((k.lin_chroma ? c.r[m][3] : c.r[m][2]) & ~3u) + k.lin_off;
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        v.v[i] = *reinterpret_cast<const uint32_t *>(ref + linear_to_tiled(a.mb_w, a.luma_bytes, a.chroma_bytes, origin + 4 * i));
+    return v;
 }
 
 // ---- step 2: the residual pass
@@ -439,22 +491,67 @@ MPG_HD void rc_cols_store(int32_t *T, int lane, const int32_t (&v)[8])
 MPG_HD void rc_rows_load(const int32_t *T, int lane, int32_t (&v)[8]) { rc_cols_load(T, lane, v); } // T[g][j * 8 + c] now
 
 // ---- step 3: motion compensation of 4 pixels (video_noasm.go:48-80); shift / oh / ov are wave-uniform.
-// `taps` -> the two aligned dwords that hold the pixels (they start `shift` bytes in) and their right neighbour;
-// the same one row below is `below` bytes further on.
-MPG_HD uint32_t rc_mc4(const uint8_t *taps, uint32_t below, uint32_t shift, bool oh, bool ov)
+// a0 a1: the two dwords that hold the pixels (they start `shift` < 4 bytes in) and their right neighbour; b0 b1 the
+// same one row below.
+MPG_HD uint32_t rc_mc4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t shift, bool oh, bool ov)
 {
-    const uint32_t *t = reinterpret_cast<const uint32_t *>(taps);
-    const uint64_t a = (uint64_t)t[0] | ((uint64_t)t[1] << 32); // (dword-aligned, not 8-byte aligned: two 4-byte reads)
+    const uint64_t a = (uint64_t)a0 | ((uint64_t)a1 << 32), b = (uint64_t)b0 | ((uint64_t)b1 << 32);
     const uint32_t p00 = (uint32_t)(a >> (8 * shift));
     if (!oh && !ov)
         return p00;
     if (!ov)
         return avg_ceil_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)));
-    const uint32_t *u = reinterpret_cast<const uint32_t *>(taps + below);
-    const uint64_t b = (uint64_t)u[0] | ((uint64_t)u[1] << 32);
     if (!oh)
         return avg_ceil_u8x4(p00, (uint32_t)(b >> (8 * shift)));
     return avg4_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)), (uint32_t)(b >> (8 * shift)), (uint32_t)(b >> (8 * shift + 8)));
+}
+
+// the window's byte offsets inside its first pieces (wave-uniform, from the record)
+struct RcTaps {
+    uint32_t luma_x;   // 0..15 (kRSlow: 0..3): the window starts this many bytes into its rows in LDS
+    uint32_t chroma_x; // 0..7 (kRSlow: 0..3)
+    uint32_t chroma_y; // 0 / 1: the window starts on the odd row of its first row pair (kRSlow: unused)
+    bool slow;
+};
+MPG_HD RcTaps rc_taps(uint32_t d0, uint32_t d2, uint32_t d3)
+{
+    RcTaps t;
+    t.slow = (d0 & kRSlow) != 0;
+    t.luma_x = t.slow ? d2 & 3 : d2 & 15;
+    t.chroma_x = t.slow ? d3 & 3 : d3 & 7;
+    t.chroma_y = (d3 >> 3) & 1;
+    return t;
+}
+
+// luma, lane (row lane>>2, quarter lane&3): rows are 32 contiguous bytes in the window
+MPG_HD uint32_t rc_mc_luma(const uint8_t *win, const RcLane &k, const RcTaps &t, bool oh, bool ov)
+{
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_luma + (t.luma_x & ~3u));
+    return rc_mc4(p[0], p[1], p[8], p[9], t.luma_x & 3, oh, ov); // (+ 8 dwords: the row below)
+}
+
+// chroma, lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1).  Tiled windows: a row's 16 bytes are two halves
+// of 8 in the pieces of the two blocks: row r of the window = row ((chroma_y + r) & 1) of pair (chroma_y + r) >> 1.
+MPG_HD uint32_t rc_chroma_row_at(uint32_t plane160, uint32_t row, uint32_t dword)
+{   // LDS offset of dword `dword` (0..3) of window row `row` (0..9, counted from the even row the first pair starts on)
+    return kRcWinLuma + plane160 + (row >> 1) * 32 + (row & 1) * 8 + (dword & 1) * 4 + (dword >> 1) * 16;
+}
+MPG_HD uint32_t rc_mc_chroma(const uint8_t *win, const RcLane &k, const RcTaps &t, int lane, bool oh, bool ov)
+{
+    if (t.slow) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_lin);
+        return rc_mc4(p[0], p[1], p[4], p[5], t.chroma_x, oh, ov); // (+ 4 dwords: the row below)
+    }
+    const uint32_t row = t.chroma_y + (((uint32_t)lane >> 1) & 7), q = t.chroma_x + ((uint32_t)lane & 1) * 4; // bytes q .. q+4 of the row
+    const uint32_t i = q >> 2;                                                                             // 0..2
+    const uint32_t a0 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row, i));
+    const uint32_t a1 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row, i + 1));
+    uint32_t b0 = 0, b1 = 0;
+    if (ov) {
+        b0 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row + 1, i));
+        b1 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row + 1, i + 1));
+    }
+    return rc_mc4(a0, a1, b0, b1, q & 3, oh, ov);
 }
 
 // ---- step 4: residual row + the 8 prediction bytes in O_m -> clamped bytes (video.go:943-971)
@@ -465,30 +562,22 @@ MPG_HD void rc_rmw(uint8_t *lds, uint32_t bw, int lane, const int32_t (&v)[8])
     *reinterpret_cast<uint64_t *>(p) = add_clamp_pack8(pred, v);
 }
 
-// ---- step 5: stores
-// frame byte offset of macroblock (mb_x, mb_y)'s origin: luma / Cb plane
-MPG_HD uint32_t rc_dst_luma(const VideoArgs &a, uint32_t d0) { return ((d0 >> 24) << 4) * a.luma_w + (((d0 >> 16) & 0xff) << 4); }
-MPG_HD uint32_t rc_dst_chroma(const VideoArgs &a, uint32_t d0)
-{
-    return a.luma_bytes + ((d0 >> 24) << 3) * a.chroma_w + (((d0 >> 16) & 0xff) << 3);
-}
+// ---- step 5: stores (tiled frame: a macroblock's luma is 256 contiguous bytes, its Cb and Cr 64 each)
+MPG_HD uint32_t rc_mb_index(const VideoArgs &a, uint32_t d0) { return (d0 >> 24) * a.mb_w + ((d0 >> 16) & 0xff); }
 
-// horizontal run: luma 16 rows x 64 bytes by all 64 lanes (row lane>>2, macroblock lane&3), chroma 2 x 8 rows x
-// 32 bytes by lanes 0..31 (plane lane>>4, row (lane>>1)&7, macroblocks 2*(lane&1) and 2*(lane&1)+1)
+// horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), Cb and Cr 256 bytes each by lanes 0..31
 MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
 {
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8);
-    const uint32_t l = (uint32_t)lane;
+    const uint32_t l = (uint32_t)lane, mb0 = rc_mb_index(a, c.r[0][0]);
     {
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l & 3) + (l >> 2) * 16);
-        *reinterpret_cast<u32x4 *>(cur + rc_dst_luma(a, c.r[0][0]) + (l >> 2) * a.luma_w + (l & 3) * 16) = v;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16);
+        *reinterpret_cast<u32x4 *>(cur + mb0 * 256 + l * 16) = v;
     }
     if (lane < 32) {
-        const uint32_t plane = l >> 4, row = (l >> 1) & 7, m = (l & 1) * 2;
-        const uint64_t lo = *reinterpret_cast<const uint64_t *>(lds + rc_win_at(m) + 256 + plane * 64 + row * 8);
-        const uint64_t hi = *reinterpret_cast<const uint64_t *>(lds + rc_win_at(m + 1) + 256 + plane * 64 + row * 8);
-        const u32x4 v = {{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)}};
-        *reinterpret_cast<u32x4 *>(cur + rc_dst_chroma(a, c.r[0][0]) + plane * a.chroma_bytes + row * a.chroma_w + (l & 1) * 16) = v;
+        const uint32_t plane = l >> 4, m = (l >> 2) & 3, part = l & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(m) + 256 + plane * 64 + part * 16);
+        *reinterpret_cast<u32x4 *>(cur + a.luma_bytes + plane * a.chroma_bytes + mb0 * 64 + (l & 15) * 16) = v;
     }
 }
 
@@ -502,11 +591,12 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
         return;
     const uint32_t d0 = c.r[m][0];
     const bool written = !(d0 & kRIntra) || ((d0 >> 8) & 0x3f & (0x20u >> b)) != 0;
+    const uint32_t mb = rc_mb_index(a, d0);
     uint32_t off;
     if (b < 4)
-        off = rc_dst_luma(a, d0) + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * a.luma_w + ((uint32_t)(b & 1) << 3);
+        off = mb * 256 + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 16 + ((uint32_t)(b & 1) << 3);
     else
-        off = rc_dst_chroma(a, d0) + (uint32_t)(b - 4) * a.chroma_bytes + (uint32_t)j * a.chroma_w;
+        off = a.luma_bytes + (uint32_t)(b - 4) * a.chroma_bytes + mb * 64 + (uint32_t)j * 8;
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + off;
     uint8_t *t = lds + rc_tile_offset(b, j, m);
     if (written)

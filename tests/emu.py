@@ -43,6 +43,8 @@ def lib():
         L.emu_make_qtable.argtypes = [P, P, P]
         L.emu_pack.restype = C.c_uint32
         L.emu_pack.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, P, P, P]
+        L.emu_relayout.restype = None
+        L.emu_relayout.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
         L.emu_rgba_convert.restype = None
         L.emu_rgba_convert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P]
         L.emu_audio_run.restype = C.c_int
@@ -107,12 +109,15 @@ class EmuStore:
     def read_planes(self, stream, slot):
         f, g = self._slot(stream, slot), self.g
         L, Cb = g["luma_bytes"], g["chroma_bytes"]
-        return f[:L].copy(), f[L:L + Cb].copy(), f[L + Cb:L + 2 * Cb].copy()
+        lin = np.zeros(L + 2 * Cb, np.uint8)    # the frame store is tiled (video_lane.h): untile, as read_planes does
+        lib().emu_relayout(_ptr(f), _ptr(lin), g["luma_w"], g["luma_h"], 1)
+        return lin[:L].copy(), lin[L:L + Cb].copy(), lin[L + Cb:L + 2 * Cb].copy()
 
     def write_planes(self, stream, slot, y, cb, cr, pad=None):
         f, g = self._slot(stream, slot), self.g
         L, Cb = g["luma_bytes"], g["chroma_bytes"]
-        f[:L], f[L:L + Cb], f[L + Cb:L + 2 * Cb] = y, cb, cr
+        lin = np.concatenate([np.asarray(y, np.uint8).reshape(-1), np.asarray(cb, np.uint8).reshape(-1), np.asarray(cr, np.uint8).reshape(-1)])
+        lib().emu_relayout(_ptr(f), _ptr(lin), g["luma_w"], g["luma_h"], 0)
         if pad is not None:
             f[L + 2 * Cb:L + 2 * Cb + g["luma_w"] * 16] = pad
 

@@ -18,6 +18,7 @@ int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, c
                   const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint64_t);
 void emu_make_qtable(uint8_t *, const uint8_t *, const uint8_t *);
 void emu_rgba_convert(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
+void emu_relayout(uint8_t *, uint8_t *, uint32_t, uint32_t, int);
 int emu_audio_run(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t, uint32_t);
 int emu_audio_run_masked(const int32_t *, void *, float *, int32_t *, const float *, uint32_t, uint32_t, int32_t, int32_t, uint32_t,
                          const uint8_t *);
@@ -52,10 +53,11 @@ public:
     }
     void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
-        const uint8_t *f = frames_.data() + slot * stride_;
-        memcpy(y, f, luma_);
-        memcpy(cb, f + luma_, chroma_);
-        memcpy(cr, f + luma_ + chroma_, chroma_);
+        std::vector<uint8_t> lin(luma_ + 2 * chroma_); // the frame store is tiled: untile, as mpeghip_video_read_planes does
+        emu_relayout(frames_.data() + slot * stride_, lin.data(), lw_, lh_, 1);
+        memcpy(y, lin.data(), luma_);
+        memcpy(cb, lin.data() + luma_, chroma_);
+        memcpy(cr, lin.data() + luma_ + chroma_, chroma_);
     }
     void readRGBA(uint32_t slot, uint8_t *dst) override
     {
@@ -146,10 +148,11 @@ public:
     }
     void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
-        const uint8_t *f = frames_.data() + ((size_t)stream * 3 + slot) * stride_;
-        memcpy(y, f, luma_);
-        memcpy(cb, f + luma_, chroma_);
-        memcpy(cr, f + luma_ + chroma_, chroma_);
+        std::vector<uint8_t> lin(luma_ + 2 * chroma_);
+        emu_relayout(frames_.data() + ((size_t)stream * 3 + slot) * stride_, lin.data(), lw_, lh_, 1);
+        memcpy(y, lin.data(), luma_);
+        memcpy(cb, lin.data() + luma_, chroma_);
+        memcpy(cr, lin.data() + luma_ + chroma_, chroma_);
     }
     void readRGBA(uint32_t stream, uint32_t slot, uint8_t *dst) override
     {

@@ -39,6 +39,8 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     VideoArgs a;
     a.frames = frames;
     a.frame_stride = frame_stride;
+    a.mb_w = luma_w / 16;
+    a.mb_h = luma_h / 16;
     a.luma_w = luma_w;
     a.luma_h = luma_h;
     a.chroma_w = luma_w / 2;
@@ -48,6 +50,8 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     if (frame_stride % 256 || rgba_stride % 256)
         abort(); // the chunks name frames in units of 256 bytes
     RcGeom geom;
+    geom.mb_w = a.mb_w;
+    geom.mb_h = a.mb_h;
     geom.luma_w = a.luma_w;
     geom.chroma_w = a.chroma_w;
     geom.luma_bytes = a.luma_bytes;
@@ -151,12 +155,20 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                 continue;
             uint8_t *win = lds + rc_win_at(m);
             uint32_t yl[64], yc[64];
+            if (!(d0 & kRIntra) && (d0 & kRSlow)) {
+                u32x4 piece[52];
+                for (int lane = 0; lane < 52; lane++)
+                    piece[lane] = rc_gather_piece(a, c, m, k[lane]);
+                for (int lane = 0; lane < 52; lane++)
+                    memcpy(win + lane * 16, &piece[lane], 16);
+            }
+            const RcTaps t = rc_taps(d0, c.r[m][2], c.r[m][3]);
             for (int lane = 0; lane < 64; lane++) {
                 yl[lane] = yc[lane] = 0;
                 if (!(d0 & kRIntra)) {
-                    yl[lane] = rc_mc4(win + k[lane].mc_luma, 2 * kRcPiece, rc_shift_luma(d0), (d0 & kROhL) != 0, (d0 & kROvL) != 0);
+                    yl[lane] = rc_mc_luma(win, k[lane], t, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
                     if (lane < 32)
-                        yc[lane] = rc_mc4(win + k[lane].mc_chroma, kRcPiece, rc_shift_chroma(d0), (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+                        yc[lane] = rc_mc_chroma(win, k[lane], t, lane, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
                 }
             }
             for (int lane = 0; lane < 64; lane++) { // (over the window: only after every lane has its taps)
@@ -195,6 +207,8 @@ uint32_t emu_pack(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride, uint6
                   const mpeghip_mb_desc *mbs, const uint8_t *coefs, uint32_t *chunks_out, uint32_t *words_out, uint32_t *n_words)
 {
     RcGeom geom;
+    geom.mb_w = luma_w / 16;
+    geom.mb_h = luma_h / 16;
     geom.luma_w = luma_w;
     geom.chroma_w = luma_w / 2;
     geom.luma_bytes = luma_w * luma_h;
@@ -230,7 +244,21 @@ void emu_rgba_convert(const uint8_t *frame, uint32_t luma_w, uint32_t luma_h, ui
     const uint32_t quads = (width + 3) / 4;
     for (uint32_t y = 0; y < ((height + 7) / 8) * 4; y++) // row pairs
         for (uint32_t x4 = 0; x4 < ((quads + 63) / 64) * 64; x4++)
-            rgba_convert_quad(frame, luma_w, luma_w / 2, luma_w * luma_h, luma_w * luma_h / 4, width, height, x4, y, rgba);
+            rgba_convert_quad(frame, luma_w / 16, luma_w * luma_h, luma_w * luma_h / 4, width, height, x4, y, rgba);
+}
+
+// the reference's linear planes (Y | Cb | Cr, n = luma_bytes + 2 chroma_bytes) <-> a slot of the tiled frame store
+// (what mpeghip_video_read_planes / write_planes do with relayout_kernel)
+void emu_relayout(uint8_t *slot, uint8_t *linear, uint32_t luma_w, uint32_t luma_h, int to_linear)
+{
+    const uint32_t L = luma_w * luma_h, Cb = L / 4;
+    for (uint32_t i = 0; i < L + 2 * Cb; i += 4) {
+        uint8_t *t = slot + linear_to_tiled(luma_w / 16, L, Cb, i);
+        if (to_linear)
+            memcpy(linear + i, t, 4);
+        else
+            memcpy(t, linear + i, 4);
+    }
 }
 
 } // extern "C"
