@@ -36,8 +36,8 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MB_PER_1080P30_STREAM = 8160 * 30
-KERNEL = {False: "recon_kernel<4, false> (one wave = 4 macroblocks; sparse coefficient entries, prediction windows by direct-to-LDS loads)",
-          True: "recon_kernel<4, true> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
+KERNEL = {False: "recon_kernel<1, false> (one wave = 4 macroblocks; sparse coefficient entries, prediction windows by direct-to-LDS loads)",
+          True: "recon_kernel<1, true> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
 def parse_args():

@@ -79,6 +79,21 @@ MPG_HD int32_t mul24(int32_t a, int32_t b)
 #endif
 }
 
+// The same for CHAINS of products (the dequantiser: level * scale * matrix entry): __mul24 is plain arithmetic to the
+// optimiser, which reassociates the chain and, unable to prove 24 bits for its new operands, emits the quarter-rate
+// v_mul_lo_u32.  The instruction itself keeps the association as written.
+MPG_HD int32_t mul24_as_written(int32_t a, int32_t b)
+{
+    MPG_CHECK(a >= -(1 << 23) && a < (1 << 23) && b >= -(1 << 23) && b < (1 << 23));
+#if MPG_ON_DEVICE
+    int32_t r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a * b;
+#endif
+}
+
 MPG_HD int32_t clampi(int32_t x, int32_t lo, int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // ---- packed-byte averages on 4 pixels (video_noasm.go:14-26 roundAvg / bilinAvg)

@@ -965,7 +965,8 @@ static int grow_pinned(mpeghip_video::Staging *sg, size_t need)
     return MPEGHIP_OK;
 }
 
-constexpr int kReconWaves = 4; // waves (= chunks) per workgroup
+constexpr int kReconWaves = 1; // waves (= chunks) per workgroup: waves of a workgroup that finish early keep their slots until the
+                               // last one has (its LDS goes back as a whole) — 1 beats 2 beats 4 (profiles/r2w_ab_waves_per_workgroup.txt)
 
 static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
 {

@@ -114,11 +114,11 @@ MPG_HD int32_t dequant(int32_t q, bool intra, int32_t qsqm, int32_t pm)
     int32_t l = 2 * q;
     if (!intra)
         l += (q >> 31) | 1;
-    l = mul24(l, qsqm) >> 4;          // |l| <= 65535, qsqm <= 31*255
+    l = mul24_as_written(l, qsqm) >> 4; // |l| <= 65535, qsqm <= 31*255
     // "if even, move one toward zero; 0 becomes +1" == (l - (l > 0)) | 1
     l = (l - (l > 0 ? 1 : 0)) | 1;
     l = clampi(l, -2048, 2047);
-    return mul24(l, pm);
+    return mul24_as_written(l, pm);
 }
 
 MPG_HD uint32_t popc6(uint32_t x) { return (uint32_t)__builtin_popcount(x & 0x3f); }

@@ -394,7 +394,7 @@ MPG_HD uint32_t rc_win_offset(const RcChunk &c, int m, const RcLane &k)
     const uint32_t base_c = d3 & ~63u, sub_c = (d3 >> 4) & 3;      // block of the origin, its row PAIR inside the block
     const uint32_t base = base_l + (k.piece_chroma & (base_c - base_l));
     const uint32_t t = sub_l + (k.piece_chroma & (sub_c - sub_l)) + k.rj;
-    return base + (t >> k.sh) * k.stride + (t & k.msk) * 16 + k.cterm;
+    return base + (k.stride & (0u - (t >> k.sh))) + (t & k.msk) * 16 + k.cterm; // (t >> sh is 0 or 1: the tile below)
 }
 
 // a kRSlow window (it leaves its plane): the reference's LINEAR reads, gathered dword by dword through
@@ -433,7 +433,7 @@ MPG_HD void rc_scatter(int32_t *T, const uint8_t *lds, uint32_t e)
     const int32_t pm = Q[128 + ((e >> 2) & 63)];    // [position]
     const int32_t level = (int32_t)e >> 16;
     const int32_t qs = (int32_t)((e >> 11) & 31);
-    const int32_t dq = dequant(level, !(e & kENonIntra), qs * qm, pm);
+    const int32_t dq = dequant(level, !(e & kENonIntra), mul24_as_written(qs, qm), pm);
     T[(e & 0x7fcu) >> 2] = (e & kEDc) ? level * 256 : dq;
 }
 
@@ -464,8 +464,12 @@ MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *l
     const i32x4_a4 lv = *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + j * 4);
     const int32_t qs = (int32_t)((bw >> 26) & 31);
     const bool intra = !(bw >> 31);
-    const uint8_t *Q = lds + kRcQtabAt;
-    const uint8_t *qm = Q + j * 16 + (intra ? 0 : 1), *pm = Q + 128 + j * 8; // position = j * 8 + r
+    // the column's 8 matrix entries of both classes (16 bytes: position j * 8 + r -> bytes 2r, 2r + 1) and its 8
+    // premultipliers, in two LDS reads up front
+    const u32x4 qm = *reinterpret_cast<const u32x4 *>(lds + kRcQtabAt + j * 16);
+    const uint32_t *pmp = reinterpret_cast<const uint32_t *>(lds + kRcQtabAt + 128 + j * 8);
+    const uint32_t pm[2] = {pmp[0], pmp[1]};
+    const uint32_t cls8 = intra ? 0u : 8u;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int32_t w = lv.v[r >> 1];
@@ -474,7 +478,9 @@ MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *l
             v[r] = 0;
             continue;
         }
-        const int32_t d = dequant(level, intra, qs * (int32_t)qm[r * 2], (int32_t)pm[r]);
+        const int32_t m = (int32_t)((qm.v[r >> 1] >> ((r & 1) * 16 + cls8)) & 0xff);
+        const int32_t p = (int32_t)((pm[r >> 2] >> ((r & 3) * 8)) & 0xff);
+        const int32_t d = dequant(level, intra, mul24_as_written(qs, m), p);
         v[r] = level ? d : 0;
     }
     if (intra && j == 0)

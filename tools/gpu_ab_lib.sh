@@ -11,7 +11,7 @@ for r in $(seq 1 $ROUNDS); do
   for which in $VARIANTS; do
     if [ $which = cur ]; then cp /tmp/lib_cur.so mpeg_amd/libmpeghip.so; else cp tools/ab/libmpeghip_$which.so mpeg_amd/libmpeghip.so; fi
     for prof in ${PROFILES:-typical dense}; do
-      timeout 300 python bench.py --profile $prof --cpu-seconds 0 --audio-streams 0 --rgba-streams 0 --check ${CHECK:-1} "$@" > /tmp/ab.json 2> /tmp/ab.err || tail -3 /tmp/ab.err
+      timeout 300 python bench.py --profile $prof --cpu-seconds 0 --audio-streams 0 --legs "" --check ${CHECK:-1} "$@" > /tmp/ab.json 2> /tmp/ab.err || tail -3 /tmp/ab.err
       python - <<PY | tee -a $OUT/ab.txt
 import json
 try:
