@@ -455,9 +455,53 @@ MPG_HD void rc_cols_load(const int32_t *T, int lane, int32_t (&v)[8])
     }
 }
 
-// a dense block: lane (g, j) takes column j straight from the unit — one 16-byte load, 8 levels dequantised in
-// place of the tile read.  Rows that are empty in every dense lane of the wave are skipped wave-wide.
+// a dense block (more than 32 non-zero levels): lane (g, j) takes column j straight from the unit — one 16-byte load, 8
+// levels dequantised in place of the tile read.  The column's matrix entries (of the lane's class) and premultipliers
+// are brought into two dwords each, so that every product takes its byte operand through the multiplier's own byte
+// select (SDWA) instead of a shift and a mask.
 struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; };
+template <int kByte> MPG_HD int32_t mul_u8(uint32_t bytes, int32_t x) // (byte kByte of `bytes`) * x, both within 24 bits
+{
+#if MPG_ON_DEVICE
+    int32_t r;
+    if (kByte == 0)
+        asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(bytes));
+    else if (kByte == 1)
+        asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(bytes));
+    else if (kByte == 2)
+        asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(bytes));
+    else
+        asm("v_mul_i32_i24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(bytes));
+    return r;
+#else
+    MPG_CHECK(x >= -(1 << 23) && x < (1 << 23));
+    return (int32_t)((bytes >> (8 * kByte)) & 0xff) * x;
+#endif
+}
+// bytes 0, 2 (or 1, 3 for the odd class) of lo and of hi -> one dword
+MPG_HD uint32_t pick_class_bytes(uint32_t lo, uint32_t hi, bool odd)
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_perm(hi, lo, odd ? 0x07050301u : 0x06040200u);
+#else
+    const uint32_t s = odd ? 8 : 0;
+    return ((lo >> s) & 0xff) | (((lo >> (16 + s)) & 0xff) << 8) | (((hi >> s) & 0xff) << 16) | (((hi >> (16 + s)) & 0xff) << 24);
+#endif
+}
+template <int R> MPG_HD int32_t rc_dense_level(const i32x4_a4 &lv, bool intra, int32_t qs, const uint32_t (&qm)[2], const uint32_t (&pm)[2])
+{
+    const int32_t w = lv.v[R >> 1];
+    const int32_t level = (R & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
+    // video.go:719-744, as video_lane.h: dequant()
+    int32_t l = 2 * level;
+    if (!intra)
+        l += (level >> 31) | 1;
+    l = mul24_as_written(l, mul_u8<R & 3>(qm[R >> 2], qs)) >> 4;
+    l = (l - (l > 0 ? 1 : 0)) | 1;
+    l = clampi(l, -2048, 2047);
+    l = mul_u8<R & 3>(pm[R >> 2], l);
+    return level ? l : 0;
+}
 MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *lds, uint32_t bw, int lane, int32_t (&v)[8])
 {
     const uint32_t j = (uint32_t)lane & 7;
@@ -465,24 +509,19 @@ MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *l
     const int32_t qs = (int32_t)((bw >> 26) & 31);
     const bool intra = !(bw >> 31);
     // the column's 8 matrix entries of both classes (16 bytes: position j * 8 + r -> bytes 2r, 2r + 1) and its 8
-    // premultipliers, in two LDS reads up front
-    const u32x4 qm = *reinterpret_cast<const u32x4 *>(lds + kRcQtabAt + j * 16);
+    // premultipliers, in two LDS reads
+    const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + kRcQtabAt + j * 16);
     const uint32_t *pmp = reinterpret_cast<const uint32_t *>(lds + kRcQtabAt + 128 + j * 8);
     const uint32_t pm[2] = {pmp[0], pmp[1]};
-    const uint32_t cls8 = intra ? 0u : 8u;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int32_t w = lv.v[r >> 1];
-        const int32_t level = (r & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
-        if (none_in_wave(level != 0)) {
-            v[r] = 0;
-            continue;
-        }
-        const int32_t m = (int32_t)((qm.v[r >> 1] >> ((r & 1) * 16 + cls8)) & 0xff);
-        const int32_t p = (int32_t)((pm[r >> 2] >> ((r & 3) * 8)) & 0xff);
-        const int32_t d = dequant(level, intra, mul24_as_written(qs, m), p);
-        v[r] = level ? d : 0;
-    }
+    const uint32_t qm[2] = {pick_class_bytes(q.v[0], q.v[1], !intra), pick_class_bytes(q.v[2], q.v[3], !intra)};
+    v[0] = rc_dense_level<0>(lv, intra, qs, qm, pm);
+    v[1] = rc_dense_level<1>(lv, intra, qs, qm, pm);
+    v[2] = rc_dense_level<2>(lv, intra, qs, qm, pm);
+    v[3] = rc_dense_level<3>(lv, intra, qs, qm, pm);
+    v[4] = rc_dense_level<4>(lv, intra, qs, qm, pm);
+    v[5] = rc_dense_level<5>(lv, intra, qs, qm, pm);
+    v[6] = rc_dense_level<6>(lv, intra, qs, qm, pm);
+    v[7] = rc_dense_level<7>(lv, intra, qs, qm, pm);
     if (intra && j == 0)
         v[0] = (int32_t)(int16_t)(lv.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
 }

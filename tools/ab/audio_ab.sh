@@ -1,0 +1,9 @@
+cp mpeg_amd/libmpeghip.so /tmp/cur.so
+for r in 1 2 3; do for v in cur slices5 slices6 slices8; do
+  if [ $v = cur ]; then cp /tmp/cur.so mpeg_amd/libmpeghip.so; else cp tools/ab/libmpeghip_$v.so mpeg_amd/libmpeghip.so; fi
+  python bench.py --steps 2 --warmup 1 --streams 16 --legs "" --cpu-seconds 0 --check 1 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])['audio']
+print('round $r %-8s audio %.4g pairs/s frac %.4f %.4f ms %s' % ('$v', d['value'], d['roofline']['frac'], d['ms_per_launch'], d['parity']))"
+done; done
+cp /tmp/cur.so mpeg_amd/libmpeghip.so
