@@ -49,6 +49,14 @@ const (
 	MbRefBwd  = C.MPEGHIP_MB_REF_BWD
 	MbCoefRaw = C.MPEGHIP_MB_COEF_RAW
 	PicRGBA   = C.MPEGHIP_PIC_RGBA
+
+	FMANone   = C.MPEGHIP_AUDIO_FMA_NONE   // mul and add rounded separately (pure Go / SSE2)
+	FMAWindow = C.MPEGHIP_AUDIO_FMA_WINDOW // fused multiply-add in the window (amd64 AVX2)
+
+	AudioF32N   = C.MPEGHIP_AUDIO_F32N // = mpeg.AudioF32N ... AudioS16, same order
+	AudioF32NLR = C.MPEGHIP_AUDIO_F32NLR
+	AudioF32    = C.MPEGHIP_AUDIO_F32
+	AudioS16    = C.MPEGHIP_AUDIO_S16
 )
 
 // lastError: mpeghip_last_error is per OS thread; goroutines that call into the library keep theirs with

@@ -1,0 +1,422 @@
+//go:build hip
+
+package mpeg
+
+import (
+	"os"
+	"strconv"
+	"sync"
+	"unsafe"
+
+	"github.com/gen2brain/mpeg/internal/mpeghip" // = go/mpeghip of this repository, vendored
+)
+
+// One device context per process (a context is bound to one GPU + one HIP stream and is not
+// thread-safe: decoders that share it must be driven from one goroutine, like the reference's own
+// decoders; one process per GPU).  MPEG_HIP_DEVICE picks the ordinal.  Many streams per GPU go through
+// the staged submit of go/mpeghip (Stage.Put from one goroutine per stream), INTEGRATION.md section 2.
+var (
+	hipOnce sync.Once
+	hipCtx  *mpeghip.Context
+	hipErr  error
+)
+
+func hipContext() (*mpeghip.Context, error) {
+	hipOnce.Do(func() {
+		dev, _ := strconv.Atoi(os.Getenv("MPEG_HIP_DEVICE"))
+		hipCtx, hipErr = mpeghip.NewContext(dev)
+	})
+	return hipCtx, hipErr
+}
+
+// blockRec is what decodeBlock recorded for one block of the current macroblock.
+type blockRec struct {
+	valid    bool      // the block ended properly (an invalid block is not reconstructed, video.go:711-714)
+	needsRaw bool      // cannot travel as int16 levels: see hipVideo.decodeBlock
+	q        [64]int16 // quantised levels at their natural (de-zigzagged, row-major) positions; [0] = DC for intra
+	touched  [64]uint8 // the positions this block wrote, in scan order
+	nTouched int
+	raw      [64]int32 // snapshot of blockData as idct() / the DC fast path would consume it
+}
+
+// hipVideo is embedded in Video (field `hip hipVideo`) under the hip tag.
+type hipVideo struct {
+	dev *mpeghip.Video
+
+	mbs     []mpeghip.MbDesc // one picture's macroblocks (reused between pictures)
+	coefs   []byte           // 128-byte units, column-major
+	written []bool           // macroblock address already emitted in the current submit
+
+	// current macroblock
+	active, intra, hasPred, backward bool
+	mbX, mbY, mvX, mvY, qscale, cbp  int
+	blocks                           [6]blockRec
+
+	blockDirty bool // blockData holds stale coefficients of an earlier invalid block
+
+	have     [3]bool // Frame.Y/Cb/Cr.Data of the Frame holding slot s equal the device's slot s
+	NoPlanes bool    // the consumer only wants Frame.RGBA(): Decode skips the plane read-back
+
+	Stats struct{ Pictures, Submits, Macroblocks, CodedBlocks, RawMacroblocks, InvalidBlocks, DuplicateSplits, RangeSkips int }
+}
+
+// open replaces the three initFrame calls of decodeSequenceHeader (video.go:324-326): the frame store
+// lives on the device; the Frames keep host slices of the same sizes for read-back.
+func (h *hipVideo) open(v *Video) bool {
+	ctx, err := hipContext()
+	if err != nil {
+		return false // no GPU: this flavour has no CPU path
+	}
+	if h.dev != nil {
+		h.dev.Close()
+	}
+	if h.dev, err = ctx.OpenVideo(v.width, v.height); err != nil {
+		return false
+	}
+	if err = h.dev.SetQuant(&v.intraQuantMatrix, &v.nonIntraQuantMatrix); err != nil {
+		return false
+	}
+	frames := [3]*Frame{&v.frameCurrent, &v.frameForward, &v.frameBackward}
+	for s, f := range frames {
+		// geometry, image headers, the RGBA buffer; Y/Cb/Cr.Data become the HOST COPY of device slot s.
+		// The reference rotates Frame VALUES in decodePicture (video.go:406-409, 430-433: slice headers
+		// move, bytes do not); hipSlot is part of the value, so the device slot travels with it and the
+		// rotation code stays as it is.
+		v.initFrame(f)
+		f.hipSlot, f.hipOwner = uint8(s), v
+		h.have[s] = true // zeros on both sides
+	}
+	h.written = make([]bool, v.mbSize)
+	h.blockDirty = false
+	return true
+}
+
+func (h *hipVideo) beginPicture(v *Video) {
+	h.Stats.Pictures++
+	h.mbs = h.mbs[:0]
+	h.coefs = h.coefs[:0]
+	for i := range h.written {
+		h.written[i] = false
+	}
+}
+
+// flush hands the recorded macroblocks to the device: ONE cgo call per picture (more only when a
+// damaged stream addresses a macroblock twice).  Submit returns with the copy and the kernel in
+// flight, so the parser works on the next picture meanwhile.
+func (h *hipVideo) flush(v *Video) {
+	if len(h.mbs) == 0 {
+		return
+	}
+	// between the two halves of decodePicture's rotation frameCurrent is the destination and
+	// frameForward / frameBackward are what copyMacroblock would read
+	cur := v.frameCurrent.hipSlot
+	pic := mpeghip.PicDesc{Cur: cur, Fwd: v.frameForward.hipSlot, Bwd: v.frameBackward.hipSlot, MbCount: uint32(len(h.mbs))}
+	if err := h.dev.Submit(&pic, h.mbs, h.coefs); err != nil {
+		// descriptors are validated by the library; the recorder never produces an invalid one.  A
+		// device failure leaves the slot as it was (the reference has no error path here either).
+		_ = err
+	}
+	h.have[cur] = false
+	h.Stats.Submits++
+	h.Stats.Macroblocks += len(h.mbs)
+	h.mbs = h.mbs[:0]
+	h.coefs = h.coefs[:0]
+	for i := range h.written {
+		h.written[i] = false
+	}
+}
+
+// beginMacroblock is called by decodeMacroblock once mbRow / mbCol / the type / quantizerScale of the
+// macroblock are known, before predictMacroblock / the blocks — and for each skipped macroblock
+// (video.go:510-517) with intra = false (v.macroblockIntra is stale there).
+func (h *hipVideo) beginMacroblock(v *Video, intra bool) {
+	addr := v.mbRow*v.mbWidth + v.mbCol
+	if h.written[addr] { // macroblocks of one submit run concurrently: keep "last writer in bitstream order"
+		h.flush(v)
+		h.Stats.DuplicateSplits++
+	}
+	h.written[addr] = true
+	h.active, h.intra, h.hasPred, h.backward = true, intra, false, false
+	h.mbX, h.mbY, h.mvX, h.mvY, h.cbp = v.mbCol, v.mbRow, 0, 0, 0
+	h.qscale = v.quantizerScale
+}
+
+// predict stands where predictMacroblock calls copyMacroblock (video.go:626-635): a later call
+// overwrites an earlier one, which is exactly what the reference's second copy does to the first.
+func (h *hipVideo) predict(v *Video, mh, mv int, backward bool) {
+	h.hasPred, h.backward, h.mvX, h.mvY = true, backward, mh, mv
+}
+
+func dequantPremult(level int, intra bool, qscale int, q byte, idx int) int32 {
+	// video.go:719-744, on one level
+	level <<= 1
+	if !intra {
+		if level < 0 {
+			level--
+		} else {
+			level++
+		}
+	}
+	level = (level * qscale * int(q)) >> 4
+	if level&1 == 0 {
+		if level > 0 {
+			level--
+		} else {
+			level++
+		}
+	}
+	if level > 2047 {
+		level = 2047
+	} else if level < -2048 {
+		level = -2048
+	}
+	return int32(level * int(videoPremultiplierMatrix[idx]))
+}
+
+// decodeBlock replaces Video.decodeBlock under the hip tag: the same bits are read in the same order
+// (video.go:643-707), but levels are STORED, not dequantised, and nothing is reconstructed here.
+//
+// v.blockData is all zero between blocks except after an invalid block (video.go:711-714 returns
+// before the clears): only then — or when this block ends invalid itself, holds an explicit zero level
+// (which dequantises to +-1) or an intra DC outside int16 — do its exact contents matter, and the block
+// travels as an int32 snapshot of what idct() / the DC fast path would consume (MPEGHIP_MB_COEF_RAW).
+func (h *hipVideo) decodeBlock(v *Video, block int) {
+	br := &h.blocks[block]
+	br.valid, br.needsRaw, br.nTouched = false, false, 0
+	br.q = [64]int16{}
+	h.cbp |= 0x20 >> uint(block)
+
+	n := 0
+	var quant *[64]byte
+	dirtyAtStart := h.blockDirty
+	explicitZero := false
+	dc256 := 0
+
+	if v.macroblockIntra {
+		plane := 0
+		if block > 3 {
+			plane = block - 3
+		}
+		dc := v.dcPredictor[plane]
+		if size := v.buf.readVlc(videoDctSize[plane]); size > 0 {
+			diff := v.buf.read(size)
+			if diff&(1<<uint(size-1)) != 0 {
+				dc += diff
+			} else {
+				dc += (-1 << uint(size)) | (diff + 1)
+			}
+		}
+		v.dcPredictor[plane] = dc
+		switch {
+		case dc < -32768:
+			br.needsRaw, br.q[0] = true, -32768
+		case dc > 32767:
+			br.needsRaw, br.q[0] = true, 32767
+		default:
+			br.q[0] = int16(dc)
+		}
+		// blockData[0] = dc << 8; beyond +-2^30 the pixel saturates whatever the AC terms add, so the
+		// clamp is exact and keeps the snapshot in int32
+		dc256 = dc << 8
+		if dc256 > 1<<30 {
+			dc256 = 1 << 30
+		} else if dc256 < -(1 << 30) {
+			dc256 = -(1 << 30)
+		}
+		if dirtyAtStart {
+			v.blockData[0] = dc256
+		}
+		quant = &v.intraQuantMatrix
+		n = 1
+	} else {
+		quant = &v.nonIntraQuantMatrix
+	}
+
+	invalid := false
+	for {
+		run, level := 0, 0
+		coeff := int(v.buf.readVlcUint(videoDctCoeff))
+		if coeff == 0x0001 && n > 0 && v.buf.read1() == 0 {
+			break // end_of_block
+		}
+		if coeff == 0xffff { // escape
+			run = v.buf.read(6)
+			level = v.buf.read(8)
+			switch {
+			case level == 0:
+				level = v.buf.read(8)
+			case level == 128:
+				level = v.buf.read(8) - 256
+			case level > 128:
+				level -= 256
+			}
+		} else {
+			run, level = coeff>>8, coeff&0xff
+			if v.buf.read1() != 0 {
+				level = -level
+			}
+		}
+		n += run
+		if n < 0 || n >= 64 {
+			invalid = true
+			break
+		}
+		dz := int(videoZigZag[n]) & 63
+		n++
+		if level == 0 {
+			explicitZero = true
+		}
+		br.q[dz] = int16(level)
+		br.touched[br.nTouched] = uint8(dz)
+		br.nTouched++
+		if dirtyAtStart {
+			v.blockData[dz] = int(dequantPremult(level, v.macroblockIntra, v.quantizerScale, quant[dz], dz))
+		}
+	}
+
+	materialize := func() { // bring blockData up to date when it was not maintained on the fly
+		if dirtyAtStart {
+			return
+		}
+		if v.macroblockIntra {
+			v.blockData[0] = dc256
+		}
+		for k := 0; k < br.nTouched; k++ {
+			dz := int(br.touched[k])
+			v.blockData[dz] = int(dequantPremult(int(br.q[dz]), v.macroblockIntra, v.quantizerScale, quant[dz], dz))
+		}
+	}
+
+	if invalid { // video.go:711-714: no reconstruction, and blockData is NOT cleared
+		h.Stats.InvalidBlocks++
+		materialize()
+		h.blockDirty = true
+		return
+	}
+	if !dirtyAtStart && !explicitZero && !br.needsRaw {
+		br.valid = true // the common case: nothing of blockData survives this block (video.go:777-796)
+		return
+	}
+
+	materialize()
+	br.needsRaw = true
+	if n == 1 { // video.go:774-777 / 787-790: only blockData[0] is used, and only it is cleared
+		br.raw = [64]int32{}
+		br.raw[0] = int32(v.blockData[0])
+		v.blockData[0] = 0
+	} else {
+		for i := 0; i < 64; i++ {
+			if n < 10 && (i>>3 >= 4 || i&7 >= 4) { // video.go:807-866: the reduced idct ignores rows, columns >= 4
+				br.raw[i] = 0
+			} else {
+				br.raw[i] = int32(v.blockData[i])
+			}
+			v.blockData[i] = 0 // video.go:781-783 / 794-796
+		}
+	}
+	h.blockDirty = false
+	for i := 0; i < 64; i++ {
+		if v.blockData[i] != 0 {
+			h.blockDirty = true
+			break
+		}
+	}
+	br.valid = true
+}
+
+// endMacroblock appends the macroblock's descriptor and its coded blocks (column-major units).
+func (h *hipVideo) endMacroblock(v *Video) {
+	if !h.active {
+		return
+	}
+	h.active = false
+	if !h.intra && !h.hasPred {
+		return // cannot happen: every non-intra macroblock is predicted (video.go:543-544)
+	}
+	if !h.intra { // copyMacroblock's legal read range (video_noasm.go:48-50): [plane start, end of base)
+		lw, cw := v.lumaWidth, v.chromaWidth
+		luma, chroma := v.lumaWidth*v.lumaHeight, v.chromaWidth*v.chromaHeight
+		total := luma + 2*chroma + lw*16
+		lsi := ((h.mbY<<4)+(h.mvY>>1))*lw + (h.mbX << 4) + (h.mvX >> 1)
+		llast := lsi + (15+(h.mvY&1))*lw + 15 + (h.mvX & 1)
+		cmh, cmv := h.mvX/2, h.mvY/2
+		csi := ((h.mbY<<3)+(cmv>>1))*cw + (h.mbX << 3) + (cmh >> 1)
+		clast := csi + (7+(cmv&1))*cw + 7 + (cmh & 1)
+		if lsi < 0 || llast >= total || csi < 0 || clast >= total-luma-chroma {
+			h.Stats.RangeSkips++ // the reference panics here
+			return
+		}
+	}
+	raw, cbp := false, 0
+	for b := 0; b < 6; b++ {
+		if h.cbp&(0x20>>uint(b)) != 0 && h.blocks[b].valid {
+			cbp |= 0x20 >> uint(b)
+			raw = raw || h.blocks[b].needsRaw
+		}
+	}
+	if h.qscale < 1 && cbp != 0 {
+		raw = true // quantiser_scale 0 (forbidden): keep the reference's arithmetic
+	}
+	d := mpeghip.MbDesc{MbX: uint16(h.mbX), MbY: uint16(h.mbY), MvX: int16(h.mvX), MvY: int16(h.mvY), Cbp: uint8(cbp)}
+	switch {
+	case h.intra:
+		d.Flags = mpeghip.MbIntra
+	case h.backward:
+		d.Flags = mpeghip.MbRefBwd
+	default:
+		d.Flags = mpeghip.MbRefFwd
+	}
+	if raw {
+		d.Flags |= mpeghip.MbCoefRaw
+		h.Stats.RawMacroblocks++
+	}
+	qs := h.qscale
+	if qs < 1 {
+		qs = 1
+	} else if qs > 31 {
+		qs = 31
+	}
+	d.Qscale = uint8(qs)
+	d.CoefOff = uint32(len(h.coefs) / 128)
+
+	quant := &v.nonIntraQuantMatrix
+	if h.intra {
+		quant = &v.intraQuantMatrix
+	}
+	for b := 0; b < 6; b++ {
+		if cbp&(0x20>>uint(b)) == 0 {
+			continue
+		}
+		br := &h.blocks[b]
+		h.Stats.CodedBlocks++
+		at := len(h.coefs)
+		if raw {
+			h.coefs = append(h.coefs, make([]byte, 256)...)
+			dst := unsafe.Slice((*int32)(unsafe.Pointer(&h.coefs[at])), 64)
+			for i := 0; i < 64; i++ {
+				val := br.raw[i]
+				if !br.needsRaw { // a clean block of a macroblock that travels raw: dequantise it here
+					val = 0
+					if br.q[i] != 0 {
+						val = dequantPremult(int(br.q[i]), h.intra, h.qscale, quant[i], i)
+					}
+					if h.intra && i == 0 {
+						val = int32(br.q[0]) << 8
+					}
+				}
+				dst[(i&7)*8+(i>>3)] = val
+			}
+		} else {
+			h.coefs = append(h.coefs, make([]byte, 128)...)
+			dst := unsafe.Slice((*int16)(unsafe.Pointer(&h.coefs[at])), 64)
+			if h.intra {
+				dst[0] = br.q[0]
+			}
+			for k := 0; k < br.nTouched; k++ {
+				i := int(br.touched[k])
+				dst[(i&7)*8+(i>>3)] = br.q[i]
+			}
+		}
+	}
+	h.mbs = append(h.mbs, d)
+}

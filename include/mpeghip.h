@@ -72,14 +72,24 @@ int mpeghip_timer_stop_ms(mpeghip_ctx *ctx, float *ms); /* records, syncs, retur
 /*
  * Frame store (replaces Video.initFrame, video.go:333-372, and the three
  * rotating Frame values frameCurrent/frameForward/frameBackward,
- * video.go:97-99).  For every stream the handle owns 3 frame "slots".  One
- * slot is one contiguous, zero-initialised allocation laid out exactly like
+ * video.go:97-99).  For every stream the handle owns 3 frame "slots",
+ * zero-initialised.  SEEN THROUGH THIS ABI (read_planes / write_planes /
+ * hash_slots / read_rgba, and every prediction, including the reference's
+ * reads past the end of a plane row or plane, video_noasm.go:48-80) a slot is
  * the reference's `base` slice:
  *
  *     Y  [luma_w  * luma_h ]   luma_w  = mb_w*16, luma_h  = mb_h*16
  *     Cb [chroma_w*chroma_h]   chroma_w= mb_w*8,  chroma_h= mb_h*8
  *     Cr [chroma_w*chroma_h]
  *     pad[luma_w * 16]         zero; half-pel reads past a plane end land here
+ *
+ * IN DEVICE MEMORY the planes are stored tiled: luma as
+ * 16x16 tiles of 256 bytes, each chroma plane as 8x8 blocks of 64 bytes, tiles
+ * in macroblock raster order, at the same plane offsets (0, luma_bytes,
+ * luma_bytes + chroma_bytes); byte (x, y) of the luma plane lives at
+ * ((y/16)*mb_w + x/16)*256 + (y%16)*16 + x%16, of a chroma plane at
+ * ((y/8)*mb_w + x/8)*64 + (y%8)*8 + x%8.  Only mpeghip_video_slot_devptr
+ * exposes that; the RGBA image is linear.
  *
  * Which slot plays current/forward/backward is the caller's business (the
  * parser mirrors the rotation of video.go:406-409/430-433) and is stated per
@@ -170,7 +180,7 @@ typedef struct mpeghip_mb_desc {
     uint8_t  qscale;      /* quantiser_scale 1..31 (ignored for COEF_RAW)            */
     uint8_t  reserved0;
     uint32_t coef_off;    /* first coefficient block, in 128-byte units              */
-    uint32_t reserved[3]; /* 0; the library's device copy keeps its picture's fields here  */
+    uint32_t reserved[3]; /* 0                                                       */
 } mpeghip_mb_desc;        /* 32 bytes */
 
 #define MPEGHIP_MB_INTRA    0x01u /* no prediction, coded blocks overwrite           */
@@ -180,14 +190,19 @@ typedef struct mpeghip_mb_desc {
 
 #define MPEGHIP_COEF_UNIT 128u
 
-/* Validate + copy descriptors to the device and reconstruct, stream ordered.
- * Asynchronous: the arrays are copied into one of two pinned staging buffers and the call returns
+/* Validate the descriptors, pack them into the library's device format and
+ * reconstruct, stream ordered.
+ * Asynchronous: the packed form is written into one of two pinned staging buffers and the call returns
  * with the H2D copy and the kernel in flight, so the caller parses picture N+1 while picture N is
  * reconstructed (the arrays may be reused at once; a third submit waits for the first).
- * Macroblocks of one submit must not overlap inside one picture (the emitter
- * starts a new submit when a damaged stream addresses a macroblock twice, so
- * "last writer in bitstream order" is kept by stream order).  Pictures of the
- * SAME stream in one submit must not depend on each other.
+ * Macroblocks of one submit run concurrently, so a submit is refused with
+ * MPEGHIP_ERR_INVALID (nothing is launched) when
+ *   - one picture addresses a macroblock position twice (the emitter starts a
+ *     new submit when a damaged stream does, so "last writer in bitstream
+ *     order" is kept by stream order),
+ *   - a picture predicts from the slot it writes (cur == the named reference),
+ *   - two pictures of the same stream write the same slot, or one reads a
+ *     slot another one of the same submit writes.
  * Returns MPEGHIP_ERR_RANGE (nothing is launched) if any prediction would
  * read outside [plane start, end of pad) — the reference panics there. */
 int mpeghip_video_submit(mpeghip_video *v,
@@ -228,7 +243,7 @@ int  mpeghip_video_batch_upload_replicated(mpeghip_video *v,
                                 uint32_t n_streams, mpeghip_batch **out);
 int  mpeghip_video_batch_run(mpeghip_video *v, const mpeghip_batch *b);
 void mpeghip_video_batch_free(mpeghip_batch *b);
-/* Algorithmic HBM bytes of one run of the batch (DESIGN.md §4):
+/* Algorithmic HBM bytes of one run of the batch (DESIGN.md section 3.1):
  * sum over macroblocks of 32 + coefficient bytes + reference window + 384
  * (+1024 per macroblock of pictures flagged MPEGHIP_PIC_RGBA). */
 uint64_t mpeghip_video_batch_alg_bytes(const mpeghip_batch *b);
@@ -258,7 +273,8 @@ int mpeghip_video_rgba_convert(mpeghip_video *v, uint32_t slot,
 /* Read the slot's RGBA image (width*height*4 bytes, stride 4*width). Synchronous. */
 int mpeghip_video_read_rgba(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *dst);
 
-/* Raw device addresses (for zero-copy consumers and on-device checks). */
+/* Raw device addresses (for zero-copy consumers and on-device checks).  The slot is in the TILED
+ * device layout described at the top of this section; the RGBA image is linear, stride 4*width. */
 void *mpeghip_video_slot_devptr(mpeghip_video *v, uint32_t stream, uint32_t slot);
 void *mpeghip_video_rgba_devptr(mpeghip_video *v, uint32_t stream, uint32_t slot);
 
