@@ -28,7 +28,7 @@ func (h *hipVideo) fetch(v *Video, f *Frame) {
 
 // hipRGBA is Frame.RGBA() under the hip tag (video.go:31-36 calls it when hipBuild): the colour
 // conversion of Go's image/draw (YCbCr 4:2:0 -> RGBA, JFIF full range, alpha 255) runs on the device,
-// bit-identical for every (Y, Cb, Cr) (tests/test_gpu_rgba.py), and only width*height*4 bytes cross
+// bit-identical for every (Y, Cb, Cr) (tests/test_gpu_video.py::test_rgba_of_every_possible_pixel), and only width*height*4 bytes cross
 // PCIe — the planes need not have been read back at all.
 func (f *Frame) hipRGBA() *image.RGBA {
 	if v := f.hipOwner; v != nil && v.hip.dev != nil {
