@@ -279,14 +279,14 @@ MPG_HD void dma16x6_to_lds(const uint8_t *const (&g_base)[6], const uint32_t (&o
 }
 // one dword per lane into a register; only valid after wait_loads + settle() — and settle() it on EVERY path, used or
 // not: until then the register belongs to the load, and the compiler must not hand it to something else
-MPG_HD uint32_t load32_uncounted(const uint32_t *g)
+MPG_HD uint32_t load32_uncounted(const uint32_t *uniform_base, uint32_t byte_off)
 {
 #if MPG_ON_DEVICE
     uint32_t v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(g) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(uniform_base) : "memory");
     return v;
 #else
-    return *g;
+    return uniform_base[byte_off / 4];
 #endif
 }
 // wait until at most `newer` of the loads above are still in flight (they complete in order)
@@ -304,6 +304,28 @@ MPG_HD void settle(uint32_t &v)
     asm volatile("" : "+v"(v)::"memory");
 #else
     (void)v;
+#endif
+}
+
+// hides a value's provenance from the optimiser (no instruction)
+MPG_HD uint32_t opaque(uint32_t v)
+{
+#if MPG_ON_DEVICE
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
+
+// 16 bytes per lane to (wave-uniform base) + (32-bit lane offset): the scalar-base form of the store, so that no lane
+// builds a 64-bit address (the compiler prefers v_lshl_add_u64 per lane when it sees base + offset itself)
+MPG_HD void store16_at(uint8_t *uniform_base, uint32_t off, const u32x4 &v)
+{
+#if MPG_ON_DEVICE
+    typedef uint32_t vec4 __attribute__((ext_vector_type(4)));
+    const vec4 d = {v.v[0], v.v[1], v.v[2], v.v[3]};
+    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(d), "s"(uniform_base) : "memory");
+#else
+    __builtin_memcpy(uniform_base + off, v.v, 16);
 #endif
 }
 

@@ -58,8 +58,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 #endif
     MPG_STAMP(0);
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kRcLdsBytes];
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    // (one wave per workgroup, the shipped shape: the wave's LDS starts at 0 and every LDS address below is lane part +
+    // immediate, with no per-wave base to add)
+    const uint32_t w = WAVES == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     const uint32_t chunk = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w);
     if (chunk >= a.n_chunks)
         return;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         return;
 #endif
     MPG_STAMP(1);
-    uint32_t e = load32_uncounted(rc_ent_src(a, c, 0, lane));
+    uint32_t e = load32_uncounted(rc_ent_src(a, c, 0, 0), (uint32_t)lane * 4);
     if (lane < kRcWinLanes) {
         const uint8_t *const src[6] = {rc_table_src(a, c), rc_blk_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1),
                                        rc_win_base(a, c, 2), rc_win_base(a, c, 3)};

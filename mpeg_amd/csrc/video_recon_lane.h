@@ -324,18 +324,22 @@ MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[5
 // what depends on the lane only (worked out once per wave)
 struct RcLane {
     // as lane of a window load (piece `lane` < 54): luma pieces (lane < 34) are (row lane>>1, tile column lane&1),
-    // chroma pieces (plane, row pair, block column); frame offset of a piece = base + (t >> sh) * stride + (t & msk) * 16
-    // + cterm with t = (window origin's row / row pair inside its tile) + rj
+    // chroma pieces (plane, row pair, block column).  A record's d2 / d3 with their low 4 bits cleared are X = (offset of
+    // the tile / block that holds the window origin) + 16 * (the origin's row / row pair inside it); with u = (X & sub_mask)
+    // + rj16 the piece's frame offset is X + rj16 + cterm + (u >> wrap_shift ? below : 0): a tile / block is wrap bytes
+    // long, the one below it is `stride` further on, and u counts 16-byte pieces from the top of the first one.
     uint32_t piece_chroma; // all ones if the piece is chroma, else 0
-    uint32_t rj;           // luma: row 0..16; chroma: row pair 0..4
-    uint32_t sh, msk;      // 4, 15 (16 rows per tile) / 2, 3 (4 row pairs per block)
-    uint32_t stride;       // bytes from a tile (block) to the one below: mb_w * 256 / mb_w * 64
-    uint32_t cterm;        // tile column * 256 / plane * chroma_bytes + block column * 64
+    uint32_t sub_mask;     // 0xf0 (16 rows per tile) / 0x30 (4 row pairs per block)
+    uint32_t rj16;         // 16 * (luma: row 0..16; chroma: row pair 0..4)
+    uint32_t rj16_cterm;   // rj16 + (tile column * 256 / plane * chroma_bytes + block column * 64)
+    uint32_t wrap_shift;   // 8 / 6
+    uint32_t below;        // mb_w * 256 - 256 / mb_w * 64 - 64
     uint32_t lin_off;      // the same piece of a LINEAR window (kRSlow; lanes < 52): luma row * luma_w + column * 16 /
                            // plane * chroma_bytes + row * chroma_w (17 rows x 2, then 9 rows per plane)
     uint32_t lin_chroma;
     uint32_t mc_luma;      // as MC lane (row lane>>2, quarter lane&3): LDS offset of its taps inside a window = (lane>>2)*32 + (lane&3)*4
     uint32_t mc_plane;     // lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1): plane * 160 — tiled chroma pieces
+    int32_t mc_c0, mc_ck, mc_ck2, mc_cs, mc_cs2; // the affine address map of rc_mc_chroma
     uint32_t mc_lin;       // linear chroma rows: kRcWinLuma + (plane*9 + row)*16 + half*4
     uint32_t out_luma;     // where the lane's 4 luma bytes go inside O_m: lane * 4
     uint32_t out_chroma;   // 4 chroma bytes: 256 + lane * 4
@@ -348,12 +352,13 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
     {
         const bool chroma = l >= 34;
         const uint32_t ci = l - 34, plane = ci >= 10 ? 1u : 0u, cj = ci - plane * 10;
-        k.piece_chroma = chroma ? ~0u : 0u;
-        k.rj = chroma ? cj >> 1 : l >> 1;
-        k.sh = chroma ? 2 : 4;
-        k.msk = chroma ? 3 : 15;
-        k.stride = chroma ? a.mb_w * 64 : a.mb_w * 256;
-        k.cterm = chroma ? plane * a.chroma_bytes + (cj & 1) * 64 : (l & 1) * 256;
+        const uint32_t rj = chroma ? cj >> 1 : l >> 1;
+        k.piece_chroma = opaque(chroma ? ~0u : 0u); // (a plain mask: the compiler must not turn `x & mask` into selects)
+        k.sub_mask = chroma ? 0x30 : 0xf0;
+        k.rj16 = rj * 16;
+        k.rj16_cterm = rj * 16 + (chroma ? plane * a.chroma_bytes + (cj & 1) * 64 : (l & 1) * 256);
+        k.wrap_shift = chroma ? 6 : 8;
+        k.below = chroma ? a.mb_w * 64 - 64 : a.mb_w * 256 - 256;
     }
     {
         const bool chroma = l >= 34;
@@ -363,6 +368,14 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
     }
     k.mc_luma = (l >> 2) * 32 + (l & 3) * 4;
     k.mc_plane = ((l >> 4) & 1) * 160;
+    {
+        const int32_t r = (int32_t)((l >> 1) & 7), b = r & 1, h = (int32_t)(l & 1);
+        k.mc_c0 = (int32_t)(kRcWinLuma + k.mc_plane) + 16 * r - 8 * b + 4 * h;
+        k.mc_ck = 8 + 16 * b;
+        k.mc_ck2 = 16 - 32 * b;
+        k.mc_cs = 4 + 8 * h;
+        k.mc_cs2 = 8 - 16 * h;
+    }
     k.mc_lin = kRcWinLuma + (((l >> 4) & 1) * 9 + ((l >> 1) & 7)) * kRcPiece + (l & 1) * 4;
     k.out_luma = l * 4;
     k.out_chroma = 256 + l * 4;
@@ -389,12 +402,10 @@ MPG_HD const uint8_t *rc_win_base(const VideoArgs &a, const RcChunk &c, int m) {
 MPG_HD uint32_t rc_win_offset(const RcChunk &c, int m, const RcLane &k)
 {
     const uint32_t tiled = (c.r[m][0] & (kRIntra | kRDead | kRSlow)) ? 0u : ~0u; // (wave-uniform)
-    const uint32_t d2 = c.r[m][2] & tiled, d3 = c.r[m][3] & tiled;
-    const uint32_t base_l = d2 & ~255u, sub_l = (d2 >> 4) & 15;     // tile of the window origin, its row inside the tile
-    const uint32_t base_c = d3 & ~63u, sub_c = (d3 >> 4) & 3;      // block of the origin, its row PAIR inside the block
-    const uint32_t base = base_l + (k.piece_chroma & (base_c - base_l));
-    const uint32_t t = sub_l + (k.piece_chroma & (sub_c - sub_l)) + k.rj;
-    return base + (k.stride & (0u - (t >> k.sh))) + (t & k.msk) * 16 + k.cterm; // (t >> sh is 0 or 1: the tile below)
+    const uint32_t xl = c.r[m][2] & tiled & ~15u, xc = c.r[m][3] & tiled & ~15u; // (scalar)
+    const uint32_t x = xl + (k.piece_chroma & (xc - xl));
+    const uint32_t u = (x & k.sub_mask) + k.rj16;
+    return x + k.rj16_cterm + (k.below & (0u - (u >> k.wrap_shift))); // (u >> wrap_shift is 0 or 1: the tile below)
 }
 
 // a kRSlow window (it leaves its plane): the reference's LINEAR reads, gathered dword by dword through
@@ -575,10 +586,18 @@ MPG_HD uint32_t rc_mc_luma(const uint8_t *win, const RcLane &k, const RcTaps &t,
     return rc_mc4(p[0], p[1], p[8], p[9], t.luma_x & 3, oh, ov); // (+ 8 dwords: the row below)
 }
 
-// chroma, lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1).  Tiled windows: a row's 16 bytes are two halves
-// of 8 in the pieces of the two blocks: row r of the window = row ((chroma_y + r) & 1) of pair (chroma_y + r) >> 1.
+// chroma, lanes 0..31 (plane lane>>4, row r = (lane>>1)&7, half h = lane&1).  Tiled windows: a row's 16 bytes are two
+// halves of 8 in the pieces of the two blocks: row w of the window (counted from the even row its first pair starts
+// on) begins at rowpart(w) = (w >> 1) * 32 + (w & 1) * 8, and dword i (0..3) of a row sits at f(i) = (i & 1) * 4 +
+// (i >> 1) * 16.  The lane reads dwords i, i + 1 of rows w, w + 1 with w = r + c, i = s + h, where c = chroma_y (0 / 1)
+// and s = chroma_x >> 2 (0 / 1) are wave-uniform.  Both maps are affine in c and s for a FIXED lane:
+//      rowpart(r + c)     = (16 r - 8 b)  + c (8 + 16 b)                 b = r & 1
+//      rowpart(r + c + 1) = rowpart(r + c) + (8 + 16 b) + c (16 - 32 b)
+//      f(s + h)           = 4 h           + s (4 + 8 h)
+//      f(s + h + 1)       = f(s + h) + (4 + 8 h) + s (8 - 16 h)
+// so the four addresses cost four multiply-adds by 0 / 1 on lane constants instead of shifts and masks per macroblock.
 MPG_HD uint32_t rc_chroma_row_at(uint32_t plane160, uint32_t row, uint32_t dword)
-{   // LDS offset of dword `dword` (0..3) of window row `row` (0..9, counted from the even row the first pair starts on)
+{   // the closed form the affine one is checked against (tests/kernel_emu): LDS offset of dword `dword` of row `row`
     return kRcWinLuma + plane160 + (row >> 1) * 32 + (row & 1) * 8 + (dword & 1) * 4 + (dword >> 1) * 16;
 }
 MPG_HD uint32_t rc_mc_chroma(const uint8_t *win, const RcLane &k, const RcTaps &t, int lane, bool oh, bool ov)
@@ -587,16 +606,20 @@ MPG_HD uint32_t rc_mc_chroma(const uint8_t *win, const RcLane &k, const RcTaps &
         const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_lin);
         return rc_mc4(p[0], p[1], p[4], p[5], t.chroma_x, oh, ov); // (+ 4 dwords: the row below)
     }
-    const uint32_t row = t.chroma_y + (((uint32_t)lane >> 1) & 7), q = t.chroma_x + ((uint32_t)lane & 1) * 4; // bytes q .. q+4 of the row
-    const uint32_t i = q >> 2;                                                                             // 0..2
-    const uint32_t a0 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row, i));
-    const uint32_t a1 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row, i + 1));
+    const int32_t c = (int32_t)t.chroma_y, s = (int32_t)(t.chroma_x >> 2); // 0 / 1 each
+    const int32_t a0 = k.mc_c0 + c * k.mc_ck + s * k.mc_cs; // row w, dword i
+    const int32_t a1 = a0 + k.mc_cs + s * k.mc_cs2;          // row w, dword i + 1
+    MPG_CHECK((uint32_t)a0 == rc_chroma_row_at(k.mc_plane, t.chroma_y + (((uint32_t)lane >> 1) & 7), (t.chroma_x >> 2) + ((uint32_t)lane & 1)));
+    MPG_CHECK((uint32_t)a1 == rc_chroma_row_at(k.mc_plane, t.chroma_y + (((uint32_t)lane >> 1) & 7), (t.chroma_x >> 2) + ((uint32_t)lane & 1) + 1));
+    const uint32_t p0 = *reinterpret_cast<const uint32_t *>(win + a0), p1 = *reinterpret_cast<const uint32_t *>(win + a1);
     uint32_t b0 = 0, b1 = 0;
     if (ov) {
-        b0 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row + 1, i));
-        b1 = *reinterpret_cast<const uint32_t *>(win + rc_chroma_row_at(k.mc_plane, row + 1, i + 1));
+        const int32_t down = k.mc_ck + c * k.mc_ck2; // to the row below
+        MPG_CHECK((uint32_t)(a0 + down) == rc_chroma_row_at(k.mc_plane, t.chroma_y + (((uint32_t)lane >> 1) & 7) + 1, (t.chroma_x >> 2) + ((uint32_t)lane & 1)));
+        b0 = *reinterpret_cast<const uint32_t *>(win + a0 + down);
+        b1 = *reinterpret_cast<const uint32_t *>(win + a1 + down);
     }
-    return rc_mc4(a0, a1, b0, b1, q & 3, oh, ov);
+    return rc_mc4(p0, p1, b0, b1, t.chroma_x & 3, oh, ov);
 }
 
 // ---- step 4: residual row + the 8 prediction bytes in O_m -> clamped bytes (video.go:943-971)
@@ -613,16 +636,13 @@ MPG_HD uint32_t rc_mb_index(const VideoArgs &a, uint32_t d0) { return (d0 >> 24)
 // horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), Cb and Cr 256 bytes each by lanes 0..31
 MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
 {
-    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8);
     const uint32_t l = (uint32_t)lane, mb0 = rc_mb_index(a, c.r[0][0]);
-    {
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16);
-        *reinterpret_cast<u32x4 *>(cur + mb0 * 256 + l * 16) = v;
-    }
+    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + (uint64_t)mb0 * 64; // wave-uniform
+    store16_at(cur + (uint64_t)mb0 * 192, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
     if (lane < 32) {
         const uint32_t plane = l >> 4, m = (l >> 2) & 3, part = l & 3;
         const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(m) + 256 + plane * 64 + part * 16);
-        *reinterpret_cast<u32x4 *>(cur + a.luma_bytes + plane * a.chroma_bytes + mb0 * 64 + (l & 15) * 16) = v;
+        store16_at(cur + a.luma_bytes, (a.chroma_bytes & (0u - plane)) + (l & 15) * 16, v);
     }
 }
 

@@ -95,7 +95,7 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
         uint32_t bw[64], e[64];
         for (int lane = 0; lane < 64; lane++) {
             k[lane] = rc_lane(a, lane);
-            e[lane] = load32_uncounted(rc_ent_src(a, c, 0, lane));
+            e[lane] = load32_uncounted(rc_ent_src(a, c, 0, 0), (uint32_t)lane * 4);
         }
         for (int i = 0; i < 6; i++) // (load by load, as they complete on the device: later loads overwrite the surplus lanes)
             for (int lane = 0; lane < kRcWinLanes; lane++) {
