@@ -50,6 +50,9 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k)
 #endif
 
+#ifndef MPG_CHUNK_AHEAD
+#define MPG_CHUNK_AHEAD 256 // chunks; 0 = off (profiles/r3f_ab_chunk_pull_ahead.txt: 64 / 256 / 1024)
+#endif
 template <int WAVES, bool kRgba>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_kernel(const VideoArgs a)
 {
@@ -68,6 +71,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     uint8_t *lds = lds_all + w * kRcLdsBytes;
     int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
 
+#if MPG_CHUNK_AHEAD
+    // pull a later chunk of this XCD's range towards L2 (two lanes, one per cache line of its 96 bytes) so that that
+    // wave's scalar loads find it there; nothing is done with the data
+    uint32_t ahead;
+    {
+        const uint32_t later = chunk + MPG_CHUNK_AHEAD < a.n_chunks ? chunk + MPG_CHUNK_AHEAD : chunk;
+        ahead = load32_uncounted(a.chunks + (uint64_t)later * kRcChunkDwords, (uint32_t)(lane & 1) * 64);
+    }
+#endif
     // step 1: one round of scalar loads, then the five vector loads of the chunk
     const RcChunk c = rc_load_chunk(a, chunk);
     const RcLane k = rc_lane(a, lane);
@@ -139,6 +151,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     // step 3: motion compensation, half-pel modes wave-uniform per macroblock: window in LDS -> O_m over it
     wait_loads<0>(); // all four windows are there
     settle(e);       // (on every path: until here the entries' register belongs to a load in flight)
+#if MPG_CHUNK_AHEAD
+    settle(ahead);
+#endif
     wave_lds_handoff();
 #pragma unroll
     for (int m = 0; m < kRcMbs; m++) {
