@@ -73,7 +73,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 
 #if MPG_CHUNK_AHEAD
     // pull a later chunk of this XCD's range towards L2 (two lanes, one per cache line of its 96 bytes) so that that
-    // wave's scalar loads find it there; nothing is done with the data
+    // wave's scalar loads find it there; nothing is done with the data.  (Also pulling that chunk's first words, by a
+    // dependent load once its header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
     uint32_t ahead;
     {
         const uint32_t later = chunk + MPG_CHUNK_AHEAD < a.n_chunks ? chunk + MPG_CHUNK_AHEAD : chunk;
