@@ -220,28 +220,40 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 }
 #undef MPG_STAMP
 
-// Frame.RGBA of the cur slot of every picture flagged MPEGHIP_PIC_RGBA: grid (x quads, rows, pictures).
+// Which 4x2 pixel block a thread of the whole-frame conversions takes.  The frame store is tiled (video_lane.h), so a
+// wave walks TILES, not picture rows: wave = 4 macroblocks side by side x 8 rows, lane = (macroblock lane>>4, row pair
+// (lane>>2)&3, quad lane&3): its luma reads are 4 x 128 contiguous bytes, each RGBA store instruction writes one row of
+// 64 pixels = 256 contiguous bytes.  Workgroup = 4 waves = 8 macroblocks x 16 rows; grid (mb_w / 8, mb_h, frames).
+MPG_HD void rgba_thread_quad(uint32_t tid, uint32_t bx, uint32_t by, uint32_t &x4, uint32_t &yp)
+{
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const uint32_t mb = (bx * 2 + (wave >> 1)) * 4 + (lane >> 4);
+    x4 = mb * 4 + (lane & 3);
+    yp = by * 8 + (wave & 1) * 4 + ((lane >> 2) & 3);
+}
+
+// Frame.RGBA of the cur slot of every picture flagged MPEGHIP_PIC_RGBA: grid (macroblock columns / 8, macroblock rows, pictures).
 __global__ __launch_bounds__(256) void rgba_pics_kernel(const VideoArgs a, uint32_t pic0)
 {
     const mpeghip_pic_desc p = a.pics[pic0 + blockIdx.z];
     if (!(p.flags & MPEGHIP_PIC_RGBA))
         return;
-    const uint32_t x4 = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    uint32_t x4, y;
+    rgba_thread_quad(threadIdx.x, blockIdx.x, blockIdx.y, x4, y);
     const uint64_t fs = (uint64_t)p.stream * MPEGHIP_SLOTS + p.cur;
     rgba_convert_quad(a.frames + fs * a.frame_stride, a.mb_w, a.luma_bytes, a.chroma_bytes, a.width, a.height, x4, y,
                       a.rgba + fs * a.rgba_stride);
 }
 
-// Frame.RGBA for whole slots: grid (x quads, row pairs / 4, streams).
+// Frame.RGBA for whole slots: grid (macroblock columns / 8, macroblock rows, streams).
 __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64_t frame_stride,
                                                   uint8_t *rgba, uint64_t rgba_stride,
                                                   uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_bytes,
                                                   uint32_t width, uint32_t height,
                                                   uint32_t slot, uint32_t stream0)
 {
-    const uint32_t x4 = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    uint32_t x4, y;
+    rgba_thread_quad(threadIdx.x, blockIdx.x, blockIdx.y, x4, y);
     const uint64_t fs = (uint64_t)(stream0 + blockIdx.z) * MPEGHIP_SLOTS + slot;
     rgba_convert_quad(frames + fs * frame_stride, mb_w, luma_bytes, chroma_bytes, width, height, x4, y, rgba + fs * rgba_stride);
 }
@@ -1033,10 +1045,9 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
                 whole_frames = true, sync = 1;
         }
     if (whole_frames) {
-        const uint32_t quads = (in.width + 3) / 4;
         for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
             const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-            hipLaunchKernelGGL(rgba_pics_kernel, dim3((quads + 63) / 64, (in.height + 7) / 8, np), dim3(256), 0, st, a,
+            hipLaunchKernelGGL(rgba_pics_kernel, dim3((in.mb_w + 7) / 8, in.mb_h, np), dim3(256), 0, st, a,
                                (uint32_t)p0);
         }
         HIP_TRY(hipGetLastError());
@@ -1561,11 +1572,10 @@ int mpeghip_video_rgba_convert(mpeghip_video *v, uint32_t slot, uint32_t stream0
             }
     }
     const mpeghip_video_info &in = v->info;
-    const uint32_t quads = (in.width + 3) / 4;
     // grid.z is limited to 65535
     for (uint32_t s0 = 0; s0 < n; s0 += 32768) {
         const uint32_t ns = n - s0 < 32768 ? n - s0 : 32768;
-        dim3 grid((quads + 63) / 64, (in.height + 7) / 8, ns);
+        dim3 grid((in.mb_w + 7) / 8, in.mb_h, ns);
         hipLaunchKernelGGL(rgba_kernel, grid, dim3(256), 0, v->ctx->stream, v->d_frames, in.frame_stride, v->d_rgba,
                            rgba_stride_of(v), in.mb_w, (uint32_t)in.luma_bytes, (uint32_t)in.chroma_bytes,
                            in.width, in.height, slot, stream0 + s0);
