@@ -286,30 +286,47 @@ MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t tg0, u
 // The 16 taps of one output sample of two sub-blocks when the ring position is 64*M
 // (audio_noasm.go:8-38).  p0/p1 = the lane's history pointers for d[0..31] / d[32..63] at slot
 // (top - 15), where `top` is the (possibly repeated) slot of the sub-block; A and B are the two
-// sub-blocks.  Everything else folds to immediates.
-template <int M, bool kFma>
-MPG_HD void window_taps(const float *p0A, const float *p1A, const float *p0B, const float *p1B, const float (&d)[16], float &accA,
-                        float &accB)
+// sub-blocks.  Everything else folds to immediates.  Two halves: window_load reads the 2 x 16 history
+// values (in accumulation order) and window_sum adds them up — so that a wave can have the NEXT pair's
+// reads in flight while it sums this one (the reads' LDS latency was what a window wave spent its time on).
+struct WinTaps {
+    float a[16], b[16];
+};
+template <int M> MPG_HD void window_load(const float *p0A, const float *p1A, const float *p0B, const float *p1B, WinTaps &w)
 {
     constexpr int32_t pos = 64 * M;
     constexpr int32_t v0 = (pos & 127) >> 1;
-    constexpr int32_t d0 = 512 - (pos >> 1);
-    float a = 0.0f, b = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) { // audio_noasm.go:14-24 — first run of 8 taps
         const int32_t e = (v0 - pos + 128 * k) & 1023;
-        const int32_t seg = ((d0 + 64 * k) & 511) >> 5;
         const int off = (15 - (e >> 6)) * kSlotStride;
-        a = tap<kFma>(a, d[seg], ((e & 63) >> 5) ? p1A[off] : p0A[off]);
-        b = tap<kFma>(b, d[seg], ((e & 63) >> 5) ? p1B[off] : p0B[off]);
+        w.a[k] = ((e & 63) >> 5) ? p1A[off] : p0A[off];
+        w.b[k] = ((e & 63) >> 5) ? p1B[off] : p0B[off];
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) { // audio_noasm.go:26-37 — second run
         const int32_t e = (96 - v0 - pos + 128 * k) & 1023;
-        const int32_t seg = ((d0 + 32 + 64 * k) & 511) >> 5;
         const int off = (15 - (e >> 6)) * kSlotStride;
-        a = tap<kFma>(a, d[seg], ((e & 63) >> 5) ? p1A[off] : p0A[off]);
-        b = tap<kFma>(b, d[seg], ((e & 63) >> 5) ? p1B[off] : p0B[off]);
+        w.a[8 + k] = ((e & 63) >> 5) ? p1A[off] : p0A[off];
+        w.b[8 + k] = ((e & 63) >> 5) ? p1B[off] : p0B[off];
+    }
+}
+template <int M, bool kFma> MPG_HD void window_sum(const WinTaps &w, const float (&d)[16], float &accA, float &accB)
+{
+    constexpr int32_t pos = 64 * M;
+    constexpr int32_t d0 = 512 - (pos >> 1);
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int32_t seg = ((d0 + 64 * k) & 511) >> 5;
+        a = tap<kFma>(a, d[seg], w.a[k]);
+        b = tap<kFma>(b, d[seg], w.b[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int32_t seg = ((d0 + 32 + 64 * k) & 511) >> 5;
+        a = tap<kFma>(a, d[seg], w.a[8 + k]);
+        b = tap<kFma>(b, d[seg], w.b[8 + k]);
     }
     accA = a;
     accB = b;
@@ -352,18 +369,31 @@ MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg,
         (reinterpret_cast<float *>(a.out) + sb)[e] = sv * 2147483648.0f;
 }
 
-// one window pair: sub-blocks tgA and tgA + 16 (same ring position modulo 16 slots, so the same taps),
-// for the ring position 64*M known at compile time
-template <int M, bool kFma, int kFormat>
-MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, uint32_t tgA, uint32_t tg1, uint32_t slotA, int ch, int i,
-                              const float *p0, const float *p1, const float (&dreg)[16])
-{
-    const uint32_t tgB = tgA + 16;
-    const uint32_t slotB = slotA + 16 >= (uint32_t)kRing ? slotA + 16 - kRing : slotA + 16; // ring_slot(TA + 16)
+// one window pair: sub-blocks tgA and tgA + 16 (same ring position modulo 16 slots, so the same taps), for the ring
+// position 64*M known at compile time.  The pair of this step whose ring position is 64*M is p = (c - M) mod 16
+// (vpos_at: the position falls by one slot per sub-block), c = the ring slot index one sub-block before the step.
+struct WinStep {
+    uint32_t c, slot0, base, tg1;
+    int ch, i;
+    const float *p0, *p1;
+};
+template <int M> MPG_HD void audio_window_load(const WinStep &s, WinTaps &w)
+{   // (also for a pair past the slice's end: it reads valid, stale history and is dropped by audio_window_finish)
+    const uint32_t p = (s.c - (uint32_t)M) & 15u;
+    const uint32_t slotA = s.slot0 + p >= (uint32_t)kRing ? s.slot0 + p - kRing : s.slot0 + p; // ring_slot(kT0 + base + p)
+    const uint32_t slotB = slotA + 16 >= (uint32_t)kRing ? slotA + 16 - kRing : slotA + 16;       // ring_slot(TA + 16)
     const int32_t offA = (int32_t)((slotA < (uint32_t)kMirrorSlots ? slotA + kRing : slotA) - 15) * kSlotStride;
     const int32_t offB = (int32_t)((slotB < (uint32_t)kMirrorSlots ? slotB + kRing : slotB) - 15) * kSlotStride;
+    window_load<M>(s.p0 + offA, s.p1 + offA, s.p0 + offB, s.p1 + offB, w);
+}
+template <int M, bool kFma, int kFormat>
+MPG_HD void audio_window_finish(const AudioArgs &a, uint32_t stream, const WinStep &s, const WinTaps &w, const float (&dreg)[16])
+{
+    const uint32_t tgA = s.base + ((s.c - (uint32_t)M) & 15u), tgB = tgA + 16;
+    if (tgA >= s.tg1)
+        return;
     float accA, accB;
-    window_taps<M, kFma>(p0 + offA, p1 + offA, p0 + offB, p1 + offB, dreg, accA, accB);
+    window_sum<M, kFma>(w, dreg, accA, accB);
     float svA, svB;
     if (all_in_wave(scale_short_ok(accA) && scale_short_ok(accB))) {
         svA = scale_short(accA);
@@ -372,22 +402,9 @@ MPG_HD void audio_window_pair(const AudioArgs &a, uint32_t stream, uint32_t tgA,
         svA = accA / kScale;
         svB = accB / kScale;
     }
-    audio_store_sample<kFormat>(a, stream, tgA, ch, i, svA);
-    if (tgB < tg1) // past the slice: B read stale history, drop it
-        audio_store_sample<kFormat>(a, stream, tgB, ch, i, svB);
-}
-
-// the pair of this step whose ring position is 64*M: p = (c - M) mod 16 (vpos_at: the position falls by one
-// slot per sub-block), c = the ring slot index one sub-block before the step
-template <int M, bool kFma, int kFormat>
-MPG_HD void audio_window_m(const AudioArgs &a, uint32_t stream, uint32_t c, uint32_t slot0, uint32_t base, uint32_t tg1, int ch,
-                           int i, const float *p0, const float *p1, const float (&dreg)[16])
-{
-    const uint32_t p = (c - (uint32_t)M) & 15u;
-    if (base + p < tg1) {
-        const uint32_t slotA = slot0 + p >= (uint32_t)kRing ? slot0 + p - kRing : slot0 + p; // ring_slot(kT0 + base + p)
-        audio_window_pair<M, kFma, kFormat>(a, stream, base + p, tg1, slotA, ch, i, p0, p1, dreg);
-    }
+    audio_store_sample<kFormat>(a, stream, tgA, s.ch, s.i, svA);
+    if (tgB < s.tg1) // past the slice: B read stale history, drop it
+        audio_store_sample<kFormat>(a, stream, tgB, s.ch, s.i, svB);
 }
 
 // ---- windows of step si: 16 pairs (p, p + 16), one per ring position M = 0..15.  Which taps a pair
@@ -406,14 +423,37 @@ MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos
     const uint32_t c = (uint32_t)(vpos_at(vpos0, kT0 + (int32_t)base) >> 6); // ring slot index of pair 0
     const uint32_t slot0 = (uint32_t)ring_slot(kT0 + (int32_t)base);         // one modulo per step, not two per pair
     const uint32_t rank = (wave - busy - 1) % kAudioWaves; // 0..2 for the three free waves, 3 for the busy one
-#define MPG_WIN(M) audio_window_m<M, kFma, kFormat>(a, stream, c, slot0, base, tg1, ch, i, p0, p1, dreg)
+    const WinStep s = {c, slot0, base, tg1, ch, i, p0, p1};
+    WinTaps w0, w1;
+    // a free wave's five pairs, software-pipelined: the reads of pair n + 1 are issued before pair n is summed
+#define MPG_WIN5(M0, M1, M2, M3, M4)                                                                                   \
+    do {                                                                                                               \
+        audio_window_load<M0>(s, w0);                                                                                  \
+        audio_window_load<M1>(s, w1);                                                                                  \
+        sched_fence();                                                                                                 \
+        audio_window_finish<M0, kFma, kFormat>(a, stream, s, w0, dreg);                                                \
+        audio_window_load<M2>(s, w0);                                                                                  \
+        sched_fence();                                                                                                 \
+        audio_window_finish<M1, kFma, kFormat>(a, stream, s, w1, dreg);                                                \
+        audio_window_load<M3>(s, w1);                                                                                  \
+        sched_fence();                                                                                                 \
+        audio_window_finish<M2, kFma, kFormat>(a, stream, s, w0, dreg);                                                \
+        audio_window_load<M4>(s, w0);                                                                                  \
+        sched_fence();                                                                                                 \
+        audio_window_finish<M3, kFma, kFormat>(a, stream, s, w1, dreg);                                                \
+        audio_window_finish<M4, kFma, kFormat>(a, stream, s, w0, dreg);                                                \
+    } while (0)
     switch (rank) {
-    case 0: MPG_WIN(0); MPG_WIN(3); MPG_WIN(6); MPG_WIN(9); MPG_WIN(12); break;
-    case 1: MPG_WIN(1); MPG_WIN(4); MPG_WIN(7); MPG_WIN(10); MPG_WIN(13); break;
-    case 2: MPG_WIN(2); MPG_WIN(5); MPG_WIN(8); MPG_WIN(11); MPG_WIN(14); break;
-    default: MPG_WIN(15); break;
+    case 0: MPG_WIN5(0, 3, 6, 9, 12); break;
+    case 1: MPG_WIN5(1, 4, 7, 10, 13); break;
+    case 2: MPG_WIN5(2, 5, 8, 11, 14); break;
+    default:
+        audio_window_load<15>(s, w0);
+        sched_fence();
+        audio_window_finish<15, kFma, kFormat>(a, stream, s, w0, dreg);
+        break;
     }
-#undef MPG_WIN
+#undef MPG_WIN5
 }
 
 // ---- state out: last 16 history slots -> Audio.v ring; thread 0 advances vPos

@@ -307,6 +307,14 @@ MPG_HD void settle(uint32_t &v)
 #endif
 }
 
+// the instruction scheduler moves nothing across this point (no instruction)
+MPG_HD void sched_fence()
+{
+#if MPG_ON_DEVICE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // hides a value's provenance from the optimiser (no instruction)
 MPG_HD uint32_t opaque(uint32_t v)
 {

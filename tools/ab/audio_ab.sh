@@ -1,5 +1,8 @@
+# audio kernel A/B on one box: the current library against every tools/ab/libmpeghip_<name>.so, interleaved
+# (BASELINE config 4: 256 streams x 100 frames; parity of all streams against the oracle in every run)
 cp mpeg_amd/libmpeghip.so /tmp/cur.so
-for r in 1 2 3; do for v in cur slices5 slices6 slices8; do
+VARIANTS="cur $(ls tools/ab/libmpeghip_*.so 2>/dev/null | sed 's/.*libmpeghip_\(.*\)\.so/\1/')"
+for r in 1 2 3; do for v in $VARIANTS; do
   if [ $v = cur ]; then cp /tmp/cur.so mpeg_amd/libmpeghip.so; else cp tools/ab/libmpeghip_$v.so mpeg_amd/libmpeghip.so; fi
   python bench.py --steps 2 --warmup 1 --streams 16 --legs "" --cpu-seconds 0 --check 1 2>/dev/null | python -c "
 import json,sys
