@@ -289,6 +289,17 @@ MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t tg0, u
 // sub-blocks.  Everything else folds to immediates.  Two halves: window_load reads the 2 x 16 history
 // values (in accumulation order) and window_sum adds them up — so that a wave can have the NEXT pair's
 // reads in flight while it sums this one (the reads' LDS latency was what a window wave spent its time on).
+// one dword read that the compiler leaves alone: a ds_read_b32 with its 16-bit immediate offset.  (Merged into
+// ds_read2_b32, whose offsets reach 1 KB, the 2 x 16 reads of a pair needed 16 extra address additions.)
+MPG_HD float lds_read_as_is(const float *p)
+{
+#if MPG_ON_DEVICE
+    typedef const volatile float __attribute__((address_space(3))) * lds_float_ptr; // (low 32 bits of an LDS address = its offset)
+    return *(lds_float_ptr)(uint32_t)(uintptr_t)p;
+#else
+    return *p;
+#endif
+}
 struct WinTaps {
     float a[16], b[16];
 };
@@ -300,15 +311,15 @@ template <int M> MPG_HD void window_load(const float *p0A, const float *p1A, con
     for (int k = 0; k < 8; k++) { // audio_noasm.go:14-24 — first run of 8 taps
         const int32_t e = (v0 - pos + 128 * k) & 1023;
         const int off = (15 - (e >> 6)) * kSlotStride;
-        w.a[k] = ((e & 63) >> 5) ? p1A[off] : p0A[off];
-        w.b[k] = ((e & 63) >> 5) ? p1B[off] : p0B[off];
+        w.a[k] = lds_read_as_is(((e & 63) >> 5) ? p1A + off : p0A + off);
+        w.b[k] = lds_read_as_is(((e & 63) >> 5) ? p1B + off : p0B + off);
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) { // audio_noasm.go:26-37 — second run
         const int32_t e = (96 - v0 - pos + 128 * k) & 1023;
         const int off = (15 - (e >> 6)) * kSlotStride;
-        w.a[8 + k] = ((e & 63) >> 5) ? p1A[off] : p0A[off];
-        w.b[8 + k] = ((e & 63) >> 5) ? p1B[off] : p0B[off];
+        w.a[8 + k] = lds_read_as_is(((e & 63) >> 5) ? p1A + off : p0A + off);
+        w.b[8 + k] = lds_read_as_is(((e & 63) >> 5) ? p1B + off : p0B + off);
     }
 }
 template <int M, bool kFma> MPG_HD void window_sum(const WinTaps &w, const float (&d)[16], float &accA, float &accB)
