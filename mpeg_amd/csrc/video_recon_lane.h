@@ -65,6 +65,12 @@
 #if !MPG_ON_DEVICE && defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#if !MPG_ON_DEVICE && defined(__x86_64__)
+#include <immintrin.h>
+#define MPG_HOST_AVX512 1 // compiled in as separate target("avx512...") functions, chosen at run time
+#else
+#define MPG_HOST_AVX512 0
+#endif
 
 namespace mpg {
 
@@ -146,6 +152,38 @@ static inline uint64_t rc_nonzero_mask(const uint8_t *unit)
 }
 
 // Room one picture of n macroblocks with `units` coefficient units can need (dwords).
+#if MPG_HOST_AVX512
+// The same two steps on 512-bit registers (run-time dispatch: rc_host_has_avx512).  Entries of one unit: its non-zero
+// words as `word << 16 | position << 2 | bits`, ascending positions — sixteen words at a time are widened, tagged with
+// their positions and compressed in a register; the store is a plain 64-byte one whose tail the next store (or the
+// chunk's next words) overwrites, so `out` needs 15 dwords of slack (rc_max_words budgets 65 per unit, a sparse block
+// uses at most 33).
+__attribute__((target("avx512f,avx512bw"))) static inline uint64_t rc_nonzero_mask_avx512(const uint8_t *unit)
+{
+    const __m512i a = _mm512_loadu_si512(unit), b = _mm512_loadu_si512(unit + 64);
+    return (uint64_t)_mm512_test_epi16_mask(a, a) | ((uint64_t)_mm512_test_epi16_mask(b, b) << 32);
+}
+__attribute__((target("avx512f,avx512bw,avx512vl"))) static inline uint32_t rc_emit_entries_avx512(const uint8_t *unit, uint64_t mask,
+                                                                                               uint32_t bits, uint32_t *out)
+{
+    const __m512i pos4 = _mm512_set_epi32(60, 56, 52, 48, 44, 40, 36, 32, 28, 24, 20, 16, 12, 8, 4, 0);
+    uint32_t n = 0;
+    for (uint32_t g = 0; g < 4; g++) {
+        const __mmask16 m = (__mmask16)(mask >> (16 * g)); // (no early-out for an empty group: the branch mispredicts)
+        const __m512i w = _mm512_cvtepu16_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(unit + 32 * g)));
+        const __m512i e = _mm512_or_si512(_mm512_slli_epi32(w, 16), _mm512_add_epi32(pos4, _mm512_set1_epi32((int)(bits + 64 * g))));
+        _mm512_storeu_si512(out + n, _mm512_maskz_compress_epi32(m, e));
+        n += (uint32_t)__builtin_popcount(m);
+    }
+    return n;
+}
+static inline bool rc_host_has_avx512()
+{
+    static const bool have = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    return have;
+}
+#endif
+
 static inline size_t rc_max_chunks(uint32_t n) { return ((size_t)n + kRcMbs - 1) / kRcMbs; }
 static inline size_t rc_max_words(uint64_t units) { return (size_t)units * 65; }
 constexpr size_t kRcWordsPad = 256; // dwords behind the last chunk's words that a wave may read (and ignore)
@@ -158,10 +196,14 @@ struct RcPacked {
 // Pack ONE picture: macroblocks mbs[0..n) (already validated), whose coef_off index 128-byte units behind
 // `coefs`.  Chunk headers name their words by index: this picture's first word is word_base (callers that
 // only learn the base afterwards pass 0 and add it with rc_rebase).
+template <bool kWide = true> // kWide: use the 512-bit forms where the CPU has them (tests compare both)
 static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &p, const mpeghip_mb_desc *mbs, uint32_t n,
                                        const uint8_t *coefs, uint32_t word_base, uint32_t *chunks_out, uint32_t *words_out)
 {
     RcPacked out;
+#if MPG_HOST_AVX512
+    const bool wide = kWide && rc_host_has_avx512();
+#endif
     const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
     const uint32_t cur256 = (uint32_t)(((s3 + p.cur) * g.frame_stride) >> 8); // strides are multiples of 256
     const uint32_t fwd256 = (uint32_t)(((s3 + p.fwd) * g.frame_stride) >> 8);
@@ -171,14 +213,18 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
     for (uint32_t k0 = 0; k0 < n; k0 += kRcMbs) {
         const uint32_t live = n - k0 < (uint32_t)kRcMbs ? n - k0 : (uint32_t)kRcMbs;
         uint32_t *h = chunks_out + (size_t)out.chunks * kRcChunkDwords;
-        struct Slot {
+        // one pass over the chunk's coded blocks: the block words come first, so their number is counted up front
+        uint32_t n_coded = 0;
+        for (uint32_t m = 0; m < live; m++)
+            n_coded += (uint32_t)__builtin_popcount(mbs[k0 + m].cbp & 0x3fu);
+        struct Deferred { // snapshot and dense blocks: their data goes behind the chunk's entries
             const uint8_t *unit;
-            uint32_t bits; // quantiser_scale << 11 | non-intra << 1
-            uint64_t mask; // non-zero levels
-            bool intra, raw, dense;
-        } slot[kRcMaxBlocks];
-        uint32_t n_slots = 0;
+            uint32_t slot, dwords;
+        } deferred[kRcMaxBlocks];
+        uint32_t n_slots = 0, n_deferred = 0;
         uint32_t *bw = words_out + out.words;
+        uint32_t *e0 = bw + n_coded, ne = 0, counts = 0, pass_start = 0;
+        bool any_raw = false, any_dense = false;
         bool run = live == (uint32_t)kRcMbs; // 4 consecutive macroblocks of one row = 4 consecutive tiles
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++) {
             uint32_t *d = h + 8 + m * 4;
@@ -221,54 +267,58 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
                   (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
             uint32_t unit = mb.coef_off;
-            for (int b = 0; b < 6; b++) {
-                if (!(mb.cbp & (0x20u >> b)))
-                    continue;
-                Slot &s = slot[n_slots];
-                s.unit = coefs + (size_t)unit * MPEGHIP_COEF_UNIT;
-                s.bits = ((uint32_t)(mb.qscale & 31) << 11) | (intra ? 0u : kENonIntra);
-                s.intra = intra;
-                s.raw = raw;
-                s.mask = raw ? 0 : rc_nonzero_mask(s.unit);
-                s.dense = !raw && (uint32_t)__builtin_popcountll(s.mask) > kDenseAbove;
-                bw[n_slots] = (rc_tile_offset(b, 0, m) >> 3) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
-                if (s.dense)
-                    bw[n_slots] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
+            for (uint32_t left = mb.cbp & 0x3fu; left; ) { // coded blocks in block order = from bit 5 down (one exit branch)
+                const int b = __builtin_clz(left) - 26;
+                left &= ~(0x20u >> b);
+                const uint8_t *u = coefs + (size_t)unit * MPEGHIP_COEF_UNIT;
+                const uint32_t s = n_slots++;
+                if ((s & 7) == 0 && s) { // a new pass of 8 blocks starts: its entries are counted separately
+                    counts |= (ne - pass_start) << (10 * ((s >> 3) - 1));
+                    pass_start = ne;
+                }
+                bw[s] = (rc_tile_offset(b, 0, m) >> 3) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
                 unit += raw ? 2 : 1;
-                n_slots++;
-            }
-        }
-        uint32_t *e0 = bw + n_slots, ne = 0, counts = 0;
-        bool any_raw = false, any_dense = false;
-        for (uint32_t pass = 0; pass * 8 < n_slots; pass++) {
-            const uint32_t before = ne;
-            for (uint32_t s = pass * 8; s < n_slots && s < pass * 8 + 8; s++) {
-                const Slot &sl = slot[s];
-                if (sl.raw || sl.dense) {
-                    any_raw = any_raw || sl.raw;
-                    any_dense = any_dense || sl.dense;
+                if (raw) {
+                    any_raw = true;
+                    deferred[n_deferred++] = Deferred{u, s, 64};
                     continue;
                 }
-                uint64_t mask = sl.mask;
-                const uint32_t bits = sl.bits | ((s & 7) << 8);
-                while (mask) {
-                    const uint32_t pos = (uint32_t)__builtin_ctzll(mask);
-                    mask &= mask - 1;
+#if MPG_HOST_AVX512
+                const uint64_t mask = wide ? rc_nonzero_mask_avx512(u) : rc_nonzero_mask(u);
+#else
+                const uint64_t mask = rc_nonzero_mask(u);
+#endif
+                if ((uint32_t)__builtin_popcountll(mask) > kDenseAbove) { // the unit as it is is the shorter form
+                    any_dense = true;
+                    bw[s] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
+                    deferred[n_deferred++] = Deferred{u, s, 32};
+                    continue;
+                }
+                const uint32_t bits = ((uint32_t)(mb.qscale & 31) << 11) | (intra ? 0u : kENonIntra) | ((s & 7) << 8);
+#if MPG_HOST_AVX512
+                if (wide) {
+                    const uint32_t first = ne;
+                    ne += rc_emit_entries_avx512(u, mask, bits, e0 + ne);
+                    if (intra && (mask & 1))
+                        e0[first] |= kEDc;
+                    continue;
+                }
+#endif
+                for (uint64_t left_bits = mask; left_bits; left_bits &= left_bits - 1) {
+                    const uint32_t pos = (uint32_t)__builtin_ctzll(left_bits);
                     uint16_t w;
-                    memcpy(&w, sl.unit + pos * 2, 2);
-                    e0[ne++] = ((uint32_t)w << 16) | bits | (pos << 2) | ((sl.intra && pos == 0) ? kEDc : 0u);
+                    memcpy(&w, u + pos * 2, 2);
+                    e0[ne++] = ((uint32_t)w << 16) | bits | (pos << 2) | ((intra && pos == 0) ? kEDc : 0u);
                 }
             }
-            counts |= (ne - before) << (10 * pass);
         }
-        if (any_raw || any_dense)
-            for (uint32_t s = 0; s < n_slots; s++)
-                if (slot[s].raw || slot[s].dense) { // the unit(s) as they are (position order = the unit's order)
-                    const uint32_t dwords = slot[s].raw ? 64 : 32;
-                    bw[s] |= ne << 12;
-                    memcpy(e0 + ne, slot[s].unit, dwords * 4);
-                    ne += dwords;
-                }
+        if (n_slots)
+            counts |= (ne - pass_start) << (10 * ((n_slots - 1) >> 3));
+        for (uint32_t i = 0; i < n_deferred; i++) { // the unit(s) as they are (position order = the unit's order)
+            bw[deferred[i].slot] |= ne << 12;
+            memcpy(e0 + ne, deferred[i].unit, deferred[i].dwords * 4);
+            ne += deferred[i].dwords;
+        }
         h[0] = cur256;
         h[1] = rgba256;
         h[2] = p.stream * kRcQtabStride;

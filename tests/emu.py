@@ -41,8 +41,10 @@ def lib():
         L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
         L.emu_make_qtable.restype = None
         L.emu_make_qtable.argtypes = [P, P, P]
-        L.emu_pack.restype = C.c_uint32
-        L.emu_pack.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, P, P, P]
+        for f in (L.emu_pack, L.emu_pack_narrow):
+            f.restype = C.c_uint32
+            f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, P, P, P]
+        L.emu_host_has_avx512.restype = C.c_int
         L.emu_relayout.restype = None
         L.emu_relayout.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
         L.emu_rgba_convert.restype = None

@@ -24,6 +24,22 @@ static const uint8_t kPremult[64] = {32, 44, 42, 38, 32, 25, 17, 9,  44, 62, 58,
                                      23, 12, 38, 52, 49, 44, 38, 30, 20, 10, 32, 44, 42, 38, 32, 25, 17, 9,  25, 35, 33, 30,
                                      25, 20, 14, 7,  17, 24, 23, 20, 17, 14, 9,  5,  9,  12, 12, 10, 9,  7,  5,  2};
 
+template <bool kWide>
+static uint32_t emu_pack_as(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride, uint64_t rgba_stride, const mpeghip_pic_desc *pic,
+                            const mpeghip_mb_desc *mbs, const uint8_t *coefs, uint32_t *chunks_out, uint32_t *words_out, uint32_t *n_words)
+{
+    RcGeom geom;
+    geom.mb_w = luma_w / 16;
+    geom.mb_h = luma_h / 16;
+    geom.luma_w = luma_w;
+    geom.chroma_w = luma_w / 2;
+    geom.luma_bytes = luma_w * luma_h;
+    geom.frame_stride = frame_stride;
+    geom.rgba_stride = rgba_stride;
+    const RcPacked got = rc_pack_picture<kWide>(geom, *pic, mbs, pic->mb_count, coefs, 0, chunks_out, words_out);
+    *n_words = got.words;
+    return got.chunks;
+}
 extern "C" {
 
 // one stream's dequantisation table in the device layout (what mpeghip_video_open / _set_quant upload)
@@ -206,17 +222,21 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
 uint32_t emu_pack(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride, uint64_t rgba_stride, const mpeghip_pic_desc *pic,
                   const mpeghip_mb_desc *mbs, const uint8_t *coefs, uint32_t *chunks_out, uint32_t *words_out, uint32_t *n_words)
 {
-    RcGeom geom;
-    geom.mb_w = luma_w / 16;
-    geom.mb_h = luma_h / 16;
-    geom.luma_w = luma_w;
-    geom.chroma_w = luma_w / 2;
-    geom.luma_bytes = luma_w * luma_h;
-    geom.frame_stride = frame_stride;
-    geom.rgba_stride = rgba_stride;
-    const RcPacked got = rc_pack_picture(geom, *pic, mbs, pic->mb_count, coefs, 0, chunks_out, words_out);
-    *n_words = got.words;
-    return got.chunks;
+    return emu_pack_as<true>(luma_w, luma_h, frame_stride, rgba_stride, pic, mbs, coefs, chunks_out, words_out, n_words);
+}
+// the packer without its 512-bit forms (what a CPU without AVX-512 runs): must write the same words
+uint32_t emu_pack_narrow(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride, uint64_t rgba_stride, const mpeghip_pic_desc *pic,
+                         const mpeghip_mb_desc *mbs, const uint8_t *coefs, uint32_t *chunks_out, uint32_t *words_out, uint32_t *n_words)
+{
+    return emu_pack_as<false>(luma_w, luma_h, frame_stride, rgba_stride, pic, mbs, coefs, chunks_out, words_out, n_words);
+}
+int emu_host_has_avx512(void)
+{
+#if MPG_HOST_AVX512
+    return rc_host_has_avx512() ? 1 : 0;
+#else
+    return 0;
+#endif
 }
 
 // rgba_pixel (the arrangement the device uses) against ycbcr_to_rgba (the reference's form) for ALL

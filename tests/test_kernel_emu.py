@@ -135,3 +135,28 @@ def test_audio_lane_logic_reproduces_golden_hash(oracle, emu, golden_dir, fma, w
             h = oracle.fnv1a64(e.synth(part, 0), h)
         i += chunk
     assert h == want
+
+
+@pytest.mark.parametrize("profile,raw", [("typical", 0.0), ("typical", 0.2), ("dense", 0.0)])
+def test_packer_512_bit_forms_write_the_same_words(emu, profile, raw):
+    """rc_pack_picture with and without its AVX-512 forms (entries by widen + compress instead of a bit-scan loop):
+    identical chunks and words, so a host without AVX-512 feeds the kernel the same bytes."""
+    import ctypes as C
+    L = emu.lib()
+    if not L.emu_host_has_avx512():
+        pytest.skip("this CPU has no AVX-512: only the narrow form exists here")
+    g = desc.geometry(176, 144)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    for s in synth.generate_sequence(176, 144, 4, profile=profile, raw_fraction=raw, seed=77):
+        pics = np.ascontiguousarray(s.pics, desc.PIC_DTYPE)
+        mbs = np.ascontiguousarray(s.mbs, desc.MB_DTYPE)
+        coefs = np.ascontiguousarray(s.coefs).view(np.uint8).reshape(-1)
+        got = []
+        for f in (L.emu_pack, L.emu_pack_narrow):
+            chunks = np.zeros((len(mbs) // 4 + 4) * 24, np.uint32)
+            words = np.zeros(len(coefs) // 2 + len(mbs) * 6 + 1024, np.uint32)
+            nw = C.c_uint32(0)
+            nc = f(g["luma_w"], g["luma_h"], 1 << 20, 1 << 20, P(pics), P(mbs), P(coefs), P(chunks), P(words), C.byref(nw))
+            got.append((nc, nw.value, chunks[:nc * 24].copy(), words[:nw.value].copy()))
+        assert got[0][0] == got[1][0] and got[0][1] == got[1][1]
+        assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])
