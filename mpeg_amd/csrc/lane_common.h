@@ -307,6 +307,19 @@ MPG_HD void settle(uint32_t &v)
 #endif
 }
 
+// Workgroup barrier that orders LDS only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also waits for every
+// global store of the wave (vmcnt(0)) — on gfx950 stores count in vmcnt — which a kernel that streams its outputs
+// out between barriers pays for at every one of them.  A wave whose direct-to-LDS loads the others are about to read
+// waits for those itself first (wait_loads<0>).
+MPG_HD void workgroup_barrier_lds()
+{
+#if MPG_ON_DEVICE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
 // the instruction scheduler moves nothing across this point (no instruction)
 MPG_HD void sched_fence()
 {

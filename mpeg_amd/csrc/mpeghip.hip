@@ -355,19 +355,28 @@ template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) vo
     const uint32_t tg0 = f0 * 36, tg1 = f1 * 36, n_steps = (tg1 - tg0 + kStep - 1) / kStep;
     float dreg[16];
     audio_load_window(a, tid, dreg);
+    // Barriers order LDS only; the wave that has direct-to-LDS loads in flight waits for them itself, and nobody waits
+    // for output stores (they are never read here).
+    auto step_barrier = [&](uint32_t loading_wave) {
+        if ((uint32_t)(tid >> 6) == loading_wave)
+            wait_loads<0>();
+        workgroup_barrier_lds();
+    };
     // prologue: samples of step 0 in flight, history from the state or rebuilt
     audio_phase_fetch(a, stream, tg0, tg1, 0, tid, lds);
     if (f0 == 0)
         audio_load_state(a, stream, vpos0, tid, lds);
     else
         audio_phase_warmup(a, stream, f0, tid, lds);
-    __syncthreads();
+    step_barrier(dct_wave(0));
     audio_phase_dct(a, stream, tg0, tg1, 0, tid, lds); // (also puts the samples of step 1 in flight)
-    __syncthreads();
+    step_barrier(dct_wave(0));
     for (uint32_t si = 0; si < n_steps; si++) {
-        audio_phase_dct(a, stream, tg0, tg1, si + 1, tid, lds); // wave (si+1)%4; refills the staging buffer for step si+2
+        // the wave that runs DCT(si + 1) does its one window pair first: its two output stores are then long gone when
+        // it waits for its refill loads in front of the barrier
         audio_phase_window<kFma, kFormat>(a, stream, vpos0, tg0, tg1, si, tid, dreg, lds);
-        __syncthreads();
+        audio_phase_dct(a, stream, tg0, tg1, si + 1, tid, lds); // wave (si+1)%4; refills the staging buffer for step si+2
+        step_barrier(dct_wave(si + 1));
     }
     if (f1 == a.n_frames) { // the slice that ends the launch owns the state hand-over
         audio_store_state(a, stream, vpos0, tid, lds);
