@@ -252,28 +252,27 @@ MPG_HD void copy16_to_lds(const void *g, void *lds_wave_base, int lane)
 // Loads complete in order, also mixed with register loads, and their data is in LDS as soon as s_waitcnt vmcnt lets
 // the wave go (lds_dma_probe3.hip: 800 000 waves on cold lines).  (dwordx3 keeps the 16-byte lane stride and
 // leaves holes: lds_dma_probe.hip.)
-template <int kAt0, int kAt1, int kAt2, int kAt3, int kAt4, int kAt5>
-MPG_HD void dma16x6_to_lds(const uint8_t *const (&g_base)[6], const uint32_t (&off)[6], void *lds_wave_base, int lane)
+template <int kAt0, int kAt1, int kAt2, int kAt3, int kAt4>
+MPG_HD void dma16x5_to_lds(const uint8_t *const (&g_base)[5], const uint32_t (&off)[5], void *lds_wave_base, int lane)
 {
-    static_assert(kAt0 >= 0 && kAt5 < 4096 && kAt1 < 4096 && kAt2 < 4096 && kAt3 < 4096 && kAt4 < 4096, "13-bit signed offset field");
+    static_assert(kAt0 >= 0 && kAt1 < 4096 && kAt2 < 4096 && kAt3 < 4096 && kAt4 < 4096, "13-bit signed offset field");
 #if MPG_ON_DEVICE
     (void)lane;
     const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base); // LDS aperture: low 32 bits = offset
-    asm volatile("s_mov_b32 m0, %12\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %6 offset:%13\n\t"
-                 "global_load_lds_dwordx4 %1, %7 offset:%14\n\t"
-                 "global_load_lds_dwordx4 %2, %8 offset:%15\n\t"
-                 "global_load_lds_dwordx4 %3, %9 offset:%16\n\t"
-                 "global_load_lds_dwordx4 %4, %10 offset:%17\n\t"
-                 "global_load_lds_dwordx4 %5, %11 offset:%18"
+    asm volatile("s_mov_b32 m0, %10\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %5 offset:%11\n\t"
+                 "global_load_lds_dwordx4 %1, %6 offset:%12\n\t"
+                 "global_load_lds_dwordx4 %2, %7 offset:%13\n\t"
+                 "global_load_lds_dwordx4 %3, %8 offset:%14\n\t"
+                 "global_load_lds_dwordx4 %4, %9 offset:%15"
                  :
-                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(g_base[0] - kAt0),
-                   "s"(g_base[1] - kAt1), "s"(g_base[2] - kAt2), "s"(g_base[3] - kAt3), "s"(g_base[4] - kAt4), "s"(g_base[5] - kAt5),
-                   "s"(base), "n"(kAt0), "n"(kAt1), "n"(kAt2), "n"(kAt3), "n"(kAt4), "n"(kAt5)
+                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "s"(g_base[0] - kAt0), "s"(g_base[1] - kAt1),
+                   "s"(g_base[2] - kAt2), "s"(g_base[3] - kAt3), "s"(g_base[4] - kAt4), "s"(base), "n"(kAt0), "n"(kAt1), "n"(kAt2),
+                   "n"(kAt3), "n"(kAt4)
                  : "memory");
 #else
-    const int at[6] = {kAt0, kAt1, kAt2, kAt3, kAt4, kAt5};
-    for (int i = 0; i < 6; i++)
+    const int at[5] = {kAt0, kAt1, kAt2, kAt3, kAt4};
+    for (int i = 0; i < 5; i++)
         __builtin_memcpy(static_cast<char *>(lds_wave_base) + at[i] + 16 * lane, g_base[i] + off[i], 16);
 #endif
 }

@@ -91,23 +91,27 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 #endif
     MPG_STAMP(1);
     uint32_t e = load32_uncounted(rc_ent_src(a, c, 0, 0), (uint32_t)lane * 4);
+    uint32_t bw = load32_uncounted(rc_blk_src(a, c), rc_blk_lane_offset(0, lane)); // (pass 0's block words)
     if (lane < kRcWinLanes) {
-        const uint8_t *const src[6] = {rc_table_src(a, c), rc_blk_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1),
-                                       rc_win_base(a, c, 2), rc_win_base(a, c, 3)};
-        const uint32_t off[6] = {(uint32_t)lane * 16, (uint32_t)lane * 16, rc_win_offset(c, 0, k), rc_win_offset(c, 1, k),
-                                 rc_win_offset(c, 2, k), rc_win_offset(c, 3, k)};
-        dma16x6_to_lds<kRcQtabAt, kRcBlkAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes>(
-            src, off, lds, lane);
+        const uint8_t *const src[5] = {rc_table_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1), rc_win_base(a, c, 2),
+                                       rc_win_base(a, c, 3)};
+        const uint32_t off[5] = {(uint32_t)lane * 16, rc_win_offset(c, 0, k), rc_win_offset(c, 1, k), rc_win_offset(c, 2, k),
+                                 rc_win_offset(c, 3, k)};
+        dma16x5_to_lds<kRcQtabAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes>(src, off, lds,
+                                                                                                                       lane);
     }
     MPG_STAMP(2);
 
     int32_t v[8];
-    uint32_t bw = 0, ent_at = 0;
+    uint32_t ent_at = 0, bw_next = 0;
     // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7; leaves lane (g, j) with row j of block g
     auto residual_pass = [&](uint32_t pass) {
         const uint32_t np = rc_pass_entries(c, pass);
         rc_zero_tile(T, lane);
-        bw = rc_blk_word(lds, pass, lane);
+        if (pass > 0)
+            bw = bw_next;
+        if ((pass + 1) * 8 < n_blocks) // the next pass's block words: on their way while this pass runs
+            bw_next = rc_blk_src(a, c)[rc_blk_lane_offset(pass + 1, lane) / 4];
         wave_lds_handoff();
         for (uint32_t r = 0; r < np; r += 64) {
             if (pass > 0 || r > 0)
@@ -143,15 +147,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
             rc_rmw(lds, bw, lane, v);
     };
     if (n_blocks) {
-        wait_loads<4>(); // the entries, the table and the block words are there; the four windows may still be on their way
+        wait_loads<4>(); // the entries, the block words and the table are there; the four windows may still be on their way
         settle(e);
+        settle(bw);
         wave_lds_handoff();
         residual_pass(0);
     }
     MPG_STAMP(3);
     // step 3: motion compensation, half-pel modes wave-uniform per macroblock: window in LDS -> O_m over it
     wait_loads<0>(); // all four windows are there
-    settle(e);       // (on every path: until here the entries' register belongs to a load in flight)
+    settle(e);       // (on every path: until here the entries' and block words' registers belong to loads in flight)
+    settle(bw);
 #if MPG_CHUNK_AHEAD
     settle(ahead);
 #endif

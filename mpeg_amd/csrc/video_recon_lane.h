@@ -36,10 +36,10 @@
 // them over as dense 128-byte units, the packer drops the zeros again.  Dequantisation, premultiply, IDCT,
 // prediction and write-back all happen on the device:
 //
-//   1  scalar loads: header + 4 records.  Then SEVEN vector loads per wave, all issued before the first use:
-//      the first 64 entries (one dword per lane), and six direct-to-LDS loads (global_load_lds_dwordx4: lane
-//      l's 16 bytes land at LDS base + 16 l, no registers in between, scalar base + 32-bit lane offset): the
-//      stream's dequantisation table (12 lanes), the chunk's block words (6 lanes), and per macroblock its
+//   1  scalar loads: header + 4 records.  Then SEVEN vector loads per wave, all issued before the first use: the
+//      first 64 entries and the first pass's block words (one dword per lane each, into registers), and five
+//      direct-to-LDS loads (global_load_lds_dwordx4: lane l's 16 bytes land at LDS base + 16 l, no registers in
+//      between, scalar base + 32-bit lane offset): the stream's dequantisation table (12 lanes) and per macroblock its
 //      whole prediction window as 54 PIECES: 17 luma rows x 2 tile rows (16 bytes each) + per chroma plane 5 row
 //      PAIRS x 2 blocks (a 16-byte piece = 2 rows of an 8x8 block).  Pieces are whole tile rows; the window's byte
 //      offset inside them (wave-uniform) is applied when the taps are read.  No registers hold prediction data (the first version of this kernel kept 32 of them and needed
@@ -56,8 +56,8 @@
 //   5  the four O_m leave as whole 64-byte luma / 32-byte chroma rows when the chunk is a horizontal run
 //      (kCRun), else as 8-byte rows per block; pictures flagged MPEGHIP_PIC_RGBA are colour-converted from them.
 //
-// Wave-private LDS, 5792 bytes (7 waves per SIMD):
-//      [   0,  192) table    [ 192,  288) 24 block words    [ 288 + 864 m, + 864) window m -> O_m    [3744, 5792) T
+// Wave-private LDS, 5696 bytes (28 waves per CU = 7 per SIMD):
+//      [   0,  192) table    [ 192 + 864 m, + 864) window m -> O_m    [3648, 5696) T
 #pragma once
 
 #include "video_lane.h"
@@ -91,11 +91,10 @@ constexpr int kRcWinBytes = kRcWinLanes * kRcPiece; // 864
 constexpr int kRcQtabBytes = 192;             // [64 positions][{intra, non-intra} matrix entry] + [64] premultiplier
 constexpr int kRcQtabStride = 256;            // per stream in HBM
 constexpr int kRcQtabAt = 0;
-constexpr int kRcBlkAt = kRcQtabBytes;        // 192: 24 block words = 6 pieces
-constexpr int kRcWinAt = kRcBlkAt + 96;       // 288
-constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3744
+constexpr int kRcWinAt = kRcQtabBytes;        // 192
+constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3648
 constexpr int kRcTileBytes = 8 * 64 * 4;      // T: int32 [8 blocks][64]
-constexpr int kRcLdsBytes = kRcTileAt + kRcTileBytes; // 5792
+constexpr int kRcLdsBytes = kRcTileAt + kRcTileBytes; // 5696: 28 one-wave workgroups per CU (160 000 usable bytes, tools/microbench/lds_residency.hip)
 
 // LDS byte offset of macroblock m's window, later its output bytes O_m: luma [16 rows][16] | Cb [8][8] | Cr [8][8]
 MPG_HD uint32_t rc_win_at(uint32_t m) { return kRcWinAt + m * kRcWinBytes; }
@@ -437,14 +436,16 @@ MPG_HD const uint32_t *rc_ent_src(const VideoArgs &a, const RcChunk &c, uint32_t
 {
     return a.words + c.h[4] + at + (uint32_t)lane; // (beyond the pass's entries: ignored; the array is padded)
 }
-// The six direct-to-LDS loads of a wave, issued by lanes 0..53 in this order: the table (12 pieces), the chunk's 24
-// block words (6 pieces), windows 0..3 (54 pieces each).  All 54 lanes take part in every one of them (one asm
-// statement, one EXEC): the table's and the block words' surplus lanes fetch 16 bytes that a LATER load of the same
-// wave overwrites — loads complete in order (tools/microbench/lds_dma_probe3.hip) and the windows cover
-// [kRcWinAt, kRcTileAt) completely.  Surplus lanes read valid memory: the table's run on into the next streams' tables
-// (the table array is padded by 1 KB), the block words' into the words array (padded).
+// The five direct-to-LDS loads of a wave, issued by lanes 0..53 in this order: the table (12 pieces), windows 0..3 (54
+// pieces each).  All 54 lanes take part in every one of them (one asm statement, one EXEC): the table's surplus lanes
+// fetch 16 bytes that a LATER load of the same wave overwrites — loads complete in order
+// (tools/microbench/lds_dma_probe3.hip) and the windows cover [kRcWinAt, kRcTileAt) completely.  Surplus lanes read
+// valid memory: they run on into the next streams' tables (the table array is padded by 1 KB).
 MPG_HD const uint8_t *rc_table_src(const VideoArgs &a, const RcChunk &c) { return a.qmat + c.h[2]; }
-MPG_HD const uint8_t *rc_blk_src(const VideoArgs &a, const RcChunk &c) { return reinterpret_cast<const uint8_t *>(a.words + c.h[3]); }
+// the chunk's block words stay in HBM: lane (g, j) loads the word of block g of a pass when the pass starts (the first
+// pass's together with the entries, before anything is waited for)
+MPG_HD const uint32_t *rc_blk_src(const VideoArgs &a, const RcChunk &c) { return a.words + c.h[3]; }
+MPG_HD uint32_t rc_blk_lane_offset(uint32_t pass, int lane) { return (pass * 8 + ((uint32_t)lane >> 3)) * 4; } // bytes
 // window m: scalar base = the reference frame, lane offset = the piece's tile row.  Intra, dead and kRSlow macroblocks
 // fetch the head of the frame store instead: valid memory, never used (a kRSlow window is gathered afterwards).
 // No selects between scalars: the compiler turns those into indexed loads from scratch.
@@ -479,11 +480,6 @@ MPG_HD void rc_zero_tile(int32_t *T, int lane)
     i32x4 *t = reinterpret_cast<i32x4 *>(T + lane * 8);
     t[0] = z;
     t[1] = z;
-}
-
-MPG_HD uint32_t rc_blk_word(const uint8_t *lds, uint32_t pass, int lane) // lane (g, j): the word of the pass's block g
-{
-    return *reinterpret_cast<const uint32_t *>(lds + kRcBlkAt + (pass * 8 + ((uint32_t)lane >> 3)) * 4);
 }
 
 // one entry: dequantise + premultiply (video.go:719-744; intra DC video.go:672), scatter to T[slot & 7][position]

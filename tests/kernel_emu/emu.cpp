@@ -113,13 +113,13 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
             k[lane] = rc_lane(a, lane);
             e[lane] = load32_uncounted(rc_ent_src(a, c, 0, 0), (uint32_t)lane * 4);
         }
-        for (int i = 0; i < 6; i++) // (load by load, as they complete on the device: later loads overwrite the surplus lanes)
+        for (int i = 0; i < 5; i++) // (load by load, as they complete on the device: later loads overwrite the surplus lanes)
             for (int lane = 0; lane < kRcWinLanes; lane++) {
-                const uint8_t *const src[6] = {rc_table_src(a, c), rc_blk_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1),
-                                               rc_win_base(a, c, 2), rc_win_base(a, c, 3)};
-                const uint32_t off[6] = {(uint32_t)lane * 16, (uint32_t)lane * 16, rc_win_offset(c, 0, k[lane]),
-                                         rc_win_offset(c, 1, k[lane]), rc_win_offset(c, 2, k[lane]), rc_win_offset(c, 3, k[lane])};
-                const int at[6] = {kRcQtabAt, kRcBlkAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes};
+                const uint8_t *const src[5] = {rc_table_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1), rc_win_base(a, c, 2),
+                                               rc_win_base(a, c, 3)};
+                const uint32_t off[5] = {(uint32_t)lane * 16, rc_win_offset(c, 0, k[lane]), rc_win_offset(c, 1, k[lane]),
+                                         rc_win_offset(c, 2, k[lane]), rc_win_offset(c, 3, k[lane])};
+                const int at[5] = {kRcQtabAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes};
                 memcpy(lds + at[i] + 16 * lane, src[i] + off[i], 16);
             }
         int32_t v[64][8];
@@ -128,7 +128,7 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
             const uint32_t np = rc_pass_entries(c, pass);
             for (int lane = 0; lane < 64; lane++) {
                 rc_zero_tile(T, lane);
-                bw[lane] = rc_blk_word(lds, pass, lane);
+                bw[lane] = rc_blk_src(a, c)[rc_blk_lane_offset(pass, lane) / 4];
             }
             for (uint32_t r = 0; r < np; r += 64)
                 for (int lane = 0; lane < 64; lane++) {
