@@ -62,7 +62,6 @@ struct AudioArgs {
 
 constexpr int kAudioWaves = 4;
 constexpr int kAudioThreads = 64 * kAudioWaves;
-constexpr int kMirrorSlots = 15;                      // ring slots 0..14 are repeated behind the ring
 constexpr int kSlotStride = 65;                       // floats per slot: [channel 2][32] + 1 pad
 constexpr int kT0 = 16;                               // local time of the launch's first sub-block
 
@@ -70,7 +69,8 @@ constexpr int kStep = 32;                             // sub-blocks per step: 64
 constexpr int kRing = 2 * kStep + 15;                 // DCT(s+1) writes [b+32, b+64) while window(s) reads [b-15, b+32)
 constexpr int kStageFloats = 64 * 32;                 // one step's samples: [8 x 16 bytes][64 lanes]
 constexpr int kHistBase = kStageFloats;               // LDS: the staging buffer, then the history
-constexpr int kAudioLdsFloats = kHistBase + (kRing + kMirrorSlots) * kSlotStride; // 32632 bytes
+constexpr int kWinBase = kHistBase + kRing * kSlotStride; // LDS: then the 16 x 32 window coefficients with the mirror's sign
+constexpr int kAudioLdsFloats = kWinBase + 512;           // 30780 bytes: 5 workgroups per CU (a CU hands out 160 000)
 
 // c_N[i] = 0.5 / cos((2i+1)*pi/(2N)); identical float32 values to the decimal
 // literals of audio.go:498-661.
@@ -133,9 +133,9 @@ MPG_HD void load_samples(const int32_t *s, int stride, int32_t (&in)[32])
     }
 }
 
-// idct36 for one (channel, sub-block) up to the mirror: v = the history slot (at this channel's
-// offset) that receives X[0..31]; v2 = its repeat behind the ring or nullptr.
-MPG_HD void matrixing(const int32_t (&in)[32], float *v, float *v2)
+// idct36 for one (channel, sub-block) up to the mirror: v = the history slot (at this channel's offset) that receives
+// X[0..31].
+MPG_HD void matrixing(const int32_t (&in)[32], float *v)
 {
     float e[16], o[16];
 #pragma unroll
@@ -152,13 +152,6 @@ MPG_HD void matrixing(const int32_t (&in)[32], float *v, float *v2)
     for (int k = 0; k < 16; k++) { // X[2k] = e[k], X[2k+1] = o[k]
         v[2 * k] = e[k];
         v[2 * k + 1] = o[k];
-    }
-    if (v2) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            v2[2 * k] = e[k];
-            v2[2 * k + 1] = o[k];
-        }
     }
 }
 
@@ -184,7 +177,7 @@ MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0,
 {
     const float *ring = a.ring + (uint64_t)stream * 2048;
     for (int idx = tid; idx < 1024; idx += kAudioThreads) {
-        const int ch = idx >> 9, T = (idx >> 5) & 15, k = idx & 31; // T = 0..15: no repeat needed, the first reader has T >= 16
+        const int ch = idx >> 9, T = (idx >> 5) & 15, k = idx & 31;
         const int e0 = 64 * (kT0 - 1 - T);                           // slot vpos0 holds the newest block (time T0-1)
         const int x = k <= 16 ? 48 - k : k - 16;
         const float d = ring[ch * 1024 + ((vpos0 + e0 + x) & 1023)];
@@ -192,16 +185,22 @@ MPG_HD void audio_load_state(const AudioArgs &a, uint32_t stream, int32_t vpos0,
     }
 }
 
-// the lane's 16 window coefficients (synthesisWindow, audio.go:812-899) with the mirror's sign:
-// segment s meets d[(s&1)*32 + i]
-MPG_HD void audio_load_window(const AudioArgs &a, int tid, float (&dreg)[16])
+// the window coefficients (synthesisWindow, audio.go:812-899) with the mirror's sign, [segment 16][sample 32], into LDS:
+// segment s meets d[(s&1)*32 + i].  A wave loads its lanes' 16 values into registers when it starts a run of sub-blocks
+// (they are not kept across the DCT, whose 64 registers would otherwise not fit next to them at 5 waves per SIMD).
+MPG_HD void audio_store_window(const AudioArgs &a, int tid, float *lds)
 {
-    const int i = tid & 31;
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-        const float w = a.window[s * 32 + i];
-        dreg[s] = (s & 1) ? -w : mirror_apply(i, w);
+    for (int idx = tid; idx < 512; idx += kAudioThreads) {
+        const int s = idx >> 5, i = idx & 31;
+        const float w = a.window[idx];
+        lds[kWinBase + idx] = (s & 1) ? -w : mirror_apply(i, w);
     }
+}
+MPG_HD void audio_load_window(const float *lds, int i, float (&dreg)[16])
+{
+#pragma unroll
+    for (int s = 0; s < 16; s++)
+        dreg[s] = lds[kWinBase + s * 32 + i];
 }
 
 MPG_HD const int32_t *samples_of(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch)
@@ -213,9 +212,7 @@ MPG_HD const int32_t *samples_of(const AudioArgs &a, uint32_t stream, uint32_t t
 // one DCT: sub-block tg (counted from the launch's first) of channel ch -> its history slot (+ repeat)
 MPG_HD void hist_matrixing(const int32_t (&in)[32], uint32_t tg, int ch, float *lds)
 {
-    const int32_t slot = ring_slot(kT0 + (int32_t)tg);
-    float *v = lds + kHistBase + slot * kSlotStride + ch * 32;
-    matrixing(in, v, slot < kMirrorSlots ? v + kRing * kSlotStride : nullptr);
+    matrixing(in, lds + kHistBase + ring_slot(kT0 + (int32_t)tg) * kSlotStride + ch * 32);
 }
 
 // ---- history rebuild for a slice that starts at frame f0 > 0: the 15 sub-blocks before it
@@ -242,17 +239,32 @@ MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, 
 // workgroups resident on a CU do not all load the same SIMD
 MPG_HD uint32_t dct_wave(uint32_t si) { return si % kAudioWaves; }
 
+// The step grid of a slice.  Steps are 32 sub-blocks long and start where the window's ring position is 15 (it cycles
+// through 15 .. 0 as the sub-blocks go by), i.e. at sub-blocks congruent to vpos0 / 64 modulo 16: the position of every
+// sub-block of a step is then a compile-time constant of its index in the step (15 - (p & 15)), which is what lets the
+// window run straight-line code with a static register file.  The first step of a slice therefore begins up to 15
+// sub-blocks BEFORE the slice (base0 <= tg0, possibly negative): those are neither transformed (their history slots hold
+// the state / the rebuilt history) nor synthesised.
+MPG_HD int32_t audio_step_base0(int32_t vpos0, uint32_t tg0)
+{
+    const int32_t v = (vpos0 >> 6) & 15;
+    return (int32_t)tg0 - (((int32_t)tg0 - v) & 15);
+}
+MPG_HD uint32_t audio_step_count(int32_t base0, uint32_t tg1) { return (uint32_t)((int32_t)tg1 - base0 + kStep - 1) / kStep; }
+MPG_HD bool audio_in_slice(int32_t tg, uint32_t tg0, uint32_t tg1) { return tg >= (int32_t)tg0 && tg < (int32_t)tg1; }
+
 // ---- samples of step si -> the staging buffer, issued by wave si%4 (lane = channel*32 + j); they
 // have landed after the next barrier
-MPG_HD void audio_phase_fetch(const AudioArgs &a, uint32_t stream, uint32_t tg0, uint32_t tg1, uint32_t si, int tid, float *lds)
+MPG_HD void audio_phase_fetch(const AudioArgs &a, uint32_t stream, int32_t base0, uint32_t tg0, uint32_t tg1, uint32_t si, int tid,
+                              float *lds)
 {
     if ((uint32_t)(tid >> 6) != dct_wave(si))
         return;
     const int lane = tid & 63;
-    const uint32_t tg = tg0 + si * kStep + (uint32_t)(lane & 31);
-    if (tg >= tg1)
+    const int32_t tg = base0 + (int32_t)(si * kStep) + (lane & 31);
+    if (!audio_in_slice(tg, tg0, tg1))
         return;
-    const int32_t *src = samples_of(a, stream, tg, lane >> 5);
+    const int32_t *src = samples_of(a, stream, (uint32_t)tg, lane >> 5);
 #pragma unroll
     for (int q = 0; q < 8; q++)
         copy16_to_lds(src + 4 * q, lds + q * 256, lane);
@@ -260,87 +272,61 @@ MPG_HD void audio_phase_fetch(const AudioArgs &a, uint32_t stream, uint32_t tg0,
 
 // ---- DCTs of step si from the staging buffer, on wave si%4; the same lanes refill the buffer for
 // step si+1 (whose DCT wave is the next one) once their own samples are in registers
-MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, uint32_t tg0, uint32_t tg1, uint32_t si, int tid, float *lds)
+MPG_HD void audio_phase_dct(const AudioArgs &a, uint32_t stream, int32_t base0, uint32_t tg0, uint32_t tg1, uint32_t si, int tid,
+                            float *lds)
 {
     if ((uint32_t)(tid >> 6) != dct_wave(si))
         return;
     const int lane = tid & 63;
-    const uint32_t tg = tg0 + si * kStep + (uint32_t)(lane & 31);
+    const int32_t tg = base0 + (int32_t)(si * kStep) + (lane & 31);
+    const bool mine = audio_in_slice(tg, tg0, tg1);
     int32_t in[32];
-    if (tg < tg1)
+    if (mine)
         load_samples(reinterpret_cast<const int32_t *>(lds) + lane * 4, 256, in);
 #if MPG_ON_DEVICE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads above are done before the refill is issued
 #endif
-    const uint32_t tn = tg + kStep; // same lane, next step
-    if (tn < tg1) {
-        const int32_t *src = samples_of(a, stream, tn, lane >> 5);
+    const int32_t tn = tg + kStep; // same lane, next step
+    if (audio_in_slice(tn, tg0, tg1)) {
+        const int32_t *src = samples_of(a, stream, (uint32_t)tn, lane >> 5);
 #pragma unroll
         for (int q = 0; q < 8; q++)
             copy16_to_lds(src + 4 * q, lds + q * 256, lane);
     }
-    if (tg < tg1)
-        hist_matrixing(in, tg, lane >> 5, lds);
+    if (mine)
+        hist_matrixing(in, (uint32_t)tg, lane >> 5, lds);
 }
 
-// The 16 taps of one output sample of two sub-blocks when the ring position is 64*M
-// (audio_noasm.go:8-38).  p0/p1 = the lane's history pointers for d[0..31] / d[32..63] at slot
-// (top - 15), where `top` is the (possibly repeated) slot of the sub-block; A and B are the two
-// sub-blocks.  Everything else folds to immediates.  Two halves: window_load reads the 2 x 16 history
-// values (in accumulation order) and window_sum adds them up — so that a wave can have the NEXT pair's
-// reads in flight while it sums this one (the reads' LDS latency was what a window wave spent its time on).
-// one dword read that the compiler leaves alone: a ds_read_b32 with its 16-bit immediate offset.  (Merged into
-// ds_read2_b32, whose offsets reach 1 KB, the 2 x 16 reads of a pair needed 16 extra address additions.)
-MPG_HD float lds_read_as_is(const float *p)
-{
-#if MPG_ON_DEVICE
-    typedef const volatile float __attribute__((address_space(3))) * lds_float_ptr; // (low 32 bits of an LDS address = its offset)
-    return *(lds_float_ptr)(uint32_t)(uintptr_t)p;
-#else
-    return *p;
-#endif
-}
-struct WinTaps {
-    float a[16], b[16];
-};
-template <int M> MPG_HD void window_load(const float *p0A, const float *p1A, const float *p0B, const float *p1B, WinTaps &w)
+// The window as a sliding register file.  The 16 taps of a sub-block read the 16 newest history slots, one value each:
+// from the slot at distance d (0 = its own) the lane's d[0..31] value (parity 0) or its d[32..63] value (parity 1); which
+// distance, which parity and which window segment tap k uses — and the ORDER of the taps, which the float sum depends on —
+// is a function of the ring position 64*M alone (audio_noasm.go:8-38).  M falls by one per sub-block while every slot's
+// distance grows by one, so the slot at distance d of the sub-block at position M can live in register pair (M + d) mod 16
+// for as long as it is needed: a wave that works through CONSECUTIVE sub-blocks reads two new values per sub-block (its
+// newest slot, both parities) instead of sixteen, and all register indices are compile-time constants of the variant M.
+// (The previous form read 16 values per sub-block through immediate offsets, which needed the first 15 ring slots
+// repeated behind the ring: 3.9 KB of LDS that now buys a fifth resident workgroup per CU.)
+template <int M, bool kFma> MPG_HD float window_sum(const float (&r0)[16], const float (&r1)[16], const float (&d)[16])
 {
     constexpr int32_t pos = 64 * M;
     constexpr int32_t v0 = (pos & 127) >> 1;
+    constexpr int32_t d0 = 512 - (pos >> 1);
+    float a = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) { // audio_noasm.go:14-24 — first run of 8 taps
         const int32_t e = (v0 - pos + 128 * k) & 1023;
-        const int off = (15 - (e >> 6)) * kSlotStride;
-        w.a[k] = lds_read_as_is(((e & 63) >> 5) ? p1A + off : p0A + off);
-        w.b[k] = lds_read_as_is(((e & 63) >> 5) ? p1B + off : p0B + off);
+        const int32_t seg = ((d0 + 64 * k) & 511) >> 5;
+        const int q = (M + (e >> 6)) & 15;
+        a = tap<kFma>(a, d[seg], ((e & 63) >> 5) ? r1[q] : r0[q]);
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) { // audio_noasm.go:26-37 — second run
         const int32_t e = (96 - v0 - pos + 128 * k) & 1023;
-        const int off = (15 - (e >> 6)) * kSlotStride;
-        w.a[8 + k] = lds_read_as_is(((e & 63) >> 5) ? p1A + off : p0A + off);
-        w.b[8 + k] = lds_read_as_is(((e & 63) >> 5) ? p1B + off : p0B + off);
-    }
-}
-template <int M, bool kFma> MPG_HD void window_sum(const WinTaps &w, const float (&d)[16], float &accA, float &accB)
-{
-    constexpr int32_t pos = 64 * M;
-    constexpr int32_t d0 = 512 - (pos >> 1);
-    float a = 0.0f, b = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int32_t seg = ((d0 + 64 * k) & 511) >> 5;
-        a = tap<kFma>(a, d[seg], w.a[k]);
-        b = tap<kFma>(b, d[seg], w.b[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
         const int32_t seg = ((d0 + 32 + 64 * k) & 511) >> 5;
-        a = tap<kFma>(a, d[seg], w.a[8 + k]);
-        b = tap<kFma>(b, d[seg], w.b[8 + k]);
+        const int q = (M + (e >> 6)) & 15;
+        a = tap<kFma>(a, d[seg], ((e & 63) >> 5) ? r1[q] : r0[q]);
     }
-    accA = a;
-    accB = b;
+    return a;
 }
 
 // x / -1090519040 (audio.go:390), correctly rounded.  The short form is Markstein's sequence
@@ -380,91 +366,97 @@ MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg,
         (reinterpret_cast<float *>(a.out) + sb)[e] = sv * 2147483648.0f;
 }
 
-// one window pair: sub-blocks tgA and tgA + 16 (same ring position modulo 16 slots, so the same taps), for the ring
-// position 64*M known at compile time.  The pair of this step whose ring position is 64*M is p = (c - M) mod 16
-// (vpos_at: the position falls by one slot per sub-block), c = the ring slot index one sub-block before the step.
-struct WinStep {
-    uint32_t c, slot0, base, tg1;
-    int ch, i;
-    const float *p0, *p1;
-};
-template <int M> MPG_HD void audio_window_load(const WinStep &s, WinTaps &w)
-{   // (also for a pair past the slice's end: it reads valid, stale history and is dropped by audio_window_finish)
-    const uint32_t p = (s.c - (uint32_t)M) & 15u;
-    const uint32_t slotA = s.slot0 + p >= (uint32_t)kRing ? s.slot0 + p - kRing : s.slot0 + p; // ring_slot(kT0 + base + p)
-    const uint32_t slotB = slotA + 16 >= (uint32_t)kRing ? slotA + 16 - kRing : slotA + 16;       // ring_slot(TA + 16)
-    const int32_t offA = (int32_t)((slotA < (uint32_t)kMirrorSlots ? slotA + kRing : slotA) - 15) * kSlotStride;
-    const int32_t offB = (int32_t)((slotB < (uint32_t)kMirrorSlots ? slotB + kRing : slotB) - 15) * kSlotStride;
-    window_load<M>(s.p0 + offA, s.p1 + offA, s.p0 + offB, s.p1 + offB, w);
-}
-template <int M, bool kFma, int kFormat>
-MPG_HD void audio_window_finish(const AudioArgs &a, uint32_t stream, const WinStep &s, const WinTaps &w, const float (&dreg)[16])
+// one dword read that the compiler leaves alone (an LDS address space pointer keeps it a ds_read_b32)
+MPG_HD float lds_read_as_is(const float *p)
 {
-    const uint32_t tgA = s.base + ((s.c - (uint32_t)M) & 15u), tgB = tgA + 16;
-    if (tgA >= s.tg1)
-        return;
-    float accA, accB;
-    window_sum<M, kFma>(w, dreg, accA, accB);
-    float svA, svB;
-    if (all_in_wave(scale_short_ok(accA) && scale_short_ok(accB))) {
-        svA = scale_short(accA);
-        svB = scale_short(accB);
-    } else {
-        svA = accA / kScale;
-        svB = accB / kScale;
-    }
-    audio_store_sample<kFormat>(a, stream, tgA, s.ch, s.i, svA);
-    if (tgB < s.tg1) // past the slice: B read stale history, drop it
-        audio_store_sample<kFormat>(a, stream, tgB, s.ch, s.i, svB);
+#if MPG_ON_DEVICE
+    typedef const volatile float __attribute__((address_space(3))) * lds_float_ptr; // (low 32 bits of an LDS address = its offset)
+    return *(lds_float_ptr)(uint32_t)(uintptr_t)p;
+#else
+    return *p;
+#endif
 }
 
-// ---- windows of step si: 16 pairs (p, p + 16), one per ring position M = 0..15.  Which taps a pair
-// reads, and in which order, depends on M alone, so the work is dealt out BY M: the three free waves take
-// M = rank, rank + 3, ... (five each), the wave that runs DCT(si + 1) in the same iteration takes
-// M = 15 — each wave runs straight-line code with immediate offsets, no per-pair dispatch.
+// A run of N consecutive sub-blocks P0 .. P0 + N - 1 of a step (indices in the step: positions and register indices are
+// compile-time constants, see audio_step_base0).  Lead-in: the 15 slots in front of the run, sub-block P0 - j into
+// register pair (M(P0) + j) & 15.  Then per sub-block: file its newest slot (read one sub-block ahead), synthesise.
+struct WinFile {
+    float r0[16], r1[16];
+    float n0, n1;  // the newest slot of the sub-block about to be worked on
+    uint32_t slot; // ring slot of the next sub-block to read
+};
+MPG_HD void audio_window_read(const float *p0, const float *p1, WinFile &w, float &v0, float &v1)
+{
+    const int32_t off = (int32_t)w.slot * kSlotStride;
+    v0 = lds_read_as_is(p0 + off);
+    v1 = lds_read_as_is(p1 + off);
+    w.slot = w.slot + 1 == (uint32_t)kRing ? 0u : w.slot + 1;
+}
+template <int P, int kEnd, bool kFma, int kFormat> struct WinSteps {
+    static MPG_HDM void run(const AudioArgs &a, uint32_t stream, int32_t base, uint32_t tg0, uint32_t tg1, int ch, int i, const float *p0,
+                            const float *p1, const float (&dreg)[16], WinFile &w)
+    {
+        constexpr int M = 15 - (P & 15);
+        w.r0[M] = w.n0;
+        w.r1[M] = w.n1;
+        if (P + 1 < kEnd)
+            audio_window_read(p0, p1, w, w.n0, w.n1); // the next sub-block's, on their way while this one is summed
+        const int32_t tg = base + P;
+        if (audio_in_slice(tg, tg0, tg1)) { // (wave-uniform)
+            const float acc = window_sum<M, kFma>(w.r0, w.r1, dreg);
+            float sv;
+            if (all_in_wave(scale_short_ok(acc)))
+                sv = scale_short(acc);
+            else
+                sv = acc / kScale;
+            audio_store_sample<kFormat>(a, stream, (uint32_t)tg, ch, i, sv);
+        }
+        WinSteps<P + 1, kEnd, kFma, kFormat>::run(a, stream, base, tg0, tg1, ch, i, p0, p1, dreg, w);
+    }
+};
+template <int kEnd, bool kFma, int kFormat> struct WinSteps<kEnd, kEnd, kFma, kFormat> {
+    static MPG_HDM void run(const AudioArgs &, uint32_t, int32_t, uint32_t, uint32_t, int, int, const float *, const float *,
+                            const float (&)[16], WinFile &)
+    {
+    }
+};
+template <int P0, int kEnd, bool kFma, int kFormat>
+MPG_HD void audio_window_run(const AudioArgs &a, uint32_t stream, int32_t base, uint32_t tg0, uint32_t tg1, int ch, int i,
+                             const float *p0, const float *p1, const float *lds)
+{
+    if (base + P0 >= (int32_t)tg1 || base + kEnd <= (int32_t)tg0)
+        return; // (nothing of this run lies inside the slice)
+    float dreg[16];
+    audio_load_window(lds, i, dreg);
+    WinFile w;
+    w.slot = (uint32_t)ring_slot(kT0 + base + P0 - 15 + kRing); // (+ kRing: the argument stays positive)
+    constexpr int M0 = 15 - (P0 & 15);
+#pragma unroll
+    for (int j = 15; j >= 1; j--) // oldest first: consecutive ring slots
+        audio_window_read(p0, p1, w, w.r0[(M0 + j) & 15], w.r1[(M0 + j) & 15]);
+    audio_window_read(p0, p1, w, w.n0, w.n1);
+    WinSteps<P0, kEnd, kFma, kFormat>::run(a, stream, base, tg0, tg1, ch, i, p0, p1, dreg, w);
+}
+
+// ---- windows of step si: the three waves that do not run DCT(si + 1) take sub-blocks 0..10, 11..21 and 22..31.
 template <bool kFma, int kFormat>
-MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, uint32_t tg0, uint32_t tg1, uint32_t si,
-                               int tid, const float (&dreg)[16], const float *lds)
+MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos0, int32_t base0, uint32_t tg0, uint32_t tg1,
+                               uint32_t si, int tid, const float *lds)
 {
     const uint32_t wave = (uint32_t)uniform(tid >> 6), busy = dct_wave(si + 1);
+    const uint32_t rank = (wave - busy - 1) % kAudioWaves; // 0..2 for the three free waves, 3 for the busy one
     const int lane = tid & 63, ch = lane >> 5, i = lane & 31;
     const float *p0 = lds + kHistBase + ch * 32 + mirror_index(i);
     const float *p1 = lds + kHistBase + ch * 32 + mirror_index(32 + i);
-    const uint32_t base = tg0 + si * kStep;
-    const uint32_t c = (uint32_t)(vpos_at(vpos0, kT0 + (int32_t)base) >> 6); // ring slot index of pair 0
-    const uint32_t slot0 = (uint32_t)ring_slot(kT0 + (int32_t)base);         // one modulo per step, not two per pair
-    const uint32_t rank = (wave - busy - 1) % kAudioWaves; // 0..2 for the three free waves, 3 for the busy one
-    const WinStep s = {c, slot0, base, tg1, ch, i, p0, p1};
-    WinTaps w0, w1;
-    // a free wave's five pairs, software-pipelined: the reads of pair n + 1 are issued before pair n is summed
-#define MPG_WIN5(M0, M1, M2, M3, M4)                                                                                   \
-    do {                                                                                                               \
-        audio_window_load<M0>(s, w0);                                                                                  \
-        audio_window_load<M1>(s, w1);                                                                                  \
-        sched_fence();                                                                                                 \
-        audio_window_finish<M0, kFma, kFormat>(a, stream, s, w0, dreg);                                                \
-        audio_window_load<M2>(s, w0);                                                                                  \
-        sched_fence();                                                                                                 \
-        audio_window_finish<M1, kFma, kFormat>(a, stream, s, w1, dreg);                                                \
-        audio_window_load<M3>(s, w1);                                                                                  \
-        sched_fence();                                                                                                 \
-        audio_window_finish<M2, kFma, kFormat>(a, stream, s, w0, dreg);                                                \
-        audio_window_load<M4>(s, w0);                                                                                  \
-        sched_fence();                                                                                                 \
-        audio_window_finish<M3, kFma, kFormat>(a, stream, s, w1, dreg);                                                \
-        audio_window_finish<M4, kFma, kFormat>(a, stream, s, w0, dreg);                                                \
-    } while (0)
+    const int32_t base = base0 + (int32_t)(si * kStep);
+    MPG_CHECK((vpos_at(vpos0, kT0 + base) >> 6) == 15); // the grid is aligned to the position cycle
+    (void)vpos0;
     switch (rank) {
-    case 0: MPG_WIN5(0, 3, 6, 9, 12); break;
-    case 1: MPG_WIN5(1, 4, 7, 10, 13); break;
-    case 2: MPG_WIN5(2, 5, 8, 11, 14); break;
-    default:
-        audio_window_load<15>(s, w0);
-        sched_fence();
-        audio_window_finish<15, kFma, kFormat>(a, stream, s, w0, dreg);
-        break;
+    case 0: audio_window_run<0, 11, kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
+    case 1: audio_window_run<11, 22, kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
+    case 2: audio_window_run<22, 32, kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
+    default: break;
     }
-#undef MPG_WIN5
 }
 
 // ---- state out: last 16 history slots -> Audio.v ring; thread 0 advances vPos

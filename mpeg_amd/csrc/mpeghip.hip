@@ -343,7 +343,8 @@ __global__ void hash_kernel(const uint8_t *frames, uint64_t frame_stride, uint32
     out[s] = h;
 }
 
-template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
+template <bool kFma, int kFormat>
+__global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kAudioLdsFloats];
     const uint32_t stream = blockIdx.x / a.n_chunks, chunk = blockIdx.x % a.n_chunks;
@@ -358,9 +359,10 @@ template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) vo
         return;
     }
     const int32_t vpos0 = a.vpos[stream];
-    const uint32_t tg0 = f0 * 36, tg1 = f1 * 36, n_steps = (tg1 - tg0 + kStep - 1) / kStep;
-    float dreg[16];
-    audio_load_window(a, tid, dreg);
+    const uint32_t tg0 = f0 * 36, tg1 = f1 * 36;
+    const int32_t base0 = audio_step_base0(vpos0, tg0); // steps aligned to the window's position cycle (audio_lane.h)
+    const uint32_t n_steps = audio_step_count(base0, tg1);
+    audio_store_window(a, tid, lds);
     // Barriers order LDS only; the wave that has direct-to-LDS loads in flight waits for them itself, and nobody waits
     // for output stores (they are never read here).
     auto step_barrier = [&](uint32_t loading_wave) {
@@ -369,19 +371,19 @@ template <bool kFma, int kFormat> __global__ __launch_bounds__(kAudioThreads) vo
         workgroup_barrier_lds();
     };
     // prologue: samples of step 0 in flight, history from the state or rebuilt
-    audio_phase_fetch(a, stream, tg0, tg1, 0, tid, lds);
+    audio_phase_fetch(a, stream, base0, tg0, tg1, 0, tid, lds);
     if (f0 == 0)
         audio_load_state(a, stream, vpos0, tid, lds);
     else
         audio_phase_warmup(a, stream, f0, tid, lds);
     step_barrier(dct_wave(0));
-    audio_phase_dct(a, stream, tg0, tg1, 0, tid, lds); // (also puts the samples of step 1 in flight)
+    audio_phase_dct(a, stream, base0, tg0, tg1, 0, tid, lds); // (also puts the samples of step 1 in flight)
     step_barrier(dct_wave(0));
     for (uint32_t si = 0; si < n_steps; si++) {
         // the wave that runs DCT(si + 1) does its one window pair first: its two output stores are then long gone when
         // it waits for its refill loads in front of the barrier
-        audio_phase_window<kFma, kFormat>(a, stream, vpos0, tg0, tg1, si, tid, dreg, lds);
-        audio_phase_dct(a, stream, tg0, tg1, si + 1, tid, lds); // wave (si+1)%4; refills the staging buffer for step si+2
+        audio_phase_window<kFma, kFormat>(a, stream, vpos0, base0, tg0, tg1, si, tid, lds);
+        audio_phase_dct(a, stream, base0, tg0, tg1, si + 1, tid, lds); // wave (si+1)%4; refills the staging buffer for step si+2
         step_barrier(dct_wave(si + 1));
     }
     if (f1 == a.n_frames) { // the slice that ends the launch owns the state hand-over
@@ -1724,11 +1726,11 @@ static int audio_launch(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_f
     args.format = format;
     args.fma = a->fma;
     args.active = d_active;
-    // time slices per stream: one full residency of workgroups (4 per CU are resident in practice: 5 x 32 KB
-    // of LDS do not fit next to the allocation granularity), at least 4 frames per slice
+    // time slices per stream: one full residency of workgroups (5 x 28 732 B of LDS fit a CU's 160 000), at least 4
+    // frames per slice
     uint32_t chunks = 1;
     {
-        const uint32_t want = ((uint32_t)a->n_cu * 4 + a->n_streams - 1) / a->n_streams;
+        const uint32_t want = ((uint32_t)a->n_cu * 5 + a->n_streams - 1) / a->n_streams;
         chunks = want < 1 ? 1 : want;
         if (chunks > n_frames / 4)
             chunks = n_frames / 4;

@@ -290,8 +290,6 @@ void emu_relayout(uint8_t *slot, uint8_t *linear, uint32_t luma_w, uint32_t luma
 template <bool kFma, int kFormat> static void emu_audio_blocks(const AudioArgs &a)
 {
     std::vector<float> lds(kAudioLdsFloats);
-    struct Regs { float dreg[16]; };
-    std::vector<Regs> regs(kAudioThreads);
     for (uint32_t blk = 0; blk < a.n_streams * a.n_chunks; blk++) {
         const uint32_t stream = blk / a.n_chunks, chunk = blk % a.n_chunks;
         uint32_t f0, f1;
@@ -307,22 +305,24 @@ template <bool kFma, int kFormat> static void emu_audio_blocks(const AudioArgs &
         for (auto &x : lds)
             x = 1e30f; // poison
         const int32_t vpos0 = a.vpos[stream];
-        const uint32_t tg0 = f0 * 36, tg1 = f1 * 36, n_steps = (tg1 - tg0 + kStep - 1) / kStep;
+        const uint32_t tg0 = f0 * 36, tg1 = f1 * 36;
+        const int32_t base0 = audio_step_base0(vpos0, tg0);
+        const uint32_t n_steps = audio_step_count(base0, tg1);
         for (int tid = 0; tid < kAudioThreads; tid++) {
-            audio_load_window(a, tid, regs[tid].dreg);
-            audio_phase_fetch(a, stream, tg0, tg1, 0, tid, lds.data());
+            audio_store_window(a, tid, lds.data());
+            audio_phase_fetch(a, stream, base0, tg0, tg1, 0, tid, lds.data());
             if (f0 == 0)
                 audio_load_state(a, stream, vpos0, tid, lds.data());
             else
                 audio_phase_warmup(a, stream, f0, tid, lds.data());
         }
         for (int tid = 0; tid < kAudioThreads; tid++)
-            audio_phase_dct(a, stream, tg0, tg1, 0, tid, lds.data());
+            audio_phase_dct(a, stream, base0, tg0, tg1, 0, tid, lds.data());
         for (uint32_t si = 0; si < n_steps; si++) {
             for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_dct(a, stream, tg0, tg1, si + 1, tid, lds.data());
+                audio_phase_dct(a, stream, base0, tg0, tg1, si + 1, tid, lds.data());
             for (int tid = 0; tid < kAudioThreads; tid++)
-                audio_phase_window<kFma, kFormat>(a, stream, vpos0, tg0, tg1, si, tid, regs[tid].dreg, lds.data());
+                audio_phase_window<kFma, kFormat>(a, stream, vpos0, base0, tg0, tg1, si, tid, lds.data());
         }
         if (f1 == a.n_frames) {
             for (int tid = 0; tid < kAudioThreads; tid++)
