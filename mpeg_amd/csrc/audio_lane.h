@@ -451,11 +451,17 @@ MPG_HD void audio_phase_window(const AudioArgs &a, uint32_t stream, int32_t vpos
     const int32_t base = base0 + (int32_t)(si * kStep);
     MPG_CHECK((vpos_at(vpos0, kT0 + base) >> 6) == 15); // the grid is aligned to the position cycle
     (void)vpos0;
+    // the free waves take [0, a), [a, b), [b, c), the DCT wave [c, 32): 10 / 10 / 10 / 2 and 10 / 11 / 10 / 1 measure the
+    // same (profiles/r3y_ab_audio_run_splits.txt)
+    constexpr int kCut[3] = {11, 22, 32};
     switch (rank) {
-    case 0: audio_window_run<0, 11, kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
-    case 1: audio_window_run<11, 22, kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
-    case 2: audio_window_run<22, 32, kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
-    default: break;
+    case 0: audio_window_run<0, kCut[0], kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
+    case 1: audio_window_run<kCut[0], kCut[1], kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
+    case 2: audio_window_run<kCut[1], kCut[2], kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds); break;
+    default:
+        if (kCut[2] < kStep)
+            audio_window_run<kCut[2], kStep, kFma, kFormat>(a, stream, base, tg0, tg1, ch, i, p0, p1, lds);
+        break;
     }
 }
 
