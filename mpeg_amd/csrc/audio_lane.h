@@ -14,24 +14,24 @@
 //   DCT:    one wave runs the step's 64 32-point DCTs, one per lane (channel x 32 sub-blocks),
 //           entirely in registers.  idct36's 64 outputs d[0..63] are a signed mirror of the 32 DCT
 //           outputs X[k] (audio.go:708-771: d[48-k] = d[48+k] = -X[k], d[k-16] = X[k], d[16] = 0),
-//           so only X is kept: a time-indexed history in LDS, slot = [channel][32] (+1 pad).  The
+//           so only X is kept: a time-indexed history ring in LDS, slot = [channel][32] (+1 pad).  The
 //           reference's 1024-entry ring only ever holds the last 16 slots.
-//   window: a wave owns sub-blocks t and t+16 at a time, lane = channel*32 + sample.  Which history
-//           slots and window segments the 16 taps read, and in which order, depends only on the ring
-//           position (16 cases, the same for t and t+16), which is wave-uniform: the wave branches
-//           once to a fully unrolled variant whose LDS reads are "per-lane base + immediate".  The
-//           lane's 16 window coefficients live in registers with the mirror's sign folded in
-//           (even segments always meet d[0..31], odd ones d[32..63]).  To keep the offsets immediate
-//           across the ring wrap, the first 15 slots are repeated behind the ring, so "the 16 slots
-//           ending at T" are always contiguous.
+//   window: lane = channel*32 + sample.  A sub-block's 16 taps read the 16 newest history slots, one value each;
+//           which slot, which of the lane's two values of it (d[0..31] / d[32..63] half), which window segment and in
+//           which ORDER (the float sum depends on it) is a function of the ring position alone, which falls by one per
+//           sub-block through a cycle of 16.  Steps start where the position is 15 (audio_step_base0), so the position
+//           of every sub-block is a compile-time constant of its index in the step, and a wave that works through
+//           CONSECUTIVE sub-blocks keeps the 16 slots in a sliding register file with static indices: two LDS reads
+//           per sub-block (its newest slot, both halves) instead of sixteen.  The lane's 16 window coefficients (mirror's
+//           sign folded in) are re-read from LDS at the start of a run.
 //   pipeline: the history ring holds 79 slots, so the DCTs of step s+1 never touch a slot the
 //           windows of step s read.  Iteration s therefore runs, between two barriers, DCT(s+1) on
-//           wave (s+1)%4 (plus one window pair) and window(s) on the other three waves (five pairs
-//           each).  The DCT wave takes its samples from an LDS staging buffer and, as soon as it has
+//           wave (s+1)%4 and window(s) on the other three waves (runs of 11, 11 and 10 sub-blocks, each behind a
+//           15-slot lead-in).  The DCT wave takes its samples from an LDS staging buffer and, as soon as it has
 //           them in registers, refills the same buffer with the samples of step s+2 straight from
 //           HBM (global_load_lds: every lane overwrites exactly the 8 x 16 bytes it has just read):
-//           one barrier per step, no wave idles through the DCT or its HBM latency, no registers
-//           are held across it.
+//           one barrier per step (ordering LDS only), no wave idles through the DCT or its HBM latency.
+//           30 780 bytes of LDS and 81 VGPRs: 5 workgroups stay resident per CU.
 //
 // Time slicing: a sub-block depends on the previous 15 only through the history, and
 // every history slot is a pure function of one sub-block's samples.  So the frames of one
