@@ -599,13 +599,12 @@ MPG_HD uint32_t rc_mc4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint3
 {
     const uint64_t a = (uint64_t)a0 | ((uint64_t)a1 << 32), b = (uint64_t)b0 | ((uint64_t)b1 << 32);
     const uint32_t p00 = (uint32_t)(a >> (8 * shift));
-    if (!oh && !ov)
-        return p00;
-    if (!ov)
-        return avg_ceil_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)));
-    if (!oh)
-        return avg_ceil_u8x4(p00, (uint32_t)(b >> (8 * shift)));
-    return avg4_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)), (uint32_t)(b >> (8 * shift)), (uint32_t)(b >> (8 * shift + 8)));
+    switch ((oh ? 1u : 0u) | (ov ? 2u : 0u)) { // (one four-way branch: chains of ifs cost a dozen scalar instructions per call)
+    case 0: return p00;
+    case 1: return avg_ceil_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)));
+    case 2: return avg_ceil_u8x4(p00, (uint32_t)(b >> (8 * shift)));
+    default: return avg4_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)), (uint32_t)(b >> (8 * shift)), (uint32_t)(b >> (8 * shift + 8)));
+    }
 }
 
 // the window's byte offsets inside its first pieces (wave-uniform, from the record)
