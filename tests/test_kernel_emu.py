@@ -160,3 +160,20 @@ def test_packer_512_bit_forms_write_the_same_words(emu, profile, raw):
             got.append((nc, nw.value, chunks[:nc * 24].copy(), words[:nw.value].copy()))
         assert got[0][0] == got[1][0] and got[0][1] == got[1][1]
         assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_audio_step_grid_at_every_ring_position(oracle, emu, chunks):
+    """The kernel's steps start where the window's ring position is 15, i.e. up to 15 sub-blocks BEFORE a slice
+    (audio_step_base0): every one of the 16 alignments, with the state's own history in front of the first slice and a
+    rebuilt one in front of the others."""
+    rng = np.random.default_rng(11)
+    s = synth.audio_frames(1, 4, seed=3)
+    for vpos in range(0, 1024, 64):
+        v = mirror_ring(rng.integers(-30000, 30000, (2, 16, 32)).astype(np.float32))
+        o, e = oracle.OracleSynth(1, 0), emu.EmuSynth(1, 0, chunks=chunks)
+        o.set_state(0, v, vpos)
+        e.set_state(0, v, vpos)
+        assert bits_equal(o.synth(s, desc.AUDIO_F32N), e.synth(s, desc.AUDIO_F32N)), vpos
+        (va, pa), (vb, pb) = o.get_state(0), e.get_state(0)
+        assert pa == pb and bits_equal(va, vb), vpos
