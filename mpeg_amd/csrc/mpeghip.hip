@@ -210,10 +210,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     if (kRgba && rgba) {
         if (!run)
             wave_lds_handoff();
+        if (run) {
 #pragma unroll
-        for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
-            if (m < n_live)
-                rc_rgba_mb(a, c, m, lane, lds);
+            for (uint32_t q = 0; q < 4; q++)
+                rc_rgba_run_rows(a, c, q, lane, lds);
+        } else {
+#pragma unroll
+            for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
+                if (m < n_live)
+                    rc_rgba_mb(a, c, m, lane, lds);
+        }
     }
 #ifdef MPG_PHASE_TIMING
     MPG_STAMP(6);

@@ -718,11 +718,11 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
 // Frame.RGBA fused (pictures flagged MPEGHIP_PIC_RGBA): macroblock m from O_m, 4 pixels per lane (lane = row*4 +
 // segment), one 16-byte store each — a macroblock row is 64 contiguous bytes of the image.  Pixels outside
 // width x height are not stored.
-MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *lds)
+// (mb_x, mb_y: the macroblock's position — of a run's macroblock m it is the first one's + m, no record is indexed by lane)
+MPG_HD void rc_rgba_quad(const VideoArgs &a, const RcChunk &c, uint32_t m, uint32_t mb_x, uint32_t mb_y, uint32_t row, uint32_t seg,
+                         const uint8_t *lds)
 {
-    const uint32_t d0 = c.r[m][0];
-    const uint32_t row = (uint32_t)lane >> 2, seg = (uint32_t)lane & 3;
-    const uint32_t py = ((d0 >> 24) << 4) + row, px0 = (((d0 >> 16) & 0xff) << 4) + seg * 4;
+    const uint32_t py = (mb_y << 4) + row, px0 = (mb_x << 4) + seg * 4;
     if (py >= a.height || px0 >= a.width)
         return;
     const uint8_t *O = lds + rc_win_at(m);
@@ -735,6 +735,18 @@ MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lan
     const uint32_t n = a.width - px0 >= 4 ? 4 : a.width - px0;
     uint8_t *img = a.rgba + ((uint64_t)c.h[1] << 8);
     rgba_store4<false>(reinterpret_cast<uint32_t *>(img) + p, p, px, n);
+}
+MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *lds)
+{
+    const uint32_t d0 = c.r[m][0];
+    rc_rgba_quad(a, c, m, (d0 >> 16) & 0xff, d0 >> 24, (uint32_t)lane >> 2, (uint32_t)lane & 3, lds);
+}
+// a horizontal run of 4 macroblocks, rows 4q .. 4q + 3: lane = (row lane>>4, macroblock (lane>>2)&3, segment lane&3), so that
+// one store instruction writes 4 rows of 256 contiguous bytes (whole cache lines) instead of 16 rows of 64
+MPG_HD void rc_rgba_run_rows(const VideoArgs &a, const RcChunk &c, uint32_t q, int lane, const uint8_t *lds)
+{
+    const uint32_t l = (uint32_t)lane, m = (l >> 2) & 3, d0 = c.r[0][0];
+    rc_rgba_quad(a, c, m, ((d0 >> 16) & 0xff) + m, d0 >> 24, q * 4 + (l >> 4), l & 3, lds);
 }
 
 } // namespace mpg

@@ -210,10 +210,17 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                 for (int lane = 0; lane < 64; lane++)
                     rc_store_mb(a, c, m, lane, lds, rgba_on);
         }
-        if (rgba_on)
-            for (uint32_t m = 0; m < n_live; m++)
-                for (int lane = 0; lane < 64; lane++)
-                    rc_rgba_mb(a, c, m, lane, lds);
+        if (rgba_on) {
+            if (run) {
+                for (uint32_t q = 0; q < 4; q++)
+                    for (int lane = 0; lane < 64; lane++)
+                        rc_rgba_run_rows(a, c, q, lane, lds);
+            } else {
+                for (uint32_t m = 0; m < n_live; m++)
+                    for (int lane = 0; lane < 64; lane++)
+                        rc_rgba_mb(a, c, m, lane, lds);
+            }
+        }
     }
     return 0;
 }
