@@ -50,6 +50,10 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k)
 #endif
 
+#ifndef MPG_CHUNKS_PER_WAVE
+#define MPG_CHUNKS_PER_WAVE 2 // profiles/r4k_ab_two_chunks_per_wave.txt
+#endif
+constexpr int kRcChunksPerWave = MPG_CHUNKS_PER_WAVE;
 #ifndef MPG_CHUNK_AHEAD
 #define MPG_CHUNK_AHEAD 256 // chunks; 0 = off (profiles/r3f_ab_chunk_pull_ahead.txt: 64 / 256 / 1024)
 #endif
@@ -65,25 +69,32 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     // immediate, with no per-wave base to add)
     const uint32_t w = WAVES == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    const uint32_t chunk = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w);
-    if (chunk >= a.n_chunks)
+    // a wave takes kRcChunksPerWave consecutive chunks, one after the other: the later ones' headers are loaded with the
+    // first one's, and the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once
+    const uint32_t first = __builtin_amdgcn_readfirstlane((xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w) * kRcChunksPerWave);
+    if (first >= a.n_chunks)
         return;
     uint8_t *lds = lds_all + w * kRcLdsBytes;
     int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
 
 #if MPG_CHUNK_AHEAD
-    // pull a later chunk of this XCD's range towards L2 (two lanes, one per cache line of its 96 bytes) so that that
-    // wave's scalar loads find it there; nothing is done with the data.  (Also pulling that chunk's first words, by a
-    // dependent load once its header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
+    // pull the chunks a later wave of this XCD's range will take towards L2 (one lane per cache line of their 96 bytes
+    // each) so that that wave's scalar loads find them there; nothing is done with the data.  (Also pulling those chunks'
+    // first words, by a dependent load once the header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
     uint32_t ahead;
     {
-        const uint32_t later = chunk + MPG_CHUNK_AHEAD < a.n_chunks ? chunk + MPG_CHUNK_AHEAD : chunk;
-        ahead = load32_uncounted(a.chunks + (uint64_t)later * kRcChunkDwords, (uint32_t)(lane & 1) * 64);
+        const uint32_t later = first + MPG_CHUNK_AHEAD * kRcChunksPerWave + kRcChunksPerWave <= a.n_chunks ? first + MPG_CHUNK_AHEAD * kRcChunksPerWave : first;
+        const uint32_t line = (uint32_t)lane < (kRcChunksPerWave * kRcChunkDwords * 4 + 63) / 64 ? (uint32_t)lane : 0u;
+        ahead = load32_uncounted(a.chunks + (uint64_t)later * kRcChunkDwords, line * 64);
     }
 #endif
-    // step 1: one round of scalar loads, then the five vector loads of the chunk
-    const RcChunk c = rc_load_chunk(a, chunk);
+    // step 1: one round of scalar loads (all of the wave's chunks), then per chunk its vector loads
+    static_assert(kRcChunksPerWave == 1 || kRcChunksPerWave == 2, "written out for one or two");
+    const RcChunk c0 = rc_load_chunk(a, first);
+    const RcChunk c1 = rc_load_chunk(a, kRcChunksPerWave == 2 && first + 1 < a.n_chunks ? first + 1 : first);
     const RcLane k = rc_lane(a, lane);
+    bool ahead_pending = MPG_CHUNK_AHEAD != 0;
+    auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
     const uint32_t n_blocks = rc_n_blocks(c);
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)
@@ -159,7 +170,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     settle(e);       // (on every path: until here the entries' and block words' registers belong to loads in flight)
     settle(bw);
 #if MPG_CHUNK_AHEAD
-    settle(ahead);
+    if (ahead_pending)
+        settle(ahead);
+    ahead_pending = false;
 #endif
     wave_lds_handoff();
 #pragma unroll
@@ -229,6 +242,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         g_phase_dump[(uint64_t)chunk * 8 + 7] = n_blocks;
     }
 #endif
+    };
+    one_chunk(c0, first);
+    if (kRcChunksPerWave == 2 && first + 1 < a.n_chunks) {
+        wave_lds_handoff(); // (the previous chunk's stores have read its output bytes)
+        one_chunk(c1, first + 1);
+    }
 }
 #undef MPG_STAMP
 
@@ -1047,7 +1066,7 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
     hipStream_t st = v->ctx->stream;
-    const uint32_t grid = (a.n_chunks + kReconWaves - 1) / kReconWaves;
+    const uint32_t grid = (a.n_chunks + kReconWaves * kRcChunksPerWave - 1) / (kReconWaves * kRcChunksPerWave);
     if (b->any_rgba)
         hipLaunchKernelGGL((recon_kernel<kReconWaves, true>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
     else
