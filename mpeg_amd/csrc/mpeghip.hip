@@ -99,6 +99,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)
         return;
+    if (chunk != first) // (a wave's second chunk starts here: its header has long arrived)
+        MPG_STAMP(0);
 #endif
     MPG_STAMP(1);
     uint32_t e = load32_uncounted(rc_ent_src(a, c, 0, 0), (uint32_t)lane * 4);
