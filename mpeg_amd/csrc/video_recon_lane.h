@@ -1,7 +1,7 @@
 // video_recon_lane.h — the reconstruction kernel: device format, host-side packer, lane functions.
 //
-// One WAVE reconstructs one CHUNK = 4 consecutive macroblocks of one picture (normally 4 horizontal
-// neighbours), with wave-private LDS and no barrier.  What the kernel reads is not the C ABI's arrays but
+// One WAVE reconstructs a CHUNK = 4 consecutive macroblocks of one picture (normally 4 horizontal
+// neighbours) at a time — two consecutive chunks one after the other (mpeghip.hip) — with wave-private LDS and no barrier.  What the kernel reads is not the C ABI's arrays but
 // the library's own device format, which the host half of the library (rc_pack_picture, called from the
 // validation pass of every submit / upload) writes straight into the buffer the H2D copy reads:
 //
