@@ -215,24 +215,37 @@ MPG_HD void hist_matrixing(const int32_t (&in)[32], uint32_t tg, int ch, float *
     matrixing(in, lds + kHistBase + ring_slot(kT0 + (int32_t)tg) * kSlotStride + ch * 32);
 }
 
-// ---- history rebuild for a slice that starts at frame f0 > 0: the 15 sub-blocks before it
-MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t f0, int tid, float *lds)
+// ---- history rebuild for a slice that starts at sub-block tg0 > 0: the 15 sub-blocks before it
+MPG_HD void audio_phase_warmup(const AudioArgs &a, uint32_t stream, uint32_t tg0, int tid, float *lds)
 {
     if (tid < 128 || tid >= 128 + 30) // wave 2: waves 0 and 1 issue the first two fetches
         return;
     const int ch = (tid - 128) / 15;
-    const uint32_t tg = f0 * 36 - 15 + (uint32_t)((tid - 128) % 15);
+    const uint32_t tg = tg0 - 15 + (uint32_t)((tid - 128) % 15);
     int32_t in[32];
     load_samples(samples_of(a, stream, tg, ch), 4, in);
     hist_matrixing(in, tg, ch, lds);
 }
 
-// frames [f0, f1) of time slice `chunk`
-MPG_HD void audio_chunk_range(const AudioArgs &a, uint32_t chunk, uint32_t &f0, uint32_t &f1)
+// sub-blocks [tg0, tg1) of time slice `chunk` of a stream whose ring position at the launch's start is vpos0.  Slices
+// are cut on the stream's own step grid (audio_step_base0: sub-blocks congruent to vpos0 / 64 modulo 32 here), in whole
+// steps: only the launch's first and last step are partly filled, not every slice's.  (Slices are sub-blocks, not frames:
+// output element tg * 64 + ... does not care.)
+MPG_HD void audio_slice_range(const AudioArgs &a, uint32_t chunk, int32_t vpos0, uint32_t &tg0, uint32_t &tg1)
 {
-    const uint32_t per = (a.n_frames + a.n_chunks - 1) / a.n_chunks;
-    f0 = chunk * per < a.n_frames ? chunk * per : a.n_frames;
-    f1 = f0 + per < a.n_frames ? f0 + per : a.n_frames;
+    const uint32_t n = a.n_frames * 36, g = (uint32_t)(vpos0 >> 6) & 15;
+    const uint32_t steps = n > g ? (n - g + kStep - 1) / kStep : 0; // from sub-block g on
+    auto cut = [&](uint32_t i) -> uint32_t {
+        const uint32_t k = i >= a.n_chunks ? steps : (uint32_t)(((uint64_t)i * steps) / a.n_chunks);
+        if (i == 0 || k == 0)
+            return 0; // (a slice that would end inside the first step is empty: the next one starts at 0)
+        if (i >= a.n_chunks)
+            return n;
+        const uint32_t at = g + kStep * k;
+        return at < n ? at : n;
+    };
+    tg0 = cut(chunk);
+    tg1 = cut(chunk + 1);
 }
 
 // the wave that runs the DCTs of step `si` (counted from the slice's first): it rotates so that the

@@ -376,17 +376,17 @@ __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
     __shared__ __attribute__((aligned(16))) float lds[kAudioLdsFloats];
     const uint32_t stream = blockIdx.x / a.n_chunks, chunk = blockIdx.x % a.n_chunks;
     const int tid = threadIdx.x;
-    uint32_t f0, f1;
-    audio_chunk_range(a, chunk, f0, f1);
-    if (f0 >= f1)
+    const int32_t vpos0 = a.vpos[stream];
+    uint32_t tg0, tg1;
+    audio_slice_range(a, chunk, vpos0, tg0, tg1);
+    if (tg0 >= tg1)
         return; // empty slice (wave-uniform, before any barrier)
+    const bool ends_launch = tg1 == a.n_frames * 36;
     if (a.active && a.active[stream] == 0) { // (workgroup-uniform)
-        if (f1 == a.n_frames)
+        if (ends_launch)
             audio_carry_state(a, stream, tid);
         return;
     }
-    const int32_t vpos0 = a.vpos[stream];
-    const uint32_t tg0 = f0 * 36, tg1 = f1 * 36;
     const int32_t base0 = audio_step_base0(vpos0, tg0); // steps aligned to the window's position cycle (audio_lane.h)
     const uint32_t n_steps = audio_step_count(base0, tg1);
     audio_store_window(a, tid, lds);
@@ -399,10 +399,10 @@ __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
     };
     // prologue: samples of step 0 in flight, history from the state or rebuilt
     audio_phase_fetch(a, stream, base0, tg0, tg1, 0, tid, lds);
-    if (f0 == 0)
+    if (tg0 == 0)
         audio_load_state(a, stream, vpos0, tid, lds);
     else
-        audio_phase_warmup(a, stream, f0, tid, lds);
+        audio_phase_warmup(a, stream, tg0, tid, lds);
     step_barrier(dct_wave(0));
     audio_phase_dct(a, stream, base0, tg0, tg1, 0, tid, lds); // (also puts the samples of step 1 in flight)
     step_barrier(dct_wave(0));
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kAudioThreads) void audio_kernel(const AudioArgs a)
         audio_phase_dct(a, stream, base0, tg0, tg1, si + 1, tid, lds); // wave (si+1)%4; refills the staging buffer for step si+2
         step_barrier(dct_wave(si + 1));
     }
-    if (f1 == a.n_frames) { // the slice that ends the launch owns the state hand-over
+    if (ends_launch) { // the slice that ends the launch owns the state hand-over
         audio_store_state(a, stream, vpos0, tid, lds);
         if (tid == 0)
             audio_store_vpos(a, stream, vpos0);

@@ -299,29 +299,29 @@ template <bool kFma, int kFormat> static void emu_audio_blocks(const AudioArgs &
     std::vector<float> lds(kAudioLdsFloats);
     for (uint32_t blk = 0; blk < a.n_streams * a.n_chunks; blk++) {
         const uint32_t stream = blk / a.n_chunks, chunk = blk % a.n_chunks;
-        uint32_t f0, f1;
-        audio_chunk_range(a, chunk, f0, f1);
-        if (f0 >= f1)
+        const int32_t vpos0 = a.vpos[stream];
+        uint32_t tg0, tg1;
+        audio_slice_range(a, chunk, vpos0, tg0, tg1);
+        if (tg0 >= tg1)
             continue;
+        const bool ends_launch = tg1 == a.n_frames * 36;
         if (a.active && a.active[stream] == 0) {
-            if (f1 == a.n_frames)
+            if (ends_launch)
                 for (int tid = 0; tid < kAudioThreads; tid++)
                     audio_carry_state(a, stream, tid);
             continue;
         }
         for (auto &x : lds)
             x = 1e30f; // poison
-        const int32_t vpos0 = a.vpos[stream];
-        const uint32_t tg0 = f0 * 36, tg1 = f1 * 36;
         const int32_t base0 = audio_step_base0(vpos0, tg0);
         const uint32_t n_steps = audio_step_count(base0, tg1);
         for (int tid = 0; tid < kAudioThreads; tid++) {
             audio_store_window(a, tid, lds.data());
             audio_phase_fetch(a, stream, base0, tg0, tg1, 0, tid, lds.data());
-            if (f0 == 0)
+            if (tg0 == 0)
                 audio_load_state(a, stream, vpos0, tid, lds.data());
             else
-                audio_phase_warmup(a, stream, f0, tid, lds.data());
+                audio_phase_warmup(a, stream, tg0, tid, lds.data());
         }
         for (int tid = 0; tid < kAudioThreads; tid++)
             audio_phase_dct(a, stream, base0, tg0, tg1, 0, tid, lds.data());
@@ -331,7 +331,7 @@ template <bool kFma, int kFormat> static void emu_audio_blocks(const AudioArgs &
             for (int tid = 0; tid < kAudioThreads; tid++)
                 audio_phase_window<kFma, kFormat>(a, stream, vpos0, base0, tg0, tg1, si, tid, lds.data());
         }
-        if (f1 == a.n_frames) {
+        if (ends_launch) {
             for (int tid = 0; tid < kAudioThreads; tid++)
                 audio_store_state(a, stream, vpos0, tid, lds.data());
             audio_store_vpos(a, stream, vpos0);
