@@ -36,7 +36,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MB_PER_1080P30_STREAM = 8160 * 30
-KERNEL = {False: "recon_kernel<1, false> (one wave = 4 macroblocks; sparse coefficient entries, prediction windows by direct-to-LDS loads)",
+KERNEL = {False: "recon_kernel<1, false> (a wave reconstructs two chunks of 4 macroblocks; sparse coefficient entries, prediction windows by direct-to-LDS loads)",
           True: "recon_kernel<1, true> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
@@ -247,7 +247,7 @@ def audio_leg(ctx, args):
         "realtime_streams_44k1": frames * 1152 / (ams * 1e-3) / 44100.0,
         "roofline": {"bound": "hbm", "achieved": abytes / (ams * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": abytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "audio_kernel<false, F32N> (DCT-32 + polyphase window, 4 waves per stream slice)"},
+                     "kernel": "audio_kernel<false, F32N> (DCT-32 + polyphase window as a sliding register file, 4 waves per stream slice)"},
         "parity": aparity,
     }
     a.close()
