@@ -45,6 +45,8 @@ def lib():
             f.restype = C.c_uint32
             f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, P, P, P]
         L.emu_host_has_avx512.restype = C.c_int
+        L.emu_audio_slice_range.restype = None
+        L.emu_audio_slice_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, P, P]
         L.emu_relayout.restype = None
         L.emu_relayout.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
         L.emu_rgba_convert.restype = None

@@ -387,6 +387,15 @@ int emu_audio_run_masked(const int32_t *samples, void *out, float *ring, int32_t
     return 0;
 }
 
+// the time slices of a launch (audio_slice_range), for the test that checks they tile it
+void emu_audio_slice_range(uint32_t n_frames, uint32_t n_chunks, int32_t vpos0, uint32_t chunk, uint32_t *tg0, uint32_t *tg1)
+{
+    AudioArgs a = {};
+    a.n_frames = n_frames;
+    a.n_chunks = n_chunks;
+    audio_slice_range(a, chunk, vpos0, *tg0, *tg1);
+}
+
 // scalar helpers exposed for unit tests
 uint32_t emu_avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return avg4_u8x4(a, b, c, d); }
 uint32_t emu_avg2(uint32_t a, uint32_t b) { return avg_ceil_u8x4(a, b); }

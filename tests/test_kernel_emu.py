@@ -177,3 +177,27 @@ def test_audio_step_grid_at_every_ring_position(oracle, emu, chunks):
         assert bits_equal(o.synth(s, desc.AUDIO_F32N), e.synth(s, desc.AUDIO_F32N)), vpos
         (va, pa), (vb, pb) = o.get_state(0), e.get_state(0)
         assert pa == pb and bits_equal(va, vb), vpos
+
+
+def test_audio_slices_tile_the_launch_on_the_step_grid(emu):
+    """audio_slice_range: the non-empty slices of a stream are disjoint, in order and cover [0, n_frames * 36); every
+    cut but 0 and the end is a whole number of 32-sub-block steps away from the stream's first grid point
+    (vpos0 / 64 mod 16), and lies at least 15 sub-blocks in (the history rebuilt in front of a slice)."""
+    import ctypes as C
+    L = emu.lib()
+    for n_frames in (1, 4, 9, 20, 100):
+        for n_chunks in (1, 2, 3, 5, 7, 25):
+            if n_chunks > n_frames:
+                continue
+            for vpos0 in range(0, 1024, 64):
+                g, n, at = (vpos0 >> 6) & 15, n_frames * 36, 0
+                for chunk in range(n_chunks):
+                    t0, t1 = C.c_uint32(0), C.c_uint32(0)
+                    L.emu_audio_slice_range(n_frames, n_chunks, vpos0, chunk, C.byref(t0), C.byref(t1))
+                    if t0.value >= t1.value:
+                        continue
+                    assert t0.value == at, (n_frames, n_chunks, vpos0, chunk)
+                    if t0.value:
+                        assert t0.value >= 15 and (t0.value - g) % 32 == 0
+                    at = t1.value
+                assert at == n, (n_frames, n_chunks, vpos0)
