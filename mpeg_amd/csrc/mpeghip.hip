@@ -120,31 +120,43 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7; leaves lane (g, j) with row j of block g
     auto residual_pass = [&](uint32_t pass) {
         const uint32_t np = rc_pass_entries(c, pass);
-        rc_zero_tile(T, lane);
         if (pass > 0)
             bw = bw_next;
         if ((pass + 1) * 8 < n_blocks) // the next pass's block words: on their way while this pass runs
             bw_next = rc_blk_src(a, c)[rc_blk_lane_offset(pass + 1, lane) / 4];
-        wave_lds_handoff();
-        for (uint32_t r = 0; r < np; r += 64) {
-            if (pass > 0 || r > 0)
-                e = *rc_ent_src(a, c, ent_at + r, lane);
-            if (r + (uint32_t)lane < np)
-                rc_scatter(T, lds, e);
-        }
-        ent_at += np;
-        if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
-#pragma unroll
-            for (uint32_t g = 0; g < 8; g++) {
-                const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
-                if (pass * 8 + g < n_blocks && (bwg & kBRaw))
-                    rc_raw_fill(a, c, T, g, bwg, lane);
+        const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
+        // a pass whose blocks ALL travel as dense units (the worst-case workload) needs neither the zeroed tile nor a
+        // column read from it: every live lane takes its column straight from its unit
+        bool from_tile = true;
+        if (rc_any_dense(c) && np == 0 && !rc_any_raw(c))
+            from_tile = !all_in_wave(!mine || (bw & kBDense) != 0);
+        if (from_tile) {
+            rc_zero_tile(T, lane);
+            wave_lds_handoff();
+            for (uint32_t r = 0; r < np; r += 64) {
+                if (pass > 0 || r > 0)
+                    e = *rc_ent_src(a, c, ent_at + r, lane);
+                if (r + (uint32_t)lane < np)
+                    rc_scatter(T, lds, e);
             }
+            ent_at += np;
+            if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
+#pragma unroll
+                for (uint32_t g = 0; g < 8; g++) {
+                    const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
+                    if (pass * 8 + g < n_blocks && (bwg & kBRaw))
+                        rc_raw_fill(a, c, T, g, bwg, lane);
+                }
+            }
+            wave_lds_handoff();
+            rc_cols_load(T, lane, v);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                v[r] = 0; // (lanes beyond the last block: their result is not used)
         }
-        wave_lds_handoff();
-        rc_cols_load(T, lane, v);
         if (rc_any_dense(c)) { // blocks that travel as dense units: their columns come straight from the unit
-            if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw & kBDense))
+            if (mine && (bw & kBDense))
                 rc_dense_cols(a, c, lds, bw, lane, v);
         }
         idct8<false>(v);

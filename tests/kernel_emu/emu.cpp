@@ -126,27 +126,40 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
         uint32_t ent_at = 0;
         auto residual_pass = [&](uint32_t pass) {
             const uint32_t np = rc_pass_entries(c, pass);
-            for (int lane = 0; lane < 64; lane++) {
-                rc_zero_tile(T, lane);
+            bool from_tile = true; // (as the kernel: a pass of dense units only does not go through the tile)
+            for (int lane = 0; lane < 64; lane++)
                 bw[lane] = rc_blk_src(a, c)[rc_blk_lane_offset(pass, lane) / 4];
+            if (rc_any_dense(c) && np == 0 && !rc_any_raw(c)) {
+                from_tile = false;
+                for (int lane = 0; lane < 64; lane++)
+                    if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks && !(bw[lane] & kBDense))
+                        from_tile = true;
             }
-            for (uint32_t r = 0; r < np; r += 64)
-                for (int lane = 0; lane < 64; lane++) {
-                    if (pass > 0 || r > 0)
-                        e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
-                    if (r + (uint32_t)lane < np)
-                        rc_scatter(T, lds, e[lane]);
-                }
-            ent_at += np;
-            if (rc_any_raw(c))
-                for (uint32_t g = 0; g < 8; g++) {
-                    const uint32_t bwg = bw[g * 8]; // the kernel's v_readlane
-                    if (pass * 8 + g < n_blocks && (bwg & kBRaw))
-                        for (int lane = 0; lane < 64; lane++)
-                            rc_raw_fill(a, c, T, g, bwg, lane);
-                }
+            if (from_tile) {
+                for (int lane = 0; lane < 64; lane++)
+                    rc_zero_tile(T, lane);
+                for (uint32_t r = 0; r < np; r += 64)
+                    for (int lane = 0; lane < 64; lane++) {
+                        if (pass > 0 || r > 0)
+                            e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
+                        if (r + (uint32_t)lane < np)
+                            rc_scatter(T, lds, e[lane]);
+                    }
+                ent_at += np;
+                if (rc_any_raw(c))
+                    for (uint32_t g = 0; g < 8; g++) {
+                        const uint32_t bwg = bw[g * 8]; // the kernel's v_readlane
+                        if (pass * 8 + g < n_blocks && (bwg & kBRaw))
+                            for (int lane = 0; lane < 64; lane++)
+                                rc_raw_fill(a, c, T, g, bwg, lane);
+                    }
+            }
             for (int lane = 0; lane < 64; lane++) {
-                rc_cols_load(T, lane, v[lane]);
+                if (from_tile)
+                    rc_cols_load(T, lane, v[lane]);
+                else
+                    for (int r = 0; r < 8; r++)
+                        v[lane][r] = 0;
                 if (rc_any_dense(c) && pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw[lane] & kBDense))
                     rc_dense_cols(a, c, lds, bw[lane], lane, v[lane]);
                 idct8<false>(v[lane]);
