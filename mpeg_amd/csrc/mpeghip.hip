@@ -117,6 +117,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 
     int32_t v[8];
     uint32_t ent_at = 0, bw_next = 0;
+    i32x4_a4 dense_next = {{0, 0, 0, 0}};
     // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7; leaves lane (g, j) with row j of block g
     auto residual_pass = [&](uint32_t pass) {
         const uint32_t np = rc_pass_entries(c, pass);
@@ -156,8 +157,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
                 v[r] = 0; // (lanes beyond the last block: their result is not used)
         }
         if (rc_any_dense(c)) { // blocks that travel as dense units: their columns come straight from the unit
-            if (mine && (bw & kBDense))
-                rc_dense_cols(a, c, lds, bw, lane, v);
+            if (mine && (bw & kBDense)) {
+                const i32x4_a4 lv = pass > 0 ? dense_next : rc_dense_read(a, c, bw, lane);
+                rc_dense_cols(lv, lds, bw, lane, v);
+            }
+            // (the next pass's columns: its block words are here by now, the units' 16 bytes per lane arrive while this
+            // pass finishes — otherwise every pass waits out a dependent HBM read)
+            if ((pass + 1) * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw_next & kBDense))
+                dense_next = rc_dense_read(a, c, bw_next, lane);
         }
         idct8<false>(v);
         rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now

@@ -559,10 +559,14 @@ template <int R> MPG_HD int32_t rc_dense_level(const i32x4_a4 &lv, bool intra, i
     l = mul_u8<R & 3>(pm[R >> 2], l);
     return level ? l : 0;
 }
-MPG_HD void rc_dense_cols(const VideoArgs &a, const RcChunk &c, const uint8_t *lds, uint32_t bw, int lane, int32_t (&v)[8])
+// column j of a dense unit: 8 int16 levels (read apart from their use: the next pass's are fetched while this pass runs)
+MPG_HD i32x4_a4 rc_dense_read(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane)
+{
+    return *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 4);
+}
+MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, int lane, int32_t (&v)[8])
 {
     const uint32_t j = (uint32_t)lane & 7;
-    const i32x4_a4 lv = *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + j * 4);
     const int32_t qs = (int32_t)((bw >> 26) & 31);
     const bool intra = !(bw >> 31);
     // the column's 8 matrix entries of both classes (16 bytes: position j * 8 + r -> bytes 2r, 2r + 1) and its 8

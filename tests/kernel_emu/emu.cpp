@@ -161,7 +161,7 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                     for (int r = 0; r < 8; r++)
                         v[lane][r] = 0;
                 if (rc_any_dense(c) && pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw[lane] & kBDense))
-                    rc_dense_cols(a, c, lds, bw[lane], lane, v[lane]);
+                    rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
                 idct8<false>(v[lane]);
             }
             for (int lane = 0; lane < 64; lane++) // (in place: only after every lane has read its column)
