@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-T=r4m
+T=r4t
 mkdir -p gpurun_out/$T
 python bench.py > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err; echo "bench rc=$?"
 tools/gpu_phase_timing.sh run ${T}_phase > /dev/null 2>&1
