@@ -262,6 +262,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product has no CPU path")
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:  # more ranks than devices (a functional run of the N>1 path on a smaller box): ranks share devices
+        print("bench.py: rank with LOCAL_RANK=%d shares device %d (%d visible)" % (local_rank, local_rank % n_dev, n_dev), file=sys.stderr)
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     ranks = Ranks(backend="gloo")  # control plane only: barrier + reductions of timings (no collective on the data path)
     world, rank = ranks.world, ranks.rank
