@@ -95,6 +95,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     const RcLane k = rc_lane(a, lane);
     bool ahead_pending = MPG_CHUNK_AHEAD != 0;
     auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
+    (void)chunk; // (the instrumented build's stamps)
     const uint32_t n_blocks = rc_n_blocks(c);
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)

@@ -651,6 +651,7 @@ MPG_HD uint32_t rc_chroma_row_at(uint32_t plane160, uint32_t row, uint32_t dword
 }
 MPG_HD uint32_t rc_mc_chroma(const uint8_t *win, const RcLane &k, const RcTaps &t, int lane, bool oh, bool ov)
 {
+    (void)lane; // (the emulator's checks below)
     if (t.slow) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_lin);
         return rc_mc4(p[0], p[1], p[4], p[5], t.chroma_x, oh, ov); // (+ 4 dwords: the row below)
