@@ -338,12 +338,16 @@ MPG_HD uint32_t opaque(uint32_t v)
 
 // 16 bytes per lane to (wave-uniform base) + (32-bit lane offset): the scalar-base form of the store, so that no lane
 // builds a 64-bit address (the compiler prefers v_lshl_add_u64 per lane when it sees base + offset itself)
-MPG_HD void store16_at(uint8_t *uniform_base, uint32_t off, const u32x4 &v)
+// kStream: non-temporal — the bytes are not read again in this launch and should not push lines that are out of L2
+template <bool kStream> MPG_HD void store16_at(uint8_t *uniform_base, uint32_t off, const u32x4 &v)
 {
 #if MPG_ON_DEVICE
     typedef uint32_t vec4 __attribute__((ext_vector_type(4)));
     const vec4 d = {v.v[0], v.v[1], v.v[2], v.v[3]};
-    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(d), "s"(uniform_base) : "memory");
+    if (kStream)
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(off), "v"(d), "s"(uniform_base) : "memory");
+    else
+        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(d), "s"(uniform_base) : "memory");
 #else
     __builtin_memcpy(uniform_base + off, v.v, 16);
 #endif

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool rgba = kRgba && (c.h[5] & kCRgba) != 0;
     const uint32_t n_live = rc_n_live(c);
     if (run) {
-        rc_store_run(a, c, lane, lds);
+        rc_store_run<!kRgba>(a, c, lane, lds);
     } else {
 #pragma unroll
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)

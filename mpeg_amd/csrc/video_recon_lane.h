@@ -683,16 +683,20 @@ MPG_HD void rc_rmw(uint8_t *lds, uint32_t bw, int lane, const int32_t (&v)[8])
 // ---- step 5: stores (tiled frame: a macroblock's luma is 256 contiguous bytes, its Cb and Cr 64 each)
 MPG_HD uint32_t rc_mb_index(const VideoArgs &a, uint32_t d0) { return (d0 >> 24) * a.mb_w + ((d0 >> 16) & 0xff); }
 
-// horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), Cb and Cr 256 bytes each by lanes 0..31
+// horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), Cb and Cr 256 bytes each by lanes 0..31.
+// kStream: as non-temporal stores — the picture is next read by a later launch; the prediction windows of the neighbouring
+// chunks, which ARE read again within microseconds, keep their place in L2 (profiles/r4z_ab_non_temporal_frame_stores.txt:
+// typical +1.9 %, dense +0.3 %; on the fused-RGBA instance nothing measurable, it keeps plain stores)
+template <bool kStream = false>
 MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
 {
     const uint32_t l = (uint32_t)lane, mb0 = rc_mb_index(a, c.r[0][0]);
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + (uint64_t)mb0 * 64; // wave-uniform
-    store16_at(cur + (uint64_t)mb0 * 192, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
+    store16_at<kStream>(cur + (uint64_t)mb0 * 192, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
     if (lane < 32) {
         const uint32_t plane = l >> 4, m = (l >> 2) & 3, part = l & 3;
         const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(m) + 256 + plane * 64 + part * 16);
-        store16_at(cur + a.luma_bytes, (a.chroma_bytes & (0u - plane)) + (l & 15) * 16, v);
+        store16_at<kStream>(cur + a.luma_bytes, (a.chroma_bytes & (0u - plane)) + (l & 15) * 16, v);
     }
 }
 
