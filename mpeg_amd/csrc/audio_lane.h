@@ -371,6 +371,12 @@ MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg,
         return;
     }
     const uint32_t e = tg * 64 + 2 * (uint32_t)i + (uint32_t)ch;
+#if MPG_ON_DEVICE && defined(MPG_NT_AUDIO_OUT) // (next round's experiment, tools/ab/next_round.sh; default: off)
+    if (kFormat == MPEGHIP_AUDIO_F32N) {
+        __builtin_nontemporal_store(sv, reinterpret_cast<float *>(a.out) + sb + e);
+        return;
+    }
+#endif
     if (kFormat == MPEGHIP_AUDIO_F32N)
         (reinterpret_cast<float *>(a.out) + sb)[e] = sv;
     else if (kFormat == MPEGHIP_AUDIO_S16) // audio.go:400-408

@@ -232,8 +232,13 @@ MPG_HD void copy16_to_lds(const void *g, void *lds_wave_base, int lane)
 {
 #if MPG_ON_DEVICE
     (void)lane;
+#ifdef MPG_NT_AUDIO_IN // (cache-policy experiments of the next round, tools/ab/next_round.sh; default: off)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2 /* nt */);
+#else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+#endif
 #else
     __builtin_memcpy(static_cast<char *>(lds_wave_base) + 16 * lane, g, 16);
 #endif
@@ -282,7 +287,11 @@ MPG_HD uint32_t load32_uncounted(const uint32_t *uniform_base, uint32_t byte_off
 {
 #if MPG_ON_DEVICE
     uint32_t v;
+#ifdef MPG_NT_ENTRIES // (next round's experiment: the coefficient words are read once)
+    asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(v) : "v"(byte_off), "s"(uniform_base) : "memory");
+#else
     asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(uniform_base) : "memory");
+#endif
     return v;
 #else
     return uniform_base[byte_off / 4];

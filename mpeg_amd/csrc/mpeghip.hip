@@ -235,7 +235,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool rgba = kRgba && (c.h[5] & kCRgba) != 0;
     const uint32_t n_live = rc_n_live(c);
     if (run) {
+#ifdef MPG_NT_FRAME_FUSED // (next round's experiment; default: the fused instance keeps plain stores)
+        rc_store_run<true>(a, c, lane, lds);
+#else
         rc_store_run<!kRgba>(a, c, lane, lds);
+#endif
     } else {
 #pragma unroll
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)

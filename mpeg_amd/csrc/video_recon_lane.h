@@ -743,7 +743,11 @@ MPG_HD void rc_rgba_quad(const VideoArgs &a, const RcChunk &c, uint32_t m, uint3
     const uint64_t p = (uint64_t)py * a.width + px0;
     const uint32_t n = a.width - px0 >= 4 ? 4 : a.width - px0;
     uint8_t *img = a.rgba + ((uint64_t)c.h[1] << 8);
+#ifdef MPG_NT_RGBA_FUSED // (next round's experiment: r4z could not tell it from the box's drift; default: off)
+    rgba_store4<true>(reinterpret_cast<uint32_t *>(img) + p, p, px, n);
+#else
     rgba_store4<false>(reinterpret_cast<uint32_t *>(img) + p, p, px, n);
+#endif
 }
 MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *lds)
 {

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Cache-policy experiments left for the next round (the reconstruction kernel turned out to be bound by the memory
+# system — profiles/r4x, r4z — so what is worth a place in L2 is the open question).  Builds one library per variant into
+# tools/ab/ (run here, hipcc cross-compiles; ONE group at a time — the A/B scripts run every library they find there), then on the GPU box:
+#   PROFILES="typical dense" bash tools/gpu_ab_lib.sh r5a 4                 # nt_entries against the product
+#   PROFILES="typical dense" bash tools/gpu_ab_lib.sh r5b 4 --rgba 1        # nt_rgba_fused, nt_frame_fused, nt_fused_both
+#   bash tools/ab/audio_ab.sh                                               # nt_audio_out, nt_audio_in (3 rounds)
+# Variants:  nt_entries      coefficient entries and block words loaded with `nt` (read once)
+#            nt_rgba_fused   the fused instance's RGBA stores non-temporal
+#            nt_frame_fused  the fused instance's frame stores non-temporal (the plain instance's already are)
+#            nt_fused_both   both
+#            nt_audio_out    audio output samples stored non-temporally
+#            nt_audio_in     audio sub-band samples loaded (direct to LDS) with `nt`
+set -eu
+cd "$(dirname "$0")/../.."
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -I include -I mpeg_amd/csrc"
+build() { name=$1; shift; /opt/rocm/bin/hipcc $FLAGS "$@" mpeg_amd/csrc/mpeghip.hip -o tools/ab/libmpeghip_$name.so && echo built $name; }
+case "${1:-video}" in
+  video) build nt_entries -DMPG_NT_ENTRIES ;;
+  fused) build nt_rgba_fused -DMPG_NT_RGBA_FUSED; build nt_frame_fused -DMPG_NT_FRAME_FUSED; build nt_fused_both -DMPG_NT_RGBA_FUSED -DMPG_NT_FRAME_FUSED ;;
+  audio) build nt_audio_out -DMPG_NT_AUDIO_OUT; build nt_audio_in -DMPG_NT_AUDIO_IN ;;
+  *) echo "usage: $0 video|fused|audio"; exit 2 ;;
+esac
