@@ -39,8 +39,22 @@ struct VideoArgs {
 // tile-like access pattern ran 30 % faster).  Tiled, a window touches 2 x 3 luma lines and ~2 x 3 chroma lines; a
 // macroblock's output is 256 + 64 + 64 CONTIGUOUS bytes.  The linear view of the reference (plane reads, hashes,
 // Frame.RGBA, and its reads past a plane's edge) is kept exactly: see linear_to_tiled and the kernel's slow path.
+//
+// MPG_CHROMA_PAIRS (a build-time layout option, default off; not yet measured on the GPU — DESIGN.md section 7): the Cb
+// and the Cr block of one macroblock side by side, 128 bytes = one cache line per macroblock for both planes, instead of
+// two planes of 64-byte blocks.  A window then touches ~4 chroma lines instead of ~6.
+#ifndef MPG_CHROMA_PAIRS
+#define MPG_CHROMA_PAIRS 0
+#endif
+constexpr bool kChromaPairs = MPG_CHROMA_PAIRS != 0;
+constexpr uint32_t kChromaBlockStep = kChromaPairs ? 128 : 64; // bytes from one macroblock's block of a plane to the next one's
 MPG_HD uint32_t tiled_luma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 4) * mb_w + (x >> 4)) * 256 + (y & 15) * 16 + (x & 15); }
-MPG_HD uint32_t tiled_chroma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 3) * mb_w + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7); }
+// offset behind the luma plane of chroma sample (x, y) of plane 0 (Cb) / 1 (Cr)
+MPG_HD uint32_t tiled_chroma_plane_offset(uint32_t chroma_bytes, uint32_t plane) { return kChromaPairs ? plane * 64 : plane * chroma_bytes; }
+MPG_HD uint32_t tiled_chroma(uint32_t mb_w, uint32_t chroma_bytes, uint32_t plane, uint32_t x, uint32_t y)
+{
+    return tiled_chroma_plane_offset(chroma_bytes, plane) + ((y >> 3) * mb_w + (x >> 3)) * kChromaBlockStep + (y & 7) * 8 + (x & 7);
+}
 // byte offset inside a slot in the reference's (linear) layout -> where that byte lives.  A dword-aligned linear dword
 // stays one dword (tile rows are 16 / 8 bytes and plane widths multiples of them).
 MPG_HD uint32_t linear_to_tiled(uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_bytes, uint32_t L)
@@ -48,14 +62,14 @@ MPG_HD uint32_t linear_to_tiled(uint32_t mb_w, uint32_t luma_bytes, uint32_t chr
     const uint32_t luma_w = mb_w * 16, chroma_w = mb_w * 8;
     if (L < luma_bytes)
         return tiled_luma(mb_w, L % luma_w, L / luma_w);
-    uint32_t c = L - luma_bytes, plane = luma_bytes;
+    uint32_t c = L - luma_bytes, plane = 0;
     if (c >= chroma_bytes) {
         c -= chroma_bytes;
-        plane += chroma_bytes;
+        plane = 1;
         if (c >= chroma_bytes)
             return L; // pad / slack: linear
     }
-    return plane + tiled_chroma(mb_w, c % chroma_w, c / chroma_w);
+    return luma_bytes + tiled_chroma(mb_w, chroma_bytes, plane, c % chroma_w, c / chroma_w);
 }
 
 // Descriptors are read-only for the whole launch.  On the device they are read through the constant
@@ -222,9 +236,9 @@ MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t mb_w, uint32_t luma
     // (a quad of 4 luma pixels lies inside one tile row, its 2 chroma samples inside one block row)
     const uint32_t yy0 = *reinterpret_cast<const uint32_t *>(frame + tiled_luma(mb_w, x0, y));
     const uint32_t yy1 = *reinterpret_cast<const uint32_t *>(frame + tiled_luma(mb_w, x0, two ? y + 1 : y));
-    const uint8_t *cbp = frame + luma_bytes + tiled_chroma(mb_w, x0 >> 1, yp);
+    const uint8_t *cbp = frame + luma_bytes + tiled_chroma(mb_w, chroma_bytes, 0, x0 >> 1, yp);
     const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp);
-    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + chroma_bytes);
+    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + tiled_chroma_plane_offset(chroma_bytes, 1));
     uint32_t px0[4], px1[4];
     const ChromaTerms c01 = chroma_terms(cb & 0xff, cr & 0xff), c23 = chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff);
     rgba_row4(yy0, c01, c23, px0);

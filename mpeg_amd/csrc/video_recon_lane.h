@@ -14,7 +14,8 @@
 //           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24        d1 reference frame offset >> 8
 //                   d2 the luma prediction window, origin (x0, y0) = macroblock origin + integer vector:
 //                      byte offset (inside the frame) of the 16x16 TILE that holds (x0, y0) | (y0 & 15) << 4 | x0 & 15
-//                   d3 the same for Cb: offset of the 8x8 block (plane offset included; Cr = + chroma_bytes)
+//                   d3 the same for Cb: offset of the 8x8 block (plane offset included; Cr = + chroma_bytes, or + 64
+//                      with MPG_CHROMA_PAIRS)
 //                      | (cy0 & 7) << 3 | cx0 & 7
 //                   kRSlow records (a window that leaves its plane: the reference reads on, linearly, into the next
 //                   row / plane / the pad, video_noasm.go:48-80) carry the window origins as LINEAR byte offsets
@@ -256,7 +257,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 if (inside) {
                     d[0] = d0;
                     d[2] = (((uint32_t)y0 >> 4) * g.mb_w + ((uint32_t)x0 >> 4)) * 256 | (((uint32_t)y0 & 15) << 4) | ((uint32_t)x0 & 15);
-                    d[3] = (g.luma_bytes + (((uint32_t)cy0 >> 3) * g.mb_w + ((uint32_t)cx0 >> 3)) * 64) | (((uint32_t)cy0 & 7) << 3) | ((uint32_t)cx0 & 7);
+                    d[3] = (g.luma_bytes + (((uint32_t)cy0 >> 3) * g.mb_w + ((uint32_t)cx0 >> 3)) * kChromaBlockStep) | (((uint32_t)cy0 & 7) << 3) | ((uint32_t)cx0 & 7);
                 } else { // the reference's linear reads (validated: inside [plane start, end of base))
                     d[0] = d0 | kRSlow;
                     d[2] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
@@ -405,9 +406,9 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
         k.piece_chroma = opaque(chroma ? ~0u : 0u); // (a plain mask: the compiler must not turn `x & mask` into selects)
         k.sub_mask = chroma ? 0x30 : 0xf0;
         k.rj16 = rj * 16;
-        k.rj16_cterm = rj * 16 + (chroma ? plane * a.chroma_bytes + (cj & 1) * 64 : (l & 1) * 256);
+        k.rj16_cterm = rj * 16 + (chroma ? tiled_chroma_plane_offset(a.chroma_bytes, plane) + (cj & 1) * kChromaBlockStep : (l & 1) * 256);
         k.wrap_shift = chroma ? 6 : 8;
-        k.below = chroma ? a.mb_w * 64 - 64 : a.mb_w * 256 - 256;
+        k.below = chroma ? a.mb_w * kChromaBlockStep - 64 : a.mb_w * 256 - 256;
     }
     {
         const bool chroma = l >= 34;
@@ -694,9 +695,14 @@ MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const u
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + (uint64_t)mb0 * 64; // wave-uniform
     store16_at<kStream>(cur + (uint64_t)mb0 * 192, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
     if (lane < 32) {
-        const uint32_t plane = l >> 4, m = (l >> 2) & 3, part = l & 3;
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(m) + 256 + plane * 64 + part * 16);
-        store16_at<kStream>(cur + a.luma_bytes, (a.chroma_bytes & (0u - plane)) + (l & 15) * 16, v);
+        if (kChromaPairs) { // 4 x (Cb | Cr) = 512 contiguous bytes, as they lie in the O_m
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 3) + 256 + (l & 7) * 16);
+            store16_at<kStream>(cur + a.luma_bytes + (uint64_t)mb0 * 64, l * 16, v); // (cur is mb0 * 64 in already)
+        } else {
+            const uint32_t plane = l >> 4, m = (l >> 2) & 3, part = l & 3;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(m) + 256 + plane * 64 + part * 16);
+            store16_at<kStream>(cur + a.luma_bytes, (a.chroma_bytes & (0u - plane)) + (l & 15) * 16, v);
+        }
     }
 }
 
@@ -715,7 +721,7 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
     if (b < 4)
         off = mb * 256 + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 16 + ((uint32_t)(b & 1) << 3);
     else
-        off = a.luma_bytes + (uint32_t)(b - 4) * a.chroma_bytes + mb * 64 + (uint32_t)j * 8;
+        off = a.luma_bytes + tiled_chroma_plane_offset(a.chroma_bytes, (uint32_t)(b - 4)) + mb * kChromaBlockStep + (uint32_t)j * 8;
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + off;
     uint8_t *t = lds + rc_tile_offset(b, j, m);
     if (written)

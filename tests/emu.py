@@ -16,26 +16,37 @@ ROOT = HERE.parent.parent
 LIB = HERE / "libkernel_emu.so"
 
 _lib = None
+_libs = {}      # variant tag -> loaded library ("" = the product's build options)
+_variant = ("", ())
+
+
+def select(tag="", flags=()):
+    """Switch the emulator to a build of the lane headers with other options (a layout option such as
+    -DMPG_CHROMA_PAIRS=1); select() goes back to the product's."""
+    global _lib, _variant
+    _variant = (tag, tuple(flags))
+    _lib = _libs.get(tag)
 
 
 def build(force=False):
+    tag, flags = _variant
+    out = LIB if not tag else HERE / ("libkernel_emu_%s.so" % tag)
     srcs = [HERE / "emu.cpp"] + sorted((ROOT / "mpeg_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "mpeghip.h"]
-    if not force and LIB.exists() and all(s.stat().st_mtime <= LIB.stat().st_mtime for s in srcs):
-        return LIB
+    if not force and out.exists() and all(s.stat().st_mtime <= out.stat().st_mtime for s in srcs):
+        return out
     cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DMPG_EMU_CHECKS", "-Wall", "-Wextra",
-           "-Wno-unknown-pragmas", "-I", str(ROOT / "include"), "-I", str(ROOT / "mpeg_amd" / "csrc"),
-           str(HERE / "emu.cpp"), "-o", str(LIB)]
+           "-Wno-unknown-pragmas", *flags, "-I", str(ROOT / "include"), "-I", str(ROOT / "mpeg_amd" / "csrc"),
+           str(HERE / "emu.cpp"), "-o", str(out)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulator build failed:\n" + r.stdout)
-    return LIB
+    return out
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(str(LIB))
+        L = C.CDLL(str(build()))
         P = C.c_void_p
         L.emu_video_run.restype = C.c_int
         L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
@@ -59,7 +70,7 @@ def lib():
         L.emu_avg2.argtypes = [C.c_uint32] * 2
         L.emu_xcd_chunk.argtypes = [C.c_uint32] * 2
         L.emu_ycbcr.argtypes = [C.c_uint32] * 3
-        _lib = L
+        _lib = _libs[_variant[0]] = L
     return _lib
 
 

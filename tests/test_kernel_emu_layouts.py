@@ -1,0 +1,73 @@
+"""Build-time layout options of the frame store (mpeg_amd/csrc/video_lane.h) keep the reference's linear view bit for bit:
+the lane emulator built with the option must reproduce the oracle on the same cases as the product's layout — prediction
+windows, windows that leave their plane (the linear reads), stores of runs and of single macroblocks, the fused and the
+whole-frame RGBA, plane write / read round trips.  (The options are not built into the product until they are measured.)"""
+import numpy as np
+import pytest
+
+from mpeg_amd import desc, synth
+from parity import run_and_compare
+
+LAYOUTS = [("chroma_pairs", ("-DMPG_CHROMA_PAIRS=1",))]
+
+
+@pytest.fixture(params=LAYOUTS, ids=[t for t, _ in LAYOUTS])
+def emu_layout(request, emu):
+    tag, flags = request.param
+    emu.select(tag, flags)
+    emu.lib()
+    yield emu
+    emu.select()
+
+
+@pytest.mark.parametrize("w,h,n,profile,raw,rgba", [
+    (352, 240, 6, "typical", 0.0, False),
+    (352, 240, 4, "typical", 0.15, False),
+    (352, 240, 3, "dense", 0.0, False),
+    (160, 120, 5, "typical", 0.05, True),
+    (176, 144, 4, "typical", 0.0, True),
+    (24, 40, 4, "typical", 0.0, True),
+    (50, 35, 3, "typical", 0.0, True),
+])
+def test_layout_option_matches_oracle(oracle, emu_layout, w, h, n, profile, raw, rgba):
+    seq = synth.generate_sequence(w, h, n, profile=profile, raw_fraction=raw, rgba=rgba)
+    run_and_compare(oracle.OracleStore(w, h), emu_layout.EmuStore(w, h), seq, check_rgba=rgba)
+
+
+@pytest.mark.parametrize("w,h", [(100, 60), (37, 23), (16, 1), (3, 16)])
+def test_layout_option_standalone_rgba_and_plane_round_trip(oracle, emu_layout, w, h):
+    o, e = oracle.OracleStore(w, h), emu_layout.EmuStore(w, h)
+    rng = np.random.default_rng(3)
+    g = desc.geometry(w, h)
+    y, cb, cr = (rng.integers(0, 256, n, dtype=np.uint8) for n in (g["luma_bytes"], g["chroma_bytes"], g["chroma_bytes"]))
+    o.write_planes(0, 1, y, cb, cr)
+    e.write_planes(0, 1, y, cb, cr)
+    for a, b in zip((y, cb, cr), e.read_planes(0, 1)):
+        assert np.array_equal(a, b)
+    e.rgba_convert(1)
+    assert np.array_equal(o.read_rgba(0, 1), e.read_rgba(0, 1))
+
+
+def test_layout_option_is_in_effect(emu):
+    """chroma_pairs: Cb and Cr of macroblock i lie side by side behind the luma plane (128 bytes per macroblock); the
+    product's layout keeps two planes of 64-byte blocks."""
+    w, h = 64, 32
+    g = desc.geometry(w, h)
+    L, C = g["luma_bytes"], g["chroma_bytes"]
+    y = np.zeros(L, np.uint8)
+    cb, cr = np.full(C, 0xB0, np.uint8), np.full(C, 0xC0, np.uint8)
+    cb[:8] = np.arange(8)                                        # row 0 of the first block of Cb
+    raw = {}
+    for tag, flags in [("", ())] + LAYOUTS:
+        emu.select(tag, flags)
+        try:
+            e = emu.EmuStore(w, h)
+            e.write_planes(0, 0, y, cb, cr)
+            raw[tag] = e.frames[:L + 2 * C].copy()
+        finally:
+            emu.select()
+    plain, pairs = raw[""][L:], raw["chroma_pairs"][L:]
+    assert list(plain[:8]) == list(range(8)) and list(pairs[:8]) == list(range(8))
+    assert (plain[8:C] == 0xB0).all() and (plain[C:] == 0xC0).all()            # plane after plane
+    blocks = pairs.reshape(-1, 2, 64)
+    assert (blocks[:, 1] == 0xC0).all() and (blocks[1:, 0] == 0xB0).all()      # Cb | Cr per macroblock

@@ -11,6 +11,11 @@
 #            nt_fused_both   both
 #            nt_audio_out    audio output samples stored non-temporally
 #            nt_audio_in     audio sub-band samples loaded (direct to LDS) with `nt`
+#            chroma_pairs    frame-store layout: Cb | Cr of a macroblock side by side (one line instead of half of two;
+#                            ~10 instead of ~12 cache lines per prediction window).  Host packer and kernels change
+#                            together; the lane emulator built with the option is bit-exact (tests/test_kernel_emu_layouts.py).
+#                            On the box:  PROFILES="typical dense" bash tools/gpu_ab_lib.sh r5d 4 ; then with --rgba 1 ;
+#                            parity of the whole -m gpu suite against it:  cp tools/ab/libmpeghip_chroma_pairs.so mpeg_amd/libmpeghip.so && python -m pytest tests -m gpu -q
 set -eu
 cd "$(dirname "$0")/../.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -I include -I mpeg_amd/csrc"
@@ -18,6 +23,7 @@ build() { name=$1; shift; /opt/rocm/bin/hipcc $FLAGS "$@" mpeg_amd/csrc/mpeghip.
 case "${1:-video}" in
   video) build nt_entries -DMPG_NT_ENTRIES ;;
   fused) build nt_rgba_fused -DMPG_NT_RGBA_FUSED; build nt_frame_fused -DMPG_NT_FRAME_FUSED; build nt_fused_both -DMPG_NT_RGBA_FUSED -DMPG_NT_FRAME_FUSED ;;
+  layout) build chroma_pairs -DMPG_CHROMA_PAIRS=1 ;;
   audio) build nt_audio_out -DMPG_NT_AUDIO_OUT; build nt_audio_in -DMPG_NT_AUDIO_IN ;;
-  *) echo "usage: $0 video|fused|audio"; exit 2 ;;
+  *) echo "usage: $0 video|fused|layout|audio"; exit 2 ;;
 esac
