@@ -49,12 +49,7 @@ struct VideoArgs {
 constexpr bool kChromaPairs = MPG_CHROMA_PAIRS != 0;
 constexpr uint32_t kChromaBlockStep = kChromaPairs ? 128 : 64; // bytes from one macroblock's block of a plane to the next one's
 MPG_HD uint32_t tiled_luma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 4) * mb_w + (x >> 4)) * 256 + (y & 15) * 16 + (x & 15); }
-// offset behind the luma plane of chroma sample (x, y) of plane 0 (Cb) / 1 (Cr)
-MPG_HD uint32_t tiled_chroma_plane_offset(uint32_t chroma_bytes, uint32_t plane) { return kChromaPairs ? plane * 64 : plane * chroma_bytes; }
-MPG_HD uint32_t tiled_chroma(uint32_t mb_w, uint32_t chroma_bytes, uint32_t plane, uint32_t x, uint32_t y)
-{
-    return tiled_chroma_plane_offset(chroma_bytes, plane) + ((y >> 3) * mb_w + (x >> 3)) * kChromaBlockStep + (y & 7) * 8 + (x & 7);
-}
+MPG_HD uint32_t tiled_chroma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 3) * mb_w + (x >> 3)) * kChromaBlockStep + (y & 7) * 8 + (x & 7); }
 // byte offset inside a slot in the reference's (linear) layout -> where that byte lives.  A dword-aligned linear dword
 // stays one dword (tile rows are 16 / 8 bytes and plane widths multiples of them).
 MPG_HD uint32_t linear_to_tiled(uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_bytes, uint32_t L)
@@ -62,14 +57,14 @@ MPG_HD uint32_t linear_to_tiled(uint32_t mb_w, uint32_t luma_bytes, uint32_t chr
     const uint32_t luma_w = mb_w * 16, chroma_w = mb_w * 8;
     if (L < luma_bytes)
         return tiled_luma(mb_w, L % luma_w, L / luma_w);
-    uint32_t c = L - luma_bytes, plane = 0;
+    uint32_t c = L - luma_bytes, plane = luma_bytes;
     if (c >= chroma_bytes) {
         c -= chroma_bytes;
-        plane = 1;
+        plane += kChromaPairs ? 64 : chroma_bytes;
         if (c >= chroma_bytes)
             return L; // pad / slack: linear
     }
-    return luma_bytes + tiled_chroma(mb_w, chroma_bytes, plane, c % chroma_w, c / chroma_w);
+    return plane + tiled_chroma(mb_w, c % chroma_w, c / chroma_w);
 }
 
 // Descriptors are read-only for the whole launch.  On the device they are read through the constant
@@ -236,9 +231,9 @@ MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t mb_w, uint32_t luma
     // (a quad of 4 luma pixels lies inside one tile row, its 2 chroma samples inside one block row)
     const uint32_t yy0 = *reinterpret_cast<const uint32_t *>(frame + tiled_luma(mb_w, x0, y));
     const uint32_t yy1 = *reinterpret_cast<const uint32_t *>(frame + tiled_luma(mb_w, x0, two ? y + 1 : y));
-    const uint8_t *cbp = frame + luma_bytes + tiled_chroma(mb_w, chroma_bytes, 0, x0 >> 1, yp);
+    const uint8_t *cbp = frame + luma_bytes + tiled_chroma(mb_w, x0 >> 1, yp);
     const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp);
-    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + tiled_chroma_plane_offset(chroma_bytes, 1));
+    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + (kChromaPairs ? 64 : chroma_bytes));
     uint32_t px0[4], px1[4];
     const ChromaTerms c01 = chroma_terms(cb & 0xff, cr & 0xff), c23 = chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff);
     rgba_row4(yy0, c01, c23, px0);

@@ -406,7 +406,7 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
         k.piece_chroma = opaque(chroma ? ~0u : 0u); // (a plain mask: the compiler must not turn `x & mask` into selects)
         k.sub_mask = chroma ? 0x30 : 0xf0;
         k.rj16 = rj * 16;
-        k.rj16_cterm = rj * 16 + (chroma ? tiled_chroma_plane_offset(a.chroma_bytes, plane) + (cj & 1) * kChromaBlockStep : (l & 1) * 256);
+        k.rj16_cterm = rj * 16 + (chroma ? plane * (kChromaPairs ? 64 : a.chroma_bytes) + (cj & 1) * kChromaBlockStep : (l & 1) * 256);
         k.wrap_shift = chroma ? 6 : 8;
         k.below = chroma ? a.mb_w * kChromaBlockStep - 64 : a.mb_w * 256 - 256;
     }
@@ -721,7 +721,7 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
     if (b < 4)
         off = mb * 256 + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 16 + ((uint32_t)(b & 1) << 3);
     else
-        off = a.luma_bytes + tiled_chroma_plane_offset(a.chroma_bytes, (uint32_t)(b - 4)) + mb * kChromaBlockStep + (uint32_t)j * 8;
+        off = a.luma_bytes + (uint32_t)(b - 4) * (kChromaPairs ? 64 : a.chroma_bytes) + mb * kChromaBlockStep + (uint32_t)j * 8;
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + off;
     uint8_t *t = lds + rc_tile_offset(b, j, m);
     if (written)
