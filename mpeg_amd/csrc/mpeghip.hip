@@ -75,7 +75,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     if (first >= a.n_chunks)
         return;
     uint8_t *lds = lds_all + w * kRcLdsBytes;
+#if MPG_TILE16
+    int16_t *T = reinterpret_cast<int16_t *>(lds + kRcTileAt);
+#else
     int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
+#endif
 
 #if MPG_CHUNK_AHEAD
     // pull the chunks a later wave of this XCD's range will take towards L2 (one lane per cache line of their 96 bytes
@@ -127,6 +131,40 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         if ((pass + 1) * 8 < n_blocks) // the next pass's block words: on their way while this pass runs
             bw_next = rc_blk_src(a, c)[rc_blk_lane_offset(pass + 1, lane) / 4];
         const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
+#if MPG_TILE16
+        // the int16 tile holds sparse blocks only: a pass without entries does not go through it
+        if (np) {
+            rc_zero_tile16(T, lane);
+            wave_lds_handoff();
+            for (uint32_t r = 0; r < np; r += 64) {
+                if (pass > 0 || r > 0)
+                    e = *rc_ent_src(a, c, ent_at + r, lane);
+                if (r + (uint32_t)lane < np)
+                    rc_scatter16(T, lds, e);
+            }
+            ent_at += np;
+            wave_lds_handoff();
+            rc_cols_load16(T, lds, lane, v);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                v[r] = 0;
+        }
+        if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are
+            rc_raw_cols(a, c, bw, lane, v);
+        if (rc_any_dense(c)) {
+            if (mine && (bw & kBDense)) {
+                const i32x4_a4 lv = pass > 0 ? dense_next : rc_dense_read(a, c, bw, lane);
+                rc_dense_cols(lv, lds, bw, lane, v);
+            }
+            if ((pass + 1) * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw_next & kBDense))
+                dense_next = rc_dense_read(a, c, bw_next, lane);
+        }
+        idct8<false>(v);
+        rc_transpose8(v, lane); // column j -> row j, across the block's 8 lanes
+        idct8<true>(v);
+        return;
+#else
         // a pass whose blocks ALL travel as dense units (the worst-case workload) needs neither the zeroed tile nor a
         // column read from it: every live lane takes its column straight from its unit
         bool from_tile = true;
@@ -172,6 +210,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         wave_lds_handoff();
         rc_rows_load(T, lane, v);
         idct8<true>(v);
+#endif
     };
     // step 4: residual rows onto the prediction
     auto add_residual = [&](uint32_t pass) {

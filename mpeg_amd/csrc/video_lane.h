@@ -130,6 +130,18 @@ MPG_HD int32_t dequant(int32_t q, bool intra, int32_t qsqm, int32_t pm)
     return mul24_as_written(l, pm);
 }
 
+// the same without the premultiplier: the clamped level, |.| <= 2048 (MPG_TILE16 keeps these as int16 and premultiplies
+// when a column is read)
+MPG_HD int32_t dequant_level(int32_t q, bool intra, int32_t qsqm)
+{
+    int32_t l = 2 * q;
+    if (!intra)
+        l += (q >> 31) | 1;
+    l = mul24_as_written(l, qsqm) >> 4;
+    l = (l - (l > 0 ? 1 : 0)) | 1;
+    return clampi(l, -2048, 2047);
+}
+
 MPG_HD uint32_t popc6(uint32_t x) { return (uint32_t)__builtin_popcount(x & 0x3f); }
 
 // ------------------------------------------------------------------ colour

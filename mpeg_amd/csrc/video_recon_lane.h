@@ -94,7 +94,20 @@ constexpr int kRcQtabStride = 256;            // per stream in HBM
 constexpr int kRcQtabAt = 0;
 constexpr int kRcWinAt = kRcQtabBytes;        // 192
 constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3648
+// MPG_TILE16 (a build-time option, default off; not yet measured on the GPU — DESIGN.md section 7): the tile holds
+// int16 dequantised levels (premultiplied when a column is read), the 8x8 transposition between the two IDCT passes is
+// done across lanes (DPP) instead of through the tile, snapshot blocks take their columns straight from HBM like
+// dense units: 4 672 bytes of LDS per wave = room for 8 waves per SIMD.
+#ifndef MPG_TILE16
+#define MPG_TILE16 0
+#endif
+constexpr bool kTile16 = MPG_TILE16 != 0;
+#if MPG_TILE16
+constexpr int kRcTileBytes = 8 * 64 * 2;      // T: int16 [8 blocks][64]
+#else
 constexpr int kRcTileBytes = 8 * 64 * 4;      // T: int32 [8 blocks][64]
+#endif
+constexpr int32_t kRcDcInTile16 = 4095;       // an intra DC level beyond this does not fit (level * 8 as int16): the block travels as a dense unit
 constexpr int kRcLdsBytes = kRcTileAt + kRcTileBytes; // 5696: 28 one-wave workgroups per CU (160 000 usable bytes, tools/microbench/lds_residency.hip)
 
 // LDS byte offset of macroblock m's window, later its output bytes O_m: luma [16 rows][16] | Cb [8][8] | Cr [8][8]
@@ -288,7 +301,13 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
 #else
                 const uint64_t mask = rc_nonzero_mask(u);
 #endif
-                if ((uint32_t)__builtin_popcountll(mask) > kDenseAbove) { // the unit as it is is the shorter form
+                bool as_unit = (uint32_t)__builtin_popcountll(mask) > kDenseAbove; // the unit as it is is the shorter form
+                if (kTile16 && intra) { // (a DC level the int16 tile cannot hold: dense units are dequantised in int32)
+                    int16_t dc;
+                    memcpy(&dc, u, 2);
+                    as_unit = as_unit || dc > kRcDcInTile16 || dc < -kRcDcInTile16;
+                }
+                if (as_unit) {
                     any_dense = true;
                     bw[s] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
                     deferred[n_deferred++] = Deferred{u, s, 32};
@@ -495,6 +514,110 @@ MPG_HD void rc_scatter(int32_t *T, const uint8_t *lds, uint32_t e)
     T[(e & 0x7fcu) >> 2] = (e & kEDc) ? level * 256 : dq;
 }
 
+struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; }; // 16 bytes at dword alignment (the words array)
+#if MPG_TILE16
+MPG_HD void rc_zero_tile16(int16_t *T, int lane)
+{
+    const i32x4 z = {{0, 0, 0, 0}};
+    *reinterpret_cast<i32x4 *>(T + lane * 8) = z;
+}
+// one entry: the dequantised level (video.go:719-741) to T[slot & 7][position]; an intra DC as level * 8 — the column
+// read multiplies by the premultiplier, 32 at position 0: level * 256 (video.go:672)
+MPG_HD void rc_scatter16(int16_t *T, const uint8_t *lds, uint32_t e)
+{
+    const uint8_t *Q = lds + kRcQtabAt;
+    const int32_t qm = Q[(e & 0xfeu) >> 1];
+    const int32_t level = (int32_t)e >> 16;
+    const int32_t qs = (int32_t)((e >> 11) & 31);
+    const int32_t dq = dequant_level(level, !(e & kENonIntra), mul24_as_written(qs, qm));
+    MPG_CHECK(!(e & kEDc) || (level >= -kRcDcInTile16 && level <= kRcDcInTile16));
+    T[(e & 0x7fcu) >> 2] = (int16_t)((e & kEDc) ? level * 8 : dq);
+}
+// (byte kByte of `bytes`) * (half-word kHalf of `words`, sign-extended): unpacking is the multiplier's operand select
+template <int kByte, int kHalf> MPG_HD int32_t mul_u8_s16(uint32_t bytes, uint32_t words)
+{
+#if MPG_ON_DEVICE
+    int32_t r;
+    if (kByte == 0 && kHalf == 0)
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_0" : "=v"(r) : "v"(bytes), "v"(words));
+    else if (kByte == 1 && kHalf == 1)
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:WORD_1" : "=v"(r) : "v"(bytes), "v"(words));
+    else if (kByte == 2 && kHalf == 0)
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:WORD_0" : "=v"(r) : "v"(bytes), "v"(words));
+    else
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:WORD_1" : "=v"(r) : "v"(bytes), "v"(words));
+    return r;
+#else
+    static_assert((kByte & 1) == kHalf, "rows 2k, 2k+1 of a column: bytes 2k, 2k+1 and the two halves of word k");
+    return (int32_t)((bytes >> (8 * kByte)) & 0xff) * (int32_t)(int16_t)(words >> (16 * kHalf));
+#endif
+}
+// lane (g, j): column j of block g from the int16 tile, premultiplied (video.go:744)
+MPG_HD void rc_cols_load16(const int16_t *T, const uint8_t *lds, int lane, int32_t (&v)[8])
+{
+    const u32x4 t = *reinterpret_cast<const u32x4 *>(T + lane * 8); // T[g][j * 8 + r]: rows 0..7 of column j
+    const uint32_t *pmp = reinterpret_cast<const uint32_t *>(lds + kRcQtabAt + 128 + ((uint32_t)lane & 7) * 8);
+    const uint32_t p0 = pmp[0], p1 = pmp[1];
+    v[0] = mul_u8_s16<0, 0>(p0, t.v[0]);
+    v[1] = mul_u8_s16<1, 1>(p0, t.v[0]);
+    v[2] = mul_u8_s16<2, 0>(p0, t.v[1]);
+    v[3] = mul_u8_s16<3, 1>(p0, t.v[1]);
+    v[4] = mul_u8_s16<0, 0>(p1, t.v[2]);
+    v[5] = mul_u8_s16<1, 1>(p1, t.v[2]);
+    v[6] = mul_u8_s16<2, 0>(p1, t.v[3]);
+    v[7] = mul_u8_s16<3, 1>(p1, t.v[3]);
+}
+// an int32 snapshot block: lane (g, j) takes column j (positions j * 8 .. j * 8 + 7) straight from its 64 dwords
+MPG_HD void rc_raw_cols(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane, int32_t (&v)[8])
+{
+    const i32x4_a4 *p = reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 8);
+    const i32x4_a4 lo = p[0], hi = p[1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        v[r] = lo.v[r];
+        v[r + 4] = hi.v[r];
+    }
+}
+// 8 x 8 transposition across the 8 lanes of a block: lane j holds column j (v[r] = row r) and leaves with row j (v[c] =
+// column c).  Three exchange steps (lane bit k against register bit k); the partner's value comes by DPP.  (Device only:
+// the emulator, which runs lane after lane, transposes at the wave level.)
+#if MPG_ON_DEVICE
+template <int kCtrl> MPG_HD int32_t dpp_quad(int32_t x) { return __builtin_amdgcn_mov_dpp(x, kCtrl, 0xf, 0xf, true); }
+#endif
+MPG_HD void rc_transpose8(int32_t (&v)[8], int lane)
+{
+#if MPG_ON_DEVICE
+    constexpr int kSwap1 = 0xB1, kSwap2 = 0x4E; // quad_perm [1,0,3,2] and [2,3,0,1]
+    constexpr int kRowShl4 = 0x104, kRowShr4 = 0x114;
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) { // lane bit 0 <-> register bit 0
+        const int32_t a = v[r], b = v[r + 1];
+        const int32_t pa = dpp_quad<kSwap1>(a), pb = dpp_quad<kSwap1>(b); // (by every lane: the partner reads them)
+        v[r] = b0 ? pb : a;
+        v[r + 1] = b0 ? b : pa;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { // bit 1
+        const int r = (q & 1) | ((q & 2) << 1);
+        const int32_t a = v[r], b = v[r + 2];
+        const int32_t pa = dpp_quad<kSwap2>(a), pb = dpp_quad<kSwap2>(b);
+        v[r] = b1 ? pb : a;
+        v[r + 2] = b1 ? b : pa;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // bit 2: lanes 0..3 of a block take from lane + 4 (banks 0, 2), lanes 4..7 from lane - 4
+        const int32_t a = v[r], b = v[r + 4];
+        v[r + 4] = __builtin_amdgcn_update_dpp(b, a, kRowShl4, 0xf, 0x5, false);
+        v[r] = __builtin_amdgcn_update_dpp(a, b, kRowShr4, 0xf, 0xa, false);
+    }
+#else
+    (void)v;
+    (void)lane;
+#endif
+}
+#endif
+
 // an int32 snapshot block: its 64 values as they are, lane = position
 MPG_HD void rc_raw_fill(const VideoArgs &a, const RcChunk &c, int32_t *T, uint32_t g, uint32_t bw, int lane)
 {
@@ -517,7 +640,6 @@ MPG_HD void rc_cols_load(const int32_t *T, int lane, int32_t (&v)[8])
 // levels dequantised in place of the tile read.  The column's matrix entries (of the lane's class) and premultipliers
 // are brought into two dwords each, so that every product takes its byte operand through the multiplier's own byte
 // select (SDWA) instead of a shift and a mask.
-struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; };
 template <int kByte> MPG_HD int32_t mul_u8(uint32_t bytes, int32_t x) // (byte kByte of `bytes`) * x, both within 24 bits
 {
 #if MPG_ON_DEVICE

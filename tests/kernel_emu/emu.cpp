@@ -104,7 +104,11 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     alignas(16) uint8_t lds[kRcLdsBytes]; // (no statics: ShardedVideoBatch tests run two emulator stores on two threads)
     for (uint32_t chunk = 0; chunk < nc; chunk++) {
         memset(lds, 0xCD, sizeof(lds)); // poison: reads of unwritten LDS must not matter
+#if MPG_TILE16
+        int16_t *T = reinterpret_cast<int16_t *>(lds + kRcTileAt);
+#else
         int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
+#endif
         const RcChunk c = rc_load_chunk(a, chunk);
         const uint32_t n_blocks = rc_n_blocks(c);
         RcLane k[64];
@@ -126,9 +130,48 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
         uint32_t ent_at = 0;
         auto residual_pass = [&](uint32_t pass) {
             const uint32_t np = rc_pass_entries(c, pass);
-            bool from_tile = true; // (as the kernel: a pass of dense units only does not go through the tile)
             for (int lane = 0; lane < 64; lane++)
                 bw[lane] = rc_blk_src(a, c)[rc_blk_lane_offset(pass, lane) / 4];
+#if MPG_TILE16
+            if (np) {
+                for (int lane = 0; lane < 64; lane++)
+                    rc_zero_tile16(T, lane);
+                for (uint32_t r = 0; r < np; r += 64)
+                    for (int lane = 0; lane < 64; lane++) {
+                        if (pass > 0 || r > 0)
+                            e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
+                        if (r + (uint32_t)lane < np)
+                            rc_scatter16(T, lds, e[lane]);
+                    }
+                ent_at += np;
+            }
+            for (int lane = 0; lane < 64; lane++) {
+                const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
+                if (np)
+                    rc_cols_load16(T, lds, lane, v[lane]);
+                else
+                    for (int r = 0; r < 8; r++)
+                        v[lane][r] = 0;
+                if (rc_any_raw(c) && mine && (bw[lane] & kBRaw))
+                    rc_raw_cols(a, c, bw[lane], lane, v[lane]);
+                if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
+                    rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
+                idct8<false>(v[lane]);
+            }
+            for (int g = 0; g < 8; g++) { // the kernel's transposition across the block's 8 lanes: lane j leaves with row j
+                int32_t m[8][8];
+                for (int j = 0; j < 8; j++)
+                    for (int r = 0; r < 8; r++)
+                        m[r][j] = v[g * 8 + j][r];
+                for (int j = 0; j < 8; j++)
+                    for (int col = 0; col < 8; col++)
+                        v[g * 8 + j][col] = m[j][col];
+            }
+            for (int lane = 0; lane < 64; lane++)
+                idct8<true>(v[lane]);
+            return;
+#else
+            bool from_tile = true; // (as the kernel: a pass of dense units only does not go through the tile)
             if (rc_any_dense(c) && np == 0 && !rc_any_raw(c)) {
                 from_tile = false;
                 for (int lane = 0; lane < 64; lane++)
@@ -170,6 +213,7 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                 rc_rows_load(T, lane, v[lane]);
                 idct8<true>(v[lane]);
             }
+#endif
         };
         auto add_residual = [&](uint32_t pass) {
             for (int lane = 0; lane < 64; lane++)

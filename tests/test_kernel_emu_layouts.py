@@ -1,4 +1,5 @@
-"""Build-time layout options of the frame store (mpeg_amd/csrc/video_lane.h) keep the reference's linear view bit for bit:
+"""Build-time options of the reconstruction kernel — the frame store's chroma layout (mpeg_amd/csrc/video_lane.h) and the
+int16 coefficient tile (video_recon_lane.h) — keep the reference's results bit for bit:
 the lane emulator built with the option must reproduce the oracle on the same cases as the product's layout — prediction
 windows, windows that leave their plane (the linear reads), stores of runs and of single macroblocks, the fused and the
 whole-frame RGBA, plane write / read round trips.  (The options are not built into the product until they are measured.)"""
@@ -8,7 +9,9 @@ import pytest
 from mpeg_amd import desc, synth
 from parity import run_and_compare
 
-LAYOUTS = [("chroma_pairs", ("-DMPG_CHROMA_PAIRS=1",))]
+LAYOUTS = [("chroma_pairs", ("-DMPG_CHROMA_PAIRS=1",)),
+           ("tile16", ("-DMPG_TILE16=1",)),                      # int16 coefficient tile, transposition across lanes
+           ("tile16_chroma_pairs", ("-DMPG_TILE16=1", "-DMPG_CHROMA_PAIRS=1"))]
 
 
 @pytest.fixture(params=LAYOUTS, ids=[t for t, _ in LAYOUTS])
@@ -58,7 +61,7 @@ def test_layout_option_is_in_effect(emu):
     cb, cr = np.full(C, 0xB0, np.uint8), np.full(C, 0xC0, np.uint8)
     cb[:8] = np.arange(8)                                        # row 0 of the first block of Cb
     raw = {}
-    for tag, flags in [("", ())] + LAYOUTS:
+    for tag, flags in [("", ())] + LAYOUTS[:1]:
         emu.select(tag, flags)
         try:
             e = emu.EmuStore(w, h)
@@ -71,3 +74,24 @@ def test_layout_option_is_in_effect(emu):
     assert (plain[8:C] == 0xB0).all() and (plain[C:] == 0xC0).all()            # plane after plane
     blocks = pairs.reshape(-1, 2, 64)
     assert (blocks[:, 1] == 0xC0).all() and (blocks[1:, 0] == 0xB0).all()      # Cb | Cr per macroblock
+
+
+def test_tile16_takes_an_oversized_intra_dc_as_a_dense_unit(oracle, emu):
+    """An intra DC level beyond +-4095 does not fit the int16 tile (level * 8): the packer sends such a block as a dense
+    unit, which is dequantised in int32.  Levels the parser never produces, but the ABI takes any int16."""
+    w, h = 64, 48
+    seq = synth.generate_sequence(w, h, 4, seed=21)
+    hit = 0
+    for sub in seq:
+        units = sub.coefs.view(np.int16).reshape(-1, 64)
+        for i, mb in enumerate(sub.mbs):
+            if (mb["flags"] & desc.MB_INTRA) and not (mb["flags"] & desc.MB_COEF_RAW) and mb["cbp"]:
+                units[mb["coef_off"], 0] = (4096, -4096, 4095, -4095, 32767, -32768)[hit % 6]
+                hit += 1
+    assert hit >= 6
+    for tag, flags in [("", ()), LAYOUTS[1]]:
+        emu.select(tag, flags)
+        try:
+            run_and_compare(oracle.OracleStore(w, h), emu.EmuStore(w, h), seq)
+        finally:
+            emu.select()

@@ -16,6 +16,13 @@
 #                            together; the lane emulator built with the option is bit-exact (tests/test_kernel_emu_layouts.py).
 #                            On the box:  PROFILES="typical dense" bash tools/gpu_ab_lib.sh r5d 4 ; then with --rgba 1 ;
 #                            parity of the whole -m gpu suite against it:  cp tools/ab/libmpeghip_chroma_pairs.so mpeg_amd/libmpeghip.so && python -m pytest tests -m gpu -q
+#            tile16          the wave's coefficient tile as int16 dequantised levels (premultiplied at the column read), the
+#                            8x8 transposition between the IDCT passes across lanes (DPP) instead of through LDS, snapshot
+#                            blocks read straight from HBM: 4 672 B of LDS and 64 vector registers = 8 waves per SIMD instead
+#                            of 7 (the build has 16 B of scratch per lane: three registers spilled around the loop over
+#                            passes 1, 2 — look at that first if it is slow).  Bit-exact in the lane emulator
+#                            (tests/test_kernel_emu_layouts.py); the DPP controls follow rocPRIM's use (row_shr:n = from lane - n).
+#                            On the box: parity first (cp ... && pytest -m gpu), then gpu_ab_lib.sh typical dense, --rgba 1
 set -eu
 cd "$(dirname "$0")/../.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -I include -I mpeg_amd/csrc"
@@ -24,6 +31,7 @@ case "${1:-video}" in
   video) build nt_entries -DMPG_NT_ENTRIES ;;
   fused) build nt_rgba_fused -DMPG_NT_RGBA_FUSED; build nt_frame_fused -DMPG_NT_FRAME_FUSED; build nt_fused_both -DMPG_NT_RGBA_FUSED -DMPG_NT_FRAME_FUSED ;;
   layout) build chroma_pairs -DMPG_CHROMA_PAIRS=1 ;;
+  tile16) build tile16 -DMPG_TILE16=1; build tile16_chroma_pairs -DMPG_TILE16=1 -DMPG_CHROMA_PAIRS=1 ;;
   audio) build nt_audio_out -DMPG_NT_AUDIO_OUT; build nt_audio_in -DMPG_NT_AUDIO_IN ;;
-  *) echo "usage: $0 video|fused|layout|audio"; exit 2 ;;
+  *) echo "usage: $0 video|fused|layout|tile16|audio"; exit 2 ;;
 esac
