@@ -96,10 +96,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     static_assert(kRcChunksPerWave == 1 || kRcChunksPerWave == 2, "written out for one or two");
     const RcChunk c0 = rc_load_chunk(a, first);
     const RcChunk c1 = rc_load_chunk(a, kRcChunksPerWave == 2 && first + 1 < a.n_chunks ? first + 1 : first);
+#if MPG_TILE16 && !defined(MPG_LANE_ONCE)
+    const int lane_all = lane; // (each chunk works its lane constants out again: kept across the other chunk they cost 15 registers and, at 64, three spills)
+#else
     const RcLane k = rc_lane(a, lane);
+#endif
     bool ahead_pending = MPG_CHUNK_AHEAD != 0;
     auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
     (void)chunk; // (the instrumented build's stamps)
+#if MPG_TILE16 && !defined(MPG_LANE_ONCE)
+    const int lane = (int)opaque((uint32_t)lane_all);
+    const RcLane k = rc_lane(a, lane);
+#endif
     const uint32_t n_blocks = rc_n_blocks(c);
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)

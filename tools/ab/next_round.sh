@@ -19,8 +19,8 @@
 #            tile16          the wave's coefficient tile as int16 dequantised levels (premultiplied at the column read), the
 #                            8x8 transposition between the IDCT passes across lanes (DPP) instead of through LDS, snapshot
 #                            blocks read straight from HBM: 4 672 B of LDS and 64 vector registers = 8 waves per SIMD instead
-#                            of 7 (the build has 16 B of scratch per lane: three registers spilled around the loop over
-#                            passes 1, 2 — look at that first if it is slow).  Bit-exact in the lane emulator
+#                            of 7.  Each chunk works out its lane constants again (49 registers, no scratch; -DMPG_LANE_ONCE
+#                            keeps them across both chunks as the product does: 64 registers and three spills).  Bit-exact in the lane emulator
 #                            (tests/test_kernel_emu_layouts.py); the DPP controls follow rocPRIM's use (row_shr:n = from lane - n).
 #                            On the box: parity first (cp ... && pytest -m gpu), then gpu_ab_lib.sh typical dense, --rgba 1
 set -eu
