@@ -49,6 +49,7 @@ type hipVideo struct {
 
 	// current macroblock
 	active, intra, hasPred, backward bool
+	outOfRange                       bool // a copyMacroblock call of this macroblock would panic in the reference
 	mbX, mbY, mvX, mvY, qscale, cbp  int
 	blocks                           [6]blockRec
 
@@ -136,15 +137,30 @@ func (h *hipVideo) beginMacroblock(v *Video, intra bool) {
 		h.Stats.DuplicateSplits++
 	}
 	h.written[addr] = true
-	h.active, h.intra, h.hasPred, h.backward = true, intra, false, false
+	h.active, h.intra, h.hasPred, h.backward, h.outOfRange = true, intra, false, false, false
 	h.mbX, h.mbY, h.mvX, h.mvY, h.cbp = v.mbCol, v.mbRow, 0, 0, 0
 	h.qscale = v.quantizerScale
 }
 
 // predict stands where predictMacroblock calls copyMacroblock (video.go:626-635): a later call
 // overwrites an earlier one, which is exactly what the reference's second copy does to the first.
+// copyMacroblock's legal read range (video_noasm.go:48-50) is [plane start, end of base); outside it the
+// reference panics.  Here the WHOLE macroblock is dropped then (endMacroblock) — also when the call that would
+// panic is one that a later call overwrites (a B macroblock's forward copy): the same rule as
+// mpeg_amd/host/video.cpp and the oracle.
 func (h *hipVideo) predict(v *Video, mh, mv int, backward bool) {
 	h.hasPred, h.backward, h.mvX, h.mvY = true, backward, mh, mv
+	lw, cw := v.lumaWidth, v.chromaWidth
+	luma, chroma := v.lumaWidth*v.lumaHeight, v.chromaWidth*v.chromaHeight
+	total := luma + 2*chroma + lw*16
+	lsi := ((h.mbY<<4)+(mv>>1))*lw + (h.mbX << 4) + (mh >> 1)
+	llast := lsi + (15+(mv&1))*lw + 15 + (mh & 1)
+	cmh, cmv := mh/2, mv/2
+	csi := ((h.mbY<<3)+(cmv>>1))*cw + (h.mbX << 3) + (cmh >> 1)
+	clast := csi + (7+(cmv&1))*cw + 7 + (cmh & 1)
+	if lsi < 0 || llast >= total || csi < 0 || clast >= total-luma-chroma {
+		h.outOfRange = true
+	}
 }
 
 func dequantPremult(level int, intra bool, qscale int, q byte, idx int) int32 {
@@ -333,19 +349,9 @@ func (h *hipVideo) endMacroblock(v *Video) {
 	if !h.intra && !h.hasPred {
 		return // cannot happen: every non-intra macroblock is predicted (video.go:543-544)
 	}
-	if !h.intra { // copyMacroblock's legal read range (video_noasm.go:48-50): [plane start, end of base)
-		lw, cw := v.lumaWidth, v.chromaWidth
-		luma, chroma := v.lumaWidth*v.lumaHeight, v.chromaWidth*v.chromaHeight
-		total := luma + 2*chroma + lw*16
-		lsi := ((h.mbY<<4)+(h.mvY>>1))*lw + (h.mbX << 4) + (h.mvX >> 1)
-		llast := lsi + (15+(h.mvY&1))*lw + 15 + (h.mvX & 1)
-		cmh, cmv := h.mvX/2, h.mvY/2
-		csi := ((h.mbY<<3)+(cmv>>1))*cw + (h.mbX << 3) + (cmh >> 1)
-		clast := csi + (7+(cmv&1))*cw + 7 + (cmh & 1)
-		if lsi < 0 || llast >= total || csi < 0 || clast >= total-luma-chroma {
-			h.Stats.RangeSkips++ // the reference panics here
-			return
-		}
+	if !h.intra && h.outOfRange {
+		h.Stats.RangeSkips++ // the reference panics here
+		return
 	}
 	raw, cbp := false, 0
 	for b := 0; b < 6; b++ {

@@ -357,7 +357,7 @@ void Video::beginMacroblockRecord(bool intra)
     written_[addr] = 1;
     // (not `rec_ = MbRec()`: that clears 2.3 KB of block storage per macroblock; a block is reset by its own
     // decodeBlock, and endMacroblockRecord only looks at the blocks of this macroblock's pattern)
-    rec_.has_pred = rec_.backward = rec_.any_raw = false;
+    rec_.has_pred = rec_.backward = rec_.any_raw = rec_.out_of_range = false;
     rec_.mv_x = rec_.mv_y = 0;
     rec_.cbp = 0;
     rec_.active = true;
@@ -374,6 +374,19 @@ void Video::emitPrediction(int mh, int mv, bool backward)
     rec_.backward = backward;
     rec_.mv_x = mh;
     rec_.mv_y = mv;
+    // legal read range of copyMacroblock (video_noasm.go:48-50): [plane start, end of base).  Outside it the reference
+    // panics; here the whole macroblock is dropped (endMacroblockRecord) — also when the call that would panic is one a
+    // later call overwrites (a B macroblock's forward copy)
+    const int64_t lw = luma_width_, cw = chroma_width_;
+    const int64_t luma = (int64_t)luma_width_ * luma_height_, chroma = (int64_t)chroma_width_ * chroma_height_;
+    const int64_t total = luma + 2 * chroma + lw * 16;
+    const int64_t lsi = ((int64_t)(rec_.mb_y << 4) + (mv >> 1)) * lw + (rec_.mb_x << 4) + (mh >> 1);
+    const int64_t llast = lsi + (15 + (mv & 1)) * lw + 15 + (mh & 1);
+    const int cmh = mh / 2, cmv = mv / 2;
+    const int64_t csi = ((int64_t)(rec_.mb_y << 3) + (cmv >> 1)) * cw + (rec_.mb_x << 3) + (cmh >> 1);
+    const int64_t clast = csi + (7 + (cmv & 1)) * cw + 7 + (cmh & 1);
+    if (lsi < 0 || llast >= total || csi < 0 || clast >= total - luma - chroma)
+        rec_.out_of_range = true;
 }
 
 void Video::endMacroblockRecord()
@@ -384,21 +397,9 @@ void Video::endMacroblockRecord()
     if (!rec_.intra && !rec_.has_pred)
         return; // cannot happen: every non-intra macroblock is predicted (video.go:543-544)
 
-    // legal read range of copyMacroblock (video_noasm.go:48-50): [plane start, end of base)
-    if (!rec_.intra) {
-        const int64_t lw = luma_width_, cw = chroma_width_;
-        const int64_t luma = (int64_t)luma_width_ * luma_height_, chroma = (int64_t)chroma_width_ * chroma_height_;
-        const int64_t total = luma + 2 * chroma + lw * 16;
-        const int mh = rec_.mv_x, mv = rec_.mv_y;
-        const int64_t lsi = ((int64_t)(rec_.mb_y << 4) + (mv >> 1)) * lw + (rec_.mb_x << 4) + (mh >> 1);
-        const int64_t llast = lsi + (15 + (mv & 1)) * lw + 15 + (mh & 1);
-        const int cmh = mh / 2, cmv = mv / 2;
-        const int64_t csi = ((int64_t)(rec_.mb_y << 3) + (cmv >> 1)) * cw + (rec_.mb_x << 3) + (cmh >> 1);
-        const int64_t clast = csi + (7 + (cmv & 1)) * cw + 7 + (cmh & 1);
-        if (lsi < 0 || llast >= total || csi < 0 || clast >= total - luma - chroma) {
-            stats_.range_skips++; // the reference panics here; the macroblock is dropped instead
-            return;
-        }
+    if (!rec_.intra && rec_.out_of_range) {
+        stats_.range_skips++; // the reference panics here; the macroblock is dropped instead
+        return;
     }
 
     bool raw = false;

@@ -433,6 +433,18 @@ static void copy_block(const uint8_t *src, uint8_t *dst, int stride, int64_t si,
 
 static _Thread_local int g_last_overread;
 
+/* would this copyMacroblock call stay inside the reference's slices (1), or panic (0)? */
+static int copy_macroblock_in_range(int motion_h, int motion_v, int mb_row, int mb_col, const orc_frame *s)
+{
+    int lw = s->luma_w, cw = s->chroma_w;
+    int64_t lsi = ((int64_t)(mb_row << 4) + (motion_v >> 1)) * lw + (mb_col << 4) + (motion_h >> 1);
+    int cm_h = motion_h / 2, cm_v = motion_v / 2;
+    int64_t csi = ((int64_t)(mb_row << 3) + (cm_v >> 1)) * cw + (mb_col << 3) + (cm_h >> 1);
+    return block_in_range(s, s->y, s->luma_size, lw, lsi, 16, (motion_h & 1) == 1, (motion_v & 1) == 1, NULL) &&
+           block_in_range(s, s->cb, s->chroma_size, cw, csi, 8, (cm_h & 1) == 1, (cm_v & 1) == 1, NULL) &&
+           block_in_range(s, s->cr, s->chroma_size, cw, csi, 8, (cm_h & 1) == 1, (cm_v & 1) == 1, NULL);
+}
+
 int orc_copy_macroblock(int motion_h, int motion_v, int mb_row, int mb_col,
                         const orc_frame *s, orc_frame *d)
 { /* video_noasm.go:28-43 */
@@ -538,6 +550,7 @@ struct orc_video {
     orc_motion mf, mb;
     int has_seq;
     int qscale, slice_begin, mb_addr, mb_row, mb_col, mb_type, mb_intra;
+    int mb_dropped; /* a copyMacroblock call of this macroblock would panic in the reference: nothing of it is written */
     int64_t dc_pred[3];
     orc_frame cur, fwd, bwd;
     int64_t block[64];
@@ -606,6 +619,27 @@ static void predict_macroblock(orc_video *v)
     if (v->mf.full_px) {
         fw_h <<= 1;
         fw_v <<= 1;
+    }
+    /* Where the reference would panic (a source slice out of range, video_noasm.go:48-50) there is nothing to restate: this
+     * build defines that the WHOLE macroblock is dropped — none of its copies, none of its blocks reach the frame — and the
+     * parse goes on.  All copies the reference would make are checked before the first one is made. */
+    {
+        int bw_h = v->mb.h * (v->mb.full_px ? 2 : 1), bw_v = v->mb.v * (v->mb.full_px ? 2 : 1);
+        int ok = 1;
+        if (v->picture_type == PIC_B) {
+            if (v->mf.is_set)
+                ok = copy_macroblock_in_range(fw_h, fw_v, v->mb_row, v->mb_col, &v->fwd) &&
+                     (!v->mb.is_set || copy_macroblock_in_range(bw_h, bw_v, v->mb_row, v->mb_col, &v->bwd));
+            else
+                ok = copy_macroblock_in_range(bw_h, bw_v, v->mb_row, v->mb_col, &v->bwd);
+        } else {
+            ok = copy_macroblock_in_range(fw_h, fw_v, v->mb_row, v->mb_col, &v->fwd);
+        }
+        if (!ok) {
+            v->st.range_errors++;
+            v->mb_dropped = 1;
+            return;
+        }
     }
     if (v->picture_type == PIC_B) {
         int bw_h = v->mb.h, bw_v = v->mb.v;
@@ -749,6 +783,13 @@ static void decode_block(orc_video *v, int block)
     }
 
     v->st.coded_blocks++;
+    if (v->mb_dropped) { /* (see predict_macroblock) the block's bookkeeping goes on, the frame is not touched */
+        if (n == 1)
+            v->block[0] = 0;
+        else
+            memset(v->block, 0, sizeof(v->block));
+        return;
+    }
     if (n == 1) {
         v->st.dc_only_blocks++;
         int64_t value = (v->block[0] + 128) >> 8;
@@ -806,6 +847,7 @@ static void decode_macroblock(orc_video *v)
             v->mb_row = v->mb_addr / v->mb_w;
             v->mb_col = v->mb_addr % v->mb_w;
             v->st.skipped_mbs++;
+            v->mb_dropped = 0;
             predict_macroblock(v);
             increment--;
         }
@@ -819,6 +861,7 @@ static void decode_macroblock(orc_video *v)
     if (v->mb_addr < 0)
         return; /* Go would index a negative plane offset and panic; unreachable on the fixtures */
 
+    v->mb_dropped = 0;
     v->mb_type = vlc_read(b, &T_mbtype[v->picture_type]);
     v->mb_intra = (v->mb_type & 0x01) != 0;
     v->mf.is_set = (v->mb_type & 0x08) != 0;

@@ -1,0 +1,94 @@
+"""Mutated streams: the product's parser (mpeg_amd/host) against the oracle's decoder on streams with random bytes and bits
+changed — frame by frame / sample by sample, bit-exact.  The reference's golden stream pins a handful of damaged
+macroblocks; this walks the error paths at large (invalid blocks, stale blockData snapshots, macroblocks addressed twice,
+vectors out of range, broken headers, truncated frames).
+
+Where the reference would PANIC (a copyMacroblock source slice out of range, video_noasm.go:48-50) there is nothing to
+restate; product and oracle define the same thing: the whole macroblock is dropped (mpeg_amd/host/video.cpp:
+emitPrediction / endMacroblockRecord; oracle/mpeg_oracle.c: predict_macroblock)."""
+import numpy as np
+import pytest
+
+import hostlib
+
+
+def mutate(data: bytes, rng, first: int, last: int) -> bytes:
+    d = bytearray(data)
+    for _ in range(int(rng.integers(3, 40))):
+        p = int(rng.integers(first, last))
+        mode = int(rng.integers(0, 3))
+        if mode == 0:
+            d[p] ^= 1 << int(rng.integers(0, 8))
+        elif mode == 1:
+            d[p] = int(rng.integers(0, 256))
+        else:
+            d[p:p + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+    return bytes(d)
+
+
+def compare_video(oracle, data, frames):
+    ref, dut = oracle.VideoDecoder(data), hostlib.HostVideo(data, emu_flavour=0)
+    try:
+        for i in range(frames):
+            a, b = ref.decode(), dut.decode()
+            assert (a is None) == (b is None), "frame %d: one decoder has ended" % i
+            if a is None:
+                break
+            for pa, pb in zip(oracle.frame_planes(a), hostlib.frame_planes(b)):
+                assert np.array_equal(pa, pb), "frame %d" % i
+        return dut.stats()
+    finally:
+        ref.close()
+        dut.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mutated_damaged_stream(oracle, golden_dir, seed):
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    rng = np.random.default_rng(1000 + seed)
+    seen = {"range_skips": 0, "invalid_blocks": 0, "duplicate_splits": 0, "raw_macroblocks": 0}
+    for _ in range(8):
+        st = compare_video(oracle, mutate(data, rng, 200, 60000), 70)     # the first 70 frames live in the first ~60 kB
+        for k in seen:
+            seen[k] += st[k]
+    assert seen["invalid_blocks"] and seen["raw_macroblocks"] and seen["duplicate_splits"]
+
+
+def test_mutations_reach_the_out_of_range_vectors(oracle, golden_dir):
+    """the case the reference cannot answer (it panics): seeds known to produce vectors out of range"""
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    rng = np.random.default_rng(2)
+    skips = 0
+    for _ in range(30):
+        skips += compare_video(oracle, mutate(data, rng, 200, 60000), 70)["range_skips"]
+    assert skips > 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_mutated_clean_stream(oracle, golden_dir, seed):
+    es, _ = oracle.ps_extract((golden_dir / "test.mpg").read_bytes(), 0xE0)
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(8):
+        compare_video(oracle, mutate(es, rng, 200, 70000), 70)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_mutated_audio_stream(oracle, emu, golden_dir, seed):
+    data = (golden_dir / "test.mp2").read_bytes()
+    win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(12):
+        d = mutate(data, rng, 4, len(data) - 8)
+        ref, dut = oracle.AudioDecoder(d, 0), hostlib.HostAudio(d, fma=0, fmt=0, window=win)
+        try:
+            n = 0
+            while True:
+                a, b = ref.decode(), dut.decode()
+                assert (a is None) == (b is None), "frame %d: one decoder has ended" % n
+                if a is None:
+                    break
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "frame %d" % n
+                n += 1
+        finally:
+            ref.close()
+            dut.close()
