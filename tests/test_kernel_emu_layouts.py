@@ -95,3 +95,31 @@ def test_tile16_takes_an_oversized_intra_dc_as_a_dense_unit(oracle, emu):
             run_and_compare(oracle.OracleStore(w, h), emu.EmuStore(w, h), seq)
         finally:
             emu.select()
+
+
+@pytest.mark.parametrize("variant", [("", ()), LAYOUTS[1]], ids=["product", "tile16"])
+def test_levels_over_the_whole_int16_range(oracle, emu, variant):
+    """The ABI takes any int16 level, any quantiser_scale 1..31 and any matrix bytes — far beyond what MPEG-1 codes
+    (+-255): every third non-zero level of every block replaced by extremes, both kernels' arithmetic against the oracle."""
+    rng = np.random.default_rng(5)
+    emu.select(*variant)
+    try:
+        for trial in range(4):
+            w, h = 96, 64
+            seq = synth.generate_sequence(w, h, 3, seed=100 + trial, profile="typical" if trial % 2 else "dense")
+            for sub in seq:
+                units = sub.coefs.view(np.int16).reshape(-1, 64)
+                for u in range(len(units)):
+                    nz = np.nonzero(units[u])[0]
+                    if len(nz):
+                        pick = rng.choice(nz, size=max(1, len(nz) // 3), replace=False)
+                        units[u, pick] = rng.choice([32767, -32768, 2047, -2048, 256, -256, 1, -1, 12345, -23456], size=len(pick)).astype(np.int16)
+                sub.mbs["qscale"] = rng.choice([1, 31, 17], size=len(sub.mbs))
+            o, e = oracle.OracleStore(w, h), emu.EmuStore(w, h)
+            if trial >= 2:
+                iq, nq = rng.integers(1, 256, 64), rng.integers(1, 256, 64)
+                o.set_quant(0, iq, nq)
+                e.set_quant(0, iq, nq)
+            run_and_compare(o, e, seq)
+    finally:
+        emu.select()
