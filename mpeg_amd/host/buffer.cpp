@@ -94,7 +94,7 @@ size_t Buffer::tell()
 void Buffer::discardReadBytes()
 { // buffer.go:189-201
     size_t byte_pos = bit_index_ >> 3;
-    if (byte_pos == bytes_.size()) {
+    if (byte_pos >= bytes_.size()) { // (beyond the end only after a read past it, where the reference has panicked: buffer.go:246-255)
         bytes_.clear();
         bit_index_ = 0;
     } else if (byte_pos > 0) {

@@ -92,3 +92,47 @@ def test_mutated_audio_stream(oracle, emu, golden_dir, seed):
         finally:
             ref.close()
             dut.close()
+
+
+def test_mutated_program_streams_through_the_facade(emu, golden_dir):
+    """Robustness of the whole host stack (Demux, MPEG facade, both parsers) on damaged program streams: no crash, no
+    hang, sane counts.  (The second stream of this seed once corrupted the heap: a read past the end of the buffer — where
+    the reference panics, buffer.go:246-255 — left the bit index behind the end, and the next discardReadBytes erased a
+    negative range.  tools/tsan/fuzz_facade.cpp and fuzz_streams.cpp run hundreds of such streams under ASan + UBSan.)"""
+    data0 = (golden_dir / "test.mpg").read_bytes()
+    win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
+    rng = np.random.default_rng(1)
+    for it in range(12):
+        d = bytearray(data0)
+        for _ in range(int(rng.integers(3, 60))):
+            p = int(rng.integers(0, len(d) - 8))
+            mode = int(rng.integers(0, 4))
+            if mode == 0:
+                d[p] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                d[p] = int(rng.integers(0, 256))
+            elif mode == 2:
+                d[p:p + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+            else:
+                d[p:p + 4] = b"\x00\x00\x01" + bytes([int(rng.choice([0xBA, 0xBB, 0xE0, 0xC0, 0xB3, 0x00, 0xB9]))])
+        if rng.integers(0, 4) == 0:
+            d = d[:int(rng.integers(1000, len(d)))]
+        try:
+            m = hostlib.HostMpeg(bytes(d), window=win)
+        except RuntimeError:
+            continue                                  # (a stream the constructor refuses, as mpeg.New does: ErrInvalidMPEG)
+        nv = na = 0
+        while nv < 400 and m.decode_video() is not None:
+            nv += 1
+        while na < 400 and m.decode_audio() is not None:
+            na += 1
+        m.seek(float(rng.uniform(0, 9)), int(rng.integers(0, 2)))
+        for _ in range(10):
+            if m.decode_video() is None:
+                break
+        m.seek_frame(float(rng.uniform(0, 9)), 1)
+        assert 0 <= m.duration < 60
+        m.rewind()
+        m.decode(0.5)
+        m.close()
+        assert nv <= 400 and na <= 400

@@ -3,6 +3,8 @@
 # lane functions run under the sanitizers too).
 #   videobatch_threads: mpeg::VideoBatch's thread pool + staged replay on the damaged golden stream
 #   mpeg_facade:        Demux, MPEG (Decode with callbacks, Seek, SeekFrame, Rewind), Video and Audio on test.mpg
+#   fuzz_facade:        mutated program streams through the same stack (address,undefined only)
+#   fuzz_streams:       mutated elementary streams, mutations aimed at the headers (address,undefined only)
 # usage: tools/tsan/run.sh [thread|address,undefined]      (default: both; the emulator translation unit takes minutes
 # to compile under a sanitizer — this is a tool, not part of the test suite)
 set -e
@@ -14,4 +16,12 @@ for SAN in ${1:-thread address,undefined}; do
     echo "== $SAN / $H"
     if [ $H = videobatch_threads ]; then /tmp/san_$H tests/golden/test.mpeg1video; else /tmp/san_$H tests/golden/test.mpg; fi
   done
+  if [ $SAN = address,undefined ]; then
+    for H in fuzz_facade fuzz_streams; do
+      g++ -O1 -g1 -fno-var-tracking-assignments -fsanitize=$SAN -std=c++17 -pthread -w -DMPG_EMU=1 -Iinclude -Impeg_amd/host -Impeg_amd/csrc tools/tsan/$H.cpp $SRC -o /tmp/san_$H
+    done
+    echo "== $SAN / fuzz_facade";  ASAN_OPTIONS=detect_leaks=0 /tmp/san_fuzz_facade tests/golden/test.mpg 0 ${FUZZ_SEEDS:-200} | grep -v "^seed\|^  " || true
+    echo "== $SAN / fuzz_streams"; ASAN_OPTIONS=detect_leaks=0 /tmp/san_fuzz_streams video tests/golden/test.mpeg1video 0 ${FUZZ_SEEDS:-200} | grep -v "^seed\|^  " || true
+    ASAN_OPTIONS=detect_leaks=0 /tmp/san_fuzz_streams audio tests/golden/test.mp2 0 ${FUZZ_SEEDS:-200} | grep -v "^seed\|^  " || true
+  fi
 done
