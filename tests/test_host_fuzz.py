@@ -136,3 +136,29 @@ def test_mutated_program_streams_through_the_facade(emu, golden_dir):
         m.decode(0.5)
         m.close()
         assert nv <= 400 and na <= 400
+
+
+def test_mutated_streams_through_the_batch(oracle, golden_dir):
+    """mpeg::VideoBatch (4 parse threads, staged hand-over, one device call per tick) on six differently damaged streams:
+    every stream's every frame equals the oracle's decode of that stream."""
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    rng = np.random.default_rng(1)
+    for _ in range(2):
+        streams = [mutate(data, rng, 200, 60000) for _ in range(6)]
+        batch = hostlib.HostBatch(len(streams), threads=4)
+        refs = [oracle.VideoDecoder(s) for s in streams]
+        try:
+            for s in streams:
+                batch.add_stream(s)
+            for tick in range(50):
+                batch.decode_all(True)
+                for i, ref in enumerate(refs):
+                    a, f = ref.decode(), batch.frame(i)
+                    assert (a is None) == (f is None), "tick %d stream %d" % (tick, i)
+                    if a is not None:
+                        for pa, pb in zip(oracle.frame_planes(a), hostlib.frame_planes(f)):
+                            assert np.array_equal(pa, pb), "tick %d stream %d" % (tick, i)
+        finally:
+            for r in refs:
+                r.close()
+            batch.close()
