@@ -162,3 +162,39 @@ def test_mutated_streams_through_the_batch(oracle, golden_dir):
             for r in refs:
                 r.close()
             batch.close()
+
+
+def test_mutated_program_streams_demux(oracle, golden_dir):
+    """mpeg::Demux against the oracle's packet extractor (the subset of demux.go:473-584 it restates) on damaged program
+    streams: the same video and audio payload bytes, packet for packet."""
+    data0 = (golden_dir / "test.mpg").read_bytes()
+    rng = np.random.default_rng(7)
+    for it in range(25):
+        d = bytearray(data0)
+        for _ in range(int(rng.integers(1, 30))):
+            p = int(rng.integers(0, len(d) - 8))
+            mode = int(rng.integers(0, 4))
+            if mode == 0:
+                d[p] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                d[p] = int(rng.integers(0, 256))
+            elif mode == 2:
+                d[p:p + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+            else:
+                d[p:p + 4] = b"\x00\x00\x01" + bytes([int(rng.choice([0xBA, 0xBB, 0xE0, 0xC0, 0xB3, 0x00, 0xB9]))])
+        d = bytes(d)
+        try:
+            dm = hostlib.HostDemux(d)
+        except RuntimeError:
+            continue
+        got = {hostlib.PACKET_VIDEO_1: [], hostlib.PACKET_AUDIO_1: []}
+        for _ in range(5000):
+            pk = dm.decode()
+            if pk is None:
+                break
+            if pk[0] in got:
+                got[pk[0]].append(pk[2])
+        dm.close()
+        for typ, parts in got.items():
+            want, n_packets = oracle.ps_extract(d, typ)
+            assert b"".join(parts) == want and len(parts) == n_packets, "stream %d, packets of type %#x" % (it, typ)
