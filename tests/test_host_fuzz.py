@@ -198,3 +198,31 @@ def test_mutated_program_streams_demux(oracle, golden_dir):
         for typ, parts in got.items():
             want, n_packets = oracle.ps_extract(d, typ)
             assert b"".join(parts) == want and len(parts) == n_packets, "stream %d, packets of type %#x" % (it, typ)
+
+
+def test_mutated_audio_streams_through_the_batch(oracle, emu, golden_dir):
+    """mpeg::AudioBatch (one synthesis call per tick for all streams) on five differently damaged MP2 streams: every
+    stream's every sample block equals the oracle's decode of that stream, bit for bit."""
+    data = (golden_dir / "test.mp2").read_bytes()
+    win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
+    rng = np.random.default_rng(11)
+    streams = [mutate(data, rng, 4, len(data) - 8) for _ in range(5)]
+    batch = hostlib.HostAudioBatch(len(streams), fmt=0, window=win)
+    refs = [oracle.AudioDecoder(s, 0) for s in streams]
+    try:
+        for s in streams:
+            batch.add_stream(s)
+        for tick in range(400):
+            produced = batch.decode_all()
+            for i, ref in enumerate(refs):
+                a, s = ref.decode(), batch.samples(i)
+                assert (a is None) == (s is None), "tick %d stream %d" % (tick, i)
+                if a is not None:
+                    assert np.array_equal(a.view(np.uint32), s.view(np.uint32)), "tick %d stream %d" % (tick, i)
+            if produced == 0:
+                break
+        assert tick > 300
+    finally:
+        for r in refs:
+            r.close()
+        batch.close()
