@@ -202,7 +202,11 @@ typedef struct mpeghip_mb_desc {
  *     order" is kept by stream order),
  *   - a picture predicts from the slot it writes (cur == the named reference),
  *   - two pictures of the same stream write the same slot, or one reads a
- *     slot another one of the same submit writes.
+ *     slot another one of the same submit writes,
+ *   - its coded blocks name more coefficient units (counted with repetition)
+ *     than `coefs` holds: blocks may share units only as far as there are as
+ *     many units as blocks name (the packed form's buffers are sized from
+ *     coef_bytes).
  * Returns MPEGHIP_ERR_RANGE (nothing is launched) if any prediction would
  * read outside [plane start, end of pad) — the reference panics there. */
 int mpeghip_video_submit(mpeghip_video *v,

@@ -897,7 +897,7 @@ static int validate_pic(const mpeghip_video_info &in, const mpeghip_pic_desc &pd
 // One macroblock of picture `pd`: field ranges, coefficient extent inside [0, coef_units), prediction
 // reads inside the frame buffer.  Adds its algorithmic bytes to *alg.
 static int validate_mb(const mpeghip_video_info &in, const mpeghip_pic_desc &pd, const mpeghip_mb_desc &m, uint32_t i,
-                       uint64_t coef_units, uint64_t *alg)
+                       uint64_t coef_units, uint64_t *alg, uint64_t *named_units)
 {
     if (m.mb_x >= in.mb_w || m.mb_y >= in.mb_h)
         return fail(MPEGHIP_ERR_INVALID, "macroblock %u: position (%u,%u) outside %ux%u", i, m.mb_x, m.mb_y, in.mb_w,
@@ -913,6 +913,7 @@ static int validate_mb(const mpeghip_video_info &in, const mpeghip_pic_desc &pd,
     const uint64_t units = (uint64_t)nb * (raw ? 2 : 1);
     if (nb && (uint64_t)m.coef_off + units > coef_units)
         return fail(MPEGHIP_ERR_INVALID, "macroblock %u: coefficient blocks beyond the buffer", i);
+    *named_units += units;
     if (!raw && nb && (m.qscale == 0 || m.qscale > 31))
         return fail(MPEGHIP_ERR_INVALID, "macroblock %u: quantiser_scale %u", i, m.qscale);
     uint64_t ref_bytes = 0;
@@ -947,17 +948,24 @@ static int validate_mb(const mpeghip_video_info &in, const mpeghip_pic_desc &pd,
 // All macroblocks of ONE picture.  Macroblocks of one submit run concurrently, so a position may be named once
 // only (the reference lets a damaged stream address a macroblock twice, video.go:462-486: the emitter starts a
 // new submit there); `seen` is scratch of at least mb_w * mb_h bits.
+// *named_units: the coefficient units the blocks validated so far name, counted with repetition.  The device-format
+// buffers are sized from the coefficient buffer (rc_max_words), so blocks may share units only as far as the buffer has
+// as many units as blocks name: beyond that the submit is refused instead of overrunning them.
 static int validate_picture(const mpeghip_video_info &in, const mpeghip_pic_desc &pd, uint32_t p, const mpeghip_mb_desc *mbs,
                             uint32_t n, uint32_t first_index, uint64_t coef_units, uint64_t *alg, PicUse *use,
-                            std::vector<uint64_t> &seen)
+                            std::vector<uint64_t> &seen, uint64_t *named_units)
 {
     seen.assign(((size_t)in.mb_w * in.mb_h + 63) / 64, 0);
     PicUse u;
     for (uint32_t k = 0; k < n; k++) {
         const mpeghip_mb_desc &m = mbs[k];
-        const int rc = validate_mb(in, pd, m, first_index + k, coef_units, alg);
+        const int rc = validate_mb(in, pd, m, first_index + k, coef_units, alg, named_units);
         if (rc != MPEGHIP_OK)
             return rc;
+        if (*named_units > coef_units)
+            return fail(MPEGHIP_ERR_INVALID, "macroblock %u: the coded blocks up to here name %llu coefficient units, the buffer "
+                        "holds %llu (blocks may not share units beyond that)", first_index + k, (unsigned long long)*named_units,
+                        (unsigned long long)coef_units);
         const uint32_t at = (uint32_t)m.mb_y * in.mb_w + m.mb_x;
         if (seen[at >> 6] & (1ull << (at & 63)))
             return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock (%u,%u) is addressed twice in one submit", p, m.mb_x, m.mb_y);
@@ -1052,14 +1060,15 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
     const uint64_t coef_units = coef_bytes / MPEGHIP_COEF_UNIT;
     std::vector<PicUse> use(n_pics);
     std::vector<uint64_t> seen;
-    uint64_t alg = 0, words = 0, chunk = 0;
+    uint64_t alg = 0, words = 0, chunk = 0, named_units = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
         const mpeghip_mb_desc *pm = mbs + pics[p].mb_first;
         for (uint32_t k = 0; k < pics[p].mb_count; k++)
             if (pm[k].pic != p)
                 return fail(MPEGHIP_ERR_INVALID, "macroblock %u: names picture %u but lies in picture %u's range",
                             pics[p].mb_first + k, pm[k].pic, p);
-        const int rc = validate_picture(in, pics[p], p, pm, pics[p].mb_count, pics[p].mb_first, coef_units, &alg, &use[p], seen);
+        const int rc = validate_picture(in, pics[p], p, pm, pics[p].mb_count, pics[p].mb_first, coef_units, &alg, &use[p], seen,
+                                        &named_units);
         if (rc != MPEGHIP_OK)
             return rc;
         if (chunks_out) {
@@ -1399,7 +1408,8 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         reinterpret_cast<mpeghip_pic_desc *>(h)[i] = pd;
         uint64_t alg = 0;
         static thread_local std::vector<uint64_t> seen;
-        if ((rc = validate_picture(v->info, pd, i, mbs, n, 0, s->units[i], &alg, &s->use[i], seen)) != MPEGHIP_OK)
+        uint64_t named_units = 0;
+        if ((rc = validate_picture(v->info, pd, i, mbs, n, 0, s->units[i], &alg, &s->use[i], seen, &named_units)) != MPEGHIP_OK)
             break;
         // the picture in the device format: its chunks go where they belong; its words are packed in this thread's
         // scratch memory first, because the room they need is only known afterwards

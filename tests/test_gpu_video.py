@@ -149,6 +149,13 @@ def test_malformed_descriptors_are_refused_and_nothing_is_launched(oracle, hip_c
         corrupt("stream", 1, "pics"), corrupt("cur", 3, "pics"), corrupt("fwd", 7, "pics"), corrupt("bwd", 200, "pics"),
         corrupt("mb_count", len(good.mbs) + 1, "pics"), corrupt("mb_first", 5, "pics"),
     ]
+    # every macroblock names the first units of a buffer that holds only as many as the largest macroblock needs: the packed
+    # form's buffers are sized from the coefficient buffer, blocks may not share units beyond it
+    pics, mbs, coefs = good.pics.copy(), good.mbs.copy(), good.coefs.copy()
+    per_mb = np.array([bin(int(c)).count("1") for c in mbs["cbp"]]) * np.where(mbs["flags"] & desc.MB_COEF_RAW, 2, 1)
+    assert (per_mb > 0).sum() >= 2
+    mbs["coef_off"] = 0
+    cases.append((pics, mbs, coefs[:int(per_mb.max()) * desc.COEF_UNIT]))
     for pics, mbs, coefs in cases:
         with pytest.raises(abi.MpegHipError) as ei:
             dut.submit(pics, mbs, coefs)
