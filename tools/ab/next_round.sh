@@ -23,6 +23,8 @@
 #                            keeps them across both chunks as the product does: 64 registers and three spills).  Bit-exact in the lane emulator
 #                            (tests/test_kernel_emu_layouts.py); the DPP controls follow rocPRIM's use (row_shr:n = from lane - n).
 #                            On the box: parity first (cp ... && pytest -m gpu), then gpu_ab_lib.sh typical dense, --rgba 1
+# Everything at once: `bash tools/ab/next_round.sh all` here, then ONE call on the box: `bash tools/ab/next_round_gpu.sh r5`
+# (parity of every variant first, then the interleaved A/Bs; ~6 minutes).
 set -eu
 cd "$(dirname "$0")/../.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -I include -I mpeg_amd/csrc"
@@ -33,5 +35,6 @@ case "${1:-video}" in
   layout) build chroma_pairs -DMPG_CHROMA_PAIRS=1 ;;
   tile16) build tile16 -DMPG_TILE16=1; build tile16_chroma_pairs -DMPG_TILE16=1 -DMPG_CHROMA_PAIRS=1 ;;
   audio) build nt_audio_out -DMPG_NT_AUDIO_OUT; build nt_audio_in -DMPG_NT_AUDIO_IN ;;
-  *) echo "usage: $0 video|fused|layout|tile16|audio"; exit 2 ;;
+  all) "$0" video; "$0" fused; "$0" layout; "$0" tile16 ;;   # (audio apart: tools/ab/audio_ab.sh runs every library it finds on the audio leg)
+  *) echo "usage: $0 video|fused|layout|tile16|audio|all"; exit 2 ;;
 esac
