@@ -584,9 +584,55 @@ MPG_HD void rc_raw_cols(const VideoArgs &a, const RcChunk &c, uint32_t bw, int l
 #if MPG_ON_DEVICE
 template <int kCtrl> MPG_HD int32_t dpp_quad(int32_t x) { return __builtin_amdgcn_mov_dpp(x, kCtrl, 0xf, 0xf, true); }
 #endif
+#if MPG_ON_DEVICE && defined(MPG_TRANSPOSE_ASM)
+// One exchange step inside quads, written out: 8 selects that take their other operand through DPP (v_cndmask_b32_dpp: D =
+// VCC ? src1 : dpp(src0)) instead of the 8 DPP moves + 8 selects the compiler makes of the same thing.  a[i] / b[i]: the four
+// register pairs of this step (bit clear / set), `set_lanes`: the lanes whose bit is set.
+#define MPG_QUAD_STEP(PERM)                                                                                                          \
+    asm volatile("s_nop 1\n\t"                                                                                                       \
+                 "s_mov_b64 vcc, %[set]\n\t"                                                                                         \
+                 "v_cndmask_b32_dpp %[nb0], %[a0], %[b0], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_cndmask_b32_dpp %[nb1], %[a1], %[b1], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_cndmask_b32_dpp %[nb2], %[a2], %[b2], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_cndmask_b32_dpp %[nb3], %[a3], %[b3], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "s_not_b64 vcc, vcc\n\t"                                                                                            \
+                 "v_cndmask_b32_dpp %[na0], %[b0], %[a0], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_cndmask_b32_dpp %[na1], %[b1], %[a1], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_cndmask_b32_dpp %[na2], %[b2], %[a2], vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                                \
+                 "v_cndmask_b32_dpp %[na3], %[b3], %[a3], vcc " PERM " row_mask:0xf bank_mask:0xf"                                     \
+                 : [na0] "=&v"(na[0]), [na1] "=&v"(na[1]), [na2] "=&v"(na[2]), [na3] "=&v"(na[3]), [nb0] "=&v"(nb[0]),                \
+                   [nb1] "=&v"(nb[1]), [nb2] "=&v"(nb[2]), [nb3] "=&v"(nb[3])                                                         \
+                 : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]),    \
+                   [b3] "v"(b[3]), [set] "s"(set_lanes)                                                                               \
+                 : "vcc", "scc")
+#endif
 MPG_HD void rc_transpose8(int32_t (&v)[8], int lane)
 {
-#if MPG_ON_DEVICE
+#if MPG_ON_DEVICE && defined(MPG_TRANSPOSE_ASM)
+    (void)lane;
+    {   // lane bit 0 <-> register bit 0: pairs (0,1) (2,3) (4,5) (6,7); partner = lane ^ 1
+        const int32_t a[4] = {v[0], v[2], v[4], v[6]}, b[4] = {v[1], v[3], v[5], v[7]};
+        int32_t na[4], nb[4];
+        const uint64_t set_lanes = 0xAAAAAAAAAAAAAAAAull;
+        MPG_QUAD_STEP("quad_perm:[1,0,3,2]");
+        v[0] = na[0], v[2] = na[1], v[4] = na[2], v[6] = na[3];
+        v[1] = nb[0], v[3] = nb[1], v[5] = nb[2], v[7] = nb[3];
+    }
+    {   // bit 1: pairs (0,2) (1,3) (4,6) (5,7); partner = lane ^ 2
+        const int32_t a[4] = {v[0], v[1], v[4], v[5]}, b[4] = {v[2], v[3], v[6], v[7]};
+        int32_t na[4], nb[4];
+        const uint64_t set_lanes = 0xCCCCCCCCCCCCCCCCull;
+        MPG_QUAD_STEP("quad_perm:[2,3,0,1]");
+        v[0] = na[0], v[1] = na[1], v[4] = na[2], v[5] = na[3];
+        v[2] = nb[0], v[3] = nb[1], v[6] = nb[2], v[7] = nb[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { // bit 2: lanes 0..3 of a block take from lane + 4 (banks 0, 2), lanes 4..7 from lane - 4
+        const int32_t a = v[r], b = v[r + 4];
+        v[r + 4] = __builtin_amdgcn_update_dpp(b, a, 0x104, 0xf, 0x5, false);
+        v[r] = __builtin_amdgcn_update_dpp(a, b, 0x114, 0xf, 0xa, false);
+    }
+#elif MPG_ON_DEVICE
     constexpr int kSwap1 = 0xB1, kSwap2 = 0x4E; // quad_perm [1,0,3,2] and [2,3,0,1]
     constexpr int kRowShl4 = 0x104, kRowShr4 = 0x114;
     const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;

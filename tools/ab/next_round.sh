@@ -22,6 +22,8 @@
 #                            of 7.  Each chunk works out its lane constants again (49 registers, no scratch; -DMPG_LANE_ONCE
 #                            keeps them across both chunks as the product does: 64 registers and three spills).  Bit-exact in the lane emulator
 #                            (tests/test_kernel_emu_layouts.py); the DPP controls follow rocPRIM's use (row_shr:n = from lane - n).
+#                            tile16_asm: the two in-quad exchange steps as 8 v_cndmask_b32_dpp each (inline asm) instead of
+#                            the compiler's 8 DPP moves + 8 selects (28 instead of 44 vector instructions per transposition).
 #                            On the box: parity first (cp ... && pytest -m gpu), then gpu_ab_lib.sh typical dense, --rgba 1
 # Everything at once: `bash tools/ab/next_round.sh all` here, then ONE call on the box: `bash tools/ab/next_round_gpu.sh r5`
 # (parity of every variant first, then the interleaved A/Bs; ~6 minutes).
@@ -33,7 +35,7 @@ case "${1:-video}" in
   video) build nt_entries -DMPG_NT_ENTRIES ;;
   fused) build nt_rgba_fused -DMPG_NT_RGBA_FUSED; build nt_frame_fused -DMPG_NT_FRAME_FUSED; build nt_fused_both -DMPG_NT_RGBA_FUSED -DMPG_NT_FRAME_FUSED ;;
   layout) build chroma_pairs -DMPG_CHROMA_PAIRS=1 ;;
-  tile16) build tile16 -DMPG_TILE16=1; build tile16_chroma_pairs -DMPG_TILE16=1 -DMPG_CHROMA_PAIRS=1 ;;
+  tile16) build tile16 -DMPG_TILE16=1; build tile16_asm -DMPG_TILE16=1 -DMPG_TRANSPOSE_ASM; build tile16_chroma_pairs -DMPG_TILE16=1 -DMPG_CHROMA_PAIRS=1 ;;
   audio) build nt_audio_out -DMPG_NT_AUDIO_OUT; build nt_audio_in -DMPG_NT_AUDIO_IN ;;
   all) "$0" video; "$0" fused; "$0" layout; "$0" tile16 ;;   # (audio apart: tools/ab/audio_ab.sh runs every library it finds on the audio leg)
   *) echo "usage: $0 video|fused|layout|tile16|audio|all"; exit 2 ;;
