@@ -22,3 +22,20 @@ def test_every_cited_profile_exists():
             if m.group(1) not in tags:
                 missing.append((doc, m.group(1) + "_*"))
     assert not missing, missing
+
+
+def test_every_entry_point_the_documents_and_the_go_binding_name_is_declared():
+    """mpeghip_* / mpeghost_* names in the documents, the Go sources and the patch notes exist in include/*.h (names that
+    end in an underscore are families; one is a stated future entry point)."""
+    declared = set()
+    for h in ("mpeghip.h", "mpeghost.h"):
+        declared |= set(re.findall(r"\b(mpegh(?:ip|ost)_[a-z0-9_]+)\b", (ROOT / "include" / h).read_text()))
+    future = {"mpeghip_video_stage_put_sparse"}
+    named = {}
+    files = [ROOT / d for d in DOCS] + sorted((ROOT / "go").rglob("*.go")) + sorted((ROOT / "go").rglob("*.md"))
+    for f in files:
+        for sym in re.findall(r"\b(mpegh(?:ip|ost)_[a-z0-9_]+)\b", f.read_text()):
+            named.setdefault(sym, f.name)
+    unknown = {s: f for s, f in named.items()
+               if s not in declared and s not in future and not s.endswith("_") and not any(d.startswith(s + "_") for d in declared)}
+    assert not unknown, unknown
