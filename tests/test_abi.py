@@ -87,3 +87,42 @@ def test_no_kernel_uses_scratch():
     assert len(names) == len(scratch) and len(names) >= 8
     bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
     assert not bad, bad
+
+
+def test_go_descriptor_structs_have_the_header_layout():
+    """go/mpeghip hands []PicDesc / []MbDesc to C as they are: the Go structs (laid out by Go's rules: natural alignment,
+    declaration order) must have the fields of mpeghip_pic_desc / mpeghip_mb_desc at the same offsets.  (The Go package
+    cannot be compiled in this image; this reads its source.)"""
+    from mpeg_amd import desc
+    src = (ROOT / "go" / "mpeghip" / "mpeghip.go").read_text()
+    size = {"uint8": 1, "int8": 1, "uint16": 2, "int16": 2, "uint32": 4, "int32": 4, "uint64": 8, "int64": 8}
+
+    def go_layout(name):
+        body = re.search(r"type %s struct \{(.*?)\n\}" % name, src, re.S).group(1)
+        off, out, align_max = 0, {}, 1
+        for line in body.splitlines():
+            line = line.split("//")[0].strip()
+            if not line:
+                continue
+            names, typ = line.rsplit(None, 1)
+            count = 1
+            m = re.match(r"\[(\d+)\](\w+)", typ)
+            if m:
+                count, typ = int(m.group(1)), m.group(2)
+            for n in [x.strip() for x in names.split(",")]:
+                a = size[typ]
+                align_max = max(align_max, a)
+                off = (off + a - 1) // a * a
+                out[n] = off
+                off += a * count
+        return out, (off + align_max - 1) // align_max * align_max
+
+    snake = lambda n: re.sub(r"(?<!^)(?=[A-Z])", "_", n).lower()
+    for go_name, dtype in (("PicDesc", desc.PIC_DTYPE), ("MbDesc", desc.MB_DTYPE)):
+        fields, total = go_layout(go_name)
+        assert total == dtype.itemsize, go_name
+        named = {snake(k): v for k, v in fields.items() if k != "_"}
+        assert named, go_name
+        for k, off in named.items():
+            assert k in dtype.fields and dtype.fields[k][1] == off, (go_name, k, off)
+        assert set(named) == {k for k in dtype.fields if not k.startswith("reserved")}, go_name
