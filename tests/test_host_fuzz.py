@@ -226,3 +226,19 @@ def test_mutated_audio_streams_through_the_batch(oracle, emu, golden_dir):
         for r in refs:
             r.close()
         batch.close()
+
+
+def test_mutated_written_streams_of_random_sizes(oracle):
+    """Streams of random picture sizes (written from synthetic descriptors, tests/mpeg1_writer.py), clean and damaged:
+    larger and odd-sized pictures, typical and dense content, through the product's parser against the oracle's."""
+    import mpeg1_writer
+    from mpeg_amd import synth
+    rng = np.random.default_rng(2)
+    for _ in range(8):
+        w, h = int(rng.integers(16, 260)), int(rng.integers(16, 200))
+        seq = synth.generate_sequence(w, h, int(rng.integers(3, 8)), seed=int(rng.integers(1, 1 << 30)),
+                                      profile=str(rng.choice(["typical", "dense"])))
+        es = mpeg1_writer.write_sequence(w, h, seq)
+        compare_video(oracle, es, 20)
+        for _ in range(2):
+            compare_video(oracle, mutate(es, rng, 12, len(es) - 8), 20)
