@@ -714,6 +714,19 @@ MPG_HD uint32_t pick_class_bytes(uint32_t lo, uint32_t hi, bool odd)
     return ((lo >> s) & 0xff) | (((lo >> (16 + s)) & 0xff) << 8) | (((hi >> s) & 0xff) << 16) | (((hi >> (16 + s)) & 0xff) << 24);
 #endif
 }
+#ifdef MPG_DENSE_MED3 // (next round's experiment on the dense path: "if even, one toward zero" without a compare + borrow)
+MPG_HD int32_t med3_with_zero(int32_t a, int32_t b) // the median of (a, b, 0)
+{
+#if MPG_ON_DEVICE
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    const int32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    return 0 < lo ? lo : (0 > hi ? hi : 0);
+#endif
+}
+#endif
 template <int R> MPG_HD int32_t rc_dense_level(const i32x4_a4 &lv, bool intra, int32_t qs, const uint32_t (&qm)[2], const uint32_t (&pm)[2])
 {
     const int32_t w = lv.v[R >> 1];
@@ -723,7 +736,11 @@ template <int R> MPG_HD int32_t rc_dense_level(const i32x4_a4 &lv, bool intra, i
     if (!intra)
         l += (level >> 31) | 1;
     l = mul24_as_written(l, mul_u8<R & 3>(qm[R >> 2], qs)) >> 4;
+#ifdef MPG_DENSE_MED3
+    l = med3_with_zero(l - 1, l) | 1; // l > 0: the median of (l - 1, l, 0) is l - 1; l <= 0: it is l
+#else
     l = (l - (l > 0 ? 1 : 0)) | 1;
+#endif
     l = clampi(l, -2048, 2047);
     l = mul_u8<R & 3>(pm[R >> 2], l);
     return level ? l : 0;

@@ -11,7 +11,8 @@ from parity import run_and_compare
 
 LAYOUTS = [("chroma_pairs", ("-DMPG_CHROMA_PAIRS=1",)),
            ("tile16", ("-DMPG_TILE16=1",)),                      # int16 coefficient tile, transposition across lanes
-           ("tile16_chroma_pairs", ("-DMPG_TILE16=1", "-DMPG_CHROMA_PAIRS=1"))]
+           ("tile16_chroma_pairs", ("-DMPG_TILE16=1", "-DMPG_CHROMA_PAIRS=1")),
+           ("dense_med3", ("-DMPG_DENSE_MED3",))]                 # dense units: the oddification by a median
 
 
 @pytest.fixture(params=LAYOUTS, ids=[t for t, _ in LAYOUTS])

@@ -6,6 +6,7 @@
 #   PROFILES="typical dense" bash tools/gpu_ab_lib.sh r5b 4 --rgba 1        # nt_rgba_fused, nt_frame_fused, nt_fused_both
 #   bash tools/ab/audio_ab.sh                                               # nt_audio_out, nt_audio_in (3 rounds)
 # Variants:  nt_entries      coefficient entries and block words loaded with `nt` (read once)
+#            dense_med3      dense units: "(l - (l > 0)) | 1" as v_med3_i32(l - 1, l, 0) | 1 (one 4-clock instruction instead of two)
 #            nt_rgba_fused   the fused instance's RGBA stores non-temporal
 #            nt_frame_fused  the fused instance's frame stores non-temporal (the plain instance's already are)
 #            nt_fused_both   both
@@ -32,7 +33,7 @@ cd "$(dirname "$0")/../.."
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -I include -I mpeg_amd/csrc"
 build() { name=$1; shift; /opt/rocm/bin/hipcc $FLAGS "$@" mpeg_amd/csrc/mpeghip.hip -o tools/ab/libmpeghip_$name.so && echo built $name; }
 case "${1:-video}" in
-  video) build nt_entries -DMPG_NT_ENTRIES ;;
+  video) build nt_entries -DMPG_NT_ENTRIES; build dense_med3 -DMPG_DENSE_MED3 ;;
   fused) build nt_rgba_fused -DMPG_NT_RGBA_FUSED; build nt_frame_fused -DMPG_NT_FRAME_FUSED; build nt_fused_both -DMPG_NT_RGBA_FUSED -DMPG_NT_FRAME_FUSED ;;
   layout) build chroma_pairs -DMPG_CHROMA_PAIRS=1 ;;
   tile16) build tile16 -DMPG_TILE16=1; build tile16_asm -DMPG_TILE16=1 -DMPG_TRANSPOSE_ASM; build tile16_chroma_pairs -DMPG_TILE16=1 -DMPG_CHROMA_PAIRS=1 ;;
