@@ -36,8 +36,9 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MB_PER_1080P30_STREAM = 8160 * 30
-KERNEL = {False: "recon_kernel<1, false> (a wave reconstructs two chunks of 4 macroblocks; sparse coefficient entries, prediction windows by direct-to-LDS loads)",
-          True: "recon_kernel<1, true> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
+KERNEL = {False: "recon_kernel<1, false, T> (a wave reconstructs two chunks of 4 macroblocks; sparse coefficient entries, prediction windows by "
+                 "direct-to-LDS loads; T: int16 tile / 8 waves per SIMD for typical batches, int32 tile / 7 for batches of dense units)",
+          True: "recon_kernel<1, true, false> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
 def parse_args():
@@ -55,13 +56,18 @@ def parse_args():
     ap.add_argument("--legs", default="dense,rgba_fused,dense_rgba_fused",
                     help="secondary video legs (comma separated; N=1 only): dense, rgba_fused, dense_rgba_fused; '' = none")
     ap.add_argument("--rgba-streams", type=int, default=-1, help="streams of the fused-RGBA legs (-1 = --streams; 0 = skip them)")
-    ap.add_argument("--host-fed-seconds", type=float, default=0.0,
-                    help="optional host-fed leg: pictures pushed through the staged submit from host threads for this many "
-                         "seconds (N=1 only; off by default: it launches the reconstruction kernel on small batches, "
-                         "which would blur a kernel trace of the run)")
+    ap.add_argument("--host-fed-seconds", type=float, default=2.0,
+                    help="host-fed leg: pictures pushed through the staged submit from host threads for this many seconds "
+                         "(N=1 only; PCIe inclusive, not `value`; 0 = skip, e.g. under a kernel trace: it launches the "
+                         "reconstruction kernel on small batches)")
+    ap.add_argument("--single-stream", type=int, default=1, help="1: the one-stream fused-RGBA leg of BASELINE config 3 (N=1 only)")
+    ap.add_argument("--audio-tile", type=int, default=8,
+                    help="second audio point: --audio-streams x this many streams (working set beyond the Infinity Cache; 1 = skip)")
     ap.add_argument("--audio-streams", type=int, default=256)
     ap.add_argument("--audio-frames", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--tile", type=int, default=0, help="mpeghip_video_set_tile_policy of every video leg: 0 = the library picks the "
+                    "kernel instance per batch (the product's behaviour), 1 = int16 tile, 2 = int32 tile (for A/B runs)")
     ap.add_argument("--check", type=int, default=1, help="verify the final frames against the oracle (rank 0)")
     return ap.parse_args()
 
@@ -107,52 +113,71 @@ def cpu_baseline(args, seq):
 
 
 def build_sequence(args, profile, rgba):
+    """-> (seq, prime): the pictures of seq[:prime] run ONCE, untimed, before the warm-up; warm-up and timed steps cycle
+    seq[prime:].  Typical: the whole decode-order GOP is cycled (prime = 0).  Dense (worst case per SURVEY §8(d)): the I
+    picture only primes the frame stores; every warm-up and every timed step is a dense P picture (every block full, odd
+    vectors in both axes, 1 635 algorithmic bytes per macroblock)."""
     from mpeg_amd import desc, synth
     seq = synth.generate_sequence(args.width, args.height, args.gop, profile=profile, rgba=rgba)
     if profile == "dense":
-        # worst case per SURVEY §8(d): every timed picture is a dense P picture
-        seq = seq[:1] + [s for s in seq[1:] if s.picture_type == desc.PIC_P]
-    return seq
+        return seq[:1] + [s for s in seq[1:] if s.picture_type == desc.PIC_P], 1
+    return seq, 0
+
+
+def sources_sha256():
+    """sha256 over the kernel sources the loaded libmpeghip.so was built from (mpeg_amd/csrc/*, sorted by name): the PMC
+    traffic figures under profiles/ carry the same hash of the build they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "mpeg_amd" / "csrc").iterdir()):
+        if f.suffix in (".h", ".hip"):
+            h.update(f.name.encode() + b"\0" + f.read_bytes())
+    return h.hexdigest()
 
 
 def traffic_of(profile, rgba, streams, args):
-    """HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json): a builder constant of the named
-    profile run, not measured in this process."""
+    """HBM bytes per launch from the committed PMC runs (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate passes, tools/gpu_traffic.sh): a figure of the named profile run, not measured in this process.
+    -> (bytes, source, the run's kernel sources are the ones this process loaded)"""
     tp = ROOT / "profiles" / "pmc_traffic.json"
     if not tp.exists() or (args.width, args.height) != (1920, 1080):
-        return None, None
+        return None, None, None
     try:
-        t = json.loads(tp.read_text()).get(profile + ("_rgba" if rgba else ""), {})
+        j = json.loads(tp.read_text())
+        t = j.get(profile + ("_rgba" if rgba else ""), {})
         if t.get("streams") == streams:
-            return t.get("hbm_bytes_per_launch"), t.get("source")
+            return t.get("hbm_bytes_per_launch"), t.get("source"), j.get("csrc_sha256") == sources_sha256()
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
-def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None):
+def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, steps=None):
     """Upload the GOP for `streams` streams, warm up, time `--steps` steps.  With `ranks` the timed region is bracketed
     by barrier + device sync on both sides and the elapsed time is the MAX over ranks (the primary leg)."""
     from mpeg_amd import abi
-    seq = build_sequence(args, profile, rgba)
+    steps = args.steps if steps is None else steps
+    seq, prime = build_sequence(args, profile, rgba)
     store = abi.VideoStore(ctx, args.width, args.height, streams)
+    store.set_tile_policy(args.tile)
     batches = [store.upload(s.pics, s.mbs, s.coefs, replicate=streams) for s in seq]
     ctx.sync()
     order = []
 
     def step(i):
-        b = batches[i % len(batches)]
+        k = prime + i if i < 0 else prime + i % (len(batches) - prime)  # (i = -prime .. -1: the priming pictures)
+        b = batches[k]
         b.run()
-        order.append(i % len(batches))
+        order.append(k)
         return b
 
-    for i in range(args.warmup):
+    for i in range(-prime, args.warmup):
         step(i)
     acc = {"mbs": 0, "alg": 0, "ev_ms": 0.0}
 
     def timed_body():
         ctx.timer_start()
-        for i in range(args.warmup, args.warmup + args.steps):
+        for i in range(args.warmup, args.warmup + steps):
             b = step(i)
             acc["mbs"] += b.n_mbs
             acc["alg"] += b.alg_bytes
@@ -194,63 +219,98 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None):
         ref.close()
         if not ok:
             raise SystemExit("bench: %s%s frames differ from the oracle — result invalid" % (profile, " (fused RGBA)" if rgba else ""))
+        # every stream holds the same bytes so far: a per-stream base that is off by a stream would still hash right.  Give
+        # far-apart streams their own reference content, run the predicted pictures of the same batches once more
+        # (untimed), compare each of them with its own oracle replay
+        if streams > 1:
+            from mpeg_amd import desc
+            from oracle import crosscheck
+            ok, text = crosscheck.distinct_content_check(store, args.width, args.height, desc.geometry(args.width, args.height),
+                                                         streams, seq, batches, rgba=bool(rgba))
+            if not ok:
+                raise SystemExit("bench: %s%s: %s — result invalid" % (profile, " (fused RGBA)" if rgba else "", text))
+            check += "; " + text
     for b in batches:
         b.free()
     store.close()
-    launch_ms = acc["ev_ms"] / args.steps
-    achieved = (acc["alg"] / args.steps) / (launch_ms * 1e-3) / 1e9
-    traffic, source = traffic_of(profile, rgba, streams, args)
+    launch_ms = acc["ev_ms"] / steps
+    achieved = (acc["alg"] / steps) / (launch_ms * 1e-3) / 1e9
+    traffic, source, matches = traffic_of(profile, rgba, streams, args)
     return {
         "seq": seq, "elapsed": elapsed, "local_elapsed": local_elapsed, "mbs": acc["mbs"], "gop_len": len(batches), "parity": check,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": source, "kernel": KERNEL[bool(rgba)],
-                     "alg_bytes_per_launch": acc["alg"] // args.steps, "avg_launch_ms": launch_ms},
+                     "traffic": traffic, "traffic_source": source, "traffic_source_matches_build": matches, "kernel": KERNEL[bool(rgba)],
+                     "alg_bytes_per_launch": acc["alg"] // steps, "avg_launch_ms": launch_ms},
+        "steps": steps,
     }
 
 
 def secondary(leg, name, streams, args):
     return {"metric": "1080p macroblocks/sec, %s" % name, "value": leg["mbs"] / leg["elapsed"], "unit": "macroblocks/s",
-            "streams": streams, "steps": args.steps, "ms_per_step": leg["elapsed"] * 1e3 / args.steps,
+            "streams": streams, "steps": leg["steps"], "ms_per_step": leg["elapsed"] * 1e3 / leg["steps"],
             "realtime_1080p30_streams": leg["mbs"] / leg["elapsed"] / MB_PER_1080P30_STREAM,
             "roofline": leg["roofline"], "parity": leg["parity"]}
 
 
-def audio_leg(ctx, args):
+def audio_leg(ctx, args, streams, tile=1):
+    """MP2 synthesis on `streams` x `tile` stereo streams, --audio-frames frames per launch.  tile > 1: the seeded samples
+    of `streams` streams are uploaded `tile` times side by side (stream s = stream s mod `streams`): the working set of the
+    timed launch then exceeds the 256 MB Infinity Cache, and every stream is still compared with the oracle."""
+    import ctypes as C
     from mpeg_amd import abi, desc, synth
-    a = abi.AudioSynth(ctx, args.audio_streams, desc.AUDIO_FMA_NONE)
-    smp = synth.audio_frames(args.audio_streams, args.audio_frames)
-    d_s, d_o = a.device_buffers(args.audio_frames, desc.AUDIO_F32N)
-    a.upload(d_s, smp)
-    a.synth_device(d_s, args.audio_frames, desc.AUDIO_F32N, d_o)  # first launch from the zero state: checked below
+    n, frames = streams * tile, args.audio_frames
+    a = abi.AudioSynth(ctx, n, desc.AUDIO_FMA_NONE)
+    smp = synth.audio_frames(streams, frames)
+    d_s, d_o = a.device_buffers(frames, desc.AUDIO_F32N)
+    for t in range(tile):
+        a.upload(C.c_void_p(d_s.value + t * smp.nbytes), smp)
+    a.synth_device(d_s, frames, desc.AUDIO_F32N, d_o)  # first launch from the zero state: checked below
     ctx.sync()
     aparity = None
     if args.check:
         from oracle import pyoracle
-        got = a.download(d_o, args.audio_streams * args.audio_frames * 2304, desc.AUDIO_F32N).reshape(args.audio_streams, -1)
-        want = pyoracle.OracleSynth(args.audio_streams, 0).synth(smp, desc.AUDIO_F32N).reshape(args.audio_streams, -1)
-        if not np.array_equal(want.view(np.uint32), got.view(np.uint32)):
-            raise SystemExit("bench: audio samples differ from the oracle — result invalid")
-        aparity = "bit-exact vs oracle (no-FMA) on all %d streams x %d frames" % (args.audio_streams, args.audio_frames)
+        want = pyoracle.OracleSynth(streams, 0).synth(smp, desc.AUDIO_F32N).reshape(streams, -1)
+        for t in range(tile):
+            got = a.download(C.c_void_p(d_o.value + t * want.nbytes), want.size, desc.AUDIO_F32N).reshape(streams, -1)
+            if not np.array_equal(want.view(np.uint32), got.view(np.uint32)):
+                raise SystemExit("bench: audio samples differ from the oracle — result invalid")
+        aparity = "bit-exact vs oracle (no-FMA) on all %d streams x %d frames" % (n, frames)
     for _ in range(2):
-        a.synth_device(d_s, args.audio_frames, desc.AUDIO_F32N, d_o)
+        a.synth_device(d_s, frames, desc.AUDIO_F32N, d_o)
     ctx.sync()
     reps = 5
     ctx.timer_start()
     for _ in range(reps):
-        a.synth_device(d_s, args.audio_frames, desc.AUDIO_F32N, d_o)
+        a.synth_device(d_s, frames, desc.AUDIO_F32N, d_o)
     ams = ctx.timer_stop_ms() / reps
-    frames = args.audio_streams * args.audio_frames
-    abytes = frames * 18432
+    abytes = n * frames * 18432
+    traffic, source, matches = traffic_of("audio_%d" % n, False, n, args)
     out = {
-        "metric": "MP2 stereo sample pairs/s", "value": frames * 1152 / (ams * 1e-3),
-        "streams": args.audio_streams, "frames_per_launch": args.audio_frames, "ms_per_launch": ams,
-        "realtime_streams_44k1": frames * 1152 / (ams * 1e-3) / 44100.0,
+        "metric": "MP2 stereo sample pairs/s", "value": n * frames * 1152 / (ams * 1e-3),
+        "streams": n, "frames_per_launch": frames, "ms_per_launch": ams,
+        "realtime_streams_44k1": n * frames * 1152 / (ams * 1e-3) / 44100.0,
+        "working_set_bytes": 2 * abytes,
         "roofline": {"bound": "hbm", "achieved": abytes / (ams * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": abytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": abytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+                     "traffic_source_matches_build": matches, "alg_bytes_per_launch": abytes,
                      "kernel": "audio_kernel<false, F32N> (DCT-32 + polyphase window as a sliding register file, 4 waves per stream slice)"},
         "parity": aparity,
     }
     a.close()
+    return out
+
+
+def single_stream_leg(ctx, args):
+    """BASELINE config 3 as written: ONE 1920x1080 stream on the GPU, IDCT + MC + YCbCr->RGBA fused, a picture per launch.
+    8 160 macroblocks = 2 040 chunks = 1 020 one-wave workgroups on a 256-CU part: a latency figure, not a bandwidth one."""
+    out = {"metric": "one %dx%d stream, one picture per launch, Frame.RGBA() fused (BASELINE config 3)" % (args.width, args.height)}
+    for profile in ("typical", "dense"):
+        leg = video_leg(ctx, args, profile, True, 1, steps=100)
+        r = leg["roofline"]
+        out[profile] = {"us_per_picture": r["avg_launch_ms"] * 1e3, "pictures_per_s": 1e3 / r["avg_launch_ms"],
+                        "macroblocks_per_s": leg["mbs"] / 100 / (r["avg_launch_ms"] * 1e-3), "achieved_GBps": r["achieved"],
+                        "frac": r["frac"], "alg_bytes_per_launch": r["alg_bytes_per_launch"], "pictures_timed": 100,
+                        "wall_us_per_picture": leg["elapsed"] * 1e4, "parity": leg["parity"]}
     return out
 
 
@@ -288,7 +348,7 @@ def main():
         for name in [x for x in args.legs.split(",") if x]:
             if name == "dense" and not (args.profile == "dense" and not args.rgba):
                 legs["dense"] = secondary(video_leg(ctx, args, "dense", False, args.streams),
-                                          "dense worst case (every block full, odd vectors, P pictures)", args.streams, args)
+                                          "dense worst case (every block full, odd vectors; every timed step a P picture, the I picture only primes the stores)", args.streams, args)
             elif name == "rgba_fused" and rs > 0 and not (args.profile == "typical" and args.rgba):
                 legs["rgba_fused"] = secondary(video_leg(ctx, args, "typical", True, rs),
                                                "Frame.RGBA() of every picture fused into the reconstruction kernel", rs, args)
@@ -296,7 +356,11 @@ def main():
                 legs["dense_rgba_fused"] = secondary(video_leg(ctx, args, "dense", True, rs),
                                                      "dense worst case with Frame.RGBA() fused", rs, args)
 
-    audio = audio_leg(ctx, args) if args.audio_streams > 0 and rank == 0 else None
+    audio = audio_leg(ctx, args, args.audio_streams) if args.audio_streams > 0 and rank == 0 else None
+    audio_large = None
+    if args.audio_streams > 0 and alone and args.audio_tile > 1:  # beyond the Infinity Cache: config 4's working set is about its size
+        audio_large = audio_leg(ctx, args, args.audio_streams, args.audio_tile)
+    single = single_stream_leg(ctx, args) if alone and args.single_stream else None
 
     # ---- host-fed rate (NOT `value`): the same pictures handed over by host threads through the staged submit,
     # i.e. validation + packing into the device format on the host, PCIe, reconstruction on the device
@@ -335,6 +399,8 @@ def main():
             "rgba_fused": legs.get("rgba_fused"),
             "dense_rgba_fused": legs.get("dense_rgba_fused"),
             "audio": audio,
+            "audio_large": audio_large,
+            "single_stream": single,
             "host_fed": host_fed,
             "parity": prim["parity"],
         }

@@ -101,6 +101,12 @@ func (v *Video) SetQuant(intra, nonIntra *[64]byte) error {
 	return lastError(C.mpeghip_video_set_quant(v.h, 0, (*C.uint8_t)(&intra[0]), (*C.uint8_t)(&nonIntra[0])))
 }
 
+// SetTilePolicy overrides the library's per-batch choice of the reconstruction kernel instance
+// (0 = automatic, 1 = int16 coefficient tile, 2 = int32 tile; include/mpeghip.h).  Results are identical either way.
+func (v *Video) SetTilePolicy(policy int) error {
+	return lastError(C.mpeghip_video_set_tile_policy(v.h, C.int(policy)))
+}
+
 // Submit hands one picture to the GPU.  The slices are only read during the call (cgo rule).
 func (v *Video) Submit(pic *PicDesc, mbs []MbDesc, coefs []byte) error {
 	var mp unsafe.Pointer

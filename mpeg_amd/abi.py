@@ -47,6 +47,7 @@ SYMBOLS = {
     "mpeghip_video_close": (None, [_P]),
     "mpeghip_video_info_get": (C.c_int, [_P, C.POINTER(VideoInfo)]),
     "mpeghip_video_set_quant": (C.c_int, [_P, C.c_uint32, _P, _P]),
+    "mpeghip_video_set_tile_policy": (C.c_int, [_P, C.c_int]),
     "mpeghip_video_submit": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t]),
     "mpeghip_video_stage_begin": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_void_p)]),
     "mpeghip_video_stage_put": (C.c_int, [_P, C.c_uint32, _P, _P, _P]),
@@ -166,6 +167,10 @@ class VideoStore:
         i = np.ascontiguousarray(intra, dtype=np.uint8)
         n = np.ascontiguousarray(non_intra, dtype=np.uint8)
         _check(self.lib.mpeghip_video_set_quant(self.h, stream, _ptr(i), _ptr(n)))
+
+    def set_tile_policy(self, policy: int):
+        """0 = the library picks the kernel instance per batch, 1 = int16 tile (8 waves per SIMD), 2 = int32 tile."""
+        _check(self.lib.mpeghip_video_set_tile_policy(self.h, policy))
 
     @staticmethod
     def _args(pics, mbs, coefs):

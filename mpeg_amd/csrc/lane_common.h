@@ -287,11 +287,8 @@ MPG_HD uint32_t load32_uncounted(const uint32_t *uniform_base, uint32_t byte_off
 {
 #if MPG_ON_DEVICE
     uint32_t v;
-#ifdef MPG_NT_ENTRIES // (next round's experiment: the coefficient words are read once)
-    asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(v) : "v"(byte_off), "s"(uniform_base) : "memory");
-#else
+    // (plain, not `nt`: read once, but a non-temporal load was 4 % slower on typical batches — profiles/r5_ab_*)
     asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(uniform_base) : "memory");
-#endif
     return v;
 #else
     return uniform_base[byte_off / 4];

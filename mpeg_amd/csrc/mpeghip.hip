@@ -42,7 +42,10 @@ static __device__ __forceinline__ void wave_lds_handoff()
 
 // ---- reconstruction (video_recon_lane.h has the whole story): one wave = one chunk of 4 macroblocks,
 // wave-private LDS, no barrier.  kRgba: the instance for batches with MPEGHIP_PIC_RGBA pictures
-// (Frame.RGBA() fused); the other one carries none of that code.
+// (Frame.RGBA() fused); the other one carries none of that code.  kT16: the form of the wave's coefficient tile
+// (video_recon_lane.h): int16 levels + transposition across lanes, 8 waves per SIMD — the instance for typical,
+// latency-bound batches; or int32 values + transposition through the tile, 7 waves per SIMD — the instance for batches
+// of dense units, which are bound by vector-ALU issue, and for fused RGBA (launch_batch picks).
 #ifdef MPG_PHASE_TIMING // instrumented build for tools/phase_timing.py only: s_memtime at the phase boundaries
 __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k) ts[k] = __builtin_readcyclecounter()
@@ -57,29 +60,27 @@ constexpr int kRcChunksPerWave = MPG_CHUNKS_PER_WAVE;
 #ifndef MPG_CHUNK_AHEAD
 #define MPG_CHUNK_AHEAD 256 // chunks; 0 = off (profiles/r3f_ab_chunk_pull_ahead.txt: 64 / 256 / 1024)
 #endif
-template <int WAVES, bool kRgba>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_kernel(const VideoArgs a)
+template <int WAVES, bool kRgba, bool kT16>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(const VideoArgs a)
 {
 #ifdef MPG_PHASE_TIMING
     uint64_t ts[8];
 #endif
     MPG_STAMP(0);
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kRcLdsBytes];
+    constexpr int kLdsBytes = rc_lds_bytes<kT16>();
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kLdsBytes];
     // (one wave per workgroup, the shipped shape: the wave's LDS starts at 0 and every LDS address below is lane part +
     // immediate, with no per-wave base to add)
     const uint32_t w = WAVES == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const int lane_all = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     // a wave takes kRcChunksPerWave consecutive chunks, one after the other: the later ones' headers are loaded with the
     // first one's, and the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once
     const uint32_t first = __builtin_amdgcn_readfirstlane((xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w) * kRcChunksPerWave);
     if (first >= a.n_chunks)
         return;
-    uint8_t *lds = lds_all + w * kRcLdsBytes;
-#if MPG_TILE16
-    int16_t *T = reinterpret_cast<int16_t *>(lds + kRcTileAt);
-#else
-    int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
-#endif
+    uint8_t *lds = lds_all + w * kLdsBytes;
+    int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);   // the int32 tile ...
+    int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt); // ... or the int16 one (kT16)
 
 #if MPG_CHUNK_AHEAD
     // pull the chunks a later wave of this XCD's range will take towards L2 (one lane per cache line of their 96 bytes
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     uint32_t ahead;
     {
         const uint32_t later = first + MPG_CHUNK_AHEAD * kRcChunksPerWave + kRcChunksPerWave <= a.n_chunks ? first + MPG_CHUNK_AHEAD * kRcChunksPerWave : first;
-        const uint32_t line = (uint32_t)lane < (kRcChunksPerWave * kRcChunkDwords * 4 + 63) / 64 ? (uint32_t)lane : 0u;
+        const uint32_t line = (uint32_t)lane_all < (kRcChunksPerWave * kRcChunkDwords * 4 + 63) / 64 ? (uint32_t)lane_all : 0u;
         ahead = load32_uncounted(a.chunks + (uint64_t)later * kRcChunkDwords, line * 64);
     }
 #endif
@@ -96,18 +97,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     static_assert(kRcChunksPerWave == 1 || kRcChunksPerWave == 2, "written out for one or two");
     const RcChunk c0 = rc_load_chunk(a, first);
     const RcChunk c1 = rc_load_chunk(a, kRcChunksPerWave == 2 && first + 1 < a.n_chunks ? first + 1 : first);
-#if MPG_TILE16 && !defined(MPG_LANE_ONCE)
-    const int lane_all = lane; // (each chunk works its lane constants out again: kept across the other chunk they cost 15 registers and, at 64, three spills)
-#else
-    const RcLane k = rc_lane(a, lane);
-#endif
+    // what depends on the lane only.  The int16-tile instance works it out again per chunk: kept across the other chunk the
+    // 15 values cost three spills at the 64 registers that 8 waves per SIMD allow.
+    const RcLane k_once = rc_lane(a, kT16 ? 0 : lane_all);
     bool ahead_pending = MPG_CHUNK_AHEAD != 0;
     auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
     (void)chunk; // (the instrumented build's stamps)
-#if MPG_TILE16 && !defined(MPG_LANE_ONCE)
-    const int lane = (int)opaque((uint32_t)lane_all);
-    const RcLane k = rc_lane(a, lane);
-#endif
+    const int lane = kT16 ? (int)opaque((uint32_t)lane_all) : lane_all;
+    const RcLane k = kT16 ? rc_lane(a, lane) : k_once;
     const uint32_t n_blocks = rc_n_blocks(c);
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)
@@ -139,86 +136,84 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         if ((pass + 1) * 8 < n_blocks) // the next pass's block words: on their way while this pass runs
             bw_next = rc_blk_src(a, c)[rc_blk_lane_offset(pass + 1, lane) / 4];
         const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
-#if MPG_TILE16
-        // the int16 tile holds sparse blocks only: a pass without entries does not go through it
-        if (np) {
-            rc_zero_tile16(T, lane);
-            wave_lds_handoff();
+        auto scatter_entries = [&](auto &&scatter_one) {
             for (uint32_t r = 0; r < np; r += 64) {
                 if (pass > 0 || r > 0)
                     e = *rc_ent_src(a, c, ent_at + r, lane);
                 if (r + (uint32_t)lane < np)
-                    rc_scatter16(T, lds, e);
+                    scatter_one(e);
             }
             ent_at += np;
-            wave_lds_handoff();
-            rc_cols_load16(T, lds, lane, v);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                v[r] = 0;
-        }
-        if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are
-            rc_raw_cols(a, c, bw, lane, v);
-        if (rc_any_dense(c)) {
-            if (mine && (bw & kBDense)) {
-                const i32x4_a4 lv = pass > 0 ? dense_next : rc_dense_read(a, c, bw, lane);
-                rc_dense_cols(lv, lds, bw, lane, v);
-            }
-            if ((pass + 1) * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw_next & kBDense))
-                dense_next = rc_dense_read(a, c, bw_next, lane);
-        }
-        idct8<false>(v);
-        rc_transpose8(v, lane); // column j -> row j, across the block's 8 lanes
-        idct8<true>(v);
-        return;
-#else
-        // a pass whose blocks ALL travel as dense units (the worst-case workload) needs neither the zeroed tile nor a
-        // column read from it: every live lane takes its column straight from its unit
-        bool from_tile = true;
-        if (rc_any_dense(c) && np == 0 && !rc_any_raw(c))
-            from_tile = !all_in_wave(!mine || (bw & kBDense) != 0);
-        if (from_tile) {
-            rc_zero_tile(T, lane);
-            wave_lds_handoff();
-            for (uint32_t r = 0; r < np; r += 64) {
-                if (pass > 0 || r > 0)
-                    e = *rc_ent_src(a, c, ent_at + r, lane);
-                if (r + (uint32_t)lane < np)
-                    rc_scatter(T, lds, e);
-            }
-            ent_at += np;
-            if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
-#pragma unroll
-                for (uint32_t g = 0; g < 8; g++) {
-                    const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
-                    if (pass * 8 + g < n_blocks && (bwg & kBRaw))
-                        rc_raw_fill(a, c, T, g, bwg, lane);
-                }
-            }
-            wave_lds_handoff();
-            rc_cols_load(T, lane, v);
-        } else {
+        };
+        auto zero_columns = [&]() {
 #pragma unroll
             for (int r = 0; r < 8; r++)
                 v[r] = 0; // (lanes beyond the last block: their result is not used)
-        }
-        if (rc_any_dense(c)) { // blocks that travel as dense units: their columns come straight from the unit
+        };
+        // blocks that travel as dense units: their columns come straight from the unit, dequantised in place of the tile
+        // read.  (The next pass's columns: its block words are here by now, the units' 16 bytes per lane arrive while this
+        // pass finishes — otherwise every pass waits out a dependent HBM read.)
+        auto dense_columns = [&]() {
+            if (!rc_any_dense(c))
+                return;
             if (mine && (bw & kBDense)) {
                 const i32x4_a4 lv = pass > 0 ? dense_next : rc_dense_read(a, c, bw, lane);
                 rc_dense_cols(lv, lds, bw, lane, v);
             }
-            // (the next pass's columns: its block words are here by now, the units' 16 bytes per lane arrive while this
-            // pass finishes — otherwise every pass waits out a dependent HBM read)
             if ((pass + 1) * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw_next & kBDense))
                 dense_next = rc_dense_read(a, c, bw_next, lane);
+        };
+        if (kT16) {
+            // the int16 tile holds sparse blocks only: a pass without entries does not go through it
+            if (np) {
+                rc_zero_tile16(T16, lane);
+                wave_lds_handoff();
+                scatter_entries([&](uint32_t ent) { rc_scatter16(T16, lds, ent); });
+                wave_lds_handoff();
+                rc_cols_load16(T16, lds, lane, v);
+            } else {
+                zero_columns();
+            }
+            if (mine)
+                rc_dc_from_word(bw, lane, v);
+            if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are, from HBM
+                rc_raw_cols(a, c, bw, lane, v);
+            dense_columns();
+            idct8<false>(v);
+            rc_transpose8(v, lane); // column j -> row j, across the block's 8 lanes
+            idct8<true>(v);
+        } else {
+            // a pass whose blocks ALL travel as dense units (the worst-case workload) needs neither the zeroed tile nor a
+            // column read from it: every live lane takes its column straight from its unit
+            bool from_tile = true;
+            if (rc_any_dense(c) && np == 0 && !rc_any_raw(c))
+                from_tile = !all_in_wave(!mine || (bw & kBDense) != 0);
+            if (from_tile) {
+                rc_zero_tile(T, lane);
+                wave_lds_handoff();
+                scatter_entries([&](uint32_t ent) { rc_scatter(T, lds, ent); });
+                if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; g++) {
+                        const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
+                        if (pass * 8 + g < n_blocks && (bwg & kBRaw))
+                            rc_raw_fill(a, c, T, g, bwg, lane);
+                    }
+                }
+                wave_lds_handoff();
+                rc_cols_load(T, lane, v);
+            } else {
+                zero_columns();
+            }
+            if (mine)
+                rc_dc_from_word(bw, lane, v);
+            dense_columns();
+            idct8<false>(v);
+            rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now
+            wave_lds_handoff();
+            rc_rows_load(T, lane, v);
+            idct8<true>(v);
         }
-        idct8<false>(v);
-        rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now
-        wave_lds_handoff();
-        rc_rows_load(T, lane, v);
-        idct8<true>(v);
-#endif
     };
     // step 4: residual rows onto the prediction
     auto add_residual = [&](uint32_t pass) {
@@ -282,11 +277,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     const bool rgba = kRgba && (c.h[5] & kCRgba) != 0;
     const uint32_t n_live = rc_n_live(c);
     if (run) {
-#ifdef MPG_NT_FRAME_FUSED // (next round's experiment; default: the fused instance keeps plain stores)
-        rc_store_run<true>(a, c, lane, lds);
-#else
-        rc_store_run<!kRgba>(a, c, lane, lds);
-#endif
+        rc_store_run(a, c, lane, lds);
     } else {
 #pragma unroll
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
@@ -530,6 +521,7 @@ struct mpeghip_batch {
     uint32_t *d_chunks = nullptr, *d_words = nullptr;
     uint64_t n_pics = 0, n_mbs = 0, n_chunks = 0;
     uint64_t alg_bytes = 0;
+    uint64_t coded_blocks = 0, dense_blocks = 0; // of the original (un-replicated) batch: launch_batch picks the kernel instance by them
     bool any_rgba = false;
     // host copy of what launch_batch needs to keep the RGBA images in step: per picture of the original
     // (un-replicated) batch {stream, cur, MPEGHIP_PIC_RGBA?, covers every macroblock of the frame?}
@@ -564,6 +556,7 @@ struct mpeghip_video {
     uint8_t *bounce = nullptr;             // pinned: read_planes / read_rgba land here first
     size_t bounce_cap = 0;
     uint8_t *d_linear = nullptr;           // one slot's planes in the reference's linear layout (read / write_planes)
+    int tile_policy = MPEGHIP_TILE_AUTO;   // mpeghip_video_set_tile_policy
 };
 
 // what validation learns about a picture (the dependency check across pictures needs it)
@@ -580,8 +573,9 @@ struct mpeghip_stage {
     std::vector<uint32_t> chunk_first;          // per picture: its first chunk
     std::vector<uint64_t> units;                // per picture: its coefficient units
     std::vector<uint64_t> alg;                  // per picture, written by its put
+    std::vector<uint32_t> blocks, dense;        // per picture, written by its put: coded blocks / dense units
     std::vector<PicUse> use;                    // per picture, written by its put
-    std::vector<uint8_t> done;                  // per picture: put succeeded
+    std::unique_ptr<std::atomic<uint8_t>[]> done; // per picture: 0 = not put, 1 = a put has claimed it, 2 = put succeeded
     size_t c_at = 0, w_at = 0;                  // staging layout: pictures | chunks | words
     uint64_t words_cap = 0;                     // room for every picture's worst case
     std::atomic<uint64_t> words_used{0};        // dwords handed out so far: a put packs its picture into scratch
@@ -768,7 +762,11 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
     in.frame_bytes = in.luma_bytes + 2 * in.chroma_bytes + (uint64_t)in.luma_w * 16; // video.go:340
     in.frame_stride = align_up(in.frame_bytes + 64, 256); // slack keeps 8-byte row loads inside the slot
     in.rgba_bytes = (uint64_t)width * height * 4;
-    const uint64_t total = in.frame_stride * MPEGHIP_SLOTS * n_streams;
+    // Tail pad behind the last slot: a kRSlow gather always fetches 17 luma rows x 32 bytes / 9 chroma rows x 16 bytes from the dword
+    // below the window origin — one row and one piece more than the half-pel mode (and validate_mb) needs — so a window that ends
+    // exactly at the end of the slot's pad reads up to luma_w + 47 bytes past frame_bytes (ignored; inside every other slot's stride).
+    const uint64_t tail_pad = align_up((uint64_t)in.luma_w + 64, 256);
+    const uint64_t total = in.frame_stride * MPEGHIP_SLOTS * n_streams + tail_pad;
     int rc = MPEGHIP_OK;
     do {
         if (hipMalloc((void **)&v->d_frames, total) != hipSuccess) {
@@ -865,6 +863,14 @@ int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream, const uint8_t int
     HIP_TRY(hipSetDevice(v->ctx->device));
     HIP_TRY(hipStreamSynchronize(v->ctx->stream)); // earlier pictures may still read the old matrices
     HIP_TRY(hipMemcpy(v->d_qmat + (size_t)stream * 256, t, 256, hipMemcpyHostToDevice));
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_set_tile_policy(mpeghip_video *v, int policy)
+{
+    if (!v || policy < MPEGHIP_TILE_AUTO || policy > MPEGHIP_TILE_INT32)
+        return fail(MPEGHIP_ERR_INVALID, "bad argument");
+    v->tile_policy = policy;
     return MPEGHIP_OK;
 }
 
@@ -1033,7 +1039,8 @@ static uint64_t chunks_of(const mpeghip_pic_desc *pics, uint32_t n_pics)
 // are mbs[mb_first .. mb_first + mb_count); every macroblock belongs to exactly one picture's range.
 static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
                              const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
-                             uint64_t *alg_bytes, uint32_t *chunks_out, uint32_t *words_out, uint64_t *n_words)
+                             uint64_t *alg_bytes, uint32_t *chunks_out, uint32_t *words_out, uint64_t *n_words,
+                             uint64_t *stats = nullptr /* -> {coded blocks, dense units} */)
 {
     const mpeghip_video_info &in = v->info;
     if (n_pics && !pics)
@@ -1060,7 +1067,7 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
     const uint64_t coef_units = coef_bytes / MPEGHIP_COEF_UNIT;
     std::vector<PicUse> use(n_pics);
     std::vector<uint64_t> seen;
-    uint64_t alg = 0, words = 0, chunk = 0, named_units = 0;
+    uint64_t alg = 0, words = 0, chunk = 0, named_units = 0, blocks = 0, dense = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
         const mpeghip_mb_desc *pm = mbs + pics[p].mb_first;
         for (uint32_t k = 0; k < pics[p].mb_count; k++)
@@ -1078,7 +1085,13 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
                                                  (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words);
             chunk += got.chunks;
             words += got.words;
+            blocks += got.blocks;
+            dense += got.dense_blocks;
         }
+    }
+    if (stats) {
+        stats[0] = blocks;
+        stats[1] = dense;
     }
     const int rc = check_dependencies(pics, use.data(), n_pics);
     if (rc != MPEGHIP_OK)
@@ -1119,6 +1132,7 @@ static int grow_pinned(mpeghip_video::Staging *sg, size_t need)
     return MPEGHIP_OK;
 }
 
+constexpr uint64_t kDenseBatchShare = 4; // more than a quarter of a batch's coded blocks dense units: the int32-tile instance
 constexpr int kReconWaves = 1; // waves (= chunks) per workgroup: waves of a workgroup that finish early keep their slots until the
                                // last one has (its LDS goes back as a whole) — 1 beats 2 beats 4 (profiles/r2w_ab_waves_per_workgroup.txt)
 
@@ -1149,10 +1163,21 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba_stride = rgba_stride_of(v);
     hipStream_t st = v->ctx->stream;
     const uint32_t grid = (a.n_chunks + kReconWaves * kRcChunksPerWave - 1) / (kReconWaves * kRcChunksPerWave);
-    if (b->any_rgba)
-        hipLaunchKernelGGL((recon_kernel<kReconWaves, true>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+    // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches of dense units are bound by vector-ALU
+    // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); so does the fused-RGBA instance, which is
+    // bound by its stores; everything else is bound by per-wave latency and wants the eighth wave (int16 tile).  Measured at
+    // the two ends (typical: 0 % dense units, worst case: 100 %; profiles/r6_ab_*); the switch-over in between is a guess.
+    bool t16 = !b->any_rgba && b->dense_blocks * kDenseBatchShare <= b->coded_blocks;
+    if (v->tile_policy != MPEGHIP_TILE_AUTO)
+        t16 = v->tile_policy == MPEGHIP_TILE_INT16;
+    if (b->any_rgba && t16)
+        hipLaunchKernelGGL((recon_kernel<kReconWaves, true, true>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+    else if (b->any_rgba)
+        hipLaunchKernelGGL((recon_kernel<kReconWaves, true, false>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+    else if (t16)
+        hipLaunchKernelGGL((recon_kernel<kReconWaves, false, true>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((recon_kernel<kReconWaves, false>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+        hipLaunchKernelGGL((recon_kernel<kReconWaves, false, false>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
     HIP_TRY(hipGetLastError());
     // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
     // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
@@ -1222,9 +1247,14 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
         return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
     if (n_pics && !pics)
         return fail(MPEGHIP_ERR_INVALID, "pics is NULL");
-    for (uint32_t p = 0; p < n_pics; p++)
+    uint64_t covered = 0;
+    for (uint32_t p = 0; p < n_pics; p++) {
         if ((uint64_t)pics[p].mb_first + pics[p].mb_count > n_mbs)
             return fail(MPEGHIP_ERR_INVALID, "picture %u: macroblock range out of bounds", p);
+        covered += pics[p].mb_count;
+    }
+    if (covered != n_mbs) // (before anything is sized from the pictures' counts: overlapping ranges would ask for a huge buffer)
+        return fail(MPEGHIP_ERR_INVALID, "the pictures' macroblock ranges cover %llu of %u macroblocks", (unsigned long long)covered, n_mbs);
     HIP_TRY(hipSetDevice(v->ctx->device));
     const uint64_t n_chunks = chunks_of(pics, n_pics);
     const BlobLayout l = blob_layout(n_pics, n_chunks);
@@ -1245,14 +1275,21 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
             HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
         h = sg->h;
     } else {
-        pageable.resize(l.w_at + words_cap * 4 + 64);
+        try {
+            pageable.resize(l.w_at + words_cap * 4 + 64);
+        } catch (const std::bad_alloc &) { // (nothing throws across the C ABI)
+            return fail(MPEGHIP_ERR_OOM, "host allocation of %zu bytes failed", l.w_at + words_cap * 4 + 64);
+        }
         h = pageable.data();
     }
     uint64_t n_words = 0;
+    uint64_t stats[2] = {0, 0};
     rc = validate_and_pack(v, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, &b->alg_bytes,
-                           reinterpret_cast<uint32_t *>(h + l.c_at), reinterpret_cast<uint32_t *>(h + l.w_at), &n_words);
+                           reinterpret_cast<uint32_t *>(h + l.c_at), reinterpret_cast<uint32_t *>(h + l.w_at), &n_words, stats);
     if (rc != MPEGHIP_OK)
         return rc;
+    b->coded_blocks = stats[0];
+    b->dense_blocks = stats[1];
     if (n_words * replicas > 0xffffffffull - kRcWordsPad)
         return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
     b->any_rgba = wants_rgba(pics, n_pics);
@@ -1344,8 +1381,12 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
     s->chunk_first.resize(n_pics);
     s->units.resize(n_pics);
     s->alg.assign(n_pics, 0);
+    s->blocks.assign(n_pics, 0);
+    s->dense.assign(n_pics, 0);
     s->use.assign(n_pics, PicUse());
-    s->done.assign(n_pics, 0);
+    s->done.reset(new std::atomic<uint8_t>[n_pics ? n_pics : 1]);
+    for (uint32_t i = 0; i < n_pics; i++)
+        s->done[i].store(0);
     uint64_t mbs = 0, chunks = 0, words = 0; // words: worst case (every coefficient of every unit non-zero)
     for (uint32_t i = 0; i < n_pics; i++) {
         if (coef_bytes[i] % MPEGHIP_COEF_UNIT)
@@ -1399,6 +1440,13 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
             rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: NULL array", i);
             break;
         }
+        // one put per picture: the staging buffer has room for each picture once (a second put — a retry after an error, the
+        // same i from two threads — would write past it)
+        uint8_t fresh = 0;
+        if (!s->done[i].compare_exchange_strong(fresh, 1)) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u was already put", i);
+            break;
+        }
         if ((rc = validate_pic(v->info, *pic, i)) != MPEGHIP_OK)
             break;
         uint8_t *h = s->sg->h;
@@ -1421,10 +1469,16 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         const RcPacked got = rc_pack_picture(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0, chunks,
                                              scratch.data());
         const uint64_t at = s->words_used.fetch_add(got.words);
+        if (at + got.words > s->words_cap) { // (cannot happen: every picture is put once and stays within its worst case)
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: the staging buffer is full", i);
+            break;
+        }
         memcpy(h + s->w_at + at * 4, scratch.data(), (size_t)got.words * 4);
         rc_rebase(chunks, got.chunks, (uint32_t)at);
         s->alg[i] = alg;
-        s->done[i] = 1;
+        s->blocks[i] = got.blocks;
+        s->dense[i] = got.dense_blocks;
+        s->done[i].store(2);
     } while (0);
     if (rc != MPEGHIP_OK) {
         std::lock_guard<std::mutex> l(s->error_lock);
@@ -1446,7 +1500,7 @@ int mpeghip_video_stage_commit(mpeghip_stage *sp)
     if (s->error.load() != MPEGHIP_OK)
         return fail(s->error.load(), "%s", s->error_text.c_str());
     for (uint32_t i = 0; i < s->n_pics; i++)
-        if (!s->done[i])
+        if (s->done[i].load() != 2)
             return fail(MPEGHIP_ERR_INVALID, "stage_commit: picture %u was never put", i);
     if (s->n_mbs == 0)
         return MPEGHIP_OK;
@@ -1476,9 +1530,12 @@ int mpeghip_video_stage_commit(mpeghip_stage *sp)
             HIP_TRY(hipMemcpyAsync(b->d_blob + at, sg->h + at, total - at < piece ? total - at : piece, hipMemcpyHostToDevice, st));
     }
     fill_notes(v, b, pics, s->n_pics);
-    b->alg_bytes = 0;
-    for (uint32_t p = 0; p < s->n_pics; p++)
+    b->alg_bytes = b->coded_blocks = b->dense_blocks = 0;
+    for (uint32_t p = 0; p < s->n_pics; p++) {
         b->alg_bytes += s->alg[p];
+        b->coded_blocks += s->blocks[p];
+        b->dense_blocks += s->dense[p];
+    }
     b->replicas = 1;
     b->n_pics = s->n_pics;
     b->n_mbs = s->n_mbs;
@@ -1501,6 +1558,8 @@ int mpeghip_video_batch_upload_replicated(mpeghip_video *v, const mpeghip_pic_de
     *out = nullptr;
     if (n_streams == 0 || n_streams > v->info.n_streams)
         return fail(MPEGHIP_ERR_INVALID, "n_streams %u out of range", n_streams);
+    if (n_pics && !pics)
+        return fail(MPEGHIP_ERR_INVALID, "pics is NULL");
     if (n_streams > 1)
         for (uint32_t p = 0; p < n_pics; p++)
             if (pics[p].stream != 0)

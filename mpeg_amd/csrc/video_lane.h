@@ -31,23 +31,18 @@ struct VideoArgs {
 };
 
 // ---- frame layout in HBM.  A slot holds the reference's `base` slice (video.go:338-355: Y | Cb | Cr | pad), but the
-// planes are TILED in macroblock order: luma as 16x16 tiles of 256 bytes (row-major inside, 16 bytes per row), Cb and
-// Cr as 8x8 blocks of 64 bytes (8 bytes per row); the pad (luma_w * 16 zero bytes) and the slack stay as they are.
+// planes are TILED in macroblock order: luma as 16x16 tiles of 256 bytes (row-major inside, 16 bytes per row); the two
+// chroma planes as one array of 128-byte PAIRS, macroblock i's 8x8 Cb block (64 bytes, 8 per row) followed by its Cr
+// block; the pad (luma_w * 16 zero bytes) and the slack stay as they are.
 // Why: motion compensation reads a 17 x 17 (9 x 9) window at an arbitrary position per macroblock.  In a row-major
 // plane that is one cache line PER ROW (35 rows -> ~39 lines, 11 useful bytes per line requested), and the number of
 // lines a wave requests is what bounded the kernel (profiles/r2t_ab_tiled_access_pattern.txt: the same kernel with a
-// tile-like access pattern ran 30 % faster).  Tiled, a window touches 2 x 3 luma lines and ~2 x 3 chroma lines; a
-// macroblock's output is 256 + 64 + 64 CONTIGUOUS bytes.  The linear view of the reference (plane reads, hashes,
+// tile-like access pattern ran 30 % faster).  Tiled, a window touches 2 x 3 luma lines and ~4 chroma lines (one line
+// holds both planes of a macroblock; with the planes apart it was ~6: profiles/r5_ab_*, r6_ab_*: +0.3 .. 1.9 % on every
+// leg); a macroblock's output is 256 + 128 CONTIGUOUS bytes.  The linear view of the reference (plane reads, hashes,
 // Frame.RGBA, and its reads past a plane's edge) is kept exactly: see linear_to_tiled and the kernel's slow path.
-//
-// MPG_CHROMA_PAIRS (a build-time layout option, default off; not yet measured on the GPU — DESIGN.md section 7): the Cb
-// and the Cr block of one macroblock side by side, 128 bytes = one cache line per macroblock for both planes, instead of
-// two planes of 64-byte blocks.  A window then touches ~4 chroma lines instead of ~6.
-#ifndef MPG_CHROMA_PAIRS
-#define MPG_CHROMA_PAIRS 0
-#endif
-constexpr bool kChromaPairs = MPG_CHROMA_PAIRS != 0;
-constexpr uint32_t kChromaBlockStep = kChromaPairs ? 128 : 64; // bytes from one macroblock's block of a plane to the next one's
+constexpr uint32_t kChromaBlockStep = 128; // bytes from one macroblock's Cb block to the next one's
+constexpr uint32_t kChromaCrAt = 64;       // a macroblock's Cr block, behind its Cb block
 MPG_HD uint32_t tiled_luma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 4) * mb_w + (x >> 4)) * 256 + (y & 15) * 16 + (x & 15); }
 MPG_HD uint32_t tiled_chroma(uint32_t mb_w, uint32_t x, uint32_t y) { return ((y >> 3) * mb_w + (x >> 3)) * kChromaBlockStep + (y & 7) * 8 + (x & 7); }
 // byte offset inside a slot in the reference's (linear) layout -> where that byte lives.  A dword-aligned linear dword
@@ -60,7 +55,7 @@ MPG_HD uint32_t linear_to_tiled(uint32_t mb_w, uint32_t luma_bytes, uint32_t chr
     uint32_t c = L - luma_bytes, plane = luma_bytes;
     if (c >= chroma_bytes) {
         c -= chroma_bytes;
-        plane += kChromaPairs ? 64 : chroma_bytes;
+        plane += kChromaCrAt;
         if (c >= chroma_bytes)
             return L; // pad / slack: linear
     }
@@ -130,7 +125,7 @@ MPG_HD int32_t dequant(int32_t q, bool intra, int32_t qsqm, int32_t pm)
     return mul24_as_written(l, pm);
 }
 
-// the same without the premultiplier: the clamped level, |.| <= 2048 (MPG_TILE16 keeps these as int16 and premultiplies
+// the same without the premultiplier: the clamped level, |.| <= 2048 (the int16-tile instance keeps these as int16 and premultiplies
 // when a column is read)
 MPG_HD int32_t dequant_level(int32_t q, bool intra, int32_t qsqm)
 {
@@ -245,7 +240,7 @@ MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t mb_w, uint32_t luma
     const uint32_t yy1 = *reinterpret_cast<const uint32_t *>(frame + tiled_luma(mb_w, x0, two ? y + 1 : y));
     const uint8_t *cbp = frame + luma_bytes + tiled_chroma(mb_w, x0 >> 1, yp);
     const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp);
-    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + (kChromaPairs ? 64 : chroma_bytes));
+    const uint32_t cr = *reinterpret_cast<const uint16_t *>(cbp + kChromaCrAt);
     uint32_t px0[4], px1[4];
     const ChromaTerms c01 = chroma_terms(cb & 0xff, cr & 0xff), c23 = chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff);
     rgba_row4(yy0, c01, c23, px0);

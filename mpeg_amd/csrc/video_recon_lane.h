@@ -14,8 +14,7 @@
 //           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24        d1 reference frame offset >> 8
 //                   d2 the luma prediction window, origin (x0, y0) = macroblock origin + integer vector:
 //                      byte offset (inside the frame) of the 16x16 TILE that holds (x0, y0) | (y0 & 15) << 4 | x0 & 15
-//                   d3 the same for Cb: offset of the 8x8 block (plane offset included; Cr = + chroma_bytes, or + 64
-//                      with MPG_CHROMA_PAIRS)
+//                   d3 the same for Cb: offset of the 8x8 block (luma_bytes included; its Cr block is 64 bytes further on)
 //                      | (cy0 & 7) << 3 | cx0 & 7
 //                   kRSlow records (a window that leaves its plane: the reference reads on, linearly, into the next
 //                   row / plane / the pad, video_noasm.go:48-80) carry the window origins as LINEAR byte offsets
@@ -25,10 +24,11 @@
 //                   LDS byte offset / 8 of the block's row 0 in the output bytes | chroma << 9 | snapshot << 10
 //                   | dense << 11 | (snapshot / dense: dword offset of its data behind the chunk's first entry) << 12
 //                   | (dense: quantiser_scale << 26 | non-intra << 31)
+//                   | (sparse intra blocks: the DC level << 12 | kBDcWord — video.go:656-672 treats it apart: no matrix, `<< 8`)
 //           entries, one per NON-ZERO quantised coefficient of the sparse blocks, grouped by pass (slots 0-7,
 //           8-15, 16-23):
 //                   level << 16 | quantiser_scale << 11 | (slot & 7) << 8 | position << 2 | non-intra << 1
-//                   | "intra DC" ; position = column * 8 + row, the order of the ABI's coefficient units
+//                   ; position = column * 8 + row, the order of the ABI's coefficient units
 //           then the data of the chunk's other blocks: int32 snapshot blocks (MPEGHIP_MB_COEF_RAW), 64 dwords
 //           each, and DENSE blocks — more than 32 non-zero levels, where a unit as the ABI hands it over
 //           (64 int16 levels, 32 dwords) is the shorter form
@@ -80,9 +80,10 @@ constexpr int kRcMaxBlocks = 6 * kRcMbs;      // 24 slots, 3 passes of 8
 constexpr int kRcChunkDwords = 8 + 4 * kRcMbs;
 constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                                    // header h5
 constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32, kRSlow = 64; // record d0
-constexpr uint32_t kBChroma = 1u << 9, kBRaw = 1u << 10, kBDense = 1u << 11;               // block word
+constexpr uint32_t kBChroma = 1u << 9, kBRaw = 1u << 10, kBDense = 1u << 11, kBDcWord = 1u << 28;    // block word
 constexpr uint32_t kDenseAbove = 32; // non-zero levels beyond which a block travels as a dense unit
-constexpr uint32_t kEDc = 1, kENonIntra = 2;                                               // entry
+constexpr int32_t kRcDenseLevelMax = 16383; // ... if none of them is beyond this (rc_dense_pair works on 16-bit halves)
+constexpr uint32_t kENonIntra = 2;                                                         // entry
 
 // wave-private LDS
 constexpr int kRcPiece = 16;                  // bytes per lane of a direct-to-LDS load
@@ -94,21 +95,18 @@ constexpr int kRcQtabStride = 256;            // per stream in HBM
 constexpr int kRcQtabAt = 0;
 constexpr int kRcWinAt = kRcQtabBytes;        // 192
 constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3648
-// MPG_TILE16 (a build-time option, default off; not yet measured on the GPU — DESIGN.md section 7): the tile holds
-// int16 dequantised levels (premultiplied when a column is read), the 8x8 transposition between the two IDCT passes is
-// done across lanes (DPP) instead of through the tile, snapshot blocks take their columns straight from HBM like
-// dense units: 4 672 bytes of LDS per wave = room for 8 waves per SIMD.
-#ifndef MPG_TILE16
-#define MPG_TILE16 0
-#endif
-constexpr bool kTile16 = MPG_TILE16 != 0;
-#if MPG_TILE16
-constexpr int kRcTileBytes = 8 * 64 * 2;      // T: int16 [8 blocks][64]
-#else
-constexpr int kRcTileBytes = 8 * 64 * 4;      // T: int32 [8 blocks][64]
-#endif
-constexpr int32_t kRcDcInTile16 = 4095;       // an intra DC level beyond this does not fit (level * 8 as int16): the block travels as a dense unit
-constexpr int kRcLdsBytes = kRcTileAt + kRcTileBytes; // 5696: 28 one-wave workgroups per CU (160 000 usable bytes, tools/microbench/lds_residency.hip)
+// The wave's coefficient tile T, two forms = two instances of the kernel (mpeghip.hip picks one per batch):
+//   int32 [8 blocks][64], 2 048 bytes: dequantised AND premultiplied values; the 8x8 transposition between the two IDCT
+//          passes goes through it (8 writes, 2 reads, one round trip, no vector-ALU work).  5 696 bytes of LDS per wave = 7
+//          waves per SIMD.  The instance for batches with many dense units (bound by vector-ALU issue) and for fused RGBA.
+//   int16 [8 blocks][64], 1 024 bytes: dequantised levels (|.| <= 2048), premultiplied when a column is read (byte x
+//          half-word multiplies); the transposition goes across the block's 8 lanes by DPP (28 instructions), snapshot
+//          blocks are read straight from HBM.  4 672 bytes = 8 waves per SIMD: the instance for the typical, latency-bound
+//          batches (profiles/r5_ab_*, r6_ab_*: typical +3 .. 4 %, dense -4 .. -6 %, fused RGBA -1 .. -6 %).
+constexpr int kRcTileBytes32 = 8 * 64 * 4, kRcTileBytes16 = 8 * 64 * 2;
+// 28 / 32 one-wave workgroups per CU (160 000 usable bytes, tools/microbench/lds_residency.hip)
+template <bool kT16> constexpr int rc_lds_bytes() { return kRcTileAt + (kT16 ? kRcTileBytes16 : kRcTileBytes32); }
+constexpr int kRcLdsBytesMax = kRcTileAt + kRcTileBytes32;
 
 // LDS byte offset of macroblock m's window, later its output bytes O_m: luma [16 rows][16] | Cb [8][8] | Cr [8][8]
 MPG_HD uint32_t rc_win_at(uint32_t m) { return kRcWinAt + m * kRcWinBytes; }
@@ -164,6 +162,22 @@ static inline uint64_t rc_nonzero_mask(const uint8_t *unit)
 #endif
 }
 
+// Can a unit travel as a dense unit?  The dense path forms 2 level + sign(level) in 16 bits (rc_dense_pair): every level
+// within +-kRcDenseLevelMax; an intra block's DC does not take that route (rc_dense_cols).
+static inline bool rc_dense_levels_fit(const uint8_t *unit, bool intra)
+{
+    int16_t w[64];
+    memcpy(w, unit, 128);
+    if (intra)
+        w[0] = 0;
+    int32_t lo = 0, hi = 0;
+    for (int k = 0; k < 64; k++) { // (vectorises: two 512-bit min / max)
+        lo = w[k] < lo ? w[k] : lo;
+        hi = w[k] > hi ? w[k] : hi;
+    }
+    return lo >= -kRcDenseLevelMax && hi <= kRcDenseLevelMax;
+}
+
 // Room one picture of n macroblocks with `units` coefficient units can need (dwords).
 #if MPG_HOST_AVX512
 // The same two steps on 512-bit registers (run-time dispatch: rc_host_has_avx512).  Entries of one unit: its non-zero
@@ -203,7 +217,8 @@ constexpr size_t kRcWordsPad = 256; // dwords behind the last chunk's words that
 constexpr size_t kRcQtabPad = 1024;  // bytes behind the last stream's table that a wave may read (and ignore)
 
 struct RcPacked {
-    uint32_t chunks = 0, words = 0; // what the picture took
+    uint32_t chunks = 0, words = 0;        // what the picture took
+    uint32_t blocks = 0, dense_blocks = 0; // its coded blocks / those that travel as dense units (which kernel instance suits the batch)
 };
 
 // Pack ONE picture: macroblocks mbs[0..n) (already validated), whose coef_off index 128-byte units behind
@@ -297,18 +312,21 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                     continue;
                 }
 #if MPG_HOST_AVX512
-                const uint64_t mask = wide ? rc_nonzero_mask_avx512(u) : rc_nonzero_mask(u);
+                uint64_t mask = wide ? rc_nonzero_mask_avx512(u) : rc_nonzero_mask(u);
 #else
-                const uint64_t mask = rc_nonzero_mask(u);
+                uint64_t mask = rc_nonzero_mask(u);
 #endif
-                bool as_unit = (uint32_t)__builtin_popcountll(mask) > kDenseAbove; // the unit as it is is the shorter form
-                if (kTile16 && intra) { // (a DC level the int16 tile cannot hold: dense units are dequantised in int32)
-                    int16_t dc;
+                // the unit as it is is the shorter form — if the dense path's 16-bit steps can hold its levels (else: entries)
+                const bool as_unit = (uint32_t)__builtin_popcountll(mask) > kDenseAbove && rc_dense_levels_fit(u, intra);
+                if (intra && !as_unit) { // an intra block's DC rides in its block word (the int16 tile holds AC levels only)
+                    uint16_t dc;
                     memcpy(&dc, u, 2);
-                    as_unit = as_unit || dc > kRcDcInTile16 || dc < -kRcDcInTile16;
+                    bw[s] |= kBDcWord | ((uint32_t)dc << 12);
+                    mask &= ~1ull;
                 }
                 if (as_unit) {
                     any_dense = true;
+                    out.dense_blocks++;
                     bw[s] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
                     deferred[n_deferred++] = Deferred{u, s, 32};
                     continue;
@@ -316,10 +334,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 const uint32_t bits = ((uint32_t)(mb.qscale & 31) << 11) | (intra ? 0u : kENonIntra) | ((s & 7) << 8);
 #if MPG_HOST_AVX512
                 if (wide) {
-                    const uint32_t first = ne;
                     ne += rc_emit_entries_avx512(u, mask, bits, e0 + ne);
-                    if (intra && (mask & 1))
-                        e0[first] |= kEDc;
                     continue;
                 }
 #endif
@@ -327,7 +342,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                     const uint32_t pos = (uint32_t)__builtin_ctzll(left_bits);
                     uint16_t w;
                     memcpy(&w, u + pos * 2, 2);
-                    e0[ne++] = ((uint32_t)w << 16) | bits | (pos << 2) | ((intra && pos == 0) ? kEDc : 0u);
+                    e0[ne++] = ((uint32_t)w << 16) | bits | (pos << 2);
                 }
             }
         }
@@ -348,6 +363,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         h[7] = 0;
         out.chunks++;
         out.words += n_slots + ne;
+        out.blocks += n_slots;
     }
     return out;
 }
@@ -425,7 +441,7 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
         k.piece_chroma = opaque(chroma ? ~0u : 0u); // (a plain mask: the compiler must not turn `x & mask` into selects)
         k.sub_mask = chroma ? 0x30 : 0xf0;
         k.rj16 = rj * 16;
-        k.rj16_cterm = rj * 16 + (chroma ? plane * (kChromaPairs ? 64 : a.chroma_bytes) + (cj & 1) * kChromaBlockStep : (l & 1) * 256);
+        k.rj16_cterm = rj * 16 + (chroma ? plane * kChromaCrAt + (cj & 1) * kChromaBlockStep : (l & 1) * 256);
         k.wrap_shift = chroma ? 6 : 8;
         k.below = chroma ? a.mb_w * kChromaBlockStep - 64 : a.mb_w * 256 - 256;
     }
@@ -502,7 +518,8 @@ MPG_HD void rc_zero_tile(int32_t *T, int lane)
     t[1] = z;
 }
 
-// one entry: dequantise + premultiply (video.go:719-744; intra DC video.go:672), scatter to T[slot & 7][position]
+// one entry: dequantise + premultiply (video.go:719-744), scatter to T[slot & 7][position]  (an intra block's DC is not an
+// entry: rc_dc_from_word)
 MPG_HD void rc_scatter(int32_t *T, const uint8_t *lds, uint32_t e)
 {
     const uint8_t *Q = lds + kRcQtabAt;
@@ -510,29 +527,10 @@ MPG_HD void rc_scatter(int32_t *T, const uint8_t *lds, uint32_t e)
     const int32_t pm = Q[128 + ((e >> 2) & 63)];    // [position]
     const int32_t level = (int32_t)e >> 16;
     const int32_t qs = (int32_t)((e >> 11) & 31);
-    const int32_t dq = dequant(level, !(e & kENonIntra), mul24_as_written(qs, qm), pm);
-    T[(e & 0x7fcu) >> 2] = (e & kEDc) ? level * 256 : dq;
+    T[(e & 0x7fcu) >> 2] = dequant(level, !(e & kENonIntra), mul24_as_written(qs, qm), pm);
 }
 
 struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; }; // 16 bytes at dword alignment (the words array)
-#if MPG_TILE16
-MPG_HD void rc_zero_tile16(int16_t *T, int lane)
-{
-    const i32x4 z = {{0, 0, 0, 0}};
-    *reinterpret_cast<i32x4 *>(T + lane * 8) = z;
-}
-// one entry: the dequantised level (video.go:719-741) to T[slot & 7][position]; an intra DC as level * 8 — the column
-// read multiplies by the premultiplier, 32 at position 0: level * 256 (video.go:672)
-MPG_HD void rc_scatter16(int16_t *T, const uint8_t *lds, uint32_t e)
-{
-    const uint8_t *Q = lds + kRcQtabAt;
-    const int32_t qm = Q[(e & 0xfeu) >> 1];
-    const int32_t level = (int32_t)e >> 16;
-    const int32_t qs = (int32_t)((e >> 11) & 31);
-    const int32_t dq = dequant_level(level, !(e & kENonIntra), mul24_as_written(qs, qm));
-    MPG_CHECK(!(e & kEDc) || (level >= -kRcDcInTile16 && level <= kRcDcInTile16));
-    T[(e & 0x7fcu) >> 2] = (int16_t)((e & kEDc) ? level * 8 : dq);
-}
 // (byte kByte of `bytes`) * (half-word kHalf of `words`, sign-extended): unpacking is the multiplier's operand select
 template <int kByte, int kHalf> MPG_HD int32_t mul_u8_s16(uint32_t bytes, uint32_t words)
 {
@@ -551,6 +549,26 @@ template <int kByte, int kHalf> MPG_HD int32_t mul_u8_s16(uint32_t bytes, uint32
     static_assert((kByte & 1) == kHalf, "rows 2k, 2k+1 of a column: bytes 2k, 2k+1 and the two halves of word k");
     return (int32_t)((bytes >> (8 * kByte)) & 0xff) * (int32_t)(int16_t)(words >> (16 * kHalf));
 #endif
+}
+MPG_HD void rc_zero_tile16(int16_t *T, int lane)
+{
+    const i32x4 z = {{0, 0, 0, 0}};
+    *reinterpret_cast<i32x4 *>(T + lane * 8) = z;
+}
+// the int16 tile: the dequantised level (video.go:719-741) to T[slot & 7][position], |.| <= 2048
+MPG_HD void rc_scatter16(int16_t *T, const uint8_t *lds, uint32_t e)
+{
+    const uint8_t *Q = lds + kRcQtabAt;
+    const int32_t qm = Q[(e & 0xfeu) >> 1];
+    const int32_t level = (int32_t)e >> 16;
+    const int32_t qs = (int32_t)((e >> 11) & 31);
+    T[(e & 0x7fcu) >> 2] = (int16_t)dequant_level(level, !(e & kENonIntra), mul24_as_written(qs, qm));
+}
+// an intra block's DC (video.go:656-672: `<<= 3 + 5`, no matrix), from its block word: lane (g, 0), row 0 of column 0
+MPG_HD void rc_dc_from_word(uint32_t bw, int lane, int32_t (&v)[8])
+{
+    if ((bw & kBDcWord) && (lane & 7) == 0)
+        v[0] = ((int32_t)(bw << 4) >> 16) * 256;
 }
 // lane (g, j): column j of block g from the int16 tile, premultiplied (video.go:744)
 MPG_HD void rc_cols_load16(const int16_t *T, const uint8_t *lds, int lane, int32_t (&v)[8])
@@ -582,11 +600,9 @@ MPG_HD void rc_raw_cols(const VideoArgs &a, const RcChunk &c, uint32_t bw, int l
 // column c).  Three exchange steps (lane bit k against register bit k); the partner's value comes by DPP.  (Device only:
 // the emulator, which runs lane after lane, transposes at the wave level.)
 #if MPG_ON_DEVICE
-template <int kCtrl> MPG_HD int32_t dpp_quad(int32_t x) { return __builtin_amdgcn_mov_dpp(x, kCtrl, 0xf, 0xf, true); }
-#endif
-#if MPG_ON_DEVICE && defined(MPG_TRANSPOSE_ASM)
 // One exchange step inside quads, written out: 8 selects that take their other operand through DPP (v_cndmask_b32_dpp: D =
-// VCC ? src1 : dpp(src0)) instead of the 8 DPP moves + 8 selects the compiler makes of the same thing.  a[i] / b[i]: the four
+// VCC ? src1 : dpp(src0)) instead of the 8 DPP moves + 8 selects the compiler makes of the same thing (28 instead of 44 instructions per transposition:
+// profiles/r5_ab_*: +2 % typical).  a[i] / b[i]: the four
 // register pairs of this step (bit clear / set), `set_lanes`: the lanes whose bit is set.
 #define MPG_QUAD_STEP(PERM)                                                                                                          \
     asm volatile("s_nop 1\n\t"                                                                                                       \
@@ -608,7 +624,7 @@ template <int kCtrl> MPG_HD int32_t dpp_quad(int32_t x) { return __builtin_amdgc
 #endif
 MPG_HD void rc_transpose8(int32_t (&v)[8], int lane)
 {
-#if MPG_ON_DEVICE && defined(MPG_TRANSPOSE_ASM)
+#if MPG_ON_DEVICE
     (void)lane;
     {   // lane bit 0 <-> register bit 0: pairs (0,1) (2,3) (4,5) (6,7); partner = lane ^ 1
         const int32_t a[4] = {v[0], v[2], v[4], v[6]}, b[4] = {v[1], v[3], v[5], v[7]};
@@ -632,37 +648,11 @@ MPG_HD void rc_transpose8(int32_t (&v)[8], int lane)
         v[r + 4] = __builtin_amdgcn_update_dpp(b, a, 0x104, 0xf, 0x5, false);
         v[r] = __builtin_amdgcn_update_dpp(a, b, 0x114, 0xf, 0xa, false);
     }
-#elif MPG_ON_DEVICE
-    constexpr int kSwap1 = 0xB1, kSwap2 = 0x4E; // quad_perm [1,0,3,2] and [2,3,0,1]
-    constexpr int kRowShl4 = 0x104, kRowShr4 = 0x114;
-    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-#pragma unroll
-    for (int r = 0; r < 8; r += 2) { // lane bit 0 <-> register bit 0
-        const int32_t a = v[r], b = v[r + 1];
-        const int32_t pa = dpp_quad<kSwap1>(a), pb = dpp_quad<kSwap1>(b); // (by every lane: the partner reads them)
-        v[r] = b0 ? pb : a;
-        v[r + 1] = b0 ? b : pa;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) { // bit 1
-        const int r = (q & 1) | ((q & 2) << 1);
-        const int32_t a = v[r], b = v[r + 2];
-        const int32_t pa = dpp_quad<kSwap2>(a), pb = dpp_quad<kSwap2>(b);
-        v[r] = b1 ? pb : a;
-        v[r + 2] = b1 ? b : pa;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) { // bit 2: lanes 0..3 of a block take from lane + 4 (banks 0, 2), lanes 4..7 from lane - 4
-        const int32_t a = v[r], b = v[r + 4];
-        v[r + 4] = __builtin_amdgcn_update_dpp(b, a, kRowShl4, 0xf, 0x5, false);
-        v[r] = __builtin_amdgcn_update_dpp(a, b, kRowShr4, 0xf, 0xa, false);
-    }
 #else
     (void)v;
     (void)lane;
 #endif
 }
-#endif
 
 // an int32 snapshot block: its 64 values as they are, lane = position
 MPG_HD void rc_raw_fill(const VideoArgs &a, const RcChunk &c, int32_t *T, uint32_t g, uint32_t bw, int lane)
@@ -714,36 +704,57 @@ MPG_HD uint32_t pick_class_bytes(uint32_t lo, uint32_t hi, bool odd)
     return ((lo >> s) & 0xff) | (((lo >> (16 + s)) & 0xff) << 8) | (((hi >> s) & 0xff) << 16) | (((hi >> (16 + s)) & 0xff) << 24);
 #endif
 }
-#ifdef MPG_DENSE_MED3 // (next round's experiment on the dense path: "if even, one toward zero" without a compare + borrow)
-MPG_HD int32_t med3_with_zero(int32_t a, int32_t b) // the median of (a, b, 0)
+// ---- a dense unit's levels, two at a time (rows 2k, 2k + 1 of a column = the two halves of one dword).  video.go:719-744
+// on PACKED halves as far as it goes: sign(level) in {-1, 0, +1} (0 for intra blocks: no "+ sign") and u = 2 level +
+// sign(level) by three packed 16-bit instructions per pair; then per level (u, sign-extended by the multiplier's operand
+// select) * matrix byte * quantiser_scale >> 4, "if even, one toward zero" as l + ((0 - l) >> 31), and `| (level != 0)` in the
+// place of the reference's `| 1`: a zero level (not coded: the reference leaves the coefficient alone) then comes out
+// as 0 through the whole chain — u = 0, product 0, 0 | 0 — with no select at the end.  u must fit int16: the packer sends
+// blocks with a level beyond +-16383 as sparse entries (kRcDenseLevelMax; the entry path works in 32 bits).
+struct RcPair { uint32_t u, nz; }; // halves: 2 level + sign(level) / level != 0
+MPG_HD RcPair rc_dense_pair(uint32_t w, uint32_t non_intra_mask)
+{
+    RcPair p;
+#if MPG_ON_DEVICE
+    // (written out: the compiler makes compares and selects of the packed minimum, and a shift + add of the multiply-add)
+    uint32_t sg;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(p.nz) : "v"(w));
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(sg) : "v"(w));
+    sg = (sg | p.nz) & non_intra_mask;
+    asm("v_pk_mad_i16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(p.u) : "v"(w), "v"(sg));
+#else
+    p.u = p.nz = 0;
+    for (int h = 0; h < 2; h++) {
+        const int32_t level = (int16_t)(w >> (16 * h));
+        const int32_t sg = non_intra_mask ? (level > 0) - (level < 0) : 0;
+        p.nz |= (uint32_t)(level != 0) << (16 * h);
+        p.u |= (uint32_t)(uint16_t)(2 * level + sg) << (16 * h); // (wraps beyond +-16383: the packer keeps those out)
+    }
+#endif
+    return p;
+}
+template <int kHalf> MPG_HD int32_t or_half(int32_t x, uint32_t halves) // x | (half kHalf of `halves`, zero-extended)
 {
 #if MPG_ON_DEVICE
     int32_t r;
-    asm("v_med3_i32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    if (kHalf == 0)
+        asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(x), "v"(halves));
+    else
+        asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(x), "v"(halves));
     return r;
 #else
-    const int32_t lo = a < b ? a : b, hi = a < b ? b : a;
-    return 0 < lo ? lo : (0 > hi ? hi : 0);
+    return x | (int32_t)((halves >> (16 * kHalf)) & 0xffff);
 #endif
 }
-#endif
-template <int R> MPG_HD int32_t rc_dense_level(const i32x4_a4 &lv, bool intra, int32_t qs, const uint32_t (&qm)[2], const uint32_t (&pm)[2])
+template <int R> MPG_HD int32_t rc_dense_level(const RcPair &p, int32_t qs, const uint32_t (&qm)[2], const uint32_t (&pm)[2])
 {
-    const int32_t w = lv.v[R >> 1];
-    const int32_t level = (R & 1) ? (w >> 16) : (int32_t)(int16_t)(w & 0xffff);
-    // video.go:719-744, as video_lane.h: dequant()
-    int32_t l = 2 * level;
-    if (!intra)
-        l += (level >> 31) | 1;
-    l = mul24_as_written(l, mul_u8<R & 3>(qm[R >> 2], qs)) >> 4;
-#ifdef MPG_DENSE_MED3
-    l = med3_with_zero(l - 1, l) | 1; // l > 0: the median of (l - 1, l, 0) is l - 1; l <= 0: it is l
-#else
-    l = (l - (l > 0 ? 1 : 0)) | 1;
-#endif
+    int32_t l = mul24_as_written(mul_u8_s16<R & 3, R & 1>(qm[R >> 2], p.u), qs) >> 4; // |u * matrix byte| < 2^23
+    l += (int32_t)opaque((uint32_t)(0 - l)) >> 31; // l > 0: one down — then odd, or one below an odd number.  (Three plain
+                                             // half-cost instructions; the compiler's own form is a compare into a scalar
+                                             // pair and a subtract-with-borrow, two full-cost ones and a hazard nop.)
+    l = or_half<R & 1>(l, p.nz);             // "| 1" of a coded level; 0 stays 0
     l = clampi(l, -2048, 2047);
-    l = mul_u8<R & 3>(pm[R >> 2], l);
-    return level ? l : 0;
+    return mul_u8<R & 3>(pm[R >> 2], l);
 }
 // column j of a dense unit: 8 int16 levels (read apart from their use: the next pass's are fetched while this pass runs)
 MPG_HD i32x4_a4 rc_dense_read(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane)
@@ -761,14 +772,23 @@ MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, i
     const uint32_t *pmp = reinterpret_cast<const uint32_t *>(lds + kRcQtabAt + 128 + j * 8);
     const uint32_t pm[2] = {pmp[0], pmp[1]};
     const uint32_t qm[2] = {pick_class_bytes(q.v[0], q.v[1], !intra), pick_class_bytes(q.v[2], q.v[3], !intra)};
-    v[0] = rc_dense_level<0>(lv, intra, qs, qm, pm);
-    v[1] = rc_dense_level<1>(lv, intra, qs, qm, pm);
-    v[2] = rc_dense_level<2>(lv, intra, qs, qm, pm);
-    v[3] = rc_dense_level<3>(lv, intra, qs, qm, pm);
-    v[4] = rc_dense_level<4>(lv, intra, qs, qm, pm);
-    v[5] = rc_dense_level<5>(lv, intra, qs, qm, pm);
-    v[6] = rc_dense_level<6>(lv, intra, qs, qm, pm);
-    v[7] = rc_dense_level<7>(lv, intra, qs, qm, pm);
+    const uint32_t non_intra_mask = (uint32_t)((int32_t)bw >> 31);
+#if !MPG_ON_DEVICE
+    for (int r = (intra && j == 0) ? 1 : 0; r < 8; r++) {
+        const int32_t level = (int16_t)((uint32_t)lv.v[r >> 1] >> (16 * (r & 1)));
+        MPG_CHECK(level >= -kRcDenseLevelMax && level <= kRcDenseLevelMax);
+    }
+#endif
+    const RcPair p0 = rc_dense_pair((uint32_t)lv.v[0], non_intra_mask), p1 = rc_dense_pair((uint32_t)lv.v[1], non_intra_mask);
+    const RcPair p2 = rc_dense_pair((uint32_t)lv.v[2], non_intra_mask), p3 = rc_dense_pair((uint32_t)lv.v[3], non_intra_mask);
+    v[0] = rc_dense_level<0>(p0, qs, qm, pm);
+    v[1] = rc_dense_level<1>(p0, qs, qm, pm);
+    v[2] = rc_dense_level<2>(p1, qs, qm, pm);
+    v[3] = rc_dense_level<3>(p1, qs, qm, pm);
+    v[4] = rc_dense_level<4>(p2, qs, qm, pm);
+    v[5] = rc_dense_level<5>(p2, qs, qm, pm);
+    v[6] = rc_dense_level<6>(p3, qs, qm, pm);
+    v[7] = rc_dense_level<7>(p3, qs, qm, pm);
     if (intra && j == 0)
         v[0] = (int32_t)(int16_t)(lv.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
 }
@@ -869,26 +889,18 @@ MPG_HD void rc_rmw(uint8_t *lds, uint32_t bw, int lane, const int32_t (&v)[8])
 // ---- step 5: stores (tiled frame: a macroblock's luma is 256 contiguous bytes, its Cb and Cr 64 each)
 MPG_HD uint32_t rc_mb_index(const VideoArgs &a, uint32_t d0) { return (d0 >> 24) * a.mb_w + ((d0 >> 16) & 0xff); }
 
-// horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), Cb and Cr 256 bytes each by lanes 0..31.
-// kStream: as non-temporal stores — the picture is next read by a later launch; the prediction windows of the neighbouring
-// chunks, which ARE read again within microseconds, keep their place in L2 (profiles/r4z_ab_non_temporal_frame_stores.txt:
-// typical +1.9 %, dense +0.3 %; on the fused-RGBA instance nothing measurable, it keeps plain stores)
-template <bool kStream = false>
+// horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), the four Cb | Cr pairs 512 bytes by lanes
+// 0..31, as they lie in the O_m.  Non-temporal stores: the picture is next read by a later launch; the prediction windows
+// of the neighbouring chunks, which ARE read again within microseconds, keep their place in L2
+// (profiles/r4z_ab_non_temporal_frame_stores.txt: typical +1.9 %, dense +0.3 %; the fused-RGBA instance likewise, with its
+// RGBA stores: profiles/r5_ab_*: +3.8 % / +1.6 %)
 MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
 {
     const uint32_t l = (uint32_t)lane, mb0 = rc_mb_index(a, c.r[0][0]);
-    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + (uint64_t)mb0 * 64; // wave-uniform
-    store16_at<kStream>(cur + (uint64_t)mb0 * 192, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
-    if (lane < 32) {
-        if (kChromaPairs) { // 4 x (Cb | Cr) = 512 contiguous bytes, as they lie in the O_m
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 3) + 256 + (l & 7) * 16);
-            store16_at<kStream>(cur + a.luma_bytes + (uint64_t)mb0 * 64, l * 16, v); // (cur is mb0 * 64 in already)
-        } else {
-            const uint32_t plane = l >> 4, m = (l >> 2) & 3, part = l & 3;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + rc_win_at(m) + 256 + plane * 64 + part * 16);
-            store16_at<kStream>(cur + a.luma_bytes, (a.chroma_bytes & (0u - plane)) + (l & 15) * 16, v);
-        }
-    }
+    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + (uint64_t)mb0 * 128; // wave-uniform
+    store16_at<true>(cur + (uint64_t)mb0 * 128, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
+    if (lane < 32)
+        store16_at<true>(cur + a.luma_bytes, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 3) + 256 + (l & 7) * 16));
 }
 
 // any other chunk: macroblock m by lanes (block b = lane>>3, row j = lane&7), 8 bytes each.  An invalid intra
@@ -906,7 +918,7 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
     if (b < 4)
         off = mb * 256 + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 16 + ((uint32_t)(b & 1) << 3);
     else
-        off = a.luma_bytes + (uint32_t)(b - 4) * (kChromaPairs ? 64 : a.chroma_bytes) + mb * kChromaBlockStep + (uint32_t)j * 8;
+        off = a.luma_bytes + (uint32_t)(b - 4) * kChromaCrAt + mb * kChromaBlockStep + (uint32_t)j * 8;
     uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + off;
     uint8_t *t = lds + rc_tile_offset(b, j, m);
     if (written)
@@ -934,11 +946,7 @@ MPG_HD void rc_rgba_quad(const VideoArgs &a, const RcChunk &c, uint32_t m, uint3
     const uint64_t p = (uint64_t)py * a.width + px0;
     const uint32_t n = a.width - px0 >= 4 ? 4 : a.width - px0;
     uint8_t *img = a.rgba + ((uint64_t)c.h[1] << 8);
-#ifdef MPG_NT_RGBA_FUSED // (next round's experiment: r4z could not tell it from the box's drift; default: off)
-    rgba_store4<true>(reinterpret_cast<uint32_t *>(img) + p, p, px, n);
-#else
-    rgba_store4<false>(reinterpret_cast<uint32_t *>(img) + p, p, px, n);
-#endif
+    rgba_store4<true>(reinterpret_cast<uint32_t *>(img) + p, p, px, n); // (non-temporal: rc_store_run)
 }
 MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *lds)
 {

@@ -21,8 +21,8 @@ _variant = ("", ())
 
 
 def select(tag="", flags=()):
-    """Switch the emulator to a build of the lane headers with other options (a layout option such as
-    -DMPG_CHROMA_PAIRS=1); select() goes back to the product's."""
+    """Switch the emulator to a build of the lane headers with other compile-time options (-D...); select() goes back to
+    the product's."""
     global _lib, _variant
     _variant = (tag, tuple(flags))
     _lib = _libs.get(tag)
@@ -50,6 +50,8 @@ def lib():
         P = C.c_void_p
         L.emu_video_run.restype = C.c_int
         L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
+        L.emu_set_tile_policy.restype = None
+        L.emu_set_tile_policy.argtypes = [C.c_int]
         L.emu_make_qtable.restype = None
         L.emu_make_qtable.argtypes = [P, P, P]
         for f in (L.emu_pack, L.emu_pack_narrow):
@@ -72,6 +74,12 @@ def lib():
         L.emu_ycbcr.argtypes = [C.c_uint32] * 3
         _lib = _libs[_variant[0]] = L
     return _lib
+
+
+def set_tile_policy(policy=0):
+    """Which instance of the reconstruction kernel the emulator runs (mpeghip_video_set_tile_policy): 0 = the library's
+    per-batch rule, 1 = int16 coefficient tile, 2 = int32 tile."""
+    lib().emu_set_tile_policy(policy)
 
 
 def _ptr(a):

@@ -40,7 +40,10 @@ static uint32_t emu_pack_as(uint32_t luma_w, uint32_t luma_h, uint64_t frame_str
     *n_words = got.words;
     return got.chunks;
 }
+static int g_tile_policy = 0; // as mpeghip_video_set_tile_policy: 0 = pick per submit like launch_batch, 1 = int16 tile, 2 = int32 tile
 extern "C" {
+
+void emu_set_tile_policy(int policy) { g_tile_policy = policy; }
 
 // one stream's dequantisation table in the device layout (what mpeghip_video_open / _set_quant upload)
 void emu_make_qtable(uint8_t *out, const uint8_t *intra, const uint8_t *non_intra) { rc_make_qtable(out, intra, non_intra, kPremult); }
@@ -85,12 +88,19 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     }
     std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1), words(rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
     uint32_t nc = 0, nw = 0;
+    uint64_t coded = 0, dense = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
         const RcPacked got = rc_pack_picture(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
                                              chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw);
         nc += got.chunks;
         nw += got.words;
+        coded += got.blocks;
+        dense += got.dense_blocks;
     }
+    // which kernel instance: the product's rule (mpeghip.hip: launch_batch), unless a test pins one
+    bool t16 = !any_rgba && dense * 4 <= coded;
+    if (g_tile_policy)
+        t16 = g_tile_policy == 1;
     a.pics = pics;
     a.chunks = chunks.data();
     a.words = words.data();
@@ -101,14 +111,11 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     a.rgba = rgba;
     a.rgba_stride = rgba_stride;
 
-    alignas(16) uint8_t lds[kRcLdsBytes]; // (no statics: ShardedVideoBatch tests run two emulator stores on two threads)
+    alignas(16) uint8_t lds[kRcLdsBytesMax]; // (no statics: ShardedVideoBatch tests run two emulator stores on two threads)
     for (uint32_t chunk = 0; chunk < nc; chunk++) {
         memset(lds, 0xCD, sizeof(lds)); // poison: reads of unwritten LDS must not matter
-#if MPG_TILE16
-        int16_t *T = reinterpret_cast<int16_t *>(lds + kRcTileAt);
-#else
         int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
-#endif
+        int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt);
         const RcChunk c = rc_load_chunk(a, chunk);
         const uint32_t n_blocks = rc_n_blocks(c);
         RcLane k[64];
@@ -132,45 +139,47 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
             const uint32_t np = rc_pass_entries(c, pass);
             for (int lane = 0; lane < 64; lane++)
                 bw[lane] = rc_blk_src(a, c)[rc_blk_lane_offset(pass, lane) / 4];
-#if MPG_TILE16
-            if (np) {
+            if (t16) {
+                if (np) {
+                    for (int lane = 0; lane < 64; lane++)
+                        rc_zero_tile16(T16, lane);
+                    for (uint32_t r = 0; r < np; r += 64)
+                        for (int lane = 0; lane < 64; lane++) {
+                            if (pass > 0 || r > 0)
+                                e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
+                            if (r + (uint32_t)lane < np)
+                                rc_scatter16(T16, lds, e[lane]);
+                        }
+                    ent_at += np;
+                }
+                for (int lane = 0; lane < 64; lane++) {
+                    const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
+                    if (np)
+                        rc_cols_load16(T16, lds, lane, v[lane]);
+                    else
+                        for (int r = 0; r < 8; r++)
+                            v[lane][r] = 0;
+                    if (mine)
+                        rc_dc_from_word(bw[lane], lane, v[lane]);
+                    if (rc_any_raw(c) && mine && (bw[lane] & kBRaw))
+                        rc_raw_cols(a, c, bw[lane], lane, v[lane]);
+                    if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
+                        rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
+                    idct8<false>(v[lane]);
+                }
+                for (int g = 0; g < 8; g++) { // the kernel's transposition across the block's 8 lanes: lane j leaves with row j
+                    int32_t m[8][8];
+                    for (int j = 0; j < 8; j++)
+                        for (int r = 0; r < 8; r++)
+                            m[r][j] = v[g * 8 + j][r];
+                    for (int j = 0; j < 8; j++)
+                        for (int col = 0; col < 8; col++)
+                            v[g * 8 + j][col] = m[j][col];
+                }
                 for (int lane = 0; lane < 64; lane++)
-                    rc_zero_tile16(T, lane);
-                for (uint32_t r = 0; r < np; r += 64)
-                    for (int lane = 0; lane < 64; lane++) {
-                        if (pass > 0 || r > 0)
-                            e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
-                        if (r + (uint32_t)lane < np)
-                            rc_scatter16(T, lds, e[lane]);
-                    }
-                ent_at += np;
+                    idct8<true>(v[lane]);
+                return;
             }
-            for (int lane = 0; lane < 64; lane++) {
-                const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
-                if (np)
-                    rc_cols_load16(T, lds, lane, v[lane]);
-                else
-                    for (int r = 0; r < 8; r++)
-                        v[lane][r] = 0;
-                if (rc_any_raw(c) && mine && (bw[lane] & kBRaw))
-                    rc_raw_cols(a, c, bw[lane], lane, v[lane]);
-                if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
-                    rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
-                idct8<false>(v[lane]);
-            }
-            for (int g = 0; g < 8; g++) { // the kernel's transposition across the block's 8 lanes: lane j leaves with row j
-                int32_t m[8][8];
-                for (int j = 0; j < 8; j++)
-                    for (int r = 0; r < 8; r++)
-                        m[r][j] = v[g * 8 + j][r];
-                for (int j = 0; j < 8; j++)
-                    for (int col = 0; col < 8; col++)
-                        v[g * 8 + j][col] = m[j][col];
-            }
-            for (int lane = 0; lane < 64; lane++)
-                idct8<true>(v[lane]);
-            return;
-#else
             bool from_tile = true; // (as the kernel: a pass of dense units only does not go through the tile)
             if (rc_any_dense(c) && np == 0 && !rc_any_raw(c)) {
                 from_tile = false;
@@ -198,12 +207,15 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                     }
             }
             for (int lane = 0; lane < 64; lane++) {
+                const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
                 if (from_tile)
                     rc_cols_load(T, lane, v[lane]);
                 else
                     for (int r = 0; r < 8; r++)
                         v[lane][r] = 0;
-                if (rc_any_dense(c) && pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw[lane] & kBDense))
+                if (mine)
+                    rc_dc_from_word(bw[lane], lane, v[lane]);
+                if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
                     rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
                 idct8<false>(v[lane]);
             }
@@ -213,7 +225,6 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
                 rc_rows_load(T, lane, v[lane]);
                 idct8<true>(v[lane]);
             }
-#endif
         };
         auto add_residual = [&](uint32_t pass) {
             for (int lane = 0; lane < 64; lane++)

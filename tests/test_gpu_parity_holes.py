@@ -23,7 +23,8 @@ def device():
 def test_config5_shard_1024_streams_of_1080p(oracle, hip_ctx):
     """BASELINE config 5's single-GPU shard at FULL size: 1024 independent 1080p streams resident on one MI355X (9.7 GB of
     frame store), one picture each per launch, I P B B; every stream's three slots against the oracle's replay by the
-    device-side FNV-1a-64 (the byte order TestVideoGolden hashes, mpeg_test.go:221-223)."""
+    device-side FNV-1a-64 (the byte order TestVideoGolden hashes, mpeg_test.go:221-223); then four far-apart streams
+    with their own content, each against its own oracle replay."""
     w, h, n_streams = 1920, 1080, 1024
     seq = synth.generate_sequence(w, h, 4, seed=0x5a5a)
     ref, dut = oracle.OracleStore(w, h, threads=4), abi.VideoStore(hip_ctx, w, h, n_streams)
@@ -45,6 +46,17 @@ def test_config5_shard_1024_streams_of_1080p(oracle, hip_ctx):
         for st in (0, 517, n_streams - 1):
             for slot in range(3):
                 assert_planes_equal(ref.read_planes(0, slot), dut.read_planes(st, slot), "stream %d slot %d" % (st, slot))
+        # So far every stream holds the same bytes: a per-stream base that is off by a stream (replicate_kernel's shifts, the
+        # packer's frame offsets beyond 4 GB) would still read identical data.  Streams 0, 1, 517 and 1023 get their OWN
+        # reference content, the P and B pictures run once more, each of them against its own oracle replay
+        # (oracle/crosscheck.py; profiles/r6_cross_stream_check_catches_a_shifted_base.txt: it fails on a library whose
+        # reference base of stream 517 is stream 516's).
+        from oracle import crosscheck
+        batches = [dut.upload(s.pics, s.mbs, s.coefs, replicate=n_streams) for s in seq]
+        ok, text = crosscheck.distinct_content_check(dut, w, h, desc.geometry(w, h), n_streams, seq, batches)
+        for b in batches:
+            b.free()
+        assert ok, text
     finally:
         dut.close()
         ref.close()

@@ -1,27 +1,21 @@
-"""Build-time options of the reconstruction kernel — the frame store's chroma layout (mpeg_amd/csrc/video_lane.h) and the
-int16 coefficient tile (video_recon_lane.h) — keep the reference's results bit for bit:
-the lane emulator built with the option must reproduce the oracle on the same cases as the product's layout — prediction
-windows, windows that leave their plane (the linear reads), stores of runs and of single macroblocks, the fused and the
-whole-frame RGBA, plane write / read round trips.  (The options are not built into the product until they are measured.)"""
+"""The two instances of the reconstruction kernel (video_recon_lane.h: int16 coefficient tile + transposition across lanes,
+int32 tile + transposition through LDS; the library picks one per batch, mpeghip_video_set_tile_policy pins one) keep the
+reference's results bit for bit on the same cases: prediction windows, windows that leave their plane (the linear reads),
+stores of runs and of single macroblocks, the fused and the whole-frame RGBA, snapshot blocks, dense units."""
 import numpy as np
 import pytest
 
 from mpeg_amd import desc, synth
 from parity import run_and_compare
 
-LAYOUTS = [("chroma_pairs", ("-DMPG_CHROMA_PAIRS=1",)),
-           ("tile16", ("-DMPG_TILE16=1",)),                      # int16 coefficient tile, transposition across lanes
-           ("tile16_chroma_pairs", ("-DMPG_TILE16=1", "-DMPG_CHROMA_PAIRS=1")),
-           ("dense_med3", ("-DMPG_DENSE_MED3",))]                 # dense units: the oddification by a median
+TILES = [("int16", 1), ("int32", 2)]
 
 
-@pytest.fixture(params=LAYOUTS, ids=[t for t, _ in LAYOUTS])
+@pytest.fixture(params=TILES, ids=[t for t, _ in TILES])
 def emu_layout(request, emu):
-    tag, flags = request.param
-    emu.select(tag, flags)
-    emu.lib()
+    emu.set_tile_policy(request.param[1])
     yield emu
-    emu.select()
+    emu.set_tile_policy(0)
 
 
 @pytest.mark.parametrize("w,h,n,profile,raw,rgba", [
@@ -52,34 +46,27 @@ def test_layout_option_standalone_rgba_and_plane_round_trip(oracle, emu_layout, 
     assert np.array_equal(o.read_rgba(0, 1), e.read_rgba(0, 1))
 
 
-def test_layout_option_is_in_effect(emu):
-    """chroma_pairs: Cb and Cr of macroblock i lie side by side behind the luma plane (128 bytes per macroblock); the
-    product's layout keeps two planes of 64-byte blocks."""
+def test_the_frame_store_keeps_cb_and_cr_of_a_macroblock_side_by_side(emu):
+    """video_lane.h: Cb and Cr of macroblock i lie side by side behind the luma plane (128 bytes per macroblock = one cache
+    line for both planes of a prediction window's macroblock)."""
     w, h = 64, 32
     g = desc.geometry(w, h)
     L, C = g["luma_bytes"], g["chroma_bytes"]
     y = np.zeros(L, np.uint8)
     cb, cr = np.full(C, 0xB0, np.uint8), np.full(C, 0xC0, np.uint8)
     cb[:8] = np.arange(8)                                        # row 0 of the first block of Cb
-    raw = {}
-    for tag, flags in [("", ())] + LAYOUTS[:1]:
-        emu.select(tag, flags)
-        try:
-            e = emu.EmuStore(w, h)
-            e.write_planes(0, 0, y, cb, cr)
-            raw[tag] = e.frames[:L + 2 * C].copy()
-        finally:
-            emu.select()
-    plain, pairs = raw[""][L:], raw["chroma_pairs"][L:]
-    assert list(plain[:8]) == list(range(8)) and list(pairs[:8]) == list(range(8))
-    assert (plain[8:C] == 0xB0).all() and (plain[C:] == 0xC0).all()            # plane after plane
+    e = emu.EmuStore(w, h)
+    e.write_planes(0, 0, y, cb, cr)
+    pairs = e.frames[L:L + 2 * C]
+    assert list(pairs[:8]) == list(range(8))
     blocks = pairs.reshape(-1, 2, 64)
     assert (blocks[:, 1] == 0xC0).all() and (blocks[1:, 0] == 0xB0).all()      # Cb | Cr per macroblock
 
 
-def test_tile16_takes_an_oversized_intra_dc_as_a_dense_unit(oracle, emu):
-    """An intra DC level beyond +-4095 does not fit the int16 tile (level * 8): the packer sends such a block as a dense
-    unit, which is dequantised in int32.  Levels the parser never produces, but the ABI takes any int16."""
+def test_any_intra_dc(oracle, emu_layout):
+    """The int16 tile holds dequantised AC levels only (|.| <= 2048); an intra block's DC — any int16 through the ABI,
+    `<< 8` in the reference (video.go:672) — rides in the block's word of the device format (sparse blocks) or is read
+    from the unit (dense blocks)."""
     w, h = 64, 48
     seq = synth.generate_sequence(w, h, 4, seed=21)
     hit = 0
@@ -90,37 +77,54 @@ def test_tile16_takes_an_oversized_intra_dc_as_a_dense_unit(oracle, emu):
                 units[mb["coef_off"], 0] = (4096, -4096, 4095, -4095, 32767, -32768)[hit % 6]
                 hit += 1
     assert hit >= 6
-    for tag, flags in [("", ()), LAYOUTS[1]]:
-        emu.select(tag, flags)
-        try:
-            run_and_compare(oracle.OracleStore(w, h), emu.EmuStore(w, h), seq)
-        finally:
-            emu.select()
+    run_and_compare(oracle.OracleStore(w, h), emu_layout.EmuStore(w, h), seq)
 
 
-@pytest.mark.parametrize("variant", [("", ()), LAYOUTS[1]], ids=["product", "tile16"])
-def test_levels_over_the_whole_int16_range(oracle, emu, variant):
+def test_levels_over_the_whole_int16_range(oracle, emu_layout):
     """The ABI takes any int16 level, any quantiser_scale 1..31 and any matrix bytes — far beyond what MPEG-1 codes
     (+-255): every third non-zero level of every block replaced by extremes, both kernels' arithmetic against the oracle."""
     rng = np.random.default_rng(5)
-    emu.select(*variant)
-    try:
-        for trial in range(4):
-            w, h = 96, 64
-            seq = synth.generate_sequence(w, h, 3, seed=100 + trial, profile="typical" if trial % 2 else "dense")
-            for sub in seq:
-                units = sub.coefs.view(np.int16).reshape(-1, 64)
-                for u in range(len(units)):
-                    nz = np.nonzero(units[u])[0]
-                    if len(nz):
-                        pick = rng.choice(nz, size=max(1, len(nz) // 3), replace=False)
-                        units[u, pick] = rng.choice([32767, -32768, 2047, -2048, 256, -256, 1, -1, 12345, -23456], size=len(pick)).astype(np.int16)
-                sub.mbs["qscale"] = rng.choice([1, 31, 17], size=len(sub.mbs))
-            o, e = oracle.OracleStore(w, h), emu.EmuStore(w, h)
-            if trial >= 2:
-                iq, nq = rng.integers(1, 256, 64), rng.integers(1, 256, 64)
-                o.set_quant(0, iq, nq)
-                e.set_quant(0, iq, nq)
-            run_and_compare(o, e, seq)
-    finally:
-        emu.select()
+    for trial in range(4):
+        w, h = 96, 64
+        seq = synth.generate_sequence(w, h, 3, seed=100 + trial, profile="typical" if trial % 2 else "dense")
+        for sub in seq:
+            units = sub.coefs.view(np.int16).reshape(-1, 64)
+            for u in range(len(units)):
+                nz = np.nonzero(units[u])[0]
+                if len(nz):
+                    pick = rng.choice(nz, size=max(1, len(nz) // 3), replace=False)
+                    units[u, pick] = rng.choice([32767, -32768, 2047, -2048, 256, -256, 1, -1, 12345, -23456], size=len(pick)).astype(np.int16)
+            sub.mbs["qscale"] = rng.choice([1, 31, 17], size=len(sub.mbs))
+        o, e = oracle.OracleStore(w, h), emu_layout.EmuStore(w, h)
+        if trial >= 2:
+            iq, nq = rng.integers(1, 256, 64), rng.integers(1, 256, 64)
+            o.set_quant(0, iq, nq)
+            e.set_quant(0, iq, nq)
+        run_and_compare(o, e, seq)
+
+
+def test_dense_units_with_zeros_large_levels_and_extreme_matrices(oracle, emu_layout):
+    """The dense path works on packed 16-bit halves (2 level + sign must fit: the packer keeps levels beyond +-16383 out of
+    it), takes a zero level through the whole chain as 0, and multiplies by any matrix byte, 0 and 1 included."""
+    rng = np.random.default_rng(9)
+    for trial in range(4):
+        w, h = 96, 64
+        seq = synth.generate_sequence(w, h, 3, seed=300 + trial, profile="dense")
+        n_dense = 0
+        for sub in seq:
+            units = sub.coefs.view(np.int16).reshape(-1, 64)
+            for u in range(len(units)):
+                pick = rng.choice(64, size=24, replace=False)
+                beyond = [16384, -16384] if u % 5 == 0 else []   # (one unit in five: beyond the dense path -> entries)
+                units[u, pick] = rng.choice([16383, -16383, 8191, -8192, 255, -255, 1, -1, 0, 0, 0] + beyond,
+                                            size=len(pick)).astype(np.int16)
+                n_dense += int(np.count_nonzero(units[u]) > 32 and np.abs(units[u, 1:].astype(np.int32)).max() <= 16383)
+            sub.mbs["qscale"] = rng.choice([1, 2, 31, 17], size=len(sub.mbs))
+        assert n_dense > 100
+        o, e = oracle.OracleStore(w, h), emu_layout.EmuStore(w, h)
+        if trial >= 1:
+            iq = rng.choice([0, 1, 2, 16, 255], size=64) if trial == 1 else rng.integers(0, 256, 64)
+            nq = rng.choice([0, 1, 3, 16, 255], size=64) if trial == 1 else rng.integers(0, 256, 64)
+            o.set_quant(0, iq, nq)
+            e.set_quant(0, iq, nq)
+        run_and_compare(o, e, seq)

@@ -21,7 +21,7 @@ for lib in tools/ab/libmpeghip_*.so; do
   fi
 done
 cp /tmp/lib_product.so mpeg_amd/libmpeghip.so
-PROFILES="typical dense" bash tools/gpu_ab_lib.sh $TAG $ROUNDS --steps 26 --warmup 13
+SKIP="${SKIP1:-fused}" PROFILES="typical dense" bash tools/gpu_ab_lib.sh $TAG $ROUNDS --steps 26 --warmup 13
 PROFILES="typical dense" bash tools/gpu_ab_lib.sh ${TAG}_rgba $ROUNDS --steps 26 --warmup 13 --rgba 1
 python - <<PY
 import re, collections

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-ab}; ROUNDS=${2:-2}; shift 2 || true
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 cp mpeg_amd/libmpeghip.so /tmp/lib_cur.so
-VARIANTS="cur $(ls tools/ab/libmpeghip_*.so 2>/dev/null | sed 's/.*libmpeghip_\(.*\)\.so/\1/')"
+VARIANTS="cur $(ls tools/ab/libmpeghip_*.so 2>/dev/null | sed 's/.*libmpeghip_\(.*\)\.so/\1/' | grep -v -E "${SKIP:-^$}")"
 for r in $(seq 1 $ROUNDS); do
   for which in $VARIANTS; do
     if [ $which = cur ]; then cp /tmp/lib_cur.so mpeg_amd/libmpeghip.so; else cp tools/ab/libmpeghip_$which.so mpeg_amd/libmpeghip.so; fi
