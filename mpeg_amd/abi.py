@@ -52,6 +52,9 @@ SYMBOLS = {
     "mpeghip_video_stage_begin": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_void_p)]),
     "mpeghip_video_stage_put": (C.c_int, [_P, C.c_uint32, _P, _P, _P]),
     "mpeghip_video_stage_commit": (C.c_int, [_P]),
+    "mpeghip_video_stage_begin_sparse": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_void_p)]),
+    "mpeghip_video_stage_put_sparse": (C.c_int, [_P, C.c_uint32, _P, _P, _P]),
+    "mpeghip_video_submit_sparse": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_size_t]),
     "mpeghip_video_batch_upload": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.POINTER(_P)]),
     "mpeghip_video_batch_upload_replicated": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     "mpeghip_video_batch_run": (C.c_int, [_P, _P]),
@@ -208,6 +211,37 @@ class VideoStore:
             for i in range(len(parts)):
                 put(i)
         _check(self.lib.mpeghip_video_stage_commit(st))  # reports the first failed put, launches nothing then
+        return rcs
+
+    def submit_sparse(self, pic, mbs, words):
+        """One picture in the sparse hand-over form (desc.to_sparse)."""
+        p = np.ascontiguousarray(np.asarray(pic).reshape(1), dtype=desc.PIC_DTYPE)
+        m = np.ascontiguousarray(mbs, dtype=desc.MB_DTYPE)
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        _check(self.lib.mpeghip_video_submit_sparse(self.h, _ptr(p), _ptr(m), len(m), _ptr(w), len(w)))
+
+    def submit_staged_sparse(self, pictures, threads: int = 1):
+        """submit_staged with every picture in the sparse form: pictures = [(pic, mbs, words)]."""
+        parts = [(np.ascontiguousarray(np.asarray(p).reshape(1), dtype=desc.PIC_DTYPE), np.ascontiguousarray(m, dtype=desc.MB_DTYPE),
+                  np.ascontiguousarray(w, dtype=np.uint32)) for p, m, w in pictures]
+        n_mbs = np.array([len(m) for _, m, _ in parts], np.uint32)
+        n_words = np.array([len(w) for _, _, w in parts], np.uint64)  # size_t
+        st = C.c_void_p()
+        _check(self.lib.mpeghip_video_stage_begin_sparse(self.h, len(parts), _ptr(n_mbs), _ptr(n_words), C.byref(st)))
+        rcs = [0] * len(parts)
+
+        def put(i):
+            p, m, w = parts[i]
+            rcs[i] = self.lib.mpeghip_video_stage_put_sparse(st, i, _ptr(p), _ptr(m), _ptr(w))
+
+        if threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(put, range(len(parts))))
+        else:
+            for i in range(len(parts)):
+                put(i)
+        _check(self.lib.mpeghip_video_stage_commit(st))
         return rcs
 
     def upload(self, pics, mbs, coefs, replicate: int = 1) -> Batch:

@@ -571,7 +571,8 @@ struct mpeghip_stage {
     uint32_t n_pics = 0, n_mbs = 0, n_chunks = 0;
     std::vector<uint32_t> mb_first, mb_count;   // per picture: its macroblocks [mb_first, mb_first + mb_count)
     std::vector<uint32_t> chunk_first;          // per picture: its first chunk
-    std::vector<uint64_t> units;                // per picture: its coefficient units
+    bool sparse = false;                        // begun by mpeghip_video_stage_begin_sparse: puts bring words, not units
+    std::vector<uint64_t> units;                // per picture: its coefficient units (sparse: its dwords)
     std::vector<uint64_t> alg;                  // per picture, written by its put
     std::vector<uint32_t> blocks, dense;        // per picture, written by its put: coded blocks / dense units
     std::vector<PicUse> use;                    // per picture, written by its put
@@ -1365,8 +1366,8 @@ int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_
     return MPEGHIP_OK;
 }
 
-int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
-                              mpeghip_stage **out)
+static int stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes, bool sparse,
+                       mpeghip_stage **out)
 {
     if (!v || !out || (n_pics && (!n_mbs || !coef_bytes)))
         return fail(MPEGHIP_ERR_INVALID, "stage_begin: NULL argument");
@@ -1375,6 +1376,7 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
     HIP_TRY(hipSetDevice(v->ctx->device));
     std::unique_ptr<mpeghip_stage> s(new mpeghip_stage);
     s->v = v;
+    s->sparse = sparse;
     s->n_pics = n_pics;
     s->mb_first.resize(n_pics);
     s->mb_count.assign(n_mbs, n_mbs + n_pics);
@@ -1389,14 +1391,15 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
         s->done[i].store(0);
     uint64_t mbs = 0, chunks = 0, words = 0; // words: worst case (every coefficient of every unit non-zero)
     for (uint32_t i = 0; i < n_pics; i++) {
-        if (coef_bytes[i] % MPEGHIP_COEF_UNIT)
-            return fail(MPEGHIP_ERR_INVALID, "stage_begin: picture %u: coef_bytes %zu is not a multiple of 128", i, coef_bytes[i]);
+        if (coef_bytes[i] % (sparse ? 4 : MPEGHIP_COEF_UNIT))
+            return fail(MPEGHIP_ERR_INVALID, "stage_begin: picture %u: %zu coefficient bytes is not a multiple of %d", i, coef_bytes[i],
+                        sparse ? 4 : MPEGHIP_COEF_UNIT);
         s->mb_first[i] = (uint32_t)mbs;
         s->chunk_first[i] = (uint32_t)chunks;
-        s->units[i] = coef_bytes[i] / MPEGHIP_COEF_UNIT;
+        s->units[i] = coef_bytes[i] / (sparse ? 4 : MPEGHIP_COEF_UNIT);
         mbs += n_mbs[i];
         chunks += rc_max_chunks(n_mbs[i]);
-        words += rc_max_words(s->units[i]);
+        words += sparse ? rc_max_words_sparse(s->units[i], n_mbs[i]) : rc_max_words(s->units[i]);
         if (mbs > 0xffffffffull || words > 0xffffffffull - kRcWordsPad)
             return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
     }
@@ -1422,12 +1425,34 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
     return MPEGHIP_OK;
 }
 
+int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
+                              mpeghip_stage **out)
+{
+    return stage_begin(v, n_pics, n_mbs, coef_bytes, false, out);
+}
+
+int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
+                                     mpeghip_stage **out)
+{
+    if (!n_words && n_pics)
+        return fail(MPEGHIP_ERR_INVALID, "stage_begin: NULL argument");
+    std::vector<size_t> bytes(n_pics);
+    for (uint32_t i = 0; i < n_pics; i++) {
+        if (n_words[i] > 0x3fffffffu)
+            return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
+        bytes[i] = n_words[i] * 4;
+    }
+    return stage_begin(v, n_pics, n_mbs, bytes.data(), true, out);
+}
+
 // Thread-safe for distinct i: touches only picture i's part of the staging buffer and of the stage's arrays.
-int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
-                            const void *coefs)
+static int stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, const void *coefs,
+                     bool sparse)
 {
     if (!s || !pic)
         return fail(MPEGHIP_ERR_INVALID, "stage_put: NULL argument");
+    if (s->sparse != sparse)
+        return fail(MPEGHIP_ERR_INVALID, "stage_put: the stage was begun for %s pictures", s->sparse ? "sparse" : "dense");
     int rc = MPEGHIP_OK;
     do {
         if (i >= s->n_pics) {
@@ -1457,17 +1482,29 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         uint64_t alg = 0;
         static thread_local std::vector<uint64_t> seen;
         uint64_t named_units = 0;
-        if ((rc = validate_picture(v->info, pd, i, mbs, n, 0, s->units[i], &alg, &s->use[i], seen, &named_units)) != MPEGHIP_OK)
+        // (sparse: the coefficient extents are in the words themselves: rc_sparse_check instead of the unit arithmetic)
+        const uint64_t unit_room = sparse ? ~0ull >> 2 : s->units[i];
+        if ((rc = validate_picture(v->info, pd, i, mbs, n, 0, unit_room, &alg, &s->use[i], seen, &named_units)) != MPEGHIP_OK)
             break;
+        if (sparse) {
+            const uint32_t bad = rc_sparse_check(mbs, n, static_cast<const uint32_t *>(coefs), s->units[i]);
+            if (bad) {
+                rc = fail(MPEGHIP_ERR_INVALID, "stage_put_sparse: picture %u, macroblock %u: malformed block data (a count beyond 64, a "
+                          "block beyond the words, a position twice, stray bits in a pair, or an intra block without its DC first)", i, bad - 1);
+                break;
+            }
+        }
         // the picture in the device format: its chunks go where they belong; its words are packed in this thread's
         // scratch memory first, because the room they need is only known afterwards
         static thread_local std::vector<uint32_t> scratch;
-        const size_t worst = rc_max_words(s->units[i]) + 64;
+        const size_t worst = (sparse ? rc_max_words_sparse(s->units[i], n) : rc_max_words(s->units[i])) + 64;
         if (scratch.size() < worst)
             scratch.resize(worst + worst / 4 + 1024);
         uint32_t *chunks = reinterpret_cast<uint32_t *>(h + s->c_at) + (size_t)s->chunk_first[i] * kRcChunkDwords;
-        const RcPacked got = rc_pack_picture(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0, chunks,
-                                             scratch.data());
+        const RcPacked got = sparse ? rc_pack_picture<true, true>(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0,
+                                                                  chunks, scratch.data())
+                                    : rc_pack_picture(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0, chunks,
+                                                      scratch.data());
         const uint64_t at = s->words_used.fetch_add(got.words);
         if (at + got.words > s->words_cap) { // (cannot happen: every picture is put once and stays within its worst case)
             rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: the staging buffer is full", i);
@@ -1488,6 +1525,37 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         }
     }
     return rc;
+}
+
+int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
+                            const void *coefs)
+{
+    return stage_put(s, i, pic, mbs, coefs, false);
+}
+
+int mpeghip_video_stage_put_sparse(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
+                                   const uint32_t *words)
+{
+    return stage_put(s, i, pic, mbs, words, true);
+}
+
+// One picture per call, sparse: a stage of one (the parser of a single stream, mpeg::Video).  Pictures of several streams
+// in one call: the staged form.
+int mpeghip_video_submit_sparse(mpeghip_video *v, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                                const uint32_t *words, size_t n_words)
+{
+    if (!v || !pic)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    mpeghip_stage *st = nullptr;
+    int rc = mpeghip_video_stage_begin_sparse(v, 1, &n_mbs, &n_words, &st);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    mpeghip_pic_desc p = *pic;
+    p.mb_first = 0;
+    p.mb_count = n_mbs;
+    rc = mpeghip_video_stage_put_sparse(st, 0, &p, mbs, words);
+    const int rc2 = mpeghip_video_stage_commit(st); // (ends the stage whatever happened; reports the put's error text)
+    return rc != MPEGHIP_OK ? rc : rc2;
 }
 
 int mpeghip_video_stage_commit(mpeghip_stage *sp)

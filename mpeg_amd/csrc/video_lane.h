@@ -231,6 +231,7 @@ MPG_HD void rgba_store4(uint32_t *dst, uint64_t p, const uint32_t (&px)[4], uint
 MPG_HD void rgba_convert_quad(const uint8_t *frame, uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_bytes,
                               uint32_t width, uint32_t height, uint32_t x4, uint32_t yp, uint8_t *rgba)
 {
+    (void)chroma_bytes; // (the planes' blocks are interleaved per macroblock: no plane stride)
     const uint32_t x0 = x4 * 4, y = yp * 2;
     if (y >= height || x0 >= width)
         return;

@@ -221,14 +221,61 @@ struct RcPacked {
     uint32_t blocks = 0, dense_blocks = 0; // its coded blocks / those that travel as dense units (which kernel instance suits the batch)
 };
 
+// ---- the sparse hand-over (mpeghip_video_stage_put_sparse): the coded blocks' data as the reference's VLC loop
+// produces it (video.go:680-745) — per sparse block a count word n and n PAIRS `level << 16 | position << 2` (an intra
+// block's first pair is its DC, position 0), per snapshot block 64 int32 values; mbs[k].coef_off = dword index of
+// macroblock k's first word.  A pair IS a device entry short of the bits the packer adds (quantiser_scale, slot, class).
+// Walks one picture's words: every block inside [0, n_words), counts <= 64, positions distinct, no stray bits.
+// Returns 0, or 1 + the index of the offending macroblock.
+static inline uint32_t rc_sparse_check(const mpeghip_mb_desc *mbs, uint32_t n, const uint32_t *words, uint64_t n_words)
+{
+    for (uint32_t k = 0; k < n; k++) {
+        const mpeghip_mb_desc &mb = mbs[k];
+        const bool intra = (mb.flags & MPEGHIP_MB_INTRA) != 0, raw = (mb.flags & MPEGHIP_MB_COEF_RAW) != 0;
+        uint64_t at = mb.coef_off;
+        for (uint32_t nb = (uint32_t)__builtin_popcount(mb.cbp & 0x3fu); nb; nb--) {
+            if (raw) {
+                if (at + 64 > n_words)
+                    return k + 1;
+                at += 64;
+                continue;
+            }
+            if (at >= n_words)
+                return k + 1;
+            const uint32_t cnt = words[at];
+            if (cnt > 64 || at + 1 + cnt > n_words || (intra && (cnt == 0 || (words[at + 1] & 0xfcu) != 0)))
+                return k + 1;
+            uint64_t seen = 0;
+            uint32_t stray = 0;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const uint32_t w = words[at + 1 + i];
+                stray |= w & 0xff03u;
+                const uint64_t bit = 1ull << ((w >> 2) & 63);
+                stray |= (seen & bit) ? 1u : 0u;
+                seen |= bit;
+            }
+            if (stray)
+                return k + 1;
+            at += 1 + cnt;
+        }
+    }
+    return 0;
+}
+// room the packed form of a sparse picture can need (dwords): its input words (an entry per pair, a block word per count
+// word, a unit where it is the shorter form) + a block word per snapshot block + the slack wide stores run into
+static inline size_t rc_max_words_sparse(uint64_t n_words, uint32_t n_mbs) { return (size_t)n_words + (size_t)n_mbs * 6 + 64; }
+
 // Pack ONE picture: macroblocks mbs[0..n) (already validated), whose coef_off index 128-byte units behind
-// `coefs`.  Chunk headers name their words by index: this picture's first word is word_base (callers that
-// only learn the base afterwards pass 0 and add it with rc_rebase).
-template <bool kWide = true> // kWide: use the 512-bit forms where the CPU has them (tests compare both)
+// `coefs` (kSparseIn: dwords of the sparse hand-over behind `coefs`, checked by rc_sparse_check).  Chunk headers name
+// their words by index: this picture's first word is word_base (callers that only learn the base afterwards pass 0
+// and add it with rc_rebase).
+template <bool kWide = true, bool kSparseIn = false> // kWide: use the 512-bit forms where the CPU has them (tests compare both)
 static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &p, const mpeghip_mb_desc *mbs, uint32_t n,
                                        const uint8_t *coefs, uint32_t word_base, uint32_t *chunks_out, uint32_t *words_out)
 {
     RcPacked out;
+    const uint32_t *sparse = reinterpret_cast<const uint32_t *>(coefs);
+    (void)sparse;
 #if MPG_HOST_AVX512
     const bool wide = kWide && rc_host_has_avx512();
 #endif
@@ -249,6 +296,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             const uint8_t *unit;
             uint32_t slot, dwords;
         } deferred[kRcMaxBlocks];
+        alignas(16) int16_t built[kSparseIn ? kRcMaxBlocks : 1][64]; // kSparseIn: units made of a block's pairs
         uint32_t n_slots = 0, n_deferred = 0;
         uint32_t *bw = words_out + out.words;
         uint32_t *e0 = bw + n_coded, ne = 0, counts = 0, pass_start = 0;
@@ -305,6 +353,47 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                     pass_start = ne;
                 }
                 bw[s] = (rc_tile_offset(b, 0, m) >> 3) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
+                if (kSparseIn) {
+                    const uint32_t *sp = sparse + unit; // (`unit` counts dwords here)
+                    if (raw) {
+                        any_raw = true;
+                        deferred[n_deferred++] = Deferred{reinterpret_cast<const uint8_t *>(sp), s, 64};
+                        unit += 64;
+                        continue;
+                    }
+                    uint32_t cnt = sp[0];
+                    const uint32_t *pr = sp + 1;
+                    unit += 1 + cnt;
+                    // more than kDenseAbove levels: a unit is the shorter form — if the dense path can take them: every level
+                    // non-zero (a coded zero level dequantises to +-1, video.go:719-736: only an entry says that) and
+                    // within its 16-bit steps; an intra block's DC is exempt from both
+                    bool as_unit = cnt > kDenseAbove;
+                    for (uint32_t i = intra ? 1 : 0; as_unit && i < cnt; i++) {
+                        const int32_t level = (int16_t)(pr[i] >> 16);
+                        as_unit = level != 0 && level >= -kRcDenseLevelMax && level <= kRcDenseLevelMax;
+                    }
+                    if (as_unit) {
+                        int16_t *bu = built[n_deferred];
+                        memset(bu, 0, 128);
+                        for (uint32_t i = 0; i < cnt; i++)
+                            bu[(pr[i] >> 2) & 63] = (int16_t)(pr[i] >> 16);
+                        any_dense = true;
+                        out.dense_blocks++;
+                        bw[s] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
+                        deferred[n_deferred++] = Deferred{reinterpret_cast<const uint8_t *>(bu), s, 32};
+                        continue;
+                    }
+                    if (intra) { // the DC pair comes first; it rides in the block word
+                        bw[s] |= kBDcWord | ((pr[0] >> 16) << 12);
+                        pr++;
+                        cnt--;
+                    }
+                    const uint32_t bits = ((uint32_t)(mb.qscale & 31) << 11) | (intra ? 0u : kENonIntra) | ((s & 7) << 8);
+                    for (uint32_t i = 0; i < cnt; i++)
+                        e0[ne + i] = pr[i] | bits;
+                    ne += cnt;
+                    continue;
+                }
                 unit += raw ? 2 : 1;
                 if (raw) {
                     any_raw = true;
@@ -777,6 +866,7 @@ MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, i
     for (int r = (intra && j == 0) ? 1 : 0; r < 8; r++) {
         const int32_t level = (int16_t)((uint32_t)lv.v[r >> 1] >> (16 * (r & 1)));
         MPG_CHECK(level >= -kRcDenseLevelMax && level <= kRcDenseLevelMax);
+        (void)level;
     }
 #endif
     const RcPair p0 = rc_dense_pair((uint32_t)lv.v[0], non_intra_mask), p1 = rc_dense_pair((uint32_t)lv.v[1], non_intra_mask);

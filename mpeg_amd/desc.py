@@ -77,3 +77,37 @@ class SlotRotation:
             return self.fwd
         self.has_reference = True
         return None
+
+
+def to_sparse(mbs, coefs, keep_zero_dc: bool = True):
+    """The same picture in the SPARSE hand-over form (include/mpeghip.h: mpeghip_video_stage_put_sparse): per coded block
+    a count word and one pair word `level << 16 | position << 2` per non-zero level of its unit (position order; an intra
+    block's DC first, present even when 0), per snapshot block its 64 int32 values.  -> (mbs with coef_off in dwords, words)"""
+    mbs = np.array(mbs, dtype=MB_DTYPE, copy=True)
+    raw_bytes = np.ascontiguousarray(coefs).view(np.uint8).reshape(-1)
+    units16 = raw_bytes.view(np.int16).reshape(-1, 64) if raw_bytes.size else np.zeros((0, 64), np.int16)
+    units32 = raw_bytes.view(np.int32).reshape(-1, 32) if raw_bytes.size else np.zeros((0, 32), np.int32)
+    out = []
+    at = 0
+    for k in range(len(mbs)):
+        mb = mbs[k]
+        nb = bin(int(mb["cbp"]) & 0x3f).count("1")
+        unit = int(mb["coef_off"])
+        mbs[k]["coef_off"] = at
+        intra, raw = bool(mb["flags"] & MB_INTRA), bool(mb["flags"] & MB_COEF_RAW)
+        for _ in range(nb):
+            if raw:
+                out.append(units32[unit:unit + 2].reshape(-1).view(np.uint32))
+                unit += 2
+                at += 64
+                continue
+            u = units16[unit]
+            unit += 1
+            pos = np.nonzero(u)[0]
+            if intra and keep_zero_dc and (len(pos) == 0 or pos[0] != 0):
+                pos = np.concatenate([[0], pos])
+            pairs = (u[pos].astype(np.uint16).astype(np.uint32) << 16) | (pos.astype(np.uint32) << 2)
+            out.append(np.concatenate([[np.uint32(len(pos))], pairs]).astype(np.uint32))
+            at += 1 + len(pos)
+    words = np.concatenate(out).astype(np.uint32) if out else np.zeros(0, np.uint32)
+    return mbs, words

@@ -595,6 +595,7 @@ void ShardedVideoBatch::start(uint32_t n_streams)
     if (n_streams == 0)
         throw std::runtime_error("ShardedVideoBatch: n_streams is 0");
     capacity_ = n_streams;
+    try {
     for (auto &sp : shards_) {
         ShardState *sh = sp.get();
         sh->worker = std::thread([sh]() {
@@ -623,9 +624,13 @@ void ShardedVideoBatch::start(uint32_t n_streams)
             }
         });
     }
+    } catch (...) { // a thread could not be created: the object is never constructed, so no destructor will join the earlier workers
+        stopWorkers();
+        throw;
+    }
 }
 
-ShardedVideoBatch::~ShardedVideoBatch()
+void ShardedVideoBatch::stopWorkers()
 {
     for (auto &sh : shards_) {
         {
@@ -637,6 +642,8 @@ ShardedVideoBatch::~ShardedVideoBatch()
             sh->worker.join();
     }
 }
+
+ShardedVideoBatch::~ShardedVideoBatch() { stopWorkers(); }
 
 VideoBatch &ShardedVideoBatch::Shard(uint32_t g) { return *shards_.at(g)->batch; }
 

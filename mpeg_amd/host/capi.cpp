@@ -433,9 +433,13 @@ int mpeghost_sharded_frame(void *hv, uint32_t stream, mpeghost_frame *out)
 uint32_t mpeghost_sharded_device_of(void *hv, uint32_t stream) { return static_cast<ShardedHandle *>(hv)->batch->ShardOf(stream); }
 void mpeghost_sharded_counters(void *hv, uint32_t shard, uint64_t out[2])
 {
-    VideoBatch &b = static_cast<ShardedHandle *>(hv)->batch->Shard(shard);
-    out[0] = b.DeviceSubmits();
-    out[1] = b.QueuedPictures();
+    out[0] = out[1] = 0;
+    guard([&]() -> int { // (Shard() range-checks with at(): nothing throws across this boundary)
+        VideoBatch &b = static_cast<ShardedHandle *>(hv)->batch->Shard(shard);
+        out[0] = b.DeviceSubmits();
+        out[1] = b.QueuedPictures();
+        return 0;
+    }, -1);
 }
 
 // AudioBatch: many MP2 streams, one synthesis call per tick (format: 0 F32N, 1 F32NLR, 2 F32, 3 S16)

@@ -408,6 +408,7 @@ public:
 private:
     struct ShardState;
     void start(uint32_t n_streams);
+    void stopWorkers();
     std::vector<std::unique_ptr<ShardState>> shards_;
     uint32_t n_added_ = 0, capacity_ = 0;
 };

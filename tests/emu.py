@@ -50,6 +50,9 @@ def lib():
         P = C.c_void_p
         L.emu_video_run.restype = C.c_int
         L.emu_video_run.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P, P, P, C.c_uint64]
+        L.emu_video_run_sparse.restype = C.c_int
+        L.emu_video_run_sparse.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32, P, C.c_uint32, P,
+                                           C.c_uint64, P, P, C.c_uint64]
         L.emu_set_tile_policy.restype = None
         L.emu_set_tile_policy.argtypes = [C.c_int]
         L.emu_make_qtable.restype = None
@@ -128,6 +131,22 @@ class EmuStore:
                                  _ptr(pics), len(pics), _ptr(mbs), len(mbs), _ptr(coefs),
                                  _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
         assert rc == 0
+
+    def submit_sparse(self, pic, mbs, words):
+        """One picture in the sparse hand-over form (desc.to_sparse): the library's sparse packer, then the kernel's lanes."""
+        pics = np.ascontiguousarray(np.asarray(pic).reshape(1), desc.PIC_DTYPE)
+        mbs = np.ascontiguousarray(mbs, desc.MB_DTYPE)
+        words = np.ascontiguousarray(words, np.uint32)
+        if (pics["flags"] & desc.PIC_RGBA).any() and not self._rgba_init:
+            for s in range(self.n_streams):
+                for slot in range(3):
+                    self.rgba_convert(slot, s, 1)
+            self._rgba_init = True
+        g = self.g
+        rc = lib().emu_video_run_sparse(_ptr(self.frames), self.stride, g["luma_w"], g["luma_h"], g["width"], g["height"],
+                                        _ptr(pics), 1, _ptr(mbs), len(mbs), _ptr(words), len(words),
+                                        _ptr(self.qmat), _ptr(self.rgba), self.rgba_stride)
+        return rc
 
     def read_planes(self, stream, slot):
         f, g = self._slot(stream, slot), self.g

@@ -50,10 +50,32 @@ void emu_make_qtable(uint8_t *out, const uint8_t *intra, const uint8_t *non_intr
 
 // recon_kernel, wave by wave: the library's packer (rc_pack_picture) turns the ABI arrays into the device
 // format, then every chunk runs through the kernel's lane functions in the kernel's order, LDS = an array.
-int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
+static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
                   uint32_t width, uint32_t height,
                   const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                  const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride, uint64_t sparse_words);
+// the unit form (mpeghip_video_submit)
+int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h, uint32_t width, uint32_t height,
+                  const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
                   const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
+{
+    return emu_video_run_form(frames, frame_stride, luma_w, luma_h, width, height, pics, n_pics, mbs, n_mbs, coefs, qtable, rgba,
+                              rgba_stride, 0);
+}
+// the sparse hand-over (mpeghip_video_stage_put_sparse): `words` checked by rc_sparse_check as the library does; -2 = malformed
+int emu_video_run_sparse(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h, uint32_t width, uint32_t height,
+                         const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                         const uint32_t *words, uint64_t n_words, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
+{
+    if (rc_sparse_check(mbs, n_mbs, words, n_words))
+        return -2;
+    return emu_video_run_form(frames, frame_stride, luma_w, luma_h, width, height, pics, n_pics, mbs, n_mbs,
+                              reinterpret_cast<const uint8_t *>(words), qtable, rgba, rgba_stride, n_words + 1);
+}
+static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
+                  uint32_t width, uint32_t height,
+                  const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
+                  const uint8_t *coefs, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride, uint64_t sparse_words)
 {
     VideoArgs a;
     a.frames = frames;
@@ -86,12 +108,15 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
         const uint64_t end = (uint64_t)mbs[i].coef_off + (uint64_t)__builtin_popcount(mbs[i].cbp) * ((mbs[i].flags & MPEGHIP_MB_COEF_RAW) ? 2 : 1);
         units = mbs[i].cbp && end > units ? end : units;
     }
-    std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1), words(rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
+    std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1),
+        words((sparse_words ? rc_max_words_sparse(sparse_words - 1, n_mbs) : rc_max_words(units)) + kRcWordsPad, 0xDEADBEEFu);
     uint32_t nc = 0, nw = 0;
     uint64_t coded = 0, dense = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
-        const RcPacked got = rc_pack_picture(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
-                                             chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw);
+        const RcPacked got = sparse_words ? rc_pack_picture<true, true>(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
+                                                                        chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw)
+                                          : rc_pack_picture(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
+                                                            chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw);
         nc += got.chunks;
         nw += got.words;
         coded += got.blocks;
