@@ -49,6 +49,7 @@ const (
 	MbRefBwd  = C.MPEGHIP_MB_REF_BWD
 	MbCoefRaw = C.MPEGHIP_MB_COEF_RAW
 	PicRGBA   = C.MPEGHIP_PIC_RGBA
+	PicSparse = C.MPEGHIP_PIC_SPARSE // the picture's coefficient data: (position, level) pairs, CoefOff in dwords
 
 	FMANone   = C.MPEGHIP_AUDIO_FMA_NONE   // mul and add rounded separately (pure Go / SSE2)
 	FMAWindow = C.MPEGHIP_AUDIO_FMA_WINDOW // fused multiply-add in the window (amd64 AVX2)
@@ -119,6 +120,26 @@ func (v *Video) Submit(pic *PicDesc, mbs []MbDesc, coefs []byte) error {
 	}
 	return lastError(C.mpeghip_video_submit(v.h, (*C.mpeghip_pic_desc)(unsafe.Pointer(pic)), 1,
 		(*C.mpeghip_mb_desc)(mp), C.uint32_t(len(mbs)), cp, C.size_t(len(coefs))))
+}
+
+// Pair is one coded coefficient of the sparse hand-over (MPEGHIP_PAIR): what the VLC loop produces per symbol
+// (video.go:680-745), position = column*8 + row.  A block = a count word, then its pairs (an intra block's DC first).
+func Pair(level int, position int) uint32 {
+	return uint32(uint16(int16(level)))<<16 | uint32(position)<<2
+}
+
+// SubmitSparse hands one picture in the sparse form to the GPU (mpeghip_video_submit_sparse): words hold, per
+// macroblock from mbs[k].CoefOff on (in dwords), its coded blocks as count + pairs; snapshot blocks as 64 int32.
+func (v *Video) SubmitSparse(pic *PicDesc, mbs []MbDesc, words []uint32) error {
+	var mp, wp unsafe.Pointer
+	if len(mbs) > 0 {
+		mp = unsafe.Pointer(&mbs[0])
+	}
+	if len(words) > 0 {
+		wp = unsafe.Pointer(&words[0])
+	}
+	return lastError(C.mpeghip_video_submit_sparse(v.h, (*C.mpeghip_pic_desc)(unsafe.Pointer(pic)), (*C.mpeghip_mb_desc)(mp),
+		C.uint32_t(len(mbs)), (*C.uint32_t)(wp), C.size_t(len(words))))
 }
 
 // ReadPlanes fills host slices (len = Info.luma_bytes / chroma_bytes) with the slot's planes.
@@ -219,6 +240,36 @@ func (s *Stage) Put(i int, pic *PicDesc, mbs []MbDesc, coefs []byte) error {
 	}
 	return lastError(C.mpeghip_video_stage_put(s.h, C.uint32_t(i), (*C.mpeghip_pic_desc)(unsafe.Pointer(pic)),
 		(*C.mpeghip_mb_desc)(mp), cp))
+}
+
+// StageBeginSparse / PutSparse: the same stage for pictures in the sparse form, sizes in dwords
+// (mpeghip_video_stage_begin_sparse / _put_sparse).
+func (v *Video) StageBeginSparse(nMbs []uint32, nWords []uint64) (*Stage, error) {
+	s := &Stage{}
+	if len(nMbs) == 0 || len(nMbs) != len(nWords) {
+		return nil, errors.New("mpeghip: StageBeginSparse: nMbs and nWords must have the same, non-zero length")
+	}
+	sizes := make([]C.size_t, len(nWords))
+	for i, n := range nWords {
+		sizes[i] = C.size_t(n)
+	}
+	if err := lastError(C.mpeghip_video_stage_begin_sparse(v.h, C.uint32_t(len(nMbs)), (*C.uint32_t)(unsafe.Pointer(&nMbs[0])),
+		&sizes[0], &s.h)); err != nil {
+		return nil, err
+	}
+	return s, nil
+}
+
+func (s *Stage) PutSparse(i int, pic *PicDesc, mbs []MbDesc, words []uint32) error {
+	var mp, wp unsafe.Pointer
+	if len(mbs) > 0 {
+		mp = unsafe.Pointer(&mbs[0])
+	}
+	if len(words) > 0 {
+		wp = unsafe.Pointer(&words[0])
+	}
+	return lastError(C.mpeghip_video_stage_put_sparse(s.h, C.uint32_t(i), (*C.mpeghip_pic_desc)(unsafe.Pointer(pic)),
+		(*C.mpeghip_mb_desc)(mp), (*C.uint32_t)(wp)))
 }
 
 // Commit sends the staged pictures and reconstructs them (asynchronous, like Submit); the Stage is over.

@@ -6,7 +6,6 @@ import (
 	"os"
 	"strconv"
 	"sync"
-	"unsafe"
 
 	"github.com/gen2brain/mpeg/internal/mpeghip" // = go/mpeghip of this repository, vendored
 )
@@ -44,7 +43,7 @@ type hipVideo struct {
 	dev *mpeghip.Video
 
 	mbs     []mpeghip.MbDesc // one picture's macroblocks (reused between pictures)
-	coefs   []byte           // 128-byte units, column-major
+	words   []uint32         // the picture's coded blocks in the sparse form (mpeghip.h: MPEGHIP_PIC_SPARSE): count + pairs; snapshots as 64 int32
 	written []bool           // macroblock address already emitted in the current submit
 
 	// current macroblock
@@ -95,7 +94,7 @@ func (h *hipVideo) open(v *Video) bool {
 func (h *hipVideo) beginPicture(v *Video) {
 	h.Stats.Pictures++
 	h.mbs = h.mbs[:0]
-	h.coefs = h.coefs[:0]
+	h.words = h.words[:0]
 	for i := range h.written {
 		h.written[i] = false
 	}
@@ -112,7 +111,7 @@ func (h *hipVideo) flush(v *Video) {
 	// frameForward / frameBackward are what copyMacroblock would read
 	cur := v.frameCurrent.hipSlot
 	pic := mpeghip.PicDesc{Cur: cur, Fwd: v.frameForward.hipSlot, Bwd: v.frameBackward.hipSlot, MbCount: uint32(len(h.mbs))}
-	if err := h.dev.Submit(&pic, h.mbs, h.coefs); err != nil {
+	if err := h.dev.SubmitSparse(&pic, h.mbs, h.words); err != nil {
 		// descriptors are validated by the library; the recorder never produces an invalid one.  A
 		// device failure leaves the slot as it was (the reference has no error path here either).
 		_ = err
@@ -121,7 +120,7 @@ func (h *hipVideo) flush(v *Video) {
 	h.Stats.Submits++
 	h.Stats.Macroblocks += len(h.mbs)
 	h.mbs = h.mbs[:0]
-	h.coefs = h.coefs[:0]
+	h.words = h.words[:0]
 	for i := range h.written {
 		h.written[i] = false
 	}
@@ -205,7 +204,6 @@ func (h *hipVideo) decodeBlock(v *Video, block int) {
 	n := 0
 	var quant *[64]byte
 	dirtyAtStart := h.blockDirty
-	explicitZero := false
 	dc256 := 0
 
 	if v.macroblockIntra {
@@ -279,10 +277,7 @@ func (h *hipVideo) decodeBlock(v *Video, block int) {
 		}
 		dz := int(videoZigZag[n]) & 63
 		n++
-		if level == 0 {
-			explicitZero = true
-		}
-		br.q[dz] = int16(level)
+		br.q[dz] = int16(level) // (a coded zero level included: it travels as a pair and dequantises to +-1 like any other)
 		br.touched[br.nTouched] = uint8(dz)
 		br.nTouched++
 		if dirtyAtStart {
@@ -309,7 +304,7 @@ func (h *hipVideo) decodeBlock(v *Video, block int) {
 		h.blockDirty = true
 		return
 	}
-	if !dirtyAtStart && !explicitZero && !br.needsRaw {
+	if !dirtyAtStart && !br.needsRaw { // (a coded zero level travels as a pair: only units, 0 = absent, would need a snapshot for it)
 		br.valid = true // the common case: nothing of blockData survives this block (video.go:777-796)
 		return
 	}
@@ -340,7 +335,9 @@ func (h *hipVideo) decodeBlock(v *Video, block int) {
 	br.valid = true
 }
 
-// endMacroblock appends the macroblock's descriptor and its coded blocks (column-major units).
+// endMacroblock appends the macroblock's descriptor and its coded blocks: per block a count word and one pair per coded
+// level, as the VLC loop produced them (an intra block's DC first; a coded zero level stays a pair); the blocks of a
+// macroblock that travels raw as 64 int32 snapshots, column-major.
 func (h *hipVideo) endMacroblock(v *Video) {
 	if !h.active {
 		return
@@ -383,7 +380,7 @@ func (h *hipVideo) endMacroblock(v *Video) {
 		qs = 31
 	}
 	d.Qscale = uint8(qs)
-	d.CoefOff = uint32(len(h.coefs) / 128)
+	d.CoefOff = uint32(len(h.words)) // dwords
 
 	quant := &v.nonIntraQuantMatrix
 	if h.intra {
@@ -395,32 +392,36 @@ func (h *hipVideo) endMacroblock(v *Video) {
 		}
 		br := &h.blocks[b]
 		h.Stats.CodedBlocks++
-		at := len(h.coefs)
 		if raw {
-			h.coefs = append(h.coefs, make([]byte, 256)...)
-			dst := unsafe.Slice((*int32)(unsafe.Pointer(&h.coefs[at])), 64)
-			for i := 0; i < 64; i++ {
-				val := br.raw[i]
-				if !br.needsRaw { // a clean block of a macroblock that travels raw: dequantise it here
-					val = 0
-					if br.q[i] != 0 {
-						val = dequantPremult(int(br.q[i]), h.intra, h.qscale, quant[i], i)
-					}
-					if h.intra && i == 0 {
-						val = int32(br.q[0]) << 8
-					}
+			var snap [64]int32
+			if br.needsRaw {
+				snap = br.raw
+			} else { // a clean block of a macroblock that travels raw: dequantise it here — its CODED levels, zeros included
+				for k := 0; k < br.nTouched; k++ {
+					i := int(br.touched[k])
+					snap[i] = dequantPremult(int(br.q[i]), h.intra, h.qscale, quant[i], i)
 				}
-				dst[(i&7)*8+(i>>3)] = val
+				if h.intra {
+					snap[0] = int32(br.q[0]) << 8
+				}
+			}
+			at := len(h.words)
+			h.words = append(h.words, make([]uint32, 64)...)
+			for i := 0; i < 64; i++ {
+				h.words[at+(i&7)*8+(i>>3)] = uint32(snap[i])
 			}
 		} else {
-			h.coefs = append(h.coefs, make([]byte, 128)...)
-			dst := unsafe.Slice((*int16)(unsafe.Pointer(&h.coefs[at])), 64)
+			n := br.nTouched
 			if h.intra {
-				dst[0] = br.q[0]
+				n++
+			}
+			h.words = append(h.words, uint32(n))
+			if h.intra {
+				h.words = append(h.words, mpeghip.Pair(int(br.q[0]), 0))
 			}
 			for k := 0; k < br.nTouched; k++ {
-				i := int(br.touched[k])
-				dst[(i&7)*8+(i>>3)] = br.q[i]
+				i := int(br.touched[k]) // natural index row*8+column -> position column*8+row
+				h.words = append(h.words, mpeghip.Pair(int(br.q[i]), (i&7)*8+(i>>3)))
 			}
 		}
 	}

@@ -144,6 +144,7 @@ typedef struct mpeghip_pic_desc {
 
 #define MPEGHIP_PIC_RGBA 0x01u /* also colour-convert every written macroblock into
                                   the cur slot's RGBA image (fused Frame.RGBA())   */
+/* MPEGHIP_PIC_SPARSE (0x02, below): the picture's coefficient data is in the sparse form */
 
 /*
  * One macroblock.  Replaces one trip through decodeMacroblock's reconstruction
@@ -243,22 +244,24 @@ int mpeghip_video_stage_commit(mpeghip_stage *s);
  * pair per coded coefficient (video.go:680-745: `n += run`, de-zigzag, level) — instead of 128-byte units of mostly
  * zeros.  The device format is sparse too (one dword per non-zero level), so the parser's pairs become device entries
  * with one OR each; nothing is densified and nothing is searched for zeros again.
- *   words[]  per macroblock, from dword index mbs[k].coef_off on, the data of its coded blocks in block order
- *            (cbp bit 5 first):
- *              a block:           a count word n (0..64), then n pair words MPEGHIP_PAIR(level, position);
- *                                 position = column * 8 + row (the order of a coefficient unit), each position at
- *                                 most once per block; level: any int16.  An INTRA block's first pair is its DC
- *                                 (position 0, always present; `<< 8` in the reference, video.go:672).  A level of 0
- *                                 is a CODED zero: the reference dequantises it to +-1 (video.go:719-736) — the form
- *                                 that units (0 = absent) need a snapshot for.
- *              a snapshot block   (macroblock flag MPEGHIP_MB_COEF_RAW): 64 int32 values, column-major, no count word
- *   mpeghip_video_stage_begin_sparse  as stage_begin, with the pictures' sizes in dwords
- *   mpeghip_video_stage_put_sparse    as stage_put; MPEGHIP_ERR_INVALID for malformed block data (a count beyond 64, a block
- *                                     that ends behind the picture's words, a position twice, bits outside the two fields
- *                                     of a pair, an intra block without its DC first)
- *   mpeghip_video_submit_sparse       ONE picture per call (a stage of one): the single-stream decoder's flush
- * Everything else — validation of the descriptors, refusals, asynchrony — as for the unit form; a stage takes pictures
- * of one form only. */
+ * A picture is in this form when its descriptor carries MPEGHIP_PIC_SPARSE; every entry point that takes pictures
+ * (submit, stage_put, batch_upload[_replicated]) takes either form, picture by picture.  For a sparse picture
+ *   mbs[k].coef_off   counts DWORDS from the start of `coefs` (not 128-byte units), and from there on lie the data of
+ *                     macroblock k's coded blocks in block order (cbp bit 5 first):
+ *     a block:           a count word n (0..64), then n pair words MPEGHIP_PAIR(level, position);
+ *                        position = column * 8 + row (the order of a coefficient unit), each position at
+ *                        most once per block; level: any int16.  An INTRA block's first pair is its DC
+ *                        (position 0, always present; `<< 8` in the reference, video.go:672).  A level of 0
+ *                        is a CODED zero: the reference dequantises it to +-1 (video.go:719-736) — the form
+ *                        that units (0 = absent) need a snapshot for.
+ *     a snapshot block   (macroblock flag MPEGHIP_MB_COEF_RAW): 64 int32 values, column-major, no count word
+ *   coef_bytes        a multiple of 4 (of 128 as soon as one picture of the call is in the unit form)
+ * Malformed block data (a count beyond 64, a block that ends behind the buffer, a position twice, bits outside the two
+ * fields of a pair, an intra block without its DC first) is refused with MPEGHIP_ERR_INVALID, nothing launched.
+ * The three functions below are the same calls with the flag set for the caller and sizes in dwords:
+ *   mpeghip_video_stage_begin_sparse / _put_sparse   the many-stream emitter (one parser thread per stream)
+ *   mpeghip_video_submit_sparse                      ONE picture per call: the single-stream decoder's flush */
+#define MPEGHIP_PIC_SPARSE 0x02u
 #define MPEGHIP_PAIR(level, position) (((uint32_t)(uint16_t)(level) << 16) | ((uint32_t)(position) << 2))
 int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
                                      mpeghip_stage **out);

@@ -44,6 +44,12 @@ int mpeghost_video_width(void *video);
 int mpeghost_video_height(void *video);
 double mpeghost_video_framerate(void *video);
 void mpeghost_video_set_no_delay(void *video, int no_delay);        /* video.go:178 */
+/* The form the parser hands pictures to libmpeghip in (include/mpeghip.h): 1 = sparse, its own (position, level) pairs
+ * (MPEGHIP_PIC_SPARSE; the default), 0 = 128-byte units.  Per decoder (before its first picture), or as the process-wide
+ * default of decoders created afterwards (those inside mpeghost_mpeg_* / mpeghost_video_batch_* included).  No reference
+ * counterpart: results are identical. */
+void mpeghost_video_set_sparse(void *video, int sparse);
+void mpeghost_set_default_sparse(int sparse);
 int mpeghost_video_decode(void *video, mpeghost_frame *out);         /* 1 frame, 0 none / end, -1 error */
 const uint8_t *mpeghost_video_rgba(void *video);                     /* Frame.RGBA() of the last decoded frame */
 void mpeghost_video_stats(void *video, uint64_t out[8]);

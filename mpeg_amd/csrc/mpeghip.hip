@@ -571,8 +571,7 @@ struct mpeghip_stage {
     uint32_t n_pics = 0, n_mbs = 0, n_chunks = 0;
     std::vector<uint32_t> mb_first, mb_count;   // per picture: its macroblocks [mb_first, mb_first + mb_count)
     std::vector<uint32_t> chunk_first;          // per picture: its first chunk
-    bool sparse = false;                        // begun by mpeghip_video_stage_begin_sparse: puts bring words, not units
-    std::vector<uint64_t> units;                // per picture: its coefficient units (sparse: its dwords)
+    std::vector<uint64_t> units;                // per picture: its coefficient bytes
     std::vector<uint64_t> alg;                  // per picture, written by its put
     std::vector<uint32_t> blocks, dense;        // per picture, written by its put: coded blocks / dense units
     std::vector<PicUse> use;                    // per picture, written by its put
@@ -1036,6 +1035,22 @@ static uint64_t chunks_of(const mpeghip_pic_desc *pics, uint32_t n_pics)
     return n;
 }
 
+// room the packed form of a picture can need (dwords), whichever form it arrives in: a unit becomes at most 65 words, a
+// sparse picture at most its own dwords + a block word per snapshot block
+static size_t words_room(uint64_t coef_bytes, uint64_t n_mbs)
+{
+    const size_t as_units = rc_max_words((coef_bytes + MPEGHIP_COEF_UNIT - 1) / MPEGHIP_COEF_UNIT);
+    const size_t as_sparse = rc_max_words_sparse(coef_bytes / 4, (uint32_t)(n_mbs > 0xffffffffull ? 0xffffffffull : n_mbs));
+    return as_units > as_sparse ? as_units : as_sparse;
+}
+static std::string sparse_error_text(uint32_t pic, uint32_t mb)
+{
+    char t[320];
+    snprintf(t, sizeof(t), "picture %u, macroblock %u: malformed sparse block data (a count beyond 64, a block that ends behind the "
+             "coefficient buffer, a position twice, bits outside a pair's two fields, or an intra block without its DC first)", pic, mb);
+    return t;
+}
+
 // Validate a whole submit and (chunks_out != NULL) pack it into the device format.  The macroblocks of picture p
 // are mbs[mb_first .. mb_first + mb_count); every macroblock belongs to exactly one picture's range.
 static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
@@ -1050,8 +1065,11 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
         return fail(MPEGHIP_ERR_INVALID, "mbs is NULL");
     if (n_mbs > 0 && coef_bytes > 0 && !coefs)
         return fail(MPEGHIP_ERR_INVALID, "coefs is NULL");
-    if (coef_bytes % MPEGHIP_COEF_UNIT)
-        return fail(MPEGHIP_ERR_INVALID, "coef_bytes %zu is not a multiple of 128", coef_bytes);
+    bool any_units = false;
+    for (uint32_t p = 0; p < n_pics; p++)
+        any_units = any_units || !(pics[p].flags & MPEGHIP_PIC_SPARSE);
+    if (coef_bytes % (any_units ? MPEGHIP_COEF_UNIT : 4))
+        return fail(MPEGHIP_ERR_INVALID, "coef_bytes %zu is not a multiple of %d", coef_bytes, any_units ? MPEGHIP_COEF_UNIT : 4);
     uint64_t covered = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
         const int rc = validate_pic(in, pics[p], p);
@@ -1075,14 +1093,23 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
             if (pm[k].pic != p)
                 return fail(MPEGHIP_ERR_INVALID, "macroblock %u: names picture %u but lies in picture %u's range",
                             pics[p].mb_first + k, pm[k].pic, p);
-        const int rc = validate_picture(in, pics[p], p, pm, pics[p].mb_count, pics[p].mb_first, coef_units, &alg, &use[p], seen,
-                                        &named_units);
+        const bool sparse = (pics[p].flags & MPEGHIP_PIC_SPARSE) != 0;
+        uint64_t ignored = 0; // (sparse: the coefficient extents are in the words themselves, rc_sparse_check)
+        const int rc = validate_picture(in, pics[p], p, pm, pics[p].mb_count, pics[p].mb_first, sparse ? ~0ull >> 2 : coef_units, &alg,
+                                        &use[p], seen, sparse ? &ignored : &named_units);
         if (rc != MPEGHIP_OK)
             return rc;
+        if (sparse) {
+            const uint32_t bad = rc_sparse_check(pm, pics[p].mb_count, static_cast<const uint32_t *>(coefs), coef_bytes / 4);
+            if (bad)
+                return fail(MPEGHIP_ERR_INVALID, "%s", sparse_error_text(p, pics[p].mb_first + bad - 1).c_str());
+        }
         if (chunks_out) {
-            if (words > 0xffffffffull - rc_max_words(coef_units))
+            if (words > 0xffffffffull - words_room(coef_bytes, n_mbs))
                 return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
-            const RcPacked got = rc_pack_picture(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
+            const RcPacked got = sparse ? rc_pack_picture<true, true>(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
+                                                                      (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words)
+                                        : rc_pack_picture(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
                                                  (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words);
             chunk += got.chunks;
             words += got.words;
@@ -1259,7 +1286,7 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
     HIP_TRY(hipSetDevice(v->ctx->device));
     const uint64_t n_chunks = chunks_of(pics, n_pics);
     const BlobLayout l = blob_layout(n_pics, n_chunks);
-    const size_t words_cap = rc_max_words(coef_bytes / MPEGHIP_COEF_UNIT) + kRcWordsPad;
+    const size_t words_cap = words_room(coef_bytes, n_mbs) + kRcWordsPad;
     const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics;
     hipStream_t st = v->ctx->stream;
     std::vector<uint8_t> pageable;
@@ -1366,8 +1393,8 @@ int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_
     return MPEGHIP_OK;
 }
 
-static int stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes, bool sparse,
-                       mpeghip_stage **out)
+int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
+                              mpeghip_stage **out)
 {
     if (!v || !out || (n_pics && (!n_mbs || !coef_bytes)))
         return fail(MPEGHIP_ERR_INVALID, "stage_begin: NULL argument");
@@ -1376,7 +1403,6 @@ static int stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs,
     HIP_TRY(hipSetDevice(v->ctx->device));
     std::unique_ptr<mpeghip_stage> s(new mpeghip_stage);
     s->v = v;
-    s->sparse = sparse;
     s->n_pics = n_pics;
     s->mb_first.resize(n_pics);
     s->mb_count.assign(n_mbs, n_mbs + n_pics);
@@ -1391,15 +1417,14 @@ static int stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs,
         s->done[i].store(0);
     uint64_t mbs = 0, chunks = 0, words = 0; // words: worst case (every coefficient of every unit non-zero)
     for (uint32_t i = 0; i < n_pics; i++) {
-        if (coef_bytes[i] % (sparse ? 4 : MPEGHIP_COEF_UNIT))
-            return fail(MPEGHIP_ERR_INVALID, "stage_begin: picture %u: %zu coefficient bytes is not a multiple of %d", i, coef_bytes[i],
-                        sparse ? 4 : MPEGHIP_COEF_UNIT);
+        if (coef_bytes[i] % 4) // (a picture in the unit form: a multiple of 128, checked by its put)
+            return fail(MPEGHIP_ERR_INVALID, "stage_begin: picture %u: %zu coefficient bytes is not a multiple of 4", i, coef_bytes[i]);
         s->mb_first[i] = (uint32_t)mbs;
         s->chunk_first[i] = (uint32_t)chunks;
-        s->units[i] = coef_bytes[i] / (sparse ? 4 : MPEGHIP_COEF_UNIT);
+        s->units[i] = coef_bytes[i];
         mbs += n_mbs[i];
         chunks += rc_max_chunks(n_mbs[i]);
-        words += sparse ? rc_max_words_sparse(s->units[i], n_mbs[i]) : rc_max_words(s->units[i]);
+        words += words_room(coef_bytes[i], n_mbs[i]);
         if (mbs > 0xffffffffull || words > 0xffffffffull - kRcWordsPad)
             return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
     }
@@ -1425,12 +1450,6 @@ static int stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs,
     return MPEGHIP_OK;
 }
 
-int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
-                              mpeghip_stage **out)
-{
-    return stage_begin(v, n_pics, n_mbs, coef_bytes, false, out);
-}
-
 int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
                                      mpeghip_stage **out)
 {
@@ -1442,17 +1461,16 @@ int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const ui
             return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
         bytes[i] = n_words[i] * 4;
     }
-    return stage_begin(v, n_pics, n_mbs, bytes.data(), true, out);
+    return mpeghip_video_stage_begin(v, n_pics, n_mbs, bytes.data(), out);
 }
 
 // Thread-safe for distinct i: touches only picture i's part of the staging buffer and of the stage's arrays.
-static int stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, const void *coefs,
-                     bool sparse)
+int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
+                            const void *coefs)
 {
     if (!s || !pic)
         return fail(MPEGHIP_ERR_INVALID, "stage_put: NULL argument");
-    if (s->sparse != sparse)
-        return fail(MPEGHIP_ERR_INVALID, "stage_put: the stage was begun for %s pictures", s->sparse ? "sparse" : "dense");
+    const bool sparse = (pic->flags & MPEGHIP_PIC_SPARSE) != 0;
     int rc = MPEGHIP_OK;
     do {
         if (i >= s->n_pics) {
@@ -1463,6 +1481,10 @@ static int stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, 
         const uint32_t n = s->mb_count[i], first = s->mb_first[i];
         if ((n && !mbs) || (n && s->units[i] && !coefs)) {
             rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: NULL array", i);
+            break;
+        }
+        if (!sparse && s->units[i] % MPEGHIP_COEF_UNIT) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: coef_bytes %llu is not a multiple of 128", i, (unsigned long long)s->units[i]);
             break;
         }
         // one put per picture: the staging buffer has room for each picture once (a second put — a retry after an error, the
@@ -1483,21 +1505,20 @@ static int stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, 
         static thread_local std::vector<uint64_t> seen;
         uint64_t named_units = 0;
         // (sparse: the coefficient extents are in the words themselves: rc_sparse_check instead of the unit arithmetic)
-        const uint64_t unit_room = sparse ? ~0ull >> 2 : s->units[i];
+        const uint64_t unit_room = sparse ? ~0ull >> 2 : s->units[i] / MPEGHIP_COEF_UNIT;
         if ((rc = validate_picture(v->info, pd, i, mbs, n, 0, unit_room, &alg, &s->use[i], seen, &named_units)) != MPEGHIP_OK)
             break;
         if (sparse) {
-            const uint32_t bad = rc_sparse_check(mbs, n, static_cast<const uint32_t *>(coefs), s->units[i]);
+            const uint32_t bad = rc_sparse_check(mbs, n, static_cast<const uint32_t *>(coefs), s->units[i] / 4);
             if (bad) {
-                rc = fail(MPEGHIP_ERR_INVALID, "stage_put_sparse: picture %u, macroblock %u: malformed block data (a count beyond 64, a "
-                          "block beyond the words, a position twice, stray bits in a pair, or an intra block without its DC first)", i, bad - 1);
+                rc = fail(MPEGHIP_ERR_INVALID, "%s", sparse_error_text(i, bad - 1).c_str());
                 break;
             }
         }
         // the picture in the device format: its chunks go where they belong; its words are packed in this thread's
         // scratch memory first, because the room they need is only known afterwards
         static thread_local std::vector<uint32_t> scratch;
-        const size_t worst = (sparse ? rc_max_words_sparse(s->units[i], n) : rc_max_words(s->units[i])) + 64;
+        const size_t worst = words_room(s->units[i], n) + 64;
         if (scratch.size() < worst)
             scratch.resize(worst + worst / 4 + 1024);
         uint32_t *chunks = reinterpret_cast<uint32_t *>(h + s->c_at) + (size_t)s->chunk_first[i] * kRcChunkDwords;
@@ -1527,35 +1548,29 @@ static int stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, 
     return rc;
 }
 
-int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
-                            const void *coefs)
-{
-    return stage_put(s, i, pic, mbs, coefs, false);
-}
-
 int mpeghip_video_stage_put_sparse(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
                                    const uint32_t *words)
 {
-    return stage_put(s, i, pic, mbs, words, true);
+    if (!pic)
+        return fail(MPEGHIP_ERR_INVALID, "stage_put: NULL argument");
+    mpeghip_pic_desc p = *pic;
+    p.flags |= MPEGHIP_PIC_SPARSE;
+    return mpeghip_video_stage_put(s, i, &p, mbs, words);
 }
 
-// One picture per call, sparse: a stage of one (the parser of a single stream, mpeg::Video).  Pictures of several streams
-// in one call: the staged form.
+// One picture per call in the sparse form: the single-stream decoder's flush (mpeg::Video).
 int mpeghip_video_submit_sparse(mpeghip_video *v, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
                                 const uint32_t *words, size_t n_words)
 {
     if (!v || !pic)
         return fail(MPEGHIP_ERR_INVALID, "NULL argument");
-    mpeghip_stage *st = nullptr;
-    int rc = mpeghip_video_stage_begin_sparse(v, 1, &n_mbs, &n_words, &st);
-    if (rc != MPEGHIP_OK)
-        return rc;
+    if (n_words > 0x3fffffffu)
+        return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
     mpeghip_pic_desc p = *pic;
+    p.flags |= MPEGHIP_PIC_SPARSE;
     p.mb_first = 0;
     p.mb_count = n_mbs;
-    rc = mpeghip_video_stage_put_sparse(st, 0, &p, mbs, words);
-    const int rc2 = mpeghip_video_stage_commit(st); // (ends the stage whatever happened; reports the put's error text)
-    return rc != MPEGHIP_OK ? rc : rc2;
+    return mpeghip_video_submit(v, &p, 1, mbs, n_mbs, words, n_words * 4);
 }
 
 int mpeghip_video_stage_commit(mpeghip_stage *sp)

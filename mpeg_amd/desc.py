@@ -16,6 +16,7 @@ MB_DTYPE = np.dtype([
 assert PIC_DTYPE.itemsize == 16 and MB_DTYPE.itemsize == 32
 
 PIC_RGBA = 0x01
+PIC_SPARSE = 0x02   # the picture's coefficient data is in the sparse hand-over form (to_sparse)
 MB_INTRA, MB_REF_FWD, MB_REF_BWD, MB_COEF_RAW = 0x01, 0x02, 0x04, 0x08
 COEF_UNIT = 128
 SLOTS = 3

@@ -268,7 +268,14 @@ void VideoBatch::queue(uint32_t stream, const mpeghip_pic_desc &pic, const mpegh
     if (pending_[stream])
         Flush(); // two pictures of one stream never share a device call
     const uint32_t pic_index = (uint32_t)pics_.size(), mb_first = (uint32_t)mbs_.size();
-    const uint32_t unit0 = (uint32_t)(coefs_.size() / MPEGHIP_COEF_UNIT);
+    // coef_off counts 128-byte units, or dwords for a picture in the sparse form (MPEGHIP_PIC_SPARSE); pictures of both
+    // forms may share the buffer: a unit-form picture starts on a unit boundary
+    const bool sparse = (pic.flags & MPEGHIP_PIC_SPARSE) != 0;
+    if (!sparse)
+        coefs_.resize((coefs_.size() + MPEGHIP_COEF_UNIT - 1) / MPEGHIP_COEF_UNIT * MPEGHIP_COEF_UNIT);
+    else
+        any_sparse_queued_ = true;
+    const uint32_t unit0 = (uint32_t)(coefs_.size() / (sparse ? 4 : MPEGHIP_COEF_UNIT));
     mpeghip_pic_desc p = pic;
     p.stream = stream;
     p.mb_first = mb_first;
@@ -288,6 +295,9 @@ void VideoBatch::Flush()
 {
     if (pics_.empty())
         return;
+    if (any_sparse_queued_) // (coef_bytes: a multiple of 128 as soon as one picture of the call is in the unit form)
+        coefs_.resize((coefs_.size() + MPEGHIP_COEF_UNIT - 1) / MPEGHIP_COEF_UNIT * MPEGHIP_COEF_UNIT);
+    any_sparse_queued_ = false;
     store_->submit(pics_.data(), (uint32_t)pics_.size(), mbs_.data(), (uint32_t)mbs_.size(), coefs_.data(), coefs_.size());
     device_submits_++;
     pics_.clear();

@@ -108,6 +108,8 @@ int mpeghost_video_width(void *h) { return static_cast<VideoHandle *>(h)->video-
 int mpeghost_video_height(void *h) { return static_cast<VideoHandle *>(h)->video->Height(); }
 double mpeghost_video_framerate(void *h) { return static_cast<VideoHandle *>(h)->video->Framerate(); }
 void mpeghost_video_set_no_delay(void *h, int v) { static_cast<VideoHandle *>(h)->video->SetNoDelay(v != 0); }
+void mpeghost_video_set_sparse(void *h, int v) { static_cast<VideoHandle *>(h)->video->SetSparse(v != 0); }
+void mpeghost_set_default_sparse(int v) { Video::SetDefaultSparse(v != 0); }
 int mpeghost_video_decode(void *hv, mpeghost_frame *out)
 {
     return guard([&]() -> int {

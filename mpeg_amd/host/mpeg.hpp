@@ -256,6 +256,12 @@ public:
     int Width() { return HasHeader() ? width_ : 0; }
     int Height() { return HasHeader() ? height_ : 0; }
     void SetNoDelay(bool v) { assume_no_b_frames_ = v; }
+    // The form the parser hands pictures over in (include/mpeghip.h): SPARSE — its own (position, level) pairs, as the
+    // reference's VLC loop produces them (video.go:680-745), MPEGHIP_PIC_SPARSE — or 128-byte UNITS of int16 levels.
+    // Sparse is the product's form; units remain for callers of the unit ABI and for tests that compare the two.
+    void SetSparse(bool v) { sparse_ = v; }
+    bool Sparse() const { return sparse_; }
+    static void SetDefaultSparse(bool v); // the form of decoders created from now on (process-wide; sparse unless told otherwise)
     double Time() const { return time_; }
     void SetTime(double t);
     void Rewind();
@@ -316,6 +322,7 @@ private:
     // persistent blockData (video.go:101): only ever non-zero after an invalid block
     int32_t block_data_[64];
     bool block_dirty_ = false;
+    bool sparse_;
 
     // per-picture recording
     std::vector<mpeghip_mb_desc> mbs_;
@@ -381,6 +388,7 @@ private:
     std::vector<mpeghip_pic_desc> pics_;
     std::vector<mpeghip_mb_desc> mbs_;
     std::vector<uint8_t> coefs_;
+    bool any_sparse_queued_ = false;
     std::vector<uint8_t> pending_;                 // stream already has a picture in the open batch
     uint64_t device_submits_ = 0, queued_pictures_ = 0;
     double t_parse_ = 0, t_put_ = 0, t_commit_ = 0, t_begin_ = 0; // wall time per phase (PhaseSeconds)

@@ -12,6 +12,7 @@
 //                         or, where the reference's persistent blockData carries stale
 //                         coefficients from an earlier invalid block, a snapshot of
 //                         blockData itself (int32, MPEGHIP_MB_COEF_RAW)
+#include <atomic>
 #include <stdexcept>
 #include <string.h>
 
@@ -19,6 +20,10 @@
 #include "vlc.hpp"
 
 namespace mpeg {
+
+static std::atomic<bool> g_default_sparse{true};
+void Video::SetDefaultSparse(bool v) { g_default_sparse.store(v); }
+
 
 namespace {
 
@@ -83,6 +88,7 @@ Video::Video(Buffer *buf, std::unique_ptr<VideoBackend> backend) : buf_(buf), ba
 
 void Video::init()
 { // video.go:110-121
+    sparse_ = g_default_sparse.load();
     memset(block_data_, 0, sizeof(block_data_));
     memset(intra_quant_, 0, sizeof(intra_quant_));
     memset(non_intra_quant_, 0, sizeof(non_intra_quant_));
@@ -320,6 +326,7 @@ void Video::flushSubmit()
     pic.bwd = (uint8_t)slot_bwd_;
     pic.mb_first = 0;
     pic.mb_count = (uint32_t)mbs_.size();
+    pic.flags = sparse_ ? MPEGHIP_PIC_SPARSE : 0;
     const size_t n_mbs = mbs_.size();
     backend_->submitOwned(pic, mbs_, coefs_); // (may swap the arrays for others)
     stats_.submits++;
@@ -423,7 +430,7 @@ void Video::endMacroblockRecord()
         d.flags |= MPEGHIP_MB_COEF_RAW;
     d.cbp = (uint8_t)cbp;
     d.qscale = (uint8_t)(rec_.qscale < 1 ? 1 : (rec_.qscale > 31 ? 31 : rec_.qscale));
-    d.coef_off = (uint32_t)(coefs_.size() / MPEGHIP_COEF_UNIT);
+    d.coef_off = (uint32_t)(coefs_.size() / (sparse_ ? 4 : MPEGHIP_COEF_UNIT)); // sparse pictures count dwords
     if (rec_.qscale < 1 && cbp)
         raw = true, d.flags |= MPEGHIP_MB_COEF_RAW; // quantiser_scale 0 (forbidden value): keep the reference's arithmetic
 
@@ -438,8 +445,11 @@ void Video::endMacroblockRecord()
                 memcpy(snap, br.raw, sizeof(snap));
             } else { // this block was clean: dequantise it here so the whole macroblock shares one format
                 const uint8_t *qm = rec_.intra ? intra_quant_ : non_intra_quant_;
-                for (int i = 0; i < 64; i++)
-                    snap[i] = br.q[i] ? dequantPremult(br.q[i], rec_.intra, rec_.qscale, qm[i], i) : 0;
+                memset(snap, 0, sizeof(snap));
+                for (int k = 0; k < br.n_touched; k++) { // the coded levels — a coded ZERO among them dequantises to +-1
+                    const int i = br.touched[k];
+                    snap[i] = dequantPremult(br.q[i], rec_.intra, rec_.qscale, qm[i], i);
+                }
                 if (rec_.intra)
                     snap[0] = (int32_t)br.q[0] * 256;
             }
@@ -449,6 +459,20 @@ void Video::endMacroblockRecord()
             for (int r = 0; r < 8; r++)
                 for (int c = 0; c < 8; c++)
                     dst[c * 8 + r] = snap[r * 8 + c]; // column-major
+        } else if (sparse_) {
+            // the block as the VLC loop produced it: a count, then one pair per coded level (an intra block's DC first) —
+            // a device entry short of the bits the library's packer adds.  A coded zero level stays a pair.
+            const size_t at = coefs_.size();
+            const uint32_t n = (uint32_t)br.n_touched + (rec_.intra ? 1u : 0u);
+            coefs_.resize(at + 4 * (size_t)(1 + n));
+            uint32_t *dst = reinterpret_cast<uint32_t *>(coefs_.data() + at);
+            *dst++ = n;
+            if (rec_.intra)
+                *dst++ = MPEGHIP_PAIR(br.q[0], 0);
+            for (int k = 0; k < br.n_touched; k++) {
+                const int i = br.touched[k]; // natural index row * 8 + column -> position column * 8 + row
+                *dst++ = MPEGHIP_PAIR(br.q[i], (i & 7) * 8 + (i >> 3));
+            }
         } else {
             const size_t at = coefs_.size();
             coefs_.resize(at + MPEGHIP_COEF_UNIT);
@@ -751,7 +775,7 @@ void Video::decodeBlock(int block)
         return;
     }
 
-    if (!dirty_at_start && !explicit_zero && !br.needs_raw) {
+    if (!dirty_at_start && (!explicit_zero || sparse_) && !br.needs_raw) { // (a coded zero level: a pair says it, a unit cannot)
         // the common case: blockData held nothing but this block, and the reference clears it
         // again after use (video.go:777, 781-783, 790, 794-796) — nothing to keep on the host
         br.valid = true;

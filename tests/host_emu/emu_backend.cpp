@@ -111,11 +111,11 @@ public:
         st_count_ = n_mbs;
         st_bytes_ = coef_bytes;
         size_t mbs = 0, bytes = 0;
-        for (size_t i = 0; i < n; i++) {
+        for (size_t i = 0; i < n; i++) { // (every picture starts on a unit boundary: either form may follow)
             st_first_[i] = (uint32_t)mbs;
             st_unit_[i] = (uint32_t)(bytes / MPEGHIP_COEF_UNIT);
             mbs += n_mbs[i];
-            bytes += coef_bytes[i];
+            bytes += (coef_bytes[i] + MPEGHIP_COEF_UNIT - 1) / MPEGHIP_COEF_UNIT * MPEGHIP_COEF_UNIT;
         }
         st_pics_.assign(n, mpeghip_pic_desc{});
         st_mbs_.assign(mbs, mpeghip_mb_desc{});
@@ -131,7 +131,7 @@ public:
         for (uint32_t k = 0; k < st_count_[i]; k++) {
             mpeghip_mb_desc m = mbs[k];
             m.pic = i;
-            m.coef_off += st_unit_[i];
+            m.coef_off += (pic.flags & MPEGHIP_PIC_SPARSE) ? st_unit_[i] * (MPEGHIP_COEF_UNIT / 4) : st_unit_[i]; // dwords / units
             st_mbs_[st_first_[i] + k] = m;
         }
         if (st_bytes_[i])

@@ -104,16 +104,31 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         any_rgba = any_rgba || (pics[p].flags & MPEGHIP_PIC_RGBA);
         n_chunks += rc_max_chunks(pics[p].mb_count);
     }
-    for (uint32_t i = 0; i < n_mbs; i++) {
-        const uint64_t end = (uint64_t)mbs[i].coef_off + (uint64_t)__builtin_popcount(mbs[i].cbp) * ((mbs[i].flags & MPEGHIP_MB_COEF_RAW) ? 2 : 1);
-        units = mbs[i].cbp && end > units ? end : units;
+    // which pictures are in the sparse form: all of them (emu_video_run_sparse), or those that say so (MPEGHIP_PIC_SPARSE)
+    std::vector<uint8_t> pic_sparse(n_pics, 0);
+    uint64_t sparse_dwords = sparse_words ? sparse_words - 1 : 0;
+    for (uint32_t p = 0; p < n_pics; p++) {
+        pic_sparse[p] = sparse_words || (pics[p].flags & MPEGHIP_PIC_SPARSE);
+        for (uint32_t i = pics[p].mb_first; i < pics[p].mb_first + pics[p].mb_count; i++) {
+            const bool raw = (mbs[i].flags & MPEGHIP_MB_COEF_RAW) != 0;
+            const uint32_t nb = (uint32_t)__builtin_popcount(mbs[i].cbp & 0x3f);
+            if (!pic_sparse[p]) {
+                const uint64_t end = (uint64_t)mbs[i].coef_off + (uint64_t)nb * (raw ? 2 : 1);
+                units = nb && end > units ? end : units;
+            } else if (!sparse_words) { // (the host parser's own words: their extent by walking them)
+                uint64_t at = mbs[i].coef_off;
+                for (uint32_t b = 0; b < nb; b++)
+                    at += raw ? 64 : 1 + reinterpret_cast<const uint32_t *>(coefs)[at];
+                sparse_dwords = at > sparse_dwords ? at : sparse_dwords;
+            }
+        }
     }
     std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1),
-        words((sparse_words ? rc_max_words_sparse(sparse_words - 1, n_mbs) : rc_max_words(units)) + kRcWordsPad, 0xDEADBEEFu);
+        words(rc_max_words_sparse(sparse_dwords, n_mbs) + rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
     uint32_t nc = 0, nw = 0;
     uint64_t coded = 0, dense = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
-        const RcPacked got = sparse_words ? rc_pack_picture<true, true>(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
+        const RcPacked got = pic_sparse[p] ? rc_pack_picture<true, true>(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
                                                                         chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw)
                                           : rc_pack_picture(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
                                                             chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw);

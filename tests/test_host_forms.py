@@ -1,0 +1,77 @@
+"""The parser hands pictures over in one of two forms (include/mpeghip.h): SPARSE — its own (position, level) pairs, the
+product's default — or 128-byte UNITS.  Both must give the reference's frames: the golden streams (the damaged one with
+its invalid blocks, stale blockData snapshots, coded zero levels and macroblocks addressed twice) through one decoder,
+through VideoBatch (merged submits and staged puts from a thread pool), and mutated streams against the oracle.  CPU
+only (lane emulator behind the host stack); the GPU twins are tests/test_gpu_sparse.py and the -m gpu golden tests,
+which run the default (sparse) form."""
+import random
+
+import numpy as np
+import pytest
+
+import hostlib
+from test_host_batch import TESTMPG_VIDEO_HASH, VIDEO_HASH, run_batch
+from test_host_parser import video_hash
+
+
+@pytest.fixture(params=[0, 1], ids=["units", "sparse"])
+def form(request):
+    hostlib.host().mpeghost_set_default_sparse(request.param)
+    yield request.param
+    hostlib.host().mpeghost_set_default_sparse(1)
+
+
+def test_damaged_golden_stream_in_both_forms(oracle, golden_dir, form):
+    dec = hostlib.HostVideo((golden_dir / "test.mpeg1video").read_bytes(), emu_flavour=0)
+    h, n = video_hash(oracle, dec)
+    st = dec.stats()
+    dec.close()
+    assert (h, n) == (VIDEO_HASH, 260)
+    assert st["invalid_blocks"] == 53 and st["raw_macroblocks"] > 0
+
+
+def test_a_coded_zero_level_needs_a_snapshot_only_in_the_unit_form(oracle, golden_dir):
+    """video.go:719-736 dequantises a coded level of 0 to +-1; units (0 = absent) cannot say that, pairs can: the damaged
+    golden stream has such levels, and the sparse form sends fewer macroblocks as int32 snapshots."""
+    raw = {}
+    for f in (0, 1):
+        hostlib.host().mpeghost_set_default_sparse(f)
+        try:
+            dec = hostlib.HostVideo((golden_dir / "test.mpeg1video").read_bytes(), emu_flavour=0)
+            assert video_hash(oracle, dec) == (VIDEO_HASH, 260)
+            raw[f] = dec.stats()["raw_macroblocks"]
+            dec.close()
+        finally:
+            hostlib.host().mpeghost_set_default_sparse(1)
+    assert 0 < raw[1] <= raw[0]
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_batches_in_both_forms(oracle, golden_dir, form, threads):
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    clean = oracle.ps_extract((golden_dir / "test.mpg").read_bytes(), 0xE0)[0]
+    h, n, c = run_batch(oracle, [es, clean, es, es], [0, 0, 2, 7], threads=threads)
+    assert h == [VIDEO_HASH, TESTMPG_VIDEO_HASH, VIDEO_HASH, VIDEO_HASH] and n == [260, 278, 260, 260]
+
+
+def test_mutated_streams_in_both_forms(oracle, golden_dir, form):
+    base = bytearray((golden_dir / "test.mpeg1video").read_bytes())
+    for seed in range(12):
+        rng = random.Random(4000 + seed)
+        data = bytearray(base)
+        for _ in range(rng.randrange(3, 30)):
+            at = rng.randrange(64, len(data))
+            data[at] ^= 1 << rng.randrange(8)
+        data = bytes(data)
+        ref, dut = oracle.VideoDecoder(data), hostlib.HostVideo(data, emu_flavour=0)
+        i = 0
+        while True:
+            a, b = ref.decode(), dut.decode()
+            assert (a is None) == (b is None), "seed %d frame %d" % (seed, i)
+            if a is None:
+                break
+            for pa, pb in zip(oracle.frame_planes(a), hostlib.frame_planes(b)):
+                assert np.array_equal(pa, pb), "seed %d frame %d" % (seed, i)
+            i += 1
+        ref.close()
+        dut.close()

@@ -30,9 +30,22 @@ def build(force: bool = False) -> Path:
 
 
 def staged_submit_rate(device: int, width: int, height: int, seq, streams: int, threads: int, seconds: float = 2.0,
-                       verbose: bool = False) -> float:
-    from mpeg_amd import abi
+                       verbose: bool = False, sparse: bool = True) -> float:
+    """sparse: the pictures are handed over in the parser's own form (MPEGHIP_PIC_SPARSE: (position, level) pairs), what the
+    product's parser emits; False: as 128-byte units."""
+    from mpeg_amd import abi, desc
     abi.load_library()
+    if sparse:
+        import copy
+        conv = []
+        for s in seq:
+            c = copy.copy(s)
+            c.mbs, words = desc.to_sparse(s.mbs, s.coefs)
+            c.coefs = words.view(np.uint8)
+            c.pics = s.pics.copy()
+            c.pics["flags"] |= desc.PIC_SPARSE
+            conv.append(c)
+        seq = conv
     H = C.CDLL(str(build()))
     H.hostbench_staged_submit_rate.restype = C.c_double
     H.hostbench_staged_submit_rate.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
