@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--tile", type=int, default=0, help="mpeghip_video_set_tile_policy of every video leg: 0 = the library picks the "
                     "kernel instance per batch (the product's behaviour), 1 = int16 tile, 2 = int32 tile (for A/B runs)")
+    ap.add_argument("--pin-numa", type=int, default=1, help="1: bind the rank to the cores of the NUMA node its GPU is attached to")
     ap.add_argument("--check", type=int, default=1, help="verify the final frames against the oracle (rank 0)")
     return ap.parse_args()
 
@@ -76,7 +77,7 @@ def cpu_baseline(args, seq):
     """Time the oracle (CPU restatement of the reference's noasm algorithm) on a bounded
     sample of the same workload: T host threads, one independent stream each."""
     from oracle import pyoracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, cores)
     # single thread first: one stream, as many GOP pictures as fit in a quarter of the budget
     st1 = pyoracle.OracleStore(args.width, args.height, 1, threads=1)
@@ -162,6 +163,7 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
     store.set_tile_policy(args.tile)
     batches = [store.upload(s.pics, s.mbs, s.coefs, replicate=streams) for s in seq]
     ctx.sync()
+    device_bytes_per_picture = float(np.mean([b.device_bytes for b in batches]))  # one stream's picture in the device format
     order = []
 
     def step(i):
@@ -241,7 +243,7 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": source, "traffic_source_matches_build": matches, "kernel": KERNEL[bool(rgba)],
                      "alg_bytes_per_launch": acc["alg"] // steps, "avg_launch_ms": launch_ms},
-        "steps": steps,
+        "steps": steps, "device_bytes_per_picture": device_bytes_per_picture,
     }
 
 
@@ -336,6 +338,13 @@ def main():
 
     tstream = torch.cuda.Stream(device=local_rank)
     ctx = abi.Context(local_rank, tstream.cuda_stream)
+    # one process per GPU: this rank's host threads (staged puts of the host-fed leg, the CPU baseline) run on the socket
+    # its GPU is attached to
+    from mpeg_amd.shard import pin_to_node
+    numa = {"node": ctx.numa_node(), "cpus_bound": 0}
+    all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if args.pin_numa:
+        numa["cpus_bound"] = pin_to_node(numa["node"])
 
     # ---- primary leg (per rank: its own streams, same seeded GOP)
     prim = video_leg(ctx, args, args.profile, bool(args.rgba), args.streams, ranks=ranks, device_sync=torch.cuda.synchronize)
@@ -372,13 +381,30 @@ def main():
         pps = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds, sparse=True)
         pps_units = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds / 2, sparse=False)
         mb_per_pic = float(np.mean([len(s.mbs) for s in seq]))
+        # what the link gives a bare copy from pinned memory (64 MB pieces, the size the staged submit sends), next to what the
+        # hand-over used of it: is PCIe the wall?
+        src = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        dst = torch.empty(64 << 20, dtype=torch.uint8, device="cuda:%d" % local_rank)
+        for _ in range(2):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(12):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d = 12 * (64 << 20) / (time.perf_counter() - t0) / 1e9
+        del src, dst
         host_fed = {"metric": "1080p macroblocks/sec handed over by host threads (mpeghip_video_stage_*: validation + packing on the host, "
                               "PCIe, reconstruction), pictures in the parser's sparse form — PCIe inclusive, NOT `value`",
                     "value": pps * mb_per_pic, "pictures_per_s": pps, "pictures_per_s_unit_form": pps_units, "host_threads": threads,
                     "pictures_per_call": 64, "realtime_1080p30_streams": pps * mb_per_pic / MB_PER_1080P30_STREAM,
+                    "device_format_bytes_per_picture": prim["device_bytes_per_picture"],
+                    "pcie_GBps_used": pps * prim["device_bytes_per_picture"] / 1e9, "pcie_h2d_GBps_bare_copy": h2d,
                     "note": "the on-device `value` is %.0f x this: no host can parse, and no PCIe link can carry, what the kernel "
                             "reconstructs (BASELINE.md)" % (prim["mbs"] / prim["elapsed"] / (pps * mb_per_pic))}
 
+    if all_cpus is not None and numa["cpus_bound"]:
+        os.sched_setaffinity(0, all_cpus)  # the CPU baseline is the whole host's: every core of both sockets
     cpu = cpu_baseline(args, prim["seq"]) if args.cpu_seconds > 0 and alone else None
 
     if rank == 0:
@@ -394,7 +420,8 @@ def main():
                                    (args.streams, args.width, args.height, prim["gop_len"], args.profile,
                                     ", fused RGBA" if args.rgba else ""),
                        "streams_per_gpu": args.streams, "macroblocks_per_step_per_gpu": prim["mbs"] // args.steps,
-                       "profile": args.profile, "rgba_fused": bool(args.rgba), "sharding": "by stream, no collective; control plane gloo"},
+                       "profile": args.profile, "rgba_fused": bool(args.rgba), "sharding": "by stream, no collective; control plane gloo",
+                       "host_numa": numa},
             "realtime_1080p30_streams": value / MB_PER_1080P30_STREAM,
             "per_rank_value": per_rank,
             "roofline": prim["roofline"],

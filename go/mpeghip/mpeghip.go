@@ -82,6 +82,10 @@ func NewContext(device int) (*Context, error) {
 }
 func (c *Context) Close() { C.mpeghip_ctx_destroy(c.h) }
 
+// NumaNode is the host NUMA node the context's GPU is attached to (-1: unknown): where the goroutines that
+// parse for this device should run (runtime.LockOSThread + sched_setaffinity) on a two-socket node.
+func (c *Context) NumaNode() int { return int(C.mpeghip_ctx_numa_node(c.h)) }
+
 // Video is the 3-slot frame store + reconstruction of one stream.
 type Video struct {
 	h    *C.mpeghip_video

@@ -54,6 +54,9 @@ typedef struct mpeghip_audio mpeghip_audio;
  * caller's torch stream) or NULL to let the context create its own. */
 int  mpeghip_ctx_create(int device, void *stream, mpeghip_ctx **out);
 void mpeghip_ctx_destroy(mpeghip_ctx *ctx);
+/* The host NUMA node the context's GPU is attached to (sysfs: its PCI function's numa_node), -1 if the platform does not
+ * say.  The multi-GPU driver pins each device's host threads (bitstream parse, staged puts) to that node's cores. */
+int  mpeghip_ctx_numa_node(const mpeghip_ctx *ctx);
 int  mpeghip_ctx_sync(mpeghip_ctx *ctx);               /* wait for all queued work   */
 int  mpeghip_device_count(void);                       /* <0 on error                */
 const char *mpeghip_last_error(void);                  /* thread-local, never NULL   */
@@ -250,13 +253,14 @@ int mpeghip_video_stage_commit(mpeghip_stage *s);
  *                     macroblock k's coded blocks in block order (cbp bit 5 first):
  *     a block:           a count word n (0..64), then n pair words MPEGHIP_PAIR(level, position);
  *                        position = column * 8 + row (the order of a coefficient unit), each position at
- *                        most once per block; level: any int16.  An INTRA block's first pair is its DC
+ *                        most once per block (not checked — a parser cannot produce it; the result of such a
+ *                        block is unspecified: one of the two levels wins); level: any int16.  An INTRA block's first pair is its DC
  *                        (position 0, always present; `<< 8` in the reference, video.go:672).  A level of 0
  *                        is a CODED zero: the reference dequantises it to +-1 (video.go:719-736) — the form
  *                        that units (0 = absent) need a snapshot for.
  *     a snapshot block   (macroblock flag MPEGHIP_MB_COEF_RAW): 64 int32 values, column-major, no count word
  *   coef_bytes        a multiple of 4 (of 128 as soon as one picture of the call is in the unit form)
- * Malformed block data (a count beyond 64, a block that ends behind the buffer, a position twice, bits outside the two
+ * Malformed block data (a count beyond 64, a block that ends behind the buffer, bits outside the two
  * fields of a pair, an intra block without its DC first) is refused with MPEGHIP_ERR_INVALID, nothing launched.
  * The three functions below are the same calls with the flag set for the caller and sizes in dwords:
  *   mpeghip_video_stage_begin_sparse / _put_sparse   the many-stream emitter (one parser thread per stream)
@@ -293,6 +297,9 @@ void mpeghip_video_batch_free(mpeghip_batch *b);
  * (+1024 per macroblock of pictures flagged MPEGHIP_PIC_RGBA). */
 uint64_t mpeghip_video_batch_alg_bytes(const mpeghip_batch *b);
 uint64_t mpeghip_video_batch_mbs(const mpeghip_batch *b);
+/* Bytes of the batch in the library's device format (picture descriptors + chunks + words) as uploaded, before any
+ * replication: what a submit of the same pictures moves over PCIe. */
+uint64_t mpeghip_video_batch_device_bytes(const mpeghip_batch *b);
 
 /* Plane access (replaces reading Frame.Y/Cb/Cr.Data, video.go:17-19).  Sizes
  * are luma_bytes / chroma_bytes.  Synchronous. `pad` (luma_w*16 bytes) may be

@@ -38,6 +38,7 @@ SYMBOLS = {
     "mpeghip_ctx_sync": (C.c_int, [_P]),
     "mpeghip_device_count": (C.c_int, []),
     "mpeghip_last_error": (C.c_char_p, []),
+    "mpeghip_ctx_numa_node": (C.c_int, [_P]),
     "mpeghip_abi_version": (C.c_int, []),
     "mpeghip_pinned_alloc": (_P, [_P, C.c_size_t]),
     "mpeghip_pinned_free": (None, [_P, _P]),
@@ -61,6 +62,7 @@ SYMBOLS = {
     "mpeghip_video_batch_free": (None, [_P]),
     "mpeghip_video_batch_alg_bytes": (C.c_uint64, [_P]),
     "mpeghip_video_batch_mbs": (C.c_uint64, [_P]),
+    "mpeghip_video_batch_device_bytes": (C.c_uint64, [_P]),
     "mpeghip_video_read_planes": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "mpeghip_video_write_planes": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "mpeghip_video_broadcast_slot": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -122,6 +124,10 @@ class Context:
         self.h = h
         self.device = device
 
+    def numa_node(self) -> int:
+        """Host NUMA node of the context's GPU (-1: unknown)."""
+        return int(self.lib.mpeghip_ctx_numa_node(self.h))
+
     def sync(self):
         _check(self.lib.mpeghip_ctx_sync(self.h))
 
@@ -144,6 +150,7 @@ class Batch:
         self.video, self.h = video, h
         self.alg_bytes = video.lib.mpeghip_video_batch_alg_bytes(h)
         self.n_mbs = video.lib.mpeghip_video_batch_mbs(h)
+        self.device_bytes = video.lib.mpeghip_video_batch_device_bytes(h)
 
     def run(self):
         _check(self.video.lib.mpeghip_video_batch_run(self.video.h, self.h))

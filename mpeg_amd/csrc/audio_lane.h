@@ -364,25 +364,22 @@ MPG_HD float scale_short(float x)
 template <int kFormat>
 MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, int i, float sv)
 {
+    // Output samples leave as non-temporal stores: nothing on the device reads them again, and kept out of L2 they leave it
+    // to the sample loads and the window table (profiles/r8_ab_audio_cache_policy.txt, F32N: +6.5 %; sub-band samples
+    // loaded with `nt`, the other experiment of that run, cost 40 % and is gone).
     const uint64_t sb = (uint64_t)stream * a.n_frames * 2304; // the stream's first output element
     if (kFormat == MPEGHIP_AUDIO_F32NLR) {
         const uint32_t f = tg / 36, t = tg % 36;
-        reinterpret_cast<float *>(a.out)[sb + f * 2304 + (uint32_t)ch * 1152 + t * 32 + (uint32_t)i] = sv;
+        store_streaming(reinterpret_cast<float *>(a.out) + sb + f * 2304 + (uint32_t)ch * 1152 + t * 32 + (uint32_t)i, sv);
         return;
     }
     const uint32_t e = tg * 64 + 2 * (uint32_t)i + (uint32_t)ch;
-#if MPG_ON_DEVICE && defined(MPG_NT_AUDIO_OUT) // (next round's experiment, tools/ab/next_round.sh; default: off)
-    if (kFormat == MPEGHIP_AUDIO_F32N) {
-        __builtin_nontemporal_store(sv, reinterpret_cast<float *>(a.out) + sb + e);
-        return;
-    }
-#endif
     if (kFormat == MPEGHIP_AUDIO_F32N)
-        (reinterpret_cast<float *>(a.out) + sb)[e] = sv;
+        store_streaming(reinterpret_cast<float *>(a.out) + sb + e, sv);
     else if (kFormat == MPEGHIP_AUDIO_S16) // audio.go:400-408
-        (reinterpret_cast<int16_t *>(a.out) + sb)[e] = (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f);
+        store_streaming(reinterpret_cast<int16_t *>(a.out) + sb + e, (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f));
     else // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
-        (reinterpret_cast<float *>(a.out) + sb)[e] = sv * 2147483648.0f;
+        store_streaming(reinterpret_cast<float *>(a.out) + sb + e, sv * 2147483648.0f);
 }
 
 // one dword read that the compiler leaves alone (an LDS address space pointer keeps it a ds_read_b32)

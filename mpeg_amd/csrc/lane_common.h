@@ -232,15 +232,20 @@ MPG_HD void copy16_to_lds(const void *g, void *lds_wave_base, int lane)
 {
 #if MPG_ON_DEVICE
     (void)lane;
-#ifdef MPG_NT_AUDIO_IN // (cache-policy experiments of the next round, tools/ab/next_round.sh; default: off)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2 /* nt */);
-#else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-#endif
 #else
     __builtin_memcpy(static_cast<char *>(lds_wave_base) + 16 * lane, g, 16);
+#endif
+}
+
+// a store of something nobody on the device reads again (non-temporal: it does not take a line's place in L2)
+template <typename T> MPG_HD void store_streaming(T *p, T v)
+{
+#if MPG_ON_DEVICE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
 #endif
 }
 

@@ -521,6 +521,7 @@ struct mpeghip_batch {
     uint32_t *d_chunks = nullptr, *d_words = nullptr;
     uint64_t n_pics = 0, n_mbs = 0, n_chunks = 0;
     uint64_t alg_bytes = 0;
+    uint64_t device_bytes = 0;                   // pictures + chunks + words of the original batch: what crossed PCIe
     uint64_t coded_blocks = 0, dense_blocks = 0; // of the original (un-replicated) batch: launch_batch picks the kernel instance by them
     bool any_rgba = false;
     // host copy of what launch_batch needs to keep the RGBA images in step: per picture of the original
@@ -626,6 +627,30 @@ int mpeghip_device_count(void)
     if (e != hipSuccess)
         return fail(MPEGHIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
     return n;
+}
+
+// The host NUMA node the context's GPU hangs off (its PCI function's numa_node in sysfs), -1 if unknown: the
+// threads that feed the device — parser pool, staged puts, the pinned staging buffers they fill — belong there.
+int mpeghip_ctx_numa_node(const mpeghip_ctx *c)
+{
+    if (!c)
+        return -1;
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, c->device) != hipSuccess)
+        return -1;
+    for (char *p = id; *p; p++)
+        if (*p >= 'A' && *p <= 'F')
+            *p = (char)(*p - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id);
+    FILE *f = fopen(path, "r");
+    if (!f)
+        return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1)
+        node = -1;
+    fclose(f);
+    return node;
 }
 
 int mpeghip_ctx_create(int device, void *stream, mpeghip_ctx **out)
@@ -1047,7 +1072,7 @@ static std::string sparse_error_text(uint32_t pic, uint32_t mb)
 {
     char t[320];
     snprintf(t, sizeof(t), "picture %u, macroblock %u: malformed sparse block data (a count beyond 64, a block that ends behind the "
-             "coefficient buffer, a position twice, bits outside a pair's two fields, or an intra block without its DC first)", pic, mb);
+             "coefficient buffer, bits outside a pair's two fields, or an intra block without its DC first)", pic, mb);
     return t;
 }
 
@@ -1094,23 +1119,21 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
                 return fail(MPEGHIP_ERR_INVALID, "macroblock %u: names picture %u but lies in picture %u's range",
                             pics[p].mb_first + k, pm[k].pic, p);
         const bool sparse = (pics[p].flags & MPEGHIP_PIC_SPARSE) != 0;
-        uint64_t ignored = 0; // (sparse: the coefficient extents are in the words themselves, rc_sparse_check)
+        uint64_t ignored = 0; // (sparse: the coefficient extents are in the words themselves: the packer checks them)
         const int rc = validate_picture(in, pics[p], p, pm, pics[p].mb_count, pics[p].mb_first, sparse ? ~0ull >> 2 : coef_units, &alg,
                                         &use[p], seen, sparse ? &ignored : &named_units);
         if (rc != MPEGHIP_OK)
             return rc;
-        if (sparse) {
-            const uint32_t bad = rc_sparse_check(pm, pics[p].mb_count, static_cast<const uint32_t *>(coefs), coef_bytes / 4);
-            if (bad)
-                return fail(MPEGHIP_ERR_INVALID, "%s", sparse_error_text(p, pics[p].mb_first + bad - 1).c_str());
-        }
         if (chunks_out) {
             if (words > 0xffffffffull - words_room(coef_bytes, n_mbs))
                 return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
             const RcPacked got = sparse ? rc_pack_picture<true, true>(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
-                                                                      (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words)
+                                                                      (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words,
+                                                                      coef_bytes / 4)
                                         : rc_pack_picture(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
                                                  (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words);
+            if (got.bad)
+                return fail(MPEGHIP_ERR_INVALID, "%s", sparse_error_text(p, pics[p].mb_first + got.bad - 1).c_str());
             chunk += got.chunks;
             words += got.words;
             blocks += got.blocks;
@@ -1365,6 +1388,7 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
     if (!sg) // pageable host memory: the copies above may still be reading it
         HIP_TRY(hipStreamSynchronize(st));
     fill_notes(v, b, pics, n_pics);
+    b->device_bytes = l.w_at + n_words * 4;
     b->replicas = replicas;
     b->n_pics = (uint64_t)n_pics * replicas;
     b->n_mbs = (uint64_t)n_mbs * replicas;
@@ -1504,17 +1528,11 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         uint64_t alg = 0;
         static thread_local std::vector<uint64_t> seen;
         uint64_t named_units = 0;
-        // (sparse: the coefficient extents are in the words themselves: rc_sparse_check instead of the unit arithmetic)
+        // (sparse: the coefficient extents are in the words themselves: the packer checks them on its way)
         const uint64_t unit_room = sparse ? ~0ull >> 2 : s->units[i] / MPEGHIP_COEF_UNIT;
         if ((rc = validate_picture(v->info, pd, i, mbs, n, 0, unit_room, &alg, &s->use[i], seen, &named_units)) != MPEGHIP_OK)
             break;
-        if (sparse) {
-            const uint32_t bad = rc_sparse_check(mbs, n, static_cast<const uint32_t *>(coefs), s->units[i] / 4);
-            if (bad) {
-                rc = fail(MPEGHIP_ERR_INVALID, "%s", sparse_error_text(i, bad - 1).c_str());
-                break;
-            }
-        }
+
         // the picture in the device format: its chunks go where they belong; its words are packed in this thread's
         // scratch memory first, because the room they need is only known afterwards
         static thread_local std::vector<uint32_t> scratch;
@@ -1523,9 +1541,13 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
             scratch.resize(worst + worst / 4 + 1024);
         uint32_t *chunks = reinterpret_cast<uint32_t *>(h + s->c_at) + (size_t)s->chunk_first[i] * kRcChunkDwords;
         const RcPacked got = sparse ? rc_pack_picture<true, true>(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0,
-                                                                  chunks, scratch.data())
+                                                                  chunks, scratch.data(), s->units[i] / 4)
                                     : rc_pack_picture(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0, chunks,
                                                       scratch.data());
+        if (got.bad) {
+            rc = fail(MPEGHIP_ERR_INVALID, "%s", sparse_error_text(i, got.bad - 1).c_str());
+            break;
+        }
         const uint64_t at = s->words_used.fetch_add(got.words);
         if (at + got.words > s->words_cap) { // (cannot happen: every picture is put once and stays within its worst case)
             rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: the staging buffer is full", i);
@@ -1690,6 +1712,7 @@ void mpeghip_video_batch_free(mpeghip_batch *b)
 
 uint64_t mpeghip_video_batch_alg_bytes(const mpeghip_batch *b) { return b ? b->alg_bytes : 0; }
 uint64_t mpeghip_video_batch_mbs(const mpeghip_batch *b) { return b ? b->n_mbs : 0; }
+uint64_t mpeghip_video_batch_device_bytes(const mpeghip_batch *b) { return b ? b->device_bytes : 0; }
 
 static uint8_t *slot_ptr(const mpeghip_video *v, uint32_t stream, uint32_t slot)
 {

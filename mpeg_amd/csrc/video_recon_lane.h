@@ -219,63 +219,59 @@ constexpr size_t kRcQtabPad = 1024;  // bytes behind the last stream's table tha
 struct RcPacked {
     uint32_t chunks = 0, words = 0;        // what the picture took
     uint32_t blocks = 0, dense_blocks = 0; // its coded blocks / those that travel as dense units (which kernel instance suits the batch)
+    uint32_t bad = 0;                      // sparse input: 1 + the index of the macroblock whose block data is malformed (nothing usable was packed)
 };
 
 // ---- the sparse hand-over (mpeghip_video_stage_put_sparse): the coded blocks' data as the reference's VLC loop
 // produces it (video.go:680-745) — per sparse block a count word n and n PAIRS `level << 16 | position << 2` (an intra
 // block's first pair is its DC, position 0), per snapshot block 64 int32 values; mbs[k].coef_off = dword index of
 // macroblock k's first word.  A pair IS a device entry short of the bits the packer adds (quantiser_scale, slot, class).
-// Walks one picture's words: every block inside [0, n_words), counts <= 64, positions distinct, no stray bits.
-// Returns 0, or 1 + the index of the offending macroblock.
-static inline uint32_t rc_sparse_check(const mpeghip_mb_desc *mbs, uint32_t n, const uint32_t *words, uint64_t n_words)
+// The packer checks a picture's words as it walks them (RcPacked::bad): every block inside [0, n_words), counts <= 64, no bit
+// outside a pair's two fields, an intra block's DC first.  (A position named twice in one block is not looked for: the
+// parser cannot produce it, and the block's result is then merely unspecified — one of the two levels wins.)
+// Pairs -> entries: out[i] = pr[i] | bits for i < cnt; returns the OR of the pairs (their stray bits, if any).  The store may
+// run up to 15 dwords past out + cnt (the words buffer has the slack); nothing is read past pr + cnt.
+#if MPG_HOST_AVX512
+__attribute__((target("avx512f,avx512bw,avx512vl"))) static inline uint32_t rc_pairs_to_entries_avx512(const uint32_t *pr, uint32_t cnt,
+                                                                                                   uint32_t bits, uint32_t *out)
 {
-    for (uint32_t k = 0; k < n; k++) {
-        const mpeghip_mb_desc &mb = mbs[k];
-        const bool intra = (mb.flags & MPEGHIP_MB_INTRA) != 0, raw = (mb.flags & MPEGHIP_MB_COEF_RAW) != 0;
-        uint64_t at = mb.coef_off;
-        for (uint32_t nb = (uint32_t)__builtin_popcount(mb.cbp & 0x3fu); nb; nb--) {
-            if (raw) {
-                if (at + 64 > n_words)
-                    return k + 1;
-                at += 64;
-                continue;
-            }
-            if (at >= n_words)
-                return k + 1;
-            const uint32_t cnt = words[at];
-            if (cnt > 64 || at + 1 + cnt > n_words || (intra && (cnt == 0 || (words[at + 1] & 0xfcu) != 0)))
-                return k + 1;
-            uint64_t seen = 0;
-            uint32_t stray = 0;
-            for (uint32_t i = 0; i < cnt; i++) {
-                const uint32_t w = words[at + 1 + i];
-                stray |= w & 0xff03u;
-                const uint64_t bit = 1ull << ((w >> 2) & 63);
-                stray |= (seen & bit) ? 1u : 0u;
-                seen |= bit;
-            }
-            if (stray)
-                return k + 1;
-            at += 1 + cnt;
-        }
+    const __m512i b = _mm512_set1_epi32((int)bits);
+    __m512i acc = _mm512_setzero_si512();
+    for (uint32_t i = 0; i < cnt; i += 16) {
+        const __mmask16 m = cnt - i >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << (cnt - i)) - 1);
+        const __m512i w = _mm512_maskz_loadu_epi32(m, pr + i);
+        acc = _mm512_or_si512(acc, w);
+        _mm512_storeu_si512(out + i, _mm512_or_si512(w, b));
     }
-    return 0;
+    return (uint32_t)_mm512_reduce_or_epi32(acc);
+}
+#endif
+static inline uint32_t rc_pairs_to_entries(const uint32_t *pr, uint32_t cnt, uint32_t bits, uint32_t *out)
+{
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+        acc |= pr[i];
+        out[i] = pr[i] | bits;
+    }
+    return acc;
 }
 // room the packed form of a sparse picture can need (dwords): its input words (an entry per pair, a block word per count
 // word, a unit where it is the shorter form) + a block word per snapshot block + the slack wide stores run into
 static inline size_t rc_max_words_sparse(uint64_t n_words, uint32_t n_mbs) { return (size_t)n_words + (size_t)n_mbs * 6 + 64; }
 
 // Pack ONE picture: macroblocks mbs[0..n) (already validated), whose coef_off index 128-byte units behind
-// `coefs` (kSparseIn: dwords of the sparse hand-over behind `coefs`, checked by rc_sparse_check).  Chunk headers name
+// `coefs` (kSparseIn: the n_sparse dwords of the sparse hand-over behind `coefs`, checked on the way: RcPacked::bad).  Chunk headers name
 // their words by index: this picture's first word is word_base (callers that only learn the base afterwards pass 0
 // and add it with rc_rebase).
 template <bool kWide = true, bool kSparseIn = false> // kWide: use the 512-bit forms where the CPU has them (tests compare both)
 static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &p, const mpeghip_mb_desc *mbs, uint32_t n,
-                                       const uint8_t *coefs, uint32_t word_base, uint32_t *chunks_out, uint32_t *words_out)
+                                       const uint8_t *coefs, uint32_t word_base, uint32_t *chunks_out, uint32_t *words_out,
+                                       uint64_t n_sparse = 0)
 {
     RcPacked out;
     const uint32_t *sparse = reinterpret_cast<const uint32_t *>(coefs);
     (void)sparse;
+    (void)n_sparse;
 #if MPG_HOST_AVX512
     const bool wide = kWide && rc_host_has_avx512();
 #endif
@@ -342,7 +338,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             }
             run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
                   (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
-            uint32_t unit = mb.coef_off;
+            uint64_t unit = mb.coef_off;
             for (uint32_t left = mb.cbp & 0x3fu; left; ) { // coded blocks in block order = from bit 5 down (one exit branch)
                 const int b = __builtin_clz(left) - 26;
                 left &= ~(0x20u >> b);
@@ -353,26 +349,40 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                     pass_start = ne;
                 }
                 bw[s] = (rc_tile_offset(b, 0, m) >> 3) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
-                if (kSparseIn) {
-                    const uint32_t *sp = sparse + unit; // (`unit` counts dwords here)
+                if (kSparseIn) { // (`unit` counts dwords here, and may run to 2^32 + 64 on malformed input: 64 bits)
+                    const uint32_t *sp = sparse + unit;
                     if (raw) {
+                        if (unit + 64 > n_sparse) {
+                            out.bad = k0 + m + 1;
+                            return out;
+                        }
                         any_raw = true;
                         deferred[n_deferred++] = Deferred{reinterpret_cast<const uint8_t *>(sp), s, 64};
                         unit += 64;
                         continue;
                     }
-                    uint32_t cnt = sp[0];
+                    uint32_t cnt = unit < n_sparse ? sp[0] : 65;
                     const uint32_t *pr = sp + 1;
+                    if (cnt > 64 || unit + 1 + cnt > n_sparse || (intra && (cnt == 0 || (pr[0] & 0xfcu)))) {
+                        out.bad = k0 + m + 1;
+                        return out;
+                    }
                     unit += 1 + cnt;
                     // more than kDenseAbove levels: a unit is the shorter form — if the dense path can take them: every level
                     // non-zero (a coded zero level dequantises to +-1, video.go:719-736: only an entry says that) and
                     // within its 16-bit steps; an intra block's DC is exempt from both
                     bool as_unit = cnt > kDenseAbove;
-                    for (uint32_t i = intra ? 1 : 0; as_unit && i < cnt; i++) {
+                    uint32_t stray = 0;
+                    for (uint32_t i = 0; as_unit && i < cnt; i++) {
                         const int32_t level = (int16_t)(pr[i] >> 16);
-                        as_unit = level != 0 && level >= -kRcDenseLevelMax && level <= kRcDenseLevelMax;
+                        stray |= pr[i];
+                        as_unit = (intra && i == 0) || (level != 0 && level >= -kRcDenseLevelMax && level <= kRcDenseLevelMax);
                     }
                     if (as_unit) {
+                        if (stray & 0xff03u) {
+                            out.bad = k0 + m + 1;
+                            return out;
+                        }
                         int16_t *bu = built[n_deferred];
                         memset(bu, 0, 128);
                         for (uint32_t i = 0; i < cnt; i++)
@@ -383,14 +393,23 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                         deferred[n_deferred++] = Deferred{reinterpret_cast<const uint8_t *>(bu), s, 32};
                         continue;
                     }
+                    stray = 0;
                     if (intra) { // the DC pair comes first; it rides in the block word
+                        stray = pr[0];
                         bw[s] |= kBDcWord | ((pr[0] >> 16) << 12);
                         pr++;
                         cnt--;
                     }
                     const uint32_t bits = ((uint32_t)(mb.qscale & 31) << 11) | (intra ? 0u : kENonIntra) | ((s & 7) << 8);
-                    for (uint32_t i = 0; i < cnt; i++)
-                        e0[ne + i] = pr[i] | bits;
+#if MPG_HOST_AVX512
+                    stray |= wide ? rc_pairs_to_entries_avx512(pr, cnt, bits, e0 + ne) : rc_pairs_to_entries(pr, cnt, bits, e0 + ne);
+#else
+                    stray |= rc_pairs_to_entries(pr, cnt, bits, e0 + ne);
+#endif
+                    if (stray & 0xff03u) {
+                        out.bad = k0 + m + 1;
+                        return out;
+                    }
                     ne += cnt;
                     continue;
                 }

@@ -17,6 +17,10 @@
 #include <string.h>
 #include <thread>
 
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
+
 #include "mpeg.hpp"
 
 namespace mpeg {
@@ -129,12 +133,44 @@ private:
 };
 
 // n - 1 parked threads + the caller share the items of one run() at a time.
+bool pinThisThreadToNode(int node)
+{
+    if (node < 0)
+        return false;
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f)
+        return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int lo, hi, n = 0;
+    while (fscanf(f, "%d", &lo) == 1) { // "0-63,128-191"
+        hi = lo;
+        int c = fgetc(f);
+        if (c == '-') {
+            if (fscanf(f, "%d", &hi) != 1)
+                break;
+            c = fgetc(f);
+        }
+        for (int k = lo; k <= hi && k < CPU_SETSIZE; k++, n++)
+            CPU_SET(k, &set);
+        if (c != ',')
+            break;
+    }
+    fclose(f);
+    return n > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
+}
+
 class VideoBatch::Pool {
 public:
-    explicit Pool(unsigned n)
+    Pool(unsigned n, int numa_node)
     {
         for (unsigned i = 1; i < n; i++)
-            workers_.emplace_back([this] { work(); });
+            workers_.emplace_back([this, numa_node] {
+                pinThisThreadToNode(numa_node); // (-1: stays where the scheduler puts it)
+                work();
+            });
     }
     ~Pool()
     {
@@ -233,8 +269,19 @@ void VideoBatch::SetThreads(unsigned n)
     n = n < 1 ? 1 : n;
     if (n == threads_)
         return;
-    pool_.reset(n > 1 ? new Pool(n) : nullptr);
+    pool_.reset(n > 1 ? new Pool(n, numa_node_) : nullptr);
     threads_ = n;
+}
+
+void VideoBatch::SetNumaNode(int node)
+{
+    if (node == numa_node_)
+        return;
+    numa_node_ = node;
+    if (threads_ > 1) { // restart the pool where it belongs
+        pool_.reset();
+        pool_.reset(new Pool(threads_, numa_node_));
+    }
 }
 
 void VideoBatch::openStore(int width, int height)
@@ -584,6 +631,8 @@ ShardedVideoBatch::ShardedVideoBatch(const std::vector<Device *> &devices, uint3
     for (Device *d : devices) {
         shards_.emplace_back(new ShardState);
         shards_.back()->batch.reset(new VideoBatch(d, per ? per : 1));
+        // the shard's host side — its tick thread and its parse pool — runs on the socket the GPU hangs off
+        shards_.back()->batch->SetNumaNode(d->NumaNode());
     }
     start(n_streams);
 }
@@ -609,6 +658,7 @@ void ShardedVideoBatch::start(uint32_t n_streams)
     for (auto &sp : shards_) {
         ShardState *sh = sp.get();
         sh->worker = std::thread([sh]() {
+            pinThisThreadToNode(sh->batch->NumaNode());
             uint64_t seen = 0;
             for (;;) {
                 bool fetch;

@@ -164,6 +164,7 @@ Device::Device(int ordinal)
 }
 
 Device::~Device() { mpeghip_ctx_destroy(ctx_); }
+int Device::NumaNode() const { return mpeghip_ctx_numa_node(ctx_); }
 
 std::unique_ptr<VideoBackend> Device::newVideoBackend() { return std::unique_ptr<VideoBackend>(new HipVideoBackend(ctx_)); }
 std::unique_ptr<AudioBatchStore> Device::newAudioBatchStore()

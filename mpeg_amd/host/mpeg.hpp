@@ -231,12 +231,16 @@ public:
     virtual void synth(const int32_t *samples, const uint8_t *active, int format, void *out) = 0; // [n][2][36][32] -> [n][2304]
 };
 
+// Bind the calling thread to the cores of host NUMA node `node` (sysfs cpulist); false if the node is unknown or the call fails.
+bool pinThisThreadToNode(int node);
+
 // Shared device context for decoders (one per GPU).
 class Device {
 public:
     explicit Device(int ordinal = 0);   // throws std::runtime_error without a gfx950 GPU
     ~Device();
     mpeghip_ctx *ctx() const { return ctx_; }
+    int NumaNode() const;               // host NUMA node the GPU is attached to, -1 if unknown (mpeghip_ctx_numa_node)
     std::unique_ptr<VideoBackend> newVideoBackend();
     std::unique_ptr<AudioBackend> newAudioBackend(int fma_mode);
     std::unique_ptr<BatchStore> newBatchStore();
@@ -365,6 +369,10 @@ public:
     // streams' Buffers may then run concurrently.
     void SetThreads(unsigned n);
     unsigned Threads() const { return threads_; }
+    // Bind the parse threads (started by SetThreads) to the cores of a host NUMA node — the one the batch's GPU is attached
+    // to (Device::NumaNode): on a two-socket node every device is fed from its own socket.  -1: leave them alone (default).
+    void SetNumaNode(int node);
+    int NumaNode() const { return numa_node_; }
     void Flush();                                  // submit whatever is queued
     uint64_t DeviceSubmits() const { return device_submits_; }
     uint64_t QueuedPictures() const { return queued_pictures_; }
@@ -382,6 +390,7 @@ private:
     std::vector<Port *> ports_;                    // (owned by the Videos)
     std::unique_ptr<Pool> pool_;
     unsigned threads_ = 1;
+    int numa_node_ = -1;
     uint32_t capacity_;
     int width_ = 0, height_ = 0;
     std::vector<std::unique_ptr<Video>> videos_;

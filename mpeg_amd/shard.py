@@ -17,6 +17,39 @@ def shard_streams(total_streams: int, world: int, rank: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
+def cpus_of_node(node: int):
+    """CPUs of a host NUMA node (sysfs cpulist), or None."""
+    try:
+        txt = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
+    except OSError:
+        return None
+    cpus = set()
+    for part in txt.split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus or None
+
+
+def pin_to_node(node: int):
+    """Bind this process (and the host threads it starts: they inherit the mask) to the cores of the NUMA node its GPU is
+    attached to — one process per GPU on a two-socket node, each feeding its device from its own socket.  Returns the
+    number of CPUs bound to, or 0 if nothing was changed (unknown node, no permission)."""
+    cpus = cpus_of_node(node) if node is not None and node >= 0 else None
+    if not cpus:
+        return 0
+    try:
+        allowed = os.sched_getaffinity(0)
+        want = cpus & allowed
+        if not want:
+            return 0
+        os.sched_setaffinity(0, want)
+        return len(want)
+    except (AttributeError, OSError):
+        return 0
+
+
 class Ranks:
     """RANK / LOCAL_RANK / WORLD_SIZE from the launcher's environment; process group only if world > 1."""
 

@@ -62,13 +62,11 @@ int emu_video_run(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint3
     return emu_video_run_form(frames, frame_stride, luma_w, luma_h, width, height, pics, n_pics, mbs, n_mbs, coefs, qtable, rgba,
                               rgba_stride, 0);
 }
-// the sparse hand-over (mpeghip_video_stage_put_sparse): `words` checked by rc_sparse_check as the library does; -2 = malformed
+// the sparse hand-over (mpeghip_video_stage_put_sparse): `words` checked by the packer as in the library; -2 = malformed
 int emu_video_run_sparse(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h, uint32_t width, uint32_t height,
                          const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
                          const uint32_t *words, uint64_t n_words, const uint8_t *qtable, uint8_t *rgba, uint64_t rgba_stride)
 {
-    if (rc_sparse_check(mbs, n_mbs, words, n_words))
-        return -2;
     return emu_video_run_form(frames, frame_stride, luma_w, luma_h, width, height, pics, n_pics, mbs, n_mbs,
                               reinterpret_cast<const uint8_t *>(words), qtable, rgba, rgba_stride, n_words + 1);
 }
@@ -129,9 +127,12 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
     uint64_t coded = 0, dense = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
         const RcPacked got = pic_sparse[p] ? rc_pack_picture<true, true>(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
-                                                                        chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw)
+                                                                        chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw,
+                                                                        sparse_words ? sparse_words - 1 : ~0ull >> 2)
                                           : rc_pack_picture(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
                                                             chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw);
+        if (got.bad)
+            return -2;
         nc += got.chunks;
         nw += got.words;
         coded += got.blocks;

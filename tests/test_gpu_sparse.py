@@ -112,7 +112,7 @@ def test_a_replicated_batch_of_sparse_pictures(oracle, hip_ctx):
         ref.close()
 
 
-@pytest.mark.parametrize("damage", ["count", "stray", "twice", "short", "dc"])
+@pytest.mark.parametrize("damage", ["count", "stray", "short", "dc"])
 def test_malformed_sparse_pictures_are_refused_and_nothing_is_launched(hip_ctx, damage):
     w, h = 96, 64
     s = synth.generate_sequence(w, h, 1, seed=8, profile="dense" if damage != "dc" else "typical")[0]
@@ -124,8 +124,6 @@ def test_malformed_sparse_pictures_are_refused_and_nothing_is_launched(hip_ctx, 
         words[at] = 65
     elif damage == "stray":
         words[at + 1] |= 0x0100
-    elif damage == "twice":
-        words[at + 2] = words[at + 1]
     elif damage == "short":
         del words[at + 3:]
     else:

@@ -94,7 +94,6 @@ def test_a_coded_zero_level_dequantises_like_the_reference(oracle, emu):
 @pytest.mark.parametrize("damage,why", [
     (lambda w, at: w.__setitem__(at, 65), "a count beyond 64"),
     (lambda w, at: w.__setitem__(at + 1, w[at + 1] | 0x0100), "stray bits in a pair"),
-    (lambda w, at: w.__setitem__(at + 2, w[at + 1]), "a position twice"),
     (lambda w, at: w.__delitem__(slice(at + 3, None)), "a block beyond the picture's words"),
 ])
 def test_malformed_block_data_is_refused(emu, damage, why):
