@@ -77,6 +77,11 @@ void mpeghost_mpeg_rewind(void *mpeg);                               /* mpeg.go:
 int mpeghost_mpeg_decode_video(void *mpeg, mpeghost_frame *out);
 const float *mpeghost_mpeg_decode_audio(void *mpeg, double *time);
 int mpeghost_mpeg_has_ended(void *mpeg);
+int mpeghost_mpeg_take_done(void *mpeg);                             /* mpeg.go:155 Done(): 1 once after the stream ended without looping (the value on the channel) */
+int mpeghost_mpeg_audio_format(void *mpeg);                          /* mpeg.go:229: 0 F32N, 1 F32NLR, 2 F32, 3 S16 */
+void mpeghost_mpeg_set_audio_format(void *mpeg, int format);         /* mpeg.go:234 */
+double mpeghost_mpeg_audio_lead_time(void *mpeg);                    /* mpeg.go:301, seconds */
+void mpeghost_mpeg_set_audio_lead_time(void *mpeg, double seconds);  /* mpeg.go:308 */
 int mpeghost_mpeg_probe(void *mpeg, size_t probe_size);
 int mpeghost_mpeg_has_headers(void *mpeg);
 double mpeghost_mpeg_duration(void *mpeg);
@@ -106,6 +111,7 @@ void *mpeghost_sharded_open(void *const *devices, uint32_t n_devices, uint32_t n
 void *mpeghost_sharded_open_stores(void *const *stores, uint32_t n_stores, uint32_t n_streams); /* test stores; takes ownership */
 void mpeghost_sharded_close(void *sharded);
 int mpeghost_sharded_add_stream(void *sharded, const uint8_t *data, size_t len);
+void mpeghost_sharded_set_threads(void *sharded, unsigned n);       /* parse threads of EVERY shard (each shard's pool runs on its GPU's NUMA node) */
 int mpeghost_sharded_decode_all(void *sharded, int fetch);
 int mpeghost_sharded_frame(void *sharded, uint32_t stream, mpeghost_frame *out);
 uint32_t mpeghost_sharded_device_of(void *sharded, uint32_t stream);

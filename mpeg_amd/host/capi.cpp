@@ -271,6 +271,11 @@ const float *mpeghost_mpeg_decode_audio(void *mv, double *time)
     }, (const float *)nullptr);
 }
 int mpeghost_mpeg_has_ended(void *m) { return M(m)->HasEnded() ? 1 : 0; }
+int mpeghost_mpeg_take_done(void *m) { return M(m)->TakeDone() ? 1 : 0; }
+int mpeghost_mpeg_audio_format(void *m) { return (int)M(m)->GetAudioFormat(); }
+double mpeghost_mpeg_audio_lead_time(void *m) { return M(m)->AudioLeadTime(); }
+void mpeghost_mpeg_set_audio_lead_time(void *m, double seconds) { M(m)->SetAudioLeadTime(seconds); }
+void mpeghost_mpeg_set_audio_format(void *m, int format) { M(m)->SetAudioFormat((AudioFormat)format); }
 int mpeghost_mpeg_probe(void *m, size_t probe_size)
 {
     return guard([&]() -> int { return M(m)->Probe(probe_size) ? 1 : 0; }, -1);
@@ -415,6 +420,13 @@ int mpeghost_sharded_add_stream(void *hv, const uint8_t *data, size_t len)
         h->bufs.push_back(Buffer::FromMemory(data, len));
         h->batch->AddStream(h->bufs.back().get());
         return (int)h->batch->Streams() - 1;
+    }, -1);
+}
+void mpeghost_sharded_set_threads(void *hv, unsigned n)
+{
+    guard([&]() -> int {
+        static_cast<ShardedHandle *>(hv)->batch->SetThreads(n);
+        return 0;
     }, -1);
 }
 int mpeghost_sharded_decode_all(void *hv, int fetch)

@@ -195,10 +195,14 @@ bool MPEG::initDecoders()
 
 void MPEG::handleEnd()
 { // mpeg.go:625-632
-    if (loop_)
+    if (loop_) {
         Rewind();
-    else
+    } else {
         has_ended_ = true;
+        done_pending_ = true; // m.done <- true
+        if (done_cb_)
+            done_cb_();
+    }
 }
 
 void MPEG::readPackets(int requested_type)

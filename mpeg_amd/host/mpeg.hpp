@@ -584,7 +584,19 @@ public:
     bool AudioEnabled() const { return audio_enabled_; }  // mpeg.go:245
     void SetAudioStream(int stream_index);                // 0..3, default 0 (mpeg.go:270-279)
     void SetAudioLeadTime(double s) { audio_lead_time_ = s; }
+    double AudioLeadTime() const { return audio_lead_time_; }  // mpeg.go:301
     void SetAudioFormat(AudioFormat f);
+    AudioFormat GetAudioFormat() const { return audio_format_; } // mpeg.go:229 (AudioFormat() there: the type's name here)
+    // mpeg.go:155 Done(): the reference sends `true` on a channel of capacity 1 when the stream ends without looping
+    // (handleEnd, :625-632).  Here: a callback run at that moment, and a flag that one TakeDone() call consumes — what
+    // `select { case <-m.Done(): }` does to the channel.
+    void SetDoneCallback(std::function<void()> f) { done_cb_ = std::move(f); }
+    bool TakeDone()
+    {
+        const bool d = done_pending_;
+        done_pending_ = false;
+        return d;
+    }
     void SetVideoCallback(VideoFunc f) { video_cb_ = std::move(f); }
     void SetAudioCallback(AudioFunc f) { audio_cb_ = std::move(f); }
     int NumVideoStreams() { return demux_->NumVideoStreams(); }
@@ -612,6 +624,8 @@ public:
 private:
     bool initDecoders();
     void handleEnd();
+    std::function<void()> done_cb_;
+    bool done_pending_ = false;
     void readPackets(int requested_type);
     void open(const uint8_t *data, size_t len);
     Backends backends_;

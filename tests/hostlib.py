@@ -52,6 +52,9 @@ def host():
             "mpeghost_mpeg_rewind": (None, [P]),
             "mpeghost_mpeg_decode_video": (C.c_int, [P, C.POINTER(HostFrame)]),
             "mpeghost_mpeg_decode_audio": (P, [P, C.POINTER(C.c_double)]), "mpeghost_mpeg_has_ended": (C.c_int, [P]),
+            "mpeghost_mpeg_take_done": (C.c_int, [P]), "mpeghost_mpeg_audio_format": (C.c_int, [P]),
+            "mpeghost_mpeg_set_audio_format": (None, [P, C.c_int]), "mpeghost_mpeg_audio_lead_time": (C.c_double, [P]),
+            "mpeghost_mpeg_set_audio_lead_time": (None, [P, C.c_double]),
             "mpeghost_mpeg_open_backends": (P, [P, P, C.c_char_p, C.c_size_t]),
             "mpeghost_mpeg_probe": (C.c_int, [P, C.c_size_t]), "mpeghost_mpeg_has_headers": (C.c_int, [P]),
             "mpeghost_mpeg_duration": (C.c_double, [P]), "mpeghost_mpeg_time": (C.c_double, [P]),
@@ -70,7 +73,7 @@ def host():
             "mpeghost_sharded_open": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
             "mpeghost_sharded_open_stores": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
             "mpeghost_sharded_close": (None, [P]), "mpeghost_sharded_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
-            "mpeghost_sharded_decode_all": (C.c_int, [P, C.c_int]),
+            "mpeghost_sharded_decode_all": (C.c_int, [P, C.c_int]), "mpeghost_sharded_set_threads": (None, [P, C.c_uint]),
             "mpeghost_sharded_frame": (C.c_int, [P, C.c_uint32, C.POINTER(HostFrame)]),
             "mpeghost_sharded_device_of": (C.c_uint32, [P, C.c_uint32]),
             "mpeghost_sharded_counters": (None, [P, C.c_uint32, C.POINTER(C.c_uint64 * 2)]),
@@ -427,6 +430,9 @@ class HostSharded:
     def frame(self, stream: int):
         f = HostFrame()
         return f if host().mpeghost_sharded_frame(self.h, stream, C.byref(f)) == 1 else None
+
+    def set_threads(self, n: int):
+        host().mpeghost_sharded_set_threads(self.h, n)
 
     def device_of(self, stream: int) -> int:
         return host().mpeghost_sharded_device_of(self.h, stream)

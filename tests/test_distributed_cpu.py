@@ -74,3 +74,19 @@ def test_two_ranks_gloo():
     assert e0 == e1 and e0 > 0                                  # both ranks hold the MAX elapsed
     assert u0 == u1 == 6 * 3 * 12                               # 6 streams x 3 pictures x 12 macroblocks, summed over ranks
     assert k0 == k1 == 2.0                                      # both shards bit-exact vs the oracle
+
+
+def test_numa_helpers_parse_sysfs_and_never_raise():
+    """mpeg_amd.shard.pin_to_node: the rank's process goes to the cores of its GPU's NUMA node; unknown nodes, or a
+    platform without sysfs / sched_setaffinity, change nothing."""
+    import os
+    from mpeg_amd import shard
+    assert shard.pin_to_node(-1) == 0 and shard.pin_to_node(None) == 0 and shard.pin_to_node(4096) == 0
+    node0 = shard.cpus_of_node(0)
+    if node0 and hasattr(os, "sched_getaffinity"):
+        before = os.sched_getaffinity(0)
+        try:
+            n = shard.pin_to_node(0)
+            assert n == len(node0 & before) and (n == 0 or os.sched_getaffinity(0) == (node0 & before))
+        finally:
+            os.sched_setaffinity(0, before)

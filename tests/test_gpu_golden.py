@@ -101,9 +101,11 @@ def test_program_stream_facade_on_gpu(oracle, golden_dir, device):
     L.mpeghost_mpeg_close(m)
 
 
-def test_seek_on_gpu_matches_the_lane_emulator(emu, golden_dir, device):
-    """MPEG.Seek / SeekFrame (mpeg.go:460-576) through the HIP backend: same frames, times and callback counts
-    as the CPU run of the same host code on the test-only lane emulator."""
+def test_seek_bookkeeping_does_not_depend_on_the_backend(emu, golden_dir, device):
+    """MPEG.Seek / SeekFrame (mpeg.go:460-576) are host logic: frame times, the callback count of a seek (mpeg_test.go:
+    442-461: exactly one) and the audio / video clocks must come out the same whichever backend reconstructs the frames.
+    (NOT a parity test of the frames: those are compared with the ORACLE's in
+    tests/test_gpu_parity_holes.py::test_exact_seek_on_gpu_returns_pictures_of_the_oracles_linear_decode.)"""
     ps = (golden_dir / "test.mpg").read_bytes()
     win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
     gpu, cpu = hostlib.HostMpeg(ps, device=device), hostlib.HostMpeg(ps, window=win)
@@ -112,8 +114,6 @@ def test_seek_on_gpu_matches_the_lane_emulator(emu, golden_dir, device):
     for t, exact in ((3.0, True), (1.0, False), (6.25, True), (100.0, True), (0.0, True)):
         fg, fc = gpu.seek_frame(t, exact), cpu.seek_frame(t, exact)
         assert fg is not None and fc is not None and fg.time == fc.time
-        for a, b in zip(hostlib.frame_planes(fg), hostlib.frame_planes(fc)):
-            assert np.array_equal(a, b)
     for m in (gpu, cpu):
         m.count_callbacks()
         assert m.seek(3.001, True)

@@ -49,7 +49,7 @@ def test_config5_shard_1024_streams_of_1080p(oracle, hip_ctx):
         # So far every stream holds the same bytes: a per-stream base that is off by a stream (replicate_kernel's shifts, the
         # packer's frame offsets beyond 4 GB) would still read identical data.  Streams 0, 1, 517 and 1023 get their OWN
         # reference content, the P and B pictures run once more, each of them against its own oracle replay
-        # (oracle/crosscheck.py; profiles/r6_cross_stream_check_catches_a_shifted_base.txt: it fails on a library whose
+        # (oracle/crosscheck.py; profiles/r10_cross_stream_check_catches_a_shifted_base.txt: it fails on a library whose
         # reference base of stream 517 is stream 516's).
         from oracle import crosscheck
         batches = [dut.upload(s.pics, s.mbs, s.coefs, replicate=n_streams) for s in seq]

@@ -137,6 +137,7 @@ def test_streams_sharded_over_two_stores(oracle, golden_dir):
     clean = oracle.ps_extract((golden_dir / "test.mpg").read_bytes(), 0xE0)[0]
     streams = [es, clean, es, clean, es]
     b = hostlib.HostSharded(len(streams), 2)
+    b.set_threads(3)      # every shard parses on its own pool (pinned to its GPU's NUMA node when there is a GPU)
     for s in streams:
         b.add_stream(s)
     assert [b.device_of(i) for i in range(5)] == [0, 1, 0, 1, 0]

@@ -192,3 +192,30 @@ def test_exact_seek_returns_a_picture_of_the_linear_decode(oracle, test_mpg, win
         same = [ft for ft, planes in frames if all(np.array_equal(a, b) for a, b in zip(planes, got))]
         assert same and abs(same[0] - t) <= 3.0 / 30 + 1e-9, (t, same)
     m.close()
+
+
+def test_done_audio_format_and_lead_time_accessors(test_mpg, window):
+    """mpeg.go:155 (Done: `true` on a channel of capacity 1 when the stream ends without looping, handleEnd :625-632),
+    mpeg.go:229-238 (AudioFormat / SetAudioFormat), mpeg.go:301-310 (AudioLeadTime / SetAudioLeadTime)."""
+    m = hostlib.HostMpeg(test_mpg, window=window)
+    m.count_callbacks()                                      # (Decode only decodes what has a callback, mpeg.go:366-367)
+    H = hostlib.host()
+    assert H.mpeghost_mpeg_audio_format(m.h) == 0 and H.mpeghost_mpeg_audio_lead_time(m.h) == 0.0    # AudioF32N, no lead
+    H.mpeghost_mpeg_set_audio_lead_time(m.h, 0.25)
+    H.mpeghost_mpeg_set_audio_format(m.h, 3)
+    assert H.mpeghost_mpeg_audio_format(m.h) == 3 and H.mpeghost_mpeg_audio_lead_time(m.h) == 0.25
+    H.mpeghost_mpeg_set_audio_format(m.h, 0)
+    H.mpeghost_mpeg_set_audio_lead_time(m.h, 0.0)
+    assert H.mpeghost_mpeg_take_done(m.h) == 0                # nothing on the channel while the stream runs
+    ticks = 0
+    while not m.has_ended and ticks < 400:
+        m.decode(0.1)
+        ticks += 1
+    assert m.has_ended
+    assert H.mpeghost_mpeg_take_done(m.h) == 1 and H.mpeghost_mpeg_take_done(m.h) == 0   # one value, received once
+    m.rewind()
+    m.set_loop(True)                                          # looping streams never signal (handleEnd rewinds instead)
+    for _ in range(200):
+        m.decode(0.1)
+    assert not m.has_ended and H.mpeghost_mpeg_take_done(m.h) == 0
+    m.close()
