@@ -254,14 +254,16 @@ def secondary(leg, name, streams, args):
             "roofline": leg["roofline"], "parity": leg["parity"]}
 
 
-def audio_leg(ctx, args, streams, tile=1):
+def audio_leg(ctx, args, streams, tile=1, fma=0):
     """MP2 synthesis on `streams` x `tile` stereo streams, --audio-frames frames per launch.  tile > 1: the seeded samples
     of `streams` streams are uploaded `tile` times side by side (stream s = stream s mod `streams`): the working set of the
-    timed launch then exceeds the 256 MB Infinity Cache, and every stream is still compared with the oracle."""
+    timed launch then exceeds the 256 MB Infinity Cache, and every stream is still compared with the oracle.
+    fma: 0 = multiply and add rounded separately in the window (the reference's pure-Go / SSE2 synthWindow, audio_noasm.go:8-38:
+    golden hash 0xf1b7...), 1 = fused multiply-add (its amd64 AVX2 routine, audio_amd64.s: golden hash 0x50f3...)."""
     import ctypes as C
     from mpeg_amd import abi, desc, synth
     n, frames = streams * tile, args.audio_frames
-    a = abi.AudioSynth(ctx, n, desc.AUDIO_FMA_NONE)
+    a = abi.AudioSynth(ctx, n, desc.AUDIO_FMA_WINDOW if fma else desc.AUDIO_FMA_NONE)
     smp = synth.audio_frames(streams, frames)
     d_s, d_o = a.device_buffers(frames, desc.AUDIO_F32N)
     for t in range(tile):
@@ -271,12 +273,12 @@ def audio_leg(ctx, args, streams, tile=1):
     aparity = None
     if args.check:
         from oracle import pyoracle
-        want = pyoracle.OracleSynth(streams, 0).synth(smp, desc.AUDIO_F32N).reshape(streams, -1)
+        want = pyoracle.OracleSynth(streams, 1 if fma else 0).synth(smp, desc.AUDIO_F32N).reshape(streams, -1)
         for t in range(tile):
             got = a.download(C.c_void_p(d_o.value + t * want.nbytes), want.size, desc.AUDIO_F32N).reshape(streams, -1)
             if not np.array_equal(want.view(np.uint32), got.view(np.uint32)):
                 raise SystemExit("bench: audio samples differ from the oracle — result invalid")
-        aparity = "bit-exact vs oracle (no-FMA) on all %d streams x %d frames" % (n, frames)
+        aparity = "bit-exact vs oracle (%s) on all %d streams x %d frames" % ("FMA window" if fma else "no-FMA", n, frames)
     for _ in range(2):
         a.synth_device(d_s, frames, desc.AUDIO_F32N, d_o)
     ctx.sync()
@@ -295,7 +297,7 @@ def audio_leg(ctx, args, streams, tile=1):
         "roofline": {"bound": "hbm", "achieved": abytes / (ams * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": abytes / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                      "traffic_source_matches_build": matches, "alg_bytes_per_launch": abytes,
-                     "kernel": "audio_kernel<false, F32N> (DCT-32 + polyphase window as a sliding register file, 4 waves per stream slice)"},
+                     "kernel": "audio_kernel<%s, F32N> (DCT-32 + polyphase window as a sliding register file, 4 waves per stream slice)" % ("true" if fma else "false")},
         "parity": aparity,
     }
     a.close()
@@ -369,6 +371,8 @@ def main():
     audio_large = None
     if args.audio_streams > 0 and alone and args.audio_tile > 1:  # beyond the Infinity Cache: config 4's working set is about its size
         audio_large = audio_leg(ctx, args, args.audio_streams, args.audio_tile)
+    # the reference's other arithmetic: its amd64 AVX2 window routine uses fused multiply-adds (what it runs on any recent x86)
+    audio_fma = audio_leg(ctx, args, args.audio_streams, fma=1) if args.audio_streams > 0 and alone else None
     single = single_stream_leg(ctx, args) if alone and args.single_stream else None
 
     # ---- host-fed rate (NOT `value`): the same pictures handed over by host threads through the staged submit,
@@ -431,6 +435,7 @@ def main():
             "dense_rgba_fused": legs.get("dense_rgba_fused"),
             "audio": audio,
             "audio_large": audio_large,
+            "audio_fma_window": audio_fma,
             "single_stream": single,
             "host_fed": host_fed,
             "parity": prim["parity"],

@@ -87,12 +87,12 @@ int mpeghip_timer_stop_ms(mpeghip_ctx *ctx, float *ms); /* records, syncs, retur
  *     pad[luma_w * 16]         zero; half-pel reads past a plane end land here
  *
  * IN DEVICE MEMORY the planes are stored tiled: luma as
- * 16x16 tiles of 256 bytes, each chroma plane as 8x8 blocks of 64 bytes, tiles
- * in macroblock raster order, at the same plane offsets (0, luma_bytes,
- * luma_bytes + chroma_bytes); byte (x, y) of the luma plane lives at
- * ((y/16)*mb_w + x/16)*256 + (y%16)*16 + x%16, of a chroma plane at
- * ((y/8)*mb_w + x/8)*64 + (y%8)*8 + x%8.  Only mpeghip_video_slot_devptr
- * exposes that; the RGBA image is linear.
+ * 16x16 tiles of 256 bytes in macroblock raster order from offset 0; behind
+ * them, from luma_bytes on, one 128-byte PAIR per macroblock, its 8x8 Cb block
+ * (64 bytes) followed by its 8x8 Cr block.  Byte (x, y) of the luma plane lives at
+ * ((y/16)*mb_w + x/16)*256 + (y%16)*16 + x%16; byte (x, y) of Cb at
+ * luma_bytes + ((y/8)*mb_w + x/8)*128 + (y%8)*8 + x%8, of Cr 64 bytes further
+ * on.  Only mpeghip_video_slot_devptr exposes that; the RGBA image is linear.
  *
  * Which slot plays current/forward/backward is the caller's business (the
  * parser mirrors the rotation of video.go:406-409/430-433) and is stated per

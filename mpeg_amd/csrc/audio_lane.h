@@ -374,12 +374,15 @@ MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg,
         return;
     }
     const uint32_t e = tg * 64 + 2 * (uint32_t)i + (uint32_t)ch;
-    if (kFormat == MPEGHIP_AUDIO_F32N)
-        store_streaming(reinterpret_cast<float *>(a.out) + sb + e, sv);
-    else if (kFormat == MPEGHIP_AUDIO_S16) // audio.go:400-408
+    if (kFormat == MPEGHIP_AUDIO_S16) { // audio.go:400-408
         store_streaming(reinterpret_cast<int16_t *>(a.out) + sb + e, (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f));
-    else // MPEGHIP_AUDIO_F32, audio.go:409-417 (both constants are 2^31 in float32)
-        store_streaming(reinterpret_cast<float *>(a.out) + sb + e, sv * 2147483648.0f);
+        return;
+    }
+    // the float formats: (the stream's and the sub-block's part of the address: wave-uniform) + (the lane's: 2 i + ch)
+    uint8_t *sub_block = reinterpret_cast<uint8_t *>(a.out) + (sb + (uint64_t)tg * 64) * 4;
+    const uint32_t lane_off = (2 * (uint32_t)i + (uint32_t)ch) * 4;
+    // MPEGHIP_AUDIO_F32: audio.go:409-417 (both constants are 2^31 in float32)
+    store32_streaming_at(sub_block, lane_off, kFormat == MPEGHIP_AUDIO_F32N ? sv : sv * 2147483648.0f);
 }
 
 // one dword read that the compiler leaves alone (an LDS address space pointer keeps it a ds_read_b32)

@@ -364,6 +364,18 @@ template <bool kStream> MPG_HD void store16_at(uint8_t *uniform_base, uint32_t o
 #endif
 }
 
+// one dword per lane to (wave-uniform base) + (32-bit lane offset), non-temporal: the scalar-base form of the store — no lane
+// builds a 64-bit address (left to itself the compiler keeps a 64-bit element index per lane: v_add, v_mov, v_lshl_add_u64
+// in front of every store of the audio kernel, 3 of ~42 vector instructions per output sample)
+MPG_HD void store32_streaming_at(uint8_t *uniform_base, uint32_t off, float v)
+{
+#if MPG_ON_DEVICE
+    asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(off), "v"(v), "s"(uniform_base) : "memory");
+#else
+    __builtin_memcpy(uniform_base + off, &v, 4);
+#endif
+}
+
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its
 // own L2).  Gives every XCD one contiguous range of work chunks so that
 // neighbouring macroblocks — which share 128-byte destination lines and overlapping

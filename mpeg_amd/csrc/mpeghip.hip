@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
             } else {
                 zero_columns();
             }
-            if (mine)
+            if (rc_any_dcword(c) && mine)
                 rc_dc_from_word(bw, lane, v);
             if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are, from HBM
                 rc_raw_cols(a, c, bw, lane, v);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
             } else {
                 zero_columns();
             }
-            if (mine)
+            if (rc_any_dcword(c) && mine)
                 rc_dc_from_word(bw, lane, v);
             dense_columns();
             idct8<false>(v);

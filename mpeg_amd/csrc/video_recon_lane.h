@@ -11,6 +11,7 @@
 //                   h3 index (into words) of the chunk's first block word     h4 of its first coefficient entry
 //                   h5 entries of pass 0 | pass 1 << 10 | pass 2 << 20 | kCRun | kCRgba
 //                   h6 coded blocks (0..24) | live macroblocks << 8 | any snapshot block << 16 | any dense block << 17
+//                      | any block with its DC in its block word << 18
 //           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24        d1 reference frame offset >> 8
 //                   d2 the luma prediction window, origin (x0, y0) = macroblock origin + integer vector:
 //                      byte offset (inside the frame) of the 16x16 TILE that holds (x0, y0) | (y0 & 15) << 4 | x0 & 15
@@ -33,9 +34,10 @@
 //           each, and DENSE blocks — more than 32 non-zero levels, where a unit as the ABI hands it over
 //           (64 int16 levels, 32 dwords) is the shorter form
 //
-// The reference's VLC loop produces exactly such (position, level) pairs (video.go:680-745); the ABI hands
-// them over as dense 128-byte units, the packer drops the zeros again.  Dequantisation, premultiply, IDCT,
-// prediction and write-back all happen on the device:
+// The reference's VLC loop produces exactly such (position, level) pairs (video.go:680-745); the ABI takes them
+// as they are (MPEGHIP_PIC_SPARSE: a pair is an entry short of three bit fields) or as dense 128-byte units, of
+// which the packer drops the zeros again.  Dequantisation, premultiply, IDCT, prediction and write-back all
+// happen on the device:
 //
 //   1  scalar loads: header + 4 records.  Then SEVEN vector loads per wave, all issued before the first use: the
 //      first 64 entries and the first pass's block words (one dword per lane each, into registers), and five
@@ -45,9 +47,11 @@
 //      PAIRS x 2 blocks (a 16-byte piece = 2 rows of an 8x8 block).  Pieces are whole tile rows; the window's byte
 //      offset inside them (wave-uniform) is applied when the taps are read.  No registers hold prediction data (the first version of this kernel kept 32 of them and needed
 //      19 load instructions per wave, with ds_bpermute for the row below).
-//   2  residual pass (8 coded blocks at a time): zero the wave's int32 tile T[8][64]; one entry per lane:
-//      dequantise (video.go:719-744) and scatter to T[slot & 7][position]; lane (g, j): column j of block
-//      g (two 16-byte LDS reads), column pass, transposed write-back, row j, row pass (+128 >> 8).
+//   2  residual pass (8 coded blocks at a time): zero the wave's tile T[8][64]; one entry per lane:
+//      dequantise (video.go:719-744) and scatter to T[slot & 7][position]; an intra block's DC from its block word; lane
+//      (g, j): column j of block g, column pass, transposition, row j, row pass (+128 >> 8).  Dense units are dequantised
+//      straight from the words, two levels at a time on packed 16-bit halves.  The tile comes in two forms = two kernel
+//      instances (below: int16 + transposition across lanes, int32 + transposition through the tile).
 //   3  motion compensation, per macroblock with WAVE-UNIFORM half-pel modes (video_noasm.go:48-80): luma
 //      by 64 lanes x 4 pixels, chroma by 32 lanes x 4 pixels, taps read from the window in LDS, result written
 //      over it (every lane has its taps before any lane writes): the macroblock's 384 output bytes O_m.
@@ -57,8 +61,8 @@
 //   5  the four O_m leave as whole 64-byte luma / 32-byte chroma rows when the chunk is a horizontal run
 //      (kCRun), else as 8-byte rows per block; pictures flagged MPEGHIP_PIC_RGBA are colour-converted from them.
 //
-// Wave-private LDS, 5696 bytes (28 waves per CU = 7 per SIMD):
-//      [   0,  192) table    [ 192 + 864 m, + 864) window m -> O_m    [3648, 5696) T
+// Wave-private LDS, 4 672 or 5 696 bytes (32 / 28 waves per CU = 8 / 7 per SIMD):
+//      [   0,  192) table    [ 192 + 864 m, + 864) window m -> O_m    [3648, 4672 / 5696) T
 #pragma once
 
 #include "video_lane.h"
@@ -296,7 +300,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         uint32_t n_slots = 0, n_deferred = 0;
         uint32_t *bw = words_out + out.words;
         uint32_t *e0 = bw + n_coded, ne = 0, counts = 0, pass_start = 0;
-        bool any_raw = false, any_dense = false;
+        bool any_raw = false, any_dense = false, any_dcword = false;
         bool run = live == (uint32_t)kRcMbs; // 4 consecutive macroblocks of one row = 4 consecutive tiles
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++) {
             uint32_t *d = h + 8 + m * 4;
@@ -397,6 +401,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                     if (intra) { // the DC pair comes first; it rides in the block word
                         stray = pr[0];
                         bw[s] |= kBDcWord | ((pr[0] >> 16) << 12);
+                        any_dcword = true;
                         pr++;
                         cnt--;
                     }
@@ -430,6 +435,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                     uint16_t dc;
                     memcpy(&dc, u, 2);
                     bw[s] |= kBDcWord | ((uint32_t)dc << 12);
+                    any_dcword = true;
                     mask &= ~1ull;
                 }
                 if (as_unit) {
@@ -467,7 +473,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         h[3] = word_base + out.words;
         h[4] = word_base + out.words + n_slots;
         h[5] = counts | (run ? kCRun : 0u) | (rgba ? kCRgba : 0u);
-        h[6] = n_slots | (live << 8) | (any_raw ? 1u << 16 : 0u) | (any_dense ? 1u << 17 : 0u);
+        h[6] = n_slots | (live << 8) | (any_raw ? 1u << 16 : 0u) | (any_dense ? 1u << 17 : 0u) | (any_dcword ? 1u << 18 : 0u);
         h[7] = 0;
         out.chunks++;
         out.words += n_slots + ne;
@@ -512,6 +518,7 @@ MPG_HD uint32_t rc_n_blocks(const RcChunk &c) { return c.h[6] & 0xff; }
 MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[6] >> 8) & 0xff; }
 MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[6] >> 16) & 1; }
 MPG_HD bool rc_any_dense(const RcChunk &c) { return (c.h[6] >> 17) & 1; }
+MPG_HD bool rc_any_dcword(const RcChunk &c) { return (c.h[6] >> 18) & 1; } // (intra macroblocks only: most chunks skip the test per lane)
 MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[5] >> (10 * pass)) & 0x3ff; }
 
 // what depends on the lane only (worked out once per wave)

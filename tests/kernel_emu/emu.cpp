@@ -200,7 +200,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                     else
                         for (int r = 0; r < 8; r++)
                             v[lane][r] = 0;
-                    if (mine)
+                    if (rc_any_dcword(c) && mine)
                         rc_dc_from_word(bw[lane], lane, v[lane]);
                     if (rc_any_raw(c) && mine && (bw[lane] & kBRaw))
                         rc_raw_cols(a, c, bw[lane], lane, v[lane]);
@@ -254,7 +254,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                 else
                     for (int r = 0; r < 8; r++)
                         v[lane][r] = 0;
-                if (mine)
+                if (rc_any_dcword(c) && mine)
                     rc_dc_from_word(bw[lane], lane, v[lane]);
                 if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
                     rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
