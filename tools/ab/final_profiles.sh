@@ -6,7 +6,7 @@
 #   3. rocprofv3 --pmc (separate passes, nothing else traced)      -> <tag>_pmc_<typical|dense|audio>.txt
 #   4. HBM traffic FETCH_SIZE / WRITE_SIZE per workload            -> <tag>_pmc_traffic.json = profiles/pmc_traffic.json
 # Every output names the sha256 of mpeg_amd/csrc/* it was measured on; bench.py compares it with the sources it loaded
-# (roofline.traffic_source_matches_build).      usage: bash tools/ab/final_profiles.sh <tag>
+# (roofline.traffic_source_matches_build).      usage: bash tools/ab/final_profiles.sh <tag> [quick]
 set -u
 T=${1:-rfinal}; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$T; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -26,6 +26,21 @@ stats() { # name, bench args...
   cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o trace -- python $R/bench.py "$@" > $OUT/trace_$name.log 2>&1; echo "stats $name rc=$?"
   cd $R
   for f in $(find $OUT/trace_$name -name "*kernel_stats.csv" | head -1); do ( echo "# csrc_sha256 $SHA   bench.py $*"; cat $f ) > $OUT/kernel_stats_$name.csv; done
+  # per dispatch: the stats' average includes the warm-up launches (the first ones run on cold caches); bench.py times the
+  # launches after them — the average of the last --steps dispatches of the reconstruction kernel is the comparable figure
+  for f in $(find $OUT/trace_$name -name "*kernel_trace.csv" | head -1); do python - "$f" "$OUT/kernel_stats_$name.csv" <<PY
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "recon_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+if d:
+    timed = d[-20:] if len(d) > 20 else d
+    line = "# %s: %d dispatches; the last %d (= the timed steps): average %.4f ms, min %.4f, max %.4f; the first %d (warm-up, cold caches): average %.4f ms" % (
+        rows[-1]["Kernel_Name"][:40], len(d), len(timed), sum(timed) / len(timed), min(timed), max(timed), len(d) - len(timed), sum(d[:len(d) - len(timed)]) / max(1, len(d) - len(timed)))
+    print(line)
+    open(sys.argv[2], "a").write(line + "\n")
+PY
+  done
   find $OUT/trace_$name -name "*kernel_trace.csv" -delete
 }
 stats typical --profile typical --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
@@ -34,6 +49,7 @@ stats fused --profile typical --rgba 1 --legs "" --audio-streams 0 --cpu-seconds
 stats dense_fused --profile dense --rgba 1 --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats audio --streams 16 --legs "" --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 2 --warmup 1 --audio-tile 8
 stats bench_default --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --check 0 --host-fed-seconds 0
+[ "${2:-}" = quick ] && { ls $OUT; exit 0; }   # (bench line + kernel stats only)
 # PMC
 bash tools/gpu_pmc.sh ${T}/pmc_typical typical --host-fed-seconds 0 --single-stream 0 > $OUT/pmc_typical.log 2>&1; ( echo "# csrc_sha256 $SHA"; cat $OUT/pmc_typical/pmc_summary.txt ) > $OUT/pmc_typical.txt
 bash tools/gpu_pmc.sh ${T}/pmc_dense dense --host-fed-seconds 0 --single-stream 0 > $OUT/pmc_dense.log 2>&1; ( echo "# csrc_sha256 $SHA"; cat $OUT/pmc_dense/pmc_summary.txt ) > $OUT/pmc_dense.txt
