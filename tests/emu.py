@@ -98,11 +98,29 @@ def _qtable(intra, non_intra):
 
 
 class EmuStore:
-    def __init__(self, width, height, n_streams=1):
+    def __init__(self, width, height, n_streams=1, guard=False):
+        """guard: the frame store ends exactly at an inaccessible page (mmap + mprotect), sized as mpeghip_video_open sizes it
+        (slots + the tail pad behind the last one): a lane that reads further than the product's allocation faults
+        (checked once with the pad taken out: SIGSEGV in the gather)."""
         self.g = desc.geometry(width, height)
         self.n_streams = n_streams
         self.stride = (self.g["frame_bytes"] + 64 + 255) // 256 * 256
-        self.frames = np.zeros(self.stride * 3 * n_streams, np.uint8)
+        self.tail_pad = (self.g["luma_w"] + 64 + 255) // 256 * 256           # mpeghip.hip: mpeghip_video_open
+        total = self.stride * 3 * n_streams + self.tail_pad
+        if guard:
+            import mmap
+            page = mmap.PAGESIZE
+            room = (total + page - 1) // page * page
+            self._map = mmap.mmap(-1, room + page)
+            base = C.addressof(C.c_char.from_buffer(self._map))
+            libc = C.CDLL(None, use_errno=True)
+            libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+            assert libc.mprotect(base + room, page, 0) == 0                   # PROT_NONE
+            whole = np.frombuffer(self._map, np.uint8, room)
+            self.frames = whole[room - total:]                                # ends exactly at the guard page
+            self.frames[:] = 0
+        else:
+            self.frames = np.zeros(total, np.uint8)
         self.rgba_stride = (width * height * 4 + 255) // 256 * 256
         self.rgba = np.zeros(self.rgba_stride * 3 * n_streams, np.uint8)
         self.qmat = np.zeros((n_streams + 4, 256), np.uint8)   # (+ the padding the lanes may read, as on the device)

@@ -201,3 +201,34 @@ def test_audio_slices_tile_the_launch_on_the_step_grid(emu):
                         assert t0.value >= 15 and (t0.value - g) % 32 == 0
                     at = t1.value
                 assert at == n, (n_frames, n_chunks, vpos0)
+
+
+def test_a_window_that_ends_with_the_slot_reads_nothing_behind_the_allocation(oracle, emu):
+    """Round 2's advisor finding: a kRSlow gather always fetches 17 luma rows x 32 bytes / 9 chroma rows x 16 bytes from the
+    dword below the window origin — a row and a piece more than the half-pel mode (and the validation) needs.  A vector the
+    reference accepts — bottom-row macroblock, mv_y = +128: its Cr window ends with the slot's pad — makes that extra row run
+    up to chroma_w + 8 bytes past frame_bytes; for slot 2 of the last stream that is past the frame store unless the store
+    has its tail pad (mpeghip_video_open).  Here the store ends exactly at an inaccessible page, sized like the product's."""
+    w, h, n = 640, 208, 2          # chroma_w + 8 = 328 bytes of overrun > the stride's own slack (at most 319)
+    g = desc.geometry(w, h)
+    assert g["luma_h"] // 4 + 16 > 64          # the chroma planes' reach into the pad is what bounds the vector, not luma's
+    ref, dut = oracle.OracleStore(w, h, n), emu.EmuStore(w, h, n, guard=True)
+    rng = np.random.default_rng(4)
+    for st in range(n):
+        for slot in range(3):
+            y, cb, cr = (rng.integers(0, 256, k, dtype=np.uint8) for k in (g["luma_bytes"], g["chroma_bytes"], g["chroma_bytes"]))
+            ref.write_planes(st, slot, y, cb, cr)
+            dut.write_planes(st, slot, y, cb, cr)
+    mbs = np.zeros(g["mb_w"], desc.MB_DTYPE)
+    mbs["mb_x"], mbs["mb_y"] = np.arange(g["mb_w"]), g["mb_h"] - 1
+    mbs["mv_x"], mbs["mv_y"] = 0, 128
+    mbs["flags"] = desc.MB_REF_FWD
+    mbs["qscale"] = 1
+    pics = np.zeros(1, desc.PIC_DTYPE)
+    pics["stream"], pics["cur"], pics["fwd"], pics["bwd"] = n - 1, 0, 2, 1     # predicts from the LAST slot of the LAST stream
+    pics["mb_count"] = len(mbs)
+    coefs = np.zeros(0, np.uint8)
+    ref.submit(pics, mbs, coefs)
+    dut.submit(pics, mbs, coefs)          # (a read past the store would fault here)
+    for a, b in zip(ref.read_planes(n - 1, 0), dut.read_planes(n - 1, 0)):
+        assert np.array_equal(a, b)

@@ -127,3 +127,58 @@ def test_to_sparse_is_what_the_header_describes():
     if s.mbs[k]["flags"] & desc.MB_INTRA:
         want.setdefault(0, np.int16(0))
     assert got == want
+
+
+def test_mutated_sparse_words_are_refused_or_reconstructed_never_worse(oracle, emu):
+    """Bit flips in count and pair words: the packer either refuses the picture (-2) or packs it — then whatever it accepted
+    is a well-formed picture (counts within the buffer, no stray bits), which the lane functions reconstruct with all of their
+    range checks on (MPG_EMU_CHECKS) and which the oracle reconstructs to the same bytes from the equivalent units, unless a
+    position was named twice (unspecified by the ABI: then only the absence of a crash is checked)."""
+    import random
+    w, h = 64, 48
+    s = synth.generate_sequence(w, h, 2, seed=17, profile="typical")[1]
+    first = synth.generate_sequence(w, h, 2, seed=17, profile="typical")[0]
+    mbs, words0 = desc.to_sparse(s.mbs, s.coefs)
+    refused = accepted = compared = 0
+    for seed in range(150):
+        rng = random.Random(seed)
+        words = words0.copy()
+        for _ in range(rng.randrange(1, 4)):
+            words[rng.randrange(len(words))] ^= np.uint32(1 << rng.randrange(32))
+        dut = emu.EmuStore(w, h)
+        dut.submit(first.pics, first.mbs, first.coefs)
+        rc = dut.submit_sparse(s.pics[0], mbs, words)
+        assert rc in (0, -2)
+        if rc == -2:
+            refused += 1
+            continue
+        accepted += 1
+        # the same picture as units (possible when no snapshot data was hit, no level is a coded zero and no position repeats)
+        units = np.zeros((int(sum(bin(int(c)).count("1") for c in mbs["cbp"])), 64), np.int16)
+        m2, ok, u = s.mbs.copy(), True, 0
+        for k in range(len(mbs)):
+            at = int(mbs[k]["coef_off"])
+            if mbs[k]["flags"] & desc.MB_COEF_RAW:
+                ok = False
+                break
+            m2[k]["coef_off"] = u
+            for _ in range(bin(int(mbs[k]["cbp"])).count("1")):
+                n = int(words[at])
+                pairs = words[at + 1:at + 1 + n]
+                pos = (pairs >> 2) & 63
+                lev = (pairs >> 16).astype(np.uint16).view(np.int16)
+                intra = bool(mbs[k]["flags"] & desc.MB_INTRA)
+                if len(set(pos.tolist())) != n or (lev[1 if intra else 0:] == 0).any():
+                    ok = False
+                units[u, pos] = lev
+                u += 1
+                at += 1 + n
+        if not ok:
+            continue
+        ref = oracle.OracleStore(w, h)
+        ref.submit(first.pics, first.mbs, first.coefs)
+        ref.submit(s.pics, m2, units.reshape(-1).view(np.uint8))
+        for slot in range(3):
+            assert_planes_equal(ref.read_planes(0, slot), dut.read_planes(0, slot), "seed %d slot %d" % (seed, slot))
+        compared += 1
+    assert refused >= 20 and accepted >= 20 and compared >= 10, (refused, accepted, compared)
