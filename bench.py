@@ -383,6 +383,7 @@ def main():
         seq = prim["seq"]
         from tools import hostbench
         pps = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds, sparse=True)
+        pps16 = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, min(16, threads), args.host_fed_seconds / 2, sparse=True)
         pps_units = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds / 2, sparse=False)
         mb_per_pic = float(np.mean([len(s.mbs) for s in seq]))
         # what the link gives a bare copy from pinned memory (64 MB pieces, the size the staged submit sends), next to what the
@@ -401,6 +402,7 @@ def main():
         host_fed = {"metric": "1080p macroblocks/sec handed over by host threads (mpeghip_video_stage_*: validation + packing on the host, "
                               "PCIe, reconstruction), pictures in the parser's sparse form — PCIe inclusive, NOT `value`",
                     "value": pps * mb_per_pic, "pictures_per_s": pps, "pictures_per_s_unit_form": pps_units, "host_threads": threads,
+                    "pictures_per_s_16_threads": pps16,  # (the rate peaks near 16 putting threads: tools/hostbench/sweep.py)
                     "pictures_per_call": 64, "realtime_1080p30_streams": pps * mb_per_pic / MB_PER_1080P30_STREAM,
                     "device_format_bytes_per_picture": prim["device_bytes_per_picture"],
                     "pcie_GBps_used": pps * prim["device_bytes_per_picture"] / 1e9, "pcie_h2d_GBps_bare_copy": h2d,
