@@ -110,6 +110,8 @@ def cpu_baseline(args, seq):
                   "1080p stream each over the bench GOP (%s profile), %d macroblocks in %.1f s; single thread: %.3g "
                   "macroblocks/s" % (threads, args.profile, nT, args.cpu_seconds * 0.75, r1),
         "single_thread": r1,
+        # what the threads really got: a container with a CPU-time quota runs 256 threads on far fewer cores' worth of time
+        "speedup_over_one_thread": rT / r1,
     }
 
 
