@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--gop", type=int, default=13, help="pictures in the cycled decode-order GOP")
-    ap.add_argument("--profile", default="typical", choices=["typical", "dense", "typical_nocoef", "typical_fullpel"],
+    ap.add_argument("--profile", default="typical", choices=["typical", "dense", "typical_nocoef", "typical_fullpel", "mc_copy", "mc_horiz", "mc_vert", "mc_bilin"],
                     help="workload of the PRIMARY leg (`value`): typical is the reported one; the others are diagnostics")
     ap.add_argument("--rgba", type=int, default=0, help="1: the primary leg fuses Frame.RGBA into the reconstruction kernel")
     ap.add_argument("--legs", default="dense,rgba_fused,dense_rgba_fused",
@@ -61,6 +61,9 @@ def parse_args():
                          "(N=1 only; PCIe inclusive, not `value`; 0 = skip, e.g. under a kernel trace: it launches the "
                          "reconstruction kernel on small batches)")
     ap.add_argument("--single-stream", type=int, default=1, help="1: the one-stream fused-RGBA leg of BASELINE config 3 (N=1 only)")
+    ap.add_argument("--reference-benchmarks", type=int, default=1,
+                    help="1: the reference's own micro-benchmarks through this path (copyMacroblock modes; DecodeVideo / DecodeAudio / "
+                         "RGBA on the golden test files), N=1 only; also off with --single-stream 0 (the quick / traced runs)")
     ap.add_argument("--audio-tile", type=int, default=8,
                     help="second audio point: --audio-streams x this many streams (working set beyond the Infinity Cache; 1 = skip)")
     ap.add_argument("--audio-streams", type=int, default=256)
@@ -122,7 +125,7 @@ def build_sequence(args, profile, rgba):
     vectors in both axes, 1 635 algorithmic bytes per macroblock)."""
     from mpeg_amd import desc, synth
     seq = synth.generate_sequence(args.width, args.height, args.gop, profile=profile, rgba=rgba)
-    if profile == "dense":
+    if profile == "dense" or profile.startswith("mc_"):
         return seq[:1] + [s for s in seq[1:] if s.picture_type == desc.PIC_P], 1
     return seq, 0
 
@@ -320,6 +323,72 @@ def single_stream_leg(ctx, args):
     return out
 
 
+def reference_benchmarks(ctx, args, device):
+    """The reference's own benchmarks through this path.  BenchmarkCopyMacroblock{Copy,Horiz,Vert,Bilin} (video_test.go:105-118:
+    copyMacroblock with the vectors (0,0), (1,0), (0,1), (3,3)) as pictures of 1024 streams in which every macroblock is
+    predicted with that vector and has no coded block; BenchmarkDecodeVideo / DecodeAudio / RGBA (mpeg_test.go:463-508) on
+    testdata/test.mpg through the host stack (libmpeghost: demux + parse on one host thread, one submit per picture, every
+    frame / sample block read back as the benchmark's loop receives them)."""
+    out = {"copy_macroblock": {}}
+    for mode in ("mc_copy", "mc_horiz", "mc_vert", "mc_bilin"):
+        leg = video_leg(ctx, args, mode, False, args.streams)
+        out["copy_macroblock"][mode[3:]] = {"macroblocks_per_s": leg["mbs"] / leg["elapsed"], "ns_per_macroblock": leg["elapsed"] / leg["mbs"] * 1e9,
+                                            "frac": leg["roofline"]["frac"], "achieved_GBps": leg["roofline"]["achieved"],
+                                            "avg_launch_ms": leg["roofline"]["avg_launch_ms"], "parity": leg["parity"]}
+    import ctypes as C
+    ps = ROOT / "tests" / "golden" / "test.mpg"
+    so = ROOT / "mpeg_amd" / "libmpeghost.so"
+    if ps.exists() and so.exists():
+        H = C.CDLL(str(so))
+        P = C.c_void_p
+        H.mpeghost_device_create.restype, H.mpeghost_device_create.argtypes = P, [C.c_int]
+        H.mpeghost_mpeg_open.restype, H.mpeghost_mpeg_open.argtypes = P, [P, C.c_char_p, C.c_size_t]
+        H.mpeghost_mpeg_decode_video.restype, H.mpeghost_mpeg_decode_video.argtypes = C.c_int, [P, C.c_void_p]
+        H.mpeghost_mpeg_decode_audio.restype, H.mpeghost_mpeg_decode_audio.argtypes = P, [P, C.POINTER(C.c_double)]
+        H.mpeghost_mpeg_set_enabled.argtypes = [P, C.c_int, C.c_int]
+        H.mpeghost_mpeg_set_loop.argtypes = [P, C.c_int]
+        H.mpeghost_mpeg_close.argtypes = [P]
+        H.mpeghost_device_destroy.argtypes = [P]
+        H.mpeghost_video_open.restype, H.mpeghost_video_open.argtypes = P, [P, C.c_char_p, C.c_size_t]
+        H.mpeghost_video_decode.restype, H.mpeghost_video_decode.argtypes = C.c_int, [P, C.c_void_p]
+        H.mpeghost_video_rgba.restype, H.mpeghost_video_rgba.argtypes = P, [P]
+        H.mpeghost_video_close.argtypes = [P]
+        data = ps.read_bytes()
+        dev = H.mpeghost_device_create(device)
+        frame = (C.c_uint8 * 256)()   # mpeghost_frame (opaque here: time, sizes, plane pointers)
+        def run(video, n):
+            m = H.mpeghost_mpeg_open(dev, data, len(data))
+            H.mpeghost_mpeg_set_loop(m, 1)
+            H.mpeghost_mpeg_set_enabled(m, 1 if video else 0, 0 if video else 1)
+            t = C.c_double()
+            for _ in range(20):  # warm-up
+                H.mpeghost_mpeg_decode_video(m, frame) if video else H.mpeghost_mpeg_decode_audio(m, C.byref(t))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                H.mpeghost_mpeg_decode_video(m, frame) if video else H.mpeghost_mpeg_decode_audio(m, C.byref(t))
+            dt = time.perf_counter() - t0
+            H.mpeghost_mpeg_close(m)
+            return n / dt
+        out["decode_video_test_mpg"] = {"pictures_per_s": run(True, 2000), "what": "MPEG.DecodeVideo in a loop, 160x120, planes read back"}
+        out["decode_audio_test_mpg"] = {"frames_per_s": run(False, 2000), "what": "MPEG.DecodeAudio in a loop, 1152 stereo samples per frame, read back"}
+        es = ROOT / "tests" / "golden" / "test.mpeg1video"
+        if es.exists():
+            ed = es.read_bytes()
+            v = H.mpeghost_video_open(dev, ed, len(ed))
+            if v and H.mpeghost_video_decode(v, frame) == 1:
+                for _ in range(20):
+                    H.mpeghost_video_rgba(v)
+                t0 = time.perf_counter()
+                for _ in range(2000):
+                    H.mpeghost_video_rgba(v)
+                out["rgba_test_mpeg1video"] = {"frames_per_s": 2000 / (time.perf_counter() - t0),
+                                               "what": "Frame.RGBA() of one decoded 160x120 frame in a loop: conversion on the device + read-back"}
+            if v:
+                H.mpeghost_video_close(v)
+        H.mpeghost_device_destroy(dev)
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -376,6 +445,7 @@ def main():
     # the reference's other arithmetic: its amd64 AVX2 window routine uses fused multiply-adds (what it runs on any recent x86)
     audio_fma = audio_leg(ctx, args, args.audio_streams, fma=1) if args.audio_streams > 0 and alone else None
     single = single_stream_leg(ctx, args) if alone and args.single_stream else None
+    ref_bench = reference_benchmarks(ctx, args, local_rank) if alone and args.reference_benchmarks and args.single_stream else None
 
     # ---- host-fed rate (NOT `value`): the same pictures handed over by host threads through the staged submit,
     # i.e. validation + packing into the device format on the host, PCIe, reconstruction on the device
@@ -441,6 +511,7 @@ def main():
             "audio_large": audio_large,
             "audio_fma_window": audio_fma,
             "single_stream": single,
+            "reference_benchmarks": ref_bench,
             "host_fed": host_fed,
             "parity": prim["parity"],
         }

@@ -109,10 +109,14 @@ def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", 
     mbs["mb_x"], mbs["mb_y"] = mb_x, mb_y
     qscale = rng.integers(1, 32, size=n)
 
+    # "mc_copy" / "mc_horiz" / "mc_vert" / "mc_bilin": prediction only, every macroblock of a predicted picture with the
+    # half-pel mode of the reference's BenchmarkCopyMacroblock{Copy,Horiz,Vert,Bilin} (video_test.go:105-118)
+    # — the same vector for every macroblock, the reference's: (0,0), (1,0), (0,1), (3,3)
+    mc_mode = {"mc_copy": (0, 0), "mc_horiz": (1, 0), "mc_vert": (0, 1), "mc_bilin": (3, 3)}.get(profile)
     if picture_type == desc.PIC_I:
         intra = np.ones(n, bool)
         skipped = np.zeros(n, bool)
-    elif profile == "dense":
+    elif profile == "dense" or mc_mode:
         intra = np.zeros(n, bool)
         skipped = np.zeros(n, bool)
     else:
@@ -125,6 +129,11 @@ def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", 
         mvy = rng.integers(-16, 16, size=n) * 2 + 1
         bad = ~mv_in_range(g, mb_x, mb_y, mvx, mvy)
         mvx[bad], mvy[bad] = 1, 1
+    elif mc_mode:
+        mvx = np.full(n, mc_mode[0], np.int64)
+        mvy = np.full(n, mc_mode[1], np.int64)
+        bad = ~mv_in_range(g, mb_x, mb_y, mvx, mvy)
+        mvx[bad], mvy[bad] = 0, 0
     else:
         mvx = rng.integers(-32, 33, size=n)
         mvy = rng.integers(-32, 33, size=n)
@@ -157,7 +166,7 @@ def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", 
         order = np.argsort(rng.random((n, 6)), axis=1)
         bits = (np.argsort(order, axis=1) < pop[:, None])
         cbp = (bits * (0x20 >> np.arange(6))[None, :]).sum(axis=1)
-    if profile in ("typical_nocoef", "typical_fullpel"):  # diagnostic: prediction only (intra stays coded)
+    if profile in ("typical_nocoef", "typical_fullpel") or mc_mode:  # prediction only (intra stays coded)
         cbp = np.zeros(n, np.int64)
     cbp = np.where(intra, 0x3f, cbp)
     cbp = np.where(skipped, 0, cbp)
