@@ -496,6 +496,18 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// Nothing throws across the C ABI: entry points that allocate on the host (std::vector, new) run their bodies through this.
+template <class F> static int no_throw(F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(MPEGHIP_ERR_OOM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(MPEGHIP_ERR_HIP, "unexpected exception: %s", e.what());
+    }
+}
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -1397,7 +1409,7 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
     return MPEGHIP_OK;
 }
 
-int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs,
+static int mpeghip_video_submit_impl(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs,
                          uint32_t n_mbs, const void *coefs, size_t coef_bytes)
 {
     if (!v)
@@ -1417,7 +1429,13 @@ int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_
     return MPEGHIP_OK;
 }
 
-int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
+int mpeghip_video_submit(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs,
+                         uint32_t n_mbs, const void *coefs, size_t coef_bytes)
+{
+    return no_throw([&] { return mpeghip_video_submit_impl(v, pics, n_pics, mbs, n_mbs, coefs, coef_bytes); });
+}
+
+static int mpeghip_video_stage_begin_impl(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
                               mpeghip_stage **out)
 {
     if (!v || !out || (n_pics && (!n_mbs || !coef_bytes)))
@@ -1474,7 +1492,13 @@ int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t 
     return MPEGHIP_OK;
 }
 
-int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
+int mpeghip_video_stage_begin(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *coef_bytes,
+                              mpeghip_stage **out)
+{
+    return no_throw([&] { return mpeghip_video_stage_begin_impl(v, n_pics, n_mbs, coef_bytes, out); });
+}
+
+static int mpeghip_video_stage_begin_sparse_impl(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
                                      mpeghip_stage **out)
 {
     if (!n_words && n_pics)
@@ -1488,8 +1512,14 @@ int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const ui
     return mpeghip_video_stage_begin(v, n_pics, n_mbs, bytes.data(), out);
 }
 
+int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
+                                     mpeghip_stage **out)
+{
+    return no_throw([&] { return mpeghip_video_stage_begin_sparse_impl(v, n_pics, n_mbs, n_words, out); });
+}
+
 // Thread-safe for distinct i: touches only picture i's part of the staging buffer and of the stage's arrays.
-int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
+static int mpeghip_video_stage_put_impl(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
                             const void *coefs)
 {
     if (!s || !pic)
@@ -1570,6 +1600,12 @@ int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
     return rc;
 }
 
+int mpeghip_video_stage_put(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
+                            const void *coefs)
+{
+    return no_throw([&] { return mpeghip_video_stage_put_impl(s, i, pic, mbs, coefs); });
+}
+
 int mpeghip_video_stage_put_sparse(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
                                    const uint32_t *words)
 {
@@ -1595,7 +1631,7 @@ int mpeghip_video_submit_sparse(mpeghip_video *v, const mpeghip_pic_desc *pic, c
     return mpeghip_video_submit(v, &p, 1, mbs, n_mbs, words, n_words * 4);
 }
 
-int mpeghip_video_stage_commit(mpeghip_stage *sp)
+static int mpeghip_video_stage_commit_impl(mpeghip_stage *sp)
 {
     if (!sp)
         return fail(MPEGHIP_ERR_INVALID, "stage_commit: NULL stage");
@@ -1654,7 +1690,12 @@ int mpeghip_video_stage_commit(mpeghip_stage *sp)
     return MPEGHIP_OK;
 }
 
-int mpeghip_video_batch_upload_replicated(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+int mpeghip_video_stage_commit(mpeghip_stage *sp)
+{
+    return no_throw([&] { return mpeghip_video_stage_commit_impl(sp); });
+}
+
+static int mpeghip_video_batch_upload_replicated_impl(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
                                           const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs,
                                           size_t coef_bytes, uint32_t n_streams, mpeghip_batch **out)
 {
@@ -1683,11 +1724,25 @@ int mpeghip_video_batch_upload_replicated(mpeghip_video *v, const mpeghip_pic_de
     return MPEGHIP_OK;
 }
 
-int mpeghip_video_batch_upload(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+int mpeghip_video_batch_upload_replicated(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                                          const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs,
+                                          size_t coef_bytes, uint32_t n_streams, mpeghip_batch **out)
+{
+    return no_throw([&] { return mpeghip_video_batch_upload_replicated_impl(v, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, n_streams, out); });
+}
+
+static int mpeghip_video_batch_upload_impl(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
                                const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
                                mpeghip_batch **out)
 {
     return mpeghip_video_batch_upload_replicated(v, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, 1, out);
+}
+
+int mpeghip_video_batch_upload(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
+                               const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
+                               mpeghip_batch **out)
+{
+    return no_throw([&] { return mpeghip_video_batch_upload_impl(v, pics, n_pics, mbs, n_mbs, coefs, coef_bytes, out); });
 }
 
 int mpeghip_video_batch_run(mpeghip_video *v, const mpeghip_batch *b)
