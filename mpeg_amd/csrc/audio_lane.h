@@ -22,8 +22,10 @@
 //           sub-block through a cycle of 16.  Steps start where the position is 15 (audio_step_base0), so the position
 //           of every sub-block is a compile-time constant of its index in the step, and a wave that works through
 //           CONSECUTIVE sub-blocks keeps the 16 slots in a sliding register file with static indices: two LDS reads
-//           per sub-block (its newest slot, both halves) instead of sixteen.  The lane's 16 window coefficients (mirror's
-//           sign folded in) are re-read from LDS at the start of a run.
+//           per sub-block (its newest slot, both halves) instead of sixteen, addressed as (the run's first slot) + an
+//           immediate offset — per sub-block 32 multiplies and adds, one compare, the three instructions of the division
+//           and nothing else on the vector unit.  The lane's 16 window coefficients (mirror's sign folded in) are re-read
+//           from LDS at the start of a run.
 //   pipeline: the history ring holds 79 slots, so the DCTs of step s+1 never touch a slot the
 //           windows of step s read.  Iteration s therefore runs, between two barriers, DCT(s+1) on
 //           wave (s+1)%4 and window(s) on the other three waves (runs of 11, 11 and 10 sub-blocks, each behind a
@@ -31,7 +33,7 @@
 //           them in registers, refills the same buffer with the samples of step s+2 straight from
 //           HBM (global_load_lds: every lane overwrites exactly the 8 x 16 bytes it has just read):
 //           one barrier per step (ordering LDS only), no wave idles through the DCT or its HBM latency.
-//           30 780 bytes of LDS and 81 VGPRs: 5 workgroups stay resident per CU.
+//           30 780 bytes of LDS and 71 - 73 VGPRs: 5 workgroups stay resident per CU.
 //
 // Time slicing: a sub-block depends on the previous 15 only through the history, and
 // every history slot is a pure function of one sub-block's samples.  So the frames of one
@@ -385,59 +387,93 @@ MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg,
     store32_streaming_at(sub_block, lane_off, kFormat == MPEGHIP_AUDIO_F32N ? sv : sv * 2147483648.0f);
 }
 
-// one dword read that the compiler leaves alone (an LDS address space pointer keeps it a ds_read_b32)
-MPG_HD float lds_read_as_is(const float *p)
-{
+// An LDS location as the window's reads carry it: the 32-bit LDS byte address on the device (so that `address + constant`
+// becomes a ds_read_b32 with an immediate offset, whatever the compiler knows about the generic pointer it came from), a
+// plain pointer in the emulator.
 #if MPG_ON_DEVICE
-    typedef const volatile float __attribute__((address_space(3))) * lds_float_ptr; // (low 32 bits of an LDS address = its offset)
-    return *(lds_float_ptr)(uint32_t)(uintptr_t)p;
-#else
-    return *p;
-#endif
+typedef uint32_t lds_at_t;
+MPG_HD lds_at_t lds_at(const float *p) { return (uint32_t)(uintptr_t)p; } // (low 32 bits of an LDS address = its offset)
+MPG_HD lds_at_t lds_at_moved(lds_at_t a, int32_t floats) { return a + (uint32_t)(floats * 4); }
+template <int kFloats> MPG_HD float lds_read_at(lds_at_t a)
+{
+    typedef const volatile float __attribute__((address_space(3))) * lds_float_ptr; // (volatile: one ds_read_b32, left where it is)
+    return *(lds_float_ptr)(a + (uint32_t)(kFloats * 4));
 }
+#else
+typedef const float *lds_at_t;
+MPG_HD lds_at_t lds_at(const float *p) { return p; }
+MPG_HD lds_at_t lds_at_moved(lds_at_t a, int32_t floats) { return a + floats; }
+template <int kFloats> MPG_HD float lds_read_at(lds_at_t a) { return a[kFloats]; }
+#endif
 
 // A run of N consecutive sub-blocks P0 .. P0 + N - 1 of a step (indices in the step: positions and register indices are
 // compile-time constants, see audio_step_base0).  Lead-in: the 15 slots in front of the run, sub-block P0 - j into
 // register pair (M(P0) + j) & 15.  Then per sub-block: file its newest slot (read one sub-block ahead), synthesise.
+//
+// The run reads 15 + N CONSECUTIVE ring slots, J = 0 .. 14 + N counted from its oldest.  Their addresses are the lane's two
+// addresses of slot J = 0 (computed once per run) plus the compile-time constant J * kSlotStride — the read instruction's
+// immediate offset, no vector instruction per read — except that the ring may wrap once inside the run: `wrap_at` is the J
+// of the first slot behind the wrap (wave-uniform; >= the run's length if there is none), where both addresses step back by
+// one ring, behind a scalar branch.  (Before: a scalar multiply and two vector adds per read, 2 x (15 + N) vector
+// instructions per run of N sub-blocks on top of its 39 x N.)
 struct WinFile {
     float r0[16], r1[16];
-    float n0, n1;  // the newest slot of the sub-block about to be worked on
-    uint32_t slot; // ring slot of the next sub-block to read
+    float n0, n1;      // the newest slot of the sub-block about to be worked on
+    lds_at_t at0, at1; // the lane's d[0..31] / d[32..63] value of the run's slot J = 0
+    uint32_t wrap_at;
+    // wave-uniform, set once per run, so that a sub-block costs two scalar instructions of bookkeeping and not fifteen:
+    uint32_t rel0, len; // sub-block P of the step lies inside the slice iff (uint32_t)(rel0 + P) < len
+    uint8_t *out0;      // interleaved float formats: where the run's first sub-block goes; sub-block P0 + n: + 256 n bytes
 };
-MPG_HD void audio_window_read(const float *p0, const float *p1, WinFile &w, float &v0, float &v1)
+template <int J> MPG_HD void audio_window_read(WinFile &w, float &v0, float &v1)
 {
-    const int32_t off = (int32_t)w.slot * kSlotStride;
-    v0 = lds_read_as_is(p0 + off);
-    v1 = lds_read_as_is(p1 + off);
-    w.slot = w.slot + 1 == (uint32_t)kRing ? 0u : w.slot + 1;
+    if (__builtin_expect((uint32_t)J == w.wrap_at, 0)) { // (wave-uniform; out of line: the common path falls through)
+        w.at0 = lds_at_moved(w.at0, -kRing * kSlotStride);
+        w.at1 = lds_at_moved(w.at1, -kRing * kSlotStride);
+        sched_fence(); // keeps this a branch around two adds, not two selects on every read
+    }
+    v0 = lds_read_at<J * kSlotStride>(w.at0);
+    v1 = lds_read_at<J * kSlotStride>(w.at1);
 }
-template <int P, int kEnd, bool kFma, int kFormat> struct WinSteps {
-    static MPG_HDM void run(const AudioArgs &a, uint32_t stream, int32_t base, uint32_t tg0, uint32_t tg1, int ch, int i, const float *p0,
-                            const float *p1, const float (&dreg)[16], WinFile &w)
+template <int J, int kLast> struct WinLeadIn { // J = 0 .. 14: sub-block P0 - 15 + J, oldest first
+    template <int M0> static MPG_HDM void run(WinFile &w)
+    {
+        audio_window_read<J>(w, w.r0[(M0 + 15 - J) & 15], w.r1[(M0 + 15 - J) & 15]);
+        WinLeadIn<J + 1, kLast>::template run<M0>(w);
+    }
+};
+template <int kLast> struct WinLeadIn<kLast, kLast> {
+    template <int M0> static MPG_HDM void run(WinFile &) {}
+};
+template <int P0, int P, int kEnd, bool kFma, int kFormat> struct WinSteps {
+    static MPG_HDM void run(const AudioArgs &a, uint32_t stream, int32_t base, uint32_t tg0, uint32_t tg1, int ch, int i,
+                            const float (&dreg)[16], WinFile &w)
     {
         constexpr int M = 15 - (P & 15);
         w.r0[M] = w.n0;
         w.r1[M] = w.n1;
         if (P + 1 < kEnd)
-            audio_window_read(p0, p1, w, w.n0, w.n1); // the next sub-block's, on their way while this one is summed
-        const int32_t tg = base + P;
-        if (audio_in_slice(tg, tg0, tg1)) { // (wave-uniform)
+            audio_window_read<16 + P - P0>(w, w.n0, w.n1); // the next sub-block's, on their way while this one is summed
+        if (w.rel0 + (uint32_t)P < w.len) { // (wave-uniform) audio_in_slice(base + P, tg0, tg1)
             const float acc = window_sum<M, kFma>(w.r0, w.r1, dreg);
+            // One compare decides in the common case; sums that are exactly zero (digital silence) fail it and are let
+            // through by the second, exact test.
             float sv;
-            if (all_in_wave(scale_short_ok(acc)))
+            if (__builtin_expect(all_in_wave(!(__builtin_fabsf(acc) < 0x1p-95f)), 1) || all_in_wave(scale_short_ok(acc)))
                 sv = scale_short(acc);
             else
                 sv = acc / kScale;
-            audio_store_sample<kFormat>(a, stream, (uint32_t)tg, ch, i, sv);
+            if (kFormat == MPEGHIP_AUDIO_F32N || kFormat == MPEGHIP_AUDIO_F32) // audio.go:409-417 (both constants are 2^31 in float32)
+                store32_streaming_at_imm<(P - P0) * 256>(w.out0, (2 * (uint32_t)i + (uint32_t)ch) * 4,
+                                                         kFormat == MPEGHIP_AUDIO_F32N ? sv : sv * 2147483648.0f);
+            else
+                audio_store_sample<kFormat>(a, stream, (uint32_t)(base + P), ch, i, sv);
         }
-        WinSteps<P + 1, kEnd, kFma, kFormat>::run(a, stream, base, tg0, tg1, ch, i, p0, p1, dreg, w);
+        WinSteps<P0, P + 1, kEnd, kFma, kFormat>::run(a, stream, base, tg0, tg1, ch, i, dreg, w);
     }
 };
-template <int kEnd, bool kFma, int kFormat> struct WinSteps<kEnd, kEnd, kFma, kFormat> {
-    static MPG_HDM void run(const AudioArgs &, uint32_t, int32_t, uint32_t, uint32_t, int, int, const float *, const float *,
-                            const float (&)[16], WinFile &)
-    {
-    }
+template <int P0, int kEnd, bool kFma, int kFormat> struct WinSteps<P0, kEnd, kEnd, kFma, kFormat> {
+    static MPG_HDM void run(const AudioArgs &, uint32_t, int32_t, uint32_t, uint32_t, int, int, const float (&)[16], WinFile &) {}
 };
 template <int P0, int kEnd, bool kFma, int kFormat>
 MPG_HD void audio_window_run(const AudioArgs &a, uint32_t stream, int32_t base, uint32_t tg0, uint32_t tg1, int ch, int i,
@@ -448,13 +484,18 @@ MPG_HD void audio_window_run(const AudioArgs &a, uint32_t stream, int32_t base, 
     float dreg[16];
     audio_load_window(lds, i, dreg);
     WinFile w;
-    w.slot = (uint32_t)ring_slot(kT0 + base + P0 - 15 + kRing); // (+ kRing: the argument stays positive)
+    const uint32_t slot0 = (uint32_t)uniform(ring_slot(kT0 + base + P0 - 15 + kRing)); // (+ kRing: the argument stays positive)
+    w.at0 = lds_at(p0 + slot0 * kSlotStride);
+    w.at1 = lds_at(p1 + slot0 * kSlotStride);
+    w.wrap_at = (uint32_t)kRing - slot0; // 1 .. kRing
+    w.rel0 = (uint32_t)uniform((int32_t)((uint32_t)base - tg0));
+    w.len = (uint32_t)uniform((int32_t)(tg1 - tg0));
+    // (base + P0 may lie in front of the slice, even of the stream's output: only sub-blocks inside the slice are stored)
+    w.out0 = reinterpret_cast<uint8_t *>(a.out) + ((int64_t)((uint64_t)stream * a.n_frames * 2304) + (int64_t)(base + P0) * 64) * 4;
     constexpr int M0 = 15 - (P0 & 15);
-#pragma unroll
-    for (int j = 15; j >= 1; j--) // oldest first: consecutive ring slots
-        audio_window_read(p0, p1, w, w.r0[(M0 + j) & 15], w.r1[(M0 + j) & 15]);
-    audio_window_read(p0, p1, w, w.n0, w.n1);
-    WinSteps<P0, kEnd, kFma, kFormat>::run(a, stream, base, tg0, tg1, ch, i, p0, p1, dreg, w);
+    WinLeadIn<0, 15>::template run<M0>(w);
+    audio_window_read<15>(w, w.n0, w.n1);
+    WinSteps<P0, P0, kEnd, kFma, kFormat>::run(a, stream, base, tg0, tg1, ch, i, dreg, w);
 }
 
 // ---- windows of step si: the three waves that do not run DCT(si + 1) take sub-blocks 0..10, 11..21 and 22..31.

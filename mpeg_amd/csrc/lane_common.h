@@ -376,6 +376,17 @@ MPG_HD void store32_streaming_at(uint8_t *uniform_base, uint32_t off, float v)
 #endif
 }
 
+// the same with a compile-time byte offset (0 .. 4095) in the instruction: one scalar base serves a run of stores
+template <int kImm> MPG_HD void store32_streaming_at_imm(uint8_t *uniform_base, uint32_t off, float v)
+{
+    static_assert(kImm >= 0 && kImm < 4096, "global_store immediate offset");
+#if MPG_ON_DEVICE
+    asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(off), "v"(v), "s"(uniform_base), "n"(kImm) : "memory");
+#else
+    __builtin_memcpy(uniform_base + off + kImm, &v, 4);
+#endif
+}
+
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its
 // own L2).  Gives every XCD one contiguous range of work chunks so that
 // neighbouring macroblocks — which share 128-byte destination lines and overlapping

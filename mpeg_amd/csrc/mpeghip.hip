@@ -2054,19 +2054,25 @@ static int audio_launch(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_f
     args.format = format;
     args.fma = a->fma;
     args.active = d_active;
-    // time slices per stream: one full residency of workgroups (5 x 28 732 B of LDS fit a CU's 160 000), at least 4
-    // frames per slice
+    // Time slices per stream.  5 workgroups stay resident per CU (5 x 30 780 B of LDS fit a CU's 160 000) and all of a launch's
+    // workgroups take the same time, so the launch runs in ceil(workgroups / resident) rounds of one slice each; a slice
+    // costs its frames plus about a quarter of a frame (rebuilding 15 history slots, state, filling the pipeline).  Take
+    // the slice count that minimises rounds x that, among those that leave a slice at least 4 frames: one residency for
+    // BASELINE config 4 (256 streams -> 5 slices), 8 full rounds instead of 1.6 -> 2 for 2048 streams.
     uint32_t chunks = 1;
     {
-        const uint32_t want = ((uint32_t)a->n_cu * 5 + a->n_streams - 1) / a->n_streams;
-        chunks = want < 1 ? 1 : want;
-        if (chunks > n_frames / 4)
-            chunks = n_frames / 4;
+        const uint64_t resident = (uint64_t)(a->n_cu > 0 ? a->n_cu : 1) * 5;
+        const uint32_t most = n_frames / 4 < 32 ? n_frames / 4 : 32;
+        double best = 0;
+        for (uint32_t c = 1; c <= (most ? most : 1); c++) {
+            const uint64_t rounds = ((uint64_t)a->n_streams * c + resident - 1) / resident;
+            const double cost = (double)rounds * ((double)n_frames / c + 0.25);
+            if (c == 1 || cost < best) {
+                best = cost;
+                chunks = c;
+            }
+        }
     }
-    if (chunks < 1)
-        chunks = 1;
-    if (chunks > n_frames)
-        chunks = n_frames;
     args.n_chunks = chunks;
     const dim3 grid(a->n_streams * chunks), block(kAudioThreads);
 #define LAUNCH_AUDIO(FMT)                                                                        \
