@@ -360,31 +360,24 @@ MPG_HD float scale_short(float x)
     return __builtin_fmaf(r, kScaleInv, q);
 }
 
-// convert (audio.go:386-418) and store one sample of sub-block tg
-// The interleaved formats need no frame / sub-block split: frame f, sub-block t, sample i, channel ch sits at
-// element (f*36 + t)*64 + 2i + ch = tg*64 + (2i + ch) of the stream's output.
+// convert (audio.go:386-418) and store one sample of sub-block tg: the planar and the int16 format.  (The interleaved float
+// formats go out from WinSteps::run: frame f, sub-block t, sample i, channel ch sits at element (f*36 + t)*64 + 2i + ch =
+// tg*64 + (2i + ch) of the stream's output — no frame / sub-block split, one scalar base per run of sub-blocks.)
+// Output samples leave as non-temporal stores: nothing on the device reads them again, and kept out of L2 they leave it
+// to the sample loads and the window table (profiles/r8_ab_audio_cache_policy.txt, F32N: +6.5 %; plain stores again at
+// 2048 streams, profiles/r23: no better there, 20 % worse on config 4).
 template <int kFormat>
 MPG_HD void audio_store_sample(const AudioArgs &a, uint32_t stream, uint32_t tg, int ch, int i, float sv)
 {
-    // Output samples leave as non-temporal stores: nothing on the device reads them again, and kept out of L2 they leave it
-    // to the sample loads and the window table (profiles/r8_ab_audio_cache_policy.txt, F32N: +6.5 %; sub-band samples
-    // loaded with `nt`, the other experiment of that run, cost 40 % and is gone).
+    static_assert(kFormat == MPEGHIP_AUDIO_F32NLR || kFormat == MPEGHIP_AUDIO_S16, "the interleaved float formats are stored by the run");
     const uint64_t sb = (uint64_t)stream * a.n_frames * 2304; // the stream's first output element
     if (kFormat == MPEGHIP_AUDIO_F32NLR) {
         const uint32_t f = tg / 36, t = tg % 36;
         store_streaming(reinterpret_cast<float *>(a.out) + sb + f * 2304 + (uint32_t)ch * 1152 + t * 32 + (uint32_t)i, sv);
         return;
     }
-    const uint32_t e = tg * 64 + 2 * (uint32_t)i + (uint32_t)ch;
-    if (kFormat == MPEGHIP_AUDIO_S16) { // audio.go:400-408
-        store_streaming(reinterpret_cast<int16_t *>(a.out) + sb + e, (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f));
-        return;
-    }
-    // the float formats: (the stream's and the sub-block's part of the address: wave-uniform) + (the lane's: 2 i + ch)
-    uint8_t *sub_block = reinterpret_cast<uint8_t *>(a.out) + (sb + (uint64_t)tg * 64) * 4;
-    const uint32_t lane_off = (2 * (uint32_t)i + (uint32_t)ch) * 4;
-    // MPEGHIP_AUDIO_F32: audio.go:409-417 (both constants are 2^31 in float32)
-    store32_streaming_at(sub_block, lane_off, kFormat == MPEGHIP_AUDIO_F32N ? sv : sv * 2147483648.0f);
+    const uint32_t e = tg * 64 + 2 * (uint32_t)i + (uint32_t)ch; // audio.go:400-408
+    store_streaming(reinterpret_cast<int16_t *>(a.out) + sb + e, (int16_t)(int32_t)(sv < 0 ? sv * 32768.0f : sv * 32767.0f));
 }
 
 // An LDS location as the window's reads carry it: the 32-bit LDS byte address on the device (so that `address + constant`
@@ -467,7 +460,8 @@ template <int P0, int P, int kEnd, bool kFma, int kFormat> struct WinSteps {
                 store32_streaming_at_imm<(P - P0) * 256>(w.out0, (2 * (uint32_t)i + (uint32_t)ch) * 4,
                                                          kFormat == MPEGHIP_AUDIO_F32N ? sv : sv * 2147483648.0f);
             else
-                audio_store_sample<kFormat>(a, stream, (uint32_t)(base + P), ch, i, sv);
+                audio_store_sample<(kFormat == MPEGHIP_AUDIO_F32NLR || kFormat == MPEGHIP_AUDIO_S16) ? kFormat : MPEGHIP_AUDIO_S16>(
+                    a, stream, (uint32_t)(base + P), ch, i, sv);
         }
         WinSteps<P0, P + 1, kEnd, kFma, kFormat>::run(a, stream, base, tg0, tg1, ch, i, dreg, w);
     }

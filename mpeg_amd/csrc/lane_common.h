@@ -364,19 +364,10 @@ template <bool kStream> MPG_HD void store16_at(uint8_t *uniform_base, uint32_t o
 #endif
 }
 
-// one dword per lane to (wave-uniform base) + (32-bit lane offset), non-temporal: the scalar-base form of the store — no lane
-// builds a 64-bit address (left to itself the compiler keeps a 64-bit element index per lane: v_add, v_mov, v_lshl_add_u64
-// in front of every store of the audio kernel, 3 of ~42 vector instructions per output sample)
-MPG_HD void store32_streaming_at(uint8_t *uniform_base, uint32_t off, float v)
-{
-#if MPG_ON_DEVICE
-    asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(off), "v"(v), "s"(uniform_base) : "memory");
-#else
-    __builtin_memcpy(uniform_base + off, &v, 4);
-#endif
-}
-
-// the same with a compile-time byte offset (0 .. 4095) in the instruction: one scalar base serves a run of stores
+// one dword per lane to (wave-uniform base) + (32-bit lane offset) + (compile-time byte offset 0 .. 4095), non-temporal: the
+// scalar-base form of the store — no lane builds a 64-bit address (left to itself the compiler keeps a 64-bit element index
+// per lane: v_add, v_mov, v_lshl_add_u64 in front of every store of the audio kernel), and one scalar base serves a run of
+// stores through the instruction's immediate offset
 template <int kImm> MPG_HD void store32_streaming_at_imm(uint8_t *uniform_base, uint32_t off, float v)
 {
     static_assert(kImm >= 0 && kImm < 4096, "global_store immediate offset");
