@@ -126,6 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     MPG_STAMP(2);
 
     int32_t v[8];
+    bool table_flat = false;
     uint32_t ent_at = 0, bw_next = 0;
     i32x4_a4 dense_next = {{0, 0, 0, 0}};
     // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7; leaves lane (g, j) with row j of block g
@@ -156,9 +157,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
         auto dense_columns = [&]() {
             if (!rc_any_dense(c))
                 return;
-            if (mine && (bw & kBDense)) {
+            const bool dense_here = mine && (bw & kBDense);
+            // the default non-intra matrix and no intra unit among the pass's: the short dequantisation (wave-uniform choice).
+            // In the int32-tile instance only, the one that batches of dense units run on: typical batches have a dense
+            // unit here and there, and the int16-tile instance lost 0.5 % to carrying the second form
+            // (profiles/r25_ab_dense_default_non_intra_matrix.txt).
+            const bool flat = !kT16 && table_flat && all_in_wave(!dense_here || (int32_t)bw < 0);
+            if (dense_here) {
                 const i32x4_a4 lv = pass > 0 ? dense_next : rc_dense_read(a, c, bw, lane);
-                rc_dense_cols(lv, lds, bw, lane, v);
+                if (flat)
+                    rc_dense_cols<true>(lv, lds, bw, lane, v);
+                else
+                    rc_dense_cols<false>(lv, lds, bw, lane, v);
             }
             if ((pass + 1) * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw_next & kBDense))
                 dense_next = rc_dense_read(a, c, bw_next, lane);
@@ -226,6 +236,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
         settle(e);
         settle(bw);
         wave_lds_handoff();
+        if (!kT16 && rc_any_dense(c)) // is the stream's non-intra matrix the default one?  (lane (g, j) looks at column j)
+            table_flat = all_in_wave(rc_non_intra_column_flat(lds, lane));
         residual_pass(0);
     }
     MPG_STAMP(3);

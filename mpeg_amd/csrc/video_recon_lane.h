@@ -649,6 +649,7 @@ struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; }; // 16 byt
 // (byte kByte of `bytes`) * (half-word kHalf of `words`, sign-extended): unpacking is the multiplier's operand select
 template <int kByte, int kHalf> MPG_HD int32_t mul_u8_s16(uint32_t bytes, uint32_t words)
 {
+    static_assert((kByte & 1) == kHalf, "rows 2k, 2k+1 of a column: bytes 2k, 2k+1 and the two halves of word k");
 #if MPG_ON_DEVICE
     int32_t r;
     if (kByte == 0 && kHalf == 0)
@@ -661,8 +662,22 @@ template <int kByte, int kHalf> MPG_HD int32_t mul_u8_s16(uint32_t bytes, uint32
         asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:WORD_1" : "=v"(r) : "v"(bytes), "v"(words));
     return r;
 #else
-    static_assert((kByte & 1) == kHalf, "rows 2k, 2k+1 of a column: bytes 2k, 2k+1 and the two halves of word k");
     return (int32_t)((bytes >> (8 * kByte)) & 0xff) * (int32_t)(int16_t)(words >> (16 * kHalf));
+#endif
+}
+// x (a small non-negative dword) * half kHalf of `words` (sign-extended), one instruction
+template <int kHalf> MPG_HD int32_t mul_s16(uint32_t x, uint32_t words)
+{
+#if MPG_ON_DEVICE
+    int32_t r;
+    if (kHalf == 0)
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(x), "v"(words));
+    else
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(x), "v"(words));
+    return r;
+#else
+    MPG_CHECK(x < (1u << 23));
+    return (int32_t)x * (int32_t)(int16_t)(words >> (16 * kHalf));
 #endif
 }
 MPG_HD void rc_zero_tile16(int16_t *T, int lane)
@@ -861,9 +876,9 @@ template <int kHalf> MPG_HD int32_t or_half(int32_t x, uint32_t halves) // x | (
     return x | (int32_t)((halves >> (16 * kHalf)) & 0xffff);
 #endif
 }
-template <int R> MPG_HD int32_t rc_dense_level(const RcPair &p, int32_t qs, const uint32_t (&qm)[2], const uint32_t (&pm)[2])
+// the chain behind the product: "if even, one toward zero", `| 1`, clamp, premultiply
+template <int R> MPG_HD int32_t rc_dense_finish(int32_t l, const RcPair &p, const uint32_t (&pm)[2])
 {
-    int32_t l = mul24_as_written(mul_u8_s16<R & 3, R & 1>(qm[R >> 2], p.u), qs) >> 4; // |u * matrix byte| < 2^23
     l += (int32_t)opaque((uint32_t)(0 - l)) >> 31; // l > 0: one down — then odd, or one below an odd number.  (Three plain
                                              // half-cost instructions; the compiler's own form is a compare into a scalar
                                              // pair and a subtract-with-borrow, two full-cost ones and a hazard nop.)
@@ -871,23 +886,39 @@ template <int R> MPG_HD int32_t rc_dense_level(const RcPair &p, int32_t qs, cons
     l = clampi(l, -2048, 2047);
     return mul_u8<R & 3>(pm[R >> 2], l);
 }
+template <int R> MPG_HD int32_t rc_dense_level(const RcPair &p, int32_t qs, const uint32_t (&qm)[2], const uint32_t (&pm)[2])
+{
+    const int32_t l = mul24_as_written(mul_u8_s16<R & 3, R & 1>(qm[R >> 2], p.u), qs) >> 4; // |u * matrix byte| < 2^23
+    return rc_dense_finish<R>(l, p, pm);
+}
+// the same where the matrix entry is 16 — the default non-intra matrix (video.go:1066-1075), i.e. nearly every stream's:
+// (u * 16 * quantiser_scale) >> 4 = u * quantiser_scale exactly, one multiply in the place of two and a shift
+template <int R> MPG_HD int32_t rc_dense_level_flat(const RcPair &p, int32_t qs, const uint32_t (&pm)[2])
+{
+    return rc_dense_finish<R>(mul_s16<R & 1>((uint32_t)qs, p.u), p, pm);
+}
+// Is column j = lane & 7 of the stream's non-intra matrix all 16?  (The wave's AND over its lanes answers for the matrix.)
+MPG_HD bool rc_non_intra_column_flat(const uint8_t *lds, int lane)
+{
+    const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + kRcQtabAt + ((uint32_t)lane & 7) * 16); // bytes 2r + 1: non-intra
+    const uint32_t differs = (q.v[0] ^ 0x10001000u) | (q.v[1] ^ 0x10001000u) | (q.v[2] ^ 0x10001000u) | (q.v[3] ^ 0x10001000u);
+    return (differs & 0xff00ff00u) == 0;
+}
 // column j of a dense unit: 8 int16 levels (read apart from their use: the next pass's are fetched while this pass runs)
 MPG_HD i32x4_a4 rc_dense_read(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane)
 {
     return *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 4);
 }
+// kFlat: every dense block of the pass is non-intra and the stream's non-intra matrix is 16 everywhere (the caller's
+// wave-uniform test): no matrix bytes, no intra DC.
+template <bool kFlat = false>
 MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, int lane, int32_t (&v)[8])
 {
     const uint32_t j = (uint32_t)lane & 7;
     const int32_t qs = (int32_t)((bw >> 26) & 31);
     const bool intra = !(bw >> 31);
-    // the column's 8 matrix entries of both classes (16 bytes: position j * 8 + r -> bytes 2r, 2r + 1) and its 8
-    // premultipliers, in two LDS reads
-    const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + kRcQtabAt + j * 16);
-    const uint32_t *pmp = reinterpret_cast<const uint32_t *>(lds + kRcQtabAt + 128 + j * 8);
+    const uint32_t *pmp = reinterpret_cast<const uint32_t *>(lds + kRcQtabAt + 128 + j * 8); // the column's 8 premultipliers
     const uint32_t pm[2] = {pmp[0], pmp[1]};
-    const uint32_t qm[2] = {pick_class_bytes(q.v[0], q.v[1], !intra), pick_class_bytes(q.v[2], q.v[3], !intra)};
-    const uint32_t non_intra_mask = (uint32_t)((int32_t)bw >> 31);
 #if !MPG_ON_DEVICE
     for (int r = (intra && j == 0) ? 1 : 0; r < 8; r++) {
         const int32_t level = (int16_t)((uint32_t)lv.v[r >> 1] >> (16 * (r & 1)));
@@ -895,6 +926,24 @@ MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, i
         (void)level;
     }
 #endif
+    if (kFlat) {
+        MPG_CHECK(!intra && rc_non_intra_column_flat(lds, lane));
+        const RcPair p0 = rc_dense_pair((uint32_t)lv.v[0], ~0u), p1 = rc_dense_pair((uint32_t)lv.v[1], ~0u);
+        const RcPair p2 = rc_dense_pair((uint32_t)lv.v[2], ~0u), p3 = rc_dense_pair((uint32_t)lv.v[3], ~0u);
+        v[0] = rc_dense_level_flat<0>(p0, qs, pm);
+        v[1] = rc_dense_level_flat<1>(p0, qs, pm);
+        v[2] = rc_dense_level_flat<2>(p1, qs, pm);
+        v[3] = rc_dense_level_flat<3>(p1, qs, pm);
+        v[4] = rc_dense_level_flat<4>(p2, qs, pm);
+        v[5] = rc_dense_level_flat<5>(p2, qs, pm);
+        v[6] = rc_dense_level_flat<6>(p3, qs, pm);
+        v[7] = rc_dense_level_flat<7>(p3, qs, pm);
+        return;
+    }
+    // the column's 8 matrix entries of both classes (16 bytes: position j * 8 + r -> bytes 2r, 2r + 1)
+    const u32x4 q = *reinterpret_cast<const u32x4 *>(lds + kRcQtabAt + j * 16);
+    const uint32_t qm[2] = {pick_class_bytes(q.v[0], q.v[1], !intra), pick_class_bytes(q.v[2], q.v[3], !intra)};
+    const uint32_t non_intra_mask = (uint32_t)((int32_t)bw >> 31);
     const RcPair p0 = rc_dense_pair((uint32_t)lv.v[0], non_intra_mask), p1 = rc_dense_pair((uint32_t)lv.v[1], non_intra_mask);
     const RcPair p2 = rc_dense_pair((uint32_t)lv.v[2], non_intra_mask), p3 = rc_dense_pair((uint32_t)lv.v[3], non_intra_mask);
     v[0] = rc_dense_level<0>(p0, qs, qm, pm);

@@ -176,10 +176,24 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
             }
         int32_t v[64][8];
         uint32_t ent_at = 0;
+        bool table_flat = !t16 && rc_any_dense(c); // (as the kernel — its int32-tile instance: the wave's AND over its lanes' columns)
+        for (int lane = 0; lane < 64 && table_flat; lane++)
+            table_flat = rc_non_intra_column_flat(lds, lane);
         auto residual_pass = [&](uint32_t pass) {
             const uint32_t np = rc_pass_entries(c, pass);
             for (int lane = 0; lane < 64; lane++)
                 bw[lane] = rc_blk_src(a, c)[rc_blk_lane_offset(pass, lane) / 4];
+            bool flat = table_flat; // the short dequantisation: no intra unit among the pass's dense ones
+            for (int lane = 0; lane < 64; lane++)
+                if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw[lane] & kBDense) && !(bw[lane] >> 31))
+                    flat = false;
+            auto dense_cols = [&](int lane) {
+                const i32x4_a4 lv = rc_dense_read(a, c, bw[lane], lane);
+                if (flat)
+                    rc_dense_cols<true>(lv, lds, bw[lane], lane, v[lane]);
+                else
+                    rc_dense_cols<false>(lv, lds, bw[lane], lane, v[lane]);
+            };
             if (t16) {
                 if (np) {
                     for (int lane = 0; lane < 64; lane++)
@@ -205,7 +219,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                     if (rc_any_raw(c) && mine && (bw[lane] & kBRaw))
                         rc_raw_cols(a, c, bw[lane], lane, v[lane]);
                     if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
-                        rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
+                        dense_cols(lane);
                     idct8<false>(v[lane]);
                 }
                 for (int g = 0; g < 8; g++) { // the kernel's transposition across the block's 8 lanes: lane j leaves with row j
@@ -257,7 +271,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                 if (rc_any_dcword(c) && mine)
                     rc_dc_from_word(bw[lane], lane, v[lane]);
                 if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
-                    rc_dense_cols(rc_dense_read(a, c, bw[lane], lane), lds, bw[lane], lane, v[lane]);
+                    dense_cols(lane);
                 idct8<false>(v[lane]);
             }
             for (int lane = 0; lane < 64; lane++) // (in place: only after every lane has read its column)

@@ -40,6 +40,30 @@ def test_custom_quant_matrices(oracle, hip_ctx):
     dut.close()
 
 
+@pytest.mark.parametrize("case", ["default", "custom_intra_default_non_intra", "first_entry_off", "last_entry_off"])
+def test_dense_units_under_the_default_and_nearly_default_non_intra_matrix(oracle, hip_ctx, case):
+    """the short dequantisation of dense non-intra units (rc_dense_cols<true>) runs only when every entry of the stream's
+    non-intra matrix is 16; both kernel instances"""
+    rng = np.random.default_rng(21)
+    w, h = 96, 64
+    seq = synth.generate_sequence(w, h, 4, seed=77, profile="dense")
+    for sub in seq:
+        sub.mbs["qscale"] = rng.integers(1, 32, size=len(sub.mbs))
+    iq, nq = rng.integers(1, 256, 64), np.full(64, 16)
+    if case == "first_entry_off":
+        nq[0] = 17
+    elif case == "last_entry_off":
+        nq[63] = 15
+    for policy in (1, 2):
+        ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h)
+        dut.set_tile_policy(policy)
+        if case != "default":
+            ref.set_quant(0, iq, nq)
+            dut.set_quant(0, iq, nq)
+        run_and_compare(ref, dut, seq)
+        dut.close()
+
+
 @pytest.mark.parametrize("w,h", [(100, 60), (37, 23), (16, 1), (3, 16)])  # odd sizes: partial quads, a last row without a partner
 def test_standalone_rgba(oracle, hip_ctx, w, h):
     ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h, 2)

@@ -128,3 +128,27 @@ def test_dense_units_with_zeros_large_levels_and_extreme_matrices(oracle, emu_la
             o.set_quant(0, iq, nq)
             e.set_quant(0, iq, nq)
         run_and_compare(o, e, seq)
+
+
+@pytest.mark.parametrize("case", ["default", "custom_intra_default_non_intra", "first_entry_off", "last_entry_off", "all_17"])
+def test_dense_units_take_the_short_dequantisation_only_under_the_default_non_intra_matrix(oracle, emu_layout, case):
+    """rc_dense_cols<true>: with the non-intra matrix 16 everywhere (video.go:1066-1075) a pass whose dense units are all
+    non-intra dequantises as u * quantiser_scale.  One entry off, anywhere, and the general path must run; intra units
+    (the I picture) always take it."""
+    rng = np.random.default_rng(21)
+    w, h = 96, 64
+    seq = synth.generate_sequence(w, h, 4, seed=77, profile="dense")
+    for sub in seq:
+        sub.mbs["qscale"] = rng.integers(1, 32, size=len(sub.mbs))
+    o, e = oracle.OracleStore(w, h), emu_layout.EmuStore(w, h)
+    iq, nq = rng.integers(1, 256, 64), np.full(64, 16)
+    if case == "first_entry_off":
+        nq[0] = 17
+    elif case == "last_entry_off":
+        nq[63] = 15
+    elif case == "all_17":
+        nq[:] = 17
+    if case != "default":
+        o.set_quant(0, iq, nq)
+        e.set_quant(0, iq, nq)
+    run_and_compare(o, e, seq)
