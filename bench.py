@@ -36,9 +36,10 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MB_PER_1080P30_STREAM = 8160 * 30
-KERNEL = {False: "recon_kernel<1, false, T> (a wave reconstructs two chunks of 4 macroblocks; sparse coefficient entries, prediction windows by "
-                 "direct-to-LDS loads; T: int16 tile / 8 waves per SIMD for typical batches, int32 tile / 7 for batches of dense units)",
-          True: "recon_kernel<1, true, false> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
+KERNEL = {False: "recon_kernel<1, false, T, N> (a wave reconstructs N = 2 chunks of 4 macroblocks, N = 1 where a launch fits the device's wave "
+                 "slots: one picture; sparse coefficient entries, prediction windows by direct-to-LDS loads; T: int16 tile / 8 waves per SIMD "
+                 "for typical batches, int32 tile / 7 for batches of dense units)",
+          True: "recon_kernel<1, true, false, N> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
 def parse_args():

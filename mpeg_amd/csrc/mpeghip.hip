@@ -53,14 +53,15 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k)
 #endif
 
-#ifndef MPG_CHUNKS_PER_WAVE
-#define MPG_CHUNKS_PER_WAVE 2 // profiles/r4k_ab_two_chunks_per_wave.txt
-#endif
-constexpr int kRcChunksPerWave = MPG_CHUNKS_PER_WAVE;
+// A wave takes TWO consecutive chunks where the launch has more waves than the device has slots for (the second header
+// arrives with the first, and the ~1 800 clocks a slot stays empty between two waves are paid half as often:
+// profiles/r4k_ab_two_chunks_per_wave.txt), and ONE where every wave is resident from the start — a single picture:
+// the launch then lasts one chunk's latency, not two (kPerWave; launch_batch picks the instance.  As a launch argument the
+// choice cost the 1024-stream legs 0.3 % in three rounds: profiles/r27_ab_one_chunk_per_wave_for_single_pictures.txt).
 #ifndef MPG_CHUNK_AHEAD
 #define MPG_CHUNK_AHEAD 256 // chunks; 0 = off (profiles/r3f_ab_chunk_pull_ahead.txt: 64 / 256 / 1024)
 #endif
-template <int WAVES, bool kRgba, bool kT16>
+template <int WAVES, bool kRgba, bool kT16, int kPerWave>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(const VideoArgs a)
 {
 #ifdef MPG_PHASE_TIMING
@@ -73,9 +74,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     // immediate, with no per-wave base to add)
     const uint32_t w = WAVES == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane_all = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    // a wave takes kRcChunksPerWave consecutive chunks, one after the other: the later ones' headers are loaded with the
+    // a wave takes `per_wave` consecutive chunks, one after the other: the second one's header is loaded with the
     // first one's, and the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once
-    const uint32_t first = __builtin_amdgcn_readfirstlane((xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w) * kRcChunksPerWave);
+    constexpr uint32_t per_wave = kPerWave;
+    static_assert(kPerWave == 1 || kPerWave == 2, "written out for one or two");
+    const uint32_t first = __builtin_amdgcn_readfirstlane((xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w) * per_wave);
     if (first >= a.n_chunks)
         return;
     uint8_t *lds = lds_all + w * kLdsBytes;
@@ -88,15 +91,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     // first words, by a dependent load once the header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
     uint32_t ahead;
     {
-        const uint32_t later = first + MPG_CHUNK_AHEAD * kRcChunksPerWave + kRcChunksPerWave <= a.n_chunks ? first + MPG_CHUNK_AHEAD * kRcChunksPerWave : first;
-        const uint32_t line = (uint32_t)lane_all < (kRcChunksPerWave * kRcChunkDwords * 4 + 63) / 64 ? (uint32_t)lane_all : 0u;
+        const uint32_t later = first + MPG_CHUNK_AHEAD * per_wave + per_wave <= a.n_chunks ? first + MPG_CHUNK_AHEAD * per_wave : first;
+        const uint32_t line = (uint32_t)lane_all < (per_wave * kRcChunkDwords * 4 + 63) / 64 ? (uint32_t)lane_all : 0u;
         ahead = load32_uncounted(a.chunks + (uint64_t)later * kRcChunkDwords, line * 64);
     }
 #endif
     // step 1: one round of scalar loads (all of the wave's chunks), then per chunk its vector loads
-    static_assert(kRcChunksPerWave == 1 || kRcChunksPerWave == 2, "written out for one or two");
+    const bool second = per_wave == 2 && first + 1 < a.n_chunks; // (written out for one or two)
     const RcChunk c0 = rc_load_chunk(a, first);
-    const RcChunk c1 = rc_load_chunk(a, kRcChunksPerWave == 2 && first + 1 < a.n_chunks ? first + 1 : first);
+    const RcChunk c1 = rc_load_chunk(a, second ? first + 1 : first);
     // what depends on the lane only.  The int16-tile instance works it out again per chunk: kept across the other chunk the
     // 15 values cost three spills at the 64 registers that 8 waves per SIMD allow.
     const RcLane k_once = rc_lane(a, kT16 ? 0 : lane_all);
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
 #endif
     };
     one_chunk(c0, first);
-    if (kRcChunksPerWave == 2 && first + 1 < a.n_chunks) {
+    if (second) {
         wave_lds_handoff(); // (the previous chunk's stores have read its output bytes)
         one_chunk(c1, first + 1);
     }
@@ -582,6 +585,7 @@ struct mpeghip_video {
     size_t bounce_cap = 0;
     uint8_t *d_linear = nullptr;           // one slot's planes in the reference's linear layout (read / write_planes)
     int tile_policy = MPEGHIP_TILE_AUTO;   // mpeghip_video_set_tile_policy
+    int n_cu = 256;                        // compute units of the device (asked once, at open)
 };
 
 // what validation learns about a picture (the dependency check across pictures needs it)
@@ -796,6 +800,7 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
     if (!v)
         return fail(MPEGHIP_ERR_OOM, "host allocation failed");
     v->ctx = c;
+    (void)hipDeviceGetAttribute(&v->n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     mpeghip_video_info &in = v->info;
     in.width = width;
     in.height = height;
@@ -1237,7 +1242,10 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
     hipStream_t st = v->ctx->stream;
-    const uint32_t grid = (a.n_chunks + kReconWaves * kRcChunksPerWave - 1) / (kReconWaves * kRcChunksPerWave);
+    // one chunk per wave where all of the launch's waves are resident at once (7 waves per SIMD: either instance), else two
+    const uint64_t wave_slots = (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 7;
+    const uint32_t per_wave = a.n_chunks <= wave_slots ? 1 : 2;
+    const uint32_t grid = (a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave);
     // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches of dense units are bound by vector-ALU
     // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); so does the fused-RGBA instance, which is
     // bound by its stores; everything else is bound by per-wave latency and wants the eighth wave (int16 tile).  Measured at
@@ -1245,14 +1253,22 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     bool t16 = !b->any_rgba && b->dense_blocks * kDenseBatchShare <= b->coded_blocks;
     if (v->tile_policy != MPEGHIP_TILE_AUTO)
         t16 = v->tile_policy == MPEGHIP_TILE_INT16;
+#define LAUNCH_RECON(RGBA, T16)                                                                                                       \
+    do {                                                                                                                              \
+        if (per_wave == 1)                                                                                                            \
+            hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, 1>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);               \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, 2>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);               \
+    } while (0)
     if (b->any_rgba && t16)
-        hipLaunchKernelGGL((recon_kernel<kReconWaves, true, true>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+        LAUNCH_RECON(true, true);
     else if (b->any_rgba)
-        hipLaunchKernelGGL((recon_kernel<kReconWaves, true, false>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+        LAUNCH_RECON(true, false);
     else if (t16)
-        hipLaunchKernelGGL((recon_kernel<kReconWaves, false, true>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+        LAUNCH_RECON(false, true);
     else
-        hipLaunchKernelGGL((recon_kernel<kReconWaves, false, false>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);
+        LAUNCH_RECON(false, false);
+#undef LAUNCH_RECON
     HIP_TRY(hipGetLastError());
     // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
     // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
