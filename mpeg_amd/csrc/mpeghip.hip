@@ -53,11 +53,13 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k)
 #endif
 
-// A wave takes TWO consecutive chunks where the launch has more waves than the device has slots for (the second header
-// arrives with the first, and the ~1 800 clocks a slot stays empty between two waves are paid half as often:
-// profiles/r4k_ab_two_chunks_per_wave.txt), and ONE where every wave is resident from the start — a single picture:
-// the launch then lasts one chunk's latency, not two (kPerWave; launch_batch picks the instance.  As a launch argument the
-// choice cost the 1024-stream legs 0.3 % in three rounds: profiles/r27_ab_one_chunk_per_wave_for_single_pictures.txt).
+// Chunks per wave (kPerWave; launch_batch picks the instance).  TWO consecutive chunks in the int32-tile instance where the
+// launch has more waves than the device has slots for: the second header arrives with the first, and the ~1 800 clocks a
+// slot stays empty between two waves are paid half as often (profiles/r4k_ab_two_chunks_per_wave.txt; dense +1.4 %,
+// r31).  ONE where every wave is resident from the start — a single picture: the launch then lasts one chunk's latency,
+// not two (profiles/r27_ab_one_chunk_per_wave_for_single_pictures.txt) — and in the int16-tile instance at any size: its
+// eighth wave per SIMD covers the hand-over, and with one header it keeps every scalar in a register (r31: +1.0 %).
+// (As a launch argument instead of a template parameter the choice cost the 1024-stream legs 0.3 %: r27.)
 #ifndef MPG_CHUNK_AHEAD
 #define MPG_CHUNK_AHEAD 256 // chunks; 0 = off (profiles/r3f_ab_chunk_pull_ahead.txt: 64 / 256 / 1024)
 #endif
@@ -1242,10 +1244,6 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
     hipStream_t st = v->ctx->stream;
-    // one chunk per wave where all of the launch's waves are resident at once (7 waves per SIMD: either instance), else two
-    const uint64_t wave_slots = (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 7;
-    const uint32_t per_wave = a.n_chunks <= wave_slots ? 1 : 2;
-    const uint32_t grid = (a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave);
     // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches of dense units are bound by vector-ALU
     // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); so does the fused-RGBA instance, which is
     // bound by its stores; everything else is bound by per-wave latency and wants the eighth wave (int16 tile).  Measured at
@@ -1253,21 +1251,31 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     bool t16 = !b->any_rgba && b->dense_blocks * kDenseBatchShare <= b->coded_blocks;
     if (v->tile_policy != MPEGHIP_TILE_AUTO)
         t16 = v->tile_policy == MPEGHIP_TILE_INT16;
-#define LAUNCH_RECON(RGBA, T16)                                                                                                       \
-    do {                                                                                                                              \
-        if (per_wave == 1)                                                                                                            \
-            hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, 1>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);               \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, 2>), dim3(grid), dim3(kReconWaves * 64), 0, st, a);               \
-    } while (0)
-    if (b->any_rgba && t16)
-        LAUNCH_RECON(true, true);
-    else if (b->any_rgba)
-        LAUNCH_RECON(true, false);
-    else if (t16)
-        LAUNCH_RECON(false, true);
-    else
-        LAUNCH_RECON(false, false);
+    // Chunks per wave: one where all of the launch's waves are resident at once (7 waves per SIMD: either instance), and one
+    // for the int16-tile instance at any size — at 8 waves per SIMD the hand-over between waves is covered, and the one-chunk
+    // form needs 49 vector and 60 scalar registers where two chunks spill scalars to lanes (+1.0 % in eight of eight rounds,
+    // profiles/r31_ab_chunks_per_wave_by_instance.txt); two for the int32-tile instance (dense +1.4 % with two).
+    const uint64_t wave_slots = (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 7;
+    const uint32_t per_wave = (t16 || a.n_chunks <= wave_slots) ? 1 : 2;
+    const uint32_t grid = (a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave);
+#define LAUNCH_RECON(RGBA, T16, PER_WAVE) \
+    hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, PER_WAVE>), dim3(grid), dim3(kReconWaves * 64), 0, st, a)
+    if (t16) {
+        if (b->any_rgba)
+            LAUNCH_RECON(true, true, 1);
+        else
+            LAUNCH_RECON(false, true, 1);
+    } else if (per_wave == 1) {
+        if (b->any_rgba)
+            LAUNCH_RECON(true, false, 1);
+        else
+            LAUNCH_RECON(false, false, 1);
+    } else {
+        if (b->any_rgba)
+            LAUNCH_RECON(true, false, 2);
+        else
+            LAUNCH_RECON(false, false, 2);
+    }
 #undef LAUNCH_RECON
     HIP_TRY(hipGetLastError());
     // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
