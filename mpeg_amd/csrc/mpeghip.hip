@@ -132,19 +132,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
 
     int32_t v[8];
     bool table_flat = false;
-    uint32_t ent_at = 0, bw_next = 0;
+    uint32_t ent_at = 0, bw_next = 0, e_next = 0;
     i32x4_a4 dense_next = {{0, 0, 0, 0}};
     // step 2: residual pass over coded blocks 8 * pass .. 8 * pass + 7; leaves lane (g, j) with row j of block g
     auto residual_pass = [&](uint32_t pass) {
         const uint32_t np = rc_pass_entries(c, pass);
         if (pass > 0)
             bw = bw_next;
-        if ((pass + 1) * 8 < n_blocks) // the next pass's block words: on their way while this pass runs
+        if (pass > 0)
+            e = e_next;
+        if ((pass + 1) * 8 < n_blocks) { // the next pass's block words and first 64 entries: on their way while this pass runs
             bw_next = rc_blk_src(a, c)[rc_blk_lane_offset(pass + 1, lane) / 4];
+            if (rc_pass_entries(c, pass + 1)) // (a pass of dense units has none)
+                e_next = *rc_ent_src(a, c, ent_at + np, lane); // (beyond that pass's entries: ignored; the array is padded)
+        }
         const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
         auto scatter_entries = [&](auto &&scatter_one) {
             for (uint32_t r = 0; r < np; r += 64) {
-                if (pass > 0 || r > 0)
+                if (r > 0)
                     e = *rc_ent_src(a, c, ent_at + r, lane);
                 if (r + (uint32_t)lane < np)
                     scatter_one(e);
