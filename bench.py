@@ -132,13 +132,16 @@ def build_sequence(args, profile, rgba):
 
 
 def sources_sha256():
-    """sha256 over the kernel sources the loaded libmpeghip.so was built from (mpeg_amd/csrc/*, sorted by name): the PMC
-    traffic figures under profiles/ carry the same hash of the build they were measured on."""
+    """sha256 over the kernel sources the loaded libmpeghip.so was built from (mpeg_amd/csrc/*, sorted by name) and the
+    compiler flags it was built with (mpeg_amd/_build.py): the PMC traffic figures under profiles/ carry the same hash of
+    the build they were measured on."""
     import hashlib
+    from mpeg_amd import _build
     h = hashlib.sha256()
     for f in sorted((ROOT / "mpeg_amd" / "csrc").iterdir()):
         if f.suffix in (".h", ".hip"):
             h.update(f.name.encode() + b"\0" + f.read_bytes())
+    h.update(" ".join(_build.HIPCC_FLAGS).encode())
     return h.hexdigest()
 
 

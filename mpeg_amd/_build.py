@@ -18,7 +18,11 @@ LIBMPEGHOST = ROOT / "mpeg_amd" / "libmpeghost.so"
 
 # -fno-slp-vectorize: packed f32 math (v_pk_mul/add_f32) issues at half rate on gfx950, so pairing two scalar
 # operations gains nothing and costs the register shuffles (audio kernel: 124 -> 97 VGPRs, +4 %)
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
+# -amdgpu-kernarg-preload-count=14: the leading scalar kernel arguments arrive in SGPRs with the wave (gfx940+; the compiler keeps
+# a load-them-yourself entry for firmware without the feature) — recon_kernel's first 14 dwords are what a wave needs before
+# its chunk header is back (mpeghip.hip)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm",
+               "-amdgpu-kernarg-preload-count=14", "-fPIC", "-shared"]
 
 
 def _newer(target: Path, sources) -> bool:

@@ -63,9 +63,25 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 #ifndef MPG_CHUNK_AHEAD
 #define MPG_CHUNK_AHEAD 256 // chunks; 0 = off (profiles/r3f_ab_chunk_pull_ahead.txt: 64 / 256 / 1024)
 #endif
+// The arguments a wave needs before its chunk header is back come as scalars in front of the struct: built with
+// -mllvm -amdgpu-kernarg-preload-count=14 (mpeg_amd/_build.py) they arrive in SGPRs with the wave instead of through three
+// dependent rounds of scalar loads (grid size -> chunk count -> chunk pointer), and the grid size is an argument because the
+// hidden one cannot be preloaded.  profiles/r34_ab_kernarg_preload.txt: typical +0.75 %, one picture 10.15 -> 9.86 us.
 template <int WAVES, bool kRgba, bool kT16, int kPerWave>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(const VideoArgs a)
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(
+    const uint32_t grid_blocks, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
+    uint8_t *const frames, const uint32_t mb_w, const uint32_t luma_bytes, const uint32_t luma_w, const uint32_t chroma_w, const VideoArgs rest)
 {
+    VideoArgs a = rest;
+    a.n_chunks = n_chunks;
+    a.chunks = chunks;
+    a.words = words;
+    a.qmat = qmat;
+    a.frames = frames;
+    a.mb_w = mb_w;
+    a.luma_bytes = luma_bytes;
+    a.luma_w = luma_w;
+    a.chroma_w = chroma_w;
 #ifdef MPG_PHASE_TIMING
     uint64_t ts[8];
 #endif
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     // first one's, and the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once
     constexpr uint32_t per_wave = kPerWave;
     static_assert(kPerWave == 1 || kPerWave == 2, "written out for one or two");
-    const uint32_t first = __builtin_amdgcn_readfirstlane((xcd_chunk(blockIdx.x, gridDim.x) * WAVES + w) * per_wave);
+    const uint32_t first = __builtin_amdgcn_readfirstlane((xcd_chunk(blockIdx.x, grid_blocks) * WAVES + w) * per_wave);
     if (first >= a.n_chunks)
         return;
     uint8_t *lds = lds_all + w * kLdsBytes;
@@ -1264,7 +1280,8 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     const uint32_t per_wave = (t16 || a.n_chunks <= wave_slots) ? 1 : 2;
     const uint32_t grid = (a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave);
 #define LAUNCH_RECON(RGBA, T16, PER_WAVE) \
-    hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, PER_WAVE>), dim3(grid), dim3(kReconWaves * 64), 0, st, a)
+    hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, PER_WAVE>), dim3(grid), dim3(kReconWaves * 64), 0, st, grid, a.n_chunks, a.chunks, \
+                       a.words, a.qmat, a.frames, a.mb_w, a.luma_bytes, a.luma_w, a.chroma_w, a)
     if (t16) {
         if (b->any_rgba)
             LAUNCH_RECON(true, true, 1);

@@ -10,7 +10,7 @@ if [ "${1:-}" = build ]; then
   mkdir -p tools/ab/broken /tmp/broken
   sed 's/r.v\[1\] += s \* k.frames256;/r.v[1] += (s == 517 ? 516u : s) * k.frames256;/' mpeg_amd/csrc/mpeghip.hip > /tmp/broken/mpeghip.hip
   cmp -s mpeg_amd/csrc/mpeghip.hip /tmp/broken/mpeghip.hip && { echo "the line to break was not found"; exit 1; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -I include -I mpeg_amd/csrc \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=14 -fPIC -shared -I include -I mpeg_amd/csrc \
       /tmp/broken/mpeghip.hip -o tools/ab/broken/libmpeghip_shifted_reference_base.so && echo built
 else
   OUT=gpurun_out/cross_stream_check_on_a_shifted_base.txt; mkdir -p gpurun_out

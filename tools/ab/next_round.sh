@@ -11,5 +11,5 @@
 set -eu
 cd "$(dirname "$0")/../.."
 name=$1; shift
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -I include -I mpeg_amd/csrc"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=14 -fPIC -shared -I include -I mpeg_amd/csrc"
 /opt/rocm/bin/hipcc $FLAGS "$@" mpeg_amd/csrc/mpeghip.hip -o tools/ab/libmpeghip_$name.so && echo built $name

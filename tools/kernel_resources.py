@@ -11,7 +11,7 @@ import bench  # noqa: E402
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         asm = Path(tmp) / "mpeghip.s"
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=14",
                         "-fPIC", "-I", str(ROOT / "include"), "-I", str(ROOT / "mpeg_amd/csrc"), "--cuda-device-only", "-S",
                         str(ROOT / "mpeg_amd/csrc/mpeghip.hip"), "-o", str(asm)], check=True, stderr=subprocess.DEVNULL)
         text = asm.read_text()
