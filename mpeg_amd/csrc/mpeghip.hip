@@ -118,14 +118,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     const bool second = per_wave == 2 && first + 1 < a.n_chunks; // (written out for one or two)
     const RcChunk c0 = rc_load_chunk(a, first);
     const RcChunk c1 = rc_load_chunk(a, second ? first + 1 : first);
-    // what depends on the lane only.  The int16-tile instance works it out again per chunk: kept across the other chunk the
-    // 15 values cost three spills at the 64 registers that 8 waves per SIMD allow.
-    const RcLane k_once = rc_lane(a, kT16 ? 0 : lane_all);
+    // what depends on the lane only: worked out once per wave, while the header is on its way
+    const int lane = lane_all;
+    const RcLane k = rc_lane(a, lane);
     bool ahead_pending = MPG_CHUNK_AHEAD != 0;
     auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
     (void)chunk; // (the instrumented build's stamps)
-    const int lane = kT16 ? (int)opaque((uint32_t)lane_all) : lane_all;
-    const RcLane k = kT16 ? rc_lane(a, lane) : k_once;
     const uint32_t n_blocks = rc_n_blocks(c);
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)
