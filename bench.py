@@ -39,7 +39,7 @@ MB_PER_1080P30_STREAM = 8160 * 30
 KERNEL = {False: "recon_kernel<1, false, T, N> (a wave reconstructs N = 2 chunks of 4 macroblocks, N = 1 where a launch fits the device's wave "
                  "slots: one picture; sparse coefficient entries, prediction windows by direct-to-LDS loads; T: int16 tile / 8 waves per SIMD "
                  "for typical batches, int32 tile / 7 for batches of dense units)",
-          True: "recon_kernel<1, true, false, N> (the instance with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
+          True: "recon_kernel<1, true, T, N> (the instances with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
 def parse_args():

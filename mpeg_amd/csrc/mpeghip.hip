@@ -45,7 +45,7 @@ static __device__ __forceinline__ void wave_lds_handoff()
 // (Frame.RGBA() fused); the other one carries none of that code.  kT16: the form of the wave's coefficient tile
 // (video_recon_lane.h): int16 levels + transposition across lanes, 8 waves per SIMD — the instance for typical,
 // latency-bound batches; or int32 values + transposition through the tile, 7 waves per SIMD — the instance for batches
-// of dense units, which are bound by vector-ALU issue, and for fused RGBA (launch_batch picks).
+// of dense units, which are bound by vector-ALU issue (launch_batch picks).
 #ifdef MPG_PHASE_TIMING // instrumented build for tools/phase_timing.py only: s_memtime at the phase boundaries
 __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k) ts[k] = __builtin_readcyclecounter()
@@ -1264,10 +1264,11 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba_stride = rgba_stride_of(v);
     hipStream_t st = v->ctx->stream;
     // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches of dense units are bound by vector-ALU
-    // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); so does the fused-RGBA instance, which is
-    // bound by its stores; everything else is bound by per-wave latency and wants the eighth wave (int16 tile).  Measured at
-    // the two ends (typical: 0 % dense units, worst case: 100 %; profiles/r6_ab_*); the switch-over in between is a guess.
-    bool t16 = !b->any_rgba && b->dense_blocks * kDenseBatchShare <= b->coded_blocks;
+    // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); everything else is bound by per-wave
+    // latency and wants the eighth wave (int16 tile) — with Frame.RGBA fused as well, since that instance runs one chunk
+    // per wave (r42: fused typical +1.2 %).  Measured at the two ends (typical: 0 % dense units, worst case: 100 %;
+    // profiles/r6_ab_*, r7); the switch-over in between is a guess.
+    bool t16 = b->dense_blocks * kDenseBatchShare <= b->coded_blocks;
     if (v->tile_policy != MPEGHIP_TILE_AUTO)
         t16 = v->tile_policy == MPEGHIP_TILE_INT16;
     // Chunks per wave: one where all of the launch's waves are resident at once (7 waves per SIMD: either instance), and one

@@ -102,11 +102,12 @@ constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3648
 // The wave's coefficient tile T, two forms = two instances of the kernel (mpeghip.hip picks one per batch):
 //   int32 [8 blocks][64], 2 048 bytes: dequantised AND premultiplied values; the 8x8 transposition between the two IDCT
 //          passes goes through it (8 writes, 2 reads, one round trip, no vector-ALU work).  5 696 bytes of LDS per wave = 7
-//          waves per SIMD.  The instance for batches with many dense units (bound by vector-ALU issue) and for fused RGBA.
+//          waves per SIMD.  The instance for batches with many dense units (bound by vector-ALU issue), fused RGBA or not.
 //   int16 [8 blocks][64], 1 024 bytes: dequantised levels (|.| <= 2048), premultiplied when a column is read (byte x
 //          half-word multiplies); the transposition goes across the block's 8 lanes by DPP (28 instructions), snapshot
 //          blocks are read straight from HBM.  4 672 bytes = 8 waves per SIMD: the instance for the typical, latency-bound
-//          batches (profiles/r5_ab_*, r6_ab_*: typical +3 .. 4 %, dense -4 .. -6 %, fused RGBA -1 .. -6 %).
+//          batches (profiles/r5_ab_*, r6_ab_*: typical +3 .. 4 %, dense -4 .. -6 %; with fused RGBA it lost 1 .. 6 % as long
+//          as it ran two chunks per wave and wins 1.2 % with one: profiles/r42_ab_fused_typical_by_tile_instance.txt).
 constexpr int kRcTileBytes32 = 8 * 64 * 4, kRcTileBytes16 = 8 * 64 * 2;
 // 28 / 32 one-wave workgroups per CU (160 000 usable bytes, tools/microbench/lds_residency.hip)
 template <bool kT16> constexpr int rc_lds_bytes() { return kRcTileAt + (kT16 ? kRcTileBytes16 : kRcTileBytes32); }

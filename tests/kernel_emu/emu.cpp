@@ -139,7 +139,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         dense += got.dense_blocks;
     }
     // which kernel instance: the product's rule (mpeghip.hip: launch_batch), unless a test pins one
-    bool t16 = !any_rgba && dense * 4 <= coded;
+    bool t16 = dense * 4 <= coded;
     if (g_tile_policy)
         t16 = g_tile_policy == 1;
     a.pics = pics;
