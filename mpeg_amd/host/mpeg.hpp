@@ -333,7 +333,8 @@ private:
     std::vector<uint8_t> coefs_;
     std::vector<uint8_t> written_;      // macroblock address already emitted in this submit
     struct BlockRec { bool valid; bool needs_raw; int16_t q[64]; int32_t raw[64];
-                      uint8_t touched[64]; int n_touched; }; // natural indices this block's levels went to, in scan order
+                      uint8_t touched[64]; int n_touched; // natural indices this block's levels went to, in scan order
+                      uint32_t pairs[64]; };              // the same levels as MPEGHIP_PAIR words (the sparse hand-over), scan order
     struct MbRec { bool active = false, intra = false; int mb_x = 0, mb_y = 0; bool has_pred = false, backward = false;
                    int mv_x = 0, mv_y = 0; int qscale = 0; int cbp = 0; BlockRec blocks[6]; bool any_raw = false;
                    bool out_of_range = false; /* a copyMacroblock call of this macroblock would panic in the reference */ } rec_;

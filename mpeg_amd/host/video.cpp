@@ -469,10 +469,7 @@ void Video::endMacroblockRecord()
             *dst++ = n;
             if (rec_.intra)
                 *dst++ = MPEGHIP_PAIR(br.q[0], 0);
-            for (int k = 0; k < br.n_touched; k++) {
-                const int i = br.touched[k]; // natural index row * 8 + column -> position column * 8 + row
-                *dst++ = MPEGHIP_PAIR(br.q[i], (i & 7) * 8 + (i >> 3));
-            }
+            memcpy(dst, br.pairs, 4 * (size_t)br.n_touched); // (written by decodeBlock, level by level)
         } else {
             const size_t at = coefs_.size();
             coefs_.resize(at + MPEGHIP_COEF_UNIT);
@@ -747,6 +744,7 @@ void Video::decodeBlock(int block)
         if (level == 0)
             explicit_zero = true; // dequantises to +-1, which "0 = absent" cannot express
         br.q[dz] = (int16_t)level;
+        br.pairs[n_touched] = MPEGHIP_PAIR(level, (dz & 7) * 8 + (dz >> 3)); // natural index row * 8 + column -> position column * 8 + row
         touched[n_touched++] = (uint8_t)dz;
         if (dirty_at_start)
             block_data_[dz] = dequantPremult(level, macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
