@@ -50,6 +50,9 @@ void mpeghost_video_set_no_delay(void *video, int no_delay);        /* video.go:
  * counterpart: results are identical. */
 void mpeghost_video_set_sparse(void *video, int sparse);
 void mpeghost_set_default_sparse(int sparse);
+/* Test hook: every VLC table of the parser (two-level lookups, mpeg_amd/host/vlc.hpp) against a walk over its ISO 11172-2
+ * code list, for all 2^L looks at the stream; returns the number that decode differently (0). */
+uint64_t mpeghost_debug_vlc_self_check(void);
 int mpeghost_video_decode(void *video, mpeghost_frame *out);         /* 1 frame, 0 none / end, -1 error */
 const uint8_t *mpeghost_video_rgba(void *video);                     /* Frame.RGBA() of the last decoded frame */
 void mpeghost_video_stats(void *video, uint64_t out[8]);

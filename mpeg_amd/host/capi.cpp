@@ -110,6 +110,7 @@ double mpeghost_video_framerate(void *h) { return static_cast<VideoHandle *>(h)-
 void mpeghost_video_set_no_delay(void *h, int v) { static_cast<VideoHandle *>(h)->video->SetNoDelay(v != 0); }
 void mpeghost_video_set_sparse(void *h, int v) { static_cast<VideoHandle *>(h)->video->SetSparse(v != 0); }
 void mpeghost_set_default_sparse(int v) { Video::SetDefaultSparse(v != 0); }
+uint64_t mpeghost_debug_vlc_self_check(void) { return Video::VlcSelfCheck(); }
 int mpeghost_video_decode(void *hv, mpeghost_frame *out)
 {
     return guard([&]() -> int {

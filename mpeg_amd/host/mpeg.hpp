@@ -266,6 +266,9 @@ public:
     void SetSparse(bool v) { sparse_ = v; }
     bool Sparse() const { return sparse_; }
     static void SetDefaultSparse(bool v); // the form of decoders created from now on (process-wide; sparse unless told otherwise)
+    // test hook: every VLC table of the parser against a walk over its code list, for every possible look at the stream
+    // (all 2^L prefixes of the table's longest code).  Returns the number of prefixes that decode differently (0).
+    static uint64_t VlcSelfCheck();
     double Time() const { return time_; }
     void SetTime(double t);
     void Rewind();

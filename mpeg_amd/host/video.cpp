@@ -42,6 +42,31 @@ const VlcTable &tabDcSize(int plane)
 }
 const VlcTable &tabCoeff() { static const VlcTable t(mpg_vlc_dct_coeff); return t; }
 
+// the code a prefix starts with, found the slow way: the first code of the list that the prefix's leading bits spell out
+// (the lists are prefix-free: the reference's tree walk, buffer.go:352-376, ends at exactly that code)
+uint64_t vlcMismatches(const mpg_vlc_code *codes, const VlcTable &table)
+{
+    const int L = table.bits();
+    uint64_t bad = 0;
+    for (uint64_t prefix = 0; prefix < (1ull << L); prefix++) {
+        int value = 0, len = 0;
+        for (const mpg_vlc_code *c = codes; c->bits; c++) {
+            const int n = (int)strlen(c->bits);
+            uint64_t code = 0;
+            for (int k = 0; k < n; k++)
+                code = (code << 1) | (uint64_t)(c->bits[k] - '0');
+            if ((prefix >> (L - n)) == code) {
+                value = c->dead ? 0 : c->value;
+                len = n;
+                break;
+            }
+        }
+        const VlcTable::Symbol got = table.at(prefix << (64 - L));
+        bad += (got.value != value || got.len != len) ? 1 : 0;
+    }
+    return bad;
+}
+
 constexpr int kPictureTypeIntra = 1, kPictureTypePredictive = 2, kPictureTypeB = 3;
 constexpr int kStartPicture = 0x00, kStartSliceFirst = 0x01, kStartSliceLast = 0xAF, kStartUserData = 0xB2,
               kStartSequence = 0xB3, kStartExtension = 0xB5;
@@ -82,6 +107,15 @@ int32_t dequantPremult(int level, bool intra, int qscale, int qm, int idx)
 }
 
 } // namespace
+
+uint64_t Video::VlcSelfCheck()
+{
+    return vlcMismatches(mpg_vlc_mba_increment, tabMba()) + vlcMismatches(mpg_vlc_mb_type_i, tabType(1)) +
+           vlcMismatches(mpg_vlc_mb_type_p, tabType(2)) + vlcMismatches(mpg_vlc_mb_type_b, tabType(3)) +
+           vlcMismatches(mpg_vlc_coded_block_pattern, tabCbp()) + vlcMismatches(mpg_vlc_motion_code, tabMotion()) +
+           vlcMismatches(mpg_vlc_dct_dc_size_luma, tabDcSize(0)) + vlcMismatches(mpg_vlc_dct_dc_size_chroma, tabDcSize(1)) +
+           vlcMismatches(mpg_vlc_dct_coeff, tabCoeff());
+}
 
 Video::Video(Buffer *buf, Device *dev) : buf_(buf), backend_(dev->newVideoBackend()) { init(); }
 Video::Video(Buffer *buf, std::unique_ptr<VideoBackend> backend) : buf_(buf), backend_(std::move(backend)) { init(); }

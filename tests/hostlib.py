@@ -37,6 +37,7 @@ def host():
             "mpeghost_video_close": (None, [P]), "mpeghost_video_width": (C.c_int, [P]), "mpeghost_video_height": (C.c_int, [P]),
             "mpeghost_video_framerate": (C.c_double, [P]), "mpeghost_video_set_no_delay": (None, [P, C.c_int]),
             "mpeghost_video_set_sparse": (None, [P, C.c_int]), "mpeghost_set_default_sparse": (None, [C.c_int]),
+            "mpeghost_debug_vlc_self_check": (C.c_uint64, []),
             "mpeghost_video_decode": (C.c_int, [P, C.POINTER(HostFrame)]), "mpeghost_video_rgba": (P, [P]),
             "mpeghost_video_stats": (None, [P, C.POINTER(C.c_uint64 * 8)]),
             "mpeghost_audio_open": (P, [P, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),

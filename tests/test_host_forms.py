@@ -75,3 +75,10 @@ def test_mutated_streams_in_both_forms(oracle, golden_dir, form):
             i += 1
         ref.close()
         dut.close()
+
+
+def test_every_vlc_table_agrees_with_its_code_list_for_every_prefix():
+    """The parser's two-level tables (mpeg_amd/host/vlc.hpp: 9 bits, then the rest) against the first matching code of the
+    ISO 11172-2 lists, dead ends of the reference's tree (buffer.go:352-376) included: all 2^17 looks for the coefficient
+    table, all 2^L for the others."""
+    assert hostlib.host().mpeghost_debug_vlc_self_check() == 0
