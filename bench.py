@@ -393,6 +393,63 @@ def reference_benchmarks(ctx, args, device):
     return out
 
 
+def host_fed_leg(args, prim, device):
+    """The same typical pictures handed over by host threads through the staged submit — PCIe inclusive, NOT `value`.
+    Headline: the DEVICE-PACKED stage (mpeghip_video_stage_begin_device: the host copies the ABI's arrays into pinned staging,
+    pack_kernel validates and packs them in front of recon_kernel) with 8 putting threads; beside it the same with the
+    pictures already in the staging buffers (a parser that writes in place: mpeghip_video_stage_map), and round 3's
+    host-packed stages (validation + packing on the putting threads) for comparison."""
+    import torch
+    from mpeg_amd import desc
+    from tools import hostbench
+    cpus = os.cpu_count() or 1
+    seq = prim["seq"]
+    sec = args.host_fed_seconds
+    w, h = args.width, args.height
+    per_call = 128
+    dev8 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(8, cpus), sec, sparse=True, device_pack=1)
+    dev4 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(4, cpus), sec / 2, sparse=True, device_pack=1)
+    dev16 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(16, cpus), sec / 2, sparse=True, device_pack=1)
+    mid = seq[len(seq) // 2: len(seq) // 2 + 1]   # (a B picture of the GOP: the in-place mode cycles one picture)
+    in_place = hostbench.staged_submit_rate(device, w, h, mid, per_call, min(8, cpus), sec / 2, sparse=True, device_pack=2)
+    host32 = hostbench.staged_submit_rate(device, w, h, seq, 64, min(32, cpus), sec / 2, sparse=True)
+    host16 = hostbench.staged_submit_rate(device, w, h, seq, 64, min(16, cpus), sec / 2, sparse=True)
+    units32 = hostbench.staged_submit_rate(device, w, h, seq, 64, min(32, cpus), sec / 2, sparse=False)
+    mb_per_pic = float(np.mean([len(s.mbs) for s in seq]))
+    # bytes per picture on the wire: the ABI's arrays as they are (device-packed) / the device format (host-packed)
+    abi_bytes = float(np.mean([32 * len(s.mbs) + 4 * len(desc.to_sparse(s.mbs, s.coefs)[1]) + 32 for s in seq]))
+    mid_bytes = 32 * len(mid[0].mbs) + 4 * len(desc.to_sparse(mid[0].mbs, mid[0].coefs)[1]) + 32
+    # what the link gives a bare copy from pinned memory (64 MB pieces, the size the staged submit sends)
+    src = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(64 << 20, dtype=torch.uint8, device="cuda:%d" % device)
+    h2d = 0.0
+    for _ in range(4):  # (best of four: the first passes also fault the pinned pages in)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(16):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d = max(h2d, 16 * (64 << 20) / (time.perf_counter() - t0) / 1e9)
+    del src, dst
+    return {"metric": "1080p macroblocks/sec handed over by host threads through a DEVICE-PACKED stage (mpeghip_video_stage_begin_device: "
+                      "the host copies the ABI's arrays — descriptors + the parser's sparse words — into pinned staging, pack_kernel "
+                      "validates and packs them on the GPU, recon_kernel reconstructs) — PCIe inclusive, NOT `value`",
+            "value": dev8 * mb_per_pic, "pictures_per_s": dev8, "host_threads": min(8, cpus), "pictures_per_call": per_call,
+            "pictures_per_s_4_threads": dev4, "pictures_per_s_16_threads": dev16,
+            "realtime_1080p30_streams": dev8 * mb_per_pic / MB_PER_1080P30_STREAM,
+            "abi_bytes_per_picture": abi_bytes, "pcie_GBps_used": dev8 * abi_bytes / 1e9, "pcie_h2d_GBps_bare_copy": h2d,
+            "pcie_frac_of_bare_copy": dev8 * abi_bytes / 1e9 / h2d if h2d else None,
+            "in_place": {"pictures_per_s": in_place, "pcie_GBps_used": in_place * mid_bytes / 1e9, "bytes_per_picture": mid_bytes,
+                         "what": "the pictures already in the pinned staging buffers (mpeghip_video_stage_map: a parser writes them "
+                                 "there): commit + PCIe + pack_kernel + recon_kernel, no host work per picture"},
+            "host_packed": {"pictures_per_s_32_threads": host32, "pictures_per_s_16_threads": host16, "pictures_per_s_unit_form_32_threads": units32,
+                            "pictures_per_call": 64, "device_format_bytes_per_picture": prim["device_bytes_per_picture"],
+                            "pcie_GBps_used": host32 * prim["device_bytes_per_picture"] / 1e9,
+                            "what": "round 3's hand-over: validation + packing into the device format on the putting threads"},
+            "note": "the on-device `value` is %.0f x this: no PCIe link can carry what the kernel reconstructs (BASELINE.md)" %
+                    (prim["mbs"] / prim["elapsed"] / (dev8 * mb_per_pic))}
+
+
 def main():
     args = parse_args()
     import torch
@@ -455,35 +512,7 @@ def main():
     # i.e. validation + packing into the device format on the host, PCIe, reconstruction on the device
     host_fed = None
     if args.host_fed_seconds > 0 and alone:
-        threads = min(32, os.cpu_count() or 1)
-        seq = prim["seq"]
-        from tools import hostbench
-        pps = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds, sparse=True)
-        pps16 = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, min(16, threads), args.host_fed_seconds / 2, sparse=True)
-        pps_units = hostbench.staged_submit_rate(local_rank, args.width, args.height, seq, 64, threads, args.host_fed_seconds / 2, sparse=False)
-        mb_per_pic = float(np.mean([len(s.mbs) for s in seq]))
-        # what the link gives a bare copy from pinned memory (64 MB pieces, the size the staged submit sends), next to what the
-        # hand-over used of it: is PCIe the wall?
-        src = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
-        dst = torch.empty(64 << 20, dtype=torch.uint8, device="cuda:%d" % local_rank)
-        h2d = 0.0
-        for _ in range(4):  # (best of four: the first passes also fault the pinned pages in)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(16):
-                dst.copy_(src, non_blocking=True)
-            torch.cuda.synchronize()
-            h2d = max(h2d, 16 * (64 << 20) / (time.perf_counter() - t0) / 1e9)
-        del src, dst
-        host_fed = {"metric": "1080p macroblocks/sec handed over by host threads (mpeghip_video_stage_*: validation + packing on the host, "
-                              "PCIe, reconstruction), pictures in the parser's sparse form — PCIe inclusive, NOT `value`",
-                    "value": pps * mb_per_pic, "pictures_per_s": pps, "pictures_per_s_unit_form": pps_units, "host_threads": threads,
-                    "pictures_per_s_16_threads": pps16,  # (the rate peaks near 16 putting threads: tools/hostbench/sweep.py)
-                    "pictures_per_call": 64, "realtime_1080p30_streams": pps * mb_per_pic / MB_PER_1080P30_STREAM,
-                    "device_format_bytes_per_picture": prim["device_bytes_per_picture"],
-                    "pcie_GBps_used": pps * prim["device_bytes_per_picture"] / 1e9, "pcie_h2d_GBps_bare_copy": h2d,
-                    "note": "the on-device `value` is %.0f x this: no host can parse, and no PCIe link can carry, what the kernel "
-                            "reconstructs (BASELINE.md)" % (prim["mbs"] / prim["elapsed"] / (pps * mb_per_pic))}
+        host_fed = host_fed_leg(args, prim, local_rank)
 
     if all_cpus is not None and numa["cpus_bound"]:
         os.sched_setaffinity(0, all_cpus)  # the CPU baseline is the whole host's: every core of both sockets

@@ -43,7 +43,7 @@ type hipVideo struct {
 	dev *mpeghip.Video
 
 	mbs     []mpeghip.MbDesc // one picture's macroblocks (reused between pictures)
-	words   []uint32         // the picture's coded blocks in the sparse form (mpeghip.h: MPEGHIP_PIC_SPARSE): count + pairs; snapshots as 64 int32
+	words   []uint32         // the picture's coded blocks in the sparse form (mpeghip.h: MPEGHIP_PIC_SPARSE): count + pairs; snapshots as the count 64 + 64 int32
 	written []bool           // macroblock address already emitted in the current submit
 
 	// current macroblock
@@ -337,7 +337,7 @@ func (h *hipVideo) decodeBlock(v *Video, block int) {
 
 // endMacroblock appends the macroblock's descriptor and its coded blocks: per block a count word and one pair per coded
 // level, as the VLC loop produced them (an intra block's DC first; a coded zero level stays a pair); the blocks of a
-// macroblock that travels raw as 64 int32 snapshots, column-major.
+// macroblock that travels raw as the count word 64 and a snapshot of 64 int32 values, column-major.
 func (h *hipVideo) endMacroblock(v *Video) {
 	if !h.active {
 		return
@@ -405,6 +405,7 @@ func (h *hipVideo) endMacroblock(v *Video) {
 					snap[0] = int32(br.q[0]) << 8
 				}
 			}
+			h.words = append(h.words, 64) // every block of the sparse form begins with its count word: 64 for a snapshot
 			at := len(h.words)
 			h.words = append(h.words, make([]uint32, 64)...)
 			for i := 0; i < 64; i++ {

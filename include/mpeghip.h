@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define MPEGHIP_ABI_VERSION 1
+/* 2: the sparse hand-over's snapshot blocks carry a count word, a sparse picture's macroblocks name their words in order;
+ *    the device-packed stage (mpeghip_video_stage_begin_device) and its deferred errors; chroma as Cb|Cr pairs in device memory */
+#define MPEGHIP_ABI_VERSION 2
 
 #define MPEGHIP_OK             0
 #define MPEGHIP_ERR_INVALID   (-1) /* bad argument / malformed descriptor            */
@@ -140,7 +142,7 @@ typedef struct mpeghip_pic_desc {
     uint8_t  cur;         /* slot written by this picture (frameCurrent)             */
     uint8_t  fwd;         /* slot read for forward prediction (frameForward)         */
     uint8_t  bwd;         /* slot read for backward prediction (frameBackward)       */
-    uint8_t  flags;       /* MPEGHIP_PIC_*                                           */
+    uint8_t  flags;       /* MPEGHIP_PIC_*; undefined bits are refused               */
     uint32_t mb_first;    /* first macroblock descriptor of this picture             */
     uint32_t mb_count;    /* number of macroblock descriptors                        */
 } mpeghip_pic_desc;       /* 16 bytes */
@@ -258,10 +260,17 @@ int mpeghip_video_stage_commit(mpeghip_stage *s);
  *                        (position 0, always present; `<< 8` in the reference, video.go:672).  A level of 0
  *                        is a CODED zero: the reference dequantises it to +-1 (video.go:719-736) — the form
  *                        that units (0 = absent) need a snapshot for.
- *     a snapshot block   (macroblock flag MPEGHIP_MB_COEF_RAW): 64 int32 values, column-major, no count word
+ *     a snapshot block   (macroblock flag MPEGHIP_MB_COEF_RAW): the count word 64, then 64 int32 values, column-major
+ *                        (ABI version 2: every block begins with a count word)
+ *   macroblocks name their words IN ORDER and without overlap: mbs[k].coef_off is at least the end of macroblock k-1's
+ *                     data and at most the picture's dwords — for every macroblock, coded blocks or not.  (So the packed form of
+ *                     a picture is never longer than its input, and the device-side packer places a chunk's words by the
+ *                     offset of its first macroblock.)
  *   coef_bytes        a multiple of 4 (of 128 as soon as one picture of the call is in the unit form)
- * Malformed block data (a count beyond 64, a block that ends behind the buffer, bits outside the two
- * fields of a pair, an intra block without its DC first) is refused with MPEGHIP_ERR_INVALID, nothing launched.
+ * Malformed block data (a count beyond 64 — or other than 64 for a snapshot block —, a block that ends behind the buffer,
+ * macroblocks out of order or overlapping, bits outside the two fields of a pair, an intra block without its DC first) is
+ * refused with MPEGHIP_ERR_INVALID, nothing launched; so are pictures of one submit that name the same words beyond the
+ * room the packed form was given (the buffer's dwords).
  * The three functions below are the same calls with the flag set for the caller and sizes in dwords:
  *   mpeghip_video_stage_begin_sparse / _put_sparse   the many-stream emitter (one parser thread per stream)
  *   mpeghip_video_submit_sparse                      ONE picture per call: the single-stream decoder's flush */
@@ -273,6 +282,36 @@ int mpeghip_video_stage_put_sparse(mpeghip_stage *s, uint32_t i, const mpeghip_p
                                    const mpeghip_mb_desc *mbs, const uint32_t *words);
 int mpeghip_video_submit_sparse(mpeghip_video *v, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
                                 const uint32_t *words, size_t n_words);
+
+/* The DEVICE-PACKED stage: the same staged submit with the library's host work reduced to a copy.  The pictures' arrays —
+ * mpeghip_pic_desc, mpeghip_mb_desc, the sparse form's count / pair words — travel to the device as they are, and a kernel in
+ * front of the reconstruction validates them and packs them into the device format there: what
+ * validate + pack cost a host core per picture (0.27 ms for a typical 1080p picture) is what kept the staged hand-over at
+ * 44 % of the PCIe link's rate.  Sparse pictures only (mpeghip_video_stage_put on such a stage fails).
+ *   mpeghip_video_stage_begin_device   as _begin_sparse: n_words[i] dwords for picture i
+ *   mpeghip_video_stage_put_sparse     copies picture i's arrays into the pinned staging buffer (thread-safe for distinct i)
+ *   mpeghip_video_stage_map            OR: where picture i's arrays live in that buffer — n_mbs[i] descriptors, n_words[i]
+ *                                      dwords — so that a parser writes them there in the first place (pinned host memory of
+ *                                      the library, valid until the commit), then
+ *   mpeghip_video_stage_put_mapped     hands over the picture's descriptor and marks picture i complete; no copy at all
+ *   mpeghip_video_stage_commit         one H2D copy, pack, reconstruct; returns with all of it in flight
+ * DEFERRED ERRORS.  put / put_mapped check the picture descriptor only.  Everything the host path refuses with
+ * MPEGHIP_ERR_INVALID / MPEGHIP_ERR_RANGE at `put` or `commit` — macroblock fields, vectors that leave the frame buffer, a
+ * position addressed twice, malformed block data, dependent pictures — is found by the device AFTER the commit has returned
+ * MPEGHIP_OK.  Such a commit reconstructs NOTHING (all of its pictures are dropped, the frame store is as before it), later
+ * commits run as queued, and the error — with the first offending picture and macroblock in mpeghip_last_error() — is returned
+ * ONCE by the next call on the handle that waits for the device: mpeghip_video_sync, read_planes, read_rgba, hash_slots, or the
+ * stage_begin / submit that reuses the commit's staging buffer (the second one after it).  A caller that must know before it
+ * goes on calls mpeghip_video_sync.
+ * The sparse form's rule that macroblocks name their words in order and without overlap is what lets the device place a
+ * chunk's words without a scan; cbp == 0 macroblocks take part in it (their coef_off: anything from the previous
+ * macroblock's end to the picture's n_words). */
+int mpeghip_video_stage_begin_device(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
+                                     mpeghip_stage **out);
+int mpeghip_video_stage_map(mpeghip_stage *s, uint32_t i, mpeghip_mb_desc **mbs, uint32_t **words);
+int mpeghip_video_stage_put_mapped(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic);
+/* Wait for everything queued on this handle; returns (once) the deferred error of a device-packed commit, if any. */
+int mpeghip_video_sync(mpeghip_video *v);
 
 /* Device-resident batches: validate + upload once, replay many times
  * (synthetic benchmark batches; a real decoder double-buffers two). */

@@ -107,6 +107,10 @@ void mpeghost_batch_set_threads(void *batch, uint32_t n);
 int mpeghost_batch_frame(void *batch, uint32_t stream, mpeghost_frame *out);
 void mpeghost_batch_counters(void *batch, uint64_t out[2]);          /* device submits, pictures queued */
 void mpeghost_batch_phase_seconds(void *batch, double out[4]);       /* parse rounds, stage begin, puts, commits */
+/* staged submits of sparse pictures validated + packed on the DEVICE (mpeghip_video_stage_begin_device; default 1) or on the host */
+void mpeghost_batch_set_device_pack(void *batch, int on);
+int mpeghost_batch_sync(void *batch);                                /* wait; -1 + mpeghost_last_error(): a device-packed commit's deferred error */
+void mpeghost_batch_numa_pins(void *batch, uint32_t out[2]);         /* pool threads asked to bind to the NUMA node, bindings that failed */
 
 /* ---- ShardedVideoBatch: streams sharded over SEVERAL devices (stream s -> device s mod G), one host thread and one
  * VideoBatch per device, no collective */

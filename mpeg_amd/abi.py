@@ -14,6 +14,7 @@ from . import desc
 from ._build import LIBMPEGHIP
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RANGE = 0, -1, -2, -3, -4, -5
+ABI_VERSION = 2  # include/mpeghip.h: MPEGHIP_ABI_VERSION this binding was written against (checked at load)
 
 
 class MpegHipError(RuntimeError):
@@ -56,6 +57,10 @@ SYMBOLS = {
     "mpeghip_video_stage_begin_sparse": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_void_p)]),
     "mpeghip_video_stage_put_sparse": (C.c_int, [_P, C.c_uint32, _P, _P, _P]),
     "mpeghip_video_submit_sparse": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_size_t]),
+    "mpeghip_video_stage_begin_device": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_void_p)]),
+    "mpeghip_video_stage_map": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(_P)]),
+    "mpeghip_video_stage_put_mapped": (C.c_int, [_P, C.c_uint32, _P]),
+    "mpeghip_video_sync": (C.c_int, [_P]),
     "mpeghip_video_batch_upload": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.POINTER(_P)]),
     "mpeghip_video_batch_upload_replicated": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     "mpeghip_video_batch_run": (C.c_int, [_P, _P]),
@@ -99,6 +104,8 @@ def load_library(path: Path | None = None) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.mpeghip_abi_version() != ABI_VERSION:
+        raise MpegHipError(ERR_INVALID, "%s has ABI version %d, this binding is for %d" % (p, lib.mpeghip_abi_version(), ABI_VERSION))
     if path is None:
         _lib = lib
     return lib
@@ -250,6 +257,48 @@ class VideoStore:
                 put(i)
         _check(self.lib.mpeghip_video_stage_commit(st))
         return rcs
+
+    def submit_staged_device(self, pictures, threads: int = 1, mapped: bool = False, sync: bool = True):
+        """A DEVICE-PACKED stage (mpeghip_video_stage_begin_device): pictures = [(pic, mbs, words)] in the sparse form; the host
+        only copies them (mapped: writes them straight into the staging buffer through mpeghip_video_stage_map), the device
+        validates and packs.  sync: wait and raise the commit's deferred error, if any (else the caller does: self.sync())."""
+        parts = [(np.ascontiguousarray(np.asarray(p).reshape(1), dtype=desc.PIC_DTYPE), np.ascontiguousarray(m, dtype=desc.MB_DTYPE),
+                  np.ascontiguousarray(w, dtype=np.uint32)) for p, m, w in pictures]
+        n_mbs = np.array([len(m) for _, m, _ in parts], np.uint32)
+        n_words = np.array([len(w) for _, _, w in parts], np.uint64)  # size_t
+        st = C.c_void_p()
+        _check(self.lib.mpeghip_video_stage_begin_device(self.h, len(parts), _ptr(n_mbs), _ptr(n_words), C.byref(st)))
+        rcs = [0] * len(parts)
+
+        def put(i):
+            p, m, w = parts[i]
+            if mapped:
+                pm, pw = C.c_void_p(), C.c_void_p()
+                rcs[i] = self.lib.mpeghip_video_stage_map(st, i, C.byref(pm), C.byref(pw))
+                if rcs[i] == OK:
+                    if len(m):
+                        C.memmove(pm, m.ctypes.data, m.nbytes)
+                    if len(w):
+                        C.memmove(pw, w.ctypes.data, w.nbytes)
+                    rcs[i] = self.lib.mpeghip_video_stage_put_mapped(st, i, _ptr(p))
+            else:
+                rcs[i] = self.lib.mpeghip_video_stage_put_sparse(st, i, _ptr(p), _ptr(m), _ptr(w))
+
+        if threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(put, range(len(parts))))
+        else:
+            for i in range(len(parts)):
+                put(i)
+        _check(self.lib.mpeghip_video_stage_commit(st))
+        if sync:
+            self.sync()
+        return rcs
+
+    def sync(self):
+        """mpeghip_video_sync: wait for the handle's queued work; raises the deferred error of a device-packed commit."""
+        _check(self.lib.mpeghip_video_sync(self.h))
 
     def upload(self, pics, mbs, coefs, replicate: int = 1) -> Batch:
         pics, mbs, coefs = self._args(pics, mbs, coefs)

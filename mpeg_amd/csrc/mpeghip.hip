@@ -24,6 +24,7 @@
 #include "iso11172_synth_window.h"
 #include "mpeghip.h"
 #include "video_lane.h"
+#include "video_pack_lane.h"
 #include "video_recon_lane.h"
 
 using namespace mpg;
@@ -392,6 +393,72 @@ __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64
 // Replicate a one-stream batch for streams 1..n-1 (benchmark batches): stream s gets its own copy of the
 // chunks, shifted to its frames, its table and its own copy of the words.  Upload-time scaffolding of
 // mpeghip_video_batch_upload_replicated, never inside a timed region.
+// ---- the device-side packer (video_pack_lane.h has the whole story): one wave = 64 consecutive macroblocks = 16 chunks of one
+// picture of a device-packed stage; grid = pictures x (waves the largest picture needs).
+__global__ __launch_bounds__(64) void pack_kernel(const PackArgs a)
+{
+    __shared__ uint32_t xch[64 * kPkXchDwords];
+    const uint32_t pic = blockIdx.x / a.groups_per_pic, g = blockIdx.x - pic * a.groups_per_pic;
+    const mpeghip_pic_desc p = a.pics[pic];
+    if (g * 64 >= p.mb_count)
+        return;
+    const PkPic x = a.aux[pic];
+    const int lane = (int)threadIdx.x;
+    const uint32_t k = g * 64 + (uint32_t)lane;
+    const PkLane L = pk_scan(a, pic, p, x, k);
+    // which of its two references the picture's macroblocks read (the dependency check between pictures, pack_gate_kernel)
+    const uint32_t use = L.ok ? L.use : 0u;
+    const bool fwd = __ballot((use & 1u) != 0) != 0, bwd = __ballot((use & 2u) != 0) != 0;
+    if (lane == 0 && (fwd || bwd))
+        atomicOr(&a.aux[pic].use, (fwd ? 1u : 0u) | (bwd ? 2u : 0u));
+    pk_share(xch, lane, L);
+    wave_lds_handoff();
+    const uint32_t k_next = g * 64 + 64;
+    const uint32_t next_coef_off = k_next < p.mb_count ? a.mbs[p.mb_first + k_next].coef_off : 0u;
+    pk_emit(a, p, x, k, lane, L, xch, next_coef_off);
+}
+
+// Behind pack_kernel: pictures of one stream that depend on each other (the host lists the candidates: picture, which of its
+// references another picture of the commit writes; whether a macroblock reads it, only pack_kernel knows), the verdict
+// where the host finds it, and — if anything was wrong — every chunk of the commit turned into a dead one: recon_kernel,
+// next on the stream, then writes nothing.
+struct PkDep { uint32_t pic, mask; };
+__global__ __launch_bounds__(256) void pack_gate_kernel(const unsigned long long *err, const PkPic *aux, const mpeghip_pic_desc *pics,
+                                                        const PkDep *deps, uint32_t n_deps, uint32_t *chunks, uint32_t n_chunks,
+                                                        unsigned long long *verdict)
+{
+    __shared__ unsigned long long key;
+    if (threadIdx.x == 0)
+        key = *err;
+    __syncthreads();
+    unsigned long long mine = kPkNoError;
+    for (uint32_t i = threadIdx.x; i < n_deps; i += 256)
+        if (aux[deps[i].pic].use & deps[i].mask) {
+            const unsigned long long k = ((unsigned long long)pics[deps[i].pic].mb_first << 8) | kPkDepends;
+            mine = k < mine ? k : mine;
+        }
+    if (mine != kPkNoError)
+        atomicMin(&key, mine);
+    __syncthreads();
+    const unsigned long long found = key;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *verdict = found; // (pinned host memory)
+        __threadfence_system();
+    }
+    if (found == kPkNoError)
+        return;
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_chunks)
+        return;
+    uint32_t *h = chunks + (size_t)c * kRcChunkDwords;
+#pragma unroll
+    for (int i = 0; i < kRcChunkDwords; i++)
+        h[i] = 0;
+#pragma unroll
+    for (int m = 0; m < kRcMbs; m++)
+        h[8 + 4 * m] = kRDead;
+}
+
 struct ReplicateSteps {
     uint32_t words;       // words of one stream
     uint32_t frames256;   // MPEGHIP_SLOTS * frame_stride >> 8
@@ -599,6 +666,16 @@ struct mpeghip_video {
         size_t cap_h = 0;
         hipEvent_t done = nullptr; // recorded after the batch's kernel
         bool in_flight = false;
+        // a device-packed stage (mpeghip_video_stage_begin_device): the staged arrays as they are on the device, the packer's
+        // scratch, and its verdict — written by pack_gate_kernel into pinned memory, looked at when `done` has passed
+        uint8_t *d_raw = nullptr;
+        size_t cap_raw = 0;
+        uint32_t *d_seen = nullptr;
+        size_t cap_seen = 0;
+        unsigned long long *d_err = nullptr;
+        unsigned long long *h_verdict = nullptr; // pinned
+        bool packed_on_device = false;           // the commit in flight was: h_verdict is meaningful once `done` has passed
+        std::vector<uint32_t> pk_mb_first;       // per picture of that commit: its first macroblock (to name the picture of a report)
     } staging[2];
     int next_staging = 0;
     struct mpeghip_stage *stage = nullptr; // the open mpeghip_video_stage_begin, if any
@@ -631,6 +708,12 @@ struct mpeghip_stage {
     std::atomic<uint64_t> words_used{0};        // dwords handed out so far: a put packs its picture into scratch
                                                 // memory of its thread, then takes exactly the room it needs, so
                                                 // that the words form one contiguous block = one H2D copy
+    // a device-packed stage: the pinned buffer holds pictures | PkPic | dependency list | macroblocks | words as the caller
+    // hands them over; pack_kernel makes chunks and words of them on the device
+    bool device = false;
+    std::vector<uint32_t> word_first;           // per picture: its first dword in the staged words (a multiple of 16)
+    size_t a_at = 0, d_at = 0, m_at = 0, in_at = 0; // staging layout of a device-packed stage
+    uint64_t words_total = 0;                   // dwords of the staged words
     std::atomic<int> error{MPEGHIP_OK};         // first failed put
     std::mutex error_lock;
     std::string error_text;
@@ -905,6 +988,14 @@ void mpeghip_video_close(mpeghip_video *v)
         (void)hipFree(v->d_linear);
     for (auto &sg : v->staging) {
         batch_release(&sg.batch);
+        if (sg.d_raw)
+            (void)hipFree(sg.d_raw);
+        if (sg.d_seen)
+            (void)hipFree(sg.d_seen);
+        if (sg.d_err)
+            (void)hipFree(sg.d_err);
+        if (sg.h_verdict)
+            (void)hipHostFree(sg.h_verdict);
         if (sg.h)
             (void)hipHostFree(sg.h);
         if (sg.done)
@@ -972,6 +1063,8 @@ static int validate_pic(const mpeghip_video_info &in, const mpeghip_pic_desc &pd
 {
     if (pd.stream >= in.n_streams || pd.cur >= MPEGHIP_SLOTS || pd.fwd >= MPEGHIP_SLOTS || pd.bwd >= MPEGHIP_SLOTS)
         return fail(MPEGHIP_ERR_INVALID, "picture %u: bad stream/slot", p);
+    if (pd.flags & ~(MPEGHIP_PIC_RGBA | MPEGHIP_PIC_SPARSE)) // (a stray bit from an uninitialised caller must not pick the coefficient form)
+        return fail(MPEGHIP_ERR_INVALID, "picture %u: flags 0x%x: undefined bits", p, pd.flags);
     return MPEGHIP_OK;
 }
 
@@ -1118,11 +1211,23 @@ static size_t words_room(uint64_t coef_bytes, uint64_t n_mbs)
     const size_t as_sparse = rc_max_words_sparse(coef_bytes / 4, (uint32_t)(n_mbs > 0xffffffffull ? 0xffffffffull : n_mbs));
     return as_units > as_sparse ? as_units : as_sparse;
 }
+// ... of a submit whose pictures may come in both forms: unit pictures can need 65 words per unit of the buffer, sparse
+// pictures the buffer's dwords once more
+static size_t words_room_submit(const mpeghip_pic_desc *pics, uint32_t n_pics, uint64_t coef_bytes, uint64_t n_mbs)
+{
+    bool units = false, sparse = false;
+    for (uint32_t p = 0; p < n_pics; p++)
+        ((pics[p].flags & MPEGHIP_PIC_SPARSE) ? sparse : units) = true;
+    if (units && sparse)
+        return rc_max_words((coef_bytes + MPEGHIP_COEF_UNIT - 1) / MPEGHIP_COEF_UNIT) + rc_max_words_sparse(coef_bytes / 4, 0);
+    return words_room(coef_bytes, n_mbs);
+}
 static std::string sparse_error_text(uint32_t pic, uint32_t mb)
 {
-    char t[320];
-    snprintf(t, sizeof(t), "picture %u, macroblock %u: malformed sparse block data (a count beyond 64, a block that ends behind the "
-             "coefficient buffer, bits outside a pair's two fields, or an intra block without its DC first)", pic, mb);
+    char t[480];
+    snprintf(t, sizeof(t), "picture %u, macroblock %u: malformed sparse block data (a count beyond 64 — other than 64 for a snapshot "
+             "block —, a block that ends behind the coefficient buffer, a macroblock whose data begins before the previous one's "
+             "ends, bits outside a pair's two fields, or an intra block without its DC first)", pic, mb);
     return t;
 }
 
@@ -1161,7 +1266,7 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
     const uint64_t coef_units = coef_bytes / MPEGHIP_COEF_UNIT;
     std::vector<PicUse> use(n_pics);
     std::vector<uint64_t> seen;
-    uint64_t alg = 0, words = 0, chunk = 0, named_units = 0, blocks = 0, dense = 0;
+    uint64_t alg = 0, words = 0, chunk = 0, named_units = 0, blocks = 0, dense = 0, sparse_used = 0;
     for (uint32_t p = 0; p < n_pics; p++) {
         const mpeghip_mb_desc *pm = mbs + pics[p].mb_first;
         for (uint32_t k = 0; k < pics[p].mb_count; k++)
@@ -1175,17 +1280,19 @@ static int validate_and_pack(const mpeghip_video *v, const mpeghip_pic_desc *pic
         if (rc != MPEGHIP_OK)
             return rc;
         if (chunks_out) {
-            if (words > 0xffffffffull - words_room(coef_bytes, n_mbs))
+            if (words > 0xffffffffull - words_room_submit(pics, n_pics, coef_bytes, n_mbs))
                 return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
             const RcPacked got = sparse ? rc_pack_picture<true, true>(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
                                                                       (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words,
-                                                                      coef_bytes / 4)
+                                                                      coef_bytes / 4, rc_max_words_sparse(coef_bytes / 4, 0) - sparse_used)
                                         : rc_pack_picture(geom, pics[p], pm, pics[p].mb_count, static_cast<const uint8_t *>(coefs),
                                                  (uint32_t)words, chunks_out + chunk * kRcChunkDwords, words_out + words);
             if (got.bad)
                 return fail(MPEGHIP_ERR_INVALID, "%s", sparse_error_text(p, pics[p].mb_first + got.bad - 1).c_str());
             chunk += got.chunks;
             words += got.words;
+            sparse_used += sparse ? got.words : 0; // (sparse pictures together: no more than the buffer's dwords — pictures may
+                                                   // name the same words, but not past the room the buffers were sized for)
             blocks += got.blocks;
             dense += got.dense_blocks;
         }
@@ -1233,6 +1340,53 @@ static int grow_pinned(mpeghip_video::Staging *sg, size_t need)
     return MPEGHIP_OK;
 }
 
+// ---- the verdict of a device-packed commit (mpeghip_video_stage_begin_device): known once the staging slot's `done` event has
+// passed.  Reasons are those of validate_mb / rc_pack_picture (video_pack_lane.h: kPk*).
+static int reap_verdict(mpeghip_video::Staging *sg)
+{
+    if (!sg->packed_on_device)
+        return MPEGHIP_OK;
+    sg->packed_on_device = false;
+    const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(sg->h_verdict);
+    if (key == kPkNoError)
+        return MPEGHIP_OK;
+    const uint32_t mb = (uint32_t)(key >> 8), reason = (uint32_t)(key & 0xff);
+    uint32_t pic = 0;
+    if (!sg->pk_mb_first.empty())
+        pic = (uint32_t)(std::upper_bound(sg->pk_mb_first.begin(), sg->pk_mb_first.end(), mb) - sg->pk_mb_first.begin()) - 1;
+    const uint32_t k = sg->pk_mb_first.empty() ? mb : mb - sg->pk_mb_first[pic];
+    static const char *const why[] = {
+        "", "position outside the picture", "flags name no or two references (or one for an intra macroblock)", "cbp beyond 0x3f",
+        "quantiser_scale outside 1..31", "predicts from the slot its picture writes", "motion vector reads outside the frame buffer",
+        "its position is addressed twice in one picture", "malformed sparse block data (a count beyond 64 — other than 64 for a snapshot "
+        "block —, a block that ends behind the picture's words, bits outside a pair's two fields, or an intra block without its DC first)",
+        "malformed sparse block data: its data begins before the previous macroblock's ends (macroblocks name their words in order)",
+        "its picture and another picture of the same stream in this commit depend on each other: they need separate commits"};
+    return fail(reason == kPkRange ? MPEGHIP_ERR_RANGE : MPEGHIP_ERR_INVALID,
+                "device-packed commit refused, nothing of it was reconstructed: picture %u, macroblock %u: %s", pic, k,
+                reason < sizeof(why) / sizeof(why[0]) ? why[reason] : "?");
+}
+// a staging slot is about to be reused, or the caller waits for the device: its last commit has finished
+static int retire(mpeghip_video::Staging *sg)
+{
+    if (sg->in_flight) {
+        HIP_TRY(hipEventSynchronize(sg->done));
+        sg->in_flight = false;
+    }
+    return reap_verdict(sg);
+}
+// everything queued on this handle has finished (the caller has synchronised the stream): deferred verdicts, oldest first
+static int reap_all(mpeghip_video *v)
+{
+    const int older = reap_verdict(&v->staging[v->next_staging]);
+    if (older != MPEGHIP_OK) {
+        v->staging[v->next_staging ^ 1].packed_on_device = false; // (it ran on what the refused commit left undone)
+        return older;
+    }
+    return reap_verdict(&v->staging[v->next_staging ^ 1]);
+}
+
+constexpr uint64_t kDenseWordsPerMb = 56; // a device-packed commit with more input dwords per macroblock than this: likewise (stage_commit_device)
 constexpr uint64_t kDenseBatchShare = 4; // more than a quarter of a batch's coded blocks dense units: the int32-tile instance
 constexpr int kReconWaves = 1; // waves (= chunks) per workgroup: waves of a workgroup that finish early keep their slots until the
                                // last one has (its LDS goes back as a whole) — 1 beats 2 beats 4 (profiles/r2w_ab_waves_per_workgroup.txt)
@@ -1378,17 +1532,15 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
     HIP_TRY(hipSetDevice(v->ctx->device));
     const uint64_t n_chunks = chunks_of(pics, n_pics);
     const BlobLayout l = blob_layout(n_pics, n_chunks);
-    const size_t words_cap = words_room(coef_bytes, n_mbs) + kRcWordsPad;
+    const size_t words_cap = words_room_submit(pics, n_pics, coef_bytes, n_mbs) + kRcWordsPad;
     const size_t pb = sizeof(mpeghip_pic_desc) * (size_t)n_pics;
     hipStream_t st = v->ctx->stream;
     std::vector<uint8_t> pageable;
     uint8_t *h;
     int rc;
     if (sg) {
-        if (sg->in_flight) { // two submits ago: normally long finished
-            HIP_TRY(hipEventSynchronize(sg->done));
-            sg->in_flight = false;
-        }
+        if ((rc = retire(sg)) != MPEGHIP_OK) // two submits ago: normally long finished (a device-packed commit's verdict: here)
+            return rc;
         if ((rc = grow_pinned(sg, l.w_at + words_cap * 4 + 64)) != MPEGHIP_OK)
             return rc;
         if (!sg->done)
@@ -1531,14 +1683,13 @@ static int mpeghip_video_stage_begin_impl(mpeghip_video *v, uint32_t n_pics, con
     s->n_chunks = (uint32_t)chunks;
     s->words_cap = words;
     mpeghip_video::Staging *sg = &v->staging[v->next_staging];
-    if (sg->in_flight) { // two submits ago: normally long finished
-        HIP_TRY(hipEventSynchronize(sg->done));
-        sg->in_flight = false;
-    }
+    int rc = retire(sg); // two submits ago: normally long finished (a device-packed commit's verdict: here)
+    if (rc != MPEGHIP_OK)
+        return rc;
     const BlobLayout l = blob_layout(n_pics, chunks);
     s->c_at = l.c_at;
     s->w_at = l.w_at;
-    int rc = grow_pinned(sg, l.w_at + (size_t)(words + kRcWordsPad) * 4 + 64);
+    rc = grow_pinned(sg, l.w_at + (size_t)(words + kRcWordsPad) * 4 + 64);
     if (rc != MPEGHIP_OK)
         return rc;
     if (!sg->done)
@@ -1575,6 +1726,8 @@ int mpeghip_video_stage_begin_sparse(mpeghip_video *v, uint32_t n_pics, const ui
     return no_throw([&] { return mpeghip_video_stage_begin_sparse_impl(v, n_pics, n_mbs, n_words, out); });
 }
 
+static int stage_put_device(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, const void *words,
+                            bool copy);
 // Thread-safe for distinct i: touches only picture i's part of the staging buffer and of the stage's arrays.
 static int mpeghip_video_stage_put_impl(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs,
                             const void *coefs)
@@ -1582,6 +1735,8 @@ static int mpeghip_video_stage_put_impl(mpeghip_stage *s, uint32_t i, const mpeg
     if (!s || !pic)
         return fail(MPEGHIP_ERR_INVALID, "stage_put: NULL argument");
     const bool sparse = (pic->flags & MPEGHIP_PIC_SPARSE) != 0;
+    if (s->device)
+        return stage_put_device(s, i, pic, mbs, coefs, true);
     int rc = MPEGHIP_OK;
     do {
         if (i >= s->n_pics) {
@@ -1628,7 +1783,7 @@ static int mpeghip_video_stage_put_impl(mpeghip_stage *s, uint32_t i, const mpeg
             scratch.resize(worst + worst / 4 + 1024);
         uint32_t *chunks = reinterpret_cast<uint32_t *>(h + s->c_at) + (size_t)s->chunk_first[i] * kRcChunkDwords;
         const RcPacked got = sparse ? rc_pack_picture<true, true>(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0,
-                                                                  chunks, scratch.data(), s->units[i] / 4)
+                                                                  chunks, scratch.data(), s->units[i] / 4, worst)
                                     : rc_pack_picture(record_geometry(v), pd, mbs, n, static_cast<const uint8_t *>(coefs), 0, chunks,
                                                       scratch.data());
         if (got.bad) {
@@ -1688,6 +1843,242 @@ int mpeghip_video_submit_sparse(mpeghip_video *v, const mpeghip_pic_desc *pic, c
     return mpeghip_video_submit(v, &p, 1, mbs, n_mbs, words, n_words * 4);
 }
 
+// ---- the device-packed stage (include/mpeghip.h: mpeghip_video_stage_begin_device): the host copies, the device packs
+static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int mpeghip_video_stage_begin_device_impl(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words,
+                                                 mpeghip_stage **out)
+{
+    if (!v || !out || (n_pics && (!n_mbs || !n_words)))
+        return fail(MPEGHIP_ERR_INVALID, "stage_begin: NULL argument");
+    if (v->stage)
+        return fail(MPEGHIP_ERR_INVALID, "stage_begin: the previous stage is still open");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    std::unique_ptr<mpeghip_stage> s(new mpeghip_stage);
+    s->v = v;
+    s->device = true;
+    s->n_pics = n_pics;
+    s->mb_first.resize(n_pics);
+    s->mb_count.assign(n_mbs, n_mbs + n_pics);
+    s->chunk_first.resize(n_pics);
+    s->word_first.resize(n_pics);
+    s->units.resize(n_pics);
+    s->use.assign(n_pics, PicUse());
+    s->done.reset(new std::atomic<uint8_t>[n_pics ? n_pics : 1]);
+    for (uint32_t i = 0; i < n_pics; i++)
+        s->done[i].store(0);
+    uint64_t mbs = 0, chunks = 0, words = 0;
+    for (uint32_t i = 0; i < n_pics; i++) {
+        if (n_words[i] > 0x3fffffffu)
+            return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
+        s->mb_first[i] = (uint32_t)mbs;
+        s->chunk_first[i] = (uint32_t)chunks;
+        s->word_first[i] = (uint32_t)words;
+        s->units[i] = (uint64_t)n_words[i] * 4;
+        mbs += n_mbs[i];
+        chunks += rc_max_chunks(n_mbs[i]);
+        words += round_up(n_words[i], 16); // (a picture's words begin on a cache-line quarter: 64 bytes)
+        if (mbs > 0xffffffffull || words > 0xffffffffull - kRcWordsPad)
+            return fail(MPEGHIP_ERR_INVALID, "batch too large for 32-bit indices");
+    }
+    s->n_mbs = (uint32_t)mbs;
+    s->n_chunks = (uint32_t)chunks;
+    s->words_total = words;
+    mpeghip_video::Staging *sg = &v->staging[v->next_staging];
+    int rc = retire(sg);
+    if (rc != MPEGHIP_OK)
+        return rc;
+    // pinned: pictures | PkPic | dependency list | macroblocks | words, every region on a 64-byte boundary
+    s->a_at = round_up(sizeof(mpeghip_pic_desc) * (size_t)n_pics, 64);
+    s->d_at = round_up(s->a_at + sizeof(PkPic) * (size_t)n_pics, 64);
+    s->m_at = round_up(s->d_at + sizeof(PkDep) * (size_t)n_pics, 64);
+    s->in_at = round_up(s->m_at + sizeof(mpeghip_mb_desc) * (size_t)mbs, 64);
+    if ((rc = grow_pinned(sg, s->in_at + (size_t)words * 4 + 64)) != MPEGHIP_OK)
+        return rc;
+    if (!sg->done)
+        HIP_TRY(hipEventCreateWithFlags(&sg->done, hipEventDisableTiming));
+    PkPic *aux = reinterpret_cast<PkPic *>(sg->h + s->a_at);
+    for (uint32_t i = 0; i < n_pics; i++)
+        aux[i] = PkPic{s->word_first[i], (uint32_t)n_words[i], s->chunk_first[i], 0u};
+    s->sg = sg;
+    v->stage = s.get();
+    *out = s.release();
+    return MPEGHIP_OK;
+}
+
+// picture i of a device-packed stage: its descriptor goes into the staging buffer; its arrays are copied there (copy) or
+// are there already (the caller wrote them through mpeghip_video_stage_map)
+static int stage_put_device(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, const void *words,
+                            bool copy)
+{
+    int rc = MPEGHIP_OK;
+    do {
+        if (i >= s->n_pics) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u of %u", i, s->n_pics);
+            break;
+        }
+        if (!(pic->flags & MPEGHIP_PIC_SPARSE)) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: a device-packed stage takes pictures in the sparse form only "
+                      "(mpeghip_video_stage_put_sparse)", i);
+            break;
+        }
+        const uint32_t n = s->mb_count[i];
+        if (copy && ((n && !mbs) || (s->units[i] && !words))) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u: NULL array", i);
+            break;
+        }
+        uint8_t fresh = 0;
+        if (!s->done[i].compare_exchange_strong(fresh, 1)) {
+            rc = fail(MPEGHIP_ERR_INVALID, "stage_put: picture %u was already put", i);
+            break;
+        }
+        if ((rc = validate_pic(s->v->info, *pic, i)) != MPEGHIP_OK)
+            break;
+        uint8_t *h = s->sg->h;
+        mpeghip_pic_desc pd = *pic;
+        pd.mb_first = s->mb_first[i];
+        pd.mb_count = n;
+        reinterpret_cast<mpeghip_pic_desc *>(h)[i] = pd;
+        if (copy) {
+            memcpy(h + s->m_at + (size_t)s->mb_first[i] * sizeof(mpeghip_mb_desc), mbs, (size_t)n * sizeof(mpeghip_mb_desc));
+            memcpy(h + s->in_at + (size_t)s->word_first[i] * 4, words, (size_t)s->units[i]);
+        }
+        s->done[i].store(2);
+    } while (0);
+    if (rc != MPEGHIP_OK) {
+        std::lock_guard<std::mutex> l(s->error_lock);
+        if (s->error.load() == MPEGHIP_OK) {
+            s->error_text = mpeghip_last_error();
+            s->error.store(rc);
+        }
+    }
+    return rc;
+}
+
+// the commit of a device-packed stage: one copy of the staged arrays, pack_kernel, pack_gate_kernel, the reconstruction
+static int stage_commit_device(mpeghip_stage *s)
+{
+    mpeghip_video *v = s->v;
+    mpeghip_video::Staging *sg = s->sg;
+    mpeghip_batch *b = &sg->batch;
+    const mpeghip_video_info &in = v->info;
+    const mpeghip_pic_desc *pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->h);
+    // Pictures of one stream inside one commit run concurrently (check_dependencies): two that write the same slot are
+    // refused here; one that READS a slot another one writes only if a macroblock really predicts from it — which the device
+    // learns while packing: the candidates go along as a list
+    PkDep *deps = reinterpret_cast<PkDep *>(sg->h + s->d_at);
+    uint32_t n_deps = 0;
+    if (s->n_pics > 1) {
+        std::vector<uint32_t> order(s->n_pics);
+        for (uint32_t p = 0; p < s->n_pics; p++)
+            order[p] = p;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            return pics[x].stream != pics[y].stream ? pics[x].stream < pics[y].stream : x < y;
+        });
+        for (uint32_t i = 0; i < s->n_pics;) {
+            uint32_t j = i + 1;
+            while (j < s->n_pics && pics[order[j]].stream == pics[order[i]].stream)
+                j++;
+            for (uint32_t y = i; y < j && j - i > 1; y++) {
+                const mpeghip_pic_desc &r = pics[order[y]];
+                uint32_t mask = 0;
+                for (uint32_t x = i; x < j; x++) {
+                    if (x == y)
+                        continue;
+                    const mpeghip_pic_desc &w = pics[order[x]];
+                    if (x < y && w.cur == r.cur)
+                        return fail(MPEGHIP_ERR_INVALID, "pictures %u and %u of stream %u depend on each other (slot %u): they need "
+                                    "separate submits", order[x], order[y], w.stream, w.cur);
+                    mask |= (r.fwd == w.cur ? 1u : 0u) | (r.bwd == w.cur ? 2u : 0u);
+                }
+                if (mask)
+                    deps[n_deps++] = PkDep{order[y], mask};
+            }
+            i = j;
+        }
+    }
+    int rc;
+    b->any_rgba = wants_rgba(pics, s->n_pics);
+    if (b->any_rgba && (rc = ensure_rgba(v)) != MPEGHIP_OK)
+        return rc;
+    const size_t raw_total = s->in_at + (size_t)s->words_total * 4;
+    const size_t c_bytes = round_up((size_t)s->n_chunks * kRcChunkDwords * 4, 64);
+    const uint32_t seen_stride = (in.mb_w * in.mb_h + 31) / 32;
+    if ((rc = grow((void **)&sg->d_raw, &sg->cap_raw, raw_total + 64)) != 0 ||
+        (rc = grow((void **)&b->d_blob, &b->cap_blob, c_bytes + ((size_t)s->words_total + kRcWordsPad) * 4)) != 0 ||
+        (rc = grow((void **)&sg->d_seen, &sg->cap_seen, (size_t)s->n_pics * seen_stride * 4)) != 0)
+        return rc;
+    if (!sg->d_err)
+        HIP_TRY(hipMalloc((void **)&sg->d_err, 8));
+    if (!sg->h_verdict)
+        HIP_TRY(hipHostMalloc((void **)&sg->h_verdict, 64, hipHostMallocDefault));
+    *sg->h_verdict = kPkNoError;
+    hipStream_t st = v->ctx->stream;
+    {
+        const size_t piece = (size_t)64 << 20; // (in pieces: mpeghip_video_stage_commit_impl)
+        for (size_t at = 0; at < raw_total; at += piece)
+            HIP_TRY(hipMemcpyAsync(sg->d_raw + at, sg->h + at, raw_total - at < piece ? raw_total - at : piece, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemsetAsync(sg->d_seen, 0, (size_t)s->n_pics * seen_stride * 4, st));
+    HIP_TRY(hipMemsetAsync(sg->d_err, 0xff, 8, st));
+    PackArgs a;
+    a.pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->d_raw);
+    a.aux = reinterpret_cast<PkPic *>(sg->d_raw + s->a_at);
+    a.mbs = reinterpret_cast<const mpeghip_mb_desc *>(sg->d_raw + s->m_at);
+    a.words_in = reinterpret_cast<const uint32_t *>(sg->d_raw + s->in_at);
+    a.chunks = reinterpret_cast<uint32_t *>(b->d_blob);
+    a.words_out = reinterpret_cast<uint32_t *>(b->d_blob + c_bytes);
+    a.seen = sg->d_seen;
+    a.err = sg->d_err;
+    a.n_pics = s->n_pics;
+    uint32_t most = 1;
+    for (uint32_t i = 0; i < s->n_pics; i++)
+        most = s->mb_count[i] > most ? s->mb_count[i] : most;
+    a.groups_per_pic = (most + 63) / 64;
+    a.seen_stride = seen_stride;
+    a.mb_w = in.mb_w;
+    a.mb_h = in.mb_h;
+    a.luma_w = in.luma_w;
+    a.chroma_w = in.chroma_w;
+    a.luma_bytes = (uint32_t)in.luma_bytes;
+    a.chroma_bytes = (uint32_t)in.chroma_bytes;
+    a.frame_bytes = in.frame_bytes;
+    a.frame_stride = in.frame_stride;
+    a.rgba_stride = rgba_stride_of(v);
+    if ((uint64_t)s->n_pics * a.groups_per_pic > 0x7fffffffull)
+        return fail(MPEGHIP_ERR_INVALID, "batch too large for one launch");
+    hipLaunchKernelGGL(pack_kernel, dim3(s->n_pics * a.groups_per_pic), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(pack_gate_kernel, dim3((s->n_chunks + 255) / 256), dim3(256), 0, st, sg->d_err, a.aux, a.pics,
+                       reinterpret_cast<const PkDep *>(sg->d_raw + s->d_at), n_deps, a.chunks, s->n_chunks, sg->h_verdict);
+    HIP_TRY(hipGetLastError());
+    fill_notes(v, b, pics, s->n_pics);
+    b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(sg->d_raw);
+    b->d_chunks = a.chunks;
+    b->d_words = a.words_out;
+    // which instance of the reconstruction kernel: the host has not looked at the blocks; their words tell (a dense unit
+    // arrives as more than 32 pairs, a typical macroblock as about 16 dwords: kDenseWordsPerMb lies between the two)
+    uint64_t words_in = 0;
+    for (uint32_t i = 0; i < s->n_pics; i++)
+        words_in += s->units[i] / 4;
+    b->coded_blocks = 1;
+    b->dense_blocks = words_in > kDenseWordsPerMb * (uint64_t)s->n_mbs ? 1 : 0;
+    b->alg_bytes = 0; // (not totalled: nobody has read the macroblocks on the host)
+    b->device_bytes = raw_total;
+    b->replicas = 1;
+    b->n_pics = s->n_pics;
+    b->n_mbs = s->n_mbs;
+    b->n_chunks = s->n_chunks;
+    v->next_staging ^= 1;
+    if ((rc = launch_batch(v, b)) != MPEGHIP_OK)
+        return rc;
+    HIP_TRY(hipEventRecord(sg->done, st));
+    sg->in_flight = true;
+    sg->packed_on_device = true;
+    sg->pk_mb_first = s->mb_first;
+    return MPEGHIP_OK;
+}
+
 static int mpeghip_video_stage_commit_impl(mpeghip_stage *sp)
 {
     if (!sp)
@@ -1703,6 +2094,8 @@ static int mpeghip_video_stage_commit_impl(mpeghip_stage *sp)
     if (s->n_mbs == 0)
         return MPEGHIP_OK;
     HIP_TRY(hipSetDevice(v->ctx->device));
+    if (s->device)
+        return stage_commit_device(s.get());
     mpeghip_video::Staging *sg = s->sg;
     mpeghip_batch *b = &sg->batch;
     const mpeghip_pic_desc *pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->h);
@@ -1750,6 +2143,46 @@ static int mpeghip_video_stage_commit_impl(mpeghip_stage *sp)
 int mpeghip_video_stage_commit(mpeghip_stage *sp)
 {
     return no_throw([&] { return mpeghip_video_stage_commit_impl(sp); });
+}
+
+int mpeghip_video_stage_begin_device(mpeghip_video *v, uint32_t n_pics, const uint32_t *n_mbs, const size_t *n_words, mpeghip_stage **out)
+{
+    return no_throw([&] { return mpeghip_video_stage_begin_device_impl(v, n_pics, n_mbs, n_words, out); });
+}
+
+int mpeghip_video_stage_map(mpeghip_stage *s, uint32_t i, mpeghip_mb_desc **mbs, uint32_t **words)
+{
+    if (!s || !mbs || !words)
+        return fail(MPEGHIP_ERR_INVALID, "stage_map: NULL argument");
+    if (!s->device)
+        return fail(MPEGHIP_ERR_INVALID, "stage_map: not a device-packed stage (mpeghip_video_stage_begin_device)");
+    if (i >= s->n_pics)
+        return fail(MPEGHIP_ERR_INVALID, "stage_map: picture %u of %u", i, s->n_pics);
+    *mbs = reinterpret_cast<mpeghip_mb_desc *>(s->sg->h + s->m_at) + s->mb_first[i];
+    *words = reinterpret_cast<uint32_t *>(s->sg->h + s->in_at) + s->word_first[i];
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_stage_put_mapped(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic)
+{
+    if (!s || !pic)
+        return fail(MPEGHIP_ERR_INVALID, "stage_put: NULL argument");
+    if (!s->device)
+        return fail(MPEGHIP_ERR_INVALID, "stage_put_mapped: not a device-packed stage (mpeghip_video_stage_begin_device)");
+    mpeghip_pic_desc p = *pic;
+    p.flags |= MPEGHIP_PIC_SPARSE;
+    return no_throw([&] { return stage_put_device(s, i, &p, nullptr, nullptr, false); });
+}
+
+int mpeghip_video_sync(mpeghip_video *v)
+{
+    if (!v)
+        return fail(MPEGHIP_ERR_INVALID, "video is NULL");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    for (auto &sg : v->staging)
+        sg.in_flight = false;
+    return reap_all(v);
 }
 
 static int mpeghip_video_batch_upload_replicated_impl(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,
@@ -1884,6 +2317,8 @@ int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(v->bounce, v->d_linear, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = reap_all(v)) != MPEGHIP_OK) // a device-packed commit that was refused: the caller learns it here at the latest
+        return rc;
     if (y)
         memcpy(y, v->bounce, v->info.luma_bytes);
     if (cb)
@@ -1953,6 +2388,9 @@ int mpeghip_video_hash_slots(mpeghip_video *v, uint32_t slot, uint64_t *out)
                        v->info.n_streams, v->d_hash);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    const int verdict = reap_all(v);
+    if (verdict != MPEGHIP_OK)
+        return verdict;
     HIP_TRY(hipMemcpy(out, v->d_hash, (size_t)v->info.n_streams * 8, hipMemcpyDeviceToHost));
     return MPEGHIP_OK;
 }
@@ -1997,6 +2435,8 @@ int mpeghip_video_read_rgba(mpeghip_video *v, uint32_t stream, uint32_t slot, ui
     if (rc != MPEGHIP_OK)
         return rc;
     HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+    if ((rc = reap_all(v)) != MPEGHIP_OK)
+        return rc;
     HIP_TRY(hipMemcpy(dst, v->d_rgba + ((uint64_t)stream * MPEGHIP_SLOTS + slot) * rgba_stride_of(v), v->info.rgba_bytes,
                       hipMemcpyDeviceToHost));
     return MPEGHIP_OK;

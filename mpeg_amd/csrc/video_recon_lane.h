@@ -229,10 +229,10 @@ struct RcPacked {
 
 // ---- the sparse hand-over (mpeghip_video_stage_put_sparse): the coded blocks' data as the reference's VLC loop
 // produces it (video.go:680-745) — per sparse block a count word n and n PAIRS `level << 16 | position << 2` (an intra
-// block's first pair is its DC, position 0), per snapshot block 64 int32 values; mbs[k].coef_off = dword index of
-// macroblock k's first word.  A pair IS a device entry short of the bits the packer adds (quantiser_scale, slot, class).
-// The packer checks a picture's words as it walks them (RcPacked::bad): every block inside [0, n_words), counts <= 64, no bit
-// outside a pair's two fields, an intra block's DC first.  (A position named twice in one block is not looked for: the
+// block's first pair is its DC, position 0), per snapshot block the count word 64 and its 64 int32 values; mbs[k].coef_off =
+// dword index of macroblock k's first word, never before the end of macroblock k - 1's data.  A pair IS a device entry short of the bits the packer adds (quantiser_scale, slot, class).
+// The packer checks a picture's words as it walks them (RcPacked::bad): every block inside [0, n_words), macroblocks in order
+// and not overlapping, counts <= 64 (= 64 for a snapshot block), no bit outside a pair's two fields, an intra block's DC first.  (A position named twice in one block is not looked for: the
 // parser cannot produce it, and the block's result is then merely unspecified — one of the two levels wins.)
 // Pairs -> entries: out[i] = pr[i] | bits for i < cnt; returns the OR of the pairs (their stray bits, if any).  The store may
 // run up to 15 dwords past out + cnt (the words buffer has the slack); nothing is read past pr + cnt.
@@ -261,8 +261,9 @@ static inline uint32_t rc_pairs_to_entries(const uint32_t *pr, uint32_t cnt, uin
     return acc;
 }
 // room the packed form of a sparse picture can need (dwords): its input words (an entry per pair, a block word per count
-// word, a unit where it is the shorter form) + a block word per snapshot block + the slack wide stores run into
-static inline size_t rc_max_words_sparse(uint64_t n_words, uint32_t n_mbs) { return (size_t)n_words + (size_t)n_mbs * 6 + 64; }
+// word, a unit where it is the shorter form: blocks do not share words, so no more than came in) + the slack wide stores
+// run into
+static inline size_t rc_max_words_sparse(uint64_t n_words, uint32_t n_mbs) { (void)n_mbs; return (size_t)n_words + 64; }
 
 // Pack ONE picture: macroblocks mbs[0..n) (already validated), whose coef_off index 128-byte units behind
 // `coefs` (kSparseIn: the n_sparse dwords of the sparse hand-over behind `coefs`, checked on the way: RcPacked::bad).  Chunk headers name
@@ -271,12 +272,17 @@ static inline size_t rc_max_words_sparse(uint64_t n_words, uint32_t n_mbs) { ret
 template <bool kWide = true, bool kSparseIn = false> // kWide: use the 512-bit forms where the CPU has them (tests compare both)
 static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &p, const mpeghip_mb_desc *mbs, uint32_t n,
                                        const uint8_t *coefs, uint32_t word_base, uint32_t *chunks_out, uint32_t *words_out,
-                                       uint64_t n_sparse = 0)
+                                       uint64_t n_sparse = 0, uint64_t out_room = ~0ull >> 1)
 {
+    // out_room (kSparseIn): dwords of room behind words_out.  One picture's packed form is never longer than its input (its
+    // macroblocks do not share words), but the pictures of one submit may name the same words: the room is checked block by
+    // block and a picture that would not fit is refused (RcPacked::bad) instead of overrunning the buffer.
     RcPacked out;
     const uint32_t *sparse = reinterpret_cast<const uint32_t *>(coefs);
+    uint64_t sparse_end = 0; // kSparseIn: where the previous macroblock's data ended (dwords)
     (void)sparse;
     (void)n_sparse;
+    (void)sparse_end;
 #if MPG_HOST_AVX512
     const bool wide = kWide && rc_host_has_avx512();
 #endif
@@ -298,8 +304,12 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             uint32_t slot, dwords;
         } deferred[kRcMaxBlocks];
         alignas(16) int16_t built[kSparseIn ? kRcMaxBlocks : 1][64]; // kSparseIn: units made of a block's pairs
-        uint32_t n_slots = 0, n_deferred = 0;
+        uint32_t n_slots = 0, n_deferred = 0, deferred_dwords = 0;
         uint32_t *bw = words_out + out.words;
+        if (kSparseIn && (uint64_t)out.words + n_coded + 16 > out_room) {
+            out.bad = k0 + 1;
+            return out;
+        }
         uint32_t *e0 = bw + n_coded, ne = 0, counts = 0, pass_start = 0;
         bool any_raw = false, any_dense = false, any_dcword = false;
         bool run = live == (uint32_t)kRcMbs; // 4 consecutive macroblocks of one row = 4 consecutive tiles
@@ -344,6 +354,15 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
                   (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
             uint64_t unit = mb.coef_off;
+            if (kSparseIn) { // a macroblock's data begins where the previous one's ended, or later (every macroblock's coef_off
+                             // takes part, coded blocks or not): no two blocks share words, so what is packed is never longer
+                             // than what came in, and the device-side packer (video_pack_lane.h) places a chunk's words by the
+                             // offset of its first macroblock
+                if (unit < sparse_end || unit > n_sparse) {
+                    out.bad = k0 + m + 1;
+                    return out;
+                }
+            }
             for (uint32_t left = mb.cbp & 0x3fu; left; ) { // coded blocks in block order = from bit 5 down (one exit branch)
                 const int b = __builtin_clz(left) - 26;
                 left &= ~(0x20u >> b);
@@ -356,19 +375,25 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 bw[s] = (rc_tile_offset(b, 0, m) >> 3) | (b >= 4 ? kBChroma : 0u) | (raw ? kBRaw : 0u);
                 if (kSparseIn) { // (`unit` counts dwords here, and may run to 2^32 + 64 on malformed input: 64 bits)
                     const uint32_t *sp = sparse + unit;
-                    if (raw) {
-                        if (unit + 64 > n_sparse) {
+                    if (raw) { // a snapshot block: the count word says 64, then its 64 int32 values
+                        if (unit + 65 > n_sparse || sp[0] != 64) {
                             out.bad = k0 + m + 1;
                             return out;
                         }
                         any_raw = true;
-                        deferred[n_deferred++] = Deferred{reinterpret_cast<const uint8_t *>(sp), s, 64};
-                        unit += 64;
+                        deferred[n_deferred++] = Deferred{reinterpret_cast<const uint8_t *>(sp + 1), s, 64};
+                        deferred_dwords += 64;
+                        unit += 65;
+                        if ((uint64_t)out.words + n_coded + ne + deferred_dwords + 16 > out_room) {
+                            out.bad = k0 + m + 1;
+                            return out;
+                        }
                         continue;
                     }
                     uint32_t cnt = unit < n_sparse ? sp[0] : 65;
                     const uint32_t *pr = sp + 1;
-                    if (cnt > 64 || unit + 1 + cnt > n_sparse || (intra && (cnt == 0 || (pr[0] & 0xfcu)))) {
+                    if (cnt > 64 || unit + 1 + cnt > n_sparse || (intra && (cnt == 0 || (pr[0] & 0xfcu))) ||
+                        (uint64_t)out.words + n_coded + ne + deferred_dwords + cnt + 16 > out_room) {
                         out.bad = k0 + m + 1;
                         return out;
                     }
@@ -396,6 +421,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                         out.dense_blocks++;
                         bw[s] |= kBDense | ((uint32_t)(mb.qscale & 31) << 26) | (intra ? 0u : 1u << 31);
                         deferred[n_deferred++] = Deferred{reinterpret_cast<const uint8_t *>(bu), s, 32};
+                        deferred_dwords += 32;
                         continue;
                     }
                     stray = 0;
@@ -460,6 +486,8 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                     e0[ne++] = ((uint32_t)w << 16) | bits | (pos << 2);
                 }
             }
+            if (kSparseIn)
+                sparse_end = unit;
         }
         if (n_slots)
             counts |= (ne - pass_start) << (10 * ((n_slots - 1) >> 3));

@@ -83,7 +83,7 @@ class SlotRotation:
 def to_sparse(mbs, coefs, keep_zero_dc: bool = True):
     """The same picture in the SPARSE hand-over form (include/mpeghip.h: mpeghip_video_stage_put_sparse): per coded block
     a count word and one pair word `level << 16 | position << 2` per non-zero level of its unit (position order; an intra
-    block's DC first, present even when 0), per snapshot block its 64 int32 values.  -> (mbs with coef_off in dwords, words)"""
+    block's DC first, present even when 0), per snapshot block the count word 64 and its 64 int32 values.  -> (mbs with coef_off in dwords, words)"""
     mbs = np.array(mbs, dtype=MB_DTYPE, copy=True)
     raw_bytes = np.ascontiguousarray(coefs).view(np.uint8).reshape(-1)
     units16 = raw_bytes.view(np.int16).reshape(-1, 64) if raw_bytes.size else np.zeros((0, 64), np.int16)
@@ -98,9 +98,9 @@ def to_sparse(mbs, coefs, keep_zero_dc: bool = True):
         intra, raw = bool(mb["flags"] & MB_INTRA), bool(mb["flags"] & MB_COEF_RAW)
         for _ in range(nb):
             if raw:
-                out.append(units32[unit:unit + 2].reshape(-1).view(np.uint32))
+                out.append(np.concatenate([[np.uint32(64)], units32[unit:unit + 2].reshape(-1).view(np.uint32)]).astype(np.uint32))
                 unit += 2
-                at += 64
+                at += 65
                 continue
             u = units16[unit]
             unit += 1

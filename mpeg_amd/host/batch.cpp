@@ -168,10 +168,15 @@ public:
     {
         for (unsigned i = 1; i < n; i++)
             workers_.emplace_back([this, numa_node] {
-                pinThisThreadToNode(numa_node); // (-1: stays where the scheduler puts it)
+                if (numa_node >= 0) { // (-1: stays where the scheduler puts it)
+                    pins_asked_++;
+                    if (!pinThisThreadToNode(numa_node))
+                        pins_failed_++;
+                }
                 work();
             });
     }
+    std::atomic<unsigned> pins_asked_{0}, pins_failed_{0};
     ~Pool()
     {
         {
@@ -282,6 +287,12 @@ void VideoBatch::SetNumaNode(int node)
         pool_.reset();
         pool_.reset(new Pool(threads_, numa_node_));
     }
+}
+
+void VideoBatch::NumaPins(unsigned out[2]) const
+{
+    out[0] = pool_ ? pool_->pins_asked_.load() : 0;
+    out[1] = pool_ ? pool_->pins_failed_.load() : 0;
 }
 
 void VideoBatch::openStore(int width, int height)
@@ -425,8 +436,11 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                             n_mbs[g] = (uint32_t)group[g0 + g]->mbs.size();
                             bytes[g] = group[g0 + g]->coefs.size();
                         }
+                        bool all_sparse = true;
+                        for (size_t g = 0; g < gn; g++)
+                            all_sparse = all_sparse && (group[g0 + g]->pic.flags & MPEGHIP_PIC_SPARSE) != 0;
                         const double s0 = nowSeconds();
-                        store_->stageBegin(n_mbs, bytes);
+                        store_->stageBegin(n_mbs, bytes, device_pack_ && all_sparse);
                         const double s1 = nowSeconds();
                         t_begin_ += s1 - s0;
                         std::exception_ptr put_failed;

@@ -389,6 +389,21 @@ void mpeghost_batch_counters(void *hv, uint64_t out[2])
 }
 
 void mpeghost_batch_phase_seconds(void *hv, double out[4]) { static_cast<BatchHandle *>(hv)->batch->PhaseSeconds(out); }
+void mpeghost_batch_set_device_pack(void *hv, int on) { static_cast<BatchHandle *>(hv)->batch->SetDevicePack(on != 0); }
+int mpeghost_batch_sync(void *hv)
+{
+    return guard([&]() -> int {
+        static_cast<BatchHandle *>(hv)->batch->Sync();
+        return 0;
+    }, -1);
+}
+void mpeghost_batch_numa_pins(void *hv, uint32_t out[2])
+{
+    unsigned p[2];
+    static_cast<BatchHandle *>(hv)->batch->NumaPins(p);
+    out[0] = p[0];
+    out[1] = p[1];
+}
 
 // ShardedVideoBatch: streams sharded over several devices (stream s -> device s mod G), one host thread per device
 void *mpeghost_sharded_open(void *const *devices, uint32_t n_devices, uint32_t n_streams)

@@ -88,8 +88,16 @@ public:
         check(mpeghip_video_read_rgba(store_, stream, slot, dst), "mpeghip_video_read_rgba");
     }
     bool canStage() const override { return true; }
-    void stageBegin(const std::vector<uint32_t> &n_mbs, const std::vector<size_t> &coef_bytes) override
+    void stageBegin(const std::vector<uint32_t> &n_mbs, const std::vector<size_t> &coef_bytes, bool device_pack) override
     {
+        if (device_pack) { // sparse pictures all: the arrays travel as they are, the device validates and packs them
+            std::vector<size_t> n_words(coef_bytes.size());
+            for (size_t i = 0; i < coef_bytes.size(); i++)
+                n_words[i] = coef_bytes[i] / 4;
+            check(mpeghip_video_stage_begin_device(store_, (uint32_t)n_mbs.size(), n_mbs.data(), n_words.data(), &stage_),
+                  "mpeghip_video_stage_begin_device");
+            return;
+        }
         check(mpeghip_video_stage_begin(store_, (uint32_t)n_mbs.size(), n_mbs.data(), coef_bytes.data(), &stage_),
               "mpeghip_video_stage_begin");
     }
@@ -103,6 +111,7 @@ public:
         stage_ = nullptr; // the commit ends the stage whatever it returns
         check(mpeghip_video_stage_commit(s), "mpeghip_video_stage_commit");
     }
+    void sync() override { check(mpeghip_video_sync(store_), "mpeghip_video_sync"); }
 
 private:
     mpeghip_ctx *ctx_;
@@ -159,6 +168,9 @@ private:
 
 Device::Device(int ordinal)
 {
+    if (mpeghip_abi_version() != MPEGHIP_ABI_VERSION) // (the header this library was built against vs the libmpeghip.so it found)
+        throw std::runtime_error("mpeg::Device: libmpeghip has ABI version " + std::to_string(mpeghip_abi_version()) + ", built for " +
+                                 std::to_string(MPEGHIP_ABI_VERSION));
     if (mpeghip_ctx_create(ordinal, nullptr, &ctx_) != MPEGHIP_OK)
         throw std::runtime_error(std::string("mpeg::Device: ") + mpeghip_last_error());
 }

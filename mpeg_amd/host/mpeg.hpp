@@ -207,10 +207,13 @@ public:
     // One submit assembled picture by picture (mpeghip_video_stage_*): stagePut may be called from several
     // threads for distinct i; each picture brings its own arrays (coef_off relative to its coefs, pic.stream
     // set).  Stores without it return false from canStage() and get one merged submit() instead.
+    // device_pack: every picture of the stage is in the sparse form and the store may have the DEVICE validate and pack them
+    // (mpeghip_video_stage_begin_device: the puts only copy; errors are deferred to the next sync()).
     virtual bool canStage() const { return false; }
-    virtual void stageBegin(const std::vector<uint32_t> &, const std::vector<size_t> &) {}
+    virtual void stageBegin(const std::vector<uint32_t> &, const std::vector<size_t> &, bool device_pack = false) { (void)device_pack; }
     virtual void stagePut(uint32_t, const mpeghip_pic_desc &, const mpeghip_mb_desc *, const uint8_t *) {}
     virtual void stageCommit() {}
+    virtual void sync() {}                          // wait for queued work; throws a device-packed commit's deferred error
 };
 
 class AudioBackend {
@@ -263,8 +266,9 @@ public:
     // The form the parser hands pictures over in (include/mpeghip.h): SPARSE — its own (position, level) pairs, as the
     // reference's VLC loop produces them (video.go:680-745), MPEGHIP_PIC_SPARSE — or 128-byte UNITS of int16 levels.
     // Sparse is the product's form; units remain for callers of the unit ABI and for tests that compare the two.
-    void SetSparse(bool v) { sparse_ = v; }
-    bool Sparse() const { return sparse_; }
+    // Takes effect at the next picture: the form is latched when a picture begins (its offsets count units or dwords).
+    void SetSparse(bool v) { sparse_wanted_ = v; }
+    bool Sparse() const { return sparse_wanted_; }
     static void SetDefaultSparse(bool v); // the form of decoders created from now on (process-wide; sparse unless told otherwise)
     // test hook: every VLC table of the parser against a walk over its code list, for every possible look at the stream
     // (all 2^L prefixes of the table's longest code).  Returns the number of prefixes that decode differently (0).
@@ -329,7 +333,8 @@ private:
     // persistent blockData (video.go:101): only ever non-zero after an invalid block
     int32_t block_data_[64];
     bool block_dirty_ = false;
-    bool sparse_;
+    bool sparse_;          // the form of the picture being recorded
+    bool sparse_wanted_;   // ... of the next one (SetSparse)
 
     // per-picture recording
     std::vector<mpeghip_mb_desc> mbs_;
@@ -375,8 +380,18 @@ public:
     unsigned Threads() const { return threads_; }
     // Bind the parse threads (started by SetThreads) to the cores of a host NUMA node — the one the batch's GPU is attached
     // to (Device::NumaNode): on a two-socket node every device is fed from its own socket.  -1: leave them alone (default).
+    // Call it while no DecodeAll is running (it restarts the pool).  The calling thread of DecodeAll parses too and is NOT
+    // bound by this (it is the application's thread: ShardedVideoBatch binds its own shard threads).
     void SetNumaNode(int node);
     int NumaNode() const { return numa_node_; }
+    // threads of this batch that asked to be bound to the node / whose binding failed (no such node, sched_setaffinity refused)
+    void NumaPins(unsigned out[2]) const;
+    // Staged submits of sparse pictures are validated and packed ON THE DEVICE (mpeghip_video_stage_begin_device; default) or
+    // by the pool's threads on the host.  Device-packed: a malformed picture is reported by Sync() / the next fetch, not by
+    // the DecodeAll that sent it (the product's parser does not emit malformed pictures).
+    void SetDevicePack(bool on) { device_pack_ = on; }
+    bool DevicePack() const { return device_pack_; }
+    void Sync() { store_->sync(); }
     void Flush();                                  // submit whatever is queued
     uint64_t DeviceSubmits() const { return device_submits_; }
     uint64_t QueuedPictures() const { return queued_pictures_; }
@@ -402,6 +417,7 @@ private:
     std::vector<mpeghip_mb_desc> mbs_;
     std::vector<uint8_t> coefs_;
     bool any_sparse_queued_ = false;
+    bool device_pack_ = true;
     std::vector<uint8_t> pending_;                 // stream already has a picture in the open batch
     uint64_t device_submits_ = 0, queued_pictures_ = 0;
     double t_parse_ = 0, t_put_ = 0, t_commit_ = 0, t_begin_ = 0; // wall time per phase (PhaseSeconds)

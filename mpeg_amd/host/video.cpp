@@ -122,7 +122,7 @@ Video::Video(Buffer *buf, std::unique_ptr<VideoBackend> backend) : buf_(buf), ba
 
 void Video::init()
 { // video.go:110-121
-    sparse_ = g_default_sparse.load();
+    sparse_ = sparse_wanted_ = g_default_sparse.load();
     memset(block_data_, 0, sizeof(block_data_));
     memset(intra_quant_, 0, sizeof(intra_quant_));
     memset(non_intra_quant_, 0, sizeof(non_intra_quant_));
@@ -329,6 +329,7 @@ void Video::decodePicture()
     mbs_.clear();
     coefs_.clear();
     std::fill(written_.begin(), written_.end(), 0);
+    sparse_ = sparse_wanted_; // the hand-over form is latched per picture: its offsets count either units or dwords
 
     do {
         start_code_ = buf_->nextStartCode();
@@ -487,7 +488,13 @@ void Video::endMacroblockRecord()
                 if (rec_.intra)
                     snap[0] = (int32_t)br.q[0] * 256;
             }
-            const size_t at = coefs_.size();
+            size_t at = coefs_.size();
+            if (sparse_) { // every block of the sparse form begins with its count word: 64 for a snapshot
+                coefs_.resize(at + 4);
+                const uint32_t n = 64;
+                memcpy(coefs_.data() + at, &n, 4);
+                at += 4;
+            }
             coefs_.resize(at + 2 * MPEGHIP_COEF_UNIT);
             int32_t *dst = reinterpret_cast<int32_t *>(coefs_.data() + at);
             for (int r = 0; r < 8; r++)

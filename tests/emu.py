@@ -60,6 +60,12 @@ def lib():
         for f in (L.emu_pack, L.emu_pack_narrow):
             f.restype = C.c_uint32
             f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, P, P, P]
+        L.emu_set_device_pack.restype = None
+        L.emu_set_device_pack.argtypes = [C.c_int]
+        L.emu_pack_sparse.restype = C.c_uint32
+        L.emu_pack_sparse.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, C.c_uint64, P, P, P, C.c_uint64]
+        L.emu_pack_device_picture.restype = C.c_uint64
+        L.emu_pack_device_picture.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, C.c_uint32, C.c_uint32, C.c_uint32, P, P, P, P, P]
         L.emu_host_has_avx512.restype = C.c_int
         L.emu_audio_slice_range.restype = None
         L.emu_audio_slice_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, P, P]
@@ -83,6 +89,47 @@ def set_tile_policy(policy=0):
     """Which instance of the reconstruction kernel the emulator runs (mpeghip_video_set_tile_policy): 0 = the library's
     per-batch rule, 1 = int16 coefficient tile, 2 = int32 tile."""
     lib().emu_set_tile_policy(policy)
+
+
+def set_device_pack(on=0):
+    """1: sparse pictures go through the DEVICE packer's lane functions (video_pack_lane.h: what pack_kernel runs) instead of the
+    host packer."""
+    lib().emu_set_device_pack(int(on))
+
+
+def pack_sparse_host(g, stride, rgba_stride, pic, mbs, words, out_room=None):
+    """The host packer on one sparse picture -> (chunks [n, 24], words) or None if it refuses the picture."""
+    pic = np.ascontiguousarray(np.asarray(pic).reshape(1), desc.PIC_DTYPE)
+    mbs = np.ascontiguousarray(mbs, desc.MB_DTYPE)
+    words = np.ascontiguousarray(words, np.uint32)
+    n_chunks = (int(pic["mb_count"][0]) + 3) // 4
+    chunks = np.zeros((n_chunks + 1, 24), np.uint32)
+    out = np.full(len(words) + 64 + 16, 0xDEADBEEF, np.uint32)
+    nw = C.c_uint32(0)
+    room = len(words) + 64 if out_room is None else out_room
+    n = lib().emu_pack_sparse(g["luma_w"], g["luma_h"], stride, rgba_stride, _ptr(pic), _ptr(mbs), _ptr(words), len(words), _ptr(chunks),
+                              _ptr(out), C.byref(nw), room)
+    if n == 0xffffffff:
+        return None
+    assert n == n_chunks
+    return chunks[:n], out[:nw.value]
+
+
+def pack_sparse_device(g, stride, rgba_stride, pic, mbs, words, word_first=0, chunk_first=0):
+    """The device packer's lane functions on one sparse picture -> (error word, chunks [n, 24], words array as long as the input
+    + word_first, use bits)."""
+    pic = np.ascontiguousarray(np.asarray(pic).reshape(1), desc.PIC_DTYPE)
+    mbs = np.ascontiguousarray(mbs, desc.MB_DTYPE)
+    words = np.ascontiguousarray(words, np.uint32)
+    n_chunks = (int(pic["mb_count"][0]) + 3) // 4
+    chunks = np.zeros((chunk_first + n_chunks + 1, 24), np.uint32)
+    staged = np.concatenate([np.full(word_first, 0xABABABAB, np.uint32), words])
+    out = np.full(word_first + len(words) + 1, 0xDEADBEEF, np.uint32)
+    use = C.c_uint32(0)
+    err = lib().emu_pack_device_picture(g["luma_w"], g["luma_h"], stride, rgba_stride, _ptr(pic), word_first, len(words), chunk_first,
+                                        _ptr(mbs), _ptr(staged), _ptr(chunks), _ptr(out), C.byref(use))
+    assert out[-1] == 0xDEADBEEF and (chunks[-1] == 0).all(), "the packer wrote past its picture"
+    return err, chunks[chunk_first:chunk_first + n_chunks], out[:-1], use.value
 
 
 def _ptr(a):

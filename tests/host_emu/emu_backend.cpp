@@ -16,6 +16,7 @@
 extern "C" {
 int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *, uint32_t,
                   const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint64_t);
+void emu_set_device_pack(int);
 void emu_make_qtable(uint8_t *, const uint8_t *, const uint8_t *);
 void emu_rgba_convert(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
 void emu_relayout(uint8_t *, uint8_t *, uint32_t, uint32_t, int);
@@ -103,8 +104,10 @@ public:
     }
     // staged submit (the product's mpeghip_video_stage_*): pictures put from several threads into one merged submit
     bool canStage() const override { return true; }
-    void stageBegin(const std::vector<uint32_t> &n_mbs, const std::vector<size_t> &coef_bytes) override
+    void stageBegin(const std::vector<uint32_t> &n_mbs, const std::vector<size_t> &coef_bytes, bool device_pack) override
     {
+        device_pack_stages_ += device_pack ? 1 : 0;
+        st_device_pack_ = device_pack;
         const size_t n = n_mbs.size();
         st_first_.assign(n, 0);
         st_unit_.assign(n, 0);
@@ -142,8 +145,11 @@ public:
     {
         if (stage_puts_.load() != st_pics_.size())
             abort();
+        // a device-packed stage: the pictures go through the DEVICE packer's lane functions (video_pack_lane.h), wave by wave
+        emu_set_device_pack(st_device_pack_ ? 1 : 0);
         submit(st_pics_.data(), (uint32_t)st_pics_.size(), st_mbs_.data(), (uint32_t)st_mbs_.size(), st_coefs_.data(),
                st_coefs_.size());
+        emu_set_device_pack(0);
         staged_commits_++;
     }
     void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
@@ -171,8 +177,10 @@ private:
     std::vector<uint8_t> st_coefs_;
     std::atomic<size_t> stage_puts_{0};
 
+    bool st_device_pack_ = false;
+
 public:
-    uint64_t staged_commits_ = 0;
+    uint64_t staged_commits_ = 0, device_pack_stages_ = 0;
 };
 
 class EmuAudioBackend : public mpeg::AudioBackend {
@@ -252,6 +260,7 @@ public:
 void *host_emu_null_batch_store(void) { return new NullBatchStore(); }
 void *host_emu_batch_store(void) { return new EmuBatchStore(); }
 // staged submits the store has seen (valid while the batch that owns the store is open)
+uint64_t host_emu_batch_store_device_pack_stages(void *store) { return static_cast<EmuBatchStore *>(static_cast<mpeg::BatchStore *>(store))->device_pack_stages_; }
 uint64_t host_emu_batch_store_staged_commits(void *store) { return static_cast<EmuBatchStore *>(static_cast<mpeg::BatchStore *>(store))->staged_commits_; }
 void *host_emu_audio_batch_store(void) { return new EmuAudioBatchStore(g_window); }
 void *host_emu_make_audio(int fma) { return new EmuAudioBackend(fma, g_window); }

@@ -71,6 +71,8 @@ def host():
             "mpeghost_batch_frame": (C.c_int, [P, C.c_uint32, C.POINTER(HostFrame)]),
             "mpeghost_batch_counters": (None, [P, C.POINTER(C.c_uint64 * 2)]),
             "mpeghost_batch_phase_seconds": (None, [P, C.POINTER(C.c_double * 4)]),
+            "mpeghost_batch_set_device_pack": (None, [P, C.c_int]), "mpeghost_batch_sync": (C.c_int, [P]),
+            "mpeghost_batch_numa_pins": (None, [P, C.POINTER(C.c_uint32 * 2)]),
             "mpeghost_sharded_open": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
             "mpeghost_sharded_open_stores": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
             "mpeghost_sharded_close": (None, [P]), "mpeghost_sharded_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
@@ -123,6 +125,8 @@ def host_emu():
         L.host_emu_batch_store.argtypes = []
         L.host_emu_batch_store_staged_commits.restype = C.c_uint64
         L.host_emu_batch_store_staged_commits.argtypes = [C.c_void_p]
+        L.host_emu_batch_store_device_pack_stages.restype = C.c_uint64
+        L.host_emu_batch_store_device_pack_stages.argtypes = [C.c_void_p]
         L.host_emu_audio_batch_store.restype = C.c_void_p
         L.host_emu_audio_batch_store.argtypes = []
         L.host_emu_configure.restype = None
@@ -382,12 +386,21 @@ class HostBatch:
         f = HostFrame()
         return f if host().mpeghost_batch_frame(self.h, stream, C.byref(f)) == 1 else None
 
+    def set_device_pack(self, on: bool):
+        """Staged submits of sparse pictures validated and packed on the device (default) or on the host."""
+        host().mpeghost_batch_set_device_pack(self.h, int(on))
+
+    def sync(self):
+        if host().mpeghost_batch_sync(self.h) != 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+
     def counters(self):
         out = (C.c_uint64 * 2)()
         host().mpeghost_batch_counters(self.h, C.byref(out))
         c = {"device_submits": out[0], "queued_pictures": out[1]}
         if getattr(self, "emu_store", None):
             c["staged_commits"] = int(host_emu().host_emu_batch_store_staged_commits(self.emu_store))
+            c["device_pack_stages"] = int(host_emu().host_emu_batch_store_device_pack_stages(self.emu_store))
         return c
 
     def close(self):

@@ -16,6 +16,7 @@
 
 #include "audio_lane.h"
 #include "video_lane.h"
+#include "video_pack_lane.h"
 #include "video_recon_lane.h"
 
 using namespace mpg;
@@ -40,10 +41,65 @@ static uint32_t emu_pack_as(uint32_t luma_w, uint32_t luma_h, uint64_t frame_str
     *n_words = got.words;
     return got.chunks;
 }
+static thread_local int g_device_pack = 0; // (per thread: ShardedVideoBatch tests run two emulator stores on two threads)
+// 1: sparse pictures are packed by the DEVICE packer's lane functions (video_pack_lane.h), wave by wave
 static int g_tile_policy = 0; // as mpeghip_video_set_tile_policy: 0 = pick per submit like launch_batch, 1 = int16 tile, 2 = int32 tile
 extern "C" {
 
 void emu_set_tile_policy(int policy) { g_tile_policy = policy; }
+void emu_set_device_pack(int on) { g_device_pack = on; }
+
+// pack_kernel for ONE picture, wave by wave: its descriptors and sparse words (n_words dwords behind words_in + aux.word_first)
+// -> chunks (from aux.chunk_first) and words_out (from aux.word_first).  Returns the error word (kPkNoError = fine).
+unsigned long long emu_pack_device_picture(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride, uint64_t rgba_stride,
+                                           const mpeghip_pic_desc *pic, uint32_t word_first, uint32_t n_words, uint32_t chunk_first,
+                                           const mpeghip_mb_desc *mbs, const uint32_t *words_in, uint32_t *chunks_out, uint32_t *words_out,
+                                           uint32_t *use_out)
+{
+    PackArgs a;
+    mpeghip_pic_desc p = *pic;
+    PkPic aux{word_first, n_words, chunk_first, 0};
+    unsigned long long err = kPkNoError;
+    a.pics = &p;
+    a.aux = &aux;
+    a.mbs = mbs;
+    a.words_in = words_in;
+    a.chunks = chunks_out;
+    a.words_out = words_out;
+    a.mb_w = luma_w / 16;
+    a.mb_h = luma_h / 16;
+    a.seen_stride = (a.mb_w * a.mb_h + 31) / 32;
+    std::vector<uint32_t> seen(a.seen_stride, 0);
+    a.seen = seen.data();
+    a.err = &err;
+    a.n_pics = 1;
+    a.groups_per_pic = (p.mb_count + 63) / 64;
+    a.luma_w = luma_w;
+    a.chroma_w = luma_w / 2;
+    a.luma_bytes = luma_w * luma_h;
+    a.chroma_bytes = a.luma_bytes / 4;
+    a.frame_bytes = (uint64_t)a.luma_bytes + 2 * a.chroma_bytes + (uint64_t)luma_w * 16;
+    a.frame_stride = frame_stride;
+    a.rgba_stride = rgba_stride;
+    uint32_t use = 0;
+    for (uint32_t g = 0; g < a.groups_per_pic; g++) {
+        uint32_t xch[64 * kPkXchDwords];
+        PkLane L[64];
+        for (int lane = 0; lane < 64; lane++) {
+            L[lane] = pk_scan(a, 0, p, aux, g * 64 + (uint32_t)lane);
+            use |= L[lane].ok ? L[lane].use : 0u;
+        }
+        for (int lane = 0; lane < 64; lane++)
+            pk_share(xch, lane, L[lane]);
+        const uint32_t k_next = g * 64 + 64;
+        const uint32_t next_coef_off = k_next < p.mb_count ? mbs[p.mb_first + k_next].coef_off : 0u;
+        for (int lane = 0; lane < 64; lane++)
+            pk_emit(a, p, aux, g * 64 + (uint32_t)lane, lane, L[lane], xch, next_coef_off);
+    }
+    if (use_out)
+        *use_out = use;
+    return err;
+}
 
 // one stream's dequantisation table in the device layout (what mpeghip_video_open / _set_quant upload)
 void emu_make_qtable(uint8_t *out, const uint8_t *intra, const uint8_t *non_intra) { rc_make_qtable(out, intra, non_intra, kPremult); }
@@ -116,16 +172,37 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
             } else if (!sparse_words) { // (the host parser's own words: their extent by walking them)
                 uint64_t at = mbs[i].coef_off;
                 for (uint32_t b = 0; b < nb; b++)
-                    at += raw ? 64 : 1 + reinterpret_cast<const uint32_t *>(coefs)[at];
+                    at += 1 + (raw ? 64 : reinterpret_cast<const uint32_t *>(coefs)[at]);
                 sparse_dwords = at > sparse_dwords ? at : sparse_dwords;
             }
         }
     }
     std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1),
-        words(rc_max_words_sparse(sparse_dwords, n_mbs) + rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
+        words((g_device_pack ? (size_t)n_pics : 1) * rc_max_words_sparse(sparse_dwords, n_mbs) + rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
     uint32_t nc = 0, nw = 0;
     uint64_t coded = 0, dense = 0;
+    std::vector<uint32_t> staged; // (device packer: the picture's words where the staged copy would have them)
     for (uint32_t p = 0; p < n_pics; p++) {
+        if (pic_sparse[p] && g_device_pack) {
+            const uint32_t n_sparse = (uint32_t)(sparse_words ? sparse_words - 1 : sparse_dwords);
+            staged.assign(words.size(), 0xDEADBEEFu);
+            if (n_sparse)
+                memcpy(staged.data() + nw, coefs, (size_t)n_sparse * 4);
+            mpeghip_pic_desc pd = pics[p];
+            const uint32_t pic_chunks = (uint32_t)rc_max_chunks(pd.mb_count);
+            if (emu_pack_device_picture(luma_w, luma_h, frame_stride, rgba_stride, &pd, nw, n_sparse, nc, mbs, staged.data(), chunks.data(),
+                                        words.data(), nullptr) != kPkNoError)
+                return -2;
+            for (uint32_t c = nc; c < nc + pic_chunks; c++) { // which kernel instance suits the batch: as the host packer counts
+                const uint32_t *h = chunks.data() + (size_t)c * kRcChunkDwords;
+                coded += h[6] & 0xff;
+                for (uint32_t i = 0; i < (h[6] & 0xff); i++)
+                    dense += (words[h[3] + i] & kBDense) ? 1 : 0;
+            }
+            nc += pic_chunks;
+            nw += n_sparse;
+            continue;
+        }
         const RcPacked got = pic_sparse[p] ? rc_pack_picture<true, true>(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
                                                                         chunks.data() + (size_t)nc * kRcChunkDwords, words.data() + nw,
                                                                         sparse_words ? sparse_words - 1 : ~0ull >> 2)
@@ -360,6 +437,25 @@ uint32_t emu_pack_narrow(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride
 {
     return emu_pack_as<false>(luma_w, luma_h, frame_stride, rgba_stride, pic, mbs, coefs, chunks_out, words_out, n_words);
 }
+// the HOST packer on a picture in the sparse form (rc_pack_picture<., true>): -> chunks, 0xffffffff if it refuses the picture
+uint32_t emu_pack_sparse(uint32_t luma_w, uint32_t luma_h, uint64_t frame_stride, uint64_t rgba_stride, const mpeghip_pic_desc *pic,
+                         const mpeghip_mb_desc *mbs, const uint32_t *words, uint64_t n_words, uint32_t *chunks_out, uint32_t *words_out,
+                         uint32_t *n_words_out, uint64_t out_room)
+{
+    RcGeom geom;
+    geom.mb_w = luma_w / 16;
+    geom.mb_h = luma_h / 16;
+    geom.luma_w = luma_w;
+    geom.chroma_w = luma_w / 2;
+    geom.luma_bytes = luma_w * luma_h;
+    geom.frame_stride = frame_stride;
+    geom.rgba_stride = rgba_stride;
+    const RcPacked got = rc_pack_picture<true, true>(geom, *pic, mbs + pic->mb_first, pic->mb_count, reinterpret_cast<const uint8_t *>(words), 0,
+                                                     chunks_out, words_out, n_words, out_room);
+    *n_words_out = got.words;
+    return got.bad ? 0xffffffffu : got.chunks;
+}
+
 int emu_host_has_avx512(void)
 {
 #if MPG_HOST_AVX512

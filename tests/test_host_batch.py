@@ -11,9 +11,10 @@ VIDEO_HASH = 0xea6d7fcb1340ba3f       # testdata/test.mpeg1video, damaged stream
 TESTMPG_VIDEO_HASH = 0xd00818edcafdc702
 
 
-def run_batch(oracle, streams, delays, device=None, threads=1):
+def run_batch(oracle, streams, delays, device=None, threads=1, device_pack=True):
     """streams[i] joins the batch after delays[i] ticks; returns per-stream (hash, frames) + counters."""
     b = hostlib.HostBatch(len(streams), device=device, threads=threads)
+    b.set_device_pack(device_pack)
     h = [oracle.FNV_OFFSET] * len(streams)
     n = [0] * len(streams)
     added, tick = 0, 0
@@ -75,6 +76,11 @@ def test_threaded_parse_gives_the_same_frames_and_device_calls(oracle, golden_di
     assert c["device_submits"] <= c1["device_submits"]
     # and the pictures went through staged submits (put from the pool), not through the merged path
     assert c1["staged_commits"] == 0 and c["staged_commits"] > 0.8 * c["device_submits"]
+    # ... packed by the DEVICE packer (here: its lane functions) — the damaged golden stream's snapshot blocks, invalid intra
+    # blocks and re-submits included; with the packing left to the host: the same frames
+    assert c["device_pack_stages"] == c["staged_commits"]
+    h0, n0, c0 = run_batch(oracle, streams, delays, threads=threads, device_pack=False)
+    assert (h0, n0) == (h, n) and c0["device_pack_stages"] == 0 and c0["staged_commits"] == c["staged_commits"]
 
 
 def test_different_picture_sizes_are_refused(oracle, golden_dir):

@@ -30,9 +30,12 @@ def build(force: bool = False) -> Path:
 
 
 def staged_submit_rate(device: int, width: int, height: int, seq, streams: int, threads: int, seconds: float = 2.0,
-                       verbose: bool = False, sparse: bool = True) -> float:
+                       verbose: bool = False, sparse: bool = True, device_pack: int = 0) -> float:
     """sparse: the pictures are handed over in the parser's own form (MPEGHIP_PIC_SPARSE: (position, level) pairs), what the
-    product's parser emits; False: as 128-byte units."""
+    product's parser emits; False: as 128-byte units.  device_pack: 0 = validated and packed by the putting threads, 1 = a
+    device-packed stage (mpeghip_video_stage_begin_device: the puts copy, the device packs), 2 = the same with the pictures
+    already in the pinned staging buffers (one picture of `seq` only): commit + PCIe + device, no host work per picture."""
+    assert sparse or not device_pack
     from mpeg_amd import abi, desc
     abi.load_library()
     if sparse:
@@ -49,7 +52,7 @@ def staged_submit_rate(device: int, width: int, height: int, seq, streams: int, 
     H = C.CDLL(str(build()))
     H.hostbench_staged_submit_rate.restype = C.c_double
     H.hostbench_staged_submit_rate.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
-                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     n = len(seq)
     pics = np.ascontiguousarray(np.concatenate([s.pics[:1] for s in seq]))
     mbs = [np.ascontiguousarray(s.mbs) for s in seq]
@@ -59,7 +62,7 @@ def staged_submit_rate(device: int, width: int, height: int, seq, streams: int, 
     n_mbs = np.array([len(m) for m in mbs], np.uint32)
     cbytes = np.array([c.nbytes for c in coefs], np.uint64)
     pps = H.hostbench_staged_submit_rate(device, width, height, streams, threads, seconds, n, pics.ctypes.data, mbs_p,
-                                         n_mbs.ctypes.data, coefs_p, cbytes.ctypes.data, int(verbose))
+                                         n_mbs.ctypes.data, coefs_p, cbytes.ctypes.data, int(verbose), int(device_pack))
     if pps < 0:
         raise RuntimeError("hostbench_staged_submit_rate failed")
     return pps

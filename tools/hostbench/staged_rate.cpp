@@ -2,6 +2,7 @@
 // Built on demand by tools/hostbench/__init__.py (g++, in-tree); the product libraries do not contain it.
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <atomic>
 #include <chrono>
@@ -24,8 +25,12 @@ extern "C" {
 double hostbench_staged_submit_rate(int device, uint32_t width, uint32_t height, uint32_t n_streams, uint32_t threads,
                                    double seconds, uint32_t n_steps, const mpeghip_pic_desc *pics,
                                    const mpeghip_mb_desc *const *mbs, const uint32_t *n_mbs, const uint8_t *const *coefs,
-                                   const size_t *coef_bytes, int verbose)
+                                   const size_t *coef_bytes, int verbose, int device_pack)
 {
+    // device_pack: 0 = the host validates and packs (mpeghip_video_stage_begin[_sparse]); 1 = a DEVICE-PACKED stage, the puts
+    // copy the arrays into pinned staging (mpeghip_video_stage_begin_device + _put_sparse; sparse pictures only); 2 = the same
+    // with the arrays written through mpeghip_video_stage_map ONCE per staging buffer and only put_mapped per call afterwards:
+    // what is left when a parser writes its pictures in place — commit, PCIe, pack kernel, reconstruction
     try {
         mpeghip_ctx *ctx = nullptr;
         if (mpeghip_ctx_create(device, nullptr, &ctx) != MPEGHIP_OK)
@@ -45,6 +50,7 @@ double hostbench_staged_submit_rate(int device, uint32_t width, uint32_t height,
             std::atomic<int> failed{0};
             mpeghip_stage *stage = nullptr;
             uint32_t step = 0;
+            bool fill = true;
         } sh;
         threads = threads < 1 ? 1 : threads;
         auto drain = [&]() {
@@ -54,6 +60,21 @@ double hostbench_staged_submit_rate(int device, uint32_t width, uint32_t height,
                     return;
                 mpeghip_pic_desc p = pics[sh.step];
                 p.stream = i;
+                if (device_pack == 2) {
+                    if (sh.fill) { // (the first two calls of a step: both staging buffers get the picture's arrays)
+                        mpeghip_mb_desc *pm = nullptr;
+                        uint32_t *pw = nullptr;
+                        if (mpeghip_video_stage_map(sh.stage, i, &pm, &pw) != MPEGHIP_OK) {
+                            sh.failed.store(1);
+                            continue;
+                        }
+                        memcpy(pm, mbs[sh.step], (size_t)n_mbs[sh.step] * sizeof(mpeghip_mb_desc));
+                        memcpy(pw, coefs[sh.step], coef_bytes[sh.step]);
+                    }
+                    if (mpeghip_video_stage_put_mapped(sh.stage, i, &p) != MPEGHIP_OK)
+                        sh.failed.store(1);
+                    continue;
+                }
                 if (mpeghip_video_stage_put(sh.stage, i, &p, mbs[sh.step], coefs[sh.step]) != MPEGHIP_OK)
                     sh.failed.store(1);
             }
@@ -90,7 +111,12 @@ double hostbench_staged_submit_rate(int device, uint32_t width, uint32_t height,
             std::fill(bytes.begin(), bytes.end(), coef_bytes[step]);
             mpeghip_stage *st = nullptr;
             const auto c0 = now();
-            if (mpeghip_video_stage_begin(v, n_streams, counts.data(), bytes.data(), &st) != MPEGHIP_OK)
+            if (device_pack) {
+                for (size_t &b : bytes)
+                    b /= 4; // (dwords)
+                if (mpeghip_video_stage_begin_device(v, n_streams, counts.data(), bytes.data(), &st) != MPEGHIP_OK)
+                    throw std::runtime_error(mpeghip_last_error());
+            } else if (mpeghip_video_stage_begin(v, n_streams, counts.data(), bytes.data(), &st) != MPEGHIP_OK)
                 throw std::runtime_error(mpeghip_last_error());
             const auto c1 = now();
             {
@@ -118,9 +144,13 @@ double hostbench_staged_submit_rate(int device, uint32_t width, uint32_t height,
         double rate = -1;
         std::exception_ptr err;
         try {
-            for (uint32_t s = 0; s < n_steps; s++)
-                one_call(s);
-            mpeghip_ctx_sync(ctx);
+            if (device_pack == 2 && n_steps != 1)
+                throw std::runtime_error("hostbench: the in-place mode cycles ONE picture (both staging buffers hold it)");
+            for (uint32_t s = 0; s < (device_pack == 2 ? 2 : n_steps); s++)
+                one_call(device_pack == 2 ? 0 : s);
+            sh.fill = false;
+            if (mpeghip_video_sync(v) != MPEGHIP_OK)
+                throw std::runtime_error(mpeghip_last_error());
             t_begin = t_put = t_commit = 0;
             const auto t0 = std::chrono::steady_clock::now();
             uint64_t n = 0;
@@ -132,7 +162,8 @@ double hostbench_staged_submit_rate(int device, uint32_t width, uint32_t height,
                 }
                 dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             } while (dt < seconds);
-            mpeghip_ctx_sync(ctx);
+            if (mpeghip_video_sync(v) != MPEGHIP_OK) // (a device-packed commit's deferred verdict)
+                throw std::runtime_error(mpeghip_last_error());
             dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             rate = (double)n / dt;
             if (verbose)
