@@ -16,6 +16,7 @@ Prints ONE JSON line (rank 0): metric/value/... plus
   dense            — the worst-case workload of SURVEY §8(d): dense P pictures (every block full, odd vectors)
   rgba_fused       — the typical GOP with Frame.RGBA() of every picture fused into the kernel (BASELINE config 3's kernel)
   dense_rgba_fused — the dense workload with Frame.RGBA() fused
+  mixed            — every stream at its own GOP phase with one of 16 contents: I, P and B pictures of different streams in ONE launch
   audio            — the MP2 synthesis kernel on 256 stereo streams (BASELINE config 4)
   host_fed         — (optional) the same pictures handed over by host threads through the staged submit (PCIe inclusive)
 Every video leg carries its own roofline object and parity string (all streams x 3 slots against the oracle's replay).
@@ -54,8 +55,8 @@ def parse_args():
     ap.add_argument("--profile", default="typical", choices=["typical", "dense", "typical_nocoef", "typical_fullpel", "mc_copy", "mc_horiz", "mc_vert", "mc_bilin"],
                     help="workload of the PRIMARY leg (`value`): typical is the reported one; the others are diagnostics")
     ap.add_argument("--rgba", type=int, default=0, help="1: the primary leg fuses Frame.RGBA into the reconstruction kernel")
-    ap.add_argument("--legs", default="dense,rgba_fused,dense_rgba_fused",
-                    help="secondary video legs (comma separated; N=1 only): dense, rgba_fused, dense_rgba_fused; '' = none")
+    ap.add_argument("--legs", default="dense,rgba_fused,dense_rgba_fused,mixed",
+                    help="secondary video legs (comma separated; N=1 only): dense, rgba_fused, dense_rgba_fused, mixed; '' = none")
     ap.add_argument("--rgba-streams", type=int, default=-1, help="streams of the fused-RGBA legs (-1 = --streams; 0 = skip them)")
     ap.add_argument("--host-fed-seconds", type=float, default=2.0,
                     help="host-fed leg: pictures pushed through the staged submit from host threads for this many seconds "
@@ -117,6 +118,67 @@ def cpu_baseline(args, seq):
         # what the threads really got: a container with a CPU-time quota runs 256 threads on far fewer cores' worth of time
         "speedup_over_one_thread": rT / r1,
     }
+
+
+def cpu_baseline_audio(args, seconds):
+    """The other half of the metric on the host: the oracle's idct36 + synthWindow + scaling (oracle_desc.c: orc_synth_frames, the
+    pure-Go arithmetic, no FMA) on config 4's samples — one thread, then one stream per host thread (ctypes releases the GIL)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from mpeg_amd import synth
+    from oracle import pyoracle
+    L = pyoracle.lib()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    frames = 20
+    smp = synth.audio_frames(min(cores, 64), frames)     # (streams beyond 64 reuse the samples: each has its own state and output)
+
+    def run(stream, until):
+        st, out, n = pyoracle.Synth(), np.empty((frames, 2304), np.float32), 0
+        s = np.ascontiguousarray(smp[stream % len(smp)])
+        while time.perf_counter() < until:
+            L.orc_synth_frames(C.byref(st), s.ctypes.data_as(C.c_void_p), frames, 0, 0, out.ctypes.data_as(C.c_void_p))
+            n += frames
+        return n
+
+    t0 = time.perf_counter()
+    n1 = run(0, t0 + seconds * 0.3)
+    r1 = n1 * 1152 / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        nT = sum(ex.map(lambda i: run(i, t0 + seconds * 0.7), range(cores)))
+    rT = nT * 1152 / (time.perf_counter() - t0)
+    return {"value": rT, "unit": "MP2 stereo sample pairs/s", "cores": cores, "kind": "port", "single_thread": r1,
+            "speedup_over_one_thread": rT / r1,
+            "sample": "oracle (C restatement of audio.go:378-422, 492-772 + audio_noasm.go:8-38, gcc -O2, no FMA): %d host threads x 1 "
+                      "stereo stream each, config 4's seeded sub-band samples, %d frames in %.1f s" % (cores, nT, seconds * 0.7)}
+
+
+def cpu_baseline_test_mpg(seconds):
+    """BASELINE config 1 as written (mpeg_test.go:463-491: BenchmarkDecodeVideo / BenchmarkDecodeAudio on testdata/test.mpg,
+    frames and samples dropped) on the oracle, one host thread: demux + parse + reconstruct every video frame, then every audio
+    frame, in a loop of at least 20 passes."""
+    from oracle import pyoracle
+    ps = ROOT / "tests" / "golden" / "test.mpg"
+    if not ps.exists():
+        return None
+    data = ps.read_bytes()
+    out = {"kind": "port", "cores": 1, "unit": "frames/s"}
+    for what, packet, make in (("video", 0xE0, pyoracle.VideoDecoder), ("audio", 0xC0, pyoracle.AudioDecoder)):
+        t0, loops, frames = time.perf_counter(), 0, 0
+        while loops < 20 or time.perf_counter() - t0 < seconds / 2:
+            es, _ = pyoracle.ps_extract(data, packet)
+            dec = make(es)
+            while dec.decode() is not None:
+                frames += 1
+            dec.close()
+            loops += 1
+        dt = time.perf_counter() - t0
+        out[what + "_frames_per_s"] = frames / dt
+        out[what + "_loops"] = loops
+        out[what + "_frames_per_loop"] = frames // loops
+    out["sample"] = ("oracle (C restatement of the reference's pure-Go path), ONE thread: tests/golden/test.mpg (160x120, MP2) demuxed "
+                     "and decoded completely, %d video / %d audio passes" % (out["video_loops"], out["audio_loops"]))
+    return out
 
 
 def build_sequence(args, profile, rgba):
@@ -256,6 +318,62 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
     }
 
 
+def mixed_leg(ctx, args, streams, n_seeds=16):
+    """What many concurrent streams look like: stream s decodes the GOP of seed s % 16, s % gop pictures ahead of stream 0 — I, P
+    and B pictures of different streams, with different content, in ONE launch (mpeg_amd/mixed.py).  One resident batch per step
+    of the GOP cycle (1024 different pictures each, validated and packed by the library's host packer at upload); parity: all
+    streams x 3 slots, every distinct (seed, phase) combination against its own oracle replay."""
+    from mpeg_amd import abi, mixed
+    t0 = time.perf_counter()
+    wl = mixed.MixedWorkload(args.width, args.height, streams, gop=args.gop, n_seeds=n_seeds, threads=min(16, os.cpu_count() or 1))
+    store = abi.VideoStore(ctx, args.width, args.height, streams)
+    store.set_tile_policy(args.tile)
+    batches = []
+    for t in range(args.gop):
+        batches.append(store.upload(*wl.step_arrays(t)))
+    ctx.sync()
+    setup_s = time.perf_counter() - t0
+    order = []
+
+    def step(t):
+        b = batches[t % args.gop]
+        b.run()
+        order.append(t)
+        return b
+
+    for t in range(args.gop):           # one whole cycle: every stream has decoded its references
+        step(t)
+    ctx.sync()
+    mbs = alg = 0
+    w0 = time.perf_counter()
+    ctx.timer_start()
+    for t in range(args.gop, args.gop + args.steps):
+        b = step(t)
+        mbs += b.n_mbs
+        alg += b.alg_bytes
+    ev_ms = ctx.timer_stop_ms()
+    elapsed = time.perf_counter() - w0
+    parity = None
+    if args.check:
+        from oracle import mixedcheck
+        ok, parity = mixedcheck.check(wl, store, order, threads=min(32, os.cpu_count() or 1))
+        if not ok:
+            raise SystemExit("bench: mixed leg: frames differ from the oracle — result invalid")
+    for b in batches:
+        b.free()
+    store.close()
+    launch_ms = ev_ms / args.steps
+    achieved = (alg / args.steps) / (launch_ms * 1e-3) / 1e9
+    return {"metric": "1080p macroblocks/sec, mixed: stream s at GOP phase s mod %d with the content of seed s mod %d — I, P and B "
+                      "pictures of different streams in every launch" % (args.gop, n_seeds),
+            "value": mbs / elapsed, "unit": "macroblocks/s", "streams": streams, "steps": args.steps,
+            "ms_per_step": elapsed * 1e3 / args.steps, "realtime_1080p30_streams": mbs / elapsed / MB_PER_1080P30_STREAM,
+            "distinct_seeds": n_seeds, "distinct_combinations": len(wl.combos()), "setup_s": setup_s,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": KERNEL[False], "alg_bytes_per_launch": alg // args.steps, "avg_launch_ms": launch_ms},
+            "parity": parity}
+
+
 def secondary(leg, name, streams, args):
     return {"metric": "1080p macroblocks/sec, %s" % name, "value": leg["mbs"] / leg["elapsed"], "unit": "macroblocks/s",
             "streams": streams, "steps": leg["steps"], "ms_per_step": leg["elapsed"] * 1e3 / leg["steps"],
@@ -263,7 +381,7 @@ def secondary(leg, name, streams, args):
             "roofline": leg["roofline"], "parity": leg["parity"]}
 
 
-def audio_leg(ctx, args, streams, tile=1, fma=0):
+def audio_leg(ctx, args, streams, tile=1, fma=0, ranks=None, device_sync=None):
     """MP2 synthesis on `streams` x `tile` stereo streams, --audio-frames frames per launch.  tile > 1: the seeded samples
     of `streams` streams are uploaded `tile` times side by side (stream s = stream s mod `streams`): the working set of the
     timed launch then exceeds the 256 MB Infinity Cache, and every stream is still compared with the oracle.
@@ -291,15 +409,30 @@ def audio_leg(ctx, args, streams, tile=1, fma=0):
     for _ in range(2):
         a.synth_device(d_s, frames, desc.AUDIO_F32N, d_o)
     ctx.sync()
-    reps = 5
-    ctx.timer_start()
-    for _ in range(reps):
-        a.synth_device(d_s, frames, desc.AUDIO_F32N, d_o)
-    ams = ctx.timer_stop_ms() / reps
+    world = ranks.world if ranks is not None else 1
+    reps = 5 if world == 1 else 40
+    ev = {}
+
+    def timed_body():
+        ctx.timer_start()
+        for _ in range(reps):
+            a.synth_device(d_s, frames, desc.AUDIO_F32N, d_o)
+        ev["ms"] = ctx.timer_stop_ms()  # HIP events on the stream the kernel runs on
+
+    if world > 1:  # every rank on its own streams between two barriers: MAX elapsed over ranks, as the video leg
+        elapsed = ranks.timed(timed_body, device_sync=device_sync)
+        per_rank = ranks.gather(n * frames * 1152 * reps / ranks.last_local)
+    else:
+        timed_body()
+        elapsed, per_rank = ev["ms"] * 1e-3, None
+    ams = ev["ms"] / reps
     abytes = n * frames * 18432
     traffic, source, matches = traffic_of("audio_%d" % n, False, n, args)
     out = {
-        "metric": "MP2 stereo sample pairs/s", "value": n * frames * 1152 / (ams * 1e-3),
+        "metric": "MP2 stereo sample pairs/s",
+        # N = 1: by the kernel's HIP events; N > 1: all ranks' sample pairs / the slowest rank's wall time between the barriers
+        "value": n * frames * 1152 / (ams * 1e-3) if world == 1 else world * n * frames * 1152 * reps / elapsed,
+        "n_gpus": world, "per_rank_value": per_rank, "launches_timed": reps,
         "streams": n, "frames_per_launch": frames, "ms_per_launch": ams,
         "realtime_streams_44k1": n * frames * 1152 / (ams * 1e-3) / 44100.0,
         "working_set_bytes": 2 * abytes,
@@ -393,7 +526,7 @@ def reference_benchmarks(ctx, args, device):
     return out
 
 
-def host_fed_leg(args, prim, device):
+def host_fed_leg(args, prim, device, ranks=None):
     """The same typical pictures handed over by host threads through the staged submit — PCIe inclusive, NOT `value`.
     Headline: the DEVICE-PACKED stage (mpeghip_video_stage_begin_device: the host copies the ABI's arrays into pinned staging,
     pack_kernel validates and packs them in front of recon_kernel) with 8 putting threads; beside it the same with the
@@ -407,6 +540,16 @@ def host_fed_leg(args, prim, device):
     sec = args.host_fed_seconds
     w, h = args.width, args.height
     per_call = 128
+    if ranks is not None and ranks.world > 1:
+        # N > 1: every rank feeds its own GPU at the same time, 8 putting threads each, bound to its GPU's NUMA node (main)
+        ranks.barrier()
+        mine = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(8, cpus), sec, sparse=True, device_pack=1)
+        per_rank = ranks.gather(mine)
+        mbpp = float(np.mean([len(s.mbs) for s in seq]))
+        return {"metric": "1080p macroblocks/sec handed over by host threads through device-packed stages, all ranks at once "
+                          "(8 putting threads per rank) — PCIe inclusive, NOT `value`",
+                "value": sum(per_rank) * mbpp, "pictures_per_s": sum(per_rank), "per_rank_pictures_per_s": per_rank,
+                "host_threads_per_rank": min(8, cpus), "pictures_per_call": per_call, "n_gpus": ranks.world}
     dev8 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(8, cpus), sec, sparse=True, device_pack=1)
     dev4 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(4, cpus), sec / 2, sparse=True, device_pack=1)
     dev16 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(16, cpus), sec / 2, sparse=True, device_pack=1)
@@ -448,6 +591,69 @@ def host_fed_leg(args, prim, device):
                             "what": "round 3's hand-over: validation + packing into the device format on the putting threads"},
             "note": "the on-device `value` is %.0f x this: no PCIe link can carry what the kernel reconstructs (BASELINE.md)" %
                     (prim["mbs"] / prim["elapsed"] / (dev8 * mb_per_pic))}
+
+
+def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
+    """Parse-inclusive: a written 1080p elementary stream (tests/mpeg1_writer.py: the `natural` level mix, coefficients as
+    Table B.5 run / level codes, escapes where the table has none) through the product's whole host stack — mpeg::VideoBatch:
+    bitstream parse on a pool of host threads -> the parser's sparse pictures -> device-packed staged commits -> pack_kernel +
+    recon_kernel; frames stay on the device.  What ONE GPU's host side delivers from bitstreams, NOT `value`."""
+    import ctypes as C
+    sys.path.insert(0, str(ROOT / "tests"))
+    import mpeg1_writer
+    from mpeg_amd import synth
+    so = ROOT / "mpeg_amd" / "libmpeghost.so"
+    if not so.exists():
+        return None
+    seq = synth.generate_sequence(args.width, args.height, gop, seed=0x5a, profile="natural")
+    es = mpeg1_writer.write_sequence(args.width, args.height, seq, repeat=groups)
+    H = C.CDLL(str(so))
+    P = C.c_void_p
+    H.mpeghost_device_create.restype, H.mpeghost_device_create.argtypes = P, [C.c_int]
+    H.mpeghost_device_destroy.argtypes = [P]
+    H.mpeghost_batch_open.restype, H.mpeghost_batch_open.argtypes = P, [P, C.c_uint32]
+    H.mpeghost_batch_close.argtypes = [P]
+    H.mpeghost_batch_add_stream.restype, H.mpeghost_batch_add_stream.argtypes = C.c_int, [P, C.c_char_p, C.c_size_t]
+    H.mpeghost_batch_decode_all.restype, H.mpeghost_batch_decode_all.argtypes = C.c_int, [P, C.c_int]
+    H.mpeghost_batch_set_threads.argtypes = [P, C.c_uint32]
+    H.mpeghost_batch_set_device_pack.argtypes = [P, C.c_int]
+    H.mpeghost_batch_sync.restype, H.mpeghost_batch_sync.argtypes = C.c_int, [P]
+    H.mpeghost_batch_phase_seconds.argtypes = [P, C.POINTER(C.c_double * 4)]
+    H.mpeghost_batch_counters.argtypes = [P, C.POINTER(C.c_uint64 * 2)]
+    H.mpeghost_last_error.restype = C.c_char_p
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    dev = H.mpeghost_device_create(device)
+    out = {"metric": "1080p pictures/s from BITSTREAMS: %d streams of a written 1080p stream (natural level mix, Table B.5 codes; %d "
+                     "pictures, %.0f kB per picture) parsed on %d host threads, handed over as device-packed staged commits, "
+                     "reconstructed — NOT `value`" % (streams, gop * groups, len(es) / (gop * groups) / 1e3, threads),
+           "streams": streams, "parse_threads": threads, "pictures_per_stream": gop * groups, "stream_bytes_per_picture": len(es) / (gop * groups)}
+    for name, device_pack in (("device_packed", 1), ("host_packed", 0)):
+        b = H.mpeghost_batch_open(dev, streams)
+        if not b:
+            raise SystemExit("bench: host_parsed: %s" % H.mpeghost_last_error().decode())
+        H.mpeghost_batch_set_threads(b, threads)
+        H.mpeghost_batch_set_device_pack(b, device_pack)
+        for _ in range(streams):
+            if H.mpeghost_batch_add_stream(b, es, len(es)) < 0:
+                raise SystemExit("bench: host_parsed: %s" % H.mpeghost_last_error().decode())
+        t0 = time.perf_counter()
+        while H.mpeghost_batch_decode_all(b, 0) > 0:
+            pass
+        if H.mpeghost_batch_sync(b) != 0:
+            raise SystemExit("bench: host_parsed: %s" % H.mpeghost_last_error().decode())
+        dt = time.perf_counter() - t0
+        ph, cn = (C.c_double * 4)(), (C.c_uint64 * 2)()
+        H.mpeghost_batch_phase_seconds(b, C.byref(ph))
+        H.mpeghost_batch_counters(b, C.byref(cn))
+        H.mpeghost_batch_close(b)
+        pictures = int(cn[1])
+        out[name] = {"pictures_per_s": pictures / dt, "pictures": pictures, "seconds": dt, "device_calls": int(cn[0]),
+                     "ms_parse_per_picture_per_thread": ph[0] * 1e3 * threads / max(pictures, 1),
+                     "wall_seconds": {"parse_rounds": ph[0], "stage_begin": ph[1], "puts": ph[2], "commits": ph[3]}}
+    H.mpeghost_device_destroy(dev)
+    out["value"] = out["device_packed"]["pictures_per_s"]
+    out["realtime_1080p30_streams"] = out["value"] / 30.0
+    return out
 
 
 def main():
@@ -495,11 +701,14 @@ def main():
             elif name == "rgba_fused" and rs > 0 and not (args.profile == "typical" and args.rgba):
                 legs["rgba_fused"] = secondary(video_leg(ctx, args, "typical", True, rs),
                                                "Frame.RGBA() of every picture fused into the reconstruction kernel", rs, args)
+            elif name == "mixed":
+                legs["mixed"] = mixed_leg(ctx, args, args.streams)
             elif name == "dense_rgba_fused" and rs > 0 and not (args.profile == "dense" and args.rgba):
                 legs["dense_rgba_fused"] = secondary(video_leg(ctx, args, "dense", True, rs),
                                                      "dense worst case with Frame.RGBA() fused", rs, args)
 
-    audio = audio_leg(ctx, args, args.audio_streams) if args.audio_streams > 0 and rank == 0 else None
+    # the other half of the metric: every rank synthesises its own --audio-streams streams (MAX time over ranks at N > 1)
+    audio = audio_leg(ctx, args, args.audio_streams, ranks=ranks, device_sync=torch.cuda.synchronize) if args.audio_streams > 0 else None
     audio_large = None
     if args.audio_streams > 0 and alone and args.audio_tile > 1:  # beyond the Infinity Cache: config 4's working set is about its size
         audio_large = audio_leg(ctx, args, args.audio_streams, args.audio_tile)
@@ -511,12 +720,20 @@ def main():
     # ---- host-fed rate (NOT `value`): the same pictures handed over by host threads through the staged submit,
     # i.e. validation + packing into the device format on the host, PCIe, reconstruction on the device
     host_fed = None
-    if args.host_fed_seconds > 0 and alone:
-        host_fed = host_fed_leg(args, prim, local_rank)
+    if args.host_fed_seconds > 0:
+        host_fed = host_fed_leg(args, prim, local_rank, ranks)
+
+    host_parsed = host_parsed_leg(args, local_rank) if args.host_fed_seconds > 0 and alone and args.single_stream else None
 
     if all_cpus is not None and numa["cpus_bound"]:
         os.sched_setaffinity(0, all_cpus)  # the CPU baseline is the whole host's: every core of both sockets
-    cpu = cpu_baseline(args, prim["seq"]) if args.cpu_seconds > 0 and alone else None
+    # the CPU baselines: rank 0 only, also at N > 1 (after the timed legs; the other ranks wait at the closing barrier)
+    cpu = None
+    if args.cpu_seconds > 0 and rank == 0:
+        cpu = cpu_baseline(args, prim["seq"])
+        cpu["audio"] = cpu_baseline_audio(args, max(2.0, args.cpu_seconds / 3))
+        cpu["test_mpg"] = cpu_baseline_test_mpg(max(2.0, args.cpu_seconds / 3))
+    ranks.barrier()
 
     if rank == 0:
         total_mbs = prim["mbs"] * world
@@ -540,12 +757,14 @@ def main():
             "dense": legs.get("dense"),
             "rgba_fused": legs.get("rgba_fused"),
             "dense_rgba_fused": legs.get("dense_rgba_fused"),
+            "mixed": legs.get("mixed"),
             "audio": audio,
             "audio_large": audio_large,
             "audio_fma_window": audio_fma,
             "single_stream": single,
             "reference_benchmarks": ref_bench,
             "host_fed": host_fed,
+            "host_parsed": host_parsed,
             "parity": prim["parity"],
         }
         print(json.dumps(line))

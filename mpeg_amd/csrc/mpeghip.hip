@@ -6,6 +6,9 @@
 // There is no CPU path in this library.  Every entry point that needs the GPU
 // fails with MPEGHIP_ERR_NO_DEVICE / MPEGHIP_ERR_HIP when it is not there.
 #include <hip/hip_runtime.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -397,7 +400,12 @@ __global__ __launch_bounds__(256) void rgba_kernel(const uint8_t *frames, uint64
 // picture of a device-packed stage; grid = pictures x (waves the largest picture needs).
 __global__ __launch_bounds__(64) void pack_kernel(const PackArgs a)
 {
-    __shared__ uint32_t xch[64 * kPkXchDwords];
+    // LDS: the exchange array, then the window — a.win_dwords of it, sized by the host for the commit's pictures (words per
+    // macroblock): 4 096 dwords for a commit with an I picture in it (2 waves per SIMD), a quarter of that for typical ones
+    extern __shared__ __attribute__((aligned(16))) uint32_t pack_lds[];
+    uint32_t *const xch = pack_lds;
+    uint32_t *const win = pack_lds + 64 * kPkXchDwords;
+    uint32_t *const wout = win + a.win_dwords; // the window of the words the wave produces
     const uint32_t pic = blockIdx.x / a.groups_per_pic, g = blockIdx.x - pic * a.groups_per_pic;
     const mpeghip_pic_desc p = a.pics[pic];
     if (g * 64 >= p.mb_count)
@@ -405,7 +413,33 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackArgs a)
     const PkPic x = a.aux[pic];
     const int lane = (int)threadIdx.x;
     const uint32_t k = g * 64 + (uint32_t)lane;
-    const PkLane L = pk_scan(a, pic, p, x, k);
+    // the lane's descriptor, and where the next wave's data begins (= where this wave's ends, by the order rule)
+    const uint32_t k_next = g * 64 + 64;
+    mpeghip_mb_desc mb;
+    memset(&mb, 0, sizeof(mb));
+    if (k < p.mb_count)
+        mb = a.mbs[p.mb_first + k];
+    const uint32_t next_coef_off = k_next < p.mb_count ? a.mbs[p.mb_first + k_next].coef_off : 0u;
+    // phase 0: the wave's window of the picture's words -> LDS, 16 bytes per lane and load, all loads in flight at once
+    PkWin in;
+    PkOut out;
+    in.glob = a.words_in + x.word_first;
+    in.lds = win;
+    out.glob = a.words_out;
+    out.lds = wout;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb.coef_off); // (lane 0 has a macroblock)
+    {
+        uint32_t lo4, n;
+        pk_window_range(lo, k_next < p.mb_count ? next_coef_off : x.n_words, x.n_words, a.win_dwords, lo4, n);
+        in.lo = lo4;
+        in.n = n;
+        out.base = x.word_first + lo4;
+        out.n = n;
+        for (uint32_t i = (uint32_t)lane * 4; i < n; i += 256) // (a picture's words begin on a 64-byte boundary; the buffer is padded)
+            *reinterpret_cast<u32x4 *>(win + i) = *reinterpret_cast<const u32x4 *>(in.glob + lo4 + i);
+    }
+    wave_lds_handoff();
+    const PkLane L = pk_scan(a, pic, p, x, k, mb, in);
     // which of its two references the picture's macroblocks read (the dependency check between pictures, pack_gate_kernel)
     const uint32_t use = L.ok ? L.use : 0u;
     const bool fwd = __ballot((use & 1u) != 0) != 0, bwd = __ballot((use & 2u) != 0) != 0;
@@ -413,9 +447,12 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackArgs a)
         atomicOr(&a.aux[pic].use, (fwd ? 1u : 0u) | (bwd ? 2u : 0u));
     pk_share(xch, lane, L);
     wave_lds_handoff();
-    const uint32_t k_next = g * 64 + 64;
-    const uint32_t next_coef_off = k_next < p.mb_count ? a.mbs[p.mb_first + k_next].coef_off : 0u;
-    pk_emit(a, p, x, k, lane, L, xch, next_coef_off);
+    pk_emit(a, p, x, k, lane, L, xch, next_coef_off, in, out);
+    // the produced words leave the window: whole-wave stores, the wave's own territory only (from its first macroblock's
+    // offset; the dwords in front of it inside the 16-byte aligned window are the previous wave's)
+    wave_lds_handoff();
+    for (uint32_t i = (uint32_t)lane + (lo - in.lo); i < out.n; i += 64)
+        out.glob[out.base + i] = wout[i];
 }
 
 // Behind pack_kernel: pictures of one stream that depend on each other (the host lists the candidates: picture, which of its
@@ -624,6 +661,9 @@ struct mpeghip_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // staged commits send their staging buffer on a stream of their own: the copy of commit N + 1 then runs while the kernels
+    // of commit N do (one stream would run copy, kernels, copy, kernels one after the other — the link idle a quarter of the time)
+    hipStream_t copy_stream = nullptr;
 };
 
 // A batch on the device is ONE allocation: pictures | chunks | words (video_recon_lane.h), each region
@@ -665,6 +705,7 @@ struct mpeghip_video {
         uint8_t *h = nullptr;      // pinned
         size_t cap_h = 0;
         hipEvent_t done = nullptr; // recorded after the batch's kernel
+        hipEvent_t copied = nullptr; // staged commits: recorded on the context's copy stream behind the buffer's H2D copy
         bool in_flight = false;
         // a device-packed stage (mpeghip_video_stage_begin_device): the staged arrays as they are on the device, the packer's
         // scratch, and its verdict — written by pack_gate_kernel into pinned memory, looked at when `done` has passed
@@ -817,9 +858,12 @@ int mpeghip_ctx_create(int device, void *stream, mpeghip_ctx **out)
         }
         c->owns_stream = true;
     }
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (c->owns_stream)
+            (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail(MPEGHIP_ERR_HIP, "hipEventCreate failed");
+        return fail(MPEGHIP_ERR_HIP, "hipEventCreate / hipStreamCreate failed");
     }
     *out = c;
     return MPEGHIP_OK;
@@ -831,6 +875,10 @@ void mpeghip_ctx_destroy(mpeghip_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
     if (c->ev0)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
@@ -1000,6 +1048,8 @@ void mpeghip_video_close(mpeghip_video *v)
             (void)hipHostFree(sg.h);
         if (sg.done)
             (void)hipEventDestroy(sg.done);
+        if (sg.copied)
+            (void)hipEventDestroy(sg.copied);
     }
     if (v->d_frames)
         (void)hipFree(v->d_frames);
@@ -1386,8 +1436,14 @@ static int reap_all(mpeghip_video *v)
     return reap_verdict(&v->staging[v->next_staging ^ 1]);
 }
 
-constexpr uint64_t kDenseWordsPerMb = 56; // a device-packed commit with more input dwords per macroblock than this: likewise (stage_commit_device)
-constexpr uint64_t kDenseBatchShare = 4; // more than a quarter of a batch's coded blocks dense units: the int32-tile instance
+// Which instance of the reconstruction kernel a batch runs on: the int32-tile one when more than two thirds of its coded blocks
+// are dense units.  Measured (profiles/r4c_dense_share_crossover.txt: 256 1080p streams at their own GOP phases, a share of
+// them with dense content, both instances interleaved on one box): dense block share 0.01 / 0.41 / 0.68 / 0.86 / 1.00 ->
+// int16 +3.2 % / int16 +1.7 % / tie / int32 +1.6 % / int32 +1.9 %.  (Rounds 2-3 switched at a quarter: a guess between the
+// two measured ends, on the wrong side of the 0.41 point.)  A device-packed commit, whose blocks the host has not looked
+// at, goes by its input dwords per macroblock: the same sweep's 24 / 116 / 207 / 299 / 390.
+constexpr uint64_t kDenseWordsPerMb = 210;
+constexpr uint64_t kDenseShareNum = 2, kDenseShareDen = 3;
 constexpr int kReconWaves = 1; // waves (= chunks) per workgroup: waves of a workgroup that finish early keep their slots until the
                                // last one has (its LDS goes back as a whole) — 1 beats 2 beats 4 (profiles/r2w_ab_waves_per_workgroup.txt)
 
@@ -1420,9 +1476,9 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches of dense units are bound by vector-ALU
     // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); everything else is bound by per-wave
     // latency and wants the eighth wave (int16 tile) — with Frame.RGBA fused as well, since that instance runs one chunk
-    // per wave (r42: fused typical +1.2 %).  Measured at the two ends (typical: 0 % dense units, worst case: 100 %;
-    // profiles/r6_ab_*, r7); the switch-over in between is a guess.
-    bool t16 = b->dense_blocks * kDenseBatchShare <= b->coded_blocks;
+    // per wave (r42: fused typical +1.2 %).  The switch-over: the measured crossover of the two (kDenseShareNum /
+    // kDenseShareDen above).
+    bool t16 = b->dense_blocks * kDenseShareDen <= b->coded_blocks * kDenseShareNum;
     if (v->tile_policy != MPEGHIP_TILE_AUTO)
         t16 = v->tile_policy == MPEGHIP_TILE_INT16;
     // Chunks per wave: one where all of the launch's waves are resident at once (7 waves per SIMD: either instance), and one
@@ -1843,6 +1899,23 @@ int mpeghip_video_submit_sparse(mpeghip_video *v, const mpeghip_pic_desc *pic, c
     return mpeghip_video_submit(v, &p, 1, mbs, n_mbs, words, n_words * 4);
 }
 
+// A staged commit's H2D copy: on the context's copy stream, in pieces (one copy of a gigabyte ran at a quarter of the rate of the
+// same bytes in 32-128 MB pieces); the compute stream waits for it.  The destination's previous use has been retired by the
+// stage's begin.  What the caller queued on the compute stream before (set_quant, write_planes ...) is not waited for by the
+// copy — it only fills a buffer nothing else reads — but by the kernels behind it, as before.
+static int send_staging(mpeghip_video *v, mpeghip_video::Staging *sg, uint8_t *d_dst, size_t total)
+{
+    hipStream_t cs = v->ctx->copy_stream;
+    if (!sg->copied)
+        HIP_TRY(hipEventCreateWithFlags(&sg->copied, hipEventDisableTiming));
+    const size_t piece = (size_t)64 << 20;
+    for (size_t at = 0; at < total; at += piece)
+        HIP_TRY(hipMemcpyAsync(d_dst + at, sg->h + at, total - at < piece ? total - at : piece, hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipEventRecord(sg->copied, cs));
+    HIP_TRY(hipStreamWaitEvent(v->ctx->stream, sg->copied, 0));
+    return MPEGHIP_OK;
+}
+
 // ---- the device-packed stage (include/mpeghip.h: mpeghip_video_stage_begin_device): the host copies, the device packs
 static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -1906,6 +1979,47 @@ static int mpeghip_video_stage_begin_device_impl(mpeghip_video *v, uint32_t n_pi
     return MPEGHIP_OK;
 }
 
+// A put's copy into the pinned staging buffer, with NON-TEMPORAL stores.  A plain memcpy leaves the lines dirty in the
+// core's caches: the H2D copy that follows then has to get them out of there line by line (the DMA engine's reads are
+// snooped), and it reads for ownership what it is about to overwrite.  Measured with 8 putting threads: 43 GB/s over PCIe
+// with memcpy against 63 GB/s when nothing had touched the buffer since it was written (profiles/r4c_*).  Streaming stores go
+// to memory past the caches; the fence at the end orders them before the commit's copy is queued.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) static void stream_copy_avx2(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    while (n && (reinterpret_cast<uintptr_t>(dst) & 31)) { // (staging regions start on 32-byte boundaries at least: rarely)
+        *dst++ = *src++;
+        n--;
+    }
+    for (; n >= 128; n -= 128, dst += 128, src += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + 96), d);
+    }
+    for (; n >= 32; n -= 32, dst += 32, src += 32)
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src)));
+    if (n)
+        memcpy(dst, src, n);
+    _mm_sfence();
+}
+#endif
+static void staging_copy(void *dst, const void *src, size_t n)
+{
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && n >= 4096) {
+        stream_copy_avx2(static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src), n);
+        return;
+    }
+#endif
+    memcpy(dst, src, n);
+}
+
 // picture i of a device-packed stage: its descriptor goes into the staging buffer; its arrays are copied there (copy) or
 // are there already (the caller wrote them through mpeghip_video_stage_map)
 static int stage_put_device(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic, const mpeghip_mb_desc *mbs, const void *words,
@@ -1940,8 +2054,8 @@ static int stage_put_device(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc
         pd.mb_count = n;
         reinterpret_cast<mpeghip_pic_desc *>(h)[i] = pd;
         if (copy) {
-            memcpy(h + s->m_at + (size_t)s->mb_first[i] * sizeof(mpeghip_mb_desc), mbs, (size_t)n * sizeof(mpeghip_mb_desc));
-            memcpy(h + s->in_at + (size_t)s->word_first[i] * 4, words, (size_t)s->units[i]);
+            staging_copy(h + s->m_at + (size_t)s->mb_first[i] * sizeof(mpeghip_mb_desc), mbs, (size_t)n * sizeof(mpeghip_mb_desc));
+            staging_copy(h + s->in_at + (size_t)s->word_first[i] * 4, words, (size_t)s->units[i]);
         }
         s->done[i].store(2);
     } while (0);
@@ -2014,13 +2128,11 @@ static int stage_commit_device(mpeghip_stage *s)
         HIP_TRY(hipHostMalloc((void **)&sg->h_verdict, 64, hipHostMallocDefault));
     *sg->h_verdict = kPkNoError;
     hipStream_t st = v->ctx->stream;
-    {
-        const size_t piece = (size_t)64 << 20; // (in pieces: mpeghip_video_stage_commit_impl)
-        for (size_t at = 0; at < raw_total; at += piece)
-            HIP_TRY(hipMemcpyAsync(sg->d_raw + at, sg->h + at, raw_total - at < piece ? raw_total - at : piece, hipMemcpyHostToDevice, st));
-    }
+    // (the packer's scratch is reset while the copy runs; the kernels wait for the copy)
     HIP_TRY(hipMemsetAsync(sg->d_seen, 0, (size_t)s->n_pics * seen_stride * 4, st));
     HIP_TRY(hipMemsetAsync(sg->d_err, 0xff, 8, st));
+    if ((rc = send_staging(v, sg, sg->d_raw, raw_total)) != MPEGHIP_OK)
+        return rc;
     PackArgs a;
     a.pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->d_raw);
     a.aux = reinterpret_cast<PkPic *>(sg->d_raw + s->a_at);
@@ -2047,7 +2159,18 @@ static int stage_commit_device(mpeghip_stage *s)
     a.rgba_stride = rgba_stride_of(v);
     if ((uint64_t)s->n_pics * a.groups_per_pic > 0x7fffffffull)
         return fail(MPEGHIP_ERR_INVALID, "batch too large for one launch");
-    hipLaunchKernelGGL(pack_kernel, dim3(s->n_pics * a.groups_per_pic), dim3(64), 0, st, a);
+    {   // the window: twice what a wave of the picture with the most words per macroblock names on average, 512 .. kPkWinDwords
+        uint64_t most_per_wave = 0;
+        for (uint32_t i = 0; i < s->n_pics; i++)
+            if (s->mb_count[i]) {
+                const uint64_t per_wave = s->units[i] / 4 * 64 / s->mb_count[i];
+                most_per_wave = per_wave > most_per_wave ? per_wave : most_per_wave;
+            }
+        uint64_t win = (2 * most_per_wave + 255) / 256 * 256;
+        win = win < 512 ? 512 : (win > kPkWinDwords ? kPkWinDwords : win);
+        a.win_dwords = (uint32_t)win;
+    }
+    hipLaunchKernelGGL(pack_kernel, dim3(s->n_pics * a.groups_per_pic), dim3(64), (64 * kPkXchDwords + 2 * a.win_dwords) * 4, st, a);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(pack_gate_kernel, dim3((s->n_chunks + 255) / 256), dim3(256), 0, st, sg->d_err, a.aux, a.pics,
                        reinterpret_cast<const PkDep *>(sg->d_raw + s->d_at), n_deps, a.chunks, s->n_chunks, sg->h_verdict);
@@ -2114,12 +2237,8 @@ static int mpeghip_video_stage_commit_impl(mpeghip_stage *sp)
     b->d_chunks = reinterpret_cast<uint32_t *>(b->d_blob + s->c_at);
     b->d_words = reinterpret_cast<uint32_t *>(b->d_blob + s->w_at);
     hipStream_t st = v->ctx->stream;
-    {
-        // in pieces: one copy of a gigabyte ran at a quarter of the rate of the same bytes in 32-128 MB pieces
-        const size_t piece = (size_t)64 << 20;
-        for (size_t at = 0; at < total; at += piece)
-            HIP_TRY(hipMemcpyAsync(b->d_blob + at, sg->h + at, total - at < piece ? total - at : piece, hipMemcpyHostToDevice, st));
-    }
+    if ((rc = send_staging(v, sg, b->d_blob, total)) != MPEGHIP_OK)
+        return rc;
     fill_notes(v, b, pics, s->n_pics);
     b->alg_bytes = b->coded_blocks = b->dense_blocks = 0;
     for (uint32_t p = 0; p < s->n_pics; p++) {

@@ -10,7 +10,8 @@
 //
 // One lane = one macroblock; a wave takes 64 consecutive macroblocks = 16 chunks of one picture, in three phases with a
 // wave-private exchange array in LDS between them (no barrier):
-//   1  pk_scan:  load the descriptor, validate it (the checks of validate_mb, one by one), mark its position in the
+//   0  the wave's window: the dwords its macroblocks can name, copied into LDS by the whole wave (PkWin below)
+//   1  pk_scan:  validate the lane's descriptor (the checks of validate_mb, one by one), mark its position in the
 //                picture's bitmap (a position named twice: the same rule as the host's), work out its record (d0..d3:
 //                the window's tile / block offsets, half-pel flags, kRSlow) and walk its coded blocks' count words
 //   2  pk_share: every lane publishes its totals (blocks, entries, dwords of snapshot / dense data, where its data ends)
@@ -52,6 +53,7 @@ struct PackArgs {
     uint32_t *seen;      // [n_pics][seen_stride] dwords, zeroed: one bit per macroblock position
     unsigned long long *err; // ~0 = nothing wrong; else (first bad macroblock's index in the submit) << 8 | kPk* reason
     uint32_t n_pics, groups_per_pic, seen_stride;
+    uint32_t win_dwords; // the waves' LDS window (PkWin)
     uint32_t mb_w, mb_h, luma_w, chroma_w, luma_bytes, chroma_bytes;
     uint64_t frame_bytes, frame_stride, rgba_stride;
 };
@@ -82,6 +84,62 @@ MPG_HD uint32_t pk_fetch_or(uint32_t *p, uint32_t bits)
 #endif
 }
 
+// The wave's view of its picture's words.  Walking a macroblock's blocks is a chain of dependent reads (every count word tells
+// where the next one is) and copying its pairs a loop of reads, one lane each: straight from HBM that is a microsecond per
+// step, and a wave of the first version took 150 of them.  So the wave first copies the dwords its 64 macroblocks can name
+// — from its first macroblock's offset to the next wave's first (the ABI's order rule makes that one contiguous range) —
+// into LDS with whole-wave 16-byte loads, all in flight at once, and reads them from there; what does not fit the window
+// (a wave of dense macroblocks: 25 000 dwords) is read from memory as before.
+struct PkWin {
+    const uint32_t *glob; // the picture's words in memory
+    const uint32_t *lds;  // dwords [lo, lo + n) of them
+    uint32_t lo, n;
+};
+MPG_HD uint32_t pk_word(const PkWin &w, uint32_t at)
+{
+    const uint32_t r = at - w.lo;
+    if (r < w.n)
+        return w.lds[r];
+    return w.glob[at];
+}
+// The words a wave PRODUCES go the same way, backwards: lanes put block words, entries and units into a second window in LDS —
+// the same dwords [lo, lo + n) of the packed array, since a chunk's words start at its first macroblock's offset — and the
+// wave writes the window out with whole-wave stores.  (Lane by lane — every lane 4 bytes into a cache line of its own per
+// store instruction — the write requests were what the first two versions of the kernel took their 300 us per 64
+// pictures for: 78 million of them, against 0.8 million now.)  Only dwords of the wave's own territory — from its first
+// macroblock's offset to the next wave's — leave the window; what falls beyond the window is stored directly.
+struct PkOut {
+    uint32_t *glob; // the packed words in memory (index = dword of the whole array)
+    uint32_t *lds;  // dwords [base, base + n) of them
+    uint32_t base, n;
+};
+MPG_HD void pk_put(const PkOut &o, uint32_t at, uint32_t v)
+{
+    const uint32_t r = at - o.base;
+    if (r < o.n)
+        o.lds[r] = v;
+    else
+        o.glob[at] = v;
+}
+MPG_HD void pk_put16(const PkOut &o, uint32_t at, uint32_t half, uint16_t v) // half-word `half` of dword `at`
+{
+    const uint32_t r = at - o.base;
+    uint16_t *p = reinterpret_cast<uint16_t *>(r < o.n ? o.lds + r : o.glob + at);
+    p[half] = v;
+}
+constexpr uint32_t kPkWinDwords = 4096; // 16 KB: a wave of a typical picture names about 1 000 dwords, of an I picture about 3 200
+// the window of the wave whose first macroblock's data begins at `lo` and whose successor's at `hi` (the picture has n_words):
+// 16-byte aligned start, at most kPkWinDwords
+MPG_HD void pk_window_range(uint32_t lo, uint32_t hi, uint32_t n_words, uint32_t cap, uint32_t &lo4, uint32_t &n)
+{
+    lo4 = lo & ~3u;
+    n = 0;
+    if (lo <= hi && hi <= n_words) {
+        n = hi - lo4;
+        n = n < cap ? n : cap;
+    }
+}
+
 constexpr uint32_t kPkSparseBlk = 0, kPkDenseBlk = 1, kPkRawBlk = 2;
 constexpr int kPkXchDwords = 8; // per lane of the exchange array
 // exchange word 0
@@ -103,7 +161,8 @@ struct PkLane {
 };
 
 // ---- phase 1
-MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p, const PkPic &x, uint32_t k)
+MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p, const PkPic &x, uint32_t k, const mpeghip_mb_desc &mb,
+                      const PkWin &in)
 {
     PkLane L;
     L.live = k < p.mb_count ? 1u : 0u;
@@ -119,7 +178,6 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
         L.blk[i] = 0;
     if (!L.live)
         return L;
-    const mpeghip_mb_desc mb = a.mbs[L.gi];
     const bool intra = (mb.flags & MPEGHIP_MB_INTRA) != 0, raw = (mb.flags & MPEGHIP_MB_COEF_RAW) != 0;
     const uint32_t nref = ((mb.flags & MPEGHIP_MB_REF_FWD) ? 1u : 0u) + ((mb.flags & MPEGHIP_MB_REF_BWD) ? 1u : 0u);
     const uint32_t nb = (uint32_t)__builtin_popcount(mb.cbp & 0x3fu);
@@ -204,21 +262,20 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
     if (!intra || mb.cbp == 0x3f) // (an invalid intra block keeps the old pixels: no whole-row stores for its chunk)
         L.flags |= kPkXRunOk;
     // ---- its coded blocks: count word by count word (each tells where the next one is)
-    const uint32_t *in = a.words_in + x.word_first;
     uint32_t at = mb.coef_off;
     bool bad = false;
 #pragma unroll
     for (int b = 0; b < 6; b++) { // (blk[] is indexed by the block number: static register indices)
         if (!(mb.cbp & (0x20u >> b)) || bad)
             continue;
-        const uint32_t cnt = at < x.n_words ? in[at] : 65u;
+        const uint32_t cnt = at < x.n_words ? pk_word(in, at) : 65u;
         if (cnt > 64 || (raw && cnt != 64) || at + 1 + cnt > x.n_words) { // (at <= n_words <= 2^30: no wrap)
             bad = true;
             continue;
         }
         uint32_t kind = raw ? kPkRawBlk : kPkSparseBlk;
         if (!raw) {
-            if (intra && (cnt == 0 || (in[at + 1] & 0xfcu))) { // an intra block's DC comes first
+            if (intra && (cnt == 0 || (pk_word(in, at + 1) & 0xfcu))) { // an intra block's DC comes first
                 bad = true;
                 continue;
             }
@@ -228,7 +285,7 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
             if (cnt > kDenseAbove) {
                 bool as_unit = true;
                 for (uint32_t i = intra ? 1u : 0u; i < cnt && as_unit; i++) {
-                    const int32_t level = (int16_t)(in[at + 1 + i] >> 16);
+                    const int32_t level = (int16_t)(pk_word(in, at + 1 + i) >> 16);
                     as_unit = level != 0 && level >= -kRcDenseLevelMax && level <= kRcDenseLevelMax;
                 }
                 kind = as_unit ? kPkDenseBlk : kPkSparseBlk;
@@ -288,7 +345,7 @@ MPG_HD void pk_share(uint32_t *xch, int lane, const PkLane &L)
 // ---- phase 3.  next_coef_off: coef_off of the macroblock behind lane 63's (the caller loads it; the picture's n_words
 // behind its last macroblock)
 MPG_HD void pk_emit(const PackArgs &a, const mpeghip_pic_desc &p, const PkPic &x, uint32_t k, int lane, const PkLane &L, const uint32_t *xch,
-                    uint32_t next_coef_off)
+                    uint32_t next_coef_off, const PkWin &in, const PkOut &out)
 {
     const uint32_t k0 = k & ~3u;
     if (k0 >= p.mb_count)
@@ -360,45 +417,46 @@ MPG_HD void pk_emit(const PackArgs &a, const mpeghip_pic_desc &p, const PkPic &x
     if (!mine || !L.nb)
         return;
     // ---- my blocks' words
-    const uint32_t *in = a.words_in + x.word_first + L.coef_off;
-    uint32_t *bw = a.words_out + W, *e0 = bw + n_slots;
+    const uint32_t bw = W, e0 = W + n_slots; // (dword indices into the packed words)
     uint32_t ent_at = ent_base, def_at = ne + def_base, stray = 0, s = slot_base;
 #pragma unroll
     for (int b = 0; b < 6; b++) {
         const uint32_t w = L.blk[b], cnt = (w >> 16) & 0x7fu, kind = (w >> 24) & 3u;
         if (!(w >> 31))
             continue;
-        const uint32_t *pr = in + (w & 0xffffu) + 1;
+        const uint32_t pr = L.coef_off + (w & 0xffffu) + 1; // (index of the block's first pair in the picture's words)
         uint32_t word = (rc_tile_offset(b, 0, m) >> 3) | (b >= 4 ? kBChroma : 0u) | (kind == kPkRawBlk ? kBRaw : 0u);
         if (kind == kPkRawBlk) {
             word |= def_at << 12;
             for (uint32_t t = 0; t < 64; t++)
-                e0[def_at + t] = pr[t];
+                pk_put(out, e0 + def_at + t, pk_word(in, pr + t));
             def_at += 64;
         } else if (kind == kPkDenseBlk) { // the block as a unit: 64 int16 levels by position
             word |= kBDense | (L.qscale << 26) | (L.intra ? 0u : 1u << 31) | (def_at << 12);
             for (uint32_t t = 0; t < 32; t++)
-                e0[def_at + t] = 0;
-            uint16_t *unit = reinterpret_cast<uint16_t *>(e0 + def_at);
+                pk_put(out, e0 + def_at + t, 0u);
             for (uint32_t t = 0; t < cnt; t++) {
-                stray |= pr[t];
-                unit[(pr[t] >> 2) & 63u] = (uint16_t)(pr[t] >> 16);
+                const uint32_t pair = pk_word(in, pr + t), pos = (pair >> 2) & 63u;
+                stray |= pair;
+                pk_put16(out, e0 + def_at + (pos >> 1), pos & 1u, (uint16_t)(pair >> 16));
             }
             def_at += 32;
         } else {
             uint32_t t = 0;
             if (L.intra) { // the DC pair comes first; it rides in the block word
-                stray |= pr[0];
-                word |= kBDcWord | ((pr[0] >> 16) << 12);
+                const uint32_t dc = pk_word(in, pr);
+                stray |= dc;
+                word |= kBDcWord | ((dc >> 16) << 12);
                 t = 1;
             }
             const uint32_t bits = (L.qscale << 11) | (L.intra ? 0u : kENonIntra) | ((s & 7u) << 8);
             for (; t < cnt; t++) {
-                stray |= pr[t];
-                e0[ent_at++] = pr[t] | bits;
+                const uint32_t pair = pk_word(in, pr + t);
+                stray |= pair;
+                pk_put(out, e0 + ent_at++, pair | bits);
             }
         }
-        bw[s++] = word;
+        pk_put(out, bw + s++, word);
     }
     if (stray & 0xff03u) // bits outside a pair's two fields
         pk_report(a, L.gi, kPkSparse);

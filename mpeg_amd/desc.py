@@ -83,7 +83,53 @@ class SlotRotation:
 def to_sparse(mbs, coefs, keep_zero_dc: bool = True):
     """The same picture in the SPARSE hand-over form (include/mpeghip.h: mpeghip_video_stage_put_sparse): per coded block
     a count word and one pair word `level << 16 | position << 2` per non-zero level of its unit (position order; an intra
-    block's DC first, present even when 0), per snapshot block the count word 64 and its 64 int32 values.  -> (mbs with coef_off in dwords, words)"""
+    block's DC first, present even when 0), per snapshot block the count word 64 and its 64 int32 values.  Macroblocks name
+    their words in order (every macroblock's coef_off = where the previous one's data ended).  -> (mbs with coef_off in
+    dwords, words)"""
+    mbs = np.array(mbs, dtype=MB_DTYPE, copy=True)
+    n = len(mbs)
+    raw_bytes = np.ascontiguousarray(coefs).view(np.uint8).reshape(-1)
+    if n == 0:
+        return mbs, np.zeros(0, np.uint32)
+    n_units = raw_bytes.size // COEF_UNIT
+    units16 = raw_bytes[:n_units * COEF_UNIT].view(np.int16).reshape(-1, 64)
+    units32 = raw_bytes[:n_units * COEF_UNIT].view(np.int32).reshape(-1, 32)
+    nb = _POPCOUNT6[mbs["cbp"].astype(np.int64) & 0x3f]
+    intra = (mbs["flags"] & MB_INTRA) != 0
+    raw = (mbs["flags"] & MB_COEF_RAW) != 0
+    blk_mb = np.repeat(np.arange(n), nb)                                  # owning macroblock of every coded block
+    first_blk = np.cumsum(nb) - nb
+    blk_k = np.arange(len(blk_mb)) - first_blk[blk_mb]                    # ordinal among the macroblock's coded blocks
+    b_raw, b_intra = raw[blk_mb], intra[blk_mb]
+    unit = mbs["coef_off"].astype(np.int64)[blk_mb] + blk_k * np.where(b_raw, 2, 1)
+    u = units16[np.where(b_raw, 0, unit)] if len(blk_mb) else np.zeros((0, 64), np.int16)
+    mask = (u != 0) & ~b_raw[:, None]
+    if keep_zero_dc:
+        mask[:, 0] |= b_intra & ~b_raw
+    cnt = mask.sum(axis=1)
+    size = np.where(b_raw, 65, 1 + cnt)                                   # dwords per block
+    blk_at = np.cumsum(size) - size
+    mb_size = np.zeros(n, np.int64)
+    np.add.at(mb_size, blk_mb, size)
+    mbs["coef_off"] = np.cumsum(mb_size) - mb_size
+    words = np.zeros(int(size.sum()), np.uint32)
+    words[blk_at] = np.where(b_raw, 64, cnt)
+    rows, cols = np.nonzero(mask)                                         # row-major: a block's positions ascending
+    rank = np.arange(len(rows)) - (np.cumsum(cnt) - cnt)[rows]
+    words[blk_at[rows] + 1 + rank] = (u[rows, cols].astype(np.uint16).astype(np.uint32) << 16) | (cols.astype(np.uint32) << 2)
+    r = np.nonzero(b_raw)[0]
+    if len(r):
+        src = (unit[r][:, None] * 32 + np.arange(64)[None, :]).reshape(-1)
+        dst = (blk_at[r][:, None] + 1 + np.arange(64)[None, :]).reshape(-1)
+        words[dst] = units32.reshape(-1)[src].view(np.uint32)
+    return mbs, words
+
+
+_POPCOUNT6 = np.array([bin(i).count("1") for i in range(64)], np.int64)
+
+
+def to_sparse_loop(mbs, coefs, keep_zero_dc: bool = True):
+    """to_sparse written as the header describes it, block by block (tests compare the two)."""
     mbs = np.array(mbs, dtype=MB_DTYPE, copy=True)
     raw_bytes = np.ascontiguousarray(coefs).view(np.uint8).reshape(-1)
     units16 = raw_bytes.view(np.int16).reshape(-1, 64) if raw_bytes.size else np.zeros((0, 64), np.int16)

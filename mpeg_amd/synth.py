@@ -82,16 +82,20 @@ def _choose(rng, n, probs):
     return rng.choice(len(probs), size=n, p=np.asarray(probs) / np.sum(probs))
 
 
-def _levels(rng, n_blocks, counts, first_pos):
+def _levels(rng, n_blocks, counts, first_pos, natural=False):
     """Quantised levels [n_blocks, 64] in NATURAL order: `counts[i]` coefficients at
-    scan positions >= first_pos[i], biased toward the low-frequency end."""
+    scan positions >= first_pos[i], biased toward the low-frequency end.  natural: magnitudes as encoders leave them (geometric:
+    half of the levels +-1, a quarter +-2 ...; the "natural" profile) instead of uniform 1..8 with 2 % of large ones."""
     key = rng.random((n_blocks, 64)) + np.arange(64)[None, :] * 0.08
     key[np.arange(64)[None, :] < first_pos[:, None]] = np.inf
     rank = np.argsort(np.argsort(key, axis=1), axis=1)
     present = rank < counts[:, None]
-    mag = rng.integers(1, 9, size=(n_blocks, 64))
-    esc = rng.random((n_blocks, 64)) < 0.02
-    mag = np.where(esc, rng.integers(1, 256, size=(n_blocks, 64)), mag)
+    if natural:
+        mag = np.minimum(rng.geometric(0.5, size=(n_blocks, 64)), 255)
+    else:
+        mag = rng.integers(1, 9, size=(n_blocks, 64))
+        esc = rng.random((n_blocks, 64)) < 0.02
+        mag = np.where(esc, rng.integers(1, 256, size=(n_blocks, 64)), mag)
     sign = np.where(rng.random((n_blocks, 64)) < 0.5, -1, 1)
     scan = np.where(present, mag * sign, 0)
     nat = np.zeros_like(scan)
@@ -199,7 +203,7 @@ def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", 
             counts = np.where(dc_only, 1, 1 + np.minimum(rng.geometric(1 / 7.7, size=nblk), 62))
         first_pos = np.where(b_intra, 1, 0)
         counts = np.where(b_intra, counts - 1, counts)            # intra: the DC is coded separately
-        nat = _levels(rng, nblk, counts, first_pos)
+        nat = _levels(rng, nblk, counts, first_pos, natural=profile == "natural")
         dc = rng.integers(16, 241, size=nblk)
         nat[:, 0] = np.where(b_intra, dc, nat[:, 0])
         b_raw = raw[blk_mb]

@@ -62,6 +62,8 @@ def lib():
             f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, P, P, P]
         L.emu_set_device_pack.restype = None
         L.emu_set_device_pack.argtypes = [C.c_int]
+        L.emu_set_pack_window.restype = None
+        L.emu_set_pack_window.argtypes = [C.c_uint32]
         L.emu_pack_sparse.restype = C.c_uint32
         L.emu_pack_sparse.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, P, P, P, C.c_uint64, P, P, P, C.c_uint64]
         L.emu_pack_device_picture.restype = C.c_uint64
@@ -97,6 +99,12 @@ def set_device_pack(on=0):
     lib().emu_set_device_pack(int(on))
 
 
+def set_pack_window(dwords=4096):
+    """The device packer's LDS window in dwords (pack_kernel's is 4096): tests shrink it so that a wave's reads fall inside,
+    across and beyond it."""
+    lib().emu_set_pack_window(int(dwords))
+
+
 def pack_sparse_host(g, stride, rgba_stride, pic, mbs, words, out_room=None):
     """The host packer on one sparse picture -> (chunks [n, 24], words) or None if it refuses the picture."""
     pic = np.ascontiguousarray(np.asarray(pic).reshape(1), desc.PIC_DTYPE)
@@ -123,7 +131,7 @@ def pack_sparse_device(g, stride, rgba_stride, pic, mbs, words, word_first=0, ch
     words = np.ascontiguousarray(words, np.uint32)
     n_chunks = (int(pic["mb_count"][0]) + 3) // 4
     chunks = np.zeros((chunk_first + n_chunks + 1, 24), np.uint32)
-    staged = np.concatenate([np.full(word_first, 0xABABABAB, np.uint32), words])
+    staged = np.concatenate([np.full(word_first, 0xABABABAB, np.uint32), words, np.full(16, 0xABABABAB, np.uint32)])  # (the buffer is padded)
     out = np.full(word_first + len(words) + 1, 0xDEADBEEF, np.uint32)
     use = C.c_uint32(0)
     err = lib().emu_pack_device_picture(g["luma_w"], g["luma_h"], stride, rgba_stride, _ptr(pic), word_first, len(words), chunk_first,

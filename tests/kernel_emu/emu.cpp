@@ -43,11 +43,13 @@ static uint32_t emu_pack_as(uint32_t luma_w, uint32_t luma_h, uint64_t frame_str
 }
 static thread_local int g_device_pack = 0; // (per thread: ShardedVideoBatch tests run two emulator stores on two threads)
 // 1: sparse pictures are packed by the DEVICE packer's lane functions (video_pack_lane.h), wave by wave
+static uint32_t g_pack_window = kPkWinDwords; // the device packer's LDS window (pack_kernel: kPkWinDwords)
 static int g_tile_policy = 0; // as mpeghip_video_set_tile_policy: 0 = pick per submit like launch_batch, 1 = int16 tile, 2 = int32 tile
 extern "C" {
 
 void emu_set_tile_policy(int policy) { g_tile_policy = policy; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
+void emu_set_pack_window(uint32_t dwords) { g_pack_window = dwords; }
 
 // pack_kernel for ONE picture, wave by wave: its descriptors and sparse words (n_words dwords behind words_in + aux.word_first)
 // -> chunks (from aux.chunk_first) and words_out (from aux.word_first).  Returns the error word (kPkNoError = fine).
@@ -73,6 +75,7 @@ unsigned long long emu_pack_device_picture(uint32_t luma_w, uint32_t luma_h, uin
     a.seen = seen.data();
     a.err = &err;
     a.n_pics = 1;
+    a.win_dwords = g_pack_window;
     a.groups_per_pic = (p.mb_count + 63) / 64;
     a.luma_w = luma_w;
     a.chroma_w = luma_w / 2;
@@ -85,16 +88,37 @@ unsigned long long emu_pack_device_picture(uint32_t luma_w, uint32_t luma_h, uin
     for (uint32_t g = 0; g < a.groups_per_pic; g++) {
         uint32_t xch[64 * kPkXchDwords];
         PkLane L[64];
+        const uint32_t k_next = g * 64 + 64;
+        const uint32_t next_coef_off = k_next < p.mb_count ? mbs[p.mb_first + k_next].coef_off : 0u;
+        // phase 0: the wave's window (g_pack_window dwords at most: tests shrink it so that reads fall on both sides of its end)
+        std::vector<uint32_t> win(g_pack_window + 4, 0xCDCDCDCDu);
+        PkWin in;
+        in.glob = words_in + word_first;
+        in.lds = win.data();
+        pk_window_range(mbs[p.mb_first + g * 64].coef_off, k_next < p.mb_count ? next_coef_off : n_words, n_words, g_pack_window, in.lo, in.n);
+        for (uint32_t i = 0; i < in.n; i += 4) // (16 bytes per lane and load: up to 3 dwords past the range, inside the padded buffer)
+            memcpy(win.data() + i, in.glob + in.lo + i, 16);
+        std::vector<uint32_t> wout(g_pack_window + 4, 0xEFEFEFEFu); // the window of the produced words (uninitialised LDS on the device)
+        PkOut out;
+        out.glob = words_out;
+        out.lds = wout.data();
+        out.base = word_first + in.lo;
+        out.n = in.n;
         for (int lane = 0; lane < 64; lane++) {
-            L[lane] = pk_scan(a, 0, p, aux, g * 64 + (uint32_t)lane);
+            const uint32_t k = g * 64 + (uint32_t)lane;
+            mpeghip_mb_desc mb;
+            memset(&mb, 0, sizeof(mb));
+            if (k < p.mb_count)
+                mb = mbs[p.mb_first + k];
+            L[lane] = pk_scan(a, 0, p, aux, k, mb, in);
             use |= L[lane].ok ? L[lane].use : 0u;
         }
         for (int lane = 0; lane < 64; lane++)
             pk_share(xch, lane, L[lane]);
-        const uint32_t k_next = g * 64 + 64;
-        const uint32_t next_coef_off = k_next < p.mb_count ? mbs[p.mb_first + k_next].coef_off : 0u;
         for (int lane = 0; lane < 64; lane++)
-            pk_emit(a, p, aux, g * 64 + (uint32_t)lane, lane, L[lane], xch, next_coef_off);
+            pk_emit(a, p, aux, g * 64 + (uint32_t)lane, lane, L[lane], xch, next_coef_off, in, out);
+        for (uint32_t i = mbs[p.mb_first + g * 64].coef_off - in.lo; i < out.n; i++) // (the wave's own territory only)
+            words_out[out.base + i] = wout[i];
     }
     if (use_out)
         *use_out = use;
@@ -178,7 +202,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         }
     }
     std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1),
-        words((g_device_pack ? (size_t)n_pics : 1) * rc_max_words_sparse(sparse_dwords, n_mbs) + rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
+        words((g_device_pack ? (size_t)n_pics : 1) * (rc_max_words_sparse(sparse_dwords, n_mbs) + 16) + rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
     uint32_t nc = 0, nw = 0;
     uint64_t coded = 0, dense = 0;
     std::vector<uint32_t> staged; // (device packer: the picture's words where the staged copy would have them)
@@ -200,7 +224,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                     dense += (words[h[3] + i] & kBDense) ? 1 : 0;
             }
             nc += pic_chunks;
-            nw += n_sparse;
+            nw += (n_sparse + 15) / 16 * 16; // (as the product's staging: a picture's words begin on a 64-byte boundary)
             continue;
         }
         const RcPacked got = pic_sparse[p] ? rc_pack_picture<true, true>(geom, pics[p], mbs + pics[p].mb_first, pics[p].mb_count, coefs, nw,
@@ -216,7 +240,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         dense += got.dense_blocks;
     }
     // which kernel instance: the product's rule (mpeghip.hip: launch_batch), unless a test pins one
-    bool t16 = dense * 4 <= coded;
+    bool t16 = dense * 3 <= coded * 2;
     if (g_tile_policy)
         t16 = g_tile_policy == 1;
     a.pics = pics;

@@ -11,8 +11,9 @@ Syntax choices that keep it small and exact:
   * P and B macroblocks always carry their (single) vector: forward, or backward for descriptors that name the
     backward reference — the reference decoder never averages two predictions (video.go:626-630), and the
     generator's descriptors name exactly one;
-  * AC coefficients (and the first coefficient of non-intra blocks) are written as escape codes (run 6 bits,
-    level 8 / 16 bits) — always legal — so Table B.5c is not needed in the write direction;
+  * coefficients are written with the run / level codes of Table B.5c-g wherever the table has a code for (run, |level|)
+    and as escape codes (run 6 bits, level 8 / 16 bits) elsewhere — what an encoder does; `table=False` writes escapes only
+    (always legal; the parser's worst case, and what rounds 1-3 measured);
   * the other tables are read from the host parser's own code list (mpeg_amd/host/iso11172_vlc_codes.h).
 The tests decode the result with the product (parser -> descriptors -> device) AND with the oracle's parser and
 compare both with the oracle's reconstruction of the ORIGINAL descriptors: a wrong code here cannot go unnoticed.
@@ -40,9 +41,9 @@ def _tables():
     out = {}
     for m in re.finditer(r"mpg_vlc_code (\w+)\[\] = \{(.*?)\};", text, re.S):
         codes = {}
-        for bits, value, dead in re.findall(r'\{"([01]+)", (-?\d+), (\d)\}', m.group(2)):
+        for bits, value, dead in re.findall(r'\{"([01]+)", (-?(?:0x[0-9a-fA-F]+|\d+)), (\d)\}', m.group(2)):
             if dead == "0":
-                codes.setdefault(int(value), bits)
+                codes.setdefault(int(value, 0), bits)
         out[m.group(1)] = codes
     return out
 
@@ -117,15 +118,31 @@ def _dc(b: Bits, table: str, value: int, pred: int) -> int:
     return value
 
 
-def _coefficients(b: Bits, scan_levels, first: int):
-    """(run, level) escapes for scan positions >= first, then end_of_block."""
+COEFF = {v: bits for v, bits in T["mpg_vlc_dct_coeff"].items() if v not in (0x0001, 0xffff)}   # run << 8 | abs(level) -> code
+
+
+def _coefficients(b: Bits, scan_levels, first: int, table: bool = True):
+    """The block's (run, level) symbols for scan positions >= first, then end_of_block (ISO 11172-2 2.4.2.8, Table B.5c-g;
+    read back by video.go:680-716 through the tree of video.go:1306-1419).  table: the code of Table B.5 where it has one for
+    (run, |level|) — `1s` for (0, 1) as a non-intra block's very first coefficient, `11s` later — and the escape (run 6 bits,
+    level 8 / 16 bits) elsewhere; False: escapes only (rounds 1-3's writer: the parser's worst case)."""
     prev = first - 1
     for pos in np.flatnonzero(scan_levels[first:]) + first:
         level = int(scan_levels[pos])
         assert -255 <= level <= 255
-        b.put(0b000001, 6)
-        b.put(int(pos) - prev - 1, 6)
+        run = int(pos) - prev - 1
         prev = int(pos)
+        if table and run == 0 and abs(level) == 1:
+            b.code("1" if (first == 0 and pos == 0) else "11")   # dct_coeff_first / dct_coeff_next
+            b.put(1 if level < 0 else 0, 1)
+            continue
+        code = COEFF.get((run << 8) | abs(level)) if (table and run < 32 and abs(level) < 256) else None
+        if code is not None:
+            b.code(code)
+            b.put(1 if level < 0 else 0, 1)
+            continue
+        b.put(0b000001, 6)
+        b.put(run, 6)
         if -127 <= level <= 127:
             b.put(level, 8)
         elif level > 0:
@@ -135,8 +152,10 @@ def _coefficients(b: Bits, scan_levels, first: int):
     b.put(0b10, 2)
 
 
-def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5) -> bytes:
-    """seq: list of mpeg_amd.synth.Submit (decode order, no MPEGHIP_MB_COEF_RAW macroblocks)."""
+def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5, table: bool = True, repeat: int = 1) -> bytes:
+    """seq: list of mpeg_amd.synth.Submit (decode order, no MPEGHIP_MB_COEF_RAW macroblocks).  table: coefficients as Table B.5
+    codes where the table has one (False: every coefficient as an escape code).  repeat: the group of pictures `repeat` times
+    over (a longer stream of the same pictures for throughput runs: every group starts with its I picture)."""
     g = desc.geometry(width, height)
     b = Bits()
     b.start_code(0xB3)
@@ -150,6 +169,8 @@ def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5) -> by
     b.put(0, 1)                 # constrained parameters flag
     b.put(0, 1)                 # default intra matrix
     b.put(0, 1)                 # default non-intra matrix
+    head = b.bytes()            # (start codes are byte aligned: the stream is header | group | group ... | end code)
+    b = Bits()
     b.start_code(0xB8)          # group of pictures
     b.put(0, 25)
     b.put(1, 1)                 # closed gop
@@ -209,11 +230,13 @@ def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5) -> by
                     k += 1
                     if intra:
                         plane = 0 if blk < 4 else blk - 3
-                        table = "mpg_vlc_dct_dc_size_luma" if blk < 4 else "mpg_vlc_dct_dc_size_chroma"
-                        dc_pred[plane] = _dc(b, table, int(scan[0]), dc_pred[plane])
-                        _coefficients(b, scan, 1)
+                        dc_table = "mpg_vlc_dct_dc_size_luma" if blk < 4 else "mpg_vlc_dct_dc_size_chroma"
+                        dc_pred[plane] = _dc(b, dc_table, int(scan[0]), dc_pred[plane])
+                        _coefficients(b, scan, 1, table)
                     else:
                         assert scan.any()
-                        _coefficients(b, scan, 0)
+                        _coefficients(b, scan, 0, table)
+    group = b.bytes()
+    b = Bits()
     b.start_code(0xB7)
-    return b.bytes()
+    return head + group * repeat + b.bytes()

@@ -67,6 +67,25 @@ def test_device_packed_equals_host_packed(emu, w, h, n, profile, raw, rgba):
             assert use == want_use
 
 
+@pytest.mark.parametrize("window", [0, 40, 333, 4096])
+def test_the_lds_window_changes_nothing(emu, window):
+    """pack_kernel reads a wave's words through an LDS window of 4 096 dwords and from memory beyond it: with windows that end
+    inside a macroblock's data, inside a block, or are not there at all, the packed form is the same."""
+    w, h = 176, 144
+    g, stride, rgba_stride = _geom(emu, w, h)
+    emu.set_pack_window(window)
+    try:
+        for profile, raw in (("typical", 0.1), ("dense", 0.0)):
+            for s in synth.generate_sequence(w, h, 3, profile=profile, raw_fraction=raw, seed=0x31):
+                mbs, words = desc.to_sparse(s.mbs, s.coefs)
+                host = emu.pack_sparse_host(g, stride, rgba_stride, s.pics[0], mbs, words)
+                err, dc, dw, _ = emu.pack_sparse_device(g, stride, rgba_stride, s.pics[0], mbs, words, 16, 2)
+                assert err == NO_ERROR
+                _compare_packed(host, dc, dw, 16)
+    finally:
+        emu.set_pack_window(4096)
+
+
 def test_device_packed_pictures_reconstruct_like_the_oracle(oracle, emu):
     """The whole path on the CPU: device packer's lanes -> reconstruction kernel's lanes, against the oracle; both kernel instances,
     a stream other than 0, coded zero levels and sparse gaps between macroblocks' data."""

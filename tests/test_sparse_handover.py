@@ -182,3 +182,11 @@ def test_mutated_sparse_words_are_refused_or_reconstructed_never_worse(oracle, e
             assert_planes_equal(ref.read_planes(0, slot), dut.read_planes(0, slot), "seed %d slot %d" % (seed, slot))
         compared += 1
     assert refused >= 20 and accepted >= 20 and compared >= 10, (refused, accepted, compared)
+
+
+@pytest.mark.parametrize("w,h,profile,raw", [(352, 240, "typical", 0.2), (96, 64, "dense", 0.0), (50, 35, "typical", 0.5)])
+def test_the_vectorised_to_sparse_equals_the_block_by_block_one(w, h, profile, raw):
+    for keep in (True, False):
+        for s in synth.generate_sequence(w, h, 3, profile=profile, raw_fraction=raw, seed=w):
+            a, b = desc.to_sparse(s.mbs, s.coefs, keep), desc.to_sparse_loop(s.mbs, s.coefs, keep)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

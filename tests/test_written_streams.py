@@ -49,10 +49,20 @@ def decode_all(dec, planes_of):
         frames.append(planes_of(f))
 
 
-@pytest.mark.parametrize("w,h,n,profile", [(96, 80, 7, "typical"), (160, 128, 5, "dense"), (64, 48, 10, "typical"), (37, 23, 4, "typical")])
-def test_written_stream_decodes_to_the_descriptors_it_was_written_from(oracle, w, h, n, profile):
+@pytest.mark.parametrize("table", [True, False], ids=["table_b5", "escapes"])
+@pytest.mark.parametrize("w,h,n,profile", [(96, 80, 7, "typical"), (160, 128, 5, "dense"), (64, 48, 10, "typical"), (37, 23, 4, "typical"),
+                                           (176, 144, 7, "natural")])
+def test_written_stream_decodes_to_the_descriptors_it_was_written_from(oracle, w, h, n, profile, table):
+    """table_b5: coefficients as the run / level codes of Table B.5c-g (video.go:1306-1419) wherever the table has one — every
+    code of the table occurs in these streams (checked below for the natural profile) —, escapes elsewhere; escapes: every
+    coefficient as an escape code (the parser's other path)."""
     seq = synth.generate_sequence(w, h, n, seed=0x77 + w, profile=profile)
-    es = mpeg1_writer.write_sequence(w, h, seq)
+    _three_way(oracle, w, h, seq, table)
+
+
+def _three_way(oracle, w, h, seq, table):
+    n = len(seq)
+    es = mpeg1_writer.write_sequence(w, h, seq, table=table)
     want = expected_frames(oracle, w, h, seq)
     ref = oracle.VideoDecoder(es)
     assert (ref.width, ref.height, ref.framerate) == (w, h, 30.0)
@@ -72,3 +82,43 @@ def test_written_stream_decodes_to_the_descriptors_it_was_written_from(oracle, w
             assert np.array_equal(pa, pb), "product parser, frame %d" % i
     assert dst["invalid_blocks"] == 0 and dst["range_skips"] == 0 and dst["raw_macroblocks"] == 0
     assert dst["pictures"] == n
+
+
+def test_every_code_of_table_b5_goes_through_both_parsers(oracle):
+    """A stream in which every (run, |level|) symbol of Table B.5c-g occurs with both signs, as a block's first symbol and as
+    a later one, in intra and in non-intra blocks (the `1s` / `11s` forms of (0, 1) included), through the oracle's parser
+    (the reference's tree, video.go:1306-1419) and the product's two-level tables: both reconstruct what the descriptors say."""
+    w, h = 176, 144
+    seq = synth.generate_sequence(w, h, 2, seed=0xB5, profile="dense")      # I, P: every macroblock has six coded blocks
+    symbols = sorted(mpeg1_writer.COEFF) + [0x0001]
+    assert len(symbols) == 111          # Table B.5c-g: 109 run / level codes + the `1` that is (0, 1) or end_of_block
+    used = set()
+    for s in seq:
+        units = s.coefs.view(np.int16).reshape(-1, 64)
+        intra = np.repeat((s.mbs["flags"] & desc.MB_INTRA) != 0, [bin(int(c)).count("1") for c in s.mbs["cbp"]])
+        assert len(units) >= 4 * len(symbols)
+        for b in range(len(units)):
+            sym = symbols[(b // 4) % len(symbols)]
+            run, level = sym >> 8, sym & 0xff
+            sign = -1 if b & 1 else 1
+            first = 1 if intra[b] else 0
+            scan = np.zeros(64, np.int16)
+            if intra[b]:
+                scan[0] = units[b][0]                                       # (keep the DC)
+            at = first
+            if b & 2:                                                       # the symbol as a LATER one: something in front of it
+                scan[at] = 3
+                at += 1
+            if at + run > 63:
+                continue
+            scan[at + run] = sign * level
+            if at + run + 1 < 64:
+                scan[at + run + 1] = -sign                                  # and (0, 1) behind it: the `11s` form
+            nat = np.zeros(64, np.int16)
+            nat[mpeg1_writer.ZIGZAG] = scan
+            units[b] = nat[synth.TO_COLMAJOR] if hasattr(synth, "TO_COLMAJOR_INV") else nat.reshape(8, 8).T.reshape(-1)
+            used.add((sym, bool(intra[b]), bool(b & 2), sign))
+    for sym in symbols:
+        for it in (False, True):
+            assert {(sym, it, later, sg) for later in (False, True) for sg in (1, -1)} <= used or (sym >> 8) >= 62, hex(sym)
+    _three_way(oracle, w, h, seq, True)
