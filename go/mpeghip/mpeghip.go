@@ -73,7 +73,15 @@ func lastError(rc C.int) error {
 // Context owns one GPU + stream.
 type Context struct{ h *C.mpeghip_ctx }
 
+// ABIVersion is the MPEGHIP_ABI_VERSION this binding was written against; NewContext refuses a libmpeghip of another version
+// (version 2: snapshot blocks of the sparse form carry a count word, macroblocks name their words in order, chroma as
+// Cb|Cr pairs in device memory, device-packed stages with deferred errors).
+const ABIVersion = 2
+
 func NewContext(device int) (*Context, error) {
+	if int(C.mpeghip_abi_version()) != ABIVersion || C.MPEGHIP_ABI_VERSION != ABIVersion {
+		return nil, errors.New("mpeghip: libmpeghip has another ABI version than this binding")
+	}
 	c := &Context{}
 	if err := lastError(C.mpeghip_ctx_create(C.int(device), nil, &c.h)); err != nil {
 		return nil, err // no GPU: there is no CPU fallback
@@ -213,7 +221,11 @@ func (v *Video) SubmitBatch(pics []PicDesc, mbs []MbDesc, coefs []byte) error {
 
 // Stage is one submit assembled picture by picture; Put may be called from several goroutines for
 // distinct i (one parser goroutine per stream), Commit from the goroutine that owns the context.
-type Stage struct{ h *C.mpeghip_stage }
+type Stage struct {
+	h      *C.mpeghip_stage
+	nMbs   []uint32 // device-packed stages: the sizes Map slices by
+	nWords []uint64
+}
 
 // StageBegin reserves room for len(nMbs) pictures of the given sizes in the next pinned staging buffer.
 func (v *Video) StageBegin(nMbs []uint32, coefBytes []uint64) (*Stage, error) {
@@ -275,6 +287,47 @@ func (s *Stage) PutSparse(i int, pic *PicDesc, mbs []MbDesc, words []uint32) err
 	return lastError(C.mpeghip_video_stage_put_sparse(s.h, C.uint32_t(i), (*C.mpeghip_pic_desc)(unsafe.Pointer(pic)),
 		(*C.mpeghip_mb_desc)(mp), (*C.uint32_t)(wp)))
 }
+
+// StageBeginDevice opens a DEVICE-PACKED stage (mpeghip_video_stage_begin_device): PutSparse only copies the picture's arrays
+// into pinned staging, Commit sends them as they are and the GPU validates and packs them in front of the reconstruction.
+// Sparse pictures only.  ERRORS ARE DEFERRED: Commit returns nil with the work in flight; a malformed picture makes the
+// whole commit reconstruct nothing and is reported once by the next call that waits for the device — Sync, ReadPlanes(Of),
+// RGBA, or the StageBegin* / Submit* that reuses the commit's staging buffer (include/mpeghip.h).
+func (v *Video) StageBeginDevice(nMbs []uint32, nWords []uint64) (*Stage, error) {
+	s := &Stage{}
+	if len(nMbs) == 0 || len(nMbs) != len(nWords) {
+		return nil, errors.New("mpeghip: StageBeginDevice: nMbs and nWords must have the same, non-zero length")
+	}
+	sizes := make([]C.size_t, len(nWords))
+	for i, n := range nWords {
+		sizes[i] = C.size_t(n)
+	}
+	if err := lastError(C.mpeghip_video_stage_begin_device(v.h, C.uint32_t(len(nMbs)), (*C.uint32_t)(unsafe.Pointer(&nMbs[0])),
+		&sizes[0], &s.h)); err != nil {
+		return nil, err
+	}
+	s.nMbs, s.nWords = nMbs, nWords
+	return s, nil
+}
+
+// Map returns picture i's arrays INSIDE the pinned staging buffer of a device-packed stage (C memory of the library, valid
+// until Commit): a parser that records its descriptors and pair words there hands them over with PutMapped and no copy at all.
+func (s *Stage) Map(i int) ([]MbDesc, []uint32, error) {
+	var mp *C.mpeghip_mb_desc
+	var wp *C.uint32_t
+	if err := lastError(C.mpeghip_video_stage_map(s.h, C.uint32_t(i), &mp, &wp)); err != nil {
+		return nil, nil, err
+	}
+	return unsafe.Slice((*MbDesc)(unsafe.Pointer(mp)), int(s.nMbs[i])), unsafe.Slice((*uint32)(unsafe.Pointer(wp)), int(s.nWords[i])), nil
+}
+
+// PutMapped marks picture i, written through Map, complete.
+func (s *Stage) PutMapped(i int, pic *PicDesc) error {
+	return lastError(C.mpeghip_video_stage_put_mapped(s.h, C.uint32_t(i), (*C.mpeghip_pic_desc)(unsafe.Pointer(pic))))
+}
+
+// Sync waits for everything queued on the handle and returns (once) the deferred error of a device-packed commit, if any.
+func (v *Video) Sync() error { return lastError(C.mpeghip_video_sync(v.h)) }
 
 // Commit sends the staged pictures and reconstructs them (asynchronous, like Submit); the Stage is over.
 func (s *Stage) Commit() error {

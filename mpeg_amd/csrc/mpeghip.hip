@@ -1437,7 +1437,7 @@ static int reap_all(mpeghip_video *v)
 }
 
 // Which instance of the reconstruction kernel a batch runs on: the int32-tile one when more than two thirds of its coded blocks
-// are dense units.  Measured (profiles/r4c_dense_share_crossover.txt: 256 1080p streams at their own GOP phases, a share of
+// are dense units.  Measured (profiles/round4_c_dense_share_crossover.txt: 256 1080p streams at their own GOP phases, a share of
 // them with dense content, both instances interleaved on one box): dense block share 0.01 / 0.41 / 0.68 / 0.86 / 1.00 ->
 // int16 +3.2 % / int16 +1.7 % / tie / int32 +1.6 % / int32 +1.9 %.  (Rounds 2-3 switched at a quarter: a guess between the
 // two measured ends, on the wrong side of the 0.41 point.)  A device-packed commit, whose blocks the host has not looked
@@ -1982,7 +1982,7 @@ static int mpeghip_video_stage_begin_device_impl(mpeghip_video *v, uint32_t n_pi
 // A put's copy into the pinned staging buffer, with NON-TEMPORAL stores.  A plain memcpy leaves the lines dirty in the
 // core's caches: the H2D copy that follows then has to get them out of there line by line (the DMA engine's reads are
 // snooped), and it reads for ownership what it is about to overwrite.  Measured with 8 putting threads: 43 GB/s over PCIe
-// with memcpy against 63 GB/s when nothing had touched the buffer since it was written (profiles/r4c_*).  Streaming stores go
+// with memcpy against 63 GB/s when nothing had touched the buffer since it was written (profiles/round4_b_*, round4_d_*: the staged hand-over sweeps).  Streaming stores go
 // to memory past the caches; the fence at the end orders them before the commit's copy is queued.
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
 __attribute__((target("avx2"))) static void stream_copy_avx2(uint8_t *dst, const uint8_t *src, size_t n)

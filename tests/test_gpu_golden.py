@@ -101,7 +101,7 @@ def test_program_stream_facade_on_gpu(oracle, golden_dir, device):
     L.mpeghost_mpeg_close(m)
 
 
-def test_seek_bookkeeping_does_not_depend_on_the_backend(emu, golden_dir, device):
+def test_seek_host_logic_runs_the_same_over_either_backend_no_parity_claim(emu, golden_dir, device):
     """MPEG.Seek / SeekFrame (mpeg.go:460-576) are host logic: frame times, the callback count of a seek (mpeg_test.go:
     442-461: exactly one) and the audio / video clocks must come out the same whichever backend reconstructs the frames.
     (NOT a parity test of the frames: those are compared with the ORACLE's in

@@ -5,7 +5,7 @@ Launches in which a share of the STREAMS carries the dense worst-case content (e
 typical content, all at their own GOP phases (mpeg_amd/mixed.py), timed on the int16-tile instance and on the int32-tile one,
 interleaved on one box (mpeghip_video_set_tile_policy).  Prints, per share: the batch's share of dense BLOCKS (what
 launch_batch looks at), its sparse-form dwords per macroblock (what a device-packed commit looks at), ms per step on either
-instance.   python tools/sweep_dense_share.py [streams] > profiles/rNN_dense_share_crossover.txt"""
+instance.   python tools/sweep_dense_share.py [streams] > profiles/round4_c_dense_share_crossover.txt"""
 import sys
 import time
 from pathlib import Path
