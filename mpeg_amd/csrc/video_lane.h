@@ -84,7 +84,10 @@ MPG_HD void idct8(int32_t (&v)[8])
     const int32_t tmp2 = v[3] + v[5];
     const int32_t b6 = v[1] - v[7];
     const int32_t b7 = tmp1 + tmp2;
-    const int32_t m0 = v[0];
+    // (row pass: the final `+ 128 >> 8` of video.go:916-925.  Every one of the eight outputs is m0 plus or minus the other
+    // terms — m0 enters each exactly once, with a plus sign — so the 128 is added to m0 once instead of to every output:
+    // the same integers, seven additions fewer per pass.  tests/test_int_ranges.py carries the bound.)
+    const int32_t m0 = kFinalShift ? v[0] + 128 : v[0];
     const int32_t x4 = ((mul24(b6, 473) - mul24(b4, 196) + 128) >> 8) - b7;
     const int32_t x0 = x4 - ((mul24(tmp1 - tmp2, 362) + 128) >> 8);
     const int32_t x1 = m0 - b1;
@@ -106,7 +109,7 @@ MPG_HD void idct8(int32_t (&v)[8])
     if (kFinalShift) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            v[k] = (v[k] + 128) >> 8;
+            v[k] >>= 8;
     }
 }
 

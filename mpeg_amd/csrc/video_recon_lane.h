@@ -86,7 +86,8 @@ constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                         
 constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32, kRSlow = 64; // record d0
 constexpr uint32_t kBChroma = 1u << 9, kBRaw = 1u << 10, kBDense = 1u << 11, kBDcWord = 1u << 28;    // block word
 constexpr uint32_t kDenseAbove = 32; // non-zero levels beyond which a block travels as a dense unit
-constexpr int32_t kRcDenseLevelMax = 16383; // ... if none of them is beyond this (rc_dense_pair works on 16-bit halves)
+constexpr int32_t kRcDenseLevelMax = 528;  // ... if none of them is beyond this: the dense path's packed 16-bit forms hold 2 * 31 * level + 31
+                                             // (rc_dense_cols<true>; an MPEG-1 level is within +-255: video.go:700-707)
 constexpr uint32_t kENonIntra = 2;                                                         // entry
 
 // wave-private LDS
@@ -926,6 +927,123 @@ template <int R> MPG_HD int32_t rc_dense_level_flat(const RcPair &p, int32_t qs,
 {
     return rc_dense_finish<R>(mul_s16<R & 1>((uint32_t)qs, p.u), p, pm);
 }
+// ---- the same on PACKED halves from end to end (round 4).  With the matrix entry 16 the reference's chain collapses:
+// u = 2 level + sign is odd, so l = u * quantiser_scale is even exactly when quantiser_scale is, and "one toward zero if
+// even" takes sign(level) off it then: l = A level + e sign(level) with A = 2 quantiser_scale, e = (quantiser_scale - 1) | 1
+// — odd by construction (the `| 1` has nothing left to do), 0 for a level of 0, and within int16 for levels up to
+// kRcDenseLevelMax.  Per PAIR of levels: sign (2 packed instructions), A level (1), + e sign (1), the clamp to
+// [-2048, 2047] (2), then the two premultiplies, whose operand select unpacks the halves: 8 instructions where the 32-bit
+// form took 18 (33 -> 17 issue clocks per level, profiles/r02j_valu_issue_rates.txt).
+MPG_HD uint32_t pk_sign_i16(uint32_t w) // per half: -1, 0, +1
+{
+#if MPG_ON_DEVICE
+    uint32_t t, r;
+    asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(w));
+    asm("v_pk_max_i16 %0, %1, -1 op_sel_hi:[1,0]" : "=v"(r) : "v"(t));
+    return r;
+#else
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+        const int32_t x = (int16_t)(w >> (16 * h));
+        r |= (uint32_t)(uint16_t)((x > 0) - (x < 0)) << (16 * h);
+    }
+    return r;
+#endif
+}
+MPG_HD uint32_t pk_mul_lo_i16(uint32_t a, uint32_t b) // per half: a * b (callers keep it within int16)
+{
+#if MPG_ON_DEVICE
+    uint32_t r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+        const int32_t x = (int32_t)(int16_t)(a >> (16 * h)) * (int32_t)(int16_t)(b >> (16 * h));
+        MPG_CHECK(x >= -32768 && x <= 32767);
+        r |= (uint32_t)(uint16_t)x << (16 * h);
+    }
+    return r;
+#endif
+}
+MPG_HD uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) // per half: a * b + c (within int16)
+{
+#if MPG_ON_DEVICE
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+        const int32_t x = (int32_t)(int16_t)(a >> (16 * h)) * (int32_t)(int16_t)(b >> (16 * h)) + (int32_t)(int16_t)(c >> (16 * h));
+        MPG_CHECK(x >= -32768 && x <= 32767);
+        r |= (uint32_t)(uint16_t)x << (16 * h);
+    }
+    return r;
+#endif
+}
+MPG_HD uint32_t pk_clamp12_i16(uint32_t x, uint32_t lo2, uint32_t hi2) // per half: clamp(x, -2048, 2047); lo2 / hi2: the bounds in both halves
+{
+#if MPG_ON_DEVICE
+    uint32_t t, r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(x), "s"(lo2));
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(t), "s"(hi2));
+    return r;
+#else
+    (void)lo2;
+    (void)hi2;
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++)
+        r |= (uint32_t)(uint16_t)clampi((int16_t)(x >> (16 * h)), -2048, 2047) << (16 * h);
+    return r;
+#endif
+}
+// a pair of levels (rows 2k, 2k + 1 of the lane's column) -> their dequantised, clamped values in the two halves
+#ifndef MPG_DENSE_SAT16
+#define MPG_DENSE_SAT16 1
+#endif
+MPG_HD uint32_t pk_mad_sat_i16(uint32_t a, uint32_t b, uint32_t c) // per half: saturate_int16(a * b + c), the sum in full precision
+{
+#if MPG_ON_DEVICE
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+        const int32_t x = (int32_t)(int16_t)(a >> (16 * h)) * (int32_t)(int16_t)(b >> (16 * h)) + (int32_t)(int16_t)(c >> (16 * h));
+        r |= (uint32_t)(uint16_t)clampi(x, -32768, 32767) << (16 * h);
+    }
+    return r;
+#endif
+}
+MPG_HD uint32_t pk_ashr4_i16(uint32_t x)
+{
+#if MPG_ON_DEVICE
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, 4, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(x));
+    return r;
+#else
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++)
+        r |= (uint32_t)(uint16_t)((int16_t)(x >> (16 * h)) >> 4) << (16 * h);
+    return r;
+#endif
+}
+// a2 / e2: 16 A / 16 e in both halves.  The clamp to [-2048, 2047] is the multiply-add's own saturation at sixteen times the
+// scale — 16 l saturates at +-32767 / -32768, whose sixteenth (an arithmetic shift) is 2047 / -2048 — one instruction in the
+// place of a packed maximum and a packed minimum (MPG_DENSE_SAT16 0: those).
+MPG_HD uint32_t rc_dense_pair_flat(uint32_t w, uint32_t a2, uint32_t e2)
+{
+    const uint32_t sg = pk_sign_i16(w);
+#if MPG_DENSE_SAT16
+    return pk_ashr4_i16(pk_mad_sat_i16(w, a2, pk_mul_lo_i16(sg, e2)));
+#else
+    const uint32_t l = pk_mad_i16(sg, e2, pk_mul_lo_i16(w, a2));
+    return pk_clamp12_i16(l, 0xf800f800u, 0x07ff07ffu);
+#endif
+}
+
 // Is column j = lane & 7 of the stream's non-intra matrix all 16?  (The wave's AND over its lanes answers for the matrix.)
 MPG_HD bool rc_non_intra_column_flat(const uint8_t *lds, int lane)
 {
@@ -957,16 +1075,18 @@ MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, i
 #endif
     if (kFlat) {
         MPG_CHECK(!intra && rc_non_intra_column_flat(lds, lane));
-        const RcPair p0 = rc_dense_pair((uint32_t)lv.v[0], ~0u), p1 = rc_dense_pair((uint32_t)lv.v[1], ~0u);
-        const RcPair p2 = rc_dense_pair((uint32_t)lv.v[2], ~0u), p3 = rc_dense_pair((uint32_t)lv.v[3], ~0u);
-        v[0] = rc_dense_level_flat<0>(p0, qs, pm);
-        v[1] = rc_dense_level_flat<1>(p0, qs, pm);
-        v[2] = rc_dense_level_flat<2>(p1, qs, pm);
-        v[3] = rc_dense_level_flat<3>(p1, qs, pm);
-        v[4] = rc_dense_level_flat<4>(p2, qs, pm);
-        v[5] = rc_dense_level_flat<5>(p2, qs, pm);
-        v[6] = rc_dense_level_flat<6>(p3, qs, pm);
-        v[7] = rc_dense_level_flat<7>(p3, qs, pm);
+        const uint32_t a1 = (uint32_t)qs << (MPG_DENSE_SAT16 ? 5 : 1), e1 = (((uint32_t)qs - 1) | 1) << (MPG_DENSE_SAT16 ? 4 : 0); // A, e of the block (x 16); in both halves:
+        const uint32_t a2 = a1 | (a1 << 16), e2 = e1 | (e1 << 16);
+        const uint32_t l0 = rc_dense_pair_flat((uint32_t)lv.v[0], a2, e2), l1 = rc_dense_pair_flat((uint32_t)lv.v[1], a2, e2);
+        const uint32_t l2 = rc_dense_pair_flat((uint32_t)lv.v[2], a2, e2), l3 = rc_dense_pair_flat((uint32_t)lv.v[3], a2, e2);
+        v[0] = mul_u8_s16<0, 0>(pm[0], l0); // the premultiply (video.go:744): byte r of the column's eight x half r & 1
+        v[1] = mul_u8_s16<1, 1>(pm[0], l0);
+        v[2] = mul_u8_s16<2, 0>(pm[0], l1);
+        v[3] = mul_u8_s16<3, 1>(pm[0], l1);
+        v[4] = mul_u8_s16<0, 0>(pm[1], l2);
+        v[5] = mul_u8_s16<1, 1>(pm[1], l2);
+        v[6] = mul_u8_s16<2, 0>(pm[1], l3);
+        v[7] = mul_u8_s16<3, 1>(pm[1], l3);
         return;
     }
     // the column's 8 matrix entries of both classes (16 bytes: position j * 8 + r -> bytes 2r, 2r + 1)

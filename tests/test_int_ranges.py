@@ -47,7 +47,7 @@ def idct8_forms(v, final_shift, lim, record):
     tmp2 = v[3] + v[5]
     b6 = v[1] - v[7]
     b7 = tmp1 + tmp2
-    m0 = v[0]
+    m0 = Form(v[0].c, v[0].slack + (128.0 if final_shift else 0.0))   # the row pass adds the final rounding's 128 to m0 (idct8)
     mulcheck(b6, 473), mulcheck(b4, 196)
     s1 = Form(b6.c * 473 - b4.c * 196, b6.slack * 473 + b4.slack * 196 + 128)
     record("sum", s1.bound(lim))
@@ -68,7 +68,7 @@ def idct8_forms(v, final_shift, lim, record):
     for t in (b3, b4, tmp1, tmp2, b6, b7, x4, x0, x1, x2, x3, y3, y4, y5, y6, y7, *outs):
         record("sum", t.bound(lim))
     if final_shift:
-        outs = [Form(o.c / 256.0, o.slack / 256.0 + 1.5) for o in outs]
+        outs = [Form(o.c / 256.0, o.slack / 256.0 + 1.0) for o in outs]
     return outs
 
 

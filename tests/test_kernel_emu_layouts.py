@@ -104,8 +104,9 @@ def test_levels_over_the_whole_int16_range(oracle, emu_layout):
 
 
 def test_dense_units_with_zeros_large_levels_and_extreme_matrices(oracle, emu_layout):
-    """The dense path works on packed 16-bit halves (2 level + sign must fit: the packer keeps levels beyond +-16383 out of
-    it), takes a zero level through the whole chain as 0, and multiplies by any matrix byte, 0 and 1 included."""
+    """The dense path works on packed 16-bit halves (2 * quantiser_scale * level + quantiser_scale must fit: the packer keeps
+    levels beyond +-528 out of it), takes a zero level through the whole chain as 0, and multiplies by any matrix byte, 0 and 1
+    included."""
     rng = np.random.default_rng(9)
     for trial in range(4):
         w, h = 96, 64
@@ -115,10 +116,10 @@ def test_dense_units_with_zeros_large_levels_and_extreme_matrices(oracle, emu_la
             units = sub.coefs.view(np.int16).reshape(-1, 64)
             for u in range(len(units)):
                 pick = rng.choice(64, size=24, replace=False)
-                beyond = [16384, -16384] if u % 5 == 0 else []   # (one unit in five: beyond the dense path -> entries)
-                units[u, pick] = rng.choice([16383, -16383, 8191, -8192, 255, -255, 1, -1, 0, 0, 0] + beyond,
+                beyond = [529, -529, 16384, -16384] if u % 5 == 0 else []   # (one unit in five: beyond the dense path -> entries)
+                units[u, pick] = rng.choice([528, -528, 527, -500, 255, -255, 1, -1, 0, 0, 0] + beyond,
                                             size=len(pick)).astype(np.int16)
-                n_dense += int(np.count_nonzero(units[u]) > 32 and np.abs(units[u, 1:].astype(np.int32)).max() <= 16383)
+                n_dense += int(np.count_nonzero(units[u]) > 32 and np.abs(units[u, 1:].astype(np.int32)).max() <= 528)
             sub.mbs["qscale"] = rng.choice([1, 2, 31, 17], size=len(sub.mbs))
         assert n_dense > 100
         o, e = oracle.OracleStore(w, h), emu_layout.EmuStore(w, h)
