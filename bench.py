@@ -216,6 +216,8 @@ def traffic_of(profile, rgba, streams, args):
         return None, None, None
     try:
         j = json.loads(tp.read_text())
+        if "current" in j:  # (a pointer to the profile set of the shipped sources, not a copy of it)
+            j = json.loads((ROOT / "profiles" / j["current"]).read_text())
         t = j.get(profile + ("_rgba" if rgba else ""), {})
         if t.get("streams") == streams:
             return t.get("hbm_bytes_per_launch"), t.get("source"), j.get("csrc_sha256") == sources_sha256()

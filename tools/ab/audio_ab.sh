@@ -4,7 +4,7 @@ cp mpeg_amd/libmpeghip.so /tmp/cur.so
 VARIANTS="cur $(ls tools/ab/libmpeghip_*.so 2>/dev/null | sed 's/.*libmpeghip_\(.*\)\.so/\1/')"
 for r in 1 2 3; do for v in $VARIANTS; do
   if [ $v = cur ]; then cp /tmp/cur.so mpeg_amd/libmpeghip.so; else cp tools/ab/libmpeghip_$v.so mpeg_amd/libmpeghip.so; fi
-  python bench.py --steps 2 --warmup 1 --streams 16 --legs "" --cpu-seconds 0 --check 1 --host-fed-seconds 0 --single-stream 0 --audio-tile 8 2>/dev/null | python -c "
+  python bench.py --steps 2 --warmup 1 --streams 16 --legs "" --cpu-seconds 0 --check ${CHECK:-1} --host-fed-seconds 0 --single-stream 0 --audio-tile 8 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); d=j['audio']
 print('round $r %-12s audio %.4g pairs/s frac %.4f %.4f ms %s' % ('$v', d['value'], d['roofline']['frac'], d['ms_per_launch'], d['parity']))
