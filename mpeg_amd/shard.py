@@ -61,7 +61,19 @@ class Ranks:
         if self.world > 1:
             import torch.distributed as dist
             kw = {"device_id": device_id} if (device_id is not None and backend == "nccl") else {}
-            dist.init_process_group(backend, **kw)
+            # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to 7 peer ranks ..."), where bench.py's
+            # one JSON line belongs: stdout points at stderr while the group forms (the first barrier completes the mesh)
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend, **kw)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.dist = dist
         self.backend = backend
         self.last_local = 0.0   # this rank's own elapsed time of the last timed() body
