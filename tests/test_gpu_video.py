@@ -172,6 +172,7 @@ def test_malformed_descriptors_are_refused_and_nothing_is_launched(oracle, hip_c
         corrupt("flags", desc.MB_INTRA | desc.MB_REF_FWD), corrupt("flags", 0),
         corrupt("stream", 1, "pics"), corrupt("cur", 3, "pics"), corrupt("fwd", 7, "pics"), corrupt("bwd", 200, "pics"),
         corrupt("mb_count", len(good.mbs) + 1, "pics"), corrupt("mb_first", 5, "pics"),
+        corrupt("flags", 0x40, "pics"), corrupt("flags", 0x04, "pics"),   # undefined picture flag bits (they must not pick the coefficient form)
     ]
     # every macroblock names the first units of a buffer that holds only as many as the largest macroblock needs: the packed
     # form's buffers are sized from the coefficient buffer, blocks may not share units beyond it

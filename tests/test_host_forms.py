@@ -82,3 +82,22 @@ def test_every_vlc_table_agrees_with_its_code_list_for_every_prefix():
     ISO 11172-2 lists, dead ends of the reference's tree (buffer.go:352-376) included: all 2^17 looks for the coefficient
     table, all 2^L for the others."""
     assert hostlib.host().mpeghost_debug_vlc_self_check() == 0
+
+
+def test_the_form_may_be_switched_at_any_time(oracle, golden_dir):
+    """Video::SetSparse between any two Decode calls: the form is latched when a picture begins (its offsets count either
+    units or dwords, never a mix — the round-3 advisor's finding), so a decoder toggled every few frames — with pictures
+    already parsed ahead of the frame it returned — still produces the reference's frames."""
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    dec = hostlib.HostVideo(es, emu_flavour=0)
+    h, n = oracle.FNV_OFFSET, 0
+    while True:
+        hostlib.host().mpeghost_video_set_sparse(dec.h, (n // 3) % 2)
+        f = dec.decode()
+        if f is None:
+            break
+        for p in hostlib.frame_planes(f):
+            h = oracle.fnv1a64(p, h)
+        n += 1
+    dec.close()
+    assert (h, n) == (VIDEO_HASH, 260)
