@@ -338,11 +338,19 @@ private:
 
     // per-picture recording
     std::vector<mpeghip_mb_desc> mbs_;
+    // The picture's coefficient bytes.  coefs_.size() runs AHEAD of what is recorded (it grows in large steps, and shrinks
+    // to coef_len_ when the arrays are handed over): in the sparse form the VLC loop writes a block's words straight behind the
+    // macroblock's earlier blocks — coef_len_ + mb_pending_ — and endMacroblockRecord only has to accept them.
     std::vector<uint8_t> coefs_;
+    size_t coef_len_ = 0;               // bytes recorded (whole macroblocks)
+    size_t mb_pending_ = 0;             // bytes the current macroblock's clean blocks have written behind coef_len_
+    uint8_t *coefRoom(size_t bytes);    // room for `bytes` behind coef_len_ + mb_pending_ (no recording; may move coefs_)
+    uint8_t *coefAppend(size_t bytes);  // `bytes` zeroed bytes recorded at coef_len_
     std::vector<uint8_t> written_;      // macroblock address already emitted in this submit
-    struct BlockRec { bool valid; bool needs_raw; int16_t q[64]; int32_t raw[64];
-                      uint8_t touched[64]; int n_touched; // natural indices this block's levels went to, in scan order
-                      uint32_t pairs[64]; };              // the same levels as MPEGHIP_PAIR words (the sparse hand-over), scan order
+    struct BlockRec { bool valid; bool needs_raw; int16_t q[64]; // (q: only [0] of an intra block and the touched indices are set)
+                      int32_t raw[64];
+                      uint8_t touched[64]; int n_touched; }; // natural indices this block's levels went to, in scan order
+    uint32_t pair_scratch_[66];         // where a block's pair words go when the picture is not in the sparse form
     struct MbRec { bool active = false, intra = false; int mb_x = 0, mb_y = 0; bool has_pred = false, backward = false;
                    int mv_x = 0, mv_y = 0; int qscale = 0; int cbp = 0; BlockRec blocks[6]; bool any_raw = false;
                    bool out_of_range = false; /* a copyMacroblock call of this macroblock would panic in the reference */ } rec_;

@@ -40,7 +40,9 @@ const VlcTable &tabDcSize(int plane)
     static const VlcTable tl(mpg_vlc_dct_dc_size_luma), tc(mpg_vlc_dct_dc_size_chroma);
     return plane == 0 ? tl : tc;
 }
-const VlcTable &tabCoeff() { static const VlcTable t(mpg_vlc_dct_coeff); return t; }
+const VlcTable &tabCoeff() { static const VlcTable t(mpg_vlc_dct_coeff); return t; }   // (the plain table: only the self-check reads it)
+const CoeffTable &tabCoeffFirst() { static const CoeffTable t(mpg_vlc_dct_coeff, true); return t; }
+const CoeffTable &tabCoeffNext() { static const CoeffTable t(mpg_vlc_dct_coeff, false); return t; }
 
 // the code a prefix starts with, found the slow way: the first code of the list that the prefix's leading bits spell out
 // (the lists are prefix-free: the reference's tree walk, buffer.go:352-376, ends at exactly that code)
@@ -63,6 +65,42 @@ uint64_t vlcMismatches(const mpg_vlc_code *codes, const VlcTable &table)
         }
         const VlcTable::Symbol got = table.at(prefix << (64 - L));
         bad += (got.value != value || got.len != len) ? 1 : 0;
+    }
+    return bad;
+}
+
+// CoeffTable against the plain table followed by the reads video.go:685-707 makes after the code, for every prefix
+uint64_t coeffMismatches(const CoeffTable &table, bool first)
+{
+    const int L = table.bits();
+    uint64_t bad = 0;
+    for (uint64_t prefix = 0; prefix < (1ull << L); prefix++) {
+        const uint64_t w = prefix << (64 - L);
+        const VlcTable::Symbol sym = tabCoeff().at(w);
+        const uint64_t rest = w << sym.len;
+        int kind, run = 0, level = 0, len = sym.len;
+        if (sym.value == 0x0001 && !first && (rest >> 63) == 0) {
+            kind = CoeffTable::kEnd;
+            len += 1;
+        } else if (sym.value == 0xffff) {
+            kind = CoeffTable::kEscape;
+        } else {
+            uint64_t r = rest;
+            if (sym.value == 0x0001 && !first) {
+                r <<= 1;
+                len += 1;
+            }
+            run = sym.value >> 8;
+            level = sym.value & 0xff;
+            if (r >> 63)
+                level = -level;
+            len += 1;
+            kind = level == 0 ? CoeffTable::kZero : CoeffTable::kCoef;
+        }
+        if (len > L)
+            continue; // (the prefix is shorter than this symbol with its sign: longer prefixes cover it)
+        const CoeffTable::Entry &e = table.at(w);
+        bad += (e.kind != kind || e.len != len || ((kind == CoeffTable::kCoef || kind == CoeffTable::kZero) && (e.run != run || e.level != level))) ? 1 : 0;
     }
     return bad;
 }
@@ -114,7 +152,7 @@ uint64_t Video::VlcSelfCheck()
            vlcMismatches(mpg_vlc_mb_type_p, tabType(2)) + vlcMismatches(mpg_vlc_mb_type_b, tabType(3)) +
            vlcMismatches(mpg_vlc_coded_block_pattern, tabCbp()) + vlcMismatches(mpg_vlc_motion_code, tabMotion()) +
            vlcMismatches(mpg_vlc_dct_dc_size_luma, tabDcSize(0)) + vlcMismatches(mpg_vlc_dct_dc_size_chroma, tabDcSize(1)) +
-           vlcMismatches(mpg_vlc_dct_coeff, tabCoeff());
+           vlcMismatches(mpg_vlc_dct_coeff, tabCoeff()) + coeffMismatches(tabCoeffFirst(), true) + coeffMismatches(tabCoeffNext(), false);
 }
 
 Video::Video(Buffer *buf, Device *dev) : buf_(buf), backend_(dev->newVideoBackend()) { init(); }
@@ -328,6 +366,7 @@ void Video::decodePicture()
 
     mbs_.clear();
     coefs_.clear();
+    coef_len_ = mb_pending_ = 0;
     std::fill(written_.begin(), written_.end(), 0);
     sparse_ = sparse_wanted_; // the hand-over form is latched per picture: its offsets count either units or dwords
 
@@ -363,11 +402,13 @@ void Video::flushSubmit()
     pic.mb_count = (uint32_t)mbs_.size();
     pic.flags = sparse_ ? MPEGHIP_PIC_SPARSE : 0;
     const size_t n_mbs = mbs_.size();
+    coefs_.resize(coef_len_); // (it ran ahead of the recording: coefRoom)
     backend_->submitOwned(pic, mbs_, coefs_); // (may swap the arrays for others)
     stats_.submits++;
     stats_.macroblocks += n_mbs;
     mbs_.clear();
     coefs_.clear();
+    coef_len_ = mb_pending_ = 0;
     std::fill(written_.begin(), written_.end(), 0);
 }
 
@@ -384,6 +425,23 @@ void Video::decodeSlice(int slice)
     do {
         decodeMacroblock();
     } while (macroblock_address_ < mb_size_ - 1 && buf_->peekNonZero(23));
+}
+
+uint8_t *Video::coefRoom(size_t bytes)
+{
+    const size_t at = coef_len_ + mb_pending_;
+    if (coefs_.size() < at + bytes)
+        coefs_.resize(at + bytes + (256u << 10)); // a picture grows its array a few times, not once per block
+    return coefs_.data() + at;
+}
+
+uint8_t *Video::coefAppend(size_t bytes)
+{
+    mb_pending_ = 0;
+    uint8_t *p = coefRoom(bytes);
+    memset(p, 0, bytes);
+    coef_len_ += bytes;
+    return p;
 }
 
 void Video::beginMacroblockRecord(bool intra)
@@ -407,6 +465,8 @@ void Video::beginMacroblockRecord(bool intra)
     rec_.mb_x = mb_col_;
     rec_.mb_y = mb_row_;
     rec_.qscale = quantizer_scale_;
+    mb_pending_ = 0;
+    coefRoom(6 * 66 * 4); // six blocks of a count word and 65 pairs at most: decodeBlock's pointers stay valid for the macroblock
 }
 
 void Video::emitPrediction(int mh, int mv, bool backward)
@@ -465,15 +525,24 @@ void Video::endMacroblockRecord()
         d.flags |= MPEGHIP_MB_COEF_RAW;
     d.cbp = (uint8_t)cbp;
     d.qscale = (uint8_t)(rec_.qscale < 1 ? 1 : (rec_.qscale > 31 ? 31 : rec_.qscale));
-    d.coef_off = (uint32_t)(coefs_.size() / (sparse_ ? 4 : MPEGHIP_COEF_UNIT)); // sparse pictures count dwords
+    d.coef_off = (uint32_t)(coef_len_ / (sparse_ ? 4 : MPEGHIP_COEF_UNIT)); // sparse pictures count dwords
     if (rec_.qscale < 1 && cbp)
         raw = true, d.flags |= MPEGHIP_MB_COEF_RAW; // quantiser_scale 0 (forbidden value): keep the reference's arithmetic
 
+    stats_.coded_blocks += (uint64_t)__builtin_popcount((unsigned)cbp);
+    if (!raw && sparse_) {
+        // The blocks are where the VLC loop wrote them: a count, then one pair per coded level (an intra block's DC first) — a
+        // device entry short of the bits the library's packer adds; a coded zero level stays a pair.  Every block that
+        // advanced mb_pending_ is valid and clean, and those are exactly the blocks of `cbp` here.
+        coef_len_ += mb_pending_;
+        mb_pending_ = 0;
+        mbs_.push_back(d);
+        return;
+    }
     for (int b = 0; b < 6; b++) {
         if (!(cbp & (0x20 >> b)))
             continue;
         const BlockRec &br = rec_.blocks[b];
-        stats_.coded_blocks++;
         if (raw) {
             int32_t snap[64];
             if (br.needs_raw) {
@@ -488,34 +557,17 @@ void Video::endMacroblockRecord()
                 if (rec_.intra)
                     snap[0] = (int32_t)br.q[0] * 256;
             }
-            size_t at = coefs_.size();
             if (sparse_) { // every block of the sparse form begins with its count word: 64 for a snapshot
-                coefs_.resize(at + 4);
                 const uint32_t n = 64;
-                memcpy(coefs_.data() + at, &n, 4);
-                at += 4;
+                memcpy(coefAppend(4), &n, 4);
             }
-            coefs_.resize(at + 2 * MPEGHIP_COEF_UNIT);
-            int32_t *dst = reinterpret_cast<int32_t *>(coefs_.data() + at);
+            int32_t *dst = reinterpret_cast<int32_t *>(coefAppend(2 * MPEGHIP_COEF_UNIT));
             for (int r = 0; r < 8; r++)
                 for (int c = 0; c < 8; c++)
                     dst[c * 8 + r] = snap[r * 8 + c]; // column-major
-        } else if (sparse_) {
-            // the block as the VLC loop produced it: a count, then one pair per coded level (an intra block's DC first) —
-            // a device entry short of the bits the library's packer adds.  A coded zero level stays a pair.
-            const size_t at = coefs_.size();
-            const uint32_t n = (uint32_t)br.n_touched + (rec_.intra ? 1u : 0u);
-            coefs_.resize(at + 4 * (size_t)(1 + n));
-            uint32_t *dst = reinterpret_cast<uint32_t *>(coefs_.data() + at);
-            *dst++ = n;
-            if (rec_.intra)
-                *dst++ = MPEGHIP_PAIR(br.q[0], 0);
-            memcpy(dst, br.pairs, 4 * (size_t)br.n_touched); // (written by decodeBlock, level by level)
         } else {
-            const size_t at = coefs_.size();
-            coefs_.resize(at + MPEGHIP_COEF_UNIT);
-            // column-major (the resize zero-filled the unit): only the positions the block's levels went to
-            int16_t *dst = reinterpret_cast<int16_t *>(coefs_.data() + at);
+            // column-major (coefAppend zero-filled the unit): only the positions the block's levels went to
+            int16_t *dst = reinterpret_cast<int16_t *>(coefAppend(MPEGHIP_COEF_UNIT));
             if (rec_.intra)
                 dst[0] = br.q[0];
             for (int k = 0; k < br.n_touched; k++) {
@@ -524,6 +576,7 @@ void Video::endMacroblockRecord()
             }
         }
     }
+    mb_pending_ = 0;
     if (raw)
         stats_.raw_macroblocks++;
     mbs_.push_back(d);
@@ -670,7 +723,6 @@ void Video::decodeBlock(int block)
     BlockRec &br = rec_.blocks[block];
     br.valid = false;
     br.needs_raw = false;
-    memset(br.q, 0, sizeof(br.q));
     int n = 0;
     const uint8_t *quant_matrix;
     // block_data_ mirrors the reference's persistent blockData.  It is all zero except
@@ -715,11 +767,19 @@ void Video::decodeBlock(int block)
     }
 
     uint8_t *touched = br.touched; // natural indices written by this block, in scan order
+    // The block's words of the sparse hand-over go straight to their place in the picture's array (beginMacroblockRecord made
+    // the room): count, an intra block's DC, then a pair per level from the loop below.  They only COUNT once the block turns
+    // out valid and clean (mb_pending_ below); a block that does not is overwritten by the next one.
+    uint32_t *const words = sparse_ ? reinterpret_cast<uint32_t *>(coefs_.data() + coef_len_ + mb_pending_) : pair_scratch_;
+    uint32_t *const pairs = words + (macroblock_intra_ ? 2 : 1);
     int n_touched = 0;
     br.n_touched = 0;
     int level = 0;
     bool invalid = false;
-    const VlcTable &coeff_table = tabCoeff();
+    // Intra blocks arrive here with n == 1 (their DC is read above), non-intra blocks with n == 0: only those can begin with
+    // the '1' that means run 0 / level 1 and not end_of_block (video.go:687).
+    const CoeffTable *const next_table = &tabCoeffNext();
+    const CoeffTable *coeff_table = n == 0 ? &tabCoeffFirst() : next_table;
     // The cursor lives in locals for the length of the block (nothing in here refills the buffer): the
     // byte stores below may alias anything, and would otherwise force the Buffer's members through memory
     // once per coefficient.
@@ -739,26 +799,30 @@ void Video::decodeBlock(int block)
         }
         return w << (bit & 7);
     };
+    // One 64-bit look at the stream serves as many symbols as fit: a table symbol is at most 18 bits with its sign, an escape
+    // 6 + 6 + 16, so a window with 28 valid bits left always holds the next one whole.  The table (CoeffTable) answers run,
+    // signed level and length in one probe: the dependent chain per coefficient is shift -> table -> shift.
+    uint64_t w = window();
+    int valid = 64 - (int)(bit & 7);
     for (;;) {
-        // One 64-bit look at the stream per coefficient: the code (<= 17 bits), then either its sign bit or the
-        // escape's run and level (<= 22 bits) — same fields, same order, same consumption as video.go:685-707
-        // reads them one by one; the dependent chain cursor -> load -> table -> cursor is walked once, not thrice.
-        int run;
-        const uint64_t w = window();
-        const VlcTable::Symbol sym = coeff_table.at(w);
-        const int coeff = sym.value;
-        uint64_t rest = w << sym.len; // what follows the code
-        int taken = sym.len;
-        if (coeff == 0x0001 && n > 0) { // '1' after the first coefficient: '10' = end_of_block, '11s' = run 0, level 1
-            taken++;
-            if ((rest >> 63) == 0) {
-                bit += (size_t)taken;
-                break;
-            }
-            rest <<= 1;
+        if (valid < 28) {
+            w = window();
+            valid = 64 - (int)(bit & 7);
         }
-        if (coeff == 0xffff) { // escape: run (6 bits), level (8 bits, or 8 + 8)
-            const uint32_t f = (uint32_t)(rest >> (64 - 22));
+        const CoeffTable::Entry &e = coeff_table->at(w);
+        coeff_table = next_table;
+        int run;
+        if (__builtin_expect(e.kind == CoeffTable::kCoef, 1)) {
+            run = e.run;
+            level = e.level;
+            bit += e.len;
+            w <<= e.len;
+            valid -= e.len;
+        } else if (e.kind == CoeffTable::kEnd) {
+            bit += e.len;
+            break;
+        } else if (e.kind == CoeffTable::kEscape) { // run (6 bits), level (8 bits, or 8 + 8): video.go:690-700
+            const uint32_t f = (uint32_t)((w << e.len) >> (64 - 22));
             run = (int)(f >> 16);
             const int b = (int)((f >> 8) & 0xff);
             int used = 14;
@@ -768,12 +832,19 @@ void Video::decodeBlock(int block)
                 level = (int)(f & 0xff) - (b ? 256 : 0);
                 used = 22;
             }
-            bit += (size_t)(taken + used);
-        } else {
-            run = coeff >> 8;
-            const int neg = (int)(rest >> 63); // sign bit, applied without a branch
-            level = ((coeff & 0xff) ^ -neg) + neg;
-            bit += (size_t)(taken + 1);
+            used += e.len;
+            bit += (size_t)used;
+            w <<= used;
+            valid -= used;
+            if (level == 0)
+                explicit_zero = true; // dequantises to +-1, which "0 = absent" cannot express
+        } else { // kZero: a dead end of the code tree reads as run 0, level 0 (+ the sign bit)
+            run = e.run;
+            level = 0;
+            bit += e.len;
+            w <<= e.len;
+            valid -= e.len;
+            explicit_zero = true;
         }
         n += run;
         if (n < 0 || n >= 64) {
@@ -782,10 +853,8 @@ void Video::decodeBlock(int block)
         }
         const int dz = kZigZag[n] & 63;
         n++;
-        if (level == 0)
-            explicit_zero = true; // dequantises to +-1, which "0 = absent" cannot express
         br.q[dz] = (int16_t)level;
-        br.pairs[n_touched] = MPEGHIP_PAIR(level, (dz & 7) * 8 + (dz >> 3)); // natural index row * 8 + column -> position column * 8 + row
+        pairs[n_touched] = MPEGHIP_PAIR(level, (dz & 7) * 8 + (dz >> 3)); // natural index row * 8 + column -> position column * 8 + row
         touched[n_touched++] = (uint8_t)dz;
         if (dirty_at_start)
             block_data_[dz] = dequantPremult(level, macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
@@ -818,6 +887,13 @@ void Video::decodeBlock(int block)
         // the common case: blockData held nothing but this block, and the reference clears it
         // again after use (video.go:777, 781-783, 790, 794-796) — nothing to keep on the host
         br.valid = true;
+        if (sparse_) {
+            const uint32_t count = (uint32_t)n_touched + (macroblock_intra_ ? 1u : 0u);
+            words[0] = count;
+            if (macroblock_intra_)
+                words[1] = MPEGHIP_PAIR(br.q[0], 0);
+            mb_pending_ += 4 * (size_t)(1 + count);
+        }
         return;
     }
 

@@ -86,4 +86,89 @@ private:
     std::vector<Entry> first_, rest_;
 };
 
+// The coefficient table with what FOLLOWS each code folded into the lookup (video.go:685-707 reads them one after the other:
+// the code; after a '1' that is not the block's first coefficient one bit that says end_of_block; then the sign bit — or, after
+// the escape code, run and level fields).  One probe of the next kFirst bits yields run, SIGNED level and the total length, or
+// says which of the rare cases it is; same fields, same order, same consumption as the reference, just not one bit at a time.
+// `first`: the table for a block's very first coefficient (n == 0: a non-intra block), where '1' is run 0 / level 1 and never
+// end_of_block.
+class CoeffTable {
+public:
+    enum Kind : uint8_t {
+        kCoef = 0,   // run, level != 0, len = code + sign bit (or '11s')
+        kEnd = 1,    // '10' after the first coefficient: end_of_block, len = 2
+        kEscape = 2, // len = the escape code alone; run (6 bits) and level (8 or 16 bits) follow
+        kZero = 3,   // a dead end of the reference's tree: it returns value 0 = run 0, level 0, and the sign bit is still read
+        kLink = 4,   // first level only: `level` is the offset of this prefix's second table
+    };
+    struct Entry {
+        int32_t level;
+        uint8_t run, len, kind, pad;
+    };
+    static constexpr int kFirst = 10;
+
+    CoeffTable(const mpg_vlc_code *codes, bool first)
+    {
+        int longest = 0;
+        for (const mpg_vlc_code *c = codes; c->bits; c++) {
+            const int L = (int)strlen(c->bits) + 2; // ('1' + end-of-block bit + sign is the only + 2, and it is short; + 1 elsewhere)
+            if (L - 1 > longest)
+                longest = L - 1;
+        }
+        bits_ = longest;
+        rest_bits_ = bits_ > kFirst ? bits_ - kFirst : 0;
+        first_.assign((size_t)1 << kFirst, Entry{0, 0, 0, kZero, 0});
+        for (const mpg_vlc_code *c = codes; c->bits; c++) {
+            const int L = (int)strlen(c->bits);
+            uint32_t code = 0;
+            for (int k = 0; k < L; k++)
+                code = (code << 1) | (uint32_t)(c->bits[k] - '0');
+            const int value = c->dead ? 0 : c->value;
+            if (value == 0xffff) {
+                put(code, L, Entry{0, 0, (uint8_t)L, kEscape, 0});
+            } else if (value == 0x0001 && !first) {
+                put(code << 1, L + 1, Entry{0, 0, (uint8_t)(L + 1), kEnd, 0});
+                put((code << 2) | 2, L + 2, Entry{1, 0, (uint8_t)(L + 2), kCoef, 0});
+                put((code << 2) | 3, L + 2, Entry{-1, 0, (uint8_t)(L + 2), kCoef, 0});
+            } else {
+                const int level = value & 0xff, run = value >> 8;
+                const uint8_t kind = level == 0 ? kZero : kCoef;
+                put(code << 1, L + 1, Entry{level, (uint8_t)run, (uint8_t)(L + 1), kind, 0});
+                put((code << 1) | 1, L + 1, Entry{-level, (uint8_t)run, (uint8_t)(L + 1), kind, 0});
+            }
+        }
+    }
+    int bits() const { return bits_; }
+    // the symbol whose code starts at the window's top bit
+    const Entry &at(uint64_t window) const
+    {
+        const Entry &e = first_[(size_t)(window >> (64 - kFirst))];
+        if (__builtin_expect(e.kind != kLink, 1))
+            return e;
+        return rest_[(size_t)e.level + (size_t)((window << kFirst) >> (64 - rest_bits_))];
+    }
+
+private:
+    void put(uint32_t code, int L, const Entry &e)
+    {
+        if (L <= kFirst) {
+            const uint32_t lo = code << (kFirst - L), n = 1u << (kFirst - L);
+            for (uint32_t k = 0; k < n; k++)
+                first_[lo + k] = e;
+            return;
+        }
+        Entry &link = first_[code >> (L - kFirst)];
+        if (link.kind != kLink) {
+            link = Entry{(int32_t)rest_.size(), 0, 0, kLink, 0};
+            rest_.resize(rest_.size() + ((size_t)1 << rest_bits_), Entry{0, 0, 0, kZero, 0});
+        }
+        const uint32_t tail = code & ((1u << (L - kFirst)) - 1);
+        const uint32_t lo = tail << (bits_ - L), n = 1u << (bits_ - L);
+        for (uint32_t k = 0; k < n; k++)
+            rest_[(size_t)link.level + lo + k] = e;
+    }
+    int bits_, rest_bits_;
+    std::vector<Entry> first_, rest_;
+};
+
 } // namespace mpeg

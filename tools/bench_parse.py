@@ -20,6 +20,7 @@ ap.add_argument("--root", default=None)
 ap.add_argument("--threads", default="1,8")
 ap.add_argument("--streams", default="escapes,table,natural")
 ap.add_argument("--pictures", type=int, default=7)
+ap.add_argument("--repeat", type=int, default=1, help="the group of pictures this many times over (a longer stream of the same pictures)")
 args = ap.parse_args()
 
 HERE = Path(__file__).resolve().parent.parent
@@ -49,6 +50,9 @@ for kind in args.streams.split(","):
     else:
         es = mpeg1_writer.write_sequence(1920, 1080, seq, table=kind != "escapes")
         cache.write_bytes(es)
+    if args.repeat > 1:   # header | group | end code -> header | group x repeat | end code (every group opens with its I picture)
+        g0 = es.index(b"\x00\x00\x01\xb8")
+        es = es[:g0] + es[g0:-4] * args.repeat + es[-4:]
     for threads in [int(x) for x in args.threads.split(",")]:
         streams = threads
         h = H.mpeghost_batch_open_store(E.host_emu_null_batch_store(), streams)
@@ -67,5 +71,5 @@ for kind in args.streams.split(","):
         H.mpeghost_batch_counters(h, C.byref(out))
         H.mpeghost_batch_close(h)
         print("%-8s 1080p stream (%4.0f kB per picture), %2d stream(s) on %2d thread(s): %3d pictures in %7.1f ms = %6.0f pictures/s"
-              " (%.3f ms per picture per thread)" % (kind, len(es) / len(seq) / 1e3, streams, threads, out[1], dt * 1e3, out[1] / dt,
+              " (%.3f ms per picture per thread)" % (kind, len(es) / len(seq) / args.repeat / 1e3, streams, threads, out[1], dt * 1e3, out[1] / dt,
                                                      dt * 1e3 * threads / out[1]), flush=True)
