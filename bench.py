@@ -657,14 +657,18 @@ def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
                      "pictures, %.0f kB per picture) parsed on %d host threads, handed over as device-packed staged commits, "
                      "reconstructed — NOT `value`" % (streams, gop * groups, len(es) / (gop * groups) / 1e3, threads),
            "streams": streams, "parse_threads": threads, "pictures_per_stream": gop * groups, "stream_bytes_per_picture": len(es) / (gop * groups)}
-    wide = max(1, min(4 * threads, streams, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else threads))
-    for name, device_pack, nthreads in (("device_packed", 1, threads), ("host_packed", 0, threads), ("device_packed_wide", 1, wide)):
-        b = H.mpeghost_batch_open(dev, streams)
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else threads
+    wide = max(1, min(4 * threads, cpus))
+    # (name, device-side packing, parse threads, streams): the wide runs show what more host threads buy — one picture per thread
+    # and round, then four
+    for name, device_pack, nthreads, nstreams in (("device_packed", 1, threads, streams), ("host_packed", 0, threads, streams),
+                                                  ("device_packed_wide", 1, wide, wide), ("device_packed_wide_x4", 1, wide, 4 * wide)):
+        b = H.mpeghost_batch_open(dev, nstreams)
         if not b:
             raise SystemExit("bench: host_parsed: %s" % H.mpeghost_last_error().decode())
         H.mpeghost_batch_set_threads(b, nthreads)
         H.mpeghost_batch_set_device_pack(b, device_pack)
-        for _ in range(streams):
+        for _ in range(nstreams):
             if H.mpeghost_batch_add_stream(b, es, len(es)) < 0:
                 raise SystemExit("bench: host_parsed: %s" % H.mpeghost_last_error().decode())
         t0 = time.perf_counter()
@@ -679,7 +683,7 @@ def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
         H.mpeghost_batch_close(b)
         pictures = int(cn[1])
         out[name] = {"pictures_per_s": pictures / dt, "pictures": pictures, "seconds": dt, "device_calls": int(cn[0]), "parse_threads": nthreads,
-                     "ms_parse_per_picture_per_thread": ph[0] * 1e3 * nthreads / max(pictures, 1),
+                     "streams": nstreams, "ms_parse_per_picture_per_thread": ph[0] * 1e3 * nthreads / max(pictures, 1),
                      "wall_seconds": {"parse_rounds": ph[0], "stage_begin": ph[1], "puts": ph[2], "commits": ph[3]}}
     H.mpeghost_device_destroy(dev)
     out["value"] = out["device_packed"]["pictures_per_s"]

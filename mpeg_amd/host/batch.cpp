@@ -9,6 +9,10 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <exception>
 #include <mutex>
 #include <stdexcept>
@@ -162,6 +166,11 @@ bool pinThisThreadToNode(int node)
     return n > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
 }
 
+// Workers sleep on a generation counter (a futex word), not on a condition variable: a condition variable hands its mutex
+// from one woken thread to the next, so waking 63 workers costs 63 lock hand-overs IN SERIES — milliseconds per run() on a
+// 64-thread pool, twice per picture round (parse, puts).  Here a run() bumps the counter and wakes everybody at once; workers
+// that finished the last run spin on the counter for about ten microseconds first (rounds follow each other closely), and the
+// caller learns of the end from a count of busy workers, the last of which wakes it.
 class VideoBatch::Pool {
 public:
     Pool(unsigned n, int numa_node)
@@ -179,40 +188,58 @@ public:
     std::atomic<unsigned> pins_asked_{0}, pins_failed_{0};
     ~Pool()
     {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
-        }
-        wake_.notify_all();
+        stop_.store(true, std::memory_order_release);
+        generation_.fetch_add(1, std::memory_order_release);
+        futexWake(&generation_, INT_MAX);
         for (std::thread &t : workers_)
             t.join();
     }
     // fn(k) for k in [0, n), each exactly once; returns when all are done; the first exception is rethrown
     void run(size_t n, const std::function<void(size_t)> &fn)
     {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &fn;
-            n_ = n;
-            next_.store(0);
-            busy_ = workers_.size();
-            error_ = nullptr;
-            generation_++;
-        }
-        wake_.notify_all();
+        fn_ = &fn;
+        n_ = n;
+        next_.store(0, std::memory_order_relaxed);
+        error_ = nullptr;
+        busy_.store((uint32_t)workers_.size(), std::memory_order_relaxed);
+        generation_.fetch_add(1, std::memory_order_release); // (publishes the four stores above)
+        futexWake(&generation_, INT_MAX);
         drain();
-        std::unique_lock<std::mutex> l(m_);
-        idle_.wait(l, [this] { return busy_ == 0; });
+        for (int spin = 0;;) { // every worker has passed through this generation when busy_ reaches 0
+            const uint32_t b = busy_.load(std::memory_order_acquire);
+            if (b == 0)
+                break;
+            if (spin < kSpins) {
+                spin++;
+                cpuRelax();
+            } else {
+                futexWait(&busy_, b);
+            }
+        }
         fn_ = nullptr;
         if (error_)
             std::rethrow_exception(error_);
     }
 
 private:
+    static constexpr int kSpins = 300; // x one pause instruction: about ten microseconds (longer spins cost a throttled container its CPU quota)
+    static void cpuRelax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    static void futexWait(std::atomic<uint32_t> *word, uint32_t seen)
+    { // sleeps only while *word == seen; spurious returns are fine (every caller re-checks)
+        syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+    }
+    static void futexWake(std::atomic<uint32_t> *word, int n) { syscall(SYS_futex, reinterpret_cast<uint32_t *>(word), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0); }
     void drain()
     {
         for (;;) {
-            const size_t k = next_.fetch_add(1);
+            const size_t k = next_.fetch_add(1, std::memory_order_relaxed);
             if (k >= n_)
                 return;
             try {
@@ -226,31 +253,35 @@ private:
     }
     void work()
     {
-        uint64_t seen = 0;
+        uint32_t seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> l(m_);
-                wake_.wait(l, [&] { return stop_ || generation_ != seen; });
-                if (stop_)
-                    return;
-                seen = generation_;
+            for (int spin = 0;;) {
+                const uint32_t g = generation_.load(std::memory_order_acquire);
+                if (g != seen) {
+                    seen = g;
+                    break;
+                }
+                if (spin < kSpins) {
+                    spin++;
+                    cpuRelax();
+                } else {
+                    futexWait(&generation_, seen);
+                }
             }
+            if (stop_.load(std::memory_order_acquire))
+                return;
             drain();
-            {
-                std::lock_guard<std::mutex> l(m_);
-                busy_--;
-            }
-            idle_.notify_one();
+            if (busy_.fetch_sub(1, std::memory_order_acq_rel) == 1)
+                futexWake(&busy_, 1);
         }
     }
     std::vector<std::thread> workers_;
-    std::mutex m_;
-    std::condition_variable wake_, idle_;
+    std::mutex m_; // error_ only
     const std::function<void(size_t)> *fn_ = nullptr;
-    size_t n_ = 0, busy_ = 0;
+    size_t n_ = 0;
     std::atomic<size_t> next_{0};
-    uint64_t generation_ = 0;
-    bool stop_ = false;
+    std::atomic<uint32_t> generation_{0}, busy_{0}; // futex words
+    std::atomic<bool> stop_{false};
     std::exception_ptr error_;
 };
 
