@@ -347,10 +347,11 @@ private:
     uint8_t *coefRoom(size_t bytes);    // room for `bytes` behind coef_len_ + mb_pending_ (no recording; may move coefs_)
     uint8_t *coefAppend(size_t bytes);  // `bytes` zeroed bytes recorded at coef_len_
     std::vector<uint8_t> written_;      // macroblock address already emitted in this submit
-    struct BlockRec { bool valid; bool needs_raw; int16_t q[64]; // (q: only [0] of an intra block and the touched indices are set)
-                      int32_t raw[64];
-                      uint8_t touched[64]; int n_touched; }; // natural indices this block's levels went to, in scan order
-    uint32_t pair_scratch_[66];         // where a block's pair words go when the picture is not in the sparse form
+    // What decodeBlock leaves of a block: an intra block's DC (clamped to int16; needs_raw says when that lost something),
+    // and its coded levels as MPEGHIP_PAIR words in scan order — in place in coefs_ for a sparse picture, in pair_scratch_
+    // otherwise; raw: the snapshot of blockData for the blocks that need the reference's own arithmetic.
+    struct BlockRec { bool valid; bool needs_raw; int16_t dc; int n_pairs; const uint32_t *pairs; int32_t raw[64]; };
+    uint32_t pair_scratch_[6][66];
     struct MbRec { bool active = false, intra = false; int mb_x = 0, mb_y = 0; bool has_pred = false, backward = false;
                    int mv_x = 0, mv_y = 0; int qscale = 0; int cbp = 0; BlockRec blocks[6]; bool any_raw = false;
                    bool out_of_range = false; /* a copyMacroblock call of this macroblock would panic in the reference */ } rec_;

@@ -112,10 +112,23 @@ constexpr int kStartPicture = 0x00, kStartSliceFirst = 0x01, kStartSliceLast = 0
 const double kPictureRate[16] = {0.000, 23.976, 24.000, 25.000, 29.970, 30.000, 50.000, 59.940,
                                  60.000, 0, 0, 0, 0, 0, 0, 0}; // ISO 11172-2 table 2-D.4 (video.go:1034-1037)
 
-const uint8_t kZigZag[64] = { // ISO 11172-2 zig-zag scan (video.go:1044-1053)
+constexpr uint8_t kZigZag[64] = { // ISO 11172-2 zig-zag scan (video.go:1044-1053)
     0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// scan index -> the level's place in a pair word: position column * 8 + row of natural index row * 8 + column, << 2
+struct ScanPos {
+    uint8_t v[64];
+    constexpr ScanPos() : v()
+    {
+        for (int n = 0; n < 64; n++)
+            v[n] = (uint8_t)((((kZigZag[n] & 7) * 8) + (kZigZag[n] >> 3)) << 2);
+    }
+};
+constexpr ScanPos kScanPos;
+inline int naturalIndexOfPair(uint32_t pair) { const int pos = (int)((pair >> 2) & 63); return (pos & 7) * 8 + (pos >> 3); }
+inline int levelOfPair(uint32_t pair) { return (int16_t)(pair >> 16); }
 
 const uint8_t kDefaultIntraQuant[64] = { // ISO default intra matrix (video.go:1055-1064)
     8,  16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37, 19, 22, 26, 27, 29, 34,
@@ -539,6 +552,15 @@ void Video::endMacroblockRecord()
         mbs_.push_back(d);
         return;
     }
+    // The rare forms.  The clean blocks' pair words may sit in coefs_ right where this macroblock's bytes are about to go
+    // (a sparse picture's raw macroblock): they are read from a copy.
+    uint32_t kept[6][66];
+    const uint32_t *pairs_of[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int b = 0; b < 6; b++)
+        if ((cbp & (0x20 >> b)) && !rec_.blocks[b].needs_raw) {
+            memcpy(kept[b], rec_.blocks[b].pairs, 4 * (size_t)rec_.blocks[b].n_pairs);
+            pairs_of[b] = kept[b];
+        }
     for (int b = 0; b < 6; b++) {
         if (!(cbp & (0x20 >> b)))
             continue;
@@ -550,12 +572,12 @@ void Video::endMacroblockRecord()
             } else { // this block was clean: dequantise it here so the whole macroblock shares one format
                 const uint8_t *qm = rec_.intra ? intra_quant_ : non_intra_quant_;
                 memset(snap, 0, sizeof(snap));
-                for (int k = 0; k < br.n_touched; k++) { // the coded levels — a coded ZERO among them dequantises to +-1
-                    const int i = br.touched[k];
-                    snap[i] = dequantPremult(br.q[i], rec_.intra, rec_.qscale, qm[i], i);
+                for (int k = 0; k < br.n_pairs; k++) { // the coded levels — a coded ZERO among them dequantises to +-1
+                    const int i = naturalIndexOfPair(pairs_of[b][k]);
+                    snap[i] = dequantPremult(levelOfPair(pairs_of[b][k]), rec_.intra, rec_.qscale, qm[i], i);
                 }
                 if (rec_.intra)
-                    snap[0] = (int32_t)br.q[0] * 256;
+                    snap[0] = (int32_t)br.dc * 256;
             }
             if (sparse_) { // every block of the sparse form begins with its count word: 64 for a snapshot
                 const uint32_t n = 64;
@@ -569,11 +591,9 @@ void Video::endMacroblockRecord()
             // column-major (coefAppend zero-filled the unit): only the positions the block's levels went to
             int16_t *dst = reinterpret_cast<int16_t *>(coefAppend(MPEGHIP_COEF_UNIT));
             if (rec_.intra)
-                dst[0] = br.q[0];
-            for (int k = 0; k < br.n_touched; k++) {
-                const int i = br.touched[k];
-                dst[(i & 7) * 8 + (i >> 3)] = br.q[i];
-            }
+                dst[0] = br.dc;
+            for (int k = 0; k < br.n_pairs; k++)
+                dst[(pairs_of[b][k] >> 2) & 63] = (int16_t)levelOfPair(pairs_of[b][k]);
         }
     }
     mb_pending_ = 0;
@@ -749,7 +769,7 @@ void Video::decodeBlock(int block)
         dc_predictor_[plane_index] = dc;
         if (dc < -32768 || dc > 32767)
             br.needs_raw = true; // not expressible as int16: goes through the snapshot path
-        br.q[0] = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc));
+        br.dc = (int16_t)(dc < -32768 ? -32768 : (dc > 32767 ? 32767 : dc));
         // blockData[0] = dc << 8.  Beyond +-2^30 the pixel saturates whatever the AC terms add
         // (their sum is below 0.6 * 2^30), so clamping there is exact and keeps int32.
         int64_t v = (int64_t)dc * 256;
@@ -766,20 +786,22 @@ void Video::decodeBlock(int block)
         quant_matrix = non_intra_quant_;
     }
 
-    uint8_t *touched = br.touched; // natural indices written by this block, in scan order
     // The block's words of the sparse hand-over go straight to their place in the picture's array (beginMacroblockRecord made
     // the room): count, an intra block's DC, then a pair per level from the loop below.  They only COUNT once the block turns
     // out valid and clean (mb_pending_ below); a block that does not is overwritten by the next one.
-    uint32_t *const words = sparse_ ? reinterpret_cast<uint32_t *>(coefs_.data() + coef_len_ + mb_pending_) : pair_scratch_;
-    uint32_t *const pairs = words + (macroblock_intra_ ? 2 : 1);
-    int n_touched = 0;
-    br.n_touched = 0;
+    uint32_t *const words = sparse_ ? reinterpret_cast<uint32_t *>(coefs_.data() + coef_len_ + mb_pending_) : pair_scratch_[block];
+    uint32_t *const __restrict pairs = words + (macroblock_intra_ ? 2 : 1);
+    int n_pairs = 0;
+    br.pairs = pairs;
+    br.n_pairs = 0;
     int level = 0;
     bool invalid = false;
     // Intra blocks arrive here with n == 1 (their DC is read above), non-intra blocks with n == 0: only those can begin with
     // the '1' that means run 0 / level 1 and not end_of_block (video.go:687).
-    const CoeffTable *const next_table = &tabCoeffNext();
-    const CoeffTable *coeff_table = n == 0 ? &tabCoeffFirst() : next_table;
+    const CoeffTable &next_table = tabCoeffNext(), &first_table = n == 0 ? tabCoeffFirst() : next_table;
+    const CoeffTable::Entry *const next_l1 = next_table.firstLevel(), *const next_l2 = next_table.secondLevel();
+    const CoeffTable::Entry *l1 = first_table.firstLevel(), *l2 = first_table.secondLevel();
+    const int rest_bits = next_table.restBits(); // (both tables are built from the same code list)
     // The cursor lives in locals for the length of the block (nothing in here refills the buffer): the
     // byte stores below may alias anything, and would otherwise force the Buffer's members through memory
     // once per coefficient.
@@ -809,8 +831,9 @@ void Video::decodeBlock(int block)
             w = window();
             valid = 64 - (int)(bit & 7);
         }
-        const CoeffTable::Entry &e = coeff_table->at(w);
-        coeff_table = next_table;
+        const CoeffTable::Entry &e = CoeffTable::at(l1, l2, rest_bits, w);
+        l1 = next_l1;
+        l2 = next_l2;
         int run;
         if (__builtin_expect(e.kind == CoeffTable::kCoef, 1)) {
             run = e.run;
@@ -851,17 +874,16 @@ void Video::decodeBlock(int block)
             invalid = true;
             break;
         }
-        const int dz = kZigZag[n] & 63;
-        n++;
-        br.q[dz] = (int16_t)level;
-        pairs[n_touched] = MPEGHIP_PAIR(level, (dz & 7) * 8 + (dz >> 3)); // natural index row * 8 + column -> position column * 8 + row
-        touched[n_touched++] = (uint8_t)dz;
-        if (dirty_at_start)
+        pairs[n_pairs++] = ((uint32_t)(uint16_t)level << 16) | kScanPos.v[n]; // = MPEGHIP_PAIR(level, position of scan index n)
+        if (dirty_at_start) {
+            const int dz = kZigZag[n];
             block_data_[dz] = dequantPremult(level, macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
+        }
+        n++;
     }
 
     buf_->setBitIndex(bit);
-    br.n_touched = n_touched;
+    br.n_pairs = n_pairs;
 
     // bring block_data_ up to date when it was not maintained on the fly
     auto materialize = [&]() {
@@ -869,9 +891,9 @@ void Video::decodeBlock(int block)
             return;
         if (macroblock_intra_)
             block_data_[0] = dc256;
-        for (int k = 0; k < n_touched; k++) {
-            const int dz = touched[k];
-            block_data_[dz] = dequantPremult(br.q[dz], macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
+        for (int k = 0; k < n_pairs; k++) {
+            const int dz = naturalIndexOfPair(pairs[k]);
+            block_data_[dz] = dequantPremult(levelOfPair(pairs[k]), macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
         }
     };
 
@@ -888,10 +910,10 @@ void Video::decodeBlock(int block)
         // again after use (video.go:777, 781-783, 790, 794-796) — nothing to keep on the host
         br.valid = true;
         if (sparse_) {
-            const uint32_t count = (uint32_t)n_touched + (macroblock_intra_ ? 1u : 0u);
+            const uint32_t count = (uint32_t)n_pairs + (macroblock_intra_ ? 1u : 0u);
             words[0] = count;
             if (macroblock_intra_)
-                words[1] = MPEGHIP_PAIR(br.q[0], 0);
+                words[1] = MPEGHIP_PAIR(br.dc, 0);
             mb_pending_ += 4 * (size_t)(1 + count);
         }
         return;

@@ -140,12 +140,17 @@ public:
     }
     int bits() const { return bits_; }
     // the symbol whose code starts at the window's top bit
-    const Entry &at(uint64_t window) const
+    const Entry &at(uint64_t window) const { return at(first_.data(), rest_.data(), rest_bits_, window); }
+    // ... for a loop that keeps the tables' addresses in registers (its stores could alias the vectors' own pointers)
+    const Entry *firstLevel() const { return first_.data(); }
+    const Entry *secondLevel() const { return rest_.data(); }
+    int restBits() const { return rest_bits_; }
+    static const Entry &at(const Entry *first, const Entry *rest, int rest_bits, uint64_t window)
     {
-        const Entry &e = first_[(size_t)(window >> (64 - kFirst))];
+        const Entry &e = first[(size_t)(window >> (64 - kFirst))];
         if (__builtin_expect(e.kind != kLink, 1))
             return e;
-        return rest_[(size_t)e.level + (size_t)((window << kFirst) >> (64 - rest_bits_))];
+        return rest[(size_t)e.level + (size_t)((window << kFirst) >> (64 - rest_bits))];
     }
 
 private:
