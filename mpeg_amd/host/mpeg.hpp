@@ -296,12 +296,41 @@ private:
     bool decodeSequenceHeader();
     void decodePicture();
     void decodeSlice(int slice);
+    // The bit cursor of ONE macroblock, held in locals: nothing inside a macroblock refills the buffer (fields past its end
+    // read as zeros, as Buffer::peek has them), and the Buffer's own members would travel through memory at every field —
+    // the parser's stores may alias them.  decodeMacroblock copies it out of *buf_ and writes the position back.
+    struct Cursor {
+        const uint8_t *data;
+        size_t len, bit;
+        uint64_t window() const // the next 57+ bits, left-aligned in 64, zero-padded past the end
+        {
+            const size_t byte = bit >> 3;
+            uint64_t w;
+            if (__builtin_expect(byte + 8 <= len, 1)) {
+                memcpy(&w, data + byte, 8);
+                w = __builtin_bswap64(w);
+            } else {
+                w = 0;
+                for (size_t k = 0; k < 8; k++)
+                    w = (w << 8) | (byte + k < len ? data[byte + k] : 0u);
+            }
+            return w << (bit & 7);
+        }
+        int bits(int count) // Buffer::read for 0 <= count <= 32
+        {
+            if (count == 0)
+                return 0;
+            const int v = (int)(window() >> (64 - count));
+            bit += (size_t)count;
+            return v;
+        }
+    };
     void decodeMacroblock();
-    void decodeMotionVectors();
-    int decodeMotionVector(int rSize, int motion);
+    void decodeMotionVectors(Cursor &c);
+    int decodeMotionVector(Cursor &c, int rSize, int motion);
     void predictMacroblock();
     void emitPrediction(int mh, int mv, bool backward);
-    void decodeBlock(int block);
+    void decodeBlock(Cursor &c, int block);
     void beginMacroblockRecord(bool intra);
     void endMacroblockRecord();
     void flushSubmit();
@@ -354,6 +383,7 @@ private:
     uint32_t pair_scratch_[6][66];
     struct MbRec { bool active = false, intra = false; int mb_x = 0, mb_y = 0; bool has_pred = false, backward = false;
                    int mv_x = 0, mv_y = 0; int qscale = 0; int cbp = 0; BlockRec blocks[6]; bool any_raw = false;
+                   int valid_cbp = 0; /* the blocks of cbp that ended valid (decodeBlock), any_raw: one of them needs the snapshot form */
                    bool out_of_range = false; /* a copyMacroblock call of this macroblock would panic in the reference */ } rec_;
 
     Frame frames_[3];

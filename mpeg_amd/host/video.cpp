@@ -159,6 +159,16 @@ int32_t dequantPremult(int level, bool intra, int qscale, int qm, int idx)
 
 } // namespace
 
+namespace {
+template <class C>
+inline int vlcAt(const VlcTable &t, C &c)
+{
+    const VlcTable::Symbol s = t.at(c.window());
+    c.bit += (size_t)s.len;
+    return s.value;
+}
+} // namespace
+
 uint64_t Video::VlcSelfCheck()
 {
     return vlcMismatches(mpg_vlc_mba_increment, tabMba()) + vlcMismatches(mpg_vlc_mb_type_i, tabType(1)) +
@@ -471,6 +481,7 @@ void Video::beginMacroblockRecord(bool intra)
     // (not `rec_ = MbRec()`: that clears 2.3 KB of block storage per macroblock; a block is reset by its own
     // decodeBlock, and endMacroblockRecord only looks at the blocks of this macroblock's pattern)
     rec_.has_pred = rec_.backward = rec_.any_raw = rec_.out_of_range = false;
+    rec_.valid_cbp = 0;
     rec_.mv_x = rec_.mv_y = 0;
     rec_.cbp = 0;
     rec_.active = true;
@@ -517,15 +528,8 @@ void Video::endMacroblockRecord()
         return;
     }
 
-    bool raw = false;
-    int cbp = 0;
-    for (int b = 0; b < 6; b++)
-        if (rec_.cbp & (0x20 >> b)) {
-            if (rec_.blocks[b].valid) {
-                cbp |= 0x20 >> b;
-                raw |= rec_.blocks[b].needs_raw;
-            }
-        }
+    bool raw = rec_.any_raw;              // (kept by decodeBlock as the blocks end)
+    const int cbp = rec_.valid_cbp & rec_.cbp;
     mpeghip_mb_desc d;
     memset(&d, 0, sizeof(d));
     d.pic = 0;
@@ -604,19 +608,27 @@ void Video::endMacroblockRecord()
 
 void Video::decodeMacroblock()
 { // video.go:462-562
+    Cursor c{buf_->Bytes(), buf_->Len(), buf_->bitIndex()};
+    struct WriteBack { // (every way out of the macroblock leaves the buffer where the cursor is)
+        Buffer *b;
+        const Cursor &c;
+        ~WriteBack() { b->setBitIndex(c.bit); }
+    } write_back{buf_, c};
     int increment = 0;
-    int t = tabMba().read(buf_);
+    int t = vlcAt(tabMba(), c);
     while (t == 34)
-        t = tabMba().read(buf_); // macroblock_stuffing
+        t = vlcAt(tabMba(), c); // macroblock_stuffing
     while (t == 35) {
         increment += 33; // macroblock_escape
-        t = tabMba().read(buf_);
+        t = vlcAt(tabMba(), c);
     }
     increment += t;
 
     if (slice_begin_) {
         slice_begin_ = false;
         macroblock_address_ += increment;
+        mb_row_ = macroblock_address_ / mb_width_;
+        mb_col_ = macroblock_address_ % mb_width_;
     } else {
         if (macroblock_address_ + increment >= mb_size_)
             return; // invalid
@@ -627,29 +639,30 @@ void Video::decodeMacroblock()
                 motion_forward_.V = 0;
             }
         }
+        // (row and column follow the address step by step here: they were derived from it when the slice began, and a
+        // division per macroblock is a tenth of a no-coefficient macroblock's parse)
         while (increment > 1) { // skipped macroblocks are predicted
             macroblock_address_++;
-            mb_row_ = macroblock_address_ / mb_width_;
-            mb_col_ = macroblock_address_ % mb_width_;
+            if (++mb_col_ == mb_width_)
+                mb_col_ = 0, mb_row_++;
             beginMacroblockRecord(false);
             predictMacroblock();
             endMacroblockRecord();
             increment--;
         }
         macroblock_address_++;
+        if (++mb_col_ == mb_width_)
+            mb_col_ = 0, mb_row_++;
     }
-
-    mb_row_ = macroblock_address_ / mb_width_;
-    mb_col_ = macroblock_address_ % mb_width_;
     if (mb_col_ >= mb_width_ || mb_row_ >= mb_height_ || macroblock_address_ < 0)
         return; // corrupt stream
 
-    macroblock_type_ = tabType(picture_type_).read(buf_);
+    macroblock_type_ = vlcAt(tabType(picture_type_), c);
     macroblock_intra_ = (macroblock_type_ & 0x01) != 0;
     motion_forward_.IsSet = (macroblock_type_ & 0x08) != 0;
     motion_backward_.IsSet = (macroblock_type_ & 0x04) != 0;
     if (macroblock_type_ & 0x10)
-        quantizer_scale_ = buf_->read(5);
+        quantizer_scale_ = c.bits(5);
 
     beginMacroblockRecord(macroblock_intra_);
     if (macroblock_intra_) {
@@ -657,48 +670,48 @@ void Video::decodeMacroblock()
         motion_backward_.V = motion_forward_.V = 0;
     } else {
         dc_predictor_[0] = dc_predictor_[1] = dc_predictor_[2] = 128;
-        decodeMotionVectors();
+        decodeMotionVectors(c);
         predictMacroblock();
     }
 
     int cbp = 0;
     if (macroblock_type_ & 0x02)
-        cbp = tabCbp().read(buf_);
+        cbp = vlcAt(tabCbp(), c);
     else if (macroblock_intra_)
         cbp = 0x3f;
     rec_.cbp = cbp;
-    for (int block = 0, mask = 0x20; block < 6; block++, mask >>= 1) {
-        rec_.blocks[block].valid = false;
-        if (cbp & mask)
-            decodeBlock(block);
+    for (unsigned todo = (unsigned)cbp & 0x3f; todo;) { // the coded blocks, first to last (0x20 = block 0): one loop exit to predict
+        const int top = 31 - __builtin_clz(todo);
+        todo &= ~(1u << top);
+        decodeBlock(c, 5 - top);
     }
     endMacroblockRecord();
 }
 
-void Video::decodeMotionVectors()
+void Video::decodeMotionVectors(Cursor &c)
 { // video.go:564-581
     if (motion_forward_.IsSet) {
         const int r = motion_forward_.RSize;
-        motion_forward_.H = decodeMotionVector(r, motion_forward_.H);
-        motion_forward_.V = decodeMotionVector(r, motion_forward_.V);
+        motion_forward_.H = decodeMotionVector(c, r, motion_forward_.H);
+        motion_forward_.V = decodeMotionVector(c, r, motion_forward_.V);
     } else if (picture_type_ == kPictureTypePredictive) {
         motion_forward_.H = 0;
         motion_forward_.V = 0;
     }
     if (motion_backward_.IsSet) {
         const int r = motion_backward_.RSize;
-        motion_backward_.H = decodeMotionVector(r, motion_backward_.H);
-        motion_backward_.V = decodeMotionVector(r, motion_backward_.V);
+        motion_backward_.H = decodeMotionVector(c, r, motion_backward_.H);
+        motion_backward_.V = decodeMotionVector(c, r, motion_backward_.V);
     }
 }
 
-int Video::decodeMotionVector(int rSize, int motion)
+int Video::decodeMotionVector(Cursor &c, int rSize, int motion)
 { // video.go:583-606
     const int fscale = 1 << rSize;
-    const int m_code = tabMotion().read(buf_);
+    const int m_code = vlcAt(tabMotion(), c);
     int d;
     if (m_code != 0 && fscale != 1) {
-        const int r = buf_->read(rSize);
+        const int r = c.bits(rSize);
         d = (((m_code < 0 ? -m_code : m_code) - 1) << rSize) + r + 1;
         if (m_code < 0)
             d = -d;
@@ -738,7 +751,7 @@ void Video::predictMacroblock()
     }
 }
 
-void Video::decodeBlock(int block)
+void Video::decodeBlock(Cursor &c, int block)
 { // video.go:639-745 (parse) + the bookkeeping that replaces :747-798
     BlockRec &br = rec_.blocks[block];
     br.valid = false;
@@ -755,10 +768,10 @@ void Video::decodeBlock(int block)
     if (macroblock_intra_) {
         const int plane_index = block > 3 ? block - 3 : 0;
         const int predictor = dc_predictor_[plane_index];
-        const int dct_size = tabDcSize(plane_index).read(buf_);
+        const int dct_size = vlcAt(tabDcSize(plane_index), c);
         int dc;
         if (dct_size > 0) {
-            const int differential = buf_->read(dct_size);
+            const int differential = c.bits(dct_size);
             if (differential & (1 << (dct_size - 1)))
                 dc = predictor + differential;
             else
@@ -802,13 +815,11 @@ void Video::decodeBlock(int block)
     const CoeffTable::Entry *const next_l1 = next_table.firstLevel(), *const next_l2 = next_table.secondLevel();
     const CoeffTable::Entry *l1 = first_table.firstLevel(), *l2 = first_table.secondLevel();
     const int rest_bits = next_table.restBits(); // (both tables are built from the same code list)
-    // The cursor lives in locals for the length of the block (nothing in here refills the buffer): the
-    // byte stores below may alias anything, and would otherwise force the Buffer's members through memory
-    // once per coefficient.
-    const uint8_t *const data = buf_->Bytes();
-    const size_t data_len = buf_->Len();
-    size_t bit = buf_->bitIndex();
-    auto window = [&]() -> uint64_t { // the next 57+ bits, left-aligned, zero-padded past the end
+    // The cursor lives in locals for the length of the block: the stores below may alias anything.
+    const uint8_t *const data = c.data;
+    const size_t data_len = c.len;
+    size_t bit = c.bit;
+    auto window = [&]() -> uint64_t { // the next 57+ bits, left-aligned, zero-padded past the end (Cursor::window on the locals)
         const size_t byte = bit >> 3;
         uint64_t w;
         if (byte + 8 <= data_len) {
@@ -882,7 +893,7 @@ void Video::decodeBlock(int block)
         n++;
     }
 
-    buf_->setBitIndex(bit);
+    c.bit = bit;
     br.n_pairs = n_pairs;
 
     // bring block_data_ up to date when it was not maintained on the fly
@@ -909,6 +920,7 @@ void Video::decodeBlock(int block)
         // the common case: blockData held nothing but this block, and the reference clears it
         // again after use (video.go:777, 781-783, 790, 794-796) — nothing to keep on the host
         br.valid = true;
+        rec_.valid_cbp |= 0x20 >> block;
         if (sparse_) {
             const uint32_t count = (uint32_t)n_pairs + (macroblock_intra_ ? 1u : 0u);
             words[0] = count;
@@ -942,6 +954,8 @@ void Video::decodeBlock(int block)
             break;
         }
     br.valid = true;
+    rec_.valid_cbp |= 0x20 >> block;
+    rec_.any_raw = true;
 }
 
 } // namespace mpeg
