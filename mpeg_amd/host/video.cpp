@@ -99,8 +99,12 @@ uint64_t coeffMismatches(const CoeffTable &table, bool first)
         }
         if (len > L)
             continue; // (the prefix is shorter than this symbol with its sign: longer prefixes cover it)
+        if (kind == CoeffTable::kCoef && len + 2 <= CoeffTable::kFirst && ((w << len) >> 62) == 2) { // ... then '10' inside the probe
+            kind = CoeffTable::kCoefEnd;
+            len += 2;
+        }
         const CoeffTable::Entry &e = table.at(w);
-        bad += (e.kind != kind || e.len != len || ((kind == CoeffTable::kCoef || kind == CoeffTable::kZero) && (e.run != run || e.level != level))) ? 1 : 0;
+        bad += (e.kind != kind || e.len != len || ((kind == CoeffTable::kCoef || kind == CoeffTable::kCoefEnd || kind == CoeffTable::kZero) && (e.run != run || e.level != level))) ? 1 : 0;
     }
     return bad;
 }
@@ -768,17 +772,18 @@ void Video::decodeBlock(Cursor &c, int block)
     if (macroblock_intra_) {
         const int plane_index = block > 3 ? block - 3 : 0;
         const int predictor = dc_predictor_[plane_index];
-        const int dct_size = vlcAt(tabDcSize(plane_index), c);
-        int dc;
+        // dct_dc_size and the differential from one look at the stream (<= 9 + 11 bits); a differential below half its range
+        // is negative: d - (2^size - 1) = the reference's (-(1 << size)) | (d + 1), without a branch on a coin flip
+        const uint64_t w0 = c.window();
+        const VlcTable::Symbol ds = tabDcSize(plane_index).at(w0);
+        const int dct_size = ds.value;
+        int dc = predictor;
         if (dct_size > 0) {
-            const int differential = c.bits(dct_size);
-            if (differential & (1 << (dct_size - 1)))
-                dc = predictor + differential;
-            else
-                dc = predictor + ((-(1 << dct_size)) | (differential + 1));
-        } else {
-            dc = predictor;
+            const int differential = (int)((w0 << ds.len) >> (64 - dct_size));
+            const int negative = ((differential >> (dct_size - 1)) & 1) ^ 1;
+            dc += differential - (((1 << dct_size) - 1) & -negative);
         }
+        c.bit += (size_t)(ds.len + dct_size);
         dc_predictor_[plane_index] = dc;
         if (dc < -32768 || dc > 32767)
             br.needs_raw = true; // not expressible as int16: goes through the snapshot path
@@ -833,12 +838,12 @@ void Video::decodeBlock(Cursor &c, int block)
         return w << (bit & 7);
     };
     // One 64-bit look at the stream serves as many symbols as fit: a table symbol is at most 18 bits with its sign, an escape
-    // 6 + 6 + 16, so a window with 28 valid bits left always holds the next one whole.  The table (CoeffTable) answers run,
+    // 6 + 6 + 16: the loop looks again below 18 valid bits, the escape below 28.  The table (CoeffTable) answers run,
     // signed level and length in one probe: the dependent chain per coefficient is shift -> table -> shift.
     uint64_t w = window();
     int valid = 64 - (int)(bit & 7);
     for (;;) {
-        if (valid < 28) {
+        if (valid < 18) { // (a table symbol with its sign; the escape below looks again if it needs its 28)
             w = window();
             valid = 64 - (int)(bit & 7);
         }
@@ -855,7 +860,26 @@ void Video::decodeBlock(Cursor &c, int block)
         } else if (e.kind == CoeffTable::kEnd) {
             bit += e.len;
             break;
+        } else if (e.kind == CoeffTable::kCoefEnd) { // the block's last coefficient with the end_of_block behind it
+            bit += e.len;
+            n += e.run;
+            if (n >= 64) { // (the reference finds the coefficient out of range before it would read the end_of_block)
+                bit -= 2;
+                invalid = true;
+                break;
+            }
+            pairs[n_pairs++] = ((uint32_t)(uint16_t)e.level << 16) | kScanPos.v[n];
+            if (dirty_at_start) {
+                const int dz = kZigZag[n];
+                block_data_[dz] = dequantPremult(e.level, macroblock_intra_, quantizer_scale_, quant_matrix[dz], dz);
+            }
+            n++;
+            break;
         } else if (e.kind == CoeffTable::kEscape) { // run (6 bits), level (8 bits, or 8 + 8): video.go:690-700
+            if (valid < 28) {
+                w = window();
+                valid = 64 - (int)(bit & 7);
+            }
             const uint32_t f = (uint32_t)((w << e.len) >> (64 - 22));
             run = (int)(f >> 16);
             const int b = (int)((f >> 8) & 0xff);

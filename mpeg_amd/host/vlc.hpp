@@ -100,6 +100,7 @@ public:
         kEscape = 2, // len = the escape code alone; run (6 bits) and level (8 or 16 bits) follow
         kZero = 3,   // a dead end of the reference's tree: it returns value 0 = run 0, level 0, and the sign bit is still read
         kLink = 4,   // first level only: `level` is the offset of this prefix's second table
+        kCoefEnd = 5, // a kCoef whose next two bits are '10' = end_of_block, both inside the first-level probe: len covers all of it
     };
     struct Entry {
         int32_t level;
@@ -160,6 +161,14 @@ private:
             const uint32_t lo = code << (kFirst - L), n = 1u << (kFirst - L);
             for (uint32_t k = 0; k < n; k++)
                 first_[lo + k] = e;
+            if (e.kind == kCoef && L + 2 <= kFirst) { // ... followed by '10': the block's last coefficient and its end in one probe
+                Entry last = e;
+                last.kind = kCoefEnd;
+                last.len = (uint8_t)(L + 2);
+                const uint32_t lo2 = ((code << 2) | 2u) << (kFirst - L - 2), n2 = 1u << (kFirst - L - 2);
+                for (uint32_t k = 0; k < n2; k++)
+                    first_[lo2 + k] = last;
+            }
             return;
         }
         Entry &link = first_[code >> (L - kFirst)];
