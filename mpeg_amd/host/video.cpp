@@ -476,7 +476,7 @@ void Video::beginMacroblockRecord(bool intra)
     // A damaged stream can address a macroblock twice in one picture; the reference
     // simply executes both in bitstream order.  Macroblocks of one submit run
     // concurrently on the device, so the earlier ones are flushed first.
-    const size_t addr = (size_t)mb_row_ * (size_t)mb_width_ + (size_t)mb_col_;
+    const size_t addr = (size_t)macroblock_address_; // (= mb_row_ * mb_width_ + mb_col_: decodeMacroblock keeps them in step)
     if (written_[addr]) {
         flushSubmit();
         stats_.duplicate_splits++;
@@ -712,16 +712,20 @@ void Video::decodeMotionVectors(Cursor &c)
 int Video::decodeMotionVector(Cursor &c, int rSize, int motion)
 { // video.go:583-606
     const int fscale = 1 << rSize;
-    const int m_code = vlcAt(tabMotion(), c);
-    int d;
-    if (m_code != 0 && fscale != 1) {
-        const int r = c.bits(rSize);
-        d = (((m_code < 0 ? -m_code : m_code) - 1) << rSize) + r + 1;
-        if (m_code < 0)
-            d = -d;
-    } else {
-        d = m_code;
-    }
+    // motion_code, then motion_r (rSize bits) if the code is not zero, from one look at the stream (<= 11 + 6 bits), and the
+    // reference's two cases (code 0 or f_code 1: d = code; else d = sign * (((|code| - 1) << rSize) + r + 1)) as ONE expression:
+    // with rSize 0 the second form is |code| itself, and a zero code is masked out — its sign and its zero-ness are coin flips
+    const uint64_t w = c.window();
+    const VlcTable::Symbol mc = tabMotion().at(w);
+    const int m_code = mc.value;
+    const int nonzero = m_code != 0;
+    const int r_bits = rSize & -nonzero;
+    const int r = (int)(((w << mc.len) >> 1) >> (63 - r_bits)); // (0 when r_bits is 0)
+    c.bit += (size_t)(mc.len + r_bits);
+    const int sign = m_code >> 31;                   // -1 / 0
+    const int mag = (m_code ^ sign) - sign;          // |code|
+    int d = ((mag - 1) * fscale + r + 1) & -nonzero; // ((mag - 1) is -1 for a zero code: a product, not a shift)
+    d = (d ^ sign) - sign;
     motion += d;
     if (motion > (fscale << 4) - 1)
         motion -= fscale << 5;
