@@ -152,10 +152,12 @@ def _coefficients(b: Bits, scan_levels, first: int, table: bool = True):
     b.put(0b10, 2)
 
 
-def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5, table: bool = True, repeat: int = 1) -> bytes:
+def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5, table: bool = True, repeat: int = 1, block_hook=None) -> bytes:
     """seq: list of mpeg_amd.synth.Submit (decode order, no MPEGHIP_MB_COEF_RAW macroblocks).  table: coefficients as Table B.5
     codes where the table has one (False: every coefficient as an escape code).  repeat: the group of pictures `repeat` times
-    over (a longer stream of the same pictures for throughput runs: every group starts with its I picture)."""
+    over (a longer stream of the same pictures for throughput runs: every group starts with its I picture).
+    block_hook(picture index, macroblock index, block, intra) -> a string of '0' / '1' written IN THE PLACE of that block's
+    coefficient symbols and end_of_block (None: the block as the descriptors have it) — for streams that are damaged on purpose."""
     g = desc.geometry(width, height)
     b = Bits()
     b.start_code(0xB3)
@@ -175,7 +177,7 @@ def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5, table
     b.put(0, 25)
     b.put(1, 1)                 # closed gop
     b.put(0, 1)
-    for s in seq:
+    for pic_index, s in enumerate(seq):
         pt = s.picture_type
         b.start_code(0x00)
         b.put(0, 10)            # temporal reference (the reference decoder ignores it)
@@ -228,10 +230,17 @@ def write_sequence(width: int, height: int, seq, frame_rate_code: int = 5, table
                         continue
                     scan = coefs[unit + k][FROM_COLMAJOR][ZIGZAG]
                     k += 1
+                    damaged = block_hook(pic_index, row * g["mb_w"] + col, blk, intra) if block_hook else None
+                    if damaged is not None and not intra:
+                        b.code(damaged)
+                        continue
                     if intra:
                         plane = 0 if blk < 4 else blk - 3
                         dc_table = "mpg_vlc_dct_dc_size_luma" if blk < 4 else "mpg_vlc_dct_dc_size_chroma"
                         dc_pred[plane] = _dc(b, dc_table, int(scan[0]), dc_pred[plane])
+                        if damaged is not None:
+                            b.code(damaged)
+                            continue
                         _coefficients(b, scan, 1, table)
                     else:
                         assert scan.any()

@@ -122,3 +122,68 @@ def test_every_code_of_table_b5_goes_through_both_parsers(oracle):
         for it in (False, True):
             assert {(sym, it, later, sg) for later in (False, True) for sg in (1, -1)} <= used or (sym >> 8) >= 62, hex(sym)
     _three_way(oracle, w, h, seq, True)
+
+
+ESCAPE = "000001"
+
+
+def _escape(run, level):
+    return ESCAPE + format(run, "06b") + format(level & 0xff, "08b")
+
+
+@pytest.mark.parametrize("name,bits", [
+    # the block's coefficients end beyond position 63 with the offending symbol FOLLOWED BY '10' (the parser's table answers
+    # "last coefficient + end_of_block" in one probe: the reference finds the overflow first and never reads the '10')
+    ("overflow_then_end_of_block", "10" + _escape(62, 1) + "110" + "10"),
+    ("overflow_then_more", "10" + _escape(62, 1) + "110" + "11" + "0"),
+    ("overflow_by_run", "10" + _escape(30, 2) + mpeg1_writer.COEFF[0x1f01] + "0" + "110" + "10"),   # (run 31, level 1): 1 + 30 + 1 + 31 = 63, full; the next overflows
+    ("overflow_by_escape", "10" + _escape(40, 1) + _escape(40, -1) + "10"),
+    # a dead end of the code tree: twelve zeros read as run 0 / level 0, and the sign bit is still consumed (buffer.go:352-376)
+    ("dead_end_code", "10" + "000000000000" + "1" + "0110" + "10"),
+    ("coded_zero_by_escape", "10" + _escape(3, 0) + "00000000" + "110" + "10"),
+    ("exactly_the_last_position", "10" + _escape(62, -5) + "10"),
+])
+@pytest.mark.parametrize("intra", [False, True], ids=["non_intra", "intra"])
+def test_damaged_blocks_read_like_the_reference(oracle, name, bits, intra):
+    """One block of a P picture (a non-intra macroblock's, or an intra macroblock's behind its DC) replaced by a hand-written
+    symbol sequence: blocks that run past position 63 (video.go:711-714: the block is dropped, blockData stays dirty, the stream
+    position stays right behind the symbol that overflowed), dead-end codes, coded zeros.  What follows the damage is read
+    from wherever that leaves the cursor — the product's parser must land exactly where the oracle's (the reference's
+    one-bit-at-a-time reading) does, and produce the same pictures."""
+    w, h = 96, 80
+    seq = synth.generate_sequence(w, h, 4, seed=0xD0, profile="typical")
+    p = seq[1]
+    assert p.picture_type == desc.PIC_P
+    is_intra = (p.mbs["flags"] & desc.MB_INTRA) != 0
+    # in every macroblock row (= slice: the damage ends at the next start code) the first macroblock of the wanted kind with two
+    # coded blocks or more: its first coded block is damaged, so the next block is read from wherever the damage leaves the cursor
+    mb_w = (w + 15) // 16
+    targets = {}
+    for i in range(len(p.mbs)):
+        if bin(int(p.mbs["cbp"][i])).count("1") >= 2 and bool(is_intra[i]) == intra:
+            targets.setdefault(i // mb_w, (i, next(b for b in range(6) if int(p.mbs["cbp"][i]) & (0x20 >> b))))
+    assert targets
+    if intra:
+        bits = bits[2:] if bits.startswith("10") else bits      # (an intra block's first symbol is behind the DC: no `1s` form)
+        bits = "110" + bits                                       # run 0 / level 1 as a later symbol
+    hook = lambda pic, mb, blk, it: bits if pic == 1 and (mb, blk) in targets.values() else None
+    es = mpeg1_writer.write_sequence(w, h, seq, block_hook=hook)
+    assert es != mpeg1_writer.write_sequence(w, h, seq)
+    ref = oracle.VideoDecoder(es)
+    want = decode_all(ref, oracle.frame_planes)
+    ref.close()
+    for sparse in (1, 0):                       # the hand-over form of pairs, and the form of 128-byte units
+        hostlib.host().mpeghost_set_default_sparse(sparse)
+        try:
+            dut = hostlib.HostVideo(es, emu_flavour=0)
+            got = decode_all(dut, hostlib.frame_planes)
+            st = dut.stats()
+            dut.close()
+        finally:
+            hostlib.host().mpeghost_set_default_sparse(1)
+        assert len(got) == len(want)
+        for i, (a, b) in enumerate(zip(want, got)):
+            for pa, pb in zip(a, b):
+                assert np.array_equal(pa, pb), "%s, frame %d (sparse %d)" % (name, i, sparse)
+        if name.startswith("overflow"):
+            assert st["invalid_blocks"] >= 1, name      # (the damage is what it says it is)
