@@ -691,6 +691,61 @@ def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
     return out
 
 
+def audio_host_parsed_leg(args, device, streams=256, threads=16):
+    """MP2 from BITSTREAMS: `streams` copies of tests/golden/test.mp2 (the reference's own audio fixture: 355 frames) through
+    mpeg::AudioBatch — every tick parses one frame of every stream on the pool (header, allocation, scale factors,
+    requantisation: audio.go:163-376, 429-490), synthesises all of them with ONE device call and hands the samples back to the
+    host.  Frames/s with 1 parse thread and with `threads`: what one GPU's host side delivers from MP2 bitstreams, NOT `value`."""
+    import ctypes as C
+    so = ROOT / "mpeg_amd" / "libmpeghost.so"
+    mp2 = ROOT / "tests" / "golden" / "test.mp2"
+    if not so.exists() or not mp2.exists():
+        return None
+    H = C.CDLL(str(so))
+    P = C.c_void_p
+    H.mpeghost_device_create.restype, H.mpeghost_device_create.argtypes = P, [C.c_int]
+    H.mpeghost_device_destroy.argtypes = [P]
+    H.mpeghost_audio_batch_open.restype, H.mpeghost_audio_batch_open.argtypes = P, [P, C.c_uint32, C.c_int, C.c_int]
+    H.mpeghost_audio_batch_close.argtypes = [P]
+    H.mpeghost_audio_batch_add_stream.restype, H.mpeghost_audio_batch_add_stream.argtypes = C.c_int, [P, C.c_char_p, C.c_size_t]
+    H.mpeghost_audio_batch_decode_all.restype, H.mpeghost_audio_batch_decode_all.argtypes = C.c_int, [P]
+    H.mpeghost_audio_batch_set_threads.argtypes = [P, C.c_uint32]
+    H.mpeghost_audio_batch_device_calls.restype, H.mpeghost_audio_batch_device_calls.argtypes = C.c_uint64, [P]
+    H.mpeghost_last_error.restype = C.c_char_p
+    data = mp2.read_bytes()
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    dev = H.mpeghost_device_create(device)
+    out = {"metric": "MP2 frames/s from BITSTREAMS: %d copies of tests/golden/test.mp2 parsed by mpeg::AudioBatch, one synthesis call per "
+                     "tick (one frame of every stream), samples back on the host — NOT `value`" % streams, "streams": streams}
+    for name, n in (("one_thread", 1), ("%d_threads" % threads, threads)):
+        b = H.mpeghost_audio_batch_open(dev, streams, 0, 0)
+        if not b:
+            raise SystemExit("bench: audio_host_parsed: %s" % H.mpeghost_last_error().decode())
+        H.mpeghost_audio_batch_set_threads(b, n)
+        for _ in range(streams):
+            if H.mpeghost_audio_batch_add_stream(b, data, len(data)) < 0:
+                raise SystemExit("bench: audio_host_parsed: %s" % H.mpeghost_last_error().decode())
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            k = H.mpeghost_audio_batch_decode_all(b)
+            if k < 0:
+                raise SystemExit("bench: audio_host_parsed: %s" % H.mpeghost_last_error().decode())
+            if k == 0:
+                break
+            frames += k
+        dt = time.perf_counter() - t0
+        calls = int(H.mpeghost_audio_batch_device_calls(b))
+        H.mpeghost_audio_batch_close(b)
+        out[name] = {"parse_threads": n, "frames": frames, "seconds": dt, "frames_per_s": frames / dt, "sample_pairs_per_s": frames * 1152 / dt,
+                     "device_calls": calls, "ms_per_tick": dt * 1e3 / max(calls, 1)}
+    H.mpeghost_device_destroy(dev)
+    best = out["%d_threads" % threads]
+    out["value"] = best["frames_per_s"]
+    out["realtime_streams_44k1"] = best["sample_pairs_per_s"] / 44100.0
+    return out
+
+
+
 def main():
     args = parse_args()
     import torch
@@ -759,6 +814,7 @@ def main():
         host_fed = host_fed_leg(args, prim, local_rank, ranks)
 
     host_parsed = host_parsed_leg(args, local_rank) if args.host_fed_seconds > 0 and alone and args.single_stream else None
+    audio_host_parsed = audio_host_parsed_leg(args, local_rank) if args.host_fed_seconds > 0 and alone and args.single_stream and args.audio_streams > 0 else None
 
     if all_cpus is not None and numa["cpus_bound"]:
         os.sched_setaffinity(0, all_cpus)  # the CPU baseline is the whole host's: every core of both sockets
@@ -800,6 +856,7 @@ def main():
             "reference_benchmarks": ref_bench,
             "host_fed": host_fed,
             "host_parsed": host_parsed,
+            "audio_host_parsed": audio_host_parsed,
             "parity": prim["parity"],
         }
         print(json.dumps(line))

@@ -132,6 +132,7 @@ int mpeghost_audio_batch_add_stream(void *batch, const uint8_t *data, size_t len
 int mpeghost_audio_batch_decode_all(void *batch);
 const void *mpeghost_audio_batch_samples(void *batch, uint32_t stream, double *time, const void **right);
 uint64_t mpeghost_audio_batch_device_calls(void *batch);
+void mpeghost_audio_batch_set_threads(void *batch, uint32_t n);   /* host threads of the parse (default 1): AudioBatch::SetThreads */
 
 /* ---- Demux (demux.go:61 NewDemux, :216 Seek) */
 void *mpeghost_demux_open(const uint8_t *data, size_t len);

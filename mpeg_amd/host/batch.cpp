@@ -171,9 +171,9 @@ bool pinThisThreadToNode(int node)
 // 64-thread pool, twice per picture round (parse, puts).  Here a run() bumps the counter and wakes everybody at once; workers
 // that finished the last run spin on the counter for about ten microseconds first (rounds follow each other closely), and the
 // caller learns of the end from a count of busy workers, the last of which wakes it.
-class VideoBatch::Pool {
+class HostPool {
 public:
-    Pool(unsigned n, int numa_node)
+    HostPool(unsigned n, int numa_node)
     {
         for (unsigned i = 1; i < n; i++)
             workers_.emplace_back([this, numa_node] {
@@ -186,7 +186,7 @@ public:
             });
     }
     std::atomic<unsigned> pins_asked_{0}, pins_failed_{0};
-    ~Pool()
+    ~HostPool()
     {
         stop_.store(true, std::memory_order_release);
         generation_.fetch_add(1, std::memory_order_release);
@@ -305,7 +305,7 @@ void VideoBatch::SetThreads(unsigned n)
     n = n < 1 ? 1 : n;
     if (n == threads_)
         return;
-    pool_.reset(n > 1 ? new Pool(n, numa_node_) : nullptr);
+    pool_.reset(n > 1 ? new HostPool(n, numa_node_) : nullptr);
     threads_ = n;
 }
 
@@ -316,7 +316,7 @@ void VideoBatch::SetNumaNode(int node)
     numa_node_ = node;
     if (threads_ > 1) { // restart the pool where it belongs
         pool_.reset();
-        pool_.reset(new Pool(threads_, numa_node_));
+        pool_.reset(new HostPool(threads_, numa_node_));
     }
 }
 
@@ -575,8 +575,11 @@ public:
     {
         if (format != abiFormat(b_->format_))
             throw std::runtime_error("AudioBatch: a stream changed its output format");
-        if (b_->active_[stream_])
+        if (b_->active_[stream_]) {
+            if (b_->parallel_)
+                throw std::logic_error("AudioBatch: a stream produced two frames in one pooled parse");
             b_->Flush(); // two frames of one stream never share a device call
+        }
         memcpy(b_->in_.data() + (size_t)stream_ * MPEGHIP_AUDIO_FRAME_INTS, samples, MPEGHIP_AUDIO_FRAME_INTS * sizeof(int32_t));
         b_->active_[stream_] = 1;
         b_->dest_[stream_].out = out;
@@ -646,12 +649,38 @@ size_t AudioBatch::DecodeAll(std::vector<Samples *> &samples)
     const size_t n = audios_.size();
     samples.assign(n, nullptr);
     size_t produced = 0;
-    for (size_t i = 0; i < n; i++) { // CPU: parse, record
-        samples[i] = audios_[i]->Decode();
-        produced += samples[i] ? 1 : 0;
+    if (pool_ && n > 1) {            // CPU: parse, record — every stream into its own slot, side by side
+        parallel_ = true;
+        std::exception_ptr failed;
+        try {
+            pool_->run(n, [&](size_t i) { samples[i] = audios_[i]->Decode(); });
+        } catch (...) {
+            failed = std::current_exception();
+        }
+        parallel_ = false;
+        if (failed) {
+            std::fill(active_.begin(), active_.end(), 0);
+            std::rethrow_exception(failed);
+        }
+        for (size_t i = 0; i < n; i++)
+            produced += samples[i] ? 1 : 0;
+    } else {
+        for (size_t i = 0; i < n; i++) {
+            samples[i] = audios_[i]->Decode();
+            produced += samples[i] ? 1 : 0;
+        }
     }
     Flush();                         // GPU: one call for all streams
     return produced;
+}
+
+void AudioBatch::SetThreads(unsigned n)
+{
+    n = n < 1 ? 1 : n;
+    if (n == threads_)
+        return;
+    pool_.reset(n > 1 ? new HostPool(n, -1) : nullptr);
+    threads_ = n;
 }
 
 // -------------------------------------------------------------------- ShardedVideoBatch

@@ -526,6 +526,14 @@ const void *mpeghost_audio_batch_samples(void *hv, uint32_t stream, double *time
     }
 }
 uint64_t mpeghost_audio_batch_device_calls(void *hv) { return static_cast<AudioBatchHandle *>(hv)->batch->DeviceCalls(); }
+// host threads of the parse (AudioBatch::SetThreads)
+void mpeghost_audio_batch_set_threads(void *hv, uint32_t n)
+{
+    guard([&]() -> int {
+        static_cast<AudioBatchHandle *>(hv)->batch->SetThreads(n);
+        return 0;
+    }, -1);
+}
 
 // NewDemux over a complete program stream (mpeg_test.go:88-100)
 void *mpeghost_demux_open(const uint8_t *data, size_t len)

@@ -397,6 +397,9 @@ private:
 // reconstructed by ONE device call (one mpeghip_pic_desc per stream), then the
 // frames are fetched.  This is the shape of the 10 000-stream deployment; a lone Video pays one
 // launch + one read-back per 330-macroblock picture.
+// The host thread pool of the batches (batch.cpp): run(n, fn) spreads fn(0 .. n-1) over the calling thread and its workers.
+class HostPool;
+
 class VideoBatch {
 public:
     VideoBatch(Device *dev, uint32_t n_streams);
@@ -440,13 +443,12 @@ public:
 private:
     class Port;
     friend class Port;
-    class Pool;
     void queue(uint32_t stream, const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
                size_t coef_bytes);
     void openStore(int width, int height);
     std::unique_ptr<BatchStore> store_;
     std::vector<Port *> ports_;                    // (owned by the Videos)
-    std::unique_ptr<Pool> pool_;
+    std::unique_ptr<HostPool> pool_;
     unsigned threads_ = 1;
     int numa_node_ = -1;
     uint32_t capacity_;
@@ -556,6 +558,10 @@ public:
     size_t DecodeAll(std::vector<Samples *> &samples);
     void Flush();
     uint64_t DeviceCalls() const { return device_calls_; }
+    // Host threads of the parse (default 1): the streams' frames of a DecodeAll are parsed side by side — every stream records
+    // into its own slot of the batch's input — and synthesised by the one device call behind them.  Call while idle.
+    void SetThreads(unsigned n);
+    unsigned Threads() const { return threads_; }
 
 private:
     class Port;
@@ -570,6 +576,9 @@ private:
     struct Dest { void *out = nullptr, *out2 = nullptr; };
     std::vector<Dest> dest_;
     uint64_t device_calls_ = 0;
+    std::unique_ptr<HostPool> pool_;
+    unsigned threads_ = 1;
+    bool parallel_ = false;                        // a pooled parse is running: no stream may flush the batch from inside it
 };
 
 // -------------------------------------------------------------------- demux.go

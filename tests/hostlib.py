@@ -86,6 +86,7 @@ def host():
             "mpeghost_audio_batch_decode_all": (C.c_int, [P]),
             "mpeghost_audio_batch_samples": (P, [P, C.c_uint32, C.POINTER(C.c_double), C.POINTER(P)]),
             "mpeghost_audio_batch_device_calls": (C.c_uint64, [P]),
+            "mpeghost_audio_batch_set_threads": (None, [P, C.c_uint32]),
             "mpeghost_demux_open": (P, [C.c_char_p, C.c_size_t]), "mpeghost_demux_close": (None, [P]),
             "mpeghost_demux_start_time": (C.c_double, [P, C.c_int]), "mpeghost_demux_duration": (C.c_double, [P, C.c_int]),
             "mpeghost_demux_probe": (C.c_int, [P, C.c_size_t]), "mpeghost_demux_streams": (None, [P, C.POINTER(C.c_int * 2)]),

@@ -180,3 +180,6 @@ def test_audio_batch_on_gpu(oracle, device):
     assert h == [AUDIO_HASH] * 6 and cnt == [355] * 6 and calls == 355 + 40
     h, cnt, _ = run_audio_batch(oracle, 3, [0, 2, 2], fmt=3, device=device)   # S16
     assert len(set(h)) == 1 and cnt == [355] * 3
+    # the streams' frames of a tick parsed on four host threads (AudioBatch::SetThreads): the same samples, the same calls
+    h, cnt, calls = run_audio_batch(oracle, 9, [0, 0, 3, 7, 40, 1, 0, 5, 2], device=device, threads=4)
+    assert h == [AUDIO_HASH] * 9 and cnt == [355] * 9 and calls == 355 + 40

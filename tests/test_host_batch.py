@@ -101,11 +101,14 @@ def test_different_picture_sizes_are_refused(oracle, golden_dir):
 AUDIO_HASH = 0xf1b76cdf8e6cdea5   # TestAudioGolden, no FMA (mpeg_test.go:193-197)
 
 
-def run_audio_batch(oracle, n, delays, fmt=0, device=None, window=None):
-    """n copies of test.mp2; stream i joins after delays[i] ticks.  Returns per-stream (hash, frames), device calls."""
+def run_audio_batch(oracle, n, delays, fmt=0, device=None, window=None, threads=1):
+    """n copies of test.mp2; stream i joins after delays[i] ticks.  Returns per-stream (hash, frames), device calls.
+    threads > 1: the streams' frames of a tick are parsed on that many host threads (AudioBatch::SetThreads)."""
     from pathlib import Path
     mp2 = (Path(__file__).resolve().parent / "golden" / "test.mp2").read_bytes()
     b = hostlib.HostAudioBatch(n, device=device, fmt=fmt, window=window)
+    if threads > 1:
+        hostlib.host().mpeghost_audio_batch_set_threads(b.h, threads)
     h, cnt = [oracle.FNV_OFFSET] * n, [0] * n
     added, tick = 0, 0
     order = sorted(range(n), key=lambda i: delays[i])
@@ -128,9 +131,10 @@ def run_audio_batch(oracle, n, delays, fmt=0, device=None, window=None):
     return h, cnt, calls
 
 
-def test_audio_batch_streams_share_one_synthesis_call_per_tick(oracle, emu):
+@pytest.mark.parametrize("threads", [1, 3])
+def test_audio_batch_streams_share_one_synthesis_call_per_tick(oracle, emu, threads):
     win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
-    h, cnt, calls = run_audio_batch(oracle, 5, [0, 0, 3, 7, 40], window=win)
+    h, cnt, calls = run_audio_batch(oracle, 5, [0, 0, 3, 7, 40], window=win, threads=threads)
     assert h == [AUDIO_HASH] * 5 and cnt == [355] * 5      # every stream exactly as if decoded alone
     assert calls == 355 + 40                                # one call per tick while any stream is alive
 
