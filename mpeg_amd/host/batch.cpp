@@ -40,7 +40,7 @@ public:
         uint8_t quant[128];
         mpeghip_pic_desc pic;
         std::vector<mpeghip_mb_desc> mbs;
-        std::vector<uint8_t> coefs;
+        CoefBytes coefs;
     };
     Port(VideoBatch *b, uint32_t stream) : b_(b), stream_(stream) {}
     // events[0 .. n_events) are this round's; the objects (and the capacity of their vectors: a 1080p picture is
@@ -87,7 +87,7 @@ public:
         }
         b_->queue(stream_, pic, mbs, n_mbs, coefs, coef_bytes);
     }
-    void submitOwned(const mpeghip_pic_desc &pic, std::vector<mpeghip_mb_desc> &mbs, std::vector<uint8_t> &coefs) override
+    void submitOwned(const mpeghip_pic_desc &pic, std::vector<mpeghip_mb_desc> &mbs, CoefBytes &coefs) override
     {
         if (recording) { // keep the parser's arrays, give it the event's old ones: no copy of a 2.5 MB picture
             Event &e = nextEvent();

@@ -23,6 +23,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <new>
+#include <utility>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -31,6 +33,25 @@
 #include "mpeghip.h"
 
 namespace mpeg {
+
+// A picture's coefficient bytes: a vector whose resize() does not zero what it adds (the parser writes every byte it hands over,
+// and grows the array in large steps ahead of what it has recorded: zero-filling those steps cost it a memset of every picture).
+template <class T>
+struct NoInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAllocator<U>; };
+    NoInitAllocator() = default;
+    template <class U> NoInitAllocator(const NoInitAllocator<U> &) {}
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args)
+    {
+        if constexpr (sizeof...(Args) == 0)
+            ::new (static_cast<void *>(p)) U; // default-initialised: nothing is written
+        else
+            ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+using CoefBytes = std::vector<uint8_t, NoInitAllocator<uint8_t>>;
+
 
 // ------------------------------------------------------------------ buffer.go
 class Buffer;
@@ -184,7 +205,7 @@ public:
                         const uint8_t *coefs, size_t coef_bytes) = 0;
     // The same submit, with the parser's own arrays handed over: a backend that keeps the picture for later may
     // swap them for arrays of its own instead of copying (the parser clears whatever it gets back).
-    virtual void submitOwned(const mpeghip_pic_desc &pic, std::vector<mpeghip_mb_desc> &mbs, std::vector<uint8_t> &coefs)
+    virtual void submitOwned(const mpeghip_pic_desc &pic, std::vector<mpeghip_mb_desc> &mbs, CoefBytes &coefs)
     {
         submit(pic, mbs.data(), (uint32_t)mbs.size(), coefs.data(), coefs.size());
     }
@@ -370,7 +391,7 @@ private:
     // The picture's coefficient bytes.  coefs_.size() runs AHEAD of what is recorded (it grows in large steps, and shrinks
     // to coef_len_ when the arrays are handed over): in the sparse form the VLC loop writes a block's words straight behind the
     // macroblock's earlier blocks — coef_len_ + mb_pending_ — and endMacroblockRecord only has to accept them.
-    std::vector<uint8_t> coefs_;
+    CoefBytes coefs_;
     size_t coef_len_ = 0;               // bytes recorded (whole macroblocks)
     size_t mb_pending_ = 0;             // bytes the current macroblock's clean blocks have written behind coef_len_
     uint8_t *coefRoom(size_t bytes);    // room for `bytes` behind coef_len_ + mb_pending_ (no recording; may move coefs_)
