@@ -580,7 +580,7 @@ public:
                 throw std::logic_error("AudioBatch: a stream produced two frames in one pooled parse");
             b_->Flush(); // two frames of one stream never share a device call
         }
-        memcpy(b_->in_.data() + (size_t)stream_ * MPEGHIP_AUDIO_FRAME_INTS, samples, MPEGHIP_AUDIO_FRAME_INTS * sizeof(int32_t));
+        memcpy(b_->in_ + (size_t)stream_ * MPEGHIP_AUDIO_FRAME_INTS, samples, MPEGHIP_AUDIO_FRAME_INTS * sizeof(int32_t));
         b_->active_[stream_] = 1;
         b_->dest_[stream_].out = out;
         b_->dest_[stream_].out2 = out2;
@@ -602,13 +602,23 @@ AudioBatch::AudioBatch(std::unique_ptr<AudioBatchStore> store, uint32_t n_stream
     if (n_streams == 0)
         throw std::runtime_error("AudioBatch: n_streams is 0");
     store_->open(n_streams, fma_mode);
-    in_.assign((size_t)n_streams * MPEGHIP_AUDIO_FRAME_INTS, 0);
-    out_.assign((size_t)n_streams * 2304 * elemSize(format), 0);
+    in_ = static_cast<int32_t *>(store_->allocHost((size_t)n_streams * MPEGHIP_AUDIO_FRAME_INTS * sizeof(int32_t)));
+    out_ = static_cast<uint8_t *>(store_->allocHost((size_t)n_streams * 2304 * elemSize(format)));
+    if (!in_ || !out_) {
+        store_->freeHost(in_);
+        store_->freeHost(out_);
+        throw std::runtime_error("AudioBatch: no memory for the batch's host arrays");
+    }
     active_.assign(n_streams, 0);
     dest_.assign(n_streams, Dest());
 }
 
-AudioBatch::~AudioBatch() {}
+AudioBatch::~AudioBatch()
+{
+    pool_.reset();
+    store_->freeHost(in_);
+    store_->freeHost(out_);
+}
 
 Audio *AudioBatch::AddStream(Buffer *buf)
 {
@@ -627,13 +637,13 @@ void AudioBatch::Flush()
         any = any || a;
     if (!any)
         return;
-    store_->synth(in_.data(), active_.data(), abiFormat(format_), out_.data());
+    store_->synth(in_, active_.data(), abiFormat(format_), out_);
     device_calls_++;
     const size_t es = elemSize(format_);
     for (uint32_t i = 0; i < capacity_; i++) {
         if (!active_[i])
             continue;
-        const uint8_t *src = out_.data() + (size_t)i * 2304 * es;
+        const uint8_t *src = out_ + (size_t)i * 2304 * es;
         if (format_ == AudioF32NLR) {
             memcpy(dest_[i].out, src, 1152 * es);
             memcpy(dest_[i].out2, src + 1152 * es, 1152 * es);

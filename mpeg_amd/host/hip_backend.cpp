@@ -158,6 +158,14 @@ public:
     {
         check(mpeghip_audio_synth_masked(synth_, samples, 1, format, out, active), "mpeghip_audio_synth_masked");
     }
+    void *allocHost(size_t bytes) override
+    {
+        void *p = mpeghip_pinned_alloc(ctx_, bytes ? bytes : 1);
+        if (p)
+            memset(p, 0, bytes);
+        return p;
+    }
+    void freeHost(void *p) override { mpeghip_pinned_free(ctx_, p); }
 
 private:
     mpeghip_ctx *ctx_;

@@ -15,6 +15,7 @@
 #pragma once
 
 #include <stddef.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -253,6 +254,11 @@ public:
     virtual ~AudioBatchStore() {}
     virtual void open(uint32_t n_streams, int fma_mode) = 0;
     virtual void synth(const int32_t *samples, const uint8_t *active, int format, void *out) = 0; // [n][2][36][32] -> [n][2304]
+    // The batch's two host arrays (what the streams record into, what the samples come back in): a device store hands out
+    // page-locked memory (mpeghip_pinned_alloc), so that the two copies of a tick run at the link's rate and not through the
+    // runtime's bounce buffers.  Zeroed; freed by the batch before the store goes.
+    virtual void *allocHost(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
+    virtual void freeHost(void *p) { free(p); }
 };
 
 // Bind the calling thread to the cores of host NUMA node `node` (sysfs cpulist); false if the node is unknown or the call fails.
@@ -591,8 +597,8 @@ private:
     uint32_t capacity_;
     AudioFormat format_;
     std::vector<std::unique_ptr<Audio>> audios_;
-    std::vector<int32_t> in_;                      // [capacity][2][36][32]
-    std::vector<uint8_t> out_;                     // [capacity][2304] elements of the format
+    int32_t *in_ = nullptr;                        // [capacity][2][36][32]   (store_->allocHost: page-locked on a device store)
+    uint8_t *out_ = nullptr;                       // [capacity][2304] elements of the format
     std::vector<uint8_t> active_;
     struct Dest { void *out = nullptr, *out2 = nullptr; };
     std::vector<Dest> dest_;
