@@ -75,6 +75,7 @@ def parse_args():
                     "kernel instance per batch (the product's behaviour), 1 = int16 tile, 2 = int32 tile (for A/B runs)")
     ap.add_argument("--pin-numa", type=int, default=1, help="1: bind the rank to the cores of the NUMA node its GPU is attached to")
     ap.add_argument("--check", type=int, default=1, help="verify the final frames against the oracle (rank 0)")
+    ap.add_argument("--gop-prewarm", type=int, default=1, help="1: one untimed GOP in front of the --warmup steps when --warmup is shorter than a GOP (clock ramp)")
     return ap.parse_args()
 
 
@@ -264,7 +265,7 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
     cycle = len(batches) - prime
     for i in range(-prime, 0):
         step(i)
-    if ramp_ms == 0 and args.warmup < cycle:
+    if ramp_ms == 0 and args.warmup < cycle and args.gop_prewarm:
         # The upload above left the GPU's compute clocks parked; W warm-up steps of 2 - 4 ms do not bring them back when W is small
         # (the driver's W = 5: 0.612 where W = 13 gives 0.617, profiles/round4_v_bench_repeatability.txt / round4_o_*).  One whole
         # GOP, untimed, in front of the W warm-up steps: the pictures are part of `order`, so the oracle replays them too.
