@@ -372,6 +372,7 @@ private:
     int frames_decoded_ = 0;
     int width_ = 0, height_ = 0, mb_width_ = 0, mb_height_ = 0, mb_size_ = 0;
     int luma_width_ = 0, luma_height_ = 0, chroma_width_ = 0, chroma_height_ = 0;
+    int64_t range_total_ = 0, range_chroma_ = 0;   // ends of the byte ranges a prediction may read (emitPrediction)
     int start_code_ = -1, picture_type_ = 0;
     Motion motion_forward_, motion_backward_;
     bool has_sequence_header_ = false;

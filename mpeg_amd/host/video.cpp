@@ -256,6 +256,11 @@ bool Video::decodeSequenceHeader()
     luma_height_ = mb_height_ << 4;
     chroma_width_ = mb_width_ << 3;
     chroma_height_ = mb_height_ << 3;
+    {   // emitPrediction's bounds (video_noasm.go:48-50), once per sequence instead of once per macroblock
+        const int64_t luma = (int64_t)luma_width_ * luma_height_, chroma = (int64_t)chroma_width_ * chroma_height_;
+        range_total_ = luma + 2 * chroma + (int64_t)luma_width_ * 16;
+        range_chroma_ = range_total_ - luma - chroma;
+    }
 
     // initFrame x3 (video.go:324-326): the three slots live in the backend's frame store
     backend_->open(width_, height_);
@@ -508,14 +513,13 @@ void Video::emitPrediction(int mh, int mv, bool backward)
     // panics; here the whole macroblock is dropped (endMacroblockRecord) — also when the call that would panic is one a
     // later call overwrites (a B macroblock's forward copy)
     const int64_t lw = luma_width_, cw = chroma_width_;
-    const int64_t luma = (int64_t)luma_width_ * luma_height_, chroma = (int64_t)chroma_width_ * chroma_height_;
-    const int64_t total = luma + 2 * chroma + lw * 16;
+    const int64_t total = range_total_, chroma_total = range_chroma_; // (luma + 2 chroma + 16 rows of padding; chroma + the padding)
     const int64_t lsi = ((int64_t)(rec_.mb_y << 4) + (mv >> 1)) * lw + (rec_.mb_x << 4) + (mh >> 1);
     const int64_t llast = lsi + (15 + (mv & 1)) * lw + 15 + (mh & 1);
     const int cmh = mh / 2, cmv = mv / 2;
     const int64_t csi = ((int64_t)(rec_.mb_y << 3) + (cmv >> 1)) * cw + (rec_.mb_x << 3) + (cmh >> 1);
     const int64_t clast = csi + (7 + (cmv & 1)) * cw + 7 + (cmh & 1);
-    if (lsi < 0 || llast >= total || csi < 0 || clast >= total - luma - chroma)
+    if (lsi < 0 || llast >= total || csi < 0 || clast >= chroma_total)
         rec_.out_of_range = true;
 }
 
