@@ -43,6 +43,7 @@ const VlcTable &tabDcSize(int plane)
 const VlcTable &tabCoeff() { static const VlcTable t(mpg_vlc_dct_coeff); return t; }   // (the plain table: only the self-check reads it)
 const CoeffTable &tabCoeffFirst() { static const CoeffTable t(mpg_vlc_dct_coeff, true); return t; }
 const CoeffTable &tabCoeffNext() { static const CoeffTable t(mpg_vlc_dct_coeff, false); return t; }
+const CoeffPairTable &tabCoeffPairs() { static const CoeffPairTable t(tabCoeffNext()); return t; }
 
 // the code a prefix starts with, found the slow way: the first code of the list that the prefix's leading bits spell out
 // (the lists are prefix-free: the reference's tree walk, buffer.go:352-376, ends at exactly that code)
@@ -106,6 +107,54 @@ uint64_t coeffMismatches(const CoeffTable &table, bool first)
         const CoeffTable::Entry &e = table.at(w);
         bad += (e.kind != kind || e.len != len || ((kind == CoeffTable::kCoef || kind == CoeffTable::kCoefEnd || kind == CoeffTable::kZero) && (e.run != run || e.level != level))) ? 1 : 0;
     }
+    return bad;
+}
+
+// CoeffPairTable against the one-symbol table: for every prefix, with the bits behind it filled in several ways, what the pair
+// entry says (one or two coefficients, an end_of_block, the bits of each) is what reading one symbol at a time finds there
+uint64_t pairMismatches(const CoeffPairTable &pairs, const CoeffTable &next)
+{
+    uint64_t bad = 0, fill = 0x9e3779b97f4a7c15ull;
+    for (uint32_t p = 0; p < (1u << CoeffPairTable::kBits); p++)
+        for (int f = 0; f < 12; f++) {
+            fill = fill * 6364136223846793005ull + 1442695040888963407ull;
+            const uint64_t tail = f == 0 ? 0 : (f == 1 ? ~0ull : fill);
+            const uint64_t w = ((uint64_t)p << (64 - CoeffPairTable::kBits)) | (tail >> CoeffPairTable::kBits);
+            const CoeffPairTable::Entry &e = pairs.at(w);
+            if (e.total == 0)
+                continue;
+            struct Ev { int kind, run, level, len; } want[3], got[4];
+            int nw = 0, ng = 0;
+            want[nw++] = Ev{0, e.run1, e.level1, e.len1};
+            if (e.flags & CoeffPairTable::kSecond)
+                want[nw++] = Ev{0, e.run2, e.level2, e.len2};
+            if (e.flags & CoeffPairTable::kEndOfBlock)
+                want[nw++] = Ev{1, 0, 0, 2};
+            int pos = 0;
+            bool ok = true;
+            while (ng < nw) { // the same events, read one symbol at a time ("coefficient + end_of_block" probes are two events)
+                const CoeffTable::Entry &s1 = next.at(w << pos);
+                if (s1.kind == CoeffTable::kCoef) {
+                    got[ng++] = Ev{0, s1.run, s1.level, s1.len};
+                } else if (s1.kind == CoeffTable::kCoefEnd) {
+                    got[ng++] = Ev{0, s1.run, s1.level, s1.len - 2};
+                    got[ng++] = Ev{1, 0, 0, 2};
+                } else if (s1.kind == CoeffTable::kEnd) {
+                    got[ng++] = Ev{1, 0, 0, 2};
+                } else {
+                    ok = false;
+                    break;
+                }
+                pos += s1.len;
+            }
+            int sum = 0;
+            for (int k = 0; ok && k < nw; k++) {
+                ok = want[k].kind == got[k].kind && want[k].run == got[k].run && want[k].level == got[k].level && want[k].len == got[k].len;
+                sum += want[k].len;
+            }
+            ok = ok && sum == e.total;
+            bad += ok ? 0 : 1;
+        }
     return bad;
 }
 
@@ -179,7 +228,8 @@ uint64_t Video::VlcSelfCheck()
            vlcMismatches(mpg_vlc_mb_type_p, tabType(2)) + vlcMismatches(mpg_vlc_mb_type_b, tabType(3)) +
            vlcMismatches(mpg_vlc_coded_block_pattern, tabCbp()) + vlcMismatches(mpg_vlc_motion_code, tabMotion()) +
            vlcMismatches(mpg_vlc_dct_dc_size_luma, tabDcSize(0)) + vlcMismatches(mpg_vlc_dct_dc_size_chroma, tabDcSize(1)) +
-           vlcMismatches(mpg_vlc_dct_coeff, tabCoeff()) + coeffMismatches(tabCoeffFirst(), true) + coeffMismatches(tabCoeffNext(), false);
+           vlcMismatches(mpg_vlc_dct_coeff, tabCoeff()) + coeffMismatches(tabCoeffFirst(), true) + coeffMismatches(tabCoeffNext(), false) +
+           pairMismatches(tabCoeffPairs(), tabCoeffNext());
 }
 
 Video::Video(Buffer *buf, Device *dev) : buf_(buf), backend_(dev->newVideoBackend()) { init(); }
@@ -850,14 +900,47 @@ void Video::decodeBlock(Cursor &c, int block)
     // signed level and length in one probe: the dependent chain per coefficient is shift -> table -> shift.
     uint64_t w = window();
     int valid = 64 - (int)(bit & 7);
+    const CoeffPairTable::Entry *const pair_tab = tabCoeffPairs().data();
+    bool two_at_once = !dirty_at_start && n != 0; // (n == 0: a non-intra block's first symbol has its own table)
     for (;;) {
         if (valid < 18) { // (a table symbol with its sign; the escape below looks again if it needs its 28)
             w = window();
             valid = 64 - (int)(bit & 7);
         }
+        if (two_at_once) {
+            // Two symbols from one probe where the table has them (CoeffPairTable); `total` 0 sends the probe the one-symbol way.
+            const CoeffPairTable::Entry pe = pair_tab[(size_t)(w >> (64 - CoeffPairTable::kBits))];
+            if (__builtin_expect(pe.total != 0, 1)) {
+                n += pe.run1;
+                if (__builtin_expect(n >= 64, 0)) { // video.go:711-714: the cursor stays behind the symbol that overflowed
+                    bit += pe.len1;
+                    invalid = true;
+                    break;
+                }
+                pairs[n_pairs++] = ((uint32_t)(uint16_t)(int16_t)pe.level1 << 16) | kScanPos.v[n];
+                n++;
+                const int second = pe.flags & CoeffPairTable::kSecond; // 0 / 1: counted, not branched on
+                const int n2 = n + pe.run2;
+                if (__builtin_expect(second & (n2 >= 64), 0)) {
+                    bit += (size_t)(pe.len1 + pe.len2);
+                    invalid = true;
+                    break;
+                }
+                pairs[n_pairs] = ((uint32_t)(uint16_t)(int16_t)pe.level2 << 16) | kScanPos.v[n2 & 63]; // (kept only if `second`)
+                n_pairs += second;
+                n = n2 + second; // (run2 is 0 without a second symbol)
+                bit += pe.total;
+                w <<= pe.total;
+                valid -= pe.total;
+                if (pe.flags & CoeffPairTable::kEndOfBlock)
+                    break;
+                continue;
+            }
+        }
         const CoeffTable::Entry &e = CoeffTable::at(l1, l2, rest_bits, w);
         l1 = next_l1;
         l2 = next_l2;
+        two_at_once = !dirty_at_start; // (behind a block's first symbol; a dirty blockData wants every level as it comes)
         int run;
         if (__builtin_expect(e.kind == CoeffTable::kCoef, 1)) {
             run = e.run;

@@ -185,4 +185,63 @@ private:
     std::vector<Entry> first_, rest_;
 };
 
+// Two symbols per probe.  The next kBits bits of the stream index a table that answers: the coefficient that starts there and,
+// where it fits in the same bits, the coefficient (or the end_of_block, or both) behind it — for the symbols AFTER a block's first
+// (CoeffTable's `next` context; a block's first symbol, escapes, dead ends and the codes that do not fit go the one-symbol way).
+// Built from the one-symbol table by decoding every kBits-bit prefix twice; checked against it for every prefix with filled-in
+// continuations (Video::VlcSelfCheck).  The loop that reads it stores the second pair word unconditionally and counts it or not:
+// whether a second symbol fits is a coin flip, and must not be a branch.
+class CoeffPairTable {
+public:
+    static constexpr int kBits = 11;
+    enum : uint8_t { kSecond = 1, kEndOfBlock = 2 };
+    struct Entry {
+        int8_t level1;
+        uint8_t run1;
+        int8_t level2;  // 0 / run2 0 without a second coefficient
+        uint8_t run2;
+        uint8_t len1, len2; // bits of each symbol with its sign (len2 0 without a second one)
+        uint8_t flags;      // kSecond, kEndOfBlock (2 more bits, behind the last coefficient)
+        uint8_t total;      // all of it; 0: not answered here — one symbol at a time
+    };
+    explicit CoeffPairTable(const CoeffTable &next)
+    {
+        tab_.assign((size_t)1 << kBits, Entry{0, 0, 0, 0, 0, 0, 0, 0});
+        for (uint32_t p = 0; p < (1u << kBits); p++) {
+            const uint64_t w = (uint64_t)p << (64 - kBits);
+            const CoeffTable::Entry &a = next.at(w);
+            if ((a.kind != CoeffTable::kCoef && a.kind != CoeffTable::kCoefEnd) || a.len > kBits || a.level < -128 || a.level > 127)
+                continue;
+            Entry e{(int8_t)a.level, a.run, 0, 0, a.len, 0, 0, a.len};
+            if (a.kind == CoeffTable::kCoefEnd) { // (its len covers the '10')
+                e.len1 = (uint8_t)(a.len - 2);
+                e.flags = kEndOfBlock;
+                tab_[p] = e;
+                continue;
+            }
+            const int left = kBits - a.len; // bits of the prefix behind the first symbol: a second one counts if it lies within them
+            const CoeffTable::Entry &b = next.at(w << a.len);
+            if (b.len <= left && b.level >= -128 && b.level <= 127) {
+                if (b.kind == CoeffTable::kEnd) {
+                    e.flags = kEndOfBlock;
+                    e.total = (uint8_t)(a.len + 2);
+                } else if (b.kind == CoeffTable::kCoef || b.kind == CoeffTable::kCoefEnd) {
+                    const bool end = b.kind == CoeffTable::kCoefEnd;
+                    e.level2 = (int8_t)b.level;
+                    e.run2 = b.run;
+                    e.len2 = (uint8_t)(end ? b.len - 2 : b.len);
+                    e.flags = (uint8_t)(kSecond | (end ? kEndOfBlock : 0));
+                    e.total = (uint8_t)(a.len + b.len);
+                }
+            }
+            tab_[p] = e;
+        }
+    }
+    const Entry *data() const { return tab_.data(); }
+    const Entry &at(uint64_t window) const { return tab_[(size_t)(window >> (64 - kBits))]; }
+
+private:
+    std::vector<Entry> tab_;
+};
+
 } // namespace mpeg

@@ -137,6 +137,9 @@ def _escape(run, level):
     ("overflow_then_end_of_block", "10" + _escape(62, 1) + "110" + "10"),
     ("overflow_then_more", "10" + _escape(62, 1) + "110" + "11" + "0"),
     ("overflow_by_run", "10" + _escape(30, 2) + mpeg1_writer.COEFF[0x1f01] + "0" + "110" + "10"),   # (run 31, level 1): 1 + 30 + 1 + 31 = 63, full; the next overflows
+    # ... the parser's two-symbols-per-probe table: the first symbol fits (position 62), the second overflows; and the first itself
+    ("overflow_by_the_second_of_a_pair", "10" + _escape(60, 1) + "110" + "0110" + "10"),
+    ("overflow_by_the_first_of_a_pair", "10" + _escape(61, 1) + "0110" + "110" + "10"),
     ("overflow_by_escape", "10" + _escape(40, 1) + _escape(40, -1) + "10"),
     # a dead end of the code tree: twelve zeros read as run 0 / level 0, and the sign bit is still consumed (buffer.go:352-376)
     ("dead_end_code", "10" + "000000000000" + "1" + "0110" + "10"),
