@@ -323,9 +323,10 @@ private:
     bool decodeSequenceHeader();
     void decodePicture();
     void decodeSlice(int slice);
-    // The bit cursor of ONE macroblock, held in locals: nothing inside a macroblock refills the buffer (fields past its end
+    // The bit cursor of a slice's macroblocks, held in locals: nothing inside a macroblock refills the buffer (fields past its end
     // read as zeros, as Buffer::peek has them), and the Buffer's own members would travel through memory at every field —
-    // the parser's stores may alias them.  decodeMacroblock copies it out of *buf_ and writes the position back.
+    // the parser's stores may alias them.  decodeSlice copies it out of *buf_ and writes the position back (and lets the buffer
+    // refill between macroblocks when it has to).
     struct Cursor {
         const uint8_t *data;
         size_t len, bit;
@@ -352,7 +353,7 @@ private:
             return v;
         }
     };
-    void decodeMacroblock();
+    void decodeMacroblock(Cursor &c);
     void decodeMotionVectors(Cursor &c);
     int decodeMotionVector(Cursor &c, int rSize, int motion);
     void predictMacroblock();

@@ -504,9 +504,26 @@ void Video::decodeSlice(int slice)
     quantizer_scale_ = buf_->read(5);
     while (buf_->read1())
         buf_->skip(8);
-    do {
-        decodeMacroblock();
-    } while (macroblock_address_ < mb_size_ - 1 && buf_->peekNonZero(23));
+    // The bit cursor of the slice, in locals (Cursor): nothing inside a macroblock refills the buffer, and between macroblocks
+    // only peekNonZero's has() may — when fewer than 23 bits are left of what is loaded; then the cursor goes back to the buffer,
+    // the buffer does what the reference does (buffer.go:341-350, 203-221: load more, or notice the end), and the cursor is read anew.
+    Cursor c{buf_->Bytes(), buf_->Len(), buf_->bitIndex()};
+    for (;;) {
+        decodeMacroblock(c);
+        if (macroblock_address_ >= mb_size_ - 1)
+            break;
+        if (__builtin_expect((c.len << 3) >= c.bit + 23, 1)) {
+            if ((c.window() >> (64 - 23)) == 0)
+                break;
+            continue;
+        }
+        buf_->setBitIndex(c.bit);
+        const bool more = buf_->peekNonZero(23);
+        c = Cursor{buf_->Bytes(), buf_->Len(), buf_->bitIndex()};
+        if (!more)
+            break;
+    }
+    buf_->setBitIndex(c.bit);
 }
 
 uint8_t *Video::coefRoom(size_t bytes)
@@ -664,14 +681,8 @@ void Video::endMacroblockRecord()
     mbs_.push_back(d);
 }
 
-void Video::decodeMacroblock()
+void Video::decodeMacroblock(Cursor &c)
 { // video.go:462-562
-    Cursor c{buf_->Bytes(), buf_->Len(), buf_->bitIndex()};
-    struct WriteBack { // (every way out of the macroblock leaves the buffer where the cursor is)
-        Buffer *b;
-        const Cursor &c;
-        ~WriteBack() { b->setBitIndex(c.bit); }
-    } write_back{buf_, c};
     int increment = 0;
     int t = vlcAt(tabMba(), c);
     while (t == 34)
