@@ -75,6 +75,9 @@ def parse_args():
                     "kernel instance per batch (the product's behaviour), 1 = int16 tile, 2 = int32 tile (for A/B runs)")
     ap.add_argument("--pin-numa", type=int, default=1, help="1: bind the rank to the cores of the NUMA node its GPU is attached to")
     ap.add_argument("--check", type=int, default=1, help="verify the final frames against the oracle (rank 0)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="allow ranks to share a physical GPU (functional runs of the N>1 path on a smaller box): without it a launch "
+                         "with more ranks than distinct devices exits non-zero; with it the line reports n_gpus = the distinct devices")
     ap.add_argument("--gop-prewarm", type=int, default=1, help="1: one untimed GOP in front of the --warmup steps when --warmup is shorter than a GOP (clock ramp)")
     return ap.parse_args()
 
@@ -110,8 +113,12 @@ def cpu_baseline(args, seq):
         i += 1
     rT = nT / (time.perf_counter() - t0)
     stT.close()
+    from mpeg_amd.shard import effective_cores
+    eff = effective_cores()
     return {
         "value": rT, "unit": "macroblocks/s", "cores": threads, "kind": "port",
+        # `cores` = the threads started (the affinity mask); what the container's CPU-time quota lets them have:
+        "effective_cores": eff["effective_cores"], "cgroup_quota_cores": eff["cgroup_quota_cores"],
         "sample": "oracle (C restatement of the reference's pure-Go noasm path, gcc -O2): %d host threads x 1 "
                   "1080p stream each over the bench GOP (%s profile), %d macroblocks in %.1f s; single thread: %.3g "
                   "macroblocks/s" % (threads, args.profile, nT, args.cpu_seconds * 0.75, r1),
@@ -265,7 +272,9 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
     cycle = len(batches) - prime
     for i in range(-prime, 0):
         step(i)
+    prewarm_steps = 0
     if ramp_ms == 0 and args.warmup < cycle and args.gop_prewarm:
+        prewarm_steps = cycle
         # The upload above left the GPU's compute clocks parked; W warm-up steps of 2 - 4 ms do not bring them back when W is small
         # (the driver's W = 5: 0.612 where W = 13 gives 0.617, profiles/round4_v_bench_repeatability.txt / round4_o_*).  One whole
         # GOP, untimed, in front of the W warm-up steps: the pictures are part of `order`, so the oracle replays them too.
@@ -346,6 +355,9 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
                      "traffic": traffic, "traffic_source": source, "traffic_source_matches_build": matches, "kernel": KERNEL[bool(rgba)],
                      "alg_bytes_per_launch": acc["alg"] // steps, "avg_launch_ms": launch_ms},
         "steps": steps, "device_bytes_per_picture": device_bytes_per_picture,
+        # untimed launches in front of the timed ones: the priming pictures, one whole GOP when --warmup is shorter than a GOP
+        # (--gop-prewarm: the upload leaves the GPU's clocks parked), then the --warmup steps
+        "untimed_prime_steps": prime, "untimed_prewarm_steps": prewarm_steps,
     }
 
 
@@ -409,7 +421,7 @@ def secondary(leg, name, streams, args):
     return {"metric": "1080p macroblocks/sec, %s" % name, "value": leg["mbs"] / leg["elapsed"], "unit": "macroblocks/s",
             "streams": streams, "steps": leg["steps"], "ms_per_step": leg["elapsed"] * 1e3 / leg["steps"],
             "realtime_1080p30_streams": leg["mbs"] / leg["elapsed"] / MB_PER_1080P30_STREAM,
-            "roofline": leg["roofline"], "parity": leg["parity"]}
+            "untimed_prewarm_steps": leg["untimed_prewarm_steps"], "roofline": leg["roofline"], "parity": leg["parity"]}
 
 
 def audio_leg(ctx, args, streams, tile=1, fma=0, ranks=None, device_sync=None):
@@ -472,7 +484,7 @@ def audio_leg(ctx, args, streams, tile=1, fma=0, ranks=None, device_sync=None):
         "metric": "MP2 stereo sample pairs/s",
         # N = 1: by the kernel's HIP events; N > 1: all ranks' sample pairs / the slowest rank's wall time between the barriers
         "value": n * frames * 1152 / (ams * 1e-3) if world == 1 else world * n * frames * 1152 * reps / elapsed,
-        "n_gpus": world, "per_rank_value": per_rank, "launches_timed": reps,
+        "n_gpus": getattr(args, "n_gpus", world), "ranks": world, "per_rank_value": per_rank, "launches_timed": reps,
         "streams": n, "frames_per_launch": frames, "ms_per_launch": ams,
         "realtime_streams_44k1": n * frames * 1152 / (ams * 1e-3) / 44100.0,
         "working_set_bytes": 2 * abytes,
@@ -589,7 +601,8 @@ def host_fed_leg(args, prim, device, ranks=None):
         return {"metric": "1080p macroblocks/sec handed over by host threads through device-packed stages, all ranks at once "
                           "(8 putting threads per rank) — PCIe inclusive, NOT `value`",
                 "value": sum(per_rank) * mbpp, "pictures_per_s": sum(per_rank), "per_rank_pictures_per_s": per_rank,
-                "host_threads_per_rank": min(8, cpus), "pictures_per_call": per_call, "n_gpus": ranks.world}
+                "host_threads_per_rank": min(8, cpus), "pictures_per_call": per_call, "n_gpus": getattr(args, "n_gpus", ranks.world),
+                "ranks": ranks.world}
     dev8 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(8, cpus), sec, sparse=True, device_pack=1)
     dev4 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(4, cpus), sec / 2, sparse=True, device_pack=1)
     dev16 = hostbench.staged_submit_rate(device, w, h, seq, per_call, min(16, cpus), sec / 2, sparse=True, device_pack=1)
@@ -661,12 +674,18 @@ def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
     H.mpeghost_batch_phase_seconds.argtypes = [P, C.POINTER(C.c_double * 4)]
     H.mpeghost_batch_counters.argtypes = [P, C.POINTER(C.c_uint64 * 2)]
     H.mpeghost_last_error.restype = C.c_char_p
+    H.mpeghost_batch_threads.restype, H.mpeghost_batch_threads.argtypes = C.c_uint32, [P]
+    H.mpeghost_effective_cores.restype = C.c_double
+    # the pool is sized by the CPU time the process gets (the cgroup quota), not by the request: BENCH_r04 ran 64 threads under a
+    # ~10-core quota 26 % SLOWER than 16.  `threads` below is the request; every run reports what the pool became.
+    eff = float(H.mpeghost_effective_cores())
     threads = max(1, min(threads, os.cpu_count() or 1))
     dev = H.mpeghost_device_create(device)
     out = {"metric": "1080p pictures/s from BITSTREAMS: %d streams of a written 1080p stream (natural level mix, Table B.5 codes; %d "
                      "pictures, %.0f kB per picture) parsed on %d host threads, handed over as device-packed staged commits, "
                      "reconstructed — NOT `value`" % (streams, gop * groups, len(es) / (gop * groups) / 1e3, threads),
-           "streams": streams, "parse_threads": threads, "pictures_per_stream": gop * groups, "stream_bytes_per_picture": len(es) / (gop * groups)}
+           "streams": streams, "parse_threads_requested": threads, "effective_cores": eff,
+           "pictures_per_stream": gop * groups, "stream_bytes_per_picture": len(es) / (gop * groups)}
     cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else threads
     wide = max(1, min(4 * threads, cpus))
     # (name, device-side packing, parse threads, streams): the wide runs show what more host threads buy — one picture per thread
@@ -677,6 +696,7 @@ def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
         if not b:
             raise SystemExit("bench: host_parsed: %s" % H.mpeghost_last_error().decode())
         H.mpeghost_batch_set_threads(b, nthreads)
+        nthreads = int(H.mpeghost_batch_threads(b))     # (what the request became: never more than the quota, rounded up)
         H.mpeghost_batch_set_device_pack(b, device_pack)
         for _ in range(nstreams):
             if H.mpeghost_batch_add_stream(b, es, len(es)) < 0:
@@ -693,7 +713,12 @@ def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
         H.mpeghost_batch_close(b)
         pictures = int(cn[1])
         out[name] = {"pictures_per_s": pictures / dt, "pictures": pictures, "seconds": dt, "device_calls": int(cn[0]), "parse_threads": nthreads,
-                     "streams": nstreams, "ms_parse_per_picture_per_thread": ph[0] * 1e3 * nthreads / max(pictures, 1),
+                     "streams": nstreams,
+                     # wall time of the parse rounds x the cores that worked on them: min(threads, the quota) — under a quota
+                     # of 10 cores 16 threads get 10 cores' worth of time, and "x threads" overstated the cost by 1.6 (BENCH_r04's
+                     # 1.49 ms against the 1.03 ms a free core needs)
+                     "ms_parse_per_picture_per_core": ph[0] * 1e3 * min(nthreads, eff) / max(pictures, 1),
+                     "ms_parse_per_picture_per_thread": ph[0] * 1e3 * nthreads / max(pictures, 1),
                      "wall_seconds": {"parse_rounds": ph[0], "stage_begin": ph[1], "puts": ph[2], "commits": ph[3]}}
     H.mpeghost_device_destroy(dev)
     out["value"] = out["device_packed"]["pictures_per_s"]
@@ -765,9 +790,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product has no CPU path")
     n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev:  # more ranks than devices (a functional run of the N>1 path on a smaller box): ranks share devices
-        print("bench.py: rank with LOCAL_RANK=%d shares device %d (%d visible)" % (local_rank, local_rank % n_dev, n_dev), file=sys.stderr)
-    local_rank %= n_dev
+    local_rank %= n_dev  # (more ranks than visible devices: they share — refused below unless --share-devices)
     torch.cuda.set_device(local_rank)
     ranks = Ranks(backend="gloo")  # control plane only: barrier + reductions of timings (no collective on the data path)
     world, rank = ranks.world, ranks.rank
@@ -775,9 +798,19 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world), file=sys.stderr)
 
     from mpeg_amd import abi
+    from mpeg_amd.shard import device_census
 
     tstream = torch.cuda.Stream(device=local_rank)
     ctx = abi.Context(local_rank, tstream.cuda_stream)
+    # which PHYSICAL devices the ranks are on (PCI addresses: ordinals are per process): n_gpus of every line below is the number
+    # of distinct ones, and a launch whose ranks share a device is refused unless --share-devices says it is meant
+    try:
+        census = device_census(ranks.gather_object(ctx.pci_bus_id()), args.share_devices)
+    except ValueError as e:
+        ctx.close()
+        ranks.close()
+        raise SystemExit("bench.py: %s" % e)
+    args.n_gpus = census["n_gpus"]
     # one process per GPU: this rank's host threads (staged puts of the host-fed leg, the CPU baseline) run on the socket
     # its GPU is attached to
     from mpeg_amd.shard import pin_to_node
@@ -841,7 +874,7 @@ def main():
         value = total_mbs / prim["elapsed"]
         line = {
             "metric": "1080p macroblocks/sec", "value": value, "unit": "macroblocks/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": census["n_gpus"], "ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": prim["elapsed"] * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": "%d independent %dx%d MPEG-1 streams per GPU, one picture each per step, decode-order "
@@ -850,7 +883,11 @@ def main():
                                     ", fused RGBA" if args.rgba else ""),
                        "streams_per_gpu": args.streams, "macroblocks_per_step_per_gpu": prim["mbs"] // args.steps,
                        "profile": args.profile, "rgba_fused": bool(args.rgba), "sharding": "by stream, no collective; control plane gloo",
-                       "host_numa": numa},
+                       "host_numa": numa,
+                       # the physical device of every rank (PCI address, rank order); n_gpus = the distinct ones
+                       "devices": census["devices"], "devices_shared": census["shared"],
+                       # launches in front of the timed ones that `warmup` does not count (clock ramp: DESIGN.md section 5.0)
+                       "untimed_prewarm_steps": prim["untimed_prewarm_steps"], "untimed_prime_steps": prim["untimed_prime_steps"]},
             "realtime_1080p30_streams": value / MB_PER_1080P30_STREAM,
             "per_rank_value": per_rank,
             "roofline": prim["roofline"],

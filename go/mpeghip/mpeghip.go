@@ -94,6 +94,16 @@ func (c *Context) Close() { C.mpeghip_ctx_destroy(c.h) }
 // parse for this device should run (runtime.LockOSThread + sched_setaffinity) on a two-socket node.
 func (c *Context) NumaNode() int { return int(C.mpeghip_ctx_numa_node(c.h)) }
 
+// PCIBusID is the PCI address of the context's GPU ("0000:c1:00.0"): what identifies the physical device when several
+// processes each see their own ordinal 0.
+func (c *Context) PCIBusID() (string, error) {
+	var buf [64]C.char
+	if err := lastError(C.mpeghip_ctx_pci_bus_id(c.h, &buf[0], C.size_t(len(buf)))); err != nil {
+		return "", err
+	}
+	return C.GoString(&buf[0]), nil
+}
+
 // Video is the 3-slot frame store + reconstruction of one stream.
 type Video struct {
 	h    *C.mpeghip_video

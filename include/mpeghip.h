@@ -59,6 +59,10 @@ void mpeghip_ctx_destroy(mpeghip_ctx *ctx);
 /* The host NUMA node the context's GPU is attached to (sysfs: its PCI function's numa_node), -1 if the platform does not
  * say.  The multi-GPU driver pins each device's host threads (bitstream parse, staged puts) to that node's cores. */
 int  mpeghip_ctx_numa_node(const mpeghip_ctx *ctx);
+/* The PCI address of the context's GPU ("0000:c1:00.0", lower case) into out[0..cap): what tells two ranks on one physical
+ * device apart from two ranks on two (HIP ordinals do not: HIP_VISIBLE_DEVICES renumbers them per process).  bench.py's N > 1
+ * line lists every rank's and counts the distinct ones as n_gpus.  MPEGHIP_ERR_INVALID if cap is too small. */
+int  mpeghip_ctx_pci_bus_id(const mpeghip_ctx *ctx, char *out, size_t cap);
 int  mpeghip_ctx_sync(mpeghip_ctx *ctx);               /* wait for all queued work   */
 int  mpeghip_device_count(void);                       /* <0 on error                */
 const char *mpeghip_last_error(void);                  /* thread-local, never NULL   */

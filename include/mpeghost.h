@@ -103,11 +103,16 @@ void *mpeghost_batch_open_store(void *store, uint32_t n_streams);    /* test sto
 void mpeghost_batch_close(void *batch);
 int mpeghost_batch_add_stream(void *batch, const uint8_t *data, size_t len);
 int mpeghost_batch_decode_all(void *batch, int fetch);               /* frames produced this tick, -1 error */
+/* parse threads of the batch's pool.  A REQUEST: never more than the CPU time the process gets (its affinity mask capped by the
+ * cgroup's CPU-time quota, rounded up — threads beyond that are throttled in turn and slow every round down); n = 0: as many as fit. */
 void mpeghost_batch_set_threads(void *batch, uint32_t n);
+uint32_t mpeghost_batch_threads(void *batch);                        /* what the request became */
+double mpeghost_effective_cores(void);                               /* that CPU time, in cores */
 int mpeghost_batch_frame(void *batch, uint32_t stream, mpeghost_frame *out);
 void mpeghost_batch_counters(void *batch, uint64_t out[2]);          /* device submits, pictures queued */
 void mpeghost_batch_phase_seconds(void *batch, double out[4]);       /* parse rounds, stage begin, puts, commits */
-/* staged submits of sparse pictures validated + packed on the DEVICE (mpeghip_video_stage_begin_device; default 1) or on the host */
+/* staged submits of sparse pictures validated + packed on the host (default: a refused picture fails the decode_all that sent it) or,
+ * with on = 1, on the DEVICE (mpeghip_video_stage_begin_device): errors are then DEFERRED to mpeghost_batch_sync / the next fetch */
 void mpeghost_batch_set_device_pack(void *batch, int on);
 int mpeghost_batch_sync(void *batch);                                /* wait; -1 + mpeghost_last_error(): a device-packed commit's deferred error */
 void mpeghost_batch_numa_pins(void *batch, uint32_t out[2]);         /* pool threads asked to bind to the NUMA node, bindings that failed */
@@ -120,6 +125,8 @@ void mpeghost_sharded_close(void *sharded);
 int mpeghost_sharded_add_stream(void *sharded, const uint8_t *data, size_t len);
 void mpeghost_sharded_set_threads(void *sharded, unsigned n);       /* parse threads of EVERY shard (each shard's pool runs on its GPU's NUMA node) */
 int mpeghost_sharded_decode_all(void *sharded, int fetch);
+void mpeghost_sharded_set_device_pack(void *sharded, int on);        /* mpeghost_batch_set_device_pack of every shard */
+int mpeghost_sharded_sync(void *sharded);                            /* mpeghost_batch_sync of every shard: -1 + the first deferred error */
 int mpeghost_sharded_frame(void *sharded, uint32_t stream, mpeghost_frame *out);
 uint32_t mpeghost_sharded_device_of(void *sharded, uint32_t stream);
 void mpeghost_sharded_counters(void *sharded, uint32_t shard, uint64_t out[2]);
@@ -130,6 +137,7 @@ void *mpeghost_audio_batch_open_store(void *store, uint32_t n_streams, int forma
 void mpeghost_audio_batch_close(void *batch);
 int mpeghost_audio_batch_add_stream(void *batch, const uint8_t *data, size_t len);
 int mpeghost_audio_batch_decode_all(void *batch);
+int mpeghost_audio_batch_decode_stream(void *batch, uint32_t stream); /* AudioBatch::Stream(i)->Decode(): 1 frame of one stream outside the tick; its samples arrive with the next decode_all */
 const void *mpeghost_audio_batch_samples(void *batch, uint32_t stream, double *time, const void **right);
 uint64_t mpeghost_audio_batch_device_calls(void *batch);
 void mpeghost_audio_batch_set_threads(void *batch, uint32_t n);   /* host threads of the parse (default 1): AudioBatch::SetThreads */

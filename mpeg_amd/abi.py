@@ -40,6 +40,7 @@ SYMBOLS = {
     "mpeghip_device_count": (C.c_int, []),
     "mpeghip_last_error": (C.c_char_p, []),
     "mpeghip_ctx_numa_node": (C.c_int, [_P]),
+    "mpeghip_ctx_pci_bus_id": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "mpeghip_abi_version": (C.c_int, []),
     "mpeghip_pinned_alloc": (_P, [_P, C.c_size_t]),
     "mpeghip_pinned_free": (None, [_P, _P]),
@@ -134,6 +135,12 @@ class Context:
     def numa_node(self) -> int:
         """Host NUMA node of the context's GPU (-1: unknown)."""
         return int(self.lib.mpeghip_ctx_numa_node(self.h))
+
+    def pci_bus_id(self) -> str:
+        """PCI address of the context's GPU: the identity of the PHYSICAL device (ordinals are per process)."""
+        buf = C.create_string_buffer(64)
+        _check(self.lib.mpeghip_ctx_pci_bus_id(self.h, buf, 64))
+        return buf.value.decode()
 
     def sync(self):
         _check(self.lib.mpeghip_ctx_sync(self.h))

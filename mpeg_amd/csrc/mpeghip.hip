@@ -804,16 +804,35 @@ int mpeghip_device_count(void)
 
 // The host NUMA node the context's GPU hangs off (its PCI function's numa_node in sysfs), -1 if unknown: the
 // threads that feed the device — parser pool, staged puts, the pinned staging buffers they fill — belong there.
+static bool pci_bus_id_of(int device, char (&id)[64])
+{
+    memset(id, 0, sizeof(id));
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, device) != hipSuccess)
+        return false;
+    for (char *p = id; *p; p++)
+        if (*p >= 'A' && *p <= 'F')
+            *p = (char)(*p - 'A' + 'a');
+    return true;
+}
+int mpeghip_ctx_pci_bus_id(const mpeghip_ctx *c, char *out, size_t cap)
+{
+    if (!c || !out)
+        return fail(MPEGHIP_ERR_INVALID, "ctx or out is NULL");
+    char id[64];
+    if (!pci_bus_id_of(c->device, id))
+        return fail(MPEGHIP_ERR_HIP, "hipDeviceGetPCIBusId failed for device %d", c->device);
+    if (strlen(id) + 1 > cap)
+        return fail(MPEGHIP_ERR_INVALID, "out holds %zu bytes, the PCI address needs %zu", cap, strlen(id) + 1);
+    memcpy(out, id, strlen(id) + 1);
+    return MPEGHIP_OK;
+}
 int mpeghip_ctx_numa_node(const mpeghip_ctx *c)
 {
     if (!c)
         return -1;
-    char id[64] = {0};
-    if (hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, c->device) != hipSuccess)
+    char id[64];
+    if (!pci_bus_id_of(c->device, id))
         return -1;
-    for (char *p = id; *p; p++)
-        if (*p >= 'A' && *p <= 'F')
-            *p = (char)(*p - 'A' + 'a');
     char path[160];
     snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id);
     FILE *f = fopen(path, "r");

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <climits>
+#include <cmath>
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -166,6 +167,50 @@ bool pinThisThreadToNode(int node)
     return n > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
 }
 
+// The CPU time this process really gets, in cores: the affinity mask, capped by the cgroup's CPU-time quota (v2: cpu.max; v1:
+// cpu.cfs_quota_us / cpu.cfs_period_us).  A container that shows 256 hardware threads under a 10-core quota runs a 64-thread
+// pool 26 % SLOWER than a 16-thread one (BENCH_r04 host_parsed: the threads are throttled in turn and every round waits for the
+// last of them), so pools are sized by this, not by the number asked for.
+double EffectiveCores()
+{
+    double cores = (double)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        cores = (double)CPU_COUNT(&set);
+    if (cores < 1)
+        cores = 1;
+    double quota = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        double period = 0;
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+            quota = atof(q) / period;
+        fclose(f);
+    } else {
+        double q = 0, period = 0;
+        if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(fq, "%lf", &q) != 1)
+                q = 0;
+            fclose(fq);
+        }
+        if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(fp, "%lf", &period) != 1)
+                period = 0;
+            fclose(fp);
+        }
+        if (q > 0 && period > 0)
+            quota = q / period;
+    }
+    return quota > 0 && quota < cores ? quota : cores;
+}
+// threads a pool gets when `asked` are asked for (0 = as many as there is CPU time for): never more than the quota rounded up
+static unsigned poolThreads(unsigned asked)
+{
+    const unsigned fit = (unsigned)std::ceil(EffectiveCores());
+    const unsigned cap = fit < 1 ? 1 : fit;
+    return asked == 0 ? cap : (asked < cap ? asked : cap);
+}
+
 // Workers sleep on a generation counter (a futex word), not on a condition variable: a condition variable hands its mutex
 // from one woken thread to the next, so waking 63 workers costs 63 lock hand-overs IN SERIES — milliseconds per run() on a
 // 64-thread pool, twice per picture round (parse, puts).  Here a run() bumps the counter and wakes everybody at once; workers
@@ -182,9 +227,15 @@ public:
                     if (!pinThisThreadToNode(numa_node))
                         pins_failed_++;
                 }
+                started_.fetch_add(1, std::memory_order_release);
                 work();
             });
+        // every worker has tried its binding when the constructor returns: NumaPins() read right after SetThreads /
+        // SetNumaNode is the final count, and no run() starts with threads still on the wrong socket
+        while (started_.load(std::memory_order_acquire) < workers_.size())
+            std::this_thread::yield();
     }
+    std::atomic<size_t> started_{0};
     std::atomic<unsigned> pins_asked_{0}, pins_failed_{0};
     ~HostPool()
     {
@@ -302,7 +353,7 @@ double nowSeconds() { return std::chrono::duration<double>(std::chrono::steady_c
 
 void VideoBatch::SetThreads(unsigned n)
 {
-    n = n < 1 ? 1 : n;
+    n = poolThreads(n); // (0: as many as the process has CPU time for; never more than that)
     if (n == threads_)
         return;
     pool_.reset(n > 1 ? new HostPool(n, numa_node_) : nullptr);
@@ -666,6 +717,8 @@ size_t AudioBatch::DecodeAll(std::vector<Samples *> &samples)
     samples.assign(n, nullptr);
     size_t produced = 0;
     if (pool_ && n > 1) {            // CPU: parse, record — every stream into its own slot, side by side
+        Flush();                     // a frame a caller decoded directly (Audio::Decode on a batch stream) goes out first, as the
+                                     // one-thread path does it: a slot holds one frame, and the pool cannot flush from inside
         parallel_ = true;
         std::exception_ptr failed;
         try {
@@ -692,7 +745,7 @@ size_t AudioBatch::DecodeAll(std::vector<Samples *> &samples)
 
 void AudioBatch::SetThreads(unsigned n)
 {
-    n = n < 1 ? 1 : n;
+    n = poolThreads(n);
     if (n == threads_)
         return;
     pool_.reset(n > 1 ? new HostPool(n, -1) : nullptr);
@@ -810,6 +863,27 @@ void ShardedVideoBatch::SetThreads(unsigned n)
 {
     for (auto &sh : shards_)
         sh->batch->SetThreads(n);
+}
+
+void ShardedVideoBatch::SetDevicePack(bool on)
+{
+    for (auto &sh : shards_)
+        sh->batch->SetDevicePack(on);
+}
+
+void ShardedVideoBatch::Sync()
+{
+    std::exception_ptr failed;
+    for (auto &sh : shards_) { // (no tick is running: DecodeAll returns only when every shard's has ended)
+        try {
+            sh->batch->Sync();
+        } catch (...) {
+            if (!failed)
+                failed = std::current_exception();
+        }
+    }
+    if (failed)
+        std::rethrow_exception(failed);
 }
 
 size_t ShardedVideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)

@@ -364,6 +364,9 @@ int mpeghost_batch_decode_all(void *hv, int fetch)
         return (int)h->batch->DecodeAll(h->frames, fetch != 0);
     }, -1);
 }
+// CPU time the process gets, in cores (affinity mask capped by the cgroup quota): what pools are sized by
+double mpeghost_effective_cores(void) { return mpeg::EffectiveCores(); }
+uint32_t mpeghost_batch_threads(void *hv) { return static_cast<BatchHandle *>(hv)->batch->Threads(); }
 // host threads of the parse (VideoBatch::SetThreads)
 void mpeghost_batch_set_threads(void *hv, uint32_t n)
 {
@@ -445,6 +448,20 @@ void mpeghost_sharded_set_threads(void *hv, unsigned n)
         return 0;
     }, -1);
 }
+void mpeghost_sharded_set_device_pack(void *hv, int on)
+{
+    guard([&]() -> int {
+        static_cast<ShardedHandle *>(hv)->batch->SetDevicePack(on != 0);
+        return 0;
+    }, -1);
+}
+int mpeghost_sharded_sync(void *hv)
+{
+    return guard([&]() -> int {
+        static_cast<ShardedHandle *>(hv)->batch->Sync();
+        return 0;
+    }, -1);
+}
 int mpeghost_sharded_decode_all(void *hv, int fetch)
 {
     return guard([&]() -> int {
@@ -505,6 +522,17 @@ int mpeghost_audio_batch_decode_all(void *hv)
     return guard([&]() -> int {
         AudioBatchHandle *h = static_cast<AudioBatchHandle *>(hv);
         return (int)h->batch->DecodeAll(h->samples);
+    }, -1);
+}
+// AudioBatch::Stream(i)->Decode(): one frame of ONE stream, outside the batch's tick (its synthesis rides with the next device
+// call: the samples are there after the next decode_all).  1 = a frame, 0 = the stream has ended, -1 error
+int mpeghost_audio_batch_decode_stream(void *hv, uint32_t stream)
+{
+    return guard([&]() -> int {
+        AudioBatchHandle *h = static_cast<AudioBatchHandle *>(hv);
+        if (stream >= h->batch->Streams())
+            throw std::runtime_error("mpeghost_audio_batch_decode_stream: no such stream");
+        return h->batch->Stream(stream)->Decode() ? 1 : 0;
     }, -1);
 }
 // samples of stream i from the last decode_all (Interleaved / Left / F32 / S16 by format; right = Right for F32NLR)

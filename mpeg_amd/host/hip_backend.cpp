@@ -64,9 +64,14 @@ public:
     }
     void open(int width, int height, uint32_t n_streams) override
     {
-        if (store_)
+        if (store_) { // (re-open: a device-packed commit still in flight on the old handle reports before the handle goes)
+            const int verdict = mpeghip_video_sync(store_);
+            const std::string why = verdict != MPEGHIP_OK ? mpeghip_last_error() : "";
             mpeghip_video_close(store_);
-        store_ = nullptr;
+            store_ = nullptr;
+            if (verdict != MPEGHIP_OK)
+                throw std::runtime_error("mpeghip_video_sync (before the store was re-opened): " + why);
+        }
         check(mpeghip_video_open(ctx_, (uint32_t)width, (uint32_t)height, n_streams, &store_), "mpeghip_video_open");
     }
     void setQuant(uint32_t stream, const uint8_t intra[64], const uint8_t non_intra[64]) override

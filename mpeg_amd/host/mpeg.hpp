@@ -428,6 +428,10 @@ private:
 // launch + one read-back per 330-macroblock picture.
 // The host thread pool of the batches (batch.cpp): run(n, fn) spreads fn(0 .. n-1) over the calling thread and its workers.
 class HostPool;
+// The CPU time the process gets, in cores: its affinity mask capped by the cgroup's CPU-time quota.  VideoBatch / AudioBatch
+// pools never start more threads than this (rounded up): SetThreads(n) is a request, Threads() says what it became;
+// SetThreads(0) asks for "as many as fit".
+double EffectiveCores();
 
 class VideoBatch {
 public:
@@ -457,9 +461,12 @@ public:
     int NumaNode() const { return numa_node_; }
     // threads of this batch that asked to be bound to the node / whose binding failed (no such node, sched_setaffinity refused)
     void NumaPins(unsigned out[2]) const;
-    // Staged submits of sparse pictures are validated and packed ON THE DEVICE (mpeghip_video_stage_begin_device; default) or
-    // by the pool's threads on the host.  Device-packed: a malformed picture is reported by Sync() / the next fetch, not by
-    // the DecodeAll that sent it (the product's parser does not emit malformed pictures).
+    // Staged submits of sparse pictures are validated and packed by the pool's threads on the host (default: a picture the
+    // validator refuses makes the DecodeAll that sent it throw, as a refused mpeghip_video_submit does) or — opt-in — ON THE
+    // DEVICE (mpeghip_video_stage_begin_device: the host side of the hand-over shrinks to a copy).  Device-packed commits report
+    // DEFERRED: a refused picture surfaces at Sync() / the next fetch / a later DecodeAll, the whole commit (other streams'
+    // healthy pictures too) has reconstructed nothing, and the parsers have moved on — call Sync() after every DecodeAll
+    // whose verdict matters.  (The product's parser does not emit pictures the validator refuses)
     void SetDevicePack(bool on) { device_pack_ = on; }
     bool DevicePack() const { return device_pack_; }
     void Sync() { store_->sync(); }
@@ -487,7 +494,7 @@ private:
     std::vector<mpeghip_mb_desc> mbs_;
     std::vector<uint8_t> coefs_;
     bool any_sparse_queued_ = false;
-    bool device_pack_ = true;
+    bool device_pack_ = false;
     std::vector<uint8_t> pending_;                 // stream already has a picture in the open batch
     uint64_t device_submits_ = 0, queued_pictures_ = 0;
     double t_parse_ = 0, t_put_ = 0, t_commit_ = 0, t_begin_ = 0; // wall time per phase (PhaseSeconds)
@@ -509,6 +516,8 @@ public:
     uint32_t ShardOf(uint32_t stream) const { return stream % Shards(); }
     VideoBatch &Shard(uint32_t g);
     void SetThreads(unsigned n);                   // parse threads of every shard
+    void SetDevicePack(bool on);                   // VideoBatch::SetDevicePack of every shard
+    void Sync();                                   // VideoBatch::Sync of every shard: waits; throws the first deferred error
     // one tick of every shard, concurrently; frames[s] = the next frame of global stream s (or nullptr)
     size_t DecodeAll(std::vector<Frame *> &frames, bool fetch = true);
 

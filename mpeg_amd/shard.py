@@ -50,6 +50,41 @@ def pin_to_node(node: int):
         return 0
 
 
+def effective_cores():
+    """The CPU time this process can really get, in cores: the cgroup quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) if one
+    is set, capped by the affinity mask; None for the quota part if there is none.  A container that exposes 256 hardware
+    threads under a 10-core quota runs 256 threads at 10 cores' worth of time: pools are sized, and baselines quoted, by this."""
+    mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            quota = None
+    return {"affinity_cpus": mask, "cgroup_quota_cores": quota, "effective_cores": min(float(mask), quota) if quota else float(mask)}
+
+
+def device_census(identities, share_devices: bool = False):
+    """identities: every rank's physical-device identity (PCI address), in rank order.  One process per GPU is the contract;
+    ranks that share a physical device are refused unless asked for (`--share-devices`: a functional run of the N > 1 path on a
+    smaller box), and then the line says how many devices it was really measured on.  Returns {"devices", "n_gpus", "ranks",
+    "shared"}; raises ValueError for the refusal."""
+    distinct = sorted(set(identities))
+    out = {"devices": list(identities), "n_gpus": len(distinct), "ranks": len(identities), "shared": len(distinct) < len(identities)}
+    if out["shared"] and not share_devices:
+        raise ValueError("%d ranks on %d distinct GPUs (%s): one process per GPU is the contract; pass --share-devices for a "
+                         "functional run of the multi-rank path on fewer devices (the line then reports n_gpus = %d)" %
+                         (len(identities), len(distinct), ", ".join(distinct), len(distinct)))
+    return out
+
+
 class Ranks:
     """RANK / LOCAL_RANK / WORLD_SIZE from the launcher's environment; process group only if world > 1."""
 
@@ -121,6 +156,14 @@ class Ranks:
         out = [torch.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(out, mine)
         return [float(t.item()) for t in out]
+
+    def gather_object(self, obj) -> list:
+        """Every rank's (picklable) `obj`, in rank order (on every rank)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def close(self):
         if self.dist is not None:

@@ -73,6 +73,8 @@ def host():
             "mpeghost_batch_phase_seconds": (None, [P, C.POINTER(C.c_double * 4)]),
             "mpeghost_batch_set_device_pack": (None, [P, C.c_int]), "mpeghost_batch_sync": (C.c_int, [P]),
             "mpeghost_batch_numa_pins": (None, [P, C.POINTER(C.c_uint32 * 2)]),
+            "mpeghost_batch_threads": (C.c_uint32, [P]), "mpeghost_effective_cores": (C.c_double, []),
+            "mpeghost_sharded_set_device_pack": (None, [P, C.c_int]), "mpeghost_sharded_sync": (C.c_int, [P]),
             "mpeghost_sharded_open": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
             "mpeghost_sharded_open_stores": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
             "mpeghost_sharded_close": (None, [P]), "mpeghost_sharded_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
@@ -84,6 +86,7 @@ def host():
             "mpeghost_audio_batch_open_store": (P, [P, C.c_uint32, C.c_int, C.c_int]),
             "mpeghost_audio_batch_close": (None, [P]), "mpeghost_audio_batch_add_stream": (C.c_int, [P, C.c_char_p, C.c_size_t]),
             "mpeghost_audio_batch_decode_all": (C.c_int, [P]),
+            "mpeghost_audio_batch_decode_stream": (C.c_int, [P, C.c_uint32]),
             "mpeghost_audio_batch_samples": (P, [P, C.c_uint32, C.POINTER(C.c_double), C.POINTER(P)]),
             "mpeghost_audio_batch_device_calls": (C.c_uint64, [P]),
             "mpeghost_audio_batch_set_threads": (None, [P, C.c_uint32]),
@@ -388,7 +391,7 @@ class HostBatch:
         return f if host().mpeghost_batch_frame(self.h, stream, C.byref(f)) == 1 else None
 
     def set_device_pack(self, on: bool):
-        """Staged submits of sparse pictures validated and packed on the device (default) or on the host."""
+        """Staged submits of sparse pictures validated and packed on the host (default) or on the device (errors deferred)."""
         host().mpeghost_batch_set_device_pack(self.h, int(on))
 
     def sync(self):
@@ -452,6 +455,13 @@ class HostSharded:
     def device_of(self, stream: int) -> int:
         return host().mpeghost_sharded_device_of(self.h, stream)
 
+    def set_device_pack(self, on: bool):
+        host().mpeghost_sharded_set_device_pack(self.h, int(on))
+
+    def sync(self):
+        if host().mpeghost_sharded_sync(self.h) != 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+
     def counters(self, shard: int):
         out = (C.c_uint64 * 2)()
         host().mpeghost_sharded_counters(self.h, shard, C.byref(out))
@@ -506,6 +516,12 @@ class HostAudioBatch:
             r = np.ctypeslib.as_array(C.cast(right.value, C.POINTER(C.c_float)), shape=(1152,))
             return np.concatenate([l, r])
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(2304,)).copy()
+
+    def decode_stream_directly(self, stream: int) -> bool:
+        r = host().mpeghost_audio_batch_decode_stream(self.h, stream)
+        if r < 0:
+            raise RuntimeError(host().mpeghost_last_error().decode())
+        return r == 1
 
     device_calls = property(lambda s: host().mpeghost_audio_batch_device_calls(s.h))
 

@@ -76,6 +76,79 @@ def test_two_ranks_gloo():
     assert k0 == k1 == 2.0                                      # both shards bit-exact vs the oracle
 
 
+def test_ranks_that_share_a_gpu_are_refused_unless_asked_for():
+    """bench.py's N > 1 line: n_gpus = the DISTINCT physical devices of the ranks (PCI addresses), and a launch whose ranks
+    share a device exits non-zero unless --share-devices says it is meant (round-4 review: `local_rank %= n_dev` let an
+    "8-GPU" number be measured on fewer).  mpeg_amd.shard.device_census is the rule, bench.py only gathers the addresses."""
+    from mpeg_amd.shard import device_census
+    eight = ["0000:%02x:00.0" % (0x05 + 0x10 * i) for i in range(8)]
+    c = device_census(eight)
+    assert c == {"devices": eight, "n_gpus": 8, "ranks": 8, "shared": False}
+    with pytest.raises(ValueError, match="--share-devices"):
+        device_census(eight[:4] * 2)                                  # 8 ranks on 4 GPUs: refused
+    with pytest.raises(ValueError):
+        device_census(["0000:05:00.0"] * 2)
+    c = device_census(["0000:05:00.0"] * 8, share_devices=True)       # the functional run on a one-GPU box
+    assert c["n_gpus"] == 1 and c["ranks"] == 8 and c["shared"] is True
+    assert device_census(["0000:05:00.0"]) == {"devices": ["0000:05:00.0"], "n_gpus": 1, "ranks": 1, "shared": False}
+    # bench.py applies it before any leg runs, and its lines carry the census, not the world size
+    src = (ROOT / "bench.py").read_text()
+    assert "device_census(ranks.gather_object(ctx.pci_bus_id()), args.share_devices)" in src
+    assert '"n_gpus": census["n_gpus"], "ranks": world' in src and '"n_gpus": world' not in src and '"n_gpus": ranks.world' not in src
+    assert '"untimed_prewarm_steps"' in src and '"effective_cores"' in src
+
+
+def _census_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [str(ROOT)]
+    from mpeg_amd.shard import Ranks, device_census
+    ranks = Ranks(backend="gloo")
+    ids = ranks.gather_object("0000:05:00.0" if rank < 2 else "0000:15:00.0")   # ranks 0 and 1 sit on one device
+    try:
+        device_census(ids)
+        refused = False
+    except ValueError:
+        refused = True
+    out.put((rank, ids, refused, device_census(ids, share_devices=True)["n_gpus"]))
+    ranks.close()
+
+
+def test_device_census_over_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_census_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ids, refused, n in res:       # every rank sees the same census and takes the same decision
+        assert ids == ["0000:05:00.0", "0000:05:00.0", "0000:15:00.0"] and refused and n == 2
+
+
+def test_effective_cores_reads_the_cgroup_quota(tmp_path, monkeypatch):
+    from mpeg_amd import shard
+    e = shard.effective_cores()
+    assert e["affinity_cpus"] >= 1 and 0 < e["effective_cores"] <= e["affinity_cpus"]
+    assert e["cgroup_quota_cores"] is None or e["effective_cores"] == min(e["affinity_cpus"], e["cgroup_quota_cores"])
+    # a v2 quota of 10.5 cores under a wide mask
+    real_open = open
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("1050000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    e = shard.effective_cores()
+    assert e == {"affinity_cpus": 256, "cgroup_quota_cores": 10.5, "effective_cores": 10.5}
+
+
 def test_numa_helpers_parse_sysfs_and_never_raise():
     """mpeg_amd.shard.pin_to_node: the rank's process goes to the cores of its GPU's NUMA node; unknown nodes, or a
     platform without sysfs / sched_setaffinity, change nothing."""

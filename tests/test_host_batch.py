@@ -165,3 +165,69 @@ def test_streams_sharded_over_two_stores(oracle, golden_dir):
     assert c0["queued_pictures"] >= 3 * 260 and c1["queued_pictures"] >= 2 * 278   # each shard queued its own streams only
     assert c0["queued_pictures"] + c1["queued_pictures"] < 5 * 300
     b.close()
+
+
+def test_sharded_batch_passes_device_pack_and_sync_through(oracle, golden_dir):
+    """ShardedVideoBatch::SetDevicePack / Sync reach every shard (round-4 advisor: the sharded driver had neither, so a
+    device-packed commit's deferred verdict could not be asked for): the same streams, device-packed on both shards, with a
+    Sync after every tick — same frames."""
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    b = hostlib.HostSharded(3, 2)
+    b.set_threads(2)
+    b.set_device_pack(True)
+    for _ in range(3):
+        b.add_stream(es)
+    h, n = [oracle.FNV_OFFSET] * 3, [0] * 3
+    while b.decode_all():
+        b.sync()
+        for i in range(3):
+            f = b.frame(i)
+            if f is not None:
+                for p in hostlib.frame_planes(f):
+                    h[i] = oracle.fnv1a64(p, h[i])
+                n[i] += 1
+    b.sync()
+    assert h == [VIDEO_HASH] * 3 and n == [260] * 3
+    b.close()
+
+
+def test_pools_are_sized_by_the_cpu_time_the_process_gets():
+    """SetThreads is a request: a pool never has more threads than the process has CPU time for (affinity mask capped by the
+    cgroup quota, rounded up) — BENCH_r04: 64 threads under a 10-core quota parsed 26 % slower than 16.  0 = as many as fit."""
+    import math
+    import os
+    L = hostlib.host()
+    eff = L.mpeghost_effective_cores()
+    assert 1 <= eff <= len(os.sched_getaffinity(0))
+    from mpeg_amd.shard import effective_cores
+    assert abs(effective_cores()["effective_cores"] - eff) < 1e-6        # bench.py's figure is the library's
+    cap = max(1, math.ceil(eff))
+    b = hostlib.HostBatch(4, threads=1)
+    for asked, got in ((1, 1), (2, min(2, cap)), (4096, cap), (0, cap)):
+        L.mpeghost_batch_set_threads(b.h, asked)
+        assert L.mpeghost_batch_threads(b.h) == got, (asked, got)
+    b.close()
+
+
+def test_audio_batch_with_a_pool_flushes_a_frame_decoded_outside_the_batch_tick(oracle, emu):
+    """A stream of the batch decoded DIRECTLY between two ticks leaves its slot occupied; the pooled DecodeAll used to throw
+    std::logic_error where the one-thread path flushes and goes on (round-4 advisor).  Both now flush first."""
+    from pathlib import Path
+    mp2 = (Path(__file__).resolve().parent / "golden" / "test.mp2").read_bytes()
+    win = (np.array(emu._window_x2(), np.float32) * np.float32(0.5)).astype(np.float32)
+    got = {}
+    for threads in (1, 3):
+        b = hostlib.HostAudioBatch(3, window=win)
+        hostlib.host().mpeghost_audio_batch_set_threads(b.h, threads)
+        for _ in range(3):
+            b.add_stream(mp2)
+        h = [oracle.FNV_OFFSET] * 3
+        for tick in range(12):
+            if tick == 5:
+                assert b.decode_stream_directly(1)          # stream 1 runs one frame ahead, outside the tick
+            assert b.decode_all() == 3
+            for k in range(3):
+                h[k] = oracle.fnv1a64(b.samples(k), h[k])
+        got[threads] = h
+        b.close()
+    assert got[1] == got[3] and got[1][0] == got[1][2] != got[1][1]

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 name=$1; rev=$2
 tmp=$(mktemp -d)
 git archive "$rev" mpeg_amd/csrc include | tar -x -C "$tmp"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=14 \
-    -fPIC -shared -I "$tmp/include" -I "$tmp/mpeg_amd/csrc" "$tmp/mpeg_amd/csrc/mpeghip.hip" -o "tools/ab/libmpeghip_$name.so"
+FLAGS=${FLAGS:-$(python -c "from mpeg_amd import _build; print(' '.join(_build.HIPCC_FLAGS))")}   # (FLAGS=...: another set, e.g. a previous round's)
+/opt/rocm/bin/hipcc $FLAGS -I "$tmp/include" -I "$tmp/mpeg_amd/csrc" "$tmp/mpeg_amd/csrc/mpeghip.hip" -o "tools/ab/libmpeghip_$name.so"
 rm -rf "$tmp"
 echo "built tools/ab/libmpeghip_$name.so from $rev"

@@ -11,8 +11,9 @@ import bench  # noqa: E402
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         asm = Path(tmp) / "mpeghip.s"
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=14",
-                        "-fPIC", "-I", str(ROOT / "include"), "-I", str(ROOT / "mpeg_amd/csrc"), "--cuda-device-only", "-S",
+        from mpeg_amd import _build
+        flags = [f for f in _build.HIPCC_FLAGS if f != "-shared"]
+        subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-I", str(ROOT / "include"), "-I", str(ROOT / "mpeg_amd/csrc"), "--cuda-device-only", "-S",
                         str(ROOT / "mpeg_amd/csrc/mpeghip.hip"), "-o", str(asm)], check=True, stderr=subprocess.DEVNULL)
         text = asm.read_text()
     print("# kernel resources of the shipped sources (hipcc --offload-arch=gfx950 -O3 ... -S, .amdgpu_metadata); csrc sha256 %s" % bench.sources_sha256())
