@@ -286,6 +286,35 @@ MPG_HD void dma16x5_to_lds(const uint8_t *const (&g_base)[5], const uint32_t (&o
         __builtin_memcpy(static_cast<char *>(lds_wave_base) + at[i] + 16 * lane, g_base[i] + off[i], 16);
 #endif
 }
+// The reconstruction kernel's five: one from the table array (its own base; lands at LDS offset kAtT = 0, so its offset field adds
+// nothing) and four from ONE frame base.  That base sits kRcDmaBias below the stream's frames and every lane offset carries
+// (kRcDmaBias - kAt_i) already (RcLane::cterm): the instruction's offset field, added to the LDS address AND to the global
+// one, restores the difference — no scalar arithmetic per load.  off[i] INCLUDES that correction: lane l's piece i is at
+// frame_base + off[i] + kAt_i.
+template <int kAtT, int kAt1, int kAt2, int kAt3, int kAt4>
+MPG_HD void dma_table_and_windows(const uint8_t *table_base, const uint8_t *frame_base, const uint32_t (&off)[5], void *lds_wave_base, int lane)
+{
+    static_assert(kAtT == 0 && kAt1 > 0 && kAt1 < 4096 && kAt2 < 4096 && kAt3 < 4096 && kAt4 < 4096, "13-bit signed offset field");
+#if MPG_ON_DEVICE
+    (void)lane;
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base); // LDS aperture: low 32 bits = offset
+    asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %5\n\t"
+                 "global_load_lds_dwordx4 %1, %6 offset:%8\n\t"
+                 "global_load_lds_dwordx4 %2, %6 offset:%9\n\t"
+                 "global_load_lds_dwordx4 %3, %6 offset:%10\n\t"
+                 "global_load_lds_dwordx4 %4, %6 offset:%11"
+                 :
+                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "s"(table_base), "s"(frame_base), "s"(base), "n"(kAt1), "n"(kAt2),
+                   "n"(kAt3), "n"(kAt4)
+                 : "memory");
+#else
+    const int at[5] = {kAtT, kAt1, kAt2, kAt3, kAt4};
+    __builtin_memcpy(static_cast<char *>(lds_wave_base) + at[0] + 16 * lane, table_base + off[0], 16);
+    for (int i = 1; i < 5; i++)
+        __builtin_memcpy(static_cast<char *>(lds_wave_base) + at[i] + 16 * lane, frame_base + off[i] + at[i], 16);
+#endif
+}
 // one dword per lane into a register; only valid after wait_loads + settle() — and settle() it on EVERY path, used or
 // not: until then the register belongs to the load, and the compiler must not hand it to something else
 MPG_HD uint32_t load32_uncounted(const uint32_t *uniform_base, uint32_t byte_off)
@@ -381,14 +410,9 @@ template <int kImm> MPG_HD void store32_streaming_at_imm(uint8_t *uniform_base, 
 // XCD-aware block remap (MI355X: 8 XCDs, block b runs on XCD b%8, each XCD has its
 // own L2).  Gives every XCD one contiguous range of work chunks so that
 // neighbouring macroblocks — which share 128-byte destination lines and overlapping
-// reference windows — meet in the same L2.  Bijective for any grid size.
-MPG_HD uint32_t xcd_chunk(uint32_t block, uint32_t n_blocks)
-{
-    const uint32_t nx = 8;
-    uint32_t q = n_blocks / nx, r = n_blocks % nx;
-    uint32_t xcd = block % nx, k = block / nx;
-    uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + k;
-}
+// reference windows — meet in the same L2.  The grid is 8 * grid8 blocks (callers round up; surplus blocks find their index
+// beyond the work and return): bijective on [0, 8 * grid8), and a multiply-add (any grid size cost a wave a dozen scalar
+// instructions of quotient-and-remainder bookkeeping).
+MPG_HD uint32_t xcd_chunk(uint32_t block, uint32_t grid8) { return (block & 7u) * grid8 + (block >> 3); }
 
 } // namespace mpg

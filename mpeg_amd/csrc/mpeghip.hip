@@ -21,6 +21,7 @@
 #include <new>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "audio_lane.h"
@@ -73,15 +74,16 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 // hidden one cannot be preloaded.  profiles/r34_ab_kernarg_preload.txt: typical +0.75 %, one picture 10.15 -> 9.86 us.
 template <int WAVES, bool kRgba, bool kT16, int kPerWave>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(
-    const uint32_t grid_blocks, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
-    uint8_t *const frames, const uint32_t mb_w, const uint32_t luma_bytes, const uint32_t luma_w, const uint32_t chroma_w, const VideoArgs rest)
+    const uint32_t grid8, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
+    uint8_t *const frames_b, const uint32_t mb_w, const uint32_t luma_bytes, const uint32_t luma_w, const uint32_t chroma_w, const VideoArgs rest)
 {
+    static_assert(WAVES == 1, "one wave per workgroup: the wave's LDS starts at 0 (lds_read32x2 / dma_table_and_windows)");
     VideoArgs a = rest;
     a.n_chunks = n_chunks;
     a.chunks = chunks;
     a.words = words;
     a.qmat = qmat;
-    a.frames = frames;
+    a.frames_b = frames_b;
     a.mb_w = mb_w;
     a.luma_bytes = luma_bytes;
     a.luma_w = luma_w;
@@ -92,30 +94,30 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     MPG_STAMP(0);
     constexpr int kLdsBytes = rc_lds_bytes<kT16>();
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kLdsBytes];
-    // (one wave per workgroup, the shipped shape: the wave's LDS starts at 0 and every LDS address below is lane part +
-    // immediate, with no per-wave base to add)
-    const uint32_t w = WAVES == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane_all = WAVES == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const int lane_all = (int)threadIdx.x;
     // a wave takes `per_wave` consecutive chunks, one after the other: the second one's header is loaded with the
     // first one's, and the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once
     constexpr uint32_t per_wave = kPerWave;
     static_assert(kPerWave == 1 || kPerWave == 2, "written out for one or two");
-    const uint32_t first = __builtin_amdgcn_readfirstlane((xcd_chunk(blockIdx.x, grid_blocks) * WAVES + w) * per_wave);
+    // XCD-aware remap (block b runs on XCD b % 8; each XCD has its own L2): every XCD gets one contiguous range of chunks.  The
+    // grid is a multiple of 8 (launch_batch rounds it up: at most 7 waves find nothing to do), so the map is a multiply-add.
+    const uint32_t first = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8) * per_wave);
     if (first >= a.n_chunks)
         return;
-    uint8_t *lds = lds_all + w * kLdsBytes;
+    uint8_t *lds = lds_all;
     int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);   // the int32 tile ...
     int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt); // ... or the int16 one (kT16)
 
 #if MPG_CHUNK_AHEAD
-    // pull the chunks a later wave of this XCD's range will take towards L2 (one lane per cache line of their 96 bytes
-    // each) so that that wave's scalar loads find them there; nothing is done with the data.  (Also pulling those chunks'
-    // first words, by a dependent load once the header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
+    // pull the chunk(s) a later wave of this XCD's range will take towards L2 (a chunk is one 128-byte line) so that that wave's
+    // scalar loads find them there; nothing is done with the data.  (Also pulling those chunks' first words, by a dependent
+    // load once the header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
     uint32_t ahead;
     {
-        const uint32_t later = first + MPG_CHUNK_AHEAD * per_wave + per_wave <= a.n_chunks ? first + MPG_CHUNK_AHEAD * per_wave : first;
-        const uint32_t line = (uint32_t)lane_all < (per_wave * kRcChunkDwords * 4 + 63) / 64 ? (uint32_t)lane_all : 0u;
-        ahead = load32_uncounted(a.chunks + (uint64_t)later * kRcChunkDwords, line * 64);
+        const uint32_t step = first + MPG_CHUNK_AHEAD * per_wave + per_wave <= a.n_chunks ? MPG_CHUNK_AHEAD * per_wave * kRcChunkDwords * 4 : 0u;
+        const uint32_t line = per_wave == 2 ? ((uint32_t)lane_all & 1u) * (kRcChunkDwords * 4) : 0u;
+        ahead = load32_uncounted(reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.chunks) + first * (kRcChunkDwords * 4)),
+                                 step + line);
     }
 #endif
     // step 1: one round of scalar loads (all of the wave's chunks), then per chunk its vector loads
@@ -136,15 +138,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
         MPG_STAMP(0);
 #endif
     MPG_STAMP(1);
-    uint32_t e = load32_uncounted(rc_ent_src(a, c, 0, 0), (uint32_t)lane * 4);
-    uint32_t bw = load32_uncounted(rc_blk_src(a, c), rc_blk_lane_offset(0, lane)); // (pass 0's block words)
+    const uint32_t *const wbase = rc_word_base(a, c); // the chunk's block words; its entries n_blocks dwords further on
+    uint8_t *const fbase = rc_frame_base(a, c);       // the stream's frames (biased: kRcDmaBias)
+    uint32_t e = load32_uncounted(wbase, rc_ent_lane_offset(c, 0, lane));
+    uint32_t bw = load32_uncounted(wbase, rc_blk_lane_offset(0, lane)); // (pass 0's block words)
     if (lane < kRcWinLanes) {
-        const uint8_t *const src[5] = {rc_table_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1), rc_win_base(a, c, 2),
-                                       rc_win_base(a, c, 3)};
-        const uint32_t off[5] = {(uint32_t)lane * 16, rc_win_offset(c, 0, k), rc_win_offset(c, 1, k), rc_win_offset(c, 2, k),
+        const uint32_t off[5] = {rc_table_lane_offset(c, lane), rc_win_offset(c, 0, k), rc_win_offset(c, 1, k), rc_win_offset(c, 2, k),
                                  rc_win_offset(c, 3, k)};
-        dma16x5_to_lds<kRcQtabAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes>(src, off, lds,
-                                                                                                                       lane);
+        dma_table_and_windows<kRcQtabAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes>(a.qmat, fbase, off,
+                                                                                                                              lds, lane);
     }
     MPG_STAMP(2);
 
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
         if (pass > 0)
             e = e_next;
         if ((pass + 1) * 8 < n_blocks) { // the next pass's block words and first 64 entries: on their way while this pass runs
-            bw_next = rc_blk_src(a, c)[rc_blk_lane_offset(pass + 1, lane) / 4];
+            bw_next = wbase[rc_blk_lane_offset(pass + 1, lane) / 4];
             if (rc_pass_entries(c, pass + 1)) // (a pass of dense units has none)
                 e_next = *rc_ent_src(a, c, ent_at + np, lane); // (beyond that pass's entries: ignored; the array is padded)
         }
@@ -279,29 +281,36 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     ahead_pending = false;
 #endif
     wave_lds_handoff();
-#pragma unroll
-    for (int m = 0; m < kRcMbs; m++) {
-        const uint32_t d0 = c.r[m][0];
-        if (d0 & kRDead)
-            continue;
-        uint8_t *win = lds + rc_win_at(m);
+    // (every macroblock of the common kind — predicted, window inside its plane — takes the short way: its record's scalars are
+    // what the instructions consume; intra macroblocks put zeros, a window that leaves its plane is gathered first)
+    auto mc_one = [&](auto M) {
+        constexpr int m = decltype(M)::value;
+        const uint32_t r0 = c.r[m][0];
         uint32_t yl = 0, yc = 0;
-        if (!(d0 & kRIntra)) {
-            if (d0 & kRSlow) { // the window leaves its plane: the reference's linear reads, gathered (rare)
+        if (!(r0 & (kRIntra | kRDead | kRSlow))) {
+            yl = rc_mc_luma<m>(lds, k, r0, c.r[m][3]);
+            yc = rc_mc_chroma<m>(lds, k, lane, r0, c.r[m][4], c.r[m][5]);
+        } else {
+            if (r0 & kRDead)
+                return;
+            if (r0 & kRSlow) { // the window leaves its plane: the reference's linear reads, gathered (rare)
+                uint8_t *win = lds + rc_win_at(m);
                 if (lane < 52)
-                    *reinterpret_cast<u32x4 *>(win + lane * 16) = rc_gather_piece(a, c, m, k);
+                    *reinterpret_cast<u32x4 *>(win + lane * 16) = rc_gather_piece(a, c, m, k, lane);
                 wave_lds_handoff();
+                yl = rc_mc_luma_slow(win, k, r0, c.r[m][3]);
+                yc = rc_mc_chroma_slow(win, k, r0, c.r[m][4]);
             }
-            const RcTaps t = rc_taps(d0, c.r[m][2], c.r[m][3]);
-            yl = rc_mc_luma(win, k, t, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
-            if (lane < 32)
-                yc = rc_mc_chroma(win, k, t, lane, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
         }
         wave_lds_handoff(); // every lane has its taps
+        uint8_t *win = lds + rc_win_at(m);
         *reinterpret_cast<uint32_t *>(win + k.out_luma) = yl;
-        if (lane < 32)
-            *reinterpret_cast<uint32_t *>(win + k.out_chroma) = yc;
-    }
+        *reinterpret_cast<uint32_t *>(win + k.out_chroma) = yc; // (lanes 32..63 repeat lanes 0..31: the same bytes to the same place)
+    };
+    mc_one(std::integral_constant<int, 0>{});
+    mc_one(std::integral_constant<int, 1>{});
+    mc_one(std::integral_constant<int, 2>{});
+    mc_one(std::integral_constant<int, 3>{});
     MPG_STAMP(4);
     if (n_blocks) {
         add_residual(0);
@@ -313,8 +322,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     MPG_STAMP(5);
     wave_lds_handoff();
     // step 5
-    const bool run = (c.h[5] & kCRun) != 0;
-    const bool rgba = kRgba && (c.h[5] & kCRgba) != 0;
+    const bool run = (c.h[4] & kCRun) != 0;
+    const bool rgba = kRgba && (c.h[4] & kCRgba) != 0;
     const uint32_t n_live = rc_n_live(c);
     if (run) {
         rc_store_run(a, c, lane, lds);
@@ -327,15 +336,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     if (kRgba && rgba) {
         if (!run)
             wave_lds_handoff();
+        uint8_t *const img = rc_rgba_image(a, c);
         if (run) {
 #pragma unroll
             for (uint32_t q = 0; q < 4; q++)
-                rc_rgba_run_rows(a, c, q, lane, lds);
+                rc_rgba_run_rows(a, c, img, q, lane, lds);
         } else {
 #pragma unroll
             for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
                 if (m < n_live)
-                    rc_rgba_mb(a, c, m, lane, lds);
+                    rc_rgba_mb(a, c, img, m, lane, lds);
         }
     }
 #ifdef MPG_PHASE_TIMING
@@ -487,19 +497,12 @@ __global__ __launch_bounds__(256) void pack_gate_kernel(const unsigned long long
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n_chunks)
         return;
-    uint32_t *h = chunks + (size_t)c * kRcChunkDwords;
-#pragma unroll
-    for (int i = 0; i < kRcChunkDwords; i++)
-        h[i] = 0;
-#pragma unroll
-    for (int m = 0; m < kRcMbs; m++)
-        h[8 + 4 * m] = kRDead;
+    rc_make_dead_chunk(chunks + (size_t)c * kRcChunkDwords);
 }
 
 struct ReplicateSteps {
     uint32_t words;       // words of one stream
-    uint32_t frames256;   // MPEGHIP_SLOTS * frame_stride >> 8
-    uint32_t rgba256;     // MPEGHIP_SLOTS * rgba_stride >> 8
+    uint64_t frames;      // MPEGHIP_SLOTS * frame_stride: bytes from one stream's first slot to the next one's
 };
 __global__ void replicate_kernel(mpeghip_pic_desc *pics, uint32_t n_pics, uint32_t *chunks, uint32_t n_chunks,
                                  uint32_t mbs_per_stream, ReplicateSteps k, uint32_t n_streams)
@@ -511,19 +514,17 @@ __global__ void replicate_kernel(mpeghip_pic_desc *pics, uint32_t n_pics, uint32
         const u32x4 *src = reinterpret_cast<const u32x4 *>(chunks + (uint64_t)i * kRcChunkDwords);
         u32x4 *dst = reinterpret_cast<u32x4 *>(chunks + gid * kRcChunkDwords);
         u32x4 h0 = src[0], h1 = src[1];
-        h0.v[0] += s * k.frames256;
-        h0.v[1] += s * k.rgba256;
-        h0.v[2] += s * 256u;
-        h0.v[3] += s * k.words;
-        h1.v[0] += s * k.words;
+        // (records name their windows from the stream's base: only the header knows which stream this is)
+        const uint64_t frames = ((uint64_t)h0.v[0] | ((uint64_t)h0.v[1] << 32)) + (uint64_t)s * k.frames;
+        const uint64_t words = ((uint64_t)h0.v[2] | ((uint64_t)h0.v[3] << 32)) + (uint64_t)s * k.words * 4;
+        h0.v[0] = (uint32_t)frames, h0.v[1] = (uint32_t)(frames >> 32);
+        h0.v[2] = (uint32_t)words, h0.v[3] = (uint32_t)(words >> 32);
+        h1.v[1] += s << kHStreamShift;
         dst[0] = h0;
         dst[1] = h1;
-        for (int m = 0; m < kRcMbs; m++) {
-            u32x4 r = src[2 + m];
-            r.v[1] += s * k.frames256; // (intra / dead records read the head of their own stream's frames instead)
-            dst[2 + m] = r;
-        }
-        static_assert(kRcChunkDwords == 24, "six 16-byte quarters per chunk");
+        for (int q = 2; q < kRcChunkDwords / 4; q++)
+            dst[q] = src[q];
+        static_assert(kRcChunkDwords == 32 && kRcHeadDwords == 8, "eight 16-byte quarters per chunk, the header in the first two");
     }
     const uint64_t total_pics = (uint64_t)n_pics * n_streams;
     if (gid >= (uint64_t)n_pics && gid < total_pics) {
@@ -964,8 +965,8 @@ int mpeghip_video_open(mpeghip_ctx *c, uint32_t width, uint32_t height, uint32_t
     if (!c || !out)
         return fail(MPEGHIP_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (width == 0 || height == 0 || width > 4095 || height > 4095 || n_streams == 0)
-        return fail(MPEGHIP_ERR_INVALID, "bad geometry %ux%u x %u streams", width, height, n_streams);
+    if (width == 0 || height == 0 || width > 4095 || height > 4095 || n_streams == 0 || n_streams > kRcMaxStreams)
+        return fail(MPEGHIP_ERR_INVALID, "bad geometry %ux%u x %u streams (at most %u streams per frame store)", width, height, n_streams, kRcMaxStreams);
     HIP_TRY(hipSetDevice(c->device));
     mpeghip_video *v = new (std::nothrow) mpeghip_video();
     if (!v)
@@ -1472,7 +1473,11 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
         return MPEGHIP_OK;
     const mpeghip_video_info &in = v->info;
     VideoArgs a;
+    if (b->n_chunks >= (1ull << 25))
+        return fail(MPEGHIP_ERR_INVALID, "batch too large for one launch: %llu chunks (a chunk's byte offset is a 32-bit product)",
+                    (unsigned long long)b->n_chunks);
     a.frames = v->d_frames;
+    a.frames_b = v->d_frames - kRcDmaBias;
     a.frame_stride = in.frame_stride;
     a.mb_w = in.mb_w;
     a.mb_h = in.mb_h;
@@ -1506,10 +1511,12 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     // profiles/r31_ab_chunks_per_wave_by_instance.txt); two for the int32-tile instance (dense +1.4 % with two).
     const uint64_t wave_slots = (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 7;
     const uint32_t per_wave = (t16 || a.n_chunks <= wave_slots) ? 1 : 2;
-    const uint32_t grid = (a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave);
+    // (a multiple of 8 workgroups: the kernel's XCD remap is then a multiply-add; the at most 7 surplus waves return at once)
+    const uint32_t grid8 = ((a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave) + 7) / 8;
+    const uint32_t grid = grid8 * 8;
 #define LAUNCH_RECON(RGBA, T16, PER_WAVE) \
-    hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, PER_WAVE>), dim3(grid), dim3(kReconWaves * 64), 0, st, grid, a.n_chunks, a.chunks, \
-                       a.words, a.qmat, a.frames, a.mb_w, a.luma_bytes, a.luma_w, a.chroma_w, a)
+    hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, PER_WAVE>), dim3(grid), dim3(kReconWaves * 64), 0, st, grid8, a.n_chunks, a.chunks, \
+                       a.words, a.qmat, a.frames_b, a.mb_w, a.luma_bytes, a.luma_w, a.chroma_w, a)
     if (t16) {
         if (b->any_rgba)
             LAUNCH_RECON(true, true, 1);
@@ -1580,7 +1587,7 @@ struct BlobLayout {
 static BlobLayout blob_layout(uint64_t n_pics, uint64_t n_chunks)
 {
     BlobLayout l;
-    l.c_at = (sizeof(mpeghip_pic_desc) * (size_t)n_pics + 63) & ~(size_t)63;
+    l.c_at = (sizeof(mpeghip_pic_desc) * (size_t)n_pics + 127) & ~(size_t)127; // (a chunk is one 128-byte line)
     l.w_at = (l.c_at + (size_t)n_chunks * kRcChunkDwords * 4 + 63) & ~(size_t)63;
     return l;
 }
@@ -1673,8 +1680,7 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
         const uint64_t work = (n_chunks > n_pics ? n_chunks : (uint64_t)n_pics) * replicas;
         ReplicateSteps k;
         k.words = (uint32_t)n_words;
-        k.frames256 = (uint32_t)((MPEGHIP_SLOTS * v->info.frame_stride) >> 8);
-        k.rgba256 = (uint32_t)((MPEGHIP_SLOTS * rgba_stride_of(v)) >> 8);
+        k.frames = (uint64_t)MPEGHIP_SLOTS * v->info.frame_stride;
         if (work) {
             hipLaunchKernelGGL(replicate_kernel, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, st, b->d_pics, n_pics,
                                b->d_chunks, (uint32_t)n_chunks, n_mbs, k, replicas);

@@ -15,6 +15,7 @@ namespace mpg {
 
 struct VideoArgs {
     uint8_t *frames;              // base of the frame store
+    uint8_t *frames_b;            // ... minus kRcDmaBias (video_recon_lane.h): what recon_kernel's waves add their stream's offset to
     uint64_t frame_stride;        // bytes between consecutive (stream, slot) frames
     uint32_t mb_w, mb_h;          // macroblocks per row / column
     uint32_t luma_w, luma_h;      // padded plane sizes = 16 mb_w, 16 mb_h

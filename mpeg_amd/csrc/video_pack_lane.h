@@ -149,7 +149,7 @@ struct PkLane {
     uint32_t live;      // the lane has a macroblock (k < the picture's count)
     uint32_t ok;        // ... and nothing is wrong with it: its words are packed
     uint32_t gi;        // its index in the submit's macroblock array
-    uint32_t d[4];      // its record
+    uint32_t d[kRcRecDwords]; // its record
     uint32_t cbp, intra, raw, qscale, mb_x, mb_y;
     uint32_t coef_off;  // dwords from the picture's first word
     uint32_t end;       // where its data ends
@@ -169,7 +169,7 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
     L.ok = 0;
     L.gi = p.mb_first + k;
     L.d[0] = kRDead;
-    L.d[1] = L.d[2] = L.d[3] = 0;
+    L.d[1] = L.d[2] = L.d[3] = L.d[4] = L.d[5] = 0;
     L.cbp = L.intra = L.raw = L.qscale = L.mb_x = L.mb_y = 0;
     L.coef_off = L.end = 0;
     L.nb = L.ents = L.def_dw = L.flags = L.use = 0;
@@ -229,36 +229,9 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
     L.qscale = mb.qscale & 31u;
     L.mb_x = mb.mb_x;
     L.mb_y = mb.mb_y;
-    // ---- the record (rc_pack_picture's, line by line)
-    {
-        const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
-        uint32_t d0 = ((uint32_t)mb.cbp << 8) | ((uint32_t)mb.mb_x << 16) | ((uint32_t)mb.mb_y << 24);
-        if (intra) {
-            L.d[0] = d0 | kRIntra;
-        } else {
-            d0 |= (mvx & 1) ? kROhL : 0;
-            d0 |= (mvy & 1) ? kROvL : 0;
-            d0 |= (cmx & 1) ? kROhC : 0;
-            d0 |= (cmy & 1) ? kROvC : 0;
-            const int32_t dst_luma = (int32_t)((uint32_t)mb.mb_y << 4) * (int32_t)a.luma_w + (int32_t)((uint32_t)mb.mb_x << 4);
-            const int32_t dst_chroma = (int32_t)((uint32_t)mb.mb_y << 3) * (int32_t)a.chroma_w + (int32_t)((uint32_t)mb.mb_x << 3);
-            const int32_t x0 = (int32_t)((uint32_t)mb.mb_x << 4) + (mvx >> 1), y0 = (int32_t)((uint32_t)mb.mb_y << 4) + (mvy >> 1);
-            const int32_t cx0 = (int32_t)((uint32_t)mb.mb_x << 3) + (cmx >> 1), cy0 = (int32_t)((uint32_t)mb.mb_y << 3) + (cmy >> 1);
-            const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (mvx & 1) <= (int32_t)a.luma_w && y0 + 16 + (mvy & 1) <= (int32_t)(a.mb_h << 4) &&
-                                cx0 >= 0 && cy0 >= 0 && cx0 + 8 + (cmx & 1) <= (int32_t)a.chroma_w && cy0 + 8 + (cmy & 1) <= (int32_t)(a.mb_h << 3);
-            L.d[1] = (uint32_t)(((s3 + ((mb.flags & MPEGHIP_MB_REF_BWD) ? p.bwd : p.fwd)) * a.frame_stride) >> 8);
-            if (inside) {
-                L.d[0] = d0;
-                L.d[2] = (((uint32_t)y0 >> 4) * a.mb_w + ((uint32_t)x0 >> 4)) * 256 | (((uint32_t)y0 & 15) << 4) | ((uint32_t)x0 & 15);
-                L.d[3] = (a.luma_bytes + (((uint32_t)cy0 >> 3) * a.mb_w + ((uint32_t)cx0 >> 3)) * kChromaBlockStep) | (((uint32_t)cy0 & 7) << 3) |
-                         ((uint32_t)cx0 & 7);
-            } else { // the reference's linear reads (validated above: inside [plane start, end of base))
-                L.d[0] = d0 | kRSlow;
-                L.d[2] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)a.luma_w + (mvx >> 1));
-                L.d[3] = a.luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)a.chroma_w + (cmx >> 1));
-            }
-        }
-    }
+    // ---- the record: the host packer's own function (video_recon_lane.h)
+    rc_make_record(a.mb_w, a.mb_h, a.luma_w, a.chroma_w, a.luma_bytes, a.frame_stride, mb.mb_x, mb.mb_y, mb.cbp, intra, mvx, mvy,
+                   (mb.flags & MPEGHIP_MB_REF_BWD) ? p.bwd : p.fwd, L.d);
     if (!intra || mb.cbp == 0x3f) // (an invalid intra block keeps the old pixels: no whole-row stores for its chunk)
         L.flags |= kPkXRunOk;
     // ---- its coded blocks: count word by count word (each tells where the next one is)
@@ -384,15 +357,14 @@ MPG_HD void pk_emit(const PackArgs &a, const mpeghip_pic_desc &p, const PkPic &x
         run = run && (s[0] & kPkXRunOk) && (s[2] >> 16) == (q[2] >> 16) && (s[2] & 0xffffu) == (q[2] & 0xffffu) + j;
     }
     uint32_t *h = a.chunks + (size_t)(x.chunk_first + (k0 >> 2)) * kRcChunkDwords;
-    uint32_t *d = h + 8 + m * 4;
+    uint32_t *d = h + kRcHeadDwords + m * kRcRecDwords;
     const bool mine = L.live && chunk_ok;
     d[0] = mine ? L.d[0] : (uint32_t)kRDead;
-    d[1] = mine ? L.d[1] : 0u;
-    d[2] = mine ? L.d[2] : 0u;
-    d[3] = mine ? L.d[3] : 0u;
+#pragma unroll
+    for (int i = 1; i < kRcRecDwords; i++)
+        d[i] = mine ? L.d[i] : 0u;
     const uint32_t W = x.word_first + q[3]; // the chunk's first word: where its first macroblock's data began
     if (m == 0) {
-        const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
         uint32_t counts = 0;
         if (chunk_ok) { // entries per pass of 8 slots
             uint32_t s = 0;
@@ -403,16 +375,16 @@ MPG_HD void pk_emit(const PackArgs &a, const mpeghip_pic_desc &p, const PkPic &x
                     counts += ((i < 4 ? sj[5] >> (8 * i) : sj[6] >> (8 * (i - 4))) & 0xffu) << (10 * (s >> 3));
             }
         }
-        h[0] = (uint32_t)(((s3 + p.cur) * a.frame_stride) >> 8);
-        h[1] = (uint32_t)(((s3 + p.cur) * a.rgba_stride) >> 8);
-        h[2] = p.stream * kRcQtabStride;
-        h[3] = W;
-        h[4] = W + (chunk_ok ? n_slots : 0u);
-        h[5] = chunk_ok ? counts | (run ? kCRun : 0u) | ((p.flags & MPEGHIP_PIC_RGBA) ? kCRgba : 0u) : 0u;
-        h[6] = chunk_ok ? n_slots | (live << 8) | ((any & kPkXAnyRaw) ? 1u << 16 : 0u) | ((any & kPkXAnyDense) ? 1u << 17 : 0u) |
-                              ((any & kPkXAnyDc) ? 1u << 18 : 0u)
-                        : 0u;
-        h[7] = 0;
+        uint32_t hd[kRcHeadDwords];
+        rc_make_header_base(a.frame_stride, a.luma_bytes, p.stream, p.cur, (q[2] >> 16) * a.mb_w + (q[2] & 0xffffu), hd);
+        const uint64_t wat = (uint64_t)W * 4;
+        h[0] = hd[0], h[1] = hd[1];
+        h[2] = (uint32_t)wat, h[3] = (uint32_t)(wat >> 32);
+        h[4] = chunk_ok ? counts | (run ? kCRun : 0u) | ((p.flags & MPEGHIP_PIC_RGBA) ? kCRgba : 0u) : 0u;
+        // (a chunk that is not packed: no blocks, no live macroblock — its records are dead)
+        h[5] = chunk_ok ? rc_header_flags(n_slots, live, (any & kPkXAnyRaw) != 0, (any & kPkXAnyDense) != 0, (any & kPkXAnyDc) != 0, p.cur, p.stream)
+                        : rc_header_flags(0, 0, false, false, false, p.cur, p.stream);
+        h[6] = hd[6], h[7] = hd[7];
     }
     if (!mine || !L.nb)
         return;

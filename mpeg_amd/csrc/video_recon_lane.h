@@ -5,21 +5,32 @@
 // the library's own device format, which the host half of the library (rc_pack_picture, called from the
 // validation pass of every submit / upload) writes straight into the buffer the H2D copy reads:
 //
-//   chunks  24 dwords per chunk: 8 header dwords + 4 records of 4 dwords — ONE round of scalar loads
-//           header  h0 destination frame offset >> 8        h1 RGBA image offset >> 8
-//                   h2 byte offset of the stream's dequantisation table (stream * kRcQtabStride)
-//                   h3 index (into words) of the chunk's first block word     h4 of its first coefficient entry
-//                   h5 entries of pass 0 | pass 1 << 10 | pass 2 << 20 | kCRun | kCRgba
-//                   h6 coded blocks (0..24) | live macroblocks << 8 | any snapshot block << 16 | any dense block << 17
-//                      | any block with its DC in its block word << 18
-//           record  d0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24        d1 reference frame offset >> 8
-//                   d2 the luma prediction window, origin (x0, y0) = macroblock origin + integer vector:
-//                      byte offset (inside the frame) of the 16x16 TILE that holds (x0, y0) | (y0 & 15) << 4 | x0 & 15
-//                   d3 the same for Cb: offset of the 8x8 block (luma_bytes included; its Cr block is 64 bytes further on)
-//                      | (cy0 & 7) << 3 | cx0 & 7
+//   chunks  32 dwords = ONE 128-byte line per chunk (round 5; 24 dwords until then): 8 header dwords + 4 records of 6 — one round
+//           of scalar loads, and everything a wave derives from them is either a scalar the packer has worked out or one vector
+//           instruction away (the round-4 form cost a wave 88 scalar instructions before its first load and ~45 per macroblock of
+//           motion compensation: DESIGN.md section 5.0)
+//           header  h0 h1  byte offset (64 bits) of the STREAM's first slot in the frame store: the wave's one frame base, for the
+//                          four windows and the stores alike
+//                   h2 h3  byte offset (64 bits) of the chunk's first block word in the words array (its entries follow its block words)
+//                   h4     entries of pass 0 | pass 1 << 10 | pass 2 << 20 | kCRun | kCRgba
+//                   h5     coded blocks (0..24) | live macroblocks << 5 | any snapshot block << 8 | any dense block << 9
+//                          | any block with its DC in its block word << 10 | destination slot << 11 | stream << 13
+//                   h6 h7  a run's destination: byte offsets, from the stream's base, of its four luma tiles / its four Cb | Cr pairs
+//                          (+ kRcDmaBias: the scalar base every access of the wave goes through sits that far below the stream)
+//           record  r0 kR* flags | cbp << 8 | mb_x << 16 | mb_y << 24
+//                   r1 the luma prediction window, origin (x0, y0) = macroblock origin + integer vector: byte offset, from the
+//                      stream's base, of the 16-byte piece that holds the window's first row in the 16x16 TILE that holds (x0, y0):
+//                      reference slot * frame_stride + tile * 256 + (y0 & 15) * 16
+//                   r2 the same for Cb MINUS r1: ... + luma_bytes + pair * 128 + ((cy0 & 7) >> 1) * 16 (its Cr block: 64 further on)
+//                   r3 8 (x0 & 3) | (8 (x0 & 3) + 8) << 8 | (x0 & 12) << 16: the luma taps' funnel shifts and the dword they start in
+//                   r4 8 (cx0 & 3) | (8 (cx0 & 3) + 8) << 8 | (cy0 & 1) << 16: the chroma taps' shifts, and whether the window starts
+//                      on the odd row of its first row pair
+//                   r5 (cx0 >> 2) & 1: the dword of a chroma row the window starts in
+//                      — every field where the instruction that consumes it looks: a shift amount in the low bits of a dword
+//                      (v_alignbit_b32 / v_lshrrev_b64 read 5 / 6 bits), a multiplicand in a 16-bit half (v_mad_u32_u16 op_sel)
 //                   kRSlow records (a window that leaves its plane: the reference reads on, linearly, into the next
-//                   row / plane / the pad, video_noasm.go:48-80) carry the window origins as LINEAR byte offsets
-//                   of the reference's layout instead; the kernel gathers those windows dword by dword
+//                   row / plane / the pad, video_noasm.go:48-80): r1 = the reference slot's offset, r2 = 0, r3 / r4 = the window
+//                   origins as LINEAR byte offsets of the reference's layout; the kernel gathers those windows dword by dword
 //   words   per chunk, one after the other (a wave's loads share cache lines):
 //           block words, one per coded block, in (macroblock, block) order = "slot" order:
 //                   LDS byte offset / 8 of the block's row 0 in the output bytes | chroma << 9 | snapshot << 10
@@ -81,8 +92,18 @@ namespace mpg {
 
 constexpr int kRcMbs = 4;                     // macroblocks per chunk = per wave
 constexpr int kRcMaxBlocks = 6 * kRcMbs;      // 24 slots, 3 passes of 8
-constexpr int kRcChunkDwords = 8 + 4 * kRcMbs;
-constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                                    // header h5
+constexpr int kRcHeadDwords = 8, kRcRecDwords = 6;
+constexpr int kRcChunkDwords = kRcHeadDwords + kRcRecDwords * kRcMbs; // 32: one 128-byte line
+constexpr uint32_t kCRun = 1u << 30, kCRgba = 1u << 31;                                    // header h4
+// header h5
+constexpr uint32_t kHBlocksMask = 0x1f, kHLiveShift = 5, kHAnyRaw = 1u << 8, kHAnyDense = 1u << 9, kHAnyDcWord = 1u << 10, kHCurShift = 11,
+                   kHStreamShift = 13;
+constexpr uint32_t kRcMaxStreams = 1u << (32 - kHStreamShift); // 524 288 per frame store
+// Every access a wave makes to the frame store goes through ONE scalar base, the stream's first slot MINUS this: the four
+// window loads carry their LDS target in the instruction's offset field, which the hardware adds to the global address as
+// well (lane_common.h: dma16x5_to_lds) — with the base moved back once, by more than the largest of those offsets, the
+// correction is a constant in each lane's piece offset instead of a 64-bit scalar subtraction per window.
+constexpr uint32_t kRcDmaBias = 4096;
 constexpr uint32_t kRIntra = 1, kRDead = 2, kROhL = 4, kROvL = 8, kROhC = 16, kROvC = 32, kRSlow = 64; // record d0
 constexpr uint32_t kBChroma = 1u << 9, kBRaw = 1u << 10, kBDense = 1u << 11, kBDcWord = 1u << 28;    // block word
 constexpr uint32_t kDenseAbove = 32; // non-zero levels beyond which a block travels as a dense unit
@@ -217,6 +238,75 @@ static inline bool rc_host_has_avx512()
 }
 #endif
 
+// ---- one macroblock's record: ONE function for the host packer below and the device packer (video_pack_lane.h), so that the two
+// cannot drift apart.  ref_slot: the slot (0..2) the macroblock predicts from (ignored for intra).  The address arithmetic of
+// video_noasm.go:28-43 / video.go:747-770 happens here, once per macroblock at pack time, not once per wave at run time.
+MPG_HD void rc_make_record(uint32_t mb_w, uint32_t mb_h, uint32_t luma_w, uint32_t chroma_w, uint32_t luma_bytes, uint64_t frame_stride,
+                           uint32_t mb_x, uint32_t mb_y, uint32_t cbp, bool intra, int32_t mvx, int32_t mvy, uint32_t ref_slot,
+                           uint32_t (&r)[kRcRecDwords])
+{
+    const uint32_t r0 = (cbp << 8) | (mb_x << 16) | (mb_y << 24);
+    r[1] = r[2] = r[3] = r[4] = r[5] = 0;
+    if (intra) { // (its window loads fetch the head of the stream's first slot: valid memory, never used)
+        r[0] = r0 | kRIntra;
+        return;
+    }
+    const int32_t cmx = mvx / 2, cmy = mvy / 2; // toward zero, video_noasm.go:35-36
+    uint32_t f = 0;
+    f |= (mvx & 1) ? kROhL : 0;
+    f |= (mvy & 1) ? kROvL : 0;
+    f |= (cmx & 1) ? kROhC : 0;
+    f |= (cmy & 1) ? kROvC : 0;
+    // window origins in pixels; inside their planes (the normal case) the tiles are addressed directly
+    const int32_t x0 = (int32_t)(mb_x << 4) + (mvx >> 1), y0 = (int32_t)(mb_y << 4) + (mvy >> 1);
+    const int32_t cx0 = (int32_t)(mb_x << 3) + (cmx >> 1), cy0 = (int32_t)(mb_y << 3) + (cmy >> 1);
+    const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (mvx & 1) <= (int32_t)luma_w && y0 + 16 + (mvy & 1) <= (int32_t)(mb_h << 4) &&
+                        cx0 >= 0 && cy0 >= 0 && cx0 + 8 + (cmx & 1) <= (int32_t)chroma_w && cy0 + 8 + (cmy & 1) <= (int32_t)(mb_h << 3);
+    const uint32_t ref_off = (uint32_t)(ref_slot * frame_stride); // (3 slots of at most 25 MB: 32 bits hold it)
+    if (inside) {
+        const uint32_t ux = (uint32_t)x0, uy = (uint32_t)y0, ucx = (uint32_t)cx0, ucy = (uint32_t)cy0;
+        const uint32_t xl = ref_off + ((uy >> 4) * mb_w + (ux >> 4)) * 256 + (uy & 15) * 16;
+        const uint32_t xc = ref_off + luma_bytes + ((ucy >> 3) * mb_w + (ucx >> 3)) * kChromaBlockStep + ((ucy & 7) >> 1) * 16;
+        const uint32_t sl = (ux & 3) * 8, sc = (ucx & 3) * 8;
+        r[0] = r0 | f;
+        r[1] = xl;
+        r[2] = xc - xl;
+        r[3] = sl | ((sl + 8) << 8) | ((ux & 12) << 16);
+        r[4] = sc | ((sc + 8) << 8) | ((ucy & 1) << 16);
+        r[5] = (ucx >> 2) & 1;
+    } else { // the reference's linear reads (validated: inside [plane start, end of base))
+        const int32_t dst_luma = (int32_t)(mb_y << 4) * (int32_t)luma_w + (int32_t)(mb_x << 4);
+        const int32_t dst_chroma = (int32_t)(mb_y << 3) * (int32_t)chroma_w + (int32_t)(mb_x << 3);
+        r[0] = r0 | f | kRSlow;
+        r[1] = ref_off;
+        r[3] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)luma_w + (mvx >> 1));
+        r[4] = luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)chroma_w + (cmx >> 1));
+    }
+}
+// the header dwords that do not depend on the chunk's blocks.  mb0: raster index of the chunk's first macroblock (a run's tiles)
+MPG_HD void rc_make_header_base(uint64_t frame_stride, uint32_t luma_bytes, uint32_t stream, uint32_t cur_slot, uint32_t mb0, uint32_t (&h)[kRcHeadDwords])
+{
+    const uint64_t base = (uint64_t)stream * MPEGHIP_SLOTS * frame_stride;
+    const uint32_t cur_off = (uint32_t)(cur_slot * frame_stride);
+    h[0] = (uint32_t)base;
+    h[1] = (uint32_t)(base >> 32);
+    h[6] = kRcDmaBias + cur_off + mb0 * 256;
+    h[7] = kRcDmaBias + cur_off + luma_bytes + mb0 * kChromaBlockStep;
+}
+MPG_HD uint32_t rc_header_flags(uint32_t n_slots, uint32_t live, bool any_raw, bool any_dense, bool any_dcword, uint32_t cur_slot, uint32_t stream)
+{
+    return n_slots | (live << kHLiveShift) | (any_raw ? kHAnyRaw : 0u) | (any_dense ? kHAnyDense : 0u) | (any_dcword ? kHAnyDcWord : 0u) |
+           (cur_slot << kHCurShift) | (stream << kHStreamShift);
+}
+// a chunk that does nothing (a refused device-packed commit; padding)
+MPG_HD void rc_make_dead_chunk(uint32_t *h)
+{
+    for (int i = 0; i < kRcChunkDwords; i++)
+        h[i] = 0;
+    for (int m = 0; m < kRcMbs; m++)
+        h[kRcHeadDwords + kRcRecDwords * m] = kRDead;
+}
+
 static inline size_t rc_max_chunks(uint32_t n) { return ((size_t)n + kRcMbs - 1) / kRcMbs; }
 static inline size_t rc_max_words(uint64_t units) { return (size_t)units * 65; }
 constexpr size_t kRcWordsPad = 256; // dwords behind the last chunk's words that a wave may read (and ignore)
@@ -287,11 +377,6 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
 #if MPG_HOST_AVX512
     const bool wide = kWide && rc_host_has_avx512();
 #endif
-    const uint64_t s3 = (uint64_t)p.stream * MPEGHIP_SLOTS;
-    const uint32_t cur256 = (uint32_t)(((s3 + p.cur) * g.frame_stride) >> 8); // strides are multiples of 256
-    const uint32_t fwd256 = (uint32_t)(((s3 + p.fwd) * g.frame_stride) >> 8);
-    const uint32_t bwd256 = (uint32_t)(((s3 + p.bwd) * g.frame_stride) >> 8);
-    const uint32_t rgba256 = (uint32_t)(((s3 + p.cur) * g.rgba_stride) >> 8);
     const bool rgba = (p.flags & MPEGHIP_PIC_RGBA) != 0;
     for (uint32_t k0 = 0; k0 < n; k0 += kRcMbs) {
         const uint32_t live = n - k0 < (uint32_t)kRcMbs ? n - k0 : (uint32_t)kRcMbs;
@@ -315,42 +400,20 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         bool any_raw = false, any_dense = false, any_dcword = false;
         bool run = live == (uint32_t)kRcMbs; // 4 consecutive macroblocks of one row = 4 consecutive tiles
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++) {
-            uint32_t *d = h + 8 + m * 4;
+            uint32_t *d = h + kRcHeadDwords + m * kRcRecDwords;
             if (m >= live) { // padding behind the picture's last macroblock
                 d[0] = kRDead;
-                d[1] = d[2] = d[3] = 0;
+                d[1] = d[2] = d[3] = d[4] = d[5] = 0;
                 continue;
             }
             const mpeghip_mb_desc &mb = mbs[k0 + m];
             const bool intra = (mb.flags & MPEGHIP_MB_INTRA) != 0, raw = (mb.flags & MPEGHIP_MB_COEF_RAW) != 0;
-            const int32_t mvx = mb.mv_x, mvy = mb.mv_y;
-            const int32_t cmx = mvx / 2, cmy = mvy / 2; // toward zero, video_noasm.go:35-36
-            uint32_t d0 = ((uint32_t)mb.cbp << 8) | ((uint32_t)mb.mb_x << 16) | ((uint32_t)mb.mb_y << 24);
-            if (intra) {
-                d[0] = d0 | kRIntra;
-                d[1] = d[2] = d[3] = 0; // its (unused) prediction loads read the head of the frame store
-            } else {
-                d0 |= (mvx & 1) ? kROhL : 0;
-                d0 |= (mvy & 1) ? kROvL : 0;
-                d0 |= (cmx & 1) ? kROhC : 0;
-                d0 |= (cmy & 1) ? kROvC : 0;
-                const int32_t dst_luma = (int32_t)((uint32_t)mb.mb_y << 4) * (int32_t)g.luma_w + (int32_t)((uint32_t)mb.mb_x << 4);
-                const int32_t dst_chroma = (int32_t)((uint32_t)mb.mb_y << 3) * (int32_t)g.chroma_w + (int32_t)((uint32_t)mb.mb_x << 3);
-                // window origins in pixels; inside their planes (the normal case) the tiles are addressed directly
-                const int32_t x0 = (int32_t)((uint32_t)mb.mb_x << 4) + (mvx >> 1), y0 = (int32_t)((uint32_t)mb.mb_y << 4) + (mvy >> 1);
-                const int32_t cx0 = (int32_t)((uint32_t)mb.mb_x << 3) + (cmx >> 1), cy0 = (int32_t)((uint32_t)mb.mb_y << 3) + (cmy >> 1);
-                const bool inside = x0 >= 0 && y0 >= 0 && x0 + 16 + (mvx & 1) <= (int32_t)g.luma_w && y0 + 16 + (mvy & 1) <= (int32_t)(g.mb_h << 4) &&
-                                    cx0 >= 0 && cy0 >= 0 && cx0 + 8 + (cmx & 1) <= (int32_t)g.chroma_w && cy0 + 8 + (cmy & 1) <= (int32_t)(g.mb_h << 3);
-                d[1] = (mb.flags & MPEGHIP_MB_REF_BWD) ? bwd256 : fwd256;
-                if (inside) {
-                    d[0] = d0;
-                    d[2] = (((uint32_t)y0 >> 4) * g.mb_w + ((uint32_t)x0 >> 4)) * 256 | (((uint32_t)y0 & 15) << 4) | ((uint32_t)x0 & 15);
-                    d[3] = (g.luma_bytes + (((uint32_t)cy0 >> 3) * g.mb_w + ((uint32_t)cx0 >> 3)) * kChromaBlockStep) | (((uint32_t)cy0 & 7) << 3) | ((uint32_t)cx0 & 7);
-                } else { // the reference's linear reads (validated: inside [plane start, end of base))
-                    d[0] = d0 | kRSlow;
-                    d[2] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)g.luma_w + (mvx >> 1));
-                    d[3] = g.luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)g.chroma_w + (cmx >> 1));
-                }
+            {
+                uint32_t rec[kRcRecDwords];
+                rc_make_record(g.mb_w, g.mb_h, g.luma_w, g.chroma_w, g.luma_bytes, g.frame_stride, mb.mb_x, mb.mb_y, mb.cbp, intra, mb.mv_x,
+                               mb.mv_y, (mb.flags & MPEGHIP_MB_REF_BWD) ? p.bwd : p.fwd, rec);
+                for (int i = 0; i < kRcRecDwords; i++)
+                    d[i] = rec[i];
             }
             run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
                   (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
@@ -497,14 +560,16 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
             memcpy(e0 + ne, deferred[i].unit, deferred[i].dwords * 4);
             ne += deferred[i].dwords;
         }
-        h[0] = cur256;
-        h[1] = rgba256;
-        h[2] = p.stream * kRcQtabStride;
-        h[3] = word_base + out.words;
-        h[4] = word_base + out.words + n_slots;
-        h[5] = counts | (run ? kCRun : 0u) | (rgba ? kCRgba : 0u);
-        h[6] = n_slots | (live << 8) | (any_raw ? 1u << 16 : 0u) | (any_dense ? 1u << 17 : 0u) | (any_dcword ? 1u << 18 : 0u);
-        h[7] = 0;
+        {
+            uint32_t hd[kRcHeadDwords];
+            rc_make_header_base(g.frame_stride, g.luma_bytes, p.stream, p.cur, (uint32_t)mbs[k0].mb_y * g.mb_w + mbs[k0].mb_x, hd);
+            const uint64_t wat = ((uint64_t)word_base + out.words) * 4;
+            h[0] = hd[0], h[1] = hd[1];
+            h[2] = (uint32_t)wat, h[3] = (uint32_t)(wat >> 32);
+            h[4] = counts | (run ? kCRun : 0u) | (rgba ? kCRgba : 0u);
+            h[5] = rc_header_flags(n_slots, live, any_raw, any_dense, any_dcword, p.cur, p.stream);
+            h[6] = hd[6], h[7] = hd[7];
+        }
         out.chunks++;
         out.words += n_slots + ne;
         out.blocks += n_slots;
@@ -516,137 +581,221 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
 static inline void rc_rebase(uint32_t *chunks, uint32_t n_chunks, uint32_t word_base)
 {
     for (uint32_t c = 0; c < n_chunks; c++) {
-        chunks[(size_t)c * kRcChunkDwords + 3] += word_base;
-        chunks[(size_t)c * kRcChunkDwords + 4] += word_base;
+        uint32_t *h = chunks + (size_t)c * kRcChunkDwords;
+        const uint64_t wat = ((uint64_t)h[2] | ((uint64_t)h[3] << 32)) + (uint64_t)word_base * 4;
+        h[2] = (uint32_t)wat, h[3] = (uint32_t)(wat >> 32);
     }
 }
+// dword index of a chunk's first block word (tests, the emulator's statistics)
+static inline uint64_t rc_chunk_word_index(const uint32_t *h) { return ((uint64_t)h[2] | ((uint64_t)h[3] << 32)) / 4; }
 
 // ===================================================================== device half: lane functions
 // (also compiled by g++ into tests/kernel_emu, which runs the 64 lanes of a wave in a loop, phase by phase)
 
 struct RcChunk {
-    uint32_t h[8];
-    uint32_t r[kRcMbs][4];
+    uint64_t off[2];           // h0 h1, h2 h3 as the two 64-bit offsets they are (one scalar add + add-with-carry each)
+    uint32_t h[kRcHeadDwords]; // (h[4..7]; 0..3 are not kept)
+    uint32_t r[kRcMbs][kRcRecDwords];
 };
 
 MPG_HD RcChunk rc_load_chunk(const VideoArgs &a, uint32_t chunk)
 {
-    const MPG_CONST_AS uint32_t *p = (const MPG_CONST_AS uint32_t *)(uintptr_t)a.chunks + (uint64_t)chunk * kRcChunkDwords;
+    // (chunk * 128 bytes: a 32-bit product — launch_batch refuses batches of 2^25 chunks and more)
+    const MPG_CONST_AS uint32_t *p = (const MPG_CONST_AS uint32_t *)((uintptr_t)a.chunks + (uint32_t)(chunk * (kRcChunkDwords * 4)));
     RcChunk c;
+    c.off[0] = *reinterpret_cast<const MPG_CONST_AS uint64_t *>(p);
+    c.off[1] = *reinterpret_cast<const MPG_CONST_AS uint64_t *>(p + 2);
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 4; i++)
+        c.h[i] = 0;
+#pragma unroll
+    for (int i = 4; i < kRcHeadDwords; i++)
         c.h[i] = p[i];
 #pragma unroll
     for (int m = 0; m < kRcMbs; m++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            c.r[m][i] = p[8 + m * 4 + i];
+        for (int i = 0; i < kRcRecDwords; i++)
+            c.r[m][i] = p[kRcHeadDwords + m * kRcRecDwords + i];
     return c;
 }
 
-MPG_HD uint32_t rc_n_blocks(const RcChunk &c) { return c.h[6] & 0xff; }
-MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[6] >> 8) & 0xff; }
-MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[6] >> 16) & 1; }
-MPG_HD bool rc_any_dense(const RcChunk &c) { return (c.h[6] >> 17) & 1; }
-MPG_HD bool rc_any_dcword(const RcChunk &c) { return (c.h[6] >> 18) & 1; } // (intra macroblocks only: most chunks skip the test per lane)
-MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[5] >> (10 * pass)) & 0x3ff; }
+MPG_HD uint32_t rc_n_blocks(const RcChunk &c) { return c.h[5] & kHBlocksMask; }
+MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[5] >> kHLiveShift) & 7; }
+MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[5] & kHAnyRaw) != 0; }
+MPG_HD bool rc_any_dense(const RcChunk &c) { return (c.h[5] & kHAnyDense) != 0; }
+MPG_HD bool rc_any_dcword(const RcChunk &c) { return (c.h[5] & kHAnyDcWord) != 0; } // (intra macroblocks only: most chunks skip the test per lane)
+MPG_HD uint32_t rc_cur_slot(const RcChunk &c) { return (c.h[5] >> kHCurShift) & 3; }
+MPG_HD uint32_t rc_stream(const RcChunk &c) { return c.h[5] >> kHStreamShift; }
+MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[4] >> (10 * pass)) & 0x3ff; }
+// the wave's scalar bases: the stream's frames (moved back by kRcDmaBias: every offset below carries that bias) and the chunk's words
+MPG_HD uint8_t *rc_frame_base(const VideoArgs &a, const RcChunk &c) { return a.frames_b + c.off[0]; }
+MPG_HD const uint32_t *rc_word_base(const VideoArgs &a, const RcChunk &c)
+{
+    return reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.words) + c.off[1]);
+}
+// the destination slot's offset from that base (chunks that are not runs, the fused colour conversion)
+MPG_HD uint32_t rc_cur_offset(const VideoArgs &a, const RcChunk &c) { return kRcDmaBias + rc_cur_slot(c) * (uint32_t)a.frame_stride; }
 
-// what depends on the lane only (worked out once per wave)
+// ---- 16-bit multiply-adds whose wave-uniform multiplicand sits in one half of a record dword (the packer puts it there): the
+// instruction's operand select picks the half, so a field of a record reaches a lane's address with no scalar instruction
+// (no s_bfe / s_lshr / s_and in front of it).  kHi: the multiplicand is the dword's upper half.
+template <bool kHi> MPG_HD uint32_t mad_u16_field(uint32_t field_dword, uint32_t lane_factor, uint32_t addend)
+{
+#if MPG_ON_DEVICE
+    uint32_t r;
+    if (kHi)
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "s"(field_dword), "v"(lane_factor), "v"(addend));
+    else
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "s"(field_dword), "v"(lane_factor), "v"(addend));
+    return r;
+#else
+    MPG_CHECK(lane_factor < 65536);
+    return ((field_dword >> (kHi ? 16 : 0)) & 0xffffu) * (lane_factor & 0xffffu) + addend;
+#endif
+}
+template <bool kHi> MPG_HD int32_t mad_i16_field(uint32_t field_dword, int32_t lane_factor, int32_t addend) // signed halves
+{
+#if MPG_ON_DEVICE
+    int32_t r;
+    if (kHi)
+        asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "s"(field_dword), "v"(lane_factor), "v"(addend));
+    else
+        asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "s"(field_dword), "v"(lane_factor), "v"(addend));
+    return r;
+#else
+    MPG_CHECK(lane_factor >= -32768 && lane_factor < 32768);
+    return (int32_t)(int16_t)(field_dword >> (kHi ? 16 : 0)) * lane_factor + addend;
+#endif
+}
+MPG_HD uint32_t add_u16_hi(uint32_t field_dword, uint32_t addend) // (upper half of a record dword) + addend
+{
+#if MPG_ON_DEVICE
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, 1, %2 op_sel:[1,0,0,0]" : "=v"(r) : "s"(field_dword), "v"(addend));
+    return r;
+#else
+    return (field_dword >> 16) + addend;
+#endif
+}
+MPG_HD uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) // a * b + c, a and b within 24 bits: one full-rate instruction
+{
+#if MPG_ON_DEVICE
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    MPG_CHECK(a < (1u << 24) && b < (1u << 24));
+    return a * b + c;
+#endif
+}
+
+// what depends on the lane only (worked out once per wave, while the chunk header is on its way)
 struct RcLane {
     // as lane of a window load (piece `lane` < 54): luma pieces (lane < 34) are (row lane>>1, tile column lane&1),
-    // chroma pieces (plane, row pair, block column).  A record's d2 / d3 with their low 4 bits cleared are X = (offset of
-    // the tile / block that holds the window origin) + 16 * (the origin's row / row pair inside it); with u = (X & sub_mask)
-    // + rj16 the piece's frame offset is X + rj16 + cterm + (u >> wrap_shift ? below : 0): a tile / block is wrap bytes
-    // long, the one below it is `stride` further on, and u counts 16-byte pieces from the top of the first one.
+    // chroma pieces (plane, row pair, block column).  A record's r1 / r1 + r2 is X = (offset of the tile / block that holds the
+    // window origin) + 16 * (the origin's row / row pair inside it); with u = (X & sub_mask) + rj16 the piece's offset is
+    // X + cterm + (u >> wrap_shift) * below: a tile / block is `wrap` bytes long, the one below it is `below + wrap` further
+    // on, and u counts 16-byte pieces from the top of the first one.
     uint32_t piece_chroma; // all ones if the piece is chroma, else 0
     uint32_t sub_mask;     // 0xf0 (16 rows per tile) / 0x30 (4 row pairs per block)
     uint32_t rj16;         // 16 * (luma: row 0..16; chroma: row pair 0..4)
-    uint32_t rj16_cterm;   // rj16 + (tile column * 256 / plane * chroma_bytes + block column * 64)
+    uint32_t cterm[kRcMbs]; // rj16 + (tile column * 256 / plane * 64 + block column * 128) + kRcDmaBias - (LDS offset of window m): the
+                           // instruction's offset field, which carries that LDS offset, is added to the global address too
     uint32_t wrap_shift;   // 8 / 6
-    uint32_t below;        // mb_w * 256 - 256 / mb_w * 64 - 64
-    uint32_t lin_off;      // the same piece of a LINEAR window (kRSlow; lanes < 52): luma row * luma_w + column * 16 /
-                           // plane * chroma_bytes + row * chroma_w (17 rows x 2, then 9 rows per plane)
-    uint32_t lin_chroma;
+    uint32_t below;        // mb_w * 256 - 256 / mb_w * 128 - 64
     uint32_t mc_luma;      // as MC lane (row lane>>2, quarter lane&3): LDS offset of its taps inside a window = (lane>>2)*32 + (lane&3)*4
-    uint32_t mc_plane;     // lanes 0..31 (plane lane>>4, row (lane>>1)&7, half lane&1): plane * 160 — tiled chroma pieces
-    int32_t mc_c0, mc_ck, mc_ck2, mc_cs, mc_cs2; // the affine address map of rc_mc_chroma
-    uint32_t mc_lin;       // linear chroma rows: kRcWinLuma + (plane*9 + row)*16 + half*4
+    // chroma taps, lanes 0..31 (plane (lane>>4)&1, row (lane>>1)&7, half lane&1; lanes 32..63 mirror them: no divergence, their
+    // results are not stored): the affine address map of rc_mc_chroma
+    uint32_t mc_plane;     // plane * 160 — tiled chroma pieces
+    uint32_t mc_c0, mc_dr, mc_dc;
+    int32_t mc_cs, mc_cs2, mc_ck, mc_ck2;
+    uint32_t mc_lin;       // linear chroma rows (kRSlow): kRcWinLuma + (plane*9 + row)*16 + half*4
+    uint32_t ones;         // 0x01010101 in a vector register: the rounding byte of v_lerp_u8 (a literal would be a scalar move per use)
     uint32_t out_luma;     // where the lane's 4 luma bytes go inside O_m: lane * 4
-    uint32_t out_chroma;   // 4 chroma bytes: 256 + lane * 4
+    uint32_t out_chroma;   // 4 chroma bytes: 256 + (lane & 31) * 4
 };
 
 MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
 {
     const uint32_t l = (uint32_t)lane;
     RcLane k;
-    {
-        const bool chroma = l >= 34;
-        const uint32_t ci = l - 34, plane = ci >= 10 ? 1u : 0u, cj = ci - plane * 10;
-        const uint32_t rj = chroma ? cj >> 1 : l >> 1;
-        k.piece_chroma = opaque(chroma ? ~0u : 0u); // (a plain mask: the compiler must not turn `x & mask` into selects)
-        k.sub_mask = chroma ? 0x30 : 0xf0;
+    {   // (arithmetic on a 0 / 1 flag, not selects between expressions: the compiler makes divergent branches of those, a dozen
+        // scalar instructions of mask bookkeeping in every wave's prologue)
+        const uint32_t ch = opaque(l >= 34 ? 1u : 0u);      // a chroma piece
+        const uint32_t ci = l - 34;                          // (chroma lanes only)
+        const uint32_t plane = opaque(l >= 44 ? 1u : 0u);    // Cr
+        const uint32_t cj = ci - plane * 10;
+        const uint32_t rj = (l >> 1) + ch * ((cj >> 1) - (l >> 1));
+        k.piece_chroma = 0u - ch;
+        k.sub_mask = 0xf0 - ch * 0xc0;
         k.rj16 = rj * 16;
-        k.rj16_cterm = rj * 16 + (chroma ? plane * kChromaCrAt + (cj & 1) * kChromaBlockStep : (l & 1) * 256);
-        k.wrap_shift = chroma ? 6 : 8;
-        k.below = chroma ? a.mb_w * kChromaBlockStep - 64 : a.mb_w * 256 - 256;
-    }
-    {
-        const bool chroma = l >= 34;
-        const uint32_t ci = l - 34, plane = ci >= 9 ? 1u : 0u;
-        k.lin_chroma = chroma ? ~0u : 0u;
-        k.lin_off = chroma ? plane * a.chroma_bytes + (ci - plane * 9) * a.chroma_w : (l >> 1) * a.luma_w + (l & 1) * kRcPiece;
+        const uint32_t col_l = (l & 1) * 256, col_c = plane * kChromaCrAt + (cj & 1) * kChromaBlockStep;
+        const uint32_t cterm = rj * 16 + col_l + ch * (col_c - col_l);
+#pragma unroll
+        for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
+            k.cterm[m] = cterm + kRcDmaBias - (kRcWinAt + m * kRcWinBytes);
+        k.wrap_shift = 8 - 2 * ch;
+        k.below = a.mb_w * (256 - ch * (256 - kChromaBlockStep)) - (256 - ch * 192);
     }
     k.mc_luma = (l >> 2) * 32 + (l & 3) * 4;
     k.mc_plane = ((l >> 4) & 1) * 160;
     {
         const int32_t r = (int32_t)((l >> 1) & 7), b = r & 1, h = (int32_t)(l & 1);
-        k.mc_c0 = (int32_t)(kRcWinLuma + k.mc_plane) + 16 * r - 8 * b + 4 * h;
+        k.mc_c0 = (uint32_t)((int32_t)(kRcWinLuma + k.mc_plane) + 16 * r - 8 * b + 4 * h);
+        k.mc_dr = (uint32_t)(8 + 16 * b);
+        k.mc_dc = (uint32_t)(4 + 8 * h);
         k.mc_ck = 8 + 16 * b;
         k.mc_ck2 = 16 - 32 * b;
         k.mc_cs = 4 + 8 * h;
         k.mc_cs2 = 8 - 16 * h;
     }
     k.mc_lin = kRcWinLuma + (((l >> 4) & 1) * 9 + ((l >> 1) & 7)) * kRcPiece + (l & 1) * 4;
+    k.ones = opaque(0x01010101u);
     k.out_luma = l * 4;
-    k.out_chroma = 256 + l * 4;
+    k.out_chroma = 256 + (l & 31) * 4;
     return k;
 }
 
-// ---- step 1: the vector loads
+// ---- step 1: the vector loads.  ONE scalar base for the chunk's words: its block words, then (n_slots dwords on) its entries
+MPG_HD uint32_t rc_ent_lane_offset(const RcChunk &c, uint32_t at, int lane) { return (rc_n_blocks(c) + at + (uint32_t)lane) * 4; } // bytes
 MPG_HD const uint32_t *rc_ent_src(const VideoArgs &a, const RcChunk &c, uint32_t at, int lane)
 {
-    return a.words + c.h[4] + at + (uint32_t)lane; // (beyond the pass's entries: ignored; the array is padded)
+    return rc_word_base(a, c) + rc_n_blocks(c) + at + (uint32_t)lane; // (beyond the pass's entries: ignored; the array is padded)
 }
 // The five direct-to-LDS loads of a wave, issued by lanes 0..53 in this order: the table (12 pieces), windows 0..3 (54
 // pieces each).  All 54 lanes take part in every one of them (one asm statement, one EXEC): the table's surplus lanes
 // fetch 16 bytes that a LATER load of the same wave overwrites — loads complete in order
 // (tools/microbench/lds_dma_probe3.hip) and the windows cover [kRcWinAt, kRcTileAt) completely.  Surplus lanes read
 // valid memory: they run on into the next streams' tables (the table array is padded by 1 KB).
-MPG_HD const uint8_t *rc_table_src(const VideoArgs &a, const RcChunk &c) { return a.qmat + c.h[2]; }
+MPG_HD uint32_t rc_table_lane_offset(const RcChunk &c, int lane) { return rc_stream(c) * kRcQtabStride + (uint32_t)lane * 16; }
 // the chunk's block words stay in HBM: lane (g, j) loads the word of block g of a pass when the pass starts (the first
 // pass's together with the entries, before anything is waited for)
-MPG_HD const uint32_t *rc_blk_src(const VideoArgs &a, const RcChunk &c) { return a.words + c.h[3]; }
 MPG_HD uint32_t rc_blk_lane_offset(uint32_t pass, int lane) { return (pass * 8 + ((uint32_t)lane >> 3)) * 4; } // bytes
-// window m: scalar base = the reference frame, lane offset = the piece's tile row.  Intra, dead and kRSlow macroblocks
-// fetch the head of the frame store instead: valid memory, never used (a kRSlow window is gathered afterwards).
-// No selects between scalars: the compiler turns those into indexed loads from scratch.
-MPG_HD const uint8_t *rc_win_base(const VideoArgs &a, const RcChunk &c, int m) { return a.frames + ((uint64_t)c.r[m][1] << 8); }
+// window m: scalar base = the stream's frames (rc_frame_base), lane offset = the piece's tile row.  Intra and dead macroblocks
+// fetch the head of the stream's first slot, kRSlow ones the head of their reference slot: valid memory, never used (a kRSlow
+// window is gathered afterwards).
 MPG_HD uint32_t rc_win_offset(const RcChunk &c, int m, const RcLane &k)
 {
-    const uint32_t tiled = (c.r[m][0] & (kRIntra | kRDead | kRSlow)) ? 0u : ~0u; // (wave-uniform)
-    const uint32_t xl = c.r[m][2] & tiled & ~15u, xc = c.r[m][3] & tiled & ~15u; // (scalar)
-    const uint32_t x = xl + (k.piece_chroma & (xc - xl));
+    const uint32_t x = c.r[m][1] + (k.piece_chroma & c.r[m][2]);
     const uint32_t u = (x & k.sub_mask) + k.rj16;
-    return x + k.rj16_cterm + (k.below & (0u - (u >> k.wrap_shift))); // (u >> wrap_shift is 0 or 1: the tile below)
+    return x + mad_u24(u >> k.wrap_shift, k.below, k.cterm[m]); // (u >> wrap_shift is 0 or 1: the tile below)
 }
 
 // a kRSlow window (it leaves its plane): the reference's LINEAR reads, gathered dword by dword through
 // linear_to_tiled.  Lane < 52 = piece of the linear window layout: luma 17 rows x 32 bytes from the dword below the
 // origin, then per chroma plane 9 rows x 16 bytes.  Returns the piece's 16 bytes.
-MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k)
+MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, int lane)
 {
-    const uint8_t *ref = rc_win_base(a, c, m);
-    const uint32_t origin = ((k.lin_chroma ? c.r[m][3] : c.r[m][2]) & ~3u) + k.lin_off;
+    (void)k;
+    const uint8_t *ref = rc_frame_base(a, c) + kRcDmaBias + c.r[m][1];
+    const uint32_t l = (uint32_t)lane, ci = l - 34, plane = ci >= 9 ? 1u : 0u;
+    const bool chroma = l >= 34;
+    // the piece of a LINEAR window (lanes < 52): luma row * luma_w + column * 16 / plane * chroma_bytes + row * chroma_w (17 rows x
+    // 2, then 9 rows per plane)
+    const uint32_t lin_off = chroma ? plane * a.chroma_bytes + (ci - plane * 9) * a.chroma_w : (l >> 1) * a.luma_w + (l & 1) * kRcPiece;
+    // (no select between two record dwords: the compiler makes an indexed load of it and moves the whole chunk to scratch)
+    const uint32_t r3 = c.r[m][3], r4 = c.r[m][4];
+    const uint32_t origin = ((r3 + ((0u - (uint32_t)chroma) & (r4 - r3))) & ~3u) + lin_off;
     u32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -748,7 +897,7 @@ MPG_HD void rc_cols_load16(const int16_t *T, const uint8_t *lds, int lane, int32
 // an int32 snapshot block: lane (g, j) takes column j (positions j * 8 .. j * 8 + 7) straight from its 64 dwords
 MPG_HD void rc_raw_cols(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane, int32_t (&v)[8])
 {
-    const i32x4_a4 *p = reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 8);
+    const i32x4_a4 *p = reinterpret_cast<const i32x4_a4 *>(rc_word_base(a, c) + rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 8);
     const i32x4_a4 lo = p[0], hi = p[1];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -817,7 +966,7 @@ MPG_HD void rc_transpose8(int32_t (&v)[8], int lane)
 // an int32 snapshot block: its 64 values as they are, lane = position
 MPG_HD void rc_raw_fill(const VideoArgs &a, const RcChunk &c, int32_t *T, uint32_t g, uint32_t bw, int lane)
 {
-    T[g * 64 + (uint32_t)lane] = (int32_t)a.words[c.h[4] + ((bw >> 12) & 0xfffu) + (uint32_t)lane];
+    T[g * 64 + (uint32_t)lane] = (int32_t)rc_word_base(a, c)[rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + (uint32_t)lane];
 }
 
 // lane (g, j) = column j of the pass's block g, then row j
@@ -1054,7 +1203,7 @@ MPG_HD bool rc_non_intra_column_flat(const uint8_t *lds, int lane)
 // column j of a dense unit: 8 int16 levels (read apart from their use: the next pass's are fetched while this pass runs)
 MPG_HD i32x4_a4 rc_dense_read(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane)
 {
-    return *reinterpret_cast<const i32x4_a4 *>(a.words + c.h[4] + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 4);
+    return *reinterpret_cast<const i32x4_a4 *>(rc_word_base(a, c) + rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 4);
 }
 // kFlat: every dense block of the pass is non-intra and the stream's non-intra matrix is 16 everywhere (the caller's
 // wave-uniform test): no matrix bytes, no intra DC.
@@ -1116,80 +1265,157 @@ MPG_HD void rc_cols_store(int32_t *T, int lane, const int32_t (&v)[8])
 }
 MPG_HD void rc_rows_load(const int32_t *T, int lane, int32_t (&v)[8]) { rc_cols_load(T, lane, v); } // T[g][j * 8 + c] now
 
-// ---- step 3: motion compensation of 4 pixels (video_noasm.go:48-80); shift / oh / ov are wave-uniform.
-// a0 a1: the two dwords that hold the pixels (they start `shift` < 4 bytes in) and their right neighbour; b0 b1 the
-// same one row below.
-MPG_HD uint32_t rc_mc4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t shift, bool oh, bool ov)
+// ---- step 3: motion compensation of 4 pixels (video_noasm.go:48-80); shifts / oh / ov are wave-uniform.
+// a0 a1: the two dwords that hold the pixels (they start sh / 8 < 4 bytes in) and their right neighbour; b0 b1 the same one
+// row below.  sh: funnel shift in bits (its low 5 bits count), sh8: sh + 8 (its low 6 bits count) — scalars the packer worked
+// out (record r3 / r4), or rc_slow_shifts for a gathered window.  ones: 0x01010101.
+MPG_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) // ({hi, lo} >> (sh & 31)): one v_alignbit_b32, no masking of sh
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
+#endif
+}
+MPG_HD uint32_t avg_ceil_u8x4_r(uint32_t a, uint32_t b, uint32_t ones)
+{
+#if MPG_ON_DEVICE
+    return __builtin_amdgcn_lerp(a, b, ones);
+#else
+    (void)ones;
+    return avg_ceil_u8x4(a, b);
+#endif
+}
+MPG_HD uint32_t avg4_u8x4_r(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t ones)
+{
+    const uint32_t p = avg_floor_u8x4(a, b), q = avg_floor_u8x4(c, d);
+    const uint32_t e = (a ^ b) & (c ^ d);
+    return avg_ceil_u8x4_r(p, q, ones) + (e & ~(p ^ q) & ones);
+}
+MPG_HD uint32_t rc_mc4_h(uint32_t a0, uint32_t a1, uint32_t sh, uint32_t sh8, uint32_t ones)
+{
+    const uint64_t a = (uint64_t)a0 | ((uint64_t)a1 << 32);
+    return avg_ceil_u8x4_r(funnel32(a1, a0, sh), (uint32_t)(a >> (sh8 & 63)), ones);
+}
+MPG_HD uint32_t rc_mc4_v(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t sh, uint32_t ones)
+{
+    return avg_ceil_u8x4_r(funnel32(a1, a0, sh), funnel32(b1, b0, sh), ones);
+}
+MPG_HD uint32_t rc_mc4_hv(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t sh, uint32_t sh8, uint32_t ones)
 {
     const uint64_t a = (uint64_t)a0 | ((uint64_t)a1 << 32), b = (uint64_t)b0 | ((uint64_t)b1 << 32);
-    const uint32_t p00 = (uint32_t)(a >> (8 * shift));
-    switch ((oh ? 1u : 0u) | (ov ? 2u : 0u)) { // (one four-way branch: chains of ifs cost a dozen scalar instructions per call)
-    case 0: return p00;
-    case 1: return avg_ceil_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)));
-    case 2: return avg_ceil_u8x4(p00, (uint32_t)(b >> (8 * shift)));
-    default: return avg4_u8x4(p00, (uint32_t)(a >> (8 * shift + 8)), (uint32_t)(b >> (8 * shift)), (uint32_t)(b >> (8 * shift + 8)));
+    return avg4_u8x4_r(funnel32(a1, a0, sh), (uint32_t)(a >> (sh8 & 63)), funnel32(b1, b0, sh), (uint32_t)(b >> (sh8 & 63)), ones);
+}
+
+// Two / four dwords of the wave's LDS at (lane part) + (compile-time part) each: the compile-time part rides in the instruction's
+// 16-bit offset field, and the wait sits in the same statement, so the values are there when it ends.  (Left to itself the
+// compiler pairs such reads into ds_read2_b32, whose offsets reach 1 KB: behind window 0 that costs an address addition per
+// pair; two ds_read_b32 are no slower — profiles/round5_b_lds_unaligned_reads.txt.)
+template <int kAt0, int kAt1> MPG_HD void lds_read32x2(const uint8_t *lds, uint32_t p0, uint32_t p1, uint32_t &v0, uint32_t &v1)
+{
+#if MPG_ON_DEVICE
+    const uint32_t base = (uint32_t)(uintptr_t)lds; // (one wave per workgroup: 0)
+    asm volatile("ds_read_b32 %0, %2 offset:%4\n\tds_read_b32 %1, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1)
+                 : "v"(p0 + base), "v"(p1 + base), "n"(kAt0), "n"(kAt1)
+                 : "memory");
+#else
+    memcpy(&v0, lds + p0 + kAt0, 4);
+    memcpy(&v1, lds + p1 + kAt1, 4);
+#endif
+}
+template <int kAt0, int kAt1, int kAt2, int kAt3>
+MPG_HD void lds_read32x4(const uint8_t *lds, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3)
+{
+#if MPG_ON_DEVICE
+    const uint32_t base = (uint32_t)(uintptr_t)lds;
+    asm volatile("ds_read_b32 %0, %4 offset:%8\n\tds_read_b32 %1, %5 offset:%9\n\tds_read_b32 %2, %6 offset:%10\n\tds_read_b32 %3, %7 offset:%11\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(p0 + base), "v"(p1 + base), "v"(p2 + base), "v"(p3 + base), "n"(kAt0), "n"(kAt1), "n"(kAt2), "n"(kAt3)
+                 : "memory");
+#else
+    memcpy(&v0, lds + p0 + kAt0, 4);
+    memcpy(&v1, lds + p1 + kAt1, 4);
+    memcpy(&v2, lds + p2 + kAt2, 4);
+    memcpy(&v3, lds + p3 + kAt3, 4);
+#endif
+}
+
+// ---- the common case: a window inside its plane, tiled (record r3 / r4 / r5 as rc_make_record packs them).
+// luma, lane (row lane>>2, quarter lane&3): rows are 32 contiguous bytes in window kM; the lane's taps start r3's upper half
+// bytes (0 / 4 / 8 / 12) into its dword pair.
+template <int kM> MPG_HD uint32_t rc_mc_luma(const uint8_t *lds, const RcLane &k, uint32_t r0, uint32_t r3)
+{
+    constexpr int W = kRcWinAt + kM * kRcWinBytes;
+    const uint32_t at = add_u16_hi(r3, k.mc_luma);
+    uint32_t a0, a1, b0, b1;
+    if (r0 & kROvL) {
+        lds_read32x4<W, W + 4, W + 32, W + 36>(lds, at, at, at, at, a0, a1, b0, b1); // (+ 32 bytes: the row below)
+        if (r0 & kROhL)
+            return rc_mc4_hv(a0, a1, b0, b1, r3, r3 >> 8, k.ones);
+        return rc_mc4_v(a0, a1, b0, b1, r3, k.ones);
     }
+    lds_read32x2<W, W + 4>(lds, at, at, a0, a1);
+    if (r0 & kROhL)
+        return rc_mc4_h(a0, a1, r3, r3 >> 8, k.ones);
+    return funnel32(a1, a0, r3);
 }
 
-// the window's byte offsets inside its first pieces (wave-uniform, from the record)
-struct RcTaps {
-    uint32_t luma_x;   // 0..15 (kRSlow: 0..3): the window starts this many bytes into its rows in LDS
-    uint32_t chroma_x; // 0..7 (kRSlow: 0..3)
-    uint32_t chroma_y; // 0 / 1: the window starts on the odd row of its first row pair (kRSlow: unused)
-    bool slow;
-};
-MPG_HD RcTaps rc_taps(uint32_t d0, uint32_t d2, uint32_t d3)
-{
-    RcTaps t;
-    t.slow = (d0 & kRSlow) != 0;
-    t.luma_x = t.slow ? d2 & 3 : d2 & 15;
-    t.chroma_x = t.slow ? d3 & 3 : d3 & 7;
-    t.chroma_y = (d3 >> 3) & 1;
-    return t;
-}
-
-// luma, lane (row lane>>2, quarter lane&3): rows are 32 contiguous bytes in the window
-MPG_HD uint32_t rc_mc_luma(const uint8_t *win, const RcLane &k, const RcTaps &t, bool oh, bool ov)
-{
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_luma + (t.luma_x & ~3u));
-    return rc_mc4(p[0], p[1], p[8], p[9], t.luma_x & 3, oh, ov); // (+ 8 dwords: the row below)
-}
-
-// chroma, lanes 0..31 (plane lane>>4, row r = (lane>>1)&7, half h = lane&1).  Tiled windows: a row's 16 bytes are two
-// halves of 8 in the pieces of the two blocks: row w of the window (counted from the even row its first pair starts
-// on) begins at rowpart(w) = (w >> 1) * 32 + (w & 1) * 8, and dword i (0..3) of a row sits at f(i) = (i & 1) * 4 +
-// (i >> 1) * 16.  The lane reads dwords i, i + 1 of rows w, w + 1 with w = r + c, i = s + h, where c = chroma_y (0 / 1)
-// and s = chroma_x >> 2 (0 / 1) are wave-uniform.  Both maps are affine in c and s for a FIXED lane:
+// chroma, lanes 0..31 (plane lane>>4, row r = (lane>>1)&7, half h = lane&1; lanes 32..63 repeat them).  A row's 16 bytes are two
+// halves of 8 in the pieces of the two blocks: row w of the window (counted from the even row its first pair starts on) begins
+// at rowpart(w) = (w >> 1) * 32 + (w & 1) * 8, and dword i (0..3) of a row sits at f(i) = (i & 1) * 4 + (i >> 1) * 16.  The lane
+// reads dwords i, i + 1 of rows w, w + 1 with w = r + c, i = s + h, where c (0 / 1: the window starts on the odd row of its first
+// pair, r4's upper half) and s (0 / 1: in the second dword, r5) are wave-uniform.  Both maps are affine in c and s for a FIXED lane:
 //      rowpart(r + c)     = (16 r - 8 b)  + c (8 + 16 b)                 b = r & 1
 //      rowpart(r + c + 1) = rowpart(r + c) + (8 + 16 b) + c (16 - 32 b)
 //      f(s + h)           = 4 h           + s (4 + 8 h)
 //      f(s + h + 1)       = f(s + h) + (4 + 8 h) + s (8 - 16 h)
-// so the four addresses cost four multiply-adds by 0 / 1 on lane constants instead of shifts and masks per macroblock.
+// so the addresses cost multiply-adds of a record half by lane constants — no scalar instruction, no shifts and masks.
 MPG_HD uint32_t rc_chroma_row_at(uint32_t plane160, uint32_t row, uint32_t dword)
 {   // the closed form the affine one is checked against (tests/kernel_emu): LDS offset of dword `dword` of row `row`
     return kRcWinLuma + plane160 + (row >> 1) * 32 + (row & 1) * 8 + (dword & 1) * 4 + (dword >> 1) * 16;
 }
-MPG_HD uint32_t rc_mc_chroma(const uint8_t *win, const RcLane &k, const RcTaps &t, int lane, bool oh, bool ov)
+template <int kM> MPG_HD uint32_t rc_mc_chroma(const uint8_t *lds, const RcLane &k, int lane, uint32_t r0, uint32_t r4, uint32_t r5)
 {
+    constexpr int W = kRcWinAt + kM * kRcWinBytes;
     (void)lane; // (the emulator's checks below)
-    if (t.slow) {
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_lin);
-        return rc_mc4(p[0], p[1], p[4], p[5], t.chroma_x, oh, ov); // (+ 4 dwords: the row below)
+    const uint32_t at0 = mad_u16_field<false>(r5, k.mc_dc, mad_u16_field<true>(r4, k.mc_dr, k.mc_c0));       // row w, dword i
+    const uint32_t at1 = at0 + (uint32_t)mad_i16_field<false>(r5, k.mc_cs2, k.mc_cs);                          // row w, dword i + 1
+    MPG_CHECK(at0 == rc_chroma_row_at(k.mc_plane, ((r4 >> 16) & 1) + (((uint32_t)lane >> 1) & 7), (r5 & 1) + ((uint32_t)lane & 1)));
+    MPG_CHECK(at1 == rc_chroma_row_at(k.mc_plane, ((r4 >> 16) & 1) + (((uint32_t)lane >> 1) & 7), (r5 & 1) + ((uint32_t)lane & 1) + 1));
+    uint32_t a0, a1, b0, b1;
+    if (r0 & kROvC) {
+        const uint32_t down = (uint32_t)mad_i16_field<true>(r4, k.mc_ck2, k.mc_ck); // to the row below
+        MPG_CHECK(at0 + down == rc_chroma_row_at(k.mc_plane, ((r4 >> 16) & 1) + (((uint32_t)lane >> 1) & 7) + 1, (r5 & 1) + ((uint32_t)lane & 1)));
+        lds_read32x4<W, W, W, W>(lds, at0, at1, at0 + down, at1 + down, a0, a1, b0, b1);
+        if (r0 & kROhC)
+            return rc_mc4_hv(a0, a1, b0, b1, r4, r4 >> 8, k.ones);
+        return rc_mc4_v(a0, a1, b0, b1, r4, k.ones);
     }
-    const int32_t c = (int32_t)t.chroma_y, s = (int32_t)(t.chroma_x >> 2); // 0 / 1 each
-    const int32_t a0 = k.mc_c0 + c * k.mc_ck + s * k.mc_cs; // row w, dword i
-    const int32_t a1 = a0 + k.mc_cs + s * k.mc_cs2;          // row w, dword i + 1
-    MPG_CHECK((uint32_t)a0 == rc_chroma_row_at(k.mc_plane, t.chroma_y + (((uint32_t)lane >> 1) & 7), (t.chroma_x >> 2) + ((uint32_t)lane & 1)));
-    MPG_CHECK((uint32_t)a1 == rc_chroma_row_at(k.mc_plane, t.chroma_y + (((uint32_t)lane >> 1) & 7), (t.chroma_x >> 2) + ((uint32_t)lane & 1) + 1));
-    const uint32_t p0 = *reinterpret_cast<const uint32_t *>(win + a0), p1 = *reinterpret_cast<const uint32_t *>(win + a1);
-    uint32_t b0 = 0, b1 = 0;
-    if (ov) {
-        const int32_t down = k.mc_ck + c * k.mc_ck2; // to the row below
-        MPG_CHECK((uint32_t)(a0 + down) == rc_chroma_row_at(k.mc_plane, t.chroma_y + (((uint32_t)lane >> 1) & 7) + 1, (t.chroma_x >> 2) + ((uint32_t)lane & 1)));
-        b0 = *reinterpret_cast<const uint32_t *>(win + a0 + down);
-        b1 = *reinterpret_cast<const uint32_t *>(win + a1 + down);
-    }
-    return rc_mc4(p0, p1, b0, b1, t.chroma_x & 3, oh, ov);
+    lds_read32x2<W, W>(lds, at0, at1, a0, a1);
+    if (r0 & kROhC)
+        return rc_mc4_h(a0, a1, r4, r4 >> 8, k.ones);
+    return funnel32(a1, a0, r4);
+}
+
+// ---- a gathered window (kRSlow: rows lie linearly, 32 bytes of luma / 16 of chroma each, from the dword below the origin)
+MPG_HD uint32_t rc_mc4_any(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t shift_bytes, uint32_t ones, bool oh, bool ov)
+{
+    const uint32_t sh = shift_bytes * 8, sh8 = sh + 8;
+    if (ov)
+        return oh ? rc_mc4_hv(a0, a1, b0, b1, sh, sh8, ones) : rc_mc4_v(a0, a1, b0, b1, sh, ones);
+    return oh ? rc_mc4_h(a0, a1, sh, sh8, ones) : funnel32(a1, a0, sh);
+}
+MPG_HD uint32_t rc_mc_luma_slow(const uint8_t *win, const RcLane &k, uint32_t r0, uint32_t r3)
+{
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_luma);
+    return rc_mc4_any(p[0], p[1], p[8], p[9], r3 & 3, k.ones, (r0 & kROhL) != 0, (r0 & kROvL) != 0); // (+ 8 dwords: the row below)
+}
+MPG_HD uint32_t rc_mc_chroma_slow(const uint8_t *win, const RcLane &k, uint32_t r0, uint32_t r4)
+{
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_lin);
+    return rc_mc4_any(p[0], p[1], p[4], p[5], r4 & 3, k.ones, (r0 & kROhC) != 0, (r0 & kROvC) != 0); // (+ 4 dwords: the row below)
 }
 
 // ---- step 4: residual row + the 8 prediction bytes in O_m -> clamped bytes (video.go:943-971)
@@ -1204,17 +1430,17 @@ MPG_HD void rc_rmw(uint8_t *lds, uint32_t bw, int lane, const int32_t (&v)[8])
 MPG_HD uint32_t rc_mb_index(const VideoArgs &a, uint32_t d0) { return (d0 >> 24) * a.mb_w + ((d0 >> 16) & 0xff); }
 
 // horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), the four Cb | Cr pairs 512 bytes by lanes
-// 0..31, as they lie in the O_m.  Non-temporal stores: the picture is next read by a later launch; the prediction windows
-// of the neighbouring chunks, which ARE read again within microseconds, keep their place in L2
-// (profiles/r4z_ab_non_temporal_frame_stores.txt: typical +1.9 %, dense +0.3 %; the fused-RGBA instance likewise, with its
-// RGBA stores: profiles/r5_ab_*: +3.8 % / +1.6 %)
+// 0..31, as they lie in the O_m; where they go the header says (h6 / h7, from the wave's one frame base).  Non-temporal stores:
+// the picture is next read by a later launch; the prediction windows of the neighbouring chunks, which ARE read again within
+// microseconds, keep their place in L2 (profiles/r4z_ab_non_temporal_frame_stores.txt: typical +1.9 %, dense +0.3 %; the
+// fused-RGBA instance likewise, with its RGBA stores: profiles/r5_ab_*: +3.8 % / +1.6 %)
 MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
 {
-    const uint32_t l = (uint32_t)lane, mb0 = rc_mb_index(a, c.r[0][0]);
-    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + (uint64_t)mb0 * 128; // wave-uniform
-    store16_at<true>(cur + (uint64_t)mb0 * 128, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
+    const uint32_t l = (uint32_t)lane;
+    uint8_t *base = rc_frame_base(a, c); // wave-uniform
+    store16_at<true>(base, c.h[6] + l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
     if (lane < 32)
-        store16_at<true>(cur + a.luma_bytes, l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 3) + 256 + (l & 7) * 16));
+        store16_at<true>(base, c.h[7] + l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 3) + 256 + (l & 7) * 16));
 }
 
 // any other chunk: macroblock m by lanes (block b = lane>>3, row j = lane&7), 8 bytes each.  An invalid intra
@@ -1233,7 +1459,7 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
         off = mb * 256 + ((uint32_t)j + ((uint32_t)(b >> 1) << 3)) * 16 + ((uint32_t)(b & 1) << 3);
     else
         off = a.luma_bytes + (uint32_t)(b - 4) * kChromaCrAt + mb * kChromaBlockStep + (uint32_t)j * 8;
-    uint8_t *cur = a.frames + ((uint64_t)c.h[0] << 8) + off;
+    uint8_t *cur = rc_frame_base(a, c) + rc_cur_offset(a, c) + off;
     uint8_t *t = lds + rc_tile_offset(b, j, m);
     if (written)
         *reinterpret_cast<uint64_t *>(cur) = *reinterpret_cast<const uint64_t *>(t);
@@ -1245,8 +1471,11 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
 // segment), one 16-byte store each — a macroblock row is 64 contiguous bytes of the image.  Pixels outside
 // width x height are not stored.
 // (mb_x, mb_y: the macroblock's position — of a run's macroblock m it is the first one's + m, no record is indexed by lane)
-MPG_HD void rc_rgba_quad(const VideoArgs &a, const RcChunk &c, uint32_t m, uint32_t mb_x, uint32_t mb_y, uint32_t row, uint32_t seg,
-                         const uint8_t *lds)
+MPG_HD uint8_t *rc_rgba_image(const VideoArgs &a, const RcChunk &c)
+{
+    return a.rgba + ((uint64_t)rc_stream(c) * MPEGHIP_SLOTS + rc_cur_slot(c)) * a.rgba_stride; // wave-uniform
+}
+MPG_HD void rc_rgba_quad(const VideoArgs &a, uint8_t *img, uint32_t m, uint32_t mb_x, uint32_t mb_y, uint32_t row, uint32_t seg, const uint8_t *lds)
 {
     const uint32_t py = (mb_y << 4) + row, px0 = (mb_x << 4) + seg * 4;
     if (py >= a.height || px0 >= a.width)
@@ -1259,20 +1488,19 @@ MPG_HD void rc_rgba_quad(const VideoArgs &a, const RcChunk &c, uint32_t m, uint3
     rgba_row4(yy, chroma_terms(cb & 0xff, cr & 0xff), chroma_terms((cb >> 8) & 0xff, (cr >> 8) & 0xff), px);
     const uint64_t p = (uint64_t)py * a.width + px0;
     const uint32_t n = a.width - px0 >= 4 ? 4 : a.width - px0;
-    uint8_t *img = a.rgba + ((uint64_t)c.h[1] << 8);
     rgba_store4<true>(reinterpret_cast<uint32_t *>(img) + p, p, px, n); // (non-temporal: rc_store_run)
 }
-MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int lane, const uint8_t *lds)
+MPG_HD void rc_rgba_mb(const VideoArgs &a, const RcChunk &c, uint8_t *img, uint32_t m, int lane, const uint8_t *lds)
 {
     const uint32_t d0 = c.r[m][0];
-    rc_rgba_quad(a, c, m, (d0 >> 16) & 0xff, d0 >> 24, (uint32_t)lane >> 2, (uint32_t)lane & 3, lds);
+    rc_rgba_quad(a, img, m, (d0 >> 16) & 0xff, d0 >> 24, (uint32_t)lane >> 2, (uint32_t)lane & 3, lds);
 }
 // a horizontal run of 4 macroblocks, rows 4q .. 4q + 3: lane = (row lane>>4, macroblock (lane>>2)&3, segment lane&3), so that
 // one store instruction writes 4 rows of 256 contiguous bytes (whole cache lines) instead of 16 rows of 64
-MPG_HD void rc_rgba_run_rows(const VideoArgs &a, const RcChunk &c, uint32_t q, int lane, const uint8_t *lds)
+MPG_HD void rc_rgba_run_rows(const VideoArgs &a, const RcChunk &c, uint8_t *img, uint32_t q, int lane, const uint8_t *lds)
 {
     const uint32_t l = (uint32_t)lane, m = (l >> 2) & 3, d0 = c.r[0][0];
-    rc_rgba_quad(a, c, m, ((d0 >> 16) & 0xff) + m, d0 >> 24, q * 4 + (l >> 4), l & 3, lds);
+    rc_rgba_quad(a, img, m, ((d0 >> 16) & 0xff) + m, d0 >> 24, q * 4 + (l >> 4), l & 3, lds);
 }
 
 } // namespace mpg

@@ -105,13 +105,16 @@ def set_pack_window(dwords=4096):
     lib().emu_set_pack_window(int(dwords))
 
 
+CHUNK_DWORDS = 32   # video_recon_lane.h: kRcChunkDwords (8 header dwords + 4 records of 6)
+
+
 def pack_sparse_host(g, stride, rgba_stride, pic, mbs, words, out_room=None):
-    """The host packer on one sparse picture -> (chunks [n, 24], words) or None if it refuses the picture."""
+    """The host packer on one sparse picture -> (chunks [n, 32], words) or None if it refuses the picture."""
     pic = np.ascontiguousarray(np.asarray(pic).reshape(1), desc.PIC_DTYPE)
     mbs = np.ascontiguousarray(mbs, desc.MB_DTYPE)
     words = np.ascontiguousarray(words, np.uint32)
     n_chunks = (int(pic["mb_count"][0]) + 3) // 4
-    chunks = np.zeros((n_chunks + 1, 24), np.uint32)
+    chunks = np.zeros((n_chunks + 1, CHUNK_DWORDS), np.uint32)
     out = np.full(len(words) + 64 + 16, 0xDEADBEEF, np.uint32)
     nw = C.c_uint32(0)
     room = len(words) + 64 if out_room is None else out_room
@@ -124,13 +127,13 @@ def pack_sparse_host(g, stride, rgba_stride, pic, mbs, words, out_room=None):
 
 
 def pack_sparse_device(g, stride, rgba_stride, pic, mbs, words, word_first=0, chunk_first=0):
-    """The device packer's lane functions on one sparse picture -> (error word, chunks [n, 24], words array as long as the input
+    """The device packer's lane functions on one sparse picture -> (error word, chunks [n, 32], words array as long as the input
     + word_first, use bits)."""
     pic = np.ascontiguousarray(np.asarray(pic).reshape(1), desc.PIC_DTYPE)
     mbs = np.ascontiguousarray(mbs, desc.MB_DTYPE)
     words = np.ascontiguousarray(words, np.uint32)
     n_chunks = (int(pic["mb_count"][0]) + 3) // 4
-    chunks = np.zeros((chunk_first + n_chunks + 1, 24), np.uint32)
+    chunks = np.zeros((chunk_first + n_chunks + 1, CHUNK_DWORDS), np.uint32)
     staged = np.concatenate([np.full(word_first, 0xABABABAB, np.uint32), words, np.full(16, 0xABABABAB, np.uint32)])  # (the buffer is padded)
     out = np.full(word_first + len(words) + 1, 0xDEADBEEF, np.uint32)
     use = C.c_uint32(0)

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "audio_lane.h"
@@ -157,6 +158,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
 {
     VideoArgs a;
     a.frames = frames;
+    a.frames_b = frames - kRcDmaBias;
     a.frame_stride = frame_stride;
     a.mb_w = luma_w / 16;
     a.mb_h = luma_h / 16;
@@ -201,7 +203,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
             }
         }
     }
-    std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 1),
+    std::vector<uint32_t> chunks(n_chunks * kRcChunkDwords + 4),
         words((g_device_pack ? (size_t)n_pics : 1) * (rc_max_words_sparse(sparse_dwords, n_mbs) + 16) + rc_max_words(units) + kRcWordsPad, 0xDEADBEEFu);
     uint32_t nc = 0, nw = 0;
     uint64_t coded = 0, dense = 0;
@@ -219,9 +221,9 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                 return -2;
             for (uint32_t c = nc; c < nc + pic_chunks; c++) { // which kernel instance suits the batch: as the host packer counts
                 const uint32_t *h = chunks.data() + (size_t)c * kRcChunkDwords;
-                coded += h[6] & 0xff;
-                for (uint32_t i = 0; i < (h[6] & 0xff); i++)
-                    dense += (words[h[3] + i] & kBDense) ? 1 : 0;
+                coded += h[5] & kHBlocksMask;
+                for (uint32_t i = 0; i < (h[5] & kHBlocksMask); i++)
+                    dense += (words[rc_chunk_word_index(h) + i] & kBDense) ? 1 : 0;
             }
             nc += pic_chunks;
             nw += (n_sparse + 15) / 16 * 16; // (as the product's staging: a picture's words begin on a 64-byte boundary)
@@ -264,16 +266,16 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         uint32_t bw[64], e[64];
         for (int lane = 0; lane < 64; lane++) {
             k[lane] = rc_lane(a, lane);
-            e[lane] = load32_uncounted(rc_ent_src(a, c, 0, 0), (uint32_t)lane * 4);
+            e[lane] = load32_uncounted(rc_word_base(a, c), rc_ent_lane_offset(c, 0, lane));
         }
         for (int i = 0; i < 5; i++) // (load by load, as they complete on the device: later loads overwrite the surplus lanes)
             for (int lane = 0; lane < kRcWinLanes; lane++) {
-                const uint8_t *const src[5] = {rc_table_src(a, c), rc_win_base(a, c, 0), rc_win_base(a, c, 1), rc_win_base(a, c, 2),
-                                               rc_win_base(a, c, 3)};
-                const uint32_t off[5] = {(uint32_t)lane * 16, rc_win_offset(c, 0, k[lane]), rc_win_offset(c, 1, k[lane]),
+                const uint32_t off[5] = {rc_table_lane_offset(c, lane), rc_win_offset(c, 0, k[lane]), rc_win_offset(c, 1, k[lane]),
                                          rc_win_offset(c, 2, k[lane]), rc_win_offset(c, 3, k[lane])};
                 const int at[5] = {kRcQtabAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes};
-                memcpy(lds + at[i] + 16 * lane, src[i] + off[i], 16);
+                // (the device adds the instruction's offset field — the LDS target — to the global address too: dma_table_and_windows)
+                const uint8_t *src = i == 0 ? a.qmat + off[0] : rc_frame_base(a, c) + off[i] + at[i];
+                memcpy(lds + at[i] + 16 * lane, src, 16);
             }
         int32_t v[64][8];
         uint32_t ent_at = 0;
@@ -283,7 +285,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         auto residual_pass = [&](uint32_t pass) {
             const uint32_t np = rc_pass_entries(c, pass);
             for (int lane = 0; lane < 64; lane++)
-                bw[lane] = rc_blk_src(a, c)[rc_blk_lane_offset(pass, lane) / 4];
+                bw[lane] = rc_word_base(a, c)[rc_blk_lane_offset(pass, lane) / 4];
             bool flat = table_flat; // the short dequantisation: no intra unit among the pass's dense ones
             for (int lane = 0; lane < 64; lane++)
                 if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw[lane] & kBDense) && !(bw[lane] >> 31))
@@ -389,34 +391,43 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         };
         if (n_blocks)
             residual_pass(0);
-        for (int m = 0; m < kRcMbs; m++) {
-            const uint32_t d0 = c.r[m][0];
-            if (d0 & kRDead)
-                continue;
+        auto mc_one = [&](auto M) { // (as the kernel: the common kind takes the record's scalars as they are)
+            constexpr int m = decltype(M)::value;
+            const uint32_t r0 = c.r[m][0];
+            if (r0 & kRDead)
+                return;
             uint8_t *win = lds + rc_win_at(m);
             uint32_t yl[64], yc[64];
-            if (!(d0 & kRIntra) && (d0 & kRSlow)) {
+            const bool fast = !(r0 & (kRIntra | kRDead | kRSlow));
+            if (!fast && (r0 & kRSlow)) {
                 u32x4 piece[52];
                 for (int lane = 0; lane < 52; lane++)
-                    piece[lane] = rc_gather_piece(a, c, m, k[lane]);
+                    piece[lane] = rc_gather_piece(a, c, m, k[lane], lane);
                 for (int lane = 0; lane < 52; lane++)
                     memcpy(win + lane * 16, &piece[lane], 16);
             }
-            const RcTaps t = rc_taps(d0, c.r[m][2], c.r[m][3]);
             for (int lane = 0; lane < 64; lane++) {
                 yl[lane] = yc[lane] = 0;
-                if (!(d0 & kRIntra)) {
-                    yl[lane] = rc_mc_luma(win, k[lane], t, (d0 & kROhL) != 0, (d0 & kROvL) != 0);
-                    if (lane < 32)
-                        yc[lane] = rc_mc_chroma(win, k[lane], t, lane, (d0 & kROhC) != 0, (d0 & kROvC) != 0);
+                if (fast) {
+                    yl[lane] = rc_mc_luma<m>(lds, k[lane], r0, c.r[m][3]);
+                    yc[lane] = rc_mc_chroma<m>(lds, k[lane], lane, r0, c.r[m][4], c.r[m][5]);
+                } else if (r0 & kRSlow) {
+                    yl[lane] = rc_mc_luma_slow(win, k[lane], r0, c.r[m][3]);
+                    yc[lane] = rc_mc_chroma_slow(win, k[lane], r0, c.r[m][4]);
                 }
             }
+            for (int lane = 0; lane < 32; lane++) // (lanes 32..63 repeat lanes 0..31's chroma: the same bytes to the same place)
+                if (yc[lane] != yc[lane + 32] || k[lane].out_chroma != k[lane + 32].out_chroma)
+                    abort();
             for (int lane = 0; lane < 64; lane++) { // (over the window: only after every lane has its taps)
                 memcpy(win + k[lane].out_luma, &yl[lane], 4);
-                if (lane < 32)
-                    memcpy(win + k[lane].out_chroma, &yc[lane], 4);
+                memcpy(win + k[lane].out_chroma, &yc[lane], 4);
             }
-        }
+        };
+        mc_one(std::integral_constant<int, 0>{});
+        mc_one(std::integral_constant<int, 1>{});
+        mc_one(std::integral_constant<int, 2>{});
+        mc_one(std::integral_constant<int, 3>{});
         if (n_blocks) {
             add_residual(0);
             for (uint32_t pass = 1; pass * 8 < n_blocks; pass++) {
@@ -424,7 +435,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                 add_residual(pass);
             }
         }
-        const bool run = (c.h[5] & kCRun) != 0, rgba_on = any_rgba && (c.h[5] & kCRgba) != 0;
+        const bool run = (c.h[4] & kCRun) != 0, rgba_on = any_rgba && (c.h[4] & kCRgba) != 0;
         const uint32_t n_live = rc_n_live(c);
         if (run) {
             for (int lane = 0; lane < 64; lane++)
@@ -435,14 +446,15 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                     rc_store_mb(a, c, m, lane, lds, rgba_on);
         }
         if (rgba_on) {
+            uint8_t *img = rc_rgba_image(a, c);
             if (run) {
                 for (uint32_t q = 0; q < 4; q++)
                     for (int lane = 0; lane < 64; lane++)
-                        rc_rgba_run_rows(a, c, q, lane, lds);
+                        rc_rgba_run_rows(a, c, img, q, lane, lds);
             } else {
                 for (uint32_t m = 0; m < n_live; m++)
                     for (int lane = 0; lane < 64; lane++)
-                        rc_rgba_mb(a, c, m, lane, lds);
+                        rc_rgba_mb(a, c, img, m, lane, lds);
             }
         }
     }

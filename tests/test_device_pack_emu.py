@@ -24,13 +24,13 @@ def _compare_packed(host, dev_chunks, dev_words, word_first=0):
     assert hc.shape == dev_chunks.shape
     for c in range(len(hc)):
         a, b = hc[c].copy(), dev_chunks[c].copy()
-        n_slots = int(a[6] & 0xff)
-        assert int(b[4]) - int(b[3]) == int(a[4]) - int(a[3]) == n_slots, "chunk %d" % c
-        a3, b3 = int(a[3]), int(b[3])
-        a[3] = a[4] = b[3] = b[4] = 0
+        n_slots = int(a[5] & 0x1f)
+        # h2 h3: the byte offset (64 bits) of the chunk's first block word
+        a3, b3 = (int(a[2]) | int(a[3]) << 32) // 4, (int(b[2]) | int(b[3]) << 32) // 4
+        a[2] = a[3] = b[2] = b[3] = 0
         assert (a == b).all(), "chunk %d: %s vs %s" % (c, a, b)
         # the chunk's extent: block words + entries + the data behind them (where the last snapshot / dense block ends)
-        ne = sum((int(a[5]) >> (10 * p)) & 0x3ff for p in range(3))
+        ne = sum((int(a[4]) >> (10 * p)) & 0x3ff for p in range(3))
         extent = n_slots + ne
         for s in range(n_slots):
             bw = int(hw[a3 + s])

@@ -72,8 +72,11 @@ def test_avg4_identity(emu):
 
 def test_xcd_chunk_is_a_permutation(emu):
     L = emu.lib()
-    for n in (1, 7, 8, 9, 64, 1020, 1021, 4099):
-        assert sorted(L.emu_xcd_chunk(b, n) for b in range(n)) == list(range(n))
+    for g8 in (1, 2, 7, 8, 9, 128, 513):     # the grid is 8 * g8 workgroups (launch_batch rounds it up)
+        got = [L.emu_xcd_chunk(b, g8) for b in range(8 * g8)]
+        assert sorted(got) == list(range(8 * g8))
+        for x in range(8):                   # XCD x (blocks x, x + 8, ...) walks ONE contiguous range, in order
+            assert got[x::8] == list(range(x * g8, (x + 1) * g8))
 
 
 @pytest.mark.parametrize("fma", [0, 1])
@@ -153,11 +156,11 @@ def test_packer_512_bit_forms_write_the_same_words(emu, profile, raw):
         coefs = np.ascontiguousarray(s.coefs).view(np.uint8).reshape(-1)
         got = []
         for f in (L.emu_pack, L.emu_pack_narrow):
-            chunks = np.zeros((len(mbs) // 4 + 4) * 24, np.uint32)
+            chunks = np.zeros((len(mbs) // 4 + 4) * emu.CHUNK_DWORDS, np.uint32)
             words = np.zeros(len(coefs) // 2 + len(mbs) * 6 + 1024, np.uint32)
             nw = C.c_uint32(0)
             nc = f(g["luma_w"], g["luma_h"], 1 << 20, 1 << 20, P(pics), P(mbs), P(coefs), P(chunks), P(words), C.byref(nw))
-            got.append((nc, nw.value, chunks[:nc * 24].copy(), words[:nw.value].copy()))
+            got.append((nc, nw.value, chunks[:nc * emu.CHUNK_DWORDS].copy(), words[:nw.value].copy()))
         assert got[0][0] == got[1][0] and got[0][1] == got[1][1]
         assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])
 
