@@ -75,19 +75,33 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 template <int WAVES, bool kRgba, bool kT16, int kPerWave>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(
     const uint32_t grid8, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
-    uint8_t *const frames_b, const uint32_t mb_w, const uint32_t luma_bytes, const uint32_t luma_w, const uint32_t chroma_w, const VideoArgs rest)
+    uint8_t *const frames_b, const uint32_t mb_w, const uint32_t luma_bytes, uint8_t *const rgba, const uint64_t rgba_stride,
+    const uint32_t width, const uint32_t height)
 {
     static_assert(WAVES == 1, "one wave per workgroup: the wave's LDS starts at 0 (lds_read32x2 / dma_table_and_windows)");
-    VideoArgs a = rest;
-    a.n_chunks = n_chunks;
+    // Everything a wave needs of the launch: the first 14 dwords arrive preloaded in SGPRs; the plane geometry follows from mb_w and
+    // luma_bytes where a rare path wants it (a gathered window, a chunk that is not a run).
+    VideoArgs a;
+    a.frames = nullptr; // (waves address frames through frames_b + the chunk's stream offset only)
+    a.frames_b = frames_b;
+    a.frame_stride = 0;
+    a.mb_w = mb_w;
+    a.mb_h = 0;
+    a.luma_w = mb_w * 16;
+    a.luma_h = 0;
+    a.chroma_w = mb_w * 8;
+    a.chroma_h = 0;
+    a.luma_bytes = luma_bytes;
+    a.chroma_bytes = luma_bytes >> 2;
+    a.pics = nullptr;
     a.chunks = chunks;
     a.words = words;
     a.qmat = qmat;
-    a.frames_b = frames_b;
-    a.mb_w = mb_w;
-    a.luma_bytes = luma_bytes;
-    a.luma_w = luma_w;
-    a.chroma_w = chroma_w;
+    a.n_chunks = n_chunks;
+    a.width = width;
+    a.height = height;
+    a.rgba = rgba;
+    a.rgba_stride = rgba_stride;
 #ifdef MPG_PHASE_TIMING
     uint64_t ts[8];
 #endif
@@ -95,46 +109,27 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     constexpr int kLdsBytes = rc_lds_bytes<kT16>();
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kLdsBytes];
     const int lane_all = (int)threadIdx.x;
-    // a wave takes `per_wave` consecutive chunks, one after the other: the second one's header is loaded with the
-    // first one's, and the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once
+    // a wave takes kPerWave consecutive chunks, one after the other: the second one's header is loaded with the first one's, and
+    // the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once.  (PERSISTENT waves —
+    // as many one-wave workgroups as the device has slots, each taking chunk after chunk of its XCD's range from ticket
+    // counters, in order — fill every slot all the time and are 4 - 8 % SLOWER: profiles/round5_d_ab_persistent_waves.txt.)
     constexpr uint32_t per_wave = kPerWave;
     static_assert(kPerWave == 1 || kPerWave == 2, "written out for one or two");
-    // XCD-aware remap (block b runs on XCD b % 8; each XCD has its own L2): every XCD gets one contiguous range of chunks.  The
-    // grid is a multiple of 8 (launch_batch rounds it up: at most 7 waves find nothing to do), so the map is a multiply-add.
-    const uint32_t first = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8) * per_wave);
-    if (first >= a.n_chunks)
-        return;
     uint8_t *lds = lds_all;
     int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);   // the int32 tile ...
     int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt); // ... or the int16 one (kT16)
-
-#if MPG_CHUNK_AHEAD
-    // pull the chunk(s) a later wave of this XCD's range will take towards L2 (a chunk is one 128-byte line) so that that wave's
-    // scalar loads find them there; nothing is done with the data.  (Also pulling those chunks' first words, by a dependent
-    // load once the header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
-    uint32_t ahead;
-    {
-        const uint32_t step = first + MPG_CHUNK_AHEAD * per_wave + per_wave <= a.n_chunks ? MPG_CHUNK_AHEAD * per_wave * kRcChunkDwords * 4 : 0u;
-        const uint32_t line = per_wave == 2 ? ((uint32_t)lane_all & 1u) * (kRcChunkDwords * 4) : 0u;
-        ahead = load32_uncounted(reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.chunks) + first * (kRcChunkDwords * 4)),
-                                 step + line);
-    }
-#endif
-    // step 1: one round of scalar loads (all of the wave's chunks), then per chunk its vector loads
-    const bool second = per_wave == 2 && first + 1 < a.n_chunks; // (written out for one or two)
-    const RcChunk c0 = rc_load_chunk(a, first);
-    const RcChunk c1 = rc_load_chunk(a, second ? first + 1 : first);
-    // what depends on the lane only: worked out once per wave, while the header is on its way
-    const int lane = lane_all;
-    const RcLane k = rc_lane(a, lane);
-    bool ahead_pending = MPG_CHUNK_AHEAD != 0;
+    uint32_t ahead = 0;
+    bool ahead_pending = false;
     auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
     (void)chunk; // (the instrumented build's stamps)
+    // what depends on the lane only: worked out while the header is on its way
+    const int lane = lane_all;
+    const RcLane k = rc_lane(a, lane);
     const uint32_t n_blocks = rc_n_blocks(c);
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)
         return;
-    if (chunk != first) // (a wave's second chunk starts here: its header has long arrived)
+    if (kPerWave == 2) // (a wave's second chunk starts here: its header has long arrived)
         MPG_STAMP(0);
 #endif
     MPG_STAMP(1);
@@ -357,6 +352,31 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     }
 #endif
     };
+    // pull the chunk(s) a later wave of this XCD's range will take towards L2 (a chunk is one 128-byte line) so that that wave's
+    // scalar loads find them there; nothing is done with the data.  (Also pulling those chunks' first words, by a dependent
+    // load once the header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
+    auto pull_ahead = [&](uint32_t first, uint32_t end) {
+#if MPG_CHUNK_AHEAD
+        const uint32_t step = first + MPG_CHUNK_AHEAD * per_wave + per_wave <= end ? MPG_CHUNK_AHEAD * per_wave * kRcChunkDwords * 4 : 0u;
+        const uint32_t line = per_wave == 2 ? ((uint32_t)lane_all & 1u) * (kRcChunkDwords * 4) : 0u;
+        ahead = load32_uncounted(reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.chunks) + first * (kRcChunkDwords * 4)),
+                                 step + line);
+        ahead_pending = true;
+#else
+        (void)first;
+        (void)end;
+#endif
+    };
+    // XCD-aware remap (block b runs on XCD b % 8; each XCD has its own L2): every XCD gets one contiguous range of chunks.  The
+    // grid is a multiple of 8 (launch_batch rounds it up: at most 7 waves find nothing to do), so the map is a multiply-add.
+    const uint32_t first = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8) * per_wave);
+    if (first >= a.n_chunks)
+        return;
+    pull_ahead(first, a.n_chunks);
+    // step 1: one round of scalar loads (all of the wave's chunks), then per chunk its vector loads
+    const bool second = per_wave == 2 && first + 1 < a.n_chunks; // (written out for one or two)
+    const RcChunk c0 = rc_load_chunk(a, first);
+    const RcChunk c1 = rc_load_chunk(a, second ? first + 1 : first);
     one_chunk(c0, first);
     if (second) {
         wave_lds_handoff(); // (the previous chunk's stores have read its output bytes)
@@ -1516,7 +1536,7 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     const uint32_t grid = grid8 * 8;
 #define LAUNCH_RECON(RGBA, T16, PER_WAVE) \
     hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, PER_WAVE>), dim3(grid), dim3(kReconWaves * 64), 0, st, grid8, a.n_chunks, a.chunks, \
-                       a.words, a.qmat, a.frames_b, a.mb_w, a.luma_bytes, a.luma_w, a.chroma_w, a)
+                       a.words, a.qmat, a.frames_b, a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height)
     if (t16) {
         if (b->any_rgba)
             LAUNCH_RECON(true, true, 1);

@@ -634,7 +634,10 @@ MPG_HD const uint32_t *rc_word_base(const VideoArgs &a, const RcChunk &c)
     return reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.words) + c.off[1]);
 }
 // the destination slot's offset from that base (chunks that are not runs, the fused colour conversion)
-MPG_HD uint32_t rc_cur_offset(const VideoArgs &a, const RcChunk &c) { return kRcDmaBias + rc_cur_slot(c) * (uint32_t)a.frame_stride; }
+// (h6 = that + 256 * the raster index of the chunk's first macroblock: no stride, no multiplication by the slot — the kernel keeps
+// nothing of the geometry in registers but mb_w and luma_bytes)
+MPG_HD uint32_t rc_mb_index(const VideoArgs &a, uint32_t d0) { return (d0 >> 24) * a.mb_w + ((d0 >> 16) & 0xff); }
+MPG_HD uint32_t rc_cur_offset(const VideoArgs &a, const RcChunk &c) { return c.h[6] - rc_mb_index(a, c.r[0][0]) * 256; }
 
 // ---- 16-bit multiply-adds whose wave-uniform multiplicand sits in one half of a record dword (the packer puts it there): the
 // instruction's operand select picks the half, so a field of a record reaches a lane's address with no scalar instruction
@@ -787,19 +790,22 @@ MPG_HD uint32_t rc_win_offset(const RcChunk &c, int m, const RcLane &k)
 MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, int lane)
 {
     (void)k;
+    // (rare: the plane geometry from the two values the kernel keeps)
+    const uint32_t mb_w = a.mb_w, luma_bytes = a.luma_bytes, chroma_bytes = luma_bytes >> 2;
+    const uint32_t luma_w = mb_w * 16, chroma_w = mb_w * 8;
     const uint8_t *ref = rc_frame_base(a, c) + kRcDmaBias + c.r[m][1];
     const uint32_t l = (uint32_t)lane, ci = l - 34, plane = ci >= 9 ? 1u : 0u;
     const bool chroma = l >= 34;
     // the piece of a LINEAR window (lanes < 52): luma row * luma_w + column * 16 / plane * chroma_bytes + row * chroma_w (17 rows x
     // 2, then 9 rows per plane)
-    const uint32_t lin_off = chroma ? plane * a.chroma_bytes + (ci - plane * 9) * a.chroma_w : (l >> 1) * a.luma_w + (l & 1) * kRcPiece;
+    const uint32_t lin_off = chroma ? plane * chroma_bytes + (ci - plane * 9) * chroma_w : (l >> 1) * luma_w + (l & 1) * kRcPiece;
     // (no select between two record dwords: the compiler makes an indexed load of it and moves the whole chunk to scratch)
     const uint32_t r3 = c.r[m][3], r4 = c.r[m][4];
     const uint32_t origin = ((r3 + ((0u - (uint32_t)chroma) & (r4 - r3))) & ~3u) + lin_off;
     u32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        v.v[i] = *reinterpret_cast<const uint32_t *>(ref + linear_to_tiled(a.mb_w, a.luma_bytes, a.chroma_bytes, origin + 4 * i));
+        v.v[i] = *reinterpret_cast<const uint32_t *>(ref + linear_to_tiled(mb_w, luma_bytes, chroma_bytes, origin + 4 * i));
     return v;
 }
 
@@ -1427,7 +1433,6 @@ MPG_HD void rc_rmw(uint8_t *lds, uint32_t bw, int lane, const int32_t (&v)[8])
 }
 
 // ---- step 5: stores (tiled frame: a macroblock's luma is 256 contiguous bytes, its Cb and Cr 64 each)
-MPG_HD uint32_t rc_mb_index(const VideoArgs &a, uint32_t d0) { return (d0 >> 24) * a.mb_w + ((d0 >> 16) & 0xff); }
 
 // horizontal run = 4 consecutive tiles: luma 1 KB by all 64 lanes (16 bytes each), the four Cb | Cr pairs 512 bytes by lanes
 // 0..31, as they lie in the O_m; where they go the header says (h6 / h7, from the wave's one frame base).  Non-temporal stores:
