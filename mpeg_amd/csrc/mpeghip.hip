@@ -209,11 +209,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
             } else {
                 zero_columns();
             }
-            if (rc_any_dcword(c) && mine)
-                rc_dc_from_word(bw, lane, v);
-            if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are, from HBM
-                rc_raw_cols(a, c, bw, lane, v);
-            dense_columns();
+            if (rc_any_special(c)) { // (one test for the common chunk — predicted macroblocks, sparse blocks — instead of three)
+                if (rc_any_dcword(c) && mine)
+                    rc_dc_from_word(bw, lane, v);
+                if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are, from HBM
+                    rc_raw_cols(a, c, bw, lane, v);
+                dense_columns();
+            }
             idct8<false>(v);
             rc_transpose8(v, lane); // column j -> row j, across the block's 8 lanes
             idct8<true>(v);

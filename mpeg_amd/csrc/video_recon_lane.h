@@ -624,6 +624,7 @@ MPG_HD uint32_t rc_n_live(const RcChunk &c) { return (c.h[5] >> kHLiveShift) & 7
 MPG_HD bool rc_any_raw(const RcChunk &c) { return (c.h[5] & kHAnyRaw) != 0; }
 MPG_HD bool rc_any_dense(const RcChunk &c) { return (c.h[5] & kHAnyDense) != 0; }
 MPG_HD bool rc_any_dcword(const RcChunk &c) { return (c.h[5] & kHAnyDcWord) != 0; } // (intra macroblocks only: most chunks skip the test per lane)
+MPG_HD bool rc_any_special(const RcChunk &c) { return (c.h[5] & (kHAnyRaw | kHAnyDense | kHAnyDcWord)) != 0; }
 MPG_HD uint32_t rc_cur_slot(const RcChunk &c) { return (c.h[5] >> kHCurShift) & 3; }
 MPG_HD uint32_t rc_stream(const RcChunk &c) { return c.h[5] >> kHStreamShift; }
 MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[4] >> (10 * pass)) & 0x3ff; }
@@ -903,7 +904,8 @@ MPG_HD void rc_cols_load16(const int16_t *T, const uint8_t *lds, int lane, int32
 // an int32 snapshot block: lane (g, j) takes column j (positions j * 8 .. j * 8 + 7) straight from its 64 dwords
 MPG_HD void rc_raw_cols(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane, int32_t (&v)[8])
 {
-    const i32x4_a4 *p = reinterpret_cast<const i32x4_a4 *>(rc_word_base(a, c) + rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 8);
+    const uint32_t at = (rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 8) * 4; // (bytes, 32 bits: rc_dense_read)
+    const i32x4_a4 *p = reinterpret_cast<const i32x4_a4 *>(reinterpret_cast<const uint8_t *>(rc_word_base(a, c)) + at);
     const i32x4_a4 lo = p[0], hi = p[1];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -1209,7 +1211,10 @@ MPG_HD bool rc_non_intra_column_flat(const uint8_t *lds, int lane)
 // column j of a dense unit: 8 int16 levels (read apart from their use: the next pass's are fetched while this pass runs)
 MPG_HD i32x4_a4 rc_dense_read(const VideoArgs &a, const RcChunk &c, uint32_t bw, int lane)
 {
-    return *reinterpret_cast<const i32x4_a4 *>(rc_word_base(a, c) + rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 4);
+    // (the BYTE offset as a 32-bit value on top of the wave's scalar base: written as a dword index the compiler widens it per lane
+    // — two 64-bit shift-adds in front of every unit load)
+    const uint32_t at = (rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + ((uint32_t)lane & 7) * 4) * 4;
+    return *reinterpret_cast<const i32x4_a4 *>(reinterpret_cast<const uint8_t *>(rc_word_base(a, c)) + at);
 }
 // kFlat: every dense block of the pass is non-intra and the stream's non-intra matrix is 16 everywhere (the caller's
 // wave-uniform test): no matrix bytes, no intra DC.
@@ -1232,8 +1237,18 @@ MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, i
         MPG_CHECK(!intra && rc_non_intra_column_flat(lds, lane));
         const uint32_t a1 = (uint32_t)qs << (MPG_DENSE_SAT16 ? 5 : 1), e1 = (((uint32_t)qs - 1) | 1) << (MPG_DENSE_SAT16 ? 4 : 0); // A, e of the block (x 16); in both halves:
         const uint32_t a2 = a1 | (a1 << 16), e2 = e1 | (e1 << 16);
+#if MPG_DENSE_SAT16
+        // (the four pairs stage by stage, not pair by pair: a packed instruction that consumes the result of the one in front of it
+        // costs a wait state — the compiler's own order had eight s_nop per column)
+        const uint32_t w0 = (uint32_t)lv.v[0], w1 = (uint32_t)lv.v[1], w2 = (uint32_t)lv.v[2], w3 = (uint32_t)lv.v[3];
+        const uint32_t g0 = pk_sign_i16(w0), g1 = pk_sign_i16(w1), g2 = pk_sign_i16(w2), g3 = pk_sign_i16(w3);
+        const uint32_t m0 = pk_mul_lo_i16(g0, e2), m1 = pk_mul_lo_i16(g1, e2), m2 = pk_mul_lo_i16(g2, e2), m3 = pk_mul_lo_i16(g3, e2);
+        const uint32_t s0 = pk_mad_sat_i16(w0, a2, m0), s1 = pk_mad_sat_i16(w1, a2, m1), s2 = pk_mad_sat_i16(w2, a2, m2), s3 = pk_mad_sat_i16(w3, a2, m3);
+        const uint32_t l0 = pk_ashr4_i16(s0), l1 = pk_ashr4_i16(s1), l2 = pk_ashr4_i16(s2), l3 = pk_ashr4_i16(s3);
+#else
         const uint32_t l0 = rc_dense_pair_flat((uint32_t)lv.v[0], a2, e2), l1 = rc_dense_pair_flat((uint32_t)lv.v[1], a2, e2);
         const uint32_t l2 = rc_dense_pair_flat((uint32_t)lv.v[2], a2, e2), l3 = rc_dense_pair_flat((uint32_t)lv.v[3], a2, e2);
+#endif
         v[0] = mul_u8_s16<0, 0>(pm[0], l0); // the premultiply (video.go:744): byte r of the column's eight x half r & 1
         v[1] = mul_u8_s16<1, 1>(pm[0], l0);
         v[2] = mul_u8_s16<2, 0>(pm[0], l1);
