@@ -315,6 +315,18 @@ MPG_HD void dma_table_and_windows(const uint8_t *table_base, const uint8_t *fram
         __builtin_memcpy(static_cast<char *>(lds_wave_base) + at[i] + 16 * lane, frame_base + off[i] + at[i], 16);
 #endif
 }
+// ONE such load: lane l's 16 bytes from base + off (+ kAt) to LDS offset kAt + 16 l (recon_wide_kernel: a wave loads one window)
+template <int kAt> MPG_HD void dma16_to_lds(const uint8_t *base, uint32_t off, void *lds_wave_base, int lane)
+{
+    static_assert(kAt >= 0 && kAt < 4096, "13-bit signed offset field");
+#if MPG_ON_DEVICE
+    (void)lane;
+    const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(off), "s"(base), "s"(lbase), "n"(kAt) : "memory");
+#else
+    __builtin_memcpy(static_cast<char *>(lds_wave_base) + kAt + 16 * lane, base + off + kAt, 16);
+#endif
+}
 // one dword per lane into a register; only valid after wait_loads + settle() — and settle() it on EVERY path, used or
 // not: until then the register belongs to the load, and the compiler must not hand it to something else
 MPG_HD uint32_t load32_uncounted(const uint32_t *uniform_base, uint32_t byte_off)

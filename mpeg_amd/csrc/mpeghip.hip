@@ -387,6 +387,176 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
 }
 #undef MPG_STAMP
 
+// ---- the same work for launches that leave most wave slots empty — ONE picture (BASELINE config 3 as written: 2 040 chunks for
+// 8 192 slots): FOUR waves per chunk.  Such a launch lasts one chunk's chain of dependent steps, and a single wave walks through
+// ~700 instructions and ~40 LDS round trips with one other wave per SIMD to hide them (profiles/round5_e_*: 9.4 us per picture over
+// a launch floor of 3.0).  Here wave w fetches window w and runs residual pass w (a chunk has at most three) and the motion
+// compensation of macroblock w, all at the same time; two workgroup barriers order the hand-over of the output bytes (residual
+// rows are added by the wave that made them; then every wave stores its share: luma / chroma of a run, four image rows each of
+// a fused colour conversion).  The lane functions, the device format and the arithmetic are recon_kernel's own (int16 tile);
+// launch_batch takes this kernel when four waves per chunk still fit the device's slots and no instance is pinned.
+template <bool kRgba>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_wide_kernel(
+    const uint32_t grid8, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
+    uint8_t *const frames_b, const uint32_t mb_w, const uint32_t luma_bytes, uint8_t *const rgba, const uint64_t rgba_stride,
+    const uint32_t width, const uint32_t height)
+{
+    VideoArgs a;
+    a.frames = nullptr;
+    a.frames_b = frames_b;
+    a.frame_stride = 0;
+    a.mb_w = mb_w;
+    a.mb_h = 0;
+    a.luma_w = mb_w * 16;
+    a.luma_h = 0;
+    a.chroma_w = mb_w * 8;
+    a.chroma_h = 0;
+    a.luma_bytes = luma_bytes;
+    a.chroma_bytes = luma_bytes >> 2;
+    a.pics = nullptr;
+    a.chunks = chunks;
+    a.words = words;
+    a.qmat = qmat;
+    a.n_chunks = n_chunks;
+    a.width = width;
+    a.height = height;
+    a.rgba = rgba;
+    a.rgba_stride = rgba_stride;
+    // table | four windows (-> O_m) as in recon_kernel, then one int16 tile per pass
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kRcTileAt + 3 * kRcTileBytes16];
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t chunk = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8));
+    if (chunk >= a.n_chunks)
+        return; // (the whole workgroup: no barrier is left waiting)
+    const RcChunk c = rc_load_chunk(a, chunk);
+    const RcLane k = rc_lane(a, lane);
+    const uint32_t n_blocks = rc_n_blocks(c);
+    const bool my_pass = w * 8 < n_blocks;
+    const uint32_t *const wbase = rc_word_base(a, c);
+    uint8_t *const fbase = rc_frame_base(a, c);
+    // what a record names by its macroblock is reached through a switch on the (wave-uniform) wave number: an index into the
+    // chunk's scalars would move the whole chunk to scratch
+    auto by_wave = [&](auto &&f) {
+        switch (w) {
+        case 0: f(std::integral_constant<int, 0>{}); break;
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        default: f(std::integral_constant<int, 3>{}); break;
+        }
+    };
+    // step 1: the wave's loads — its pass's first 64 entries and block words, the table (every wave asks for the same 192 bytes:
+    // no barrier in front of the passes), its window
+    uint32_t ent_at = 0, np = 0;
+    if (w == 0)
+        np = rc_pass_entries(c, 0);
+    if (w == 1)
+        ent_at = rc_pass_entries(c, 0), np = rc_pass_entries(c, 1);
+    if (w == 2)
+        ent_at = rc_pass_entries(c, 0) + rc_pass_entries(c, 1), np = rc_pass_entries(c, 2);
+    uint32_t e = 0, bw = 0;
+    if (my_pass) {
+        e = load32_uncounted(wbase, rc_ent_lane_offset(c, ent_at, lane));
+        bw = load32_uncounted(wbase, rc_blk_lane_offset(w, lane));
+    }
+    if (lane < kRcQtabBytes / kRcPiece) // (its own lanes only: another wave's window must not be written over)
+        dma16_to_lds<kRcQtabAt>(a.qmat, rc_table_lane_offset(c, lane), lds, lane);
+    if (lane < kRcWinLanes)
+        by_wave([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            dma16_to_lds<kRcWinAt + m * kRcWinBytes>(fbase, rc_win_offset(c, m, k), lds, lane);
+        });
+    // step 2: residual pass w (recon_kernel's int16-tile form) -> row j of block g in lane (g, j)
+    int32_t v[8];
+    const bool mine = w * 8 + ((uint32_t)lane >> 3) < n_blocks;
+    if (my_pass) {
+        int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt + w * kRcTileBytes16);
+        wait_loads<1>(); // the entries, the block words and the table are there; the window may still be on its way
+        settle(e);
+        settle(bw);
+        wave_lds_handoff();
+        if (np) {
+            rc_zero_tile16(T16, lane);
+            wave_lds_handoff();
+            for (uint32_t r = 0; r < np; r += 64) {
+                if (r > 0)
+                    e = *rc_ent_src(a, c, ent_at + r, lane);
+                if (r + (uint32_t)lane < np)
+                    rc_scatter16(T16, lds, e);
+            }
+            wave_lds_handoff();
+            rc_cols_load16(T16, lds, lane, v);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                v[r] = 0;
+        }
+        if (rc_any_special(c)) {
+            if (rc_any_dcword(c) && mine)
+                rc_dc_from_word(bw, lane, v);
+            if (rc_any_raw(c) && mine && (bw & kBRaw))
+                rc_raw_cols(a, c, bw, lane, v);
+            if (rc_any_dense(c) && mine && (bw & kBDense))
+                rc_dense_cols<false>(rc_dense_read(a, c, bw, lane), lds, bw, lane, v);
+        }
+        idct8<false>(v);
+        rc_transpose8(v, lane);
+        idct8<true>(v);
+    }
+    // step 3: motion compensation of macroblock w
+    wait_loads<0>();
+    settle(e);
+    settle(bw);
+    wave_lds_handoff();
+    by_wave([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        const uint32_t r0 = c.r[m][0];
+        if (r0 & kRDead)
+            return;
+        uint32_t yl = 0, yc = 0;
+        uint8_t *win = lds + rc_win_at(m);
+        if (!(r0 & (kRIntra | kRSlow))) {
+            yl = rc_mc_luma<m>(lds, k, r0, c.r[m][3]);
+            yc = rc_mc_chroma<m>(lds, k, lane, r0, c.r[m][4], c.r[m][5]);
+        } else if (r0 & kRSlow) {
+            if (lane < 52)
+                *reinterpret_cast<u32x4 *>(win + lane * 16) = rc_gather_piece(a, c, m, k, lane);
+            wave_lds_handoff();
+            yl = rc_mc_luma_slow(win, k, r0, c.r[m][3]);
+            yc = rc_mc_chroma_slow(win, k, r0, c.r[m][4]);
+        }
+        wave_lds_handoff(); // every lane has its taps
+        *reinterpret_cast<uint32_t *>(win + k.out_luma) = yl;
+        *reinterpret_cast<uint32_t *>(win + k.out_chroma) = yc;
+    });
+    workgroup_barrier_lds(); // the four O_m are complete
+    // step 4: the wave's residual rows onto them
+    if (my_pass && mine)
+        rc_rmw(lds, bw, lane, v);
+    workgroup_barrier_lds();
+    // step 5: stores, every wave its share
+    const bool run = (c.h[4] & kCRun) != 0;
+    const bool to_rgba = kRgba && (c.h[4] & kCRgba) != 0;
+    const uint32_t n_live = rc_n_live(c);
+    if (run) {
+        if (w == 0)
+            rc_store_run_luma(a, c, lane, lds);
+        if (w == 1)
+            rc_store_run_chroma(a, c, lane, lds);
+        if (kRgba && to_rgba)
+            rc_rgba_run_rows(a, c, rc_rgba_image(a, c), w, lane, lds);
+    } else if (w < n_live) {
+        by_wave([&](auto M) {
+            constexpr uint32_t m = (uint32_t)decltype(M)::value;
+            rc_store_mb(a, c, m, lane, lds, to_rgba);
+            if (kRgba && to_rgba) {
+                wave_lds_handoff();
+                rc_rgba_mb(a, c, rc_rgba_image(a, c), m, lane, lds);
+            }
+        });
+    }
+}
+
 // Which 4x2 pixel block a thread of the whole-frame conversions takes.  The frame store is tiled (video_lane.h), so a
 // wave walks TILES, not picture rows: wave = 4 macroblocks side by side x 8 rows, lane = (macroblock lane>>4, row pair
 // (lane>>2)&3, quad lane&3): its luma reads are 4 x 128 contiguous bytes, each RGBA store instruction writes one row of
@@ -1489,6 +1659,35 @@ constexpr uint64_t kDenseShareNum = 2, kDenseShareDen = 3;
 constexpr int kReconWaves = 1; // waves (= chunks) per workgroup: waves of a workgroup that finish early keep their slots until the
                                // last one has (its LDS goes back as a whole) — 1 beats 2 beats 4 (profiles/r2w_ab_waves_per_workgroup.txt)
 
+// Behind a reconstruction launch, Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
+static int finish_rgba_bookkeeping(mpeghip_video *v, const mpeghip_batch *b, const VideoArgs &a)
+{
+    const mpeghip_video_info &in = v->info;
+    hipStream_t st = v->ctx->stream;
+    // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
+    // image was out of date (an unflagged picture or write_planes touched the slot since).
+    bool whole_frames = false;
+    for (uint32_t r = 0; r < b->replicas; r++)
+        for (const mpeghip_batch::PicNote &n : b->notes) {
+            uint8_t &sync = v->rgba_sync[((size_t)n.stream + r) * MPEGHIP_SLOTS + n.cur];
+            if (!n.rgba)
+                sync = 0;
+            else if (n.full)
+                sync = 1;
+            else if (!sync)
+                whole_frames = true, sync = 1;
+        }
+    if (whole_frames) {
+        for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
+            const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
+            hipLaunchKernelGGL(rgba_pics_kernel, dim3((in.mb_w + 7) / 8, in.mb_h, np), dim3(256), 0, st, a,
+                               (uint32_t)p0);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return MPEGHIP_OK;
+}
+
 static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
 {
     if (b->n_chunks == 0)
@@ -1532,6 +1731,19 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     // form needs 49 vector and 60 scalar registers where two chunks spill scalars to lanes (+1.0 % in eight of eight rounds,
     // profiles/r31_ab_chunks_per_wave_by_instance.txt); two for the int32-tile instance (dense +1.4 % with two).
     const uint64_t wave_slots = (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 7;
+    // A launch that leaves most slots empty — four waves per chunk still fit — goes to recon_wide_kernel: its duration is one chunk's
+    // chain, which four waves walk in parallel.  (Only when the library picks: a pinned policy names recon_kernel's instances.)
+    if (v->tile_policy == MPEGHIP_TILE_AUTO && a.n_chunks * 4 <= (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 8) {
+        const uint32_t g8 = (a.n_chunks + 7) / 8;
+        if (b->any_rgba)
+            hipLaunchKernelGGL((recon_wide_kernel<true>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat, a.frames_b,
+                               a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height);
+        else
+            hipLaunchKernelGGL((recon_wide_kernel<false>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat, a.frames_b,
+                               a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height);
+        HIP_TRY(hipGetLastError());
+        return finish_rgba_bookkeeping(v, b, a);
+    }
     const uint32_t per_wave = (t16 || a.n_chunks <= wave_slots) ? 1 : 2;
     // (a multiple of 8 workgroups: the kernel's XCD remap is then a multiply-add; the at most 7 surplus waves return at once)
     const uint32_t grid8 = ((a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave) + 7) / 8;
@@ -1557,29 +1769,7 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     }
 #undef LAUNCH_RECON
     HIP_TRY(hipGetLastError());
-    // Frame.RGBA bookkeeping: the kernel has converted every macroblock that flagged pictures wrote.
-    // A whole-frame pass is still owed when a flagged picture covered only part of a frame whose
-    // image was out of date (an unflagged picture or write_planes touched the slot since).
-    bool whole_frames = false;
-    for (uint32_t r = 0; r < b->replicas; r++)
-        for (const mpeghip_batch::PicNote &n : b->notes) {
-            uint8_t &sync = v->rgba_sync[((size_t)n.stream + r) * MPEGHIP_SLOTS + n.cur];
-            if (!n.rgba)
-                sync = 0;
-            else if (n.full)
-                sync = 1;
-            else if (!sync)
-                whole_frames = true, sync = 1;
-        }
-    if (whole_frames) {
-        for (uint64_t p0 = 0; p0 < b->n_pics; p0 += 32768) {
-            const uint32_t np = (uint32_t)(b->n_pics - p0 < 32768 ? b->n_pics - p0 : 32768);
-            hipLaunchKernelGGL(rgba_pics_kernel, dim3((in.mb_w + 7) / 8, in.mb_h, np), dim3(256), 0, st, a,
-                               (uint32_t)p0);
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    return MPEGHIP_OK;
+    return finish_rgba_bookkeeping(v, b, a);
 }
 
 static bool wants_rgba(const mpeghip_pic_desc *pics, uint32_t n_pics)

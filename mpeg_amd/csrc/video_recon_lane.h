@@ -1454,13 +1454,21 @@ MPG_HD void rc_rmw(uint8_t *lds, uint32_t bw, int lane, const int32_t (&v)[8])
 // the picture is next read by a later launch; the prediction windows of the neighbouring chunks, which ARE read again within
 // microseconds, keep their place in L2 (profiles/r4z_ab_non_temporal_frame_stores.txt: typical +1.9 %, dense +0.3 %; the
 // fused-RGBA instance likewise, with its RGBA stores: profiles/r5_ab_*: +3.8 % / +1.6 %)
-MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
+MPG_HD void rc_store_run_luma(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
 {
     const uint32_t l = (uint32_t)lane;
-    uint8_t *base = rc_frame_base(a, c); // wave-uniform
-    store16_at<true>(base, c.h[6] + l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
+    store16_at<true>(rc_frame_base(a, c), c.h[6] + l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 4) + (l & 15) * 16));
+}
+MPG_HD void rc_store_run_chroma(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
+{
+    const uint32_t l = (uint32_t)lane;
     if (lane < 32)
-        store16_at<true>(base, c.h[7] + l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 3) + 256 + (l & 7) * 16));
+        store16_at<true>(rc_frame_base(a, c), c.h[7] + l * 16, *reinterpret_cast<const u32x4 *>(lds + rc_win_at(l >> 3) + 256 + (l & 7) * 16));
+}
+MPG_HD void rc_store_run(const VideoArgs &a, const RcChunk &c, int lane, const uint8_t *lds)
+{
+    rc_store_run_luma(a, c, lane, lds);
+    rc_store_run_chroma(a, c, lane, lds);
 }
 
 // any other chunk: macroblock m by lanes (block b = lane>>3, row j = lane&7), 8 bytes each.  An invalid intra

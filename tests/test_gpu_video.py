@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
     (50, 35, 3, "typical", 0.0, True),        # odd height: the last RGBA row has no partner
     (1920, 1080, 4, "typical", 0.0, True),    # BASELINE config 3: 1080p, fused IDCT+MC+RGBA
     (1920, 1080, 2, "dense", 0.0, False),
+    (1920, 1080, 2, "dense", 0.0, True),      # BASELINE config 3's worst case: dense + fused RGBA at 1080p
 ])
 def test_reconstruction_bit_exact(oracle, hip_ctx, w, h, n, profile, raw, rgba):
     seq = synth.generate_sequence(w, h, n, profile=profile, raw_fraction=raw, rgba=rgba)
