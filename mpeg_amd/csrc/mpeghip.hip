@@ -637,8 +637,12 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackArgs a)
         in.n = n;
         out.base = x.word_first + lo4;
         out.n = n;
-        for (uint32_t i = (uint32_t)lane * 4; i < n; i += 256) // (a picture's words begin on a 64-byte boundary; the buffer is padded)
+        for (uint32_t i = (uint32_t)lane * 4; i < n; i += 256) { // (a picture's words begin on a 64-byte boundary; the buffer is padded)
             *reinterpret_cast<u32x4 *>(win + i) = *reinterpret_cast<const u32x4 *>(in.glob + lo4 + i);
+            // (the produced words' window starts out zeroed: the gaps between chunks' words leave it as they are — no
+            // uninitialised LDS reaches device memory)
+            *reinterpret_cast<u32x4 *>(wout + i) = u32x4{{0, 0, 0, 0}};
+        }
     }
     wave_lds_handoff();
     const PkLane L = pk_scan(a, pic, p, x, k, mb, in);
@@ -2368,8 +2372,13 @@ static int stage_commit_device(mpeghip_stage *s)
     // (the packer's scratch is reset while the copy runs; the kernels wait for the copy)
     HIP_TRY(hipMemsetAsync(sg->d_seen, 0, (size_t)s->n_pics * seen_stride * 4, st));
     HIP_TRY(hipMemsetAsync(sg->d_err, 0xff, 8, st));
-    if ((rc = send_staging(v, sg, sg->d_raw, raw_total)) != MPEGHIP_OK)
+    if ((rc = send_staging(v, sg, sg->d_raw, raw_total)) != MPEGHIP_OK) {
+        (void)hipStreamSynchronize(v->ctx->copy_stream); // (what was queued of the copy has read the staging buffer)
         return rc;
+    }
+    // From here on the H2D copy is reading sg->h on the copy stream.  Whatever fails below, the call must not return with that
+    // copy still in flight and the slot marked idle: the next stage_begin would refill the buffer under it (round-4 advisor).
+    rc = [&]() -> int {
     PackArgs a;
     a.pics = reinterpret_cast<const mpeghip_pic_desc *>(sg->d_raw);
     a.aux = reinterpret_cast<PkPic *>(sg->d_raw + s->a_at);
@@ -2430,13 +2439,20 @@ static int stage_commit_device(mpeghip_stage *s)
     b->n_mbs = s->n_mbs;
     b->n_chunks = s->n_chunks;
     v->next_staging ^= 1;
-    if ((rc = launch_batch(v, b)) != MPEGHIP_OK)
-        return rc;
+    int rc2;
+    if ((rc2 = launch_batch(v, b)) != MPEGHIP_OK)
+        return rc2;
     HIP_TRY(hipEventRecord(sg->done, st));
     sg->in_flight = true;
     sg->packed_on_device = true;
     sg->pk_mb_first = s->mb_first;
     return MPEGHIP_OK;
+    }();
+    if (rc != MPEGHIP_OK) { // keep the error text: the synchronisation calls below do not touch it
+        (void)hipStreamSynchronize(v->ctx->copy_stream);
+        (void)hipStreamSynchronize(st);
+    }
+    return rc;
 }
 
 static int mpeghip_video_stage_commit_impl(mpeghip_stage *sp)

@@ -723,23 +723,23 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
 {
     const uint32_t l = (uint32_t)lane;
     RcLane k;
-    {   // (arithmetic on a 0 / 1 flag, not selects between expressions: the compiler makes divergent branches of those, a dozen
-        // scalar instructions of mask bookkeeping in every wave's prologue)
-        const uint32_t ch = opaque(l >= 34 ? 1u : 0u);      // a chroma piece
-        const uint32_t ci = l - 34;                          // (chroma lanes only)
-        const uint32_t plane = opaque(l >= 44 ? 1u : 0u);    // Cr
-        const uint32_t cj = ci - plane * 10;
-        const uint32_t rj = (l >> 1) + ch * ((cj >> 1) - (l >> 1));
-        k.piece_chroma = 0u - ch;
-        k.sub_mask = 0xf0 - ch * 0xc0;
+    {   // (selects by an all-ones / all-zeros MASK — one v_bfi_b32 each — not `chroma ? a : b` between expressions: the compiler makes
+        // divergent branches of those, a dozen scalar instructions of mask bookkeeping in every wave's prologue; and not products
+        // with a 0 / 1 flag either: those become quarter-rate v_mul_lo_u32)
+        const uint32_t chm = opaque(l >= 34 ? ~0u : 0u);    // a chroma piece
+        const uint32_t crm = opaque(l >= 44 ? ~0u : 0u);    // ... of Cr
+        auto pick = [](uint32_t mask, uint32_t if_set, uint32_t if_clear) { return (mask & if_set) | (~mask & if_clear); };
+        const uint32_t cj = l - 34 - (crm & 10u);            // (chroma lanes only)
+        const uint32_t rj = pick(chm, cj >> 1, l >> 1);
+        k.piece_chroma = chm;
+        k.sub_mask = pick(chm, 0x30u, 0xf0u);
         k.rj16 = rj * 16;
-        const uint32_t col_l = (l & 1) * 256, col_c = plane * kChromaCrAt + (cj & 1) * kChromaBlockStep;
-        const uint32_t cterm = rj * 16 + col_l + ch * (col_c - col_l);
+        const uint32_t cterm = rj * 16 + pick(chm, (crm & kChromaCrAt) + (cj & 1) * kChromaBlockStep, (l & 1) * 256);
 #pragma unroll
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
             k.cterm[m] = cterm + kRcDmaBias - (kRcWinAt + m * kRcWinBytes);
-        k.wrap_shift = 8 - 2 * ch;
-        k.below = a.mb_w * (256 - ch * (256 - kChromaBlockStep)) - (256 - ch * 192);
+        k.wrap_shift = pick(chm, 6u, 8u);
+        k.below = pick(chm, a.mb_w * kChromaBlockStep - 64, a.mb_w * 256 - 256);
     }
     k.mc_luma = (l >> 2) * 32 + (l & 3) * 4;
     k.mc_plane = ((l >> 4) & 1) * 160;
