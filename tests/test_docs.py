@@ -12,7 +12,7 @@ def test_every_cited_profile_exists():
     missing = []
     for doc in DOCS:
         text = (ROOT / doc).read_text()
-        for m in re.finditer(r"`(?:profiles/)?((?:r\d\w*?|round4_[a-z])_[\w.\-]+\.(?:txt|json|csv|log))`", text):  # full file names
+        for m in re.finditer(r"`(?:profiles/)?((?:r\d\w*?|round[45]_[a-z]+)_[\w.\-]+\.(?:txt|json|csv|log))`", text):  # full file names
             name = m.group(1)
             if "*" in name or "…" in name:
                 continue
