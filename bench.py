@@ -37,10 +37,11 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MB_PER_1080P30_STREAM = 8160 * 30
-KERNEL = {False: "recon_kernel<1, false, T, N> (a wave reconstructs N = 2 chunks of 4 macroblocks, N = 1 where a launch fits the device's wave "
-                 "slots: one picture; sparse coefficient entries, prediction windows by direct-to-LDS loads; T: int16 tile / 8 waves per SIMD "
-                 "for typical batches, int32 tile / 7 for batches of dense units)",
-          True: "recon_kernel<1, true, T, N> (the instances with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
+KERNEL = {False: "recon_kernel<1, false, T, N> (a wave reconstructs N chunks of 4 macroblocks; sparse coefficient entries, prediction windows "
+                 "by direct-to-LDS loads, records that carry their own address arithmetic; T: int16 tile / 8 waves per SIMD, N = 1 for typical "
+                 "batches; int32 tile / 7, N = 2 for batches of dense units); launches that leave the wave slots empty (one picture) run "
+                 "recon_wide_kernel: four waves per chunk",
+          True: "recon_kernel<1, true, T, N> / recon_wide_kernel<true> (the instances with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
 def parse_args():
@@ -500,7 +501,8 @@ def audio_leg(ctx, args, streams, tile=1, fma=0, ranks=None, device_sync=None):
 
 def single_stream_leg(ctx, args):
     """BASELINE config 3 as written: ONE 1920x1080 stream on the GPU, IDCT + MC + YCbCr->RGBA fused, a picture per launch.
-    8 160 macroblocks = 2 040 chunks = 1 020 one-wave workgroups on a 256-CU part: a latency figure, not a bandwidth one."""
+    8 160 macroblocks = 2 040 chunks = 2 040 four-wave workgroups of recon_wide_kernel (8 160 waves: the device's slots) on a 256-CU
+    part: a latency figure, not a bandwidth one."""
     out = {"metric": "one %dx%d stream, one picture per launch, Frame.RGBA() fused (BASELINE config 3)" % (args.width, args.height)}
     for profile in ("typical", "dense"):
         leg = video_leg(ctx, args, profile, True, 1, steps=100, ramp_ms=40.0)
@@ -646,7 +648,7 @@ def host_fed_leg(args, prim, device, ranks=None):
                     (prim["mbs"] / prim["elapsed"] / (dev8 * mb_per_pic))}
 
 
-def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
+def host_parsed_leg(args, device, streams=256, threads=16, gop=7, groups=6):
     """Parse-inclusive: a written 1080p elementary stream (tests/mpeg1_writer.py: the `natural` level mix, coefficients as
     Table B.5 run / level codes, escapes where the table has none) through the product's whole host stack — mpeg::VideoBatch:
     bitstream parse on a pool of host threads -> the parser's sparse pictures -> device-packed staged commits -> pack_kernel +
@@ -686,12 +688,12 @@ def host_parsed_leg(args, device, streams=64, threads=16, gop=7, groups=6):
                      "reconstructed — NOT `value`" % (streams, gop * groups, len(es) / (gop * groups) / 1e3, threads),
            "streams": streams, "parse_threads_requested": threads, "effective_cores": eff,
            "pictures_per_stream": gop * groups, "stream_bytes_per_picture": len(es) / (gop * groups)}
-    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else threads
-    wide = max(1, min(4 * threads, cpus))
-    # (name, device-side packing, parse threads, streams): the wide runs show what more host threads buy — one picture per thread
-    # and round, then four
+    # (name, device-side packing, parse threads, streams).  A tick parses ONE picture of every stream: with few streams per thread
+    # a round is short and its hand-over (stage begin, commit, the wait for the slowest thread) weighs — BENCH_r04 / round 5:
+    # 64 streams on 16 threads 7 800 pictures/s, 256 streams 12 800.  The headline arm has 16 streams per thread; the few-streams
+    # arm shows the other end.
     for name, device_pack, nthreads, nstreams in (("device_packed", 1, threads, streams), ("host_packed", 0, threads, streams),
-                                                  ("device_packed_wide", 1, wide, wide), ("device_packed_wide_x4", 1, wide, 4 * wide)):
+                                                  ("device_packed_few_streams", 1, threads, max(threads, streams // 4))):
         b = H.mpeghost_batch_open(dev, nstreams)
         if not b:
             raise SystemExit("bench: host_parsed: %s" % H.mpeghost_last_error().decode())

@@ -30,13 +30,28 @@ stats() { # name, bench args...
   # launches after them — the average of the last --steps dispatches of the reconstruction kernel is the comparable figure
   for f in $(find $OUT/trace_$name -name "*kernel_trace.csv" | head -1); do python - "$f" "$OUT/kernel_stats_$name.csv" <<PY
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "recon_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "recon_kernel" in r["Kernel_Name"] or "recon_wide_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 if d:
     timed = d[-20:] if len(d) > 20 else d
     line = "# %s: %d dispatches; the last %d (= the timed steps): average %.4f ms, min %.4f, max %.4f; the first %d (warm-up, cold caches): average %.4f ms" % (
         rows[-1]["Kernel_Name"][:40], len(d), len(timed), sum(timed) / len(timed), min(timed), max(timed), len(d) - len(timed), sum(d[:len(d) - len(timed)]) / max(1, len(d) - len(timed)))
+    print(line)
+    open(sys.argv[2], "a").write(line + "\n")
+# the audio kernel: launches of 256 and of 2048 streams share a name and differ in grid size; bench.py times the LAST ones of
+# each size (after >= 40 ms of warm-up launches), the stats' average above mixes sizes and includes the ramp
+import collections
+by = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if "audio_kernel" in r["Kernel_Name"]:
+        by[(r["Kernel_Name"][:34], int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0))].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+for (name, grid), xs in sorted(by.items()):
+    xs.sort()
+    d = [x[1] for x in xs]
+    timed = d[len(d) // 2:]
+    line = "# %s grid %d: %d dispatches; the later half (bench.py times the last ones): average %.4f ms, min %.4f, max %.4f; the first three: %s" % (
+        name, grid, len(d), sum(timed) / len(timed), min(timed), max(timed), " ".join("%.4f" % v for v in d[:3]))
     print(line)
     open(sys.argv[2], "a").write(line + "\n")
 PY
@@ -48,11 +63,26 @@ stats dense --profile dense --legs "" --audio-streams 0 --cpu-seconds 0 --check 
 stats fused --profile typical --rgba 1 --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats dense_fused --profile dense --rgba 1 --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats audio --streams 16 --legs "" --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 2 --warmup 1 --audio-tile 8
+stats mixed --profile typical --legs mixed --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats bench_default --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --check 0 --host-fed-seconds 0
+# the device-packed hand-over under the kernel trace: pack_kernel / pack_gate_kernel / recon_kernel per commit of 64 pictures
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hand_over -o trace -- python $R/tools/hostbench/sweep.py quick > $OUT/trace_hand_over.log 2>&1; echo "stats hand_over rc=$?"
+cd $R
+for f in $(find $OUT/trace_hand_over -name "*kernel_stats.csv" | head -1); do ( echo "# csrc_sha256 $SHA   tools/hostbench/sweep.py quick (64 typical 1080p pictures per commit)"; cat $f ) > $OUT/kernel_stats_hand_over.csv; done
+find $OUT/trace_hand_over -name "*kernel_trace.csv" -delete
+# the N > 1 code on this ONE GPU: eight ranks share it (128 streams each): audio + video + host_fed per rank, cpu_baseline on rank 0
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --share-devices --steps 20 --warmup 5 --streams 128 --audio-streams 32 --host-fed-seconds 1 --cpu-seconds 6 > $OUT/bench_8_ranks_sharing_one_gpu.json 2> $OUT/bench_8_ranks.err; echo "8 ranks rc=$?"
+tail -2 $OUT/bench_8_ranks.err
+# ... and the same launch WITHOUT --share-devices: refused (ranks on one physical GPU), non-zero exit, no line
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 2 --warmup 1 --streams 16 > $OUT/bench_2_ranks_refused.out 2> $OUT/bench_2_ranks_refused.err; echo "2 ranks on one GPU without --share-devices: rc=$?" | tee $OUT/bench_2_ranks_refused.txt
+grep -h "bench.py:" $OUT/bench_2_ranks_refused.err | head -2 >> $OUT/bench_2_ranks_refused.txt
+# ONE 1080p picture per launch (BASELINE config 3 as written): recon_wide_kernel under the kernel trace
+stats single_picture --streams 1 --rgba 1 --profile typical --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 40 --warmup 10
 [ "${2:-}" = quick ] && { ls $OUT; exit 0; }   # (bench line + kernel stats only)
 # PMC
 bash tools/gpu_pmc.sh ${T}/pmc_typical typical --host-fed-seconds 0 --single-stream 0 > $OUT/pmc_typical.log 2>&1; ( echo "# csrc_sha256 $SHA"; cat $OUT/pmc_typical/pmc_summary.txt ) > $OUT/pmc_typical.txt
 bash tools/gpu_pmc.sh ${T}/pmc_dense dense --host-fed-seconds 0 --single-stream 0 > $OUT/pmc_dense.log 2>&1; ( echo "# csrc_sha256 $SHA"; cat $OUT/pmc_dense/pmc_summary.txt ) > $OUT/pmc_dense.txt
+bash tools/gpu_pmc.sh ${T}/pmc_single_picture typical --streams 1 --rgba 1 --steps 40 --warmup 10 --host-fed-seconds 0 --single-stream 0 > $OUT/pmc_single_picture.log 2>&1; ( echo "# csrc_sha256 $SHA   one 1080p picture per launch (recon_wide_kernel)"; cat $OUT/pmc_single_picture/pmc_summary.txt ) > $OUT/pmc_single_picture.txt
 sed -i 's/--cpu-seconds 0 --check 0 --legs ""/--cpu-seconds 0 --check 0 --legs "" --host-fed-seconds 0 --single-stream 0 --audio-tile 1/' tools/gpu_pmc_audio.sh
 bash tools/gpu_pmc_audio.sh ${T}/pmc_audio > $OUT/pmc_audio.log 2>&1; ( echo "# csrc_sha256 $SHA"; cat $OUT/pmc_audio/pmc_summary.txt ) > $OUT/pmc_audio.txt
 # HBM traffic

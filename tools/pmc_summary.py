@@ -12,7 +12,7 @@ for f in sorted(root.rglob("*counter_collection.csv")):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name", "")
-            key = next((k for k in ("recon_kernel", "rgba", "audio_kernel") if k in name), None)
+            key = next((k for k in ("recon_wide_kernel", "recon_kernel", "rgba", "audio_kernel") if k in name), None)
             if key is None:
                 continue
             agg[variant + " " + key][row["Counter_Name"]].append(float(row["Counter_Value"]))
