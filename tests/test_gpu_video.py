@@ -267,12 +267,14 @@ def test_overread_into_next_plane_and_pad(oracle, hip_ctx):
     dut.close()
 
 
-@pytest.mark.parametrize("n_streams", [64, 86, 87, 128])
+@pytest.mark.parametrize("n_streams", [24, 25, 64, 86, 87, 128])
 def test_many_streams_replicated_batch(oracle, hip_ctx, n_streams):
     """BASELINE config 5 in miniature: independent streams, one descriptor set each, no cross-talk.
     Property: identical inputs => identical FNV-1a-64 per stream, equal to the oracle's.
-    (A SIF picture is 83 chunks: on a 256-CU part 86 streams = 7 138 chunks still run one chunk per wave, 87 = 7 221 take the
-    two-chunk instances — launch_batch; a last wave with a single chunk at odd totals.)"""
+    (A SIF picture is 83 chunks: on a 256-CU part 24 streams = 1 992 chunks are the last launch recon_wide_kernel takes — four
+    waves per chunk still fit the 8 192 wave slots —, 25 = 2 075 the first one back on recon_kernel; 86 streams = 7 138 chunks
+    still run one chunk per wave, 87 = 7 221 take the two-chunk instances — launch_batch; a last wave with a single chunk at odd
+    totals.)"""
     w, h = 352, 240
     seq = synth.generate_sequence(w, h, 6, seed=21)
     ref, dut = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h, n_streams)
