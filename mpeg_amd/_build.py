@@ -26,8 +26,13 @@ LIBMPEGHOST = ROOT / "mpeg_amd" / "libmpeghost.so"
 # control flow: boolean flags in SGPR pairs, `s_andn2_b64 vcc, exec, flag; s_cbranch_vccnz` in the place of `s_cmp; s_cbranch_scc`.
 # Same sources, interleaved on one box (profiles/round5_a_ab_structurizer_skips_uniform_regions.txt): scalar instructions per wave
 # 349 -> 319, typical 0.621 -> 0.633 of the roofline, dense 0.550 -> 0.561, bit-exact.
+# -amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism first (its default weighs register
+# pressure first).  With the round-5 kernel: typical +0.3 ... 0.6 % in six of six interleaved rounds on two boxes, dense +0.1 ... 0.4 %,
+# audio and the one-picture launch within noise (profiles/round5_j_ab_scheduler_strategies.txt); register counts rise (the int16-tile instance 49 -> 57,
+# the audio kernel 70 -> 80) without costing a resident wave.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm",
-               "-amdgpu-kernarg-preload-count=14", "-mllvm", "-structurizecfg-skip-uniform-regions", "-fPIC", "-shared"]
+               "-amdgpu-kernarg-preload-count=14", "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm",
+               "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared"]
 
 
 def _newer(target: Path, sources) -> bool:
