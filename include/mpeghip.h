@@ -133,8 +133,11 @@ int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream,
 /* Tuning knob: which instance of the reconstruction kernel a submit / batch of this handle runs on.  The library picks
  * per batch (AUTO): batches with more than two thirds of their coded blocks dense (more than 32 non-zero
  * levels) take the instance that is built for vector-ALU-bound work (int32 coefficient tile, 7 waves per SIMD); the others
- * the one built for latency-bound work (int16 tile, 8 waves per SIMD).  Results are identical bit for bit either way; the
- * override exists for measurements (bench.py --tile) and for callers who know their streams.  No reference counterpart. */
+ * the one built for latency-bound work (int16 tile, 8 waves per SIMD); and a launch small enough to leave most of the device
+ * empty (one 1080p picture) runs on a third kernel that puts four waves on every chunk of 4 macroblocks (recon_wide_kernel: the
+ * launch lasts one chunk's chain of dependent steps, which four waves walk in parallel).  Results are identical bit for bit
+ * either way; the override pins one of the two instances at any size and exists for measurements (bench.py --tile) and for
+ * callers who know their streams.  No reference counterpart. */
 #define MPEGHIP_TILE_AUTO  0
 #define MPEGHIP_TILE_INT16 1
 #define MPEGHIP_TILE_INT32 2
