@@ -207,6 +207,15 @@ def test_abi_rejects_macroblocks_addressed_twice(hip_ctx):
     st.close()
 
 
+def test_abi_refuses_more_streams_than_a_chunk_header_can_name(hip_ctx):
+    """The device format keeps a chunk's stream index in 19 bits of a header dword (video_recon_lane.h: kRcMaxStreams): a frame
+    store of more streams is refused when it is opened — before anything is allocated —, not mis-addressed later."""
+    with pytest.raises(abi.MpegHipError) as ei:
+        abi.VideoStore(hip_ctx, 16, 16, (1 << 19) + 1)
+    assert ei.value.code == abi.ERR_INVALID and "streams" in str(ei.value)
+    abi.VideoStore(hip_ctx, 16, 16, 4096).close()      # (many small streams are fine)
+
+
 def test_abi_rejects_dependent_pictures_and_self_prediction(hip_ctx):
     """Two pictures of one stream in one submit must not depend on each other (one's cur is the other's cur / fwd / bwd);
     a macroblock must not predict from the slot its picture writes.  Different streams may share slot numbers."""
