@@ -252,6 +252,18 @@ def test_golden_and_written_streams_through_the_parser_and_the_device_packer(ora
         assert h == [VIDEO_HASH] * 4 and n == [260] * 4, device_pack
 
 
+def test_the_damaged_golden_stream_on_recon_kernel_too(oracle, golden_dir, device):
+    """A few streams of 160x120 are launches of a few dozen chunks, which the library gives to recon_wide_kernel; 112 lockstep
+    copies of the damaged golden stream are 2 240 chunks per tick — more than four waves per chunk fit — so that ITS snapshot
+    blocks, invalid intra blocks, chunks that are not runs and re-submits run through recon_kernel's one-wave-per-chunk instances
+    as well (both hand-overs).  Every stream: the reference's hash."""
+    from test_host_batch import VIDEO_HASH, run_batch
+    es = (golden_dir / "test.mpeg1video").read_bytes()
+    for device_pack in (True, False):
+        h, n, c = run_batch(oracle, [es] * 112, [0] * 112, device=device, threads=4, device_pack=device_pack)
+        assert h == [VIDEO_HASH] * 112 and n == [260] * 112, device_pack
+
+
 def test_config5_shard_device_packed(oracle, hip_ctx):
     """One picture for each of 256 1080p streams per commit, staged from 8 threads and packed on the device: a GOP's worth,
     every stream x slot against the oracle by device-side hash."""

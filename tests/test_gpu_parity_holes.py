@@ -102,8 +102,11 @@ def test_set_no_delay_on_gpu(oracle, golden_dir, device, name):
     assert n in (261, 279)    # no-delay returns every picture, also the one the delayed mode holds back (260 / 278 + 1)
 
 
-def test_reference_copy_macroblock_sweep_on_gpu(oracle, hip_ctx):
-    """The reference's own motion-compensation sweep (video_test.go:63-103 runParitySweep): 64x64 pattern frames,
+@pytest.mark.parametrize("policy", [0, 1], ids=["auto_wide_kernel", "pinned_int16_recon_kernel"])
+def test_reference_copy_macroblock_sweep_on_gpu(oracle, hip_ctx, policy):
+    """(Both kernels: one macroblock per submit is the smallest launch there is, which the library gives to recon_wide_kernel; with
+    the instance pinned the same sweep runs through recon_kernel — incl. its gathered windows that leave their plane.)
+    The reference's own motion-compensation sweep (video_test.go:63-103 runParitySweep): 64x64 pattern frames,
     macroblock (row, col) in {1,2}^2, vectors in [-3,3]^2 — covers all four half-pel modes and the negative odd chroma
     rounding — through the HIP path (write_planes + one inter macroblock per submit), against the oracle's restatement
     of the reference's scalar copyMacroblockRef (video_test.go:10-43)."""
@@ -119,6 +122,7 @@ def test_reference_copy_macroblock_sweep_on_gpu(oracle, hip_ctx):
     src = square(1)
     sy, scb, scr = oracle.frame_planes(src)
     dut = abi.VideoStore(hip_ctx, w, h)
+    dut.set_tile_policy(policy)
     dut.write_planes(0, 1, sy, scb, scr)
     blank = square(0)
     background = [p.copy() for p in oracle.frame_planes(blank)]

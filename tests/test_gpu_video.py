@@ -21,9 +21,12 @@ pytestmark = pytest.mark.gpu
     (1920, 1080, 2, "dense", 0.0, False),
     (1920, 1080, 2, "dense", 0.0, True),      # BASELINE config 3's worst case: dense + fused RGBA at 1080p
 ])
-def test_reconstruction_bit_exact(oracle, hip_ctx, w, h, n, profile, raw, rgba):
+@pytest.mark.parametrize("policy", [0, 1], ids=["auto", "pinned_int16"])
+def test_reconstruction_bit_exact(oracle, hip_ctx, w, h, n, profile, raw, rgba, policy):
+    """(policy 0: the library's choice — recon_wide_kernel for these one-picture launches; 1: recon_kernel's int16-tile instance)"""
     seq = synth.generate_sequence(w, h, n, profile=profile, raw_fraction=raw, rgba=rgba)
     ref, dut = oracle.OracleStore(w, h, threads=4), abi.VideoStore(hip_ctx, w, h)
+    dut.set_tile_policy(policy)
     try:
         run_and_compare(ref, dut, seq, check_rgba=rgba)
     finally:
