@@ -37,11 +37,11 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MB_PER_1080P30_STREAM = 8160 * 30
-KERNEL = {False: "recon_kernel<1, false, T, N> (a wave reconstructs N chunks of 4 macroblocks; sparse coefficient entries, prediction windows "
-                 "by direct-to-LDS loads, records that carry their own address arithmetic; T: int16 tile / 8 waves per SIMD, N = 1 for typical "
-                 "batches; int32 tile / 7, N = 2 for batches of dense units); launches that leave the wave slots empty (one picture) run "
+KERNEL = {False: "recon_kernel<1, false, T> (a wave reconstructs one chunk of 4 macroblocks; sparse coefficient entries, prediction windows "
+                 "by direct-to-LDS loads, records that carry their own address arithmetic; T: int16 tile / 8 waves per SIMD for typical "
+                 "batches; int32 tile / 7 for batches of dense units); launches that leave the wave slots empty (one or two pictures) run "
                  "recon_wide_kernel: four waves per chunk",
-          True: "recon_kernel<1, true, T, N> / recon_wide_kernel<true> (the instances with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
+          True: "recon_kernel<1, true, T> / recon_wide_kernel<true> (the instances with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
 def parse_args():

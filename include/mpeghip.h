@@ -134,7 +134,7 @@ int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream,
  * per batch (AUTO): batches with more than two thirds of their coded blocks dense (more than 32 non-zero
  * levels) take the instance that is built for vector-ALU-bound work (int32 coefficient tile, 7 waves per SIMD); the others
  * the one built for latency-bound work (int16 tile, 8 waves per SIMD); and a launch small enough to leave most of the device
- * empty (one 1080p picture) runs on a third kernel that puts four waves on every chunk of 4 macroblocks (recon_wide_kernel: the
+ * empty (one or two 1080p pictures) runs on a third kernel that puts four waves on every chunk of 4 macroblocks (recon_wide_kernel: the
  * launch lasts one chunk's chain of dependent steps, which four waves walk in parallel).  Results are identical bit for bit
  * either way; the override pins one of the two instances at any size and exists for measurements (bench.py --tile) and for
  * callers who know their streams.  No reference counterpart. */

@@ -58,13 +58,11 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k)
 #endif
 
-// Chunks per wave (kPerWave; launch_batch picks the instance).  TWO consecutive chunks in the int32-tile instance where the
-// launch has more waves than the device has slots for: the second header arrives with the first, and the ~1 800 clocks a
-// slot stays empty between two waves are paid half as often (profiles/r4k_ab_two_chunks_per_wave.txt; dense +1.4 %,
-// r31).  ONE where every wave is resident from the start — a single picture: the launch then lasts one chunk's latency,
-// not two (profiles/r27_ab_one_chunk_per_wave_for_single_pictures.txt) — and in the int16-tile instance at any size: its
-// eighth wave per SIMD covers the hand-over, and with one header it keeps every scalar in a register (r31: +1.0 %).
-// (As a launch argument instead of a template parameter the choice cost the 1024-stream legs 0.3 %: r27.)
+// Chunks per wave: ONE.  Rounds 3 - 4 ran two consecutive chunks per wave in the int32-tile instance when a launch had more waves
+// than the device has slots (the second header arrived with the first, the hand-over between two workgroups was paid half as
+// often: dense +1.4 % then).  With round 5's prologue that no longer pays at any size — 1024 pictures per launch: within 0.2 %,
+// with Frame.RGBA fused 1 - 1.5 % SLOWER; 4 - 16 pictures per launch: 8 - 18 % slower, the launch lasts two chunks' chains with
+// half the waves (profiles/round5_k_ab_chunks_per_wave_by_launch_size.txt) — and the second form is gone.
 #ifndef MPG_CHUNK_AHEAD
 #define MPG_CHUNK_AHEAD 256 // chunks; 0 = off (profiles/r3f_ab_chunk_pull_ahead.txt: 64 / 256 / 1024)
 #endif
@@ -72,7 +70,7 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 // -mllvm -amdgpu-kernarg-preload-count=14 (mpeg_amd/_build.py) they arrive in SGPRs with the wave instead of through three
 // dependent rounds of scalar loads (grid size -> chunk count -> chunk pointer), and the grid size is an argument because the
 // hidden one cannot be preloaded.  profiles/r34_ab_kernarg_preload.txt: typical +0.75 %, one picture 10.15 -> 9.86 us.
-template <int WAVES, bool kRgba, bool kT16, int kPerWave>
+template <int WAVES, bool kRgba, bool kT16>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(
     const uint32_t grid8, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
     uint8_t *const frames_b, const uint32_t mb_w, const uint32_t luma_bytes, uint8_t *const rgba, const uint64_t rgba_stride,
@@ -109,12 +107,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     constexpr int kLdsBytes = rc_lds_bytes<kT16>();
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[WAVES * kLdsBytes];
     const int lane_all = (int)threadIdx.x;
-    // a wave takes kPerWave consecutive chunks, one after the other: the second one's header is loaded with the first one's, and
-    // the workgroup hand-over (a wave slot stays empty for ~1 800 clocks between two waves) is paid once.  (PERSISTENT waves —
-    // as many one-wave workgroups as the device has slots, each taking chunk after chunk of its XCD's range from ticket
-    // counters, in order — fill every slot all the time and are 4 - 8 % SLOWER: profiles/round5_d_ab_persistent_waves.txt.)
-    constexpr uint32_t per_wave = kPerWave;
-    static_assert(kPerWave == 1 || kPerWave == 2, "written out for one or two");
+    // (PERSISTENT waves — as many one-wave workgroups as the device has slots, each taking chunk after chunk of its XCD's range from
+    // ticket counters, in order — fill every slot all the time and are 4 - 8 % SLOWER: profiles/round5_d_ab_persistent_waves.txt.)
     uint8_t *lds = lds_all;
     int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);   // the int32 tile ...
     int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt); // ... or the int16 one (kT16)
@@ -129,8 +123,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
 #ifdef MPG_PHASE_TIMING
     if (n_blocks > 24) // (never: makes the stamp wait for the chunk)
         return;
-    if (kPerWave == 2) // (a wave's second chunk starts here: its header has long arrived)
-        MPG_STAMP(0);
 #endif
     MPG_STAMP(1);
     const uint32_t *const wbase = rc_word_base(a, c); // the chunk's block words; its entries n_blocks dwords further on
@@ -354,15 +346,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     }
 #endif
     };
-    // pull the chunk(s) a later wave of this XCD's range will take towards L2 (a chunk is one 128-byte line) so that that wave's
+    // pull the chunk a later wave of this XCD's range will take towards L2 (a chunk is one 128-byte line) so that that wave's
     // scalar loads find them there; nothing is done with the data.  (Also pulling those chunks' first words, by a dependent
     // load once the header is here, gains nothing: profiles/r3g_ab_pull_ahead_distance_and_words.txt.)
     auto pull_ahead = [&](uint32_t first, uint32_t end) {
 #if MPG_CHUNK_AHEAD
-        const uint32_t step = first + MPG_CHUNK_AHEAD * per_wave + per_wave <= end ? MPG_CHUNK_AHEAD * per_wave * kRcChunkDwords * 4 : 0u;
-        const uint32_t line = per_wave == 2 ? ((uint32_t)lane_all & 1u) * (kRcChunkDwords * 4) : 0u;
-        ahead = load32_uncounted(reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.chunks) + first * (kRcChunkDwords * 4)),
-                                 step + line);
+        const uint32_t step = first + MPG_CHUNK_AHEAD + 1 <= end ? MPG_CHUNK_AHEAD * kRcChunkDwords * 4 : 0u;
+        ahead = load32_uncounted(reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.chunks) + first * (kRcChunkDwords * 4)), step);
         ahead_pending = true;
 #else
         (void)first;
@@ -371,19 +361,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     };
     // XCD-aware remap (block b runs on XCD b % 8; each XCD has its own L2): every XCD gets one contiguous range of chunks.  The
     // grid is a multiple of 8 (launch_batch rounds it up: at most 7 waves find nothing to do), so the map is a multiply-add.
-    const uint32_t first = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8) * per_wave);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8));
     if (first >= a.n_chunks)
         return;
     pull_ahead(first, a.n_chunks);
-    // step 1: one round of scalar loads (all of the wave's chunks), then per chunk its vector loads
-    const bool second = per_wave == 2 && first + 1 < a.n_chunks; // (written out for one or two)
+    // step 1: one round of scalar loads (the chunk), then its vector loads
     const RcChunk c0 = rc_load_chunk(a, first);
-    const RcChunk c1 = rc_load_chunk(a, second ? first + 1 : first);
     one_chunk(c0, first);
-    if (second) {
-        wave_lds_handoff(); // (the previous chunk's stores have read its output bytes)
-        one_chunk(c1, first + 1);
-    }
 }
 #undef MPG_STAMP
 
@@ -1724,20 +1708,17 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     hipStream_t st = v->ctx->stream;
     // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches of dense units are bound by vector-ALU
     // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); everything else is bound by per-wave
-    // latency and wants the eighth wave (int16 tile) — with Frame.RGBA fused as well, since that instance runs one chunk
-    // per wave (r42: fused typical +1.2 %).  The switch-over: the measured crossover of the two (kDenseShareNum /
+    // latency and wants the eighth wave (int16 tile), with Frame.RGBA fused as well.  The switch-over: the measured crossover of the two (kDenseShareNum /
     // kDenseShareDen above).
     bool t16 = b->dense_blocks * kDenseShareDen <= b->coded_blocks * kDenseShareNum;
     if (v->tile_policy != MPEGHIP_TILE_AUTO)
         t16 = v->tile_policy == MPEGHIP_TILE_INT16;
-    // Chunks per wave: one where all of the launch's waves are resident at once (7 waves per SIMD: either instance), and one
-    // for the int16-tile instance at any size — at 8 waves per SIMD the hand-over between waves is covered, and the one-chunk
-    // form needs 49 vector and 60 scalar registers where two chunks spill scalars to lanes (+1.0 % in eight of eight rounds,
-    // profiles/r31_ab_chunks_per_wave_by_instance.txt); two for the int32-tile instance (dense +1.4 % with two).
-    const uint64_t wave_slots = (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 7;
-    // A launch that leaves most slots empty — four waves per chunk still fit — goes to recon_wide_kernel: its duration is one chunk's
-    // chain, which four waves walk in parallel.  (Only when the library picks: a pinned policy names recon_kernel's instances.)
-    if (v->tile_policy == MPEGHIP_TILE_AUTO && a.n_chunks * 4 <= (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 8) {
+    // A launch that leaves most slots empty goes to recon_wide_kernel, four waves per chunk: its duration is one chunk's chain, which
+    // four waves walk in parallel.  Measured against recon_kernel for launches of 1 .. 16 1080p pictures
+    // (profiles/round5_k_ab_wide_kernel_by_launch_size.txt): ahead for one and two pictures (-27 % / -9 .. -15 % typical, -25 % /
+    // -3 .. -5 % dense), behind from three on — so up to twice the device's wave slots.  (Only when the library picks: a pinned
+    // policy names recon_kernel's instances.)
+    if (v->tile_policy == MPEGHIP_TILE_AUTO && a.n_chunks * 4 <= (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 8 * 2) {
         const uint32_t g8 = (a.n_chunks + 7) / 8;
         if (b->any_rgba)
             hipLaunchKernelGGL((recon_wide_kernel<true>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat, a.frames_b,
@@ -1748,28 +1729,23 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
         HIP_TRY(hipGetLastError());
         return finish_rgba_bookkeeping(v, b, a);
     }
-    const uint32_t per_wave = (t16 || a.n_chunks <= wave_slots) ? 1 : 2;
-    // (a multiple of 8 workgroups: the kernel's XCD remap is then a multiply-add; the at most 7 surplus waves return at once)
-    const uint32_t grid8 = ((a.n_chunks + kReconWaves * per_wave - 1) / (kReconWaves * per_wave) + 7) / 8;
+    // One chunk per wave (the comment at recon_kernel).  A multiple of 8 workgroups: the kernel's XCD remap is then a multiply-add;
+    // the at most 7 surplus waves return at once.
+    const uint32_t grid8 = ((a.n_chunks + kReconWaves - 1) / kReconWaves + 7) / 8;
     const uint32_t grid = grid8 * 8;
-#define LAUNCH_RECON(RGBA, T16, PER_WAVE) \
-    hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16, PER_WAVE>), dim3(grid), dim3(kReconWaves * 64), 0, st, grid8, a.n_chunks, a.chunks, \
-                       a.words, a.qmat, a.frames_b, a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height)
+#define LAUNCH_RECON(RGBA, T16) \
+    hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16>), dim3(grid), dim3(kReconWaves * 64), 0, st, grid8, a.n_chunks, a.chunks, a.words, \
+                       a.qmat, a.frames_b, a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height)
     if (t16) {
         if (b->any_rgba)
-            LAUNCH_RECON(true, true, 1);
+            LAUNCH_RECON(true, true);
         else
-            LAUNCH_RECON(false, true, 1);
-    } else if (per_wave == 1) {
-        if (b->any_rgba)
-            LAUNCH_RECON(true, false, 1);
-        else
-            LAUNCH_RECON(false, false, 1);
+            LAUNCH_RECON(false, true);
     } else {
         if (b->any_rgba)
-            LAUNCH_RECON(true, false, 2);
+            LAUNCH_RECON(true, false);
         else
-            LAUNCH_RECON(false, false, 2);
+            LAUNCH_RECON(false, false);
     }
 #undef LAUNCH_RECON
     HIP_TRY(hipGetLastError());
