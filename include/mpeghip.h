@@ -131,7 +131,7 @@ int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream,
                             const uint8_t intra[64], const uint8_t non_intra[64]);
 
 /* Tuning knob: which instance of the reconstruction kernel a submit / batch of this handle runs on.  The library picks
- * per batch (AUTO): batches with more than two thirds of their coded blocks dense (more than 32 non-zero
+ * per batch (AUTO): batches with more than a third of their coded blocks dense (more than 32 non-zero
  * levels) take the instance that is built for vector-ALU-bound work (int32 coefficient tile, 7 waves per SIMD); the others
  * the one built for latency-bound work (int16 tile, 8 waves per SIMD); and a launch small enough to leave most of the device
  * empty (one or two 1080p pictures) runs on a third kernel that puts four waves on every chunk of 4 macroblocks (recon_wide_kernel: the

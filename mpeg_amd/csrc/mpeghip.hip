@@ -1636,14 +1636,15 @@ static int reap_all(mpeghip_video *v)
     return reap_verdict(&v->staging[v->next_staging ^ 1]);
 }
 
-// Which instance of the reconstruction kernel a batch runs on: the int32-tile one when more than two thirds of its coded blocks
-// are dense units.  Measured (profiles/round4_c_dense_share_crossover.txt: 256 1080p streams at their own GOP phases, a share of
-// them with dense content, both instances interleaved on one box): dense block share 0.01 / 0.41 / 0.68 / 0.86 / 1.00 ->
-// int16 +3.2 % / int16 +1.7 % / tie / int32 +1.6 % / int32 +1.9 %.  (Rounds 2-3 switched at a quarter: a guess between the
-// two measured ends, on the wrong side of the 0.41 point.)  A device-packed commit, whose blocks the host has not looked
-// at, goes by its input dwords per macroblock: the same sweep's 24 / 116 / 207 / 299 / 390.
-constexpr uint64_t kDenseWordsPerMb = 210;
-constexpr uint64_t kDenseShareNum = 2, kDenseShareDen = 3;
+// Which instance of the reconstruction kernel a batch runs on: the int32-tile one when more than ONE THIRD of its coded blocks are
+// dense units.  Measured (profiles/round5_l_dense_share_crossover.txt: 256 1080p streams at their own GOP phases, a share of them
+// with dense content, both instances interleaved on one box): dense block share 0.01 / 0.13 / 0.24 / 0.33 / 0.41 / 0.49 / 0.56 /
+// 0.68 / 1.00 -> int16 +5.9 % / +4.8 % / +2.5 % / tie / int32 +0.9 % / +1.8 % / +2.8 % / +5.0 % / +11.4 %.  (Round 4 had measured
+// the tie at two thirds, profiles/round4_c_*: round 5's dense-unit loads and staged dequantisation sped the int32-tile instance
+// up by more than the int16-tile one.)  A device-packed commit, whose blocks the host has not looked at, goes by its input dwords
+// per macroblock: the same sweep's 24 / 47 / 70 / 93 / 116 / 139 / 162 / 207 / 390.
+constexpr uint64_t kDenseWordsPerMb = 93;
+constexpr uint64_t kDenseShareNum = 1, kDenseShareDen = 3;
 constexpr int kReconWaves = 1; // waves (= chunks) per workgroup: waves of a workgroup that finish early keep their slots until the
                                // last one has (its LDS goes back as a whole) — 1 beats 2 beats 4 (profiles/r2w_ab_waves_per_workgroup.txt)
 

@@ -20,9 +20,10 @@ from . import desc, synth
 
 class MixedWorkload:
     def __init__(self, width: int, height: int, n_streams: int, gop: int = 13, n_seeds: int = 16, dense_share: float = 0.0,
-                 rgba: bool = False, seed0: int = 0x4D58, threads: int = 8):
+                 rgba: bool = False, seed0: int = 0x4D58, threads: int = 8, dense_den: int = 4):
         self.w, self.h, self.n, self.gop, self.n_seeds = width, height, n_streams, gop, n_seeds
-        self.dense_quarters = int(round(dense_share * 4))       # streams with s % 4 < dense_quarters are dense
+        self.dense_den = dense_den                                      # streams with s % dense_den < dense_quarters are dense
+        self.dense_quarters = int(round(dense_share * dense_den))       # ("quarters": dense_den = 4 everywhere but in the fine sweep)
         kinds = [("typical", j) for j in range(n_seeds)]
         if self.dense_quarters:
             kinds += [("dense", j) for j in range(min(n_seeds, 2))]   # (dense pictures are 2.5 MB of units each: two seeds)
@@ -33,8 +34,8 @@ class MixedWorkload:
 
     def combo(self, s: int):
         """(profile, seed, phase) of stream s."""
-        if self.dense_quarters and s % 4 < self.dense_quarters:
-            return ("dense", (s // 4) % min(self.n_seeds, 2), s % self.gop)
+        if self.dense_quarters and s % self.dense_den < self.dense_quarters:
+            return ("dense", (s // self.dense_den) % min(self.n_seeds, 2), s % self.gop)
         return ("typical", s % self.n_seeds, s % self.gop)
 
     def picture(self, s: int, t: int):

@@ -5,7 +5,7 @@ Launches in which a share of the STREAMS carries the dense worst-case content (e
 typical content, all at their own GOP phases (mpeg_amd/mixed.py), timed on the int16-tile instance and on the int32-tile one,
 interleaved on one box (mpeghip_video_set_tile_policy).  Prints, per share: the batch's share of dense BLOCKS (what
 launch_batch looks at), its sparse-form dwords per macroblock (what a device-packed commit looks at), ms per step on either
-instance.   python tools/sweep_dense_share.py [streams] > profiles/round4_c_dense_share_crossover.txt"""
+instance.   python tools/sweep_dense_share.py [streams [share of dense streams in per cent ...]] > profiles/round4_c_dense_share_crossover.txt"""
 import sys
 import time
 from pathlib import Path
@@ -21,9 +21,8 @@ W, H, GOP, ROUNDS, REPS = 1920, 1080, 4, 3, 6
 ctx = abi.Context(0)
 print("# %d streams of %dx%d, GOP of %d (I P B B), stream s at phase s mod %d; a step = one picture per stream = one launch" % (streams, W, H, GOP, GOP))
 print("# %-12s %-18s %-16s %-14s %-14s %s" % ("dense streams", "dense block share", "dwords per mb", "int16 ms/step", "int32 ms/step", "faster"))
-for quarters in (0, 1, 2, 3, 4):
-    share = quarters / 4
-    wl = mixed.MixedWorkload(W, H, streams, gop=GOP, n_seeds=4, dense_share=share, threads=8)
+for share in ([float(x) / 100 for x in sys.argv[2:]] or [0.0, 0.25, 0.5, 0.75, 1.0]):
+    wl = mixed.MixedWorkload(W, H, streams, gop=GOP, n_seeds=4, dense_share=share, threads=8, dense_den=16)
     store = abi.VideoStore(ctx, W, H, streams)
     batches, blocks, dense_blocks, words, mbs = [], 0, 0, 0, 0
     for t in range(GOP):
@@ -51,7 +50,7 @@ for quarters in (0, 1, 2, 3, 4):
                     batches[t].run()
             ms[policy].append(ctx.timer_stop_ms() / (REPS * GOP))
     a, b = float(np.median(ms[1])), float(np.median(ms[2]))
-    print("  %-12s %-18.3f %-16.1f %-14.4f %-14.4f %s (%+.1f %%)" % ("%d %%" % (share * 100), dense_blocks / blocks, words / mbs, a, b,
+    print("  %-12s %-18.3f %-16.1f %-14.4f %-14.4f %s (%+.1f %%)" % ("%.4g %%" % (share * 100), dense_blocks / blocks, words / mbs, a, b,
                                                                   "int16" if a < b else "int32", (max(a, b) / min(a, b) - 1) * 100), flush=True)
     for x in batches:
         x.free()
