@@ -11,6 +11,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k(uint32_t *out, int 
     uint32_t sb = seed * 5u, sc = seed * 7u + 1u; // wave-uniform: scalar registers
     uint64_t mask = 0x5555555555555555ull * seed, mask2 = 0;
     for (int i = 0; i < 8; i++) a[i] = seed + i * 7 + threadIdx.x;
+    if (KIND == 3 || KIND == 35 || KIND == 50 || KIND >= 56) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\ts_mov_b64 s[20:21], vcc" : : "v"(b), "v"(c) : "vcc", "s20", "s21");
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -48,6 +49,42 @@ template <int KIND> __global__ __launch_bounds__(256) void k(uint32_t *out, int 
                 if (KIND == 29) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (KIND == 30) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(a[i]));
                 if (KIND == 31) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                // round 5: what decides between the two rates — the encoding, a scalar source, a literal, DPP?
+                if (KIND == 32) asm volatile("v_and_b32 %0, 0x00ff00ff, %0" : "+v"(a[i]));
+                if (KIND == 33) asm volatile("v_add_u32 %0, 5, %0" : "+v"(a[i]));
+                if (KIND == 34) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+                if (KIND == 35) asm volatile("v_cndmask_b32_dpp %0, %0, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+                if (KIND == 36) asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+                if (KIND == 37) asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(a[i]) : "s"(sc), "v"(b));
+                if (KIND == 38) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "s"(sc));
+                if (KIND == 39) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(a[i]) : "s"(sc));
+                if (KIND == 40) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(a[i]));
+                if (KIND == 41) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 42) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 43) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 44) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+                if (KIND == 45) asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 46) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 47) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 48) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 49) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 50) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                if (KIND == 51) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 52) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7])); // (a second changing source)
+                if (KIND == 53) asm volatile("v_lshrrev_b64 %0, 8, %0" : "+v"(*(uint64_t *)&a[i & 6]));
+                if (KIND == 56) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                if (KIND == 57) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (KIND == 58) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 59) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20", "s21");
+                // ... one select among seven additions: is the VOP2 select's cost additive in a mix?
+                if (KIND >= 60 && KIND <= 64 && i != 3) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 60 && i == 3) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                if (KIND == 61 && i == 3) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                if (KIND == 62 && i == 3) asm volatile("v_cndmask_b32_dpp %0, %0, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+                if (KIND == 63 && i == 3) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+                if (KIND == 64 && i == 3) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (KIND == 54) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a[i]) : "s"(sc), "v"(b));
+                if (KIND == 55) asm volatile("v_mad_i32_i24 %0, %0, %1, 1" : "+v"(a[i]) : "v"(b));
             }
         }
     }
@@ -85,5 +122,16 @@ int main()
     run<18>("v_sat_pk_u8_i16", out, cus, ghz); run<28>("v_cvt_pk_i16_i32", out, cus, ghz); run<19>("v_add3_u32", out, cus, ghz);
     run<20>("v_lshl_add_u32", out, cus, ghz); run<21>("v_cmp_lt_i32_e64", out, cus, ghz); run<22>("v_mul_i24_sdwa", out, cus, ghz);
     run<23>("v_bfe_u32", out, cus, ghz); run<24>("v_lshl_add_u64", out, cus, ghz); run<29>("v_bitop3_b32", out, cus, ghz);
+    run<32>("v_and_b32 literal", out, cus, ghz); run<33>("v_add_u32 inline", out, cus, ghz); run<40>("v_add_u32 literal", out, cus, ghz);
+    run<38>("v_and_b32 s,v", out, cus, ghz); run<39>("v_lshlrev_b32 s,v", out, cus, ghz); run<49>("v_add_u32_e64", out, cus, ghz);
+    run<34>("v_mov_b32_dpp", out, cus, ghz); run<35>("v_cndmask_dpp", out, cus, ghz); run<36>("v_add_u32_dpp", out, cus, ghz);
+    run<50>("v_cndmask_e32 vcc", out, cus, ghz); run<37>("v_mad_u32_u16 s", out, cus, ghz); run<41>("v_max_i32", out, cus, ghz);
+    run<42>("v_or_b32", out, cus, ghz); run<43>("v_mul_u32_u24", out, cus, ghz); run<44>("v_cmp_lt_u32_e32", out, cus, ghz);
+    run<45>("v_lshl_or_b32", out, cus, ghz); run<46>("v_and_or_b32", out, cus, ghz); run<47>("v_pk_mad_i16", out, cus, ghz);
+    run<48>("v_alignbit_b32", out, cus, ghz); run<51>("v_bfi_b32", out, cus, ghz); run<52>("v_sub_u32 2 srcs", out, cus, ghz);
+    run<53>("v_lshrrev_b64", out, cus, ghz); run<56>("v_cndmask_e64 vcc", out, cus, ghz); run<57>("v_addc_co_u32 vcc", out, cus, ghz); run<58>("v_cndmask d!=s vcc", out, cus, ghz); run<59>("v_cndmask_e64 s[20:21]", out, cus, ghz);
+    run<64>("8 v_add_u32", out, cus, ghz); run<60>("7 add + cndmask_e32", out, cus, ghz); run<61>("7 add + cndmask_e64", out, cus, ghz);
+    run<62>("7 add + cndmask_dpp", out, cus, ghz); run<63>("7 add + mov_dpp", out, cus, ghz);
+    run<54>("v_mad_i24 v,s,v", out, cus, ghz); run<55>("v_mad_i24 +inline", out, cus, ghz);
     return 0;
 }
