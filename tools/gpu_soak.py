@@ -1,0 +1,83 @@
+"""Randomised differential soak of the reconstruction path on the GPU: seeded (geometry, content, picture types, snapshot
+share, fused RGBA, kernel policy, hand-over form: dense units / sparse words packed on the host / sparse words packed on the device) cases beyond the fixed parametrisations of tests/, every picture of every case compared with
+the oracle on all three slots (and the RGBA image when fused) through the C ABI.  Test infrastructure: the oracle is the checker.
+usage: python tools/gpu_soak.py [seconds] [master seed]   -> one summary line per 25 cases, exit status 1 on any mismatch"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    master = int(sys.argv[2]) if len(sys.argv) > 2 else 20260928
+    from mpeg_amd import abi, desc, synth
+    from oracle import pyoracle
+    from parity import run_and_compare
+
+    class Via:
+        """the device store behind one of the three hand-over forms"""
+        def __init__(self, store, form):
+            self.store, self.form = store, form
+            self.read_planes, self.read_rgba = store.read_planes, store.read_rgba
+
+        def submit(self, pics, mbs, coefs):
+            if self.form == 0:
+                return self.store.submit(pics, mbs, coefs)
+            m, w = desc.to_sparse(mbs, coefs)
+            if self.form == 1:
+                return self.store.submit_sparse(pics[0], m, w)
+            return self.store.submit_staged_device([(pics[0], m, w)], mapped=bool(len(m) & 1))
+
+    ctx = abi.Context(0)
+    rng = np.random.default_rng(master)
+    t0 = time.time()
+    cases = pictures = mbs = 0
+    by_policy = {0: 0, 1: 0, 2: 0}
+    by_form = {0: 0, 1: 0, 2: 0}
+    while time.time() - t0 < budget:
+        big = rng.random() < 0.08
+        w = int(rng.integers(16, 1921 if big else 420))
+        h = int(rng.integers(16, 1089 if big else 300))
+        n = int(rng.integers(2, 4 if big else 9))
+        profile = "dense" if rng.random() < 0.3 else "typical"
+        raw = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
+        rgba = bool(rng.random() < 0.5)
+        policy = int(rng.integers(0, 3))
+        form = int(rng.integers(0, 3))
+        seed = int(rng.integers(1, 1 << 30))
+        types = None
+        if rng.random() < 0.5:  # any order of picture types behind the leading I picture (B pictures need two anchors)
+            types = [1, 2] + [int(x) for x in rng.choice([1, 2, 3], size=n)]
+        seq = synth.generate_sequence(w, h, n, seed=seed, profile=profile, raw_fraction=raw, rgba=rgba, types=types)
+        ref, dut = pyoracle.OracleStore(w, h, threads=4), abi.VideoStore(ctx, w, h)
+        dut.set_tile_policy(policy)
+        try:
+            run_and_compare(ref, Via(dut, form), seq, check_rgba=rgba)
+        except AssertionError as e:
+            print("MISMATCH: w=%d h=%d n=%d profile=%s raw=%.2f rgba=%d policy=%d form=%d seed=%d types=%s: %s" % (w, h, n, profile, raw, rgba, policy, form, seed, types, e))
+            sys.exit(1)
+        finally:
+            dut.close()
+            ref.close()
+        cases += 1
+        pictures += len(seq)
+        mbs += sum(len(s.mbs) for s in seq)
+        by_policy[policy] += 1
+        by_form[form] += 1
+        if cases % 25 == 0:
+            print("%d cases, %d pictures, %d macroblocks bit-exact (policy auto / int16 / int32: %d / %d / %d), %.0f s" % (
+                cases, pictures, mbs, by_policy[0], by_policy[1], by_policy[2], time.time() - t0), flush=True)
+    print("soak done: master seed %d, %d cases, %d pictures, %d macroblocks, every slot of every picture bit-exact vs the oracle "
+          "(policy auto / int16 / int32: %d / %d / %d; hand-over units / sparse / device-packed: %d / %d / %d) in %.0f s" % (
+              master, cases, pictures, mbs, by_policy[0], by_policy[1], by_policy[2], by_form[0], by_form[1], by_form[2], time.time() - t0))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
