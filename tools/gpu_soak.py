@@ -1,7 +1,9 @@
 """Randomised differential soak of the reconstruction path on the GPU: seeded (geometry, content, picture types, snapshot
 share, fused RGBA, kernel policy, hand-over form: dense units / sparse words packed on the host / sparse words packed on the device) cases beyond the fixed parametrisations of tests/, every picture of every case compared with
 the oracle on all three slots (and the RGBA image when fused) through the C ABI.  Test infrastructure: the oracle is the checker.
-usage: python tools/gpu_soak.py [seconds] [master seed]   -> one summary line per 25 cases, exit status 1 on any mismatch"""
+A second phase does the same for the MP2 synthesis (stream counts, frames per call, calls in a row on one state, the four output
+formats, both window arithmetics, streams masked out of a call): bit equality with the oracle's synthesis and of the V ring state.
+usage: python tools/gpu_soak.py [seconds] [master seed] [audio seconds]  -> a summary line per 25 cases, exit status 1 on any mismatch"""
 import os
 import sys
 import time
@@ -76,7 +78,55 @@ def main():
     print("soak done: master seed %d, %d cases, %d pictures, %d macroblocks, every slot of every picture bit-exact vs the oracle "
           "(policy auto / int16 / int32: %d / %d / %d; hand-over units / sparse / device-packed: %d / %d / %d) in %.0f s" % (
               master, cases, pictures, mbs, by_policy[0], by_policy[1], by_policy[2], by_form[0], by_form[1], by_form[2], time.time() - t0))
+    audio_soak(ctx, float(sys.argv[3]) if len(sys.argv) > 3 else budget / 4, master)
     ctx.close()
+
+
+def audio_soak(ctx, budget, master):
+    from mpeg_amd import abi, desc
+    from oracle import pyoracle
+    from parity import bits_equal
+
+    rng = np.random.default_rng(master + 1)
+    t0 = time.time()
+    cases = frames = 0
+    while time.time() - t0 < budget:
+        n_streams = int(rng.choice([1, 2, 3, 7, 33, 130, 600])) if rng.random() < 0.7 else int(rng.integers(1, 400))
+        fma = int(rng.integers(0, 2))
+        fmt = int(rng.choice([desc.AUDIO_F32N, desc.AUDIO_F32NLR, desc.AUDIO_F32, desc.AUDIO_S16]))
+        calls = int(rng.integers(1, 4))
+        ref, dut = pyoracle.OracleSynth(n_streams, fma), abi.AudioSynth(ctx, n_streams, fma)
+        try:
+            for _ in range(calls):
+                n_frames = int(rng.integers(1, 40 if n_streams < 50 else 6))
+                sblimit = int(rng.choice([8, 12, 27, 30, 32]))
+                smp = rng.integers(-32768, 32768, size=(n_streams, n_frames, 2, 36, 32), dtype=np.int32)
+                smp[..., sblimit:] = 0
+                if rng.random() < 0.3 and n_frames == 1:  # (a masked call is one frame per stream: AudioBatch's tick)
+                    active = (rng.random(n_streams) < 0.7).astype(np.uint8)
+                    b = np.asarray(dut.synth_masked(smp, active, fmt))[active != 0]
+                    rows = []
+                    for i in np.nonzero(active)[0]:  # the oracle: the active streams one by one, each on its own state
+                        one = pyoracle.OracleSynth(1, fma)
+                        one.states = [ref.states[i]]
+                        rows.append(one.synth(smp[i:i + 1], fmt)[0])
+                    a = np.stack(rows) if rows else b
+                else:
+                    a, b = ref.synth(smp, fmt), dut.synth(smp, fmt)
+                if not bits_equal(a, b):
+                    print("AUDIO MISMATCH: streams=%d fma=%d fmt=%d frames=%d sblimit=%d" % (n_streams, fma, fmt, n_frames, sblimit))
+                    sys.exit(1)
+                frames += n_streams * n_frames
+            for st in sorted({0, n_streams - 1, int(rng.integers(0, n_streams))}):
+                (va, pa), (vb, pb) = ref.get_state(st), dut.get_state(st)
+                if pa != pb or not bits_equal(va, vb):
+                    print("AUDIO STATE MISMATCH: streams=%d fma=%d stream %d" % (n_streams, fma, st))
+                    sys.exit(1)
+        finally:
+            dut.close()
+        cases += 1
+    print("audio soak done: master seed %d, %d cases, %d stream-frames (%d stereo sample pairs) bit-identical with the oracle's synthesis, "
+          "V ring state included, in %.0f s" % (master + 1, cases, frames, frames * 1152, time.time() - t0))
 
 
 if __name__ == "__main__":
