@@ -5,7 +5,7 @@ The other benchmark batches replicate ONE stream's picture to every stream: all 
 all a B picture in a launch, with the same words per chunk.  Real concurrent streams sit at different phases of their GOPs and
 carry different content.  Here stream s decodes the GOP of seed `s % n_seeds`, `s % gop` pictures ahead of stream 0: one
 launch reconstructs I, P and B pictures of different streams side by side, and `n_seeds x gop` distinct (content, phase)
-combinations — each checked against its own CPU replay by the tests and bench.py (oracle/mixedcheck.py).  `dense_share` of the streams (s % 4 < 4 * share) decode the dense
+combinations — each checked against its own CPU replay by the tests and bench.py (oracle/mixedcheck.py).  `dense_share` of the streams (s % dense_den < dense_den * share; dense_den = 4) decode the dense
 worst-case profile instead (every block full, odd vectors), for the kernel-instance crossover (mpeghip.hip: kDenseBatchShare).
 
 Batches are built in the unit form of the ABI (mpeghip_video_batch_upload), one picture per stream and step."""
