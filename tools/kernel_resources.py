@@ -17,8 +17,8 @@ def main():
                         str(ROOT / "mpeg_amd/csrc/mpeghip.hip"), "-o", str(asm)], check=True, stderr=subprocess.DEVNULL)
         text = asm.read_text()
     print("# kernel resources of the shipped sources (hipcc --offload-arch=gfx950 -O3 ... -S, .amdgpu_metadata); csrc sha256 %s" % bench.sources_sha256())
-    print("# waves per SIMD = min(512 / VGPRs rounded up to 8, LDS: 160000 / bytes / 4 for one-wave workgroups (workgroups per CU for the "
-          "4-wave audio workgroups), 8)")
+    print("# waves per SIMD = min(512 / VGPRs rounded up to 8, LDS: workgroups per CU (160000 / bytes) x waves per workgroup (from "
+          ".max_flat_workgroup_size) / 4 SIMDs, 8)")
     print("%-74s %6s %6s %8s %8s %s" % ("kernel", "VGPR", "SGPR", "LDS B", "scratch", "waves/SIMD"))
     for block in text.split("  - .agpr_count:")[1:]:
         def field(name):
@@ -28,8 +28,9 @@ def main():
         name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip() or sym
         vgpr, sgpr, lds, scratch = int(field("vgpr_count")), int(field("sgpr_count")), int(field("group_segment_fixed_size")), int(field("private_segment_fixed_size"))
         by_regs = 512 // ((vgpr + 7) // 8 * 8) if vgpr else 8
-        audio = "audio_kernel" in name
-        by_lds = 8 if lds == 0 else (160000 // lds if audio else 160000 // lds // 4)
+        wg = field("max_flat_workgroup_size")
+        waves_per_wg = max(1, int(wg) // 64) if wg != "?" else 1
+        by_lds = 8 if lds == 0 else 160000 // lds * waves_per_wg // 4
         print("%-74s %6d %6d %8d %8d %d" % (name[:70], vgpr, sgpr, lds, scratch, min(8, by_regs, by_lds)))
 
 
