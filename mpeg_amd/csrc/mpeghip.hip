@@ -45,12 +45,27 @@ static __device__ __forceinline__ void wave_lds_handoff()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The 8 x 8 transposition through LDS, in two halves of 4 blocks (video_recon_lane.h: rc_tpose_store / rc_tpose_load): DS operations
+// of a wave execute in issue order, so the second half's stores follow the first half's loads without a wait in between.
+static __device__ __forceinline__ void rc_transpose8_lds(int32_t *T, int lane, int32_t (&v)[8])
+{
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if ((lane >> 5) == h)
+            rc_tpose_store(T, lane, v);
+        wave_lds_handoff();
+        if ((lane >> 5) == h)
+            rc_tpose_load(T, lane, v);
+        wave_lds_handoff();
+    }
+}
+
 // ---- reconstruction (video_recon_lane.h has the whole story): one wave = one chunk of 4 macroblocks,
 // wave-private LDS, no barrier.  kRgba: the instance for batches with MPEGHIP_PIC_RGBA pictures
-// (Frame.RGBA() fused); the other one carries none of that code.  kT16: the form of the wave's coefficient tile
-// (video_recon_lane.h): int16 levels + transposition across lanes, 8 waves per SIMD — the instance for typical,
-// latency-bound batches; or int32 values + transposition through the tile, 7 waves per SIMD — the instance for batches
-// of dense units, which are bound by vector-ALU issue (launch_batch picks).
+// (Frame.RGBA() fused); the other one carries none of that code.  kT16 (video_recon_lane.h, "the wave's coefficient tile"):
+// true = the 8 x 8 transposition across lanes by DPP — the instance for typical batches; false = through LDS in two halves, and the
+// short dequantisation of dense units under the default matrix — the instance for batches with dense units, which are bound by
+// vector-ALU issue (launch_batch picks).  Both on the int16 tile, 8 waves per SIMD.
 #ifdef MPG_PHASE_TIMING // instrumented build for tools/phase_timing.py only: s_memtime at the phase boundaries
 __device__ uint64_t g_phase_dump[60000 * 8];
 #define MPG_STAMP(k) ts[k] = __builtin_readcyclecounter()
@@ -71,7 +86,7 @@ __device__ uint64_t g_phase_dump[60000 * 8];
 // dependent rounds of scalar loads (grid size -> chunk count -> chunk pointer), and the grid size is an argument because the
 // hidden one cannot be preloaded.  profiles/r34_ab_kernarg_preload.txt: typical +0.75 %, one picture 10.15 -> 9.86 us.
 template <int WAVES, bool kRgba, bool kT16>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16 ? 8 : 7, 8))) void recon_kernel(
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_kernel(
     const uint32_t grid8, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
     uint8_t *const frames_b, const uint32_t mb_w, const uint32_t luma_bytes, uint8_t *const rgba, const uint64_t rgba_stride,
     const uint32_t width, const uint32_t height)
@@ -110,8 +125,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
     // (PERSISTENT waves — as many one-wave workgroups as the device has slots, each taking chunk after chunk of its XCD's range from
     // ticket counters, in order — fill every slot all the time and are 4 - 8 % SLOWER: profiles/round5_d_ab_persistent_waves.txt.)
     uint8_t *lds = lds_all;
-    int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);   // the int32 tile ...
-    int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt); // ... or the int16 one (kT16)
+    int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt); // the int16 tile (and, for !kT16, the transposition buffer over it)
     uint32_t ahead = 0;
     bool ahead_pending = false;
     auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
                 return;
             const bool dense_here = mine && (bw & kBDense);
             // the default non-intra matrix and no intra unit among the pass's: the short dequantisation (wave-uniform choice).
-            // In the int32-tile instance only, the one that batches of dense units run on: typical batches have a dense
+            // In the !kT16 instance only, the one that batches of dense units run on: typical batches have a dense
             // unit here and there, and the int16-tile instance lost 0.5 % to carrying the second form
             // (profiles/r25_ab_dense_default_non_intra_matrix.txt).
             const bool flat = !kT16 && table_flat && all_in_wave(!dense_here || (int32_t)bw < 0);
@@ -190,59 +204,31 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(kT16
             if ((pass + 1) * 8 + ((uint32_t)lane >> 3) < n_blocks && (bw_next & kBDense))
                 dense_next = rc_dense_read(a, c, bw_next, lane);
         };
-        if (kT16) {
-            // the int16 tile holds sparse blocks only: a pass without entries does not go through it
-            if (np) {
-                rc_zero_tile16(T16, lane);
-                wave_lds_handoff();
-                scatter_entries([&](uint32_t ent) { rc_scatter16(T16, lds, ent); });
-                wave_lds_handoff();
-                rc_cols_load16(T16, lds, lane, v);
-            } else {
-                zero_columns();
-            }
-            if (rc_any_special(c)) { // (one test for the common chunk — predicted macroblocks, sparse blocks — instead of three)
-                if (rc_any_dcword(c) && mine)
-                    rc_dc_from_word(bw, lane, v);
-                if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are, from HBM
-                    rc_raw_cols(a, c, bw, lane, v);
-                dense_columns();
-            }
-            idct8<false>(v);
-            rc_transpose8(v, lane); // column j -> row j, across the block's 8 lanes
-            idct8<true>(v);
+        // the int16 tile holds sparse blocks only: a pass without entries does not go through it
+        if (np) {
+            rc_zero_tile16(T16, lane);
+            wave_lds_handoff();
+            scatter_entries([&](uint32_t ent) { rc_scatter16(T16, lds, ent); });
+            wave_lds_handoff();
+            rc_cols_load16(T16, lds, lane, v);
         } else {
-            // a pass whose blocks ALL travel as dense units (the worst-case workload) needs neither the zeroed tile nor a
-            // column read from it: every live lane takes its column straight from its unit
-            bool from_tile = true;
-            if (rc_any_dense(c) && np == 0 && !rc_any_raw(c))
-                from_tile = !all_in_wave(!mine || (bw & kBDense) != 0);
-            if (from_tile) {
-                rc_zero_tile(T, lane);
-                wave_lds_handoff();
-                scatter_entries([&](uint32_t ent) { rc_scatter(T, lds, ent); });
-                if (rc_any_raw(c)) { // int32 snapshot blocks (damaged streams): as they are
-#pragma unroll
-                    for (uint32_t g = 0; g < 8; g++) {
-                        const uint32_t bwg = (uint32_t)__builtin_amdgcn_readlane((int)bw, (int)(g * 8));
-                        if (pass * 8 + g < n_blocks && (bwg & kBRaw))
-                            rc_raw_fill(a, c, T, g, bwg, lane);
-                    }
-                }
-                wave_lds_handoff();
-                rc_cols_load(T, lane, v);
-            } else {
-                zero_columns();
-            }
+            zero_columns();
+        }
+        if (rc_any_special(c)) { // (one test for the common chunk — predicted macroblocks, sparse blocks — instead of three)
             if (rc_any_dcword(c) && mine)
                 rc_dc_from_word(bw, lane, v);
+            if (rc_any_raw(c) && mine && (bw & kBRaw)) // int32 snapshot blocks (damaged streams): as they are, from HBM
+                rc_raw_cols(a, c, bw, lane, v);
             dense_columns();
-            idct8<false>(v);
-            rc_cols_store(T, lane, v); // in place: every lane of the wave has read its column by now
-            wave_lds_handoff();
-            rc_rows_load(T, lane, v);
-            idct8<true>(v);
         }
+        idct8<false>(v);
+        // column j -> row j: across the block's 8 lanes by DPP, or — the instance for batches of dense units, which are bound by
+        // vector-ALU issue — through the tile, which every lane has read by now
+        if (kT16)
+            rc_transpose8(v, lane);
+        else
+            rc_transpose8_lds(reinterpret_cast<int32_t *>(T16), lane, v);
+        idct8<true>(v);
     };
     // step 4: residual rows onto the prediction
     auto add_residual = [&](uint32_t pass) {
@@ -1636,15 +1622,16 @@ static int reap_all(mpeghip_video *v)
     return reap_verdict(&v->staging[v->next_staging ^ 1]);
 }
 
-// Which instance of the reconstruction kernel a batch runs on: the int32-tile one when more than ONE THIRD of its coded blocks are
-// dense units.  Measured (profiles/round5_l_dense_share_crossover.txt: 256 1080p streams at their own GOP phases, a share of them
-// with dense content, both instances interleaved on one box): dense block share 0.01 / 0.13 / 0.24 / 0.33 / 0.41 / 0.49 / 0.56 /
-// 0.68 / 1.00 -> int16 +5.9 % / +4.8 % / +2.5 % / tie / int32 +0.9 % / +1.8 % / +2.8 % / +5.0 % / +11.4 %.  (Round 4 had measured
-// the tie at two thirds, profiles/round4_c_*: round 5's dense-unit loads and staged dequantisation sped the int32-tile instance
-// up by more than the int16-tile one.)  A device-packed commit, whose blocks the host has not looked at, goes by its input dwords
-// per macroblock: the same sweep's 24 / 47 / 70 / 93 / 116 / 139 / 162 / 207 / 390.
-constexpr uint64_t kDenseWordsPerMb = 93;
-constexpr uint64_t kDenseShareNum = 1, kDenseShareDen = 3;
+// Which instance of the reconstruction kernel a batch runs on: the one built for dense units (kT16 = false) when more than ONE
+// EIGHTH of its coded blocks are dense units.  Measured (profiles/round5_p_dense_share_crossover_lds_transposition.txt: 256 1080p
+// streams at their own GOP phases, a share of them with dense content, both instances interleaved on one box): dense block share
+// 0.01 / 0.24 / 0.33 / 0.41 / 0.56 / 0.68 / 1.00 -> tie (+0.3 %) / +3.0 % / +4.3 % / +4.9 % / +8.0 % / +8.3 % / +13.2 % for that
+// instance: it is never behind, and typical batches (share 0.01) stay on the instance the headline was measured on.  (Rounds 2 - 5
+// ran dense batches on an int32-tile instance with 7 waves per SIMD, which lost to the DPP instance below a third: round5_l_*.)
+// A device-packed commit, whose blocks the host has not looked at, goes by its input dwords per macroblock: the same sweep's
+// 24 / 70 / 93 / 116 / 162 / 207 / 390 (an eighth: 48).
+constexpr uint64_t kDenseWordsPerMb = 48;
+constexpr uint64_t kDenseShareNum = 1, kDenseShareDen = 8;
 constexpr int kReconWaves = 1; // waves (= chunks) per workgroup: waves of a workgroup that finish early keep their slots until the
                                // last one has (its LDS goes back as a whole) — 1 beats 2 beats 4 (profiles/r2w_ab_waves_per_workgroup.txt)
 
@@ -1707,10 +1694,9 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     a.rgba = v->d_rgba;
     a.rgba_stride = rgba_stride_of(v);
     hipStream_t st = v->ctx->stream;
-    // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches of dense units are bound by vector-ALU
-    // issue and want the transposition through LDS (int32 tile, 7 waves per SIMD); everything else is bound by per-wave
-    // latency and wants the eighth wave (int16 tile), with Frame.RGBA fused as well.  The switch-over: the measured crossover of the two (kDenseShareNum /
-    // kDenseShareDen above).
+    // Which instance (video_recon_lane.h, "the wave's coefficient tile"): batches with dense units are bound by vector-ALU issue
+    // and want the transposition through LDS and the short dequantisation; the others the transposition by DPP (no LDS round
+    // trip), with Frame.RGBA fused as well.  The switch-over: kDenseShareNum / kDenseShareDen above.
     bool t16 = b->dense_blocks * kDenseShareDen <= b->coded_blocks * kDenseShareNum;
     if (v->tile_policy != MPEGHIP_TILE_AUTO)
         t16 = v->tile_policy == MPEGHIP_TILE_INT16;

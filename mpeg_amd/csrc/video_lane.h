@@ -114,9 +114,10 @@ MPG_HD void idct8(int32_t (&v)[8])
     }
 }
 
-// Dequantise one quantised level the way the VLC loop does (video.go:719-741),
-// then premultiply (video.go:744).  q != 0.  qsqm = quantiser_scale * matrix entry.
-MPG_HD int32_t dequant(int32_t q, bool intra, int32_t qsqm, int32_t pm)
+// Dequantise one quantised level the way the VLC loop does (video.go:719-741): the clamped level, |.| <= 2048.  q != 0.
+// qsqm = quantiser_scale * matrix entry.  (The premultiplication of video.go:744 happens when a column is read from the int16
+// tile: rc_cols_load16.)
+MPG_HD int32_t dequant_level(int32_t q, bool intra, int32_t qsqm)
 {
     // level = 2q (+ sign(q) unless intra); q != 0 so sign(q) = (q >> 31) | 1
     int32_t l = 2 * q;
@@ -124,19 +125,6 @@ MPG_HD int32_t dequant(int32_t q, bool intra, int32_t qsqm, int32_t pm)
         l += (q >> 31) | 1;
     l = mul24_as_written(l, qsqm) >> 4; // |l| <= 65535, qsqm <= 31*255
     // "if even, move one toward zero; 0 becomes +1" == (l - (l > 0)) | 1
-    l = (l - (l > 0 ? 1 : 0)) | 1;
-    l = clampi(l, -2048, 2047);
-    return mul24_as_written(l, pm);
-}
-
-// the same without the premultiplier: the clamped level, |.| <= 2048 (the int16-tile instance keeps these as int16 and premultiplies
-// when a column is read)
-MPG_HD int32_t dequant_level(int32_t q, bool intra, int32_t qsqm)
-{
-    int32_t l = 2 * q;
-    if (!intra)
-        l += (q >> 31) | 1;
-    l = mul24_as_written(l, qsqm) >> 4;
     l = (l - (l > 0 ? 1 : 0)) | 1;
     return clampi(l, -2048, 2047);
 }

@@ -121,19 +121,26 @@ constexpr int kRcQtabStride = 256;            // per stream in HBM
 constexpr int kRcQtabAt = 0;
 constexpr int kRcWinAt = kRcQtabBytes;        // 192
 constexpr int kRcTileAt = kRcWinAt + 4 * kRcWinBytes; // 3648
-// The wave's coefficient tile T, two forms = two instances of the kernel (mpeghip.hip picks one per batch):
-//   int32 [8 blocks][64], 2 048 bytes: dequantised AND premultiplied values; the 8x8 transposition between the two IDCT
-//          passes goes through it (8 writes, 2 reads, one round trip, no vector-ALU work).  5 696 bytes of LDS per wave = 7
-//          waves per SIMD.  The instance for batches with many dense units (bound by vector-ALU issue), fused RGBA or not.
-//   int16 [8 blocks][64], 1 024 bytes: dequantised levels (|.| <= 2048), premultiplied when a column is read (byte x
-//          half-word multiplies); the transposition goes across the block's 8 lanes by DPP (28 instructions), snapshot
-//          blocks are read straight from HBM.  4 672 bytes = 8 waves per SIMD: the instance for the typical, latency-bound
-//          batches (profiles/r5_ab_*, r6_ab_*: typical +3 .. 4 %, dense -4 .. -6 %; with fused RGBA it lost 1 .. 6 % as long
-//          as it ran two chunks per wave and wins 1.2 % with one: profiles/r42_ab_fused_typical_by_tile_instance.txt).
-constexpr int kRcTileBytes32 = 8 * 64 * 4, kRcTileBytes16 = 8 * 64 * 2;
-// 28 / 32 one-wave workgroups per CU (160 000 usable bytes, tools/microbench/lds_residency.hip)
-template <bool kT16> constexpr int rc_lds_bytes() { return kRcTileAt + (kT16 ? kRcTileBytes16 : kRcTileBytes32); }
-constexpr int kRcLdsBytesMax = kRcTileAt + kRcTileBytes32;
+// The wave's coefficient tile T: int16 [8 blocks][64], 1 024 bytes — dequantised levels (|.| <= 2048) of the pass's SPARSE blocks,
+// premultiplied when a column is read (byte x half-word multiplies); snapshot blocks and dense units are read straight from
+// HBM.  Two instances of the kernel (mpeghip.hip picks one per batch) differ in how the 8 x 8 transposition between the two
+// IDCT passes is done and in what they carry for dense units:
+//   kT16 = true   across the block's 8 lanes by DPP (28 vector instructions, no LDS round trip); the general dequantisation of
+//                 dense units only.  4 672 bytes of LDS.  The instance for typical batches (a dense unit here and there).
+//   kT16 = false  through LDS, in two halves of 4 blocks over the (by then dead) tile: [4][72] int32 — the stride keeps the 32
+//                 lanes of a store instruction on 32 banks —, 8 stores + 2 16-byte loads per half, no vector-ALU work; plus the
+//                 short dequantisation of dense non-intra units under the default matrix (rc_dense_cols<true>).  4 800 bytes.
+//                 The instance for batches with dense units (bound by vector-ALU issue).  (The name is history: rounds 2 - 5
+//                 ran this instance on an int32 tile [8][64] of dequantised AND premultiplied values, 5 696 bytes = 7 waves per
+//                 SIMD, and transposed through that.  Each resident wave is worth 5 % here — profiles/round5_o_*: 7 -> 6 waves
+//                 -5.3 % dense, 8 -> 7 waves -5.7 % typical — and this form runs 8: dense +1.6 %, batches of mixed content
+//                 +3 .. 4 %, ahead of BOTH old instances at every share of dense blocks: profiles/round5_p_*.)
+// Both run 8 waves per SIMD (32 one-wave workgroups per CU: 160 000 usable bytes, tools/microbench/lds_residency.hip).
+constexpr int kRcTileBytes16 = 8 * 64 * 2;
+constexpr int kRcTposeStride = 72;                           // dwords per block of the transposition buffer
+constexpr int kRcTposeBytes = 4 * kRcTposeStride * 4;        // 1 152
+template <bool kT16> constexpr int rc_lds_bytes() { return kRcTileAt + (kT16 ? kRcTileBytes16 : kRcTposeBytes); }
+constexpr int kRcLdsBytesMax = kRcTileAt + kRcTposeBytes;
 
 // LDS byte offset of macroblock m's window, later its output bytes O_m: luma [16 rows][16] | Cb [8][8] | Cr [8][8]
 MPG_HD uint32_t rc_win_at(uint32_t m) { return kRcWinAt + m * kRcWinBytes; }
@@ -811,26 +818,6 @@ MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const 
 }
 
 // ---- step 2: the residual pass
-MPG_HD void rc_zero_tile(int32_t *T, int lane)
-{
-    const i32x4 z = {{0, 0, 0, 0}};
-    i32x4 *t = reinterpret_cast<i32x4 *>(T + lane * 8);
-    t[0] = z;
-    t[1] = z;
-}
-
-// one entry: dequantise + premultiply (video.go:719-744), scatter to T[slot & 7][position]  (an intra block's DC is not an
-// entry: rc_dc_from_word)
-MPG_HD void rc_scatter(int32_t *T, const uint8_t *lds, uint32_t e)
-{
-    const uint8_t *Q = lds + kRcQtabAt;
-    const int32_t qm = Q[(e & 0xfeu) >> 1];         // [position][class]
-    const int32_t pm = Q[128 + ((e >> 2) & 63)];    // [position]
-    const int32_t level = (int32_t)e >> 16;
-    const int32_t qs = (int32_t)((e >> 11) & 31);
-    T[(e & 0x7fcu) >> 2] = dequant(level, !(e & kENonIntra), mul24_as_written(qs, qm), pm);
-}
-
 struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; }; // 16 bytes at dword alignment (the words array)
 // (byte kByte of `bytes`) * (half-word kHalf of `words`, sign-extended): unpacking is the multiplier's operand select
 template <int kByte, int kHalf> MPG_HD int32_t mul_u8_s16(uint32_t bytes, uint32_t words)
@@ -969,24 +956,6 @@ MPG_HD void rc_transpose8(int32_t (&v)[8], int lane)
     (void)v;
     (void)lane;
 #endif
-}
-
-// an int32 snapshot block: its 64 values as they are, lane = position
-MPG_HD void rc_raw_fill(const VideoArgs &a, const RcChunk &c, int32_t *T, uint32_t g, uint32_t bw, int lane)
-{
-    T[g * 64 + (uint32_t)lane] = (int32_t)rc_word_base(a, c)[rc_n_blocks(c) + ((bw >> 12) & 0xfffu) + (uint32_t)lane];
-}
-
-// lane (g, j) = column j of the pass's block g, then row j
-MPG_HD void rc_cols_load(const int32_t *T, int lane, int32_t (&v)[8])
-{
-    const i32x4 *t = reinterpret_cast<const i32x4 *>(T + lane * 8); // T[g][j * 8 + r]: rows 0..7 of column j
-    const i32x4 t0 = t[0], t1 = t[1];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        v[r] = t0.v[r];
-        v[r + 4] = t1.v[r];
-    }
 }
 
 // a dense block (more than 32 non-zero levels): lane (g, j) takes column j straight from the unit — one 16-byte load, 8
@@ -1277,14 +1246,26 @@ MPG_HD void rc_dense_cols(const i32x4_a4 &lv, const uint8_t *lds, uint32_t bw, i
         v[0] = (int32_t)(int16_t)(lv.v[0] & 0xffff) * 256; // DC: `<<= 3+5`, video.go:672
 }
 
-MPG_HD void rc_cols_store(int32_t *T, int lane, const int32_t (&v)[8])
+// The transposition through LDS (kT16 = false), one half of the wave at a time: T = [4 blocks][kRcTposeStride] int32 over the
+// tile.  Lane (g, j) stores column j of block g & 3 (v[r] = row r) and loads row j back (v[c] = column c).  The caller runs
+// lanes 0..31, then lanes 32..63, store before load (mpeghip.hip: rc_transpose8_lds; the emulator the same, lane after lane).
+MPG_HD void rc_tpose_store(int32_t *T, int lane, const int32_t (&v)[8])
 {
-    int32_t *t = T + (lane >> 3) * 64 + (lane & 7);
+    int32_t *t = T + ((lane >> 3) & 3) * kRcTposeStride + (lane & 7);
 #pragma unroll
     for (int r = 0; r < 8; r++)
         t[r * 8] = v[r];
 }
-MPG_HD void rc_rows_load(const int32_t *T, int lane, int32_t (&v)[8]) { rc_cols_load(T, lane, v); } // T[g][j * 8 + c] now
+MPG_HD void rc_tpose_load(const int32_t *T, int lane, int32_t (&v)[8])
+{
+    const i32x4 *t = reinterpret_cast<const i32x4 *>(T + ((lane >> 3) & 3) * kRcTposeStride + (lane & 7) * 8);
+    const i32x4 t0 = t[0], t1 = t[1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        v[r] = t0.v[r];
+        v[r + 4] = t1.v[r];
+    }
+}
 
 // ---- step 3: motion compensation of 4 pixels (video_noasm.go:48-80); shifts / oh / ov are wave-uniform.
 // a0 a1: the two dwords that hold the pixels (they start sh / 8 < 4 bytes in) and their right neighbour; b0 b1 the same one

@@ -45,7 +45,7 @@ static uint32_t emu_pack_as(uint32_t luma_w, uint32_t luma_h, uint64_t frame_str
 static thread_local int g_device_pack = 0; // (per thread: ShardedVideoBatch tests run two emulator stores on two threads)
 // 1: sparse pictures are packed by the DEVICE packer's lane functions (video_pack_lane.h), wave by wave
 static uint32_t g_pack_window = kPkWinDwords; // the device packer's LDS window (pack_kernel: kPkWinDwords)
-static int g_tile_policy = 0; // as mpeghip_video_set_tile_policy: 0 = pick per submit like launch_batch, 1 = int16 tile, 2 = int32 tile
+static int g_tile_policy = 0; // as mpeghip_video_set_tile_policy: 0 = pick per submit like launch_batch, 1 = the DPP instance, 2 = the instance for dense units
 extern "C" {
 
 void emu_set_tile_policy(int policy) { g_tile_policy = policy; }
@@ -242,7 +242,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         dense += got.dense_blocks;
     }
     // which kernel instance: the product's rule (mpeghip.hip: launch_batch), unless a test pins one
-    bool t16 = dense * 3 <= coded * 2;
+    bool t16 = dense * 8 <= coded; // (kDenseShareNum / kDenseShareDen)
     if (g_tile_policy)
         t16 = g_tile_policy == 1;
     a.pics = pics;
@@ -258,7 +258,6 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
     alignas(16) uint8_t lds[kRcLdsBytesMax]; // (no statics: ShardedVideoBatch tests run two emulator stores on two threads)
     for (uint32_t chunk = 0; chunk < nc; chunk++) {
         memset(lds, 0xCD, sizeof(lds)); // poison: reads of unwritten LDS must not matter
-        int32_t *T = reinterpret_cast<int32_t *>(lds + kRcTileAt);
         int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt);
         const RcChunk c = rc_load_chunk(a, chunk);
         const uint32_t n_blocks = rc_n_blocks(c);
@@ -279,7 +278,7 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
             }
         int32_t v[64][8];
         uint32_t ent_at = 0;
-        bool table_flat = !t16 && rc_any_dense(c); // (as the kernel — its int32-tile instance: the wave's AND over its lanes' columns)
+        bool table_flat = !t16 && rc_any_dense(c); // (as the kernel — the instance for dense units: the wave's AND over its lanes' columns)
         for (int lane = 0; lane < 64 && table_flat; lane++)
             table_flat = rc_non_intra_column_flat(lds, lane);
         auto residual_pass = [&](uint32_t pass) {
@@ -297,34 +296,34 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                 else
                     rc_dense_cols<false>(lv, lds, bw[lane], lane, v[lane]);
             };
+            if (np) {
+                for (int lane = 0; lane < 64; lane++)
+                    rc_zero_tile16(T16, lane);
+                for (uint32_t r = 0; r < np; r += 64)
+                    for (int lane = 0; lane < 64; lane++) {
+                        if (pass > 0 || r > 0)
+                            e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
+                        if (r + (uint32_t)lane < np)
+                            rc_scatter16(T16, lds, e[lane]);
+                    }
+                ent_at += np;
+            }
+            for (int lane = 0; lane < 64; lane++) {
+                const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
+                if (np)
+                    rc_cols_load16(T16, lds, lane, v[lane]);
+                else
+                    for (int r = 0; r < 8; r++)
+                        v[lane][r] = 0;
+                if (rc_any_dcword(c) && mine)
+                    rc_dc_from_word(bw[lane], lane, v[lane]);
+                if (rc_any_raw(c) && mine && (bw[lane] & kBRaw))
+                    rc_raw_cols(a, c, bw[lane], lane, v[lane]);
+                if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
+                    dense_cols(lane);
+                idct8<false>(v[lane]);
+            }
             if (t16) {
-                if (np) {
-                    for (int lane = 0; lane < 64; lane++)
-                        rc_zero_tile16(T16, lane);
-                    for (uint32_t r = 0; r < np; r += 64)
-                        for (int lane = 0; lane < 64; lane++) {
-                            if (pass > 0 || r > 0)
-                                e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
-                            if (r + (uint32_t)lane < np)
-                                rc_scatter16(T16, lds, e[lane]);
-                        }
-                    ent_at += np;
-                }
-                for (int lane = 0; lane < 64; lane++) {
-                    const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
-                    if (np)
-                        rc_cols_load16(T16, lds, lane, v[lane]);
-                    else
-                        for (int r = 0; r < 8; r++)
-                            v[lane][r] = 0;
-                    if (rc_any_dcword(c) && mine)
-                        rc_dc_from_word(bw[lane], lane, v[lane]);
-                    if (rc_any_raw(c) && mine && (bw[lane] & kBRaw))
-                        rc_raw_cols(a, c, bw[lane], lane, v[lane]);
-                    if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
-                        dense_cols(lane);
-                    idct8<false>(v[lane]);
-                }
                 for (int g = 0; g < 8; g++) { // the kernel's transposition across the block's 8 lanes: lane j leaves with row j
                     int32_t m[8][8];
                     for (int j = 0; j < 8; j++)
@@ -334,55 +333,17 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                         for (int col = 0; col < 8; col++)
                             v[g * 8 + j][col] = m[j][col];
                 }
-                for (int lane = 0; lane < 64; lane++)
-                    idct8<true>(v[lane]);
-                return;
+            } else { // the kernel's transposition through LDS (rc_transpose8_lds): lanes 0..31, then lanes 32..63, over the dead tile
+                int32_t *T = reinterpret_cast<int32_t *>(T16);
+                for (int h = 0; h < 2; h++) {
+                    for (int lane = 32 * h; lane < 32 * h + 32; lane++)
+                        rc_tpose_store(T, lane, v[lane]);
+                    for (int lane = 32 * h; lane < 32 * h + 32; lane++)
+                        rc_tpose_load(T, lane, v[lane]);
+                }
             }
-            bool from_tile = true; // (as the kernel: a pass of dense units only does not go through the tile)
-            if (rc_any_dense(c) && np == 0 && !rc_any_raw(c)) {
-                from_tile = false;
-                for (int lane = 0; lane < 64; lane++)
-                    if (pass * 8 + ((uint32_t)lane >> 3) < n_blocks && !(bw[lane] & kBDense))
-                        from_tile = true;
-            }
-            if (from_tile) {
-                for (int lane = 0; lane < 64; lane++)
-                    rc_zero_tile(T, lane);
-                for (uint32_t r = 0; r < np; r += 64)
-                    for (int lane = 0; lane < 64; lane++) {
-                        if (pass > 0 || r > 0)
-                            e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
-                        if (r + (uint32_t)lane < np)
-                            rc_scatter(T, lds, e[lane]);
-                    }
-                ent_at += np;
-                if (rc_any_raw(c))
-                    for (uint32_t g = 0; g < 8; g++) {
-                        const uint32_t bwg = bw[g * 8]; // the kernel's v_readlane
-                        if (pass * 8 + g < n_blocks && (bwg & kBRaw))
-                            for (int lane = 0; lane < 64; lane++)
-                                rc_raw_fill(a, c, T, g, bwg, lane);
-                    }
-            }
-            for (int lane = 0; lane < 64; lane++) {
-                const bool mine = pass * 8 + ((uint32_t)lane >> 3) < n_blocks;
-                if (from_tile)
-                    rc_cols_load(T, lane, v[lane]);
-                else
-                    for (int r = 0; r < 8; r++)
-                        v[lane][r] = 0;
-                if (rc_any_dcword(c) && mine)
-                    rc_dc_from_word(bw[lane], lane, v[lane]);
-                if (rc_any_dense(c) && mine && (bw[lane] & kBDense))
-                    dense_cols(lane);
-                idct8<false>(v[lane]);
-            }
-            for (int lane = 0; lane < 64; lane++) // (in place: only after every lane has read its column)
-                rc_cols_store(T, lane, v[lane]);
-            for (int lane = 0; lane < 64; lane++) {
-                rc_rows_load(T, lane, v[lane]);
+            for (int lane = 0; lane < 64; lane++)
                 idct8<true>(v[lane]);
-            }
         };
         auto add_residual = [&](uint32_t pass) {
             for (int lane = 0; lane < 64; lane++)
