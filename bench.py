@@ -38,8 +38,9 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MB_PER_1080P30_STREAM = 8160 * 30
 KERNEL = {False: "recon_kernel<1, false, T> (a wave reconstructs one chunk of 4 macroblocks; sparse coefficient entries, prediction windows "
-                 "by direct-to-LDS loads, records that carry their own address arithmetic; T: int16 tile / 8 waves per SIMD for typical "
-                 "batches; int32 tile / 7 for batches of dense units); launches that leave the wave slots empty (one or two pictures) run "
+                 "by direct-to-LDS loads, records that carry their own address arithmetic; int16 coefficient tile, 8 waves per SIMD; T = true: the "
+                 "IDCT's transposition across lanes (typical batches), false: through LDS + the short dequantisation of dense units (batches "
+                 "with dense units)); launches that leave the wave slots empty (one or two pictures) run "
                  "recon_wide_kernel: four waves per chunk",
           True: "recon_kernel<1, true, T> / recon_wide_kernel<true> (the instances with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
@@ -73,7 +74,7 @@ def parse_args():
     ap.add_argument("--audio-frames", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--tile", type=int, default=0, help="mpeghip_video_set_tile_policy of every video leg: 0 = the library picks the "
-                    "kernel instance per batch (the product's behaviour), 1 = int16 tile, 2 = int32 tile (for A/B runs)")
+                    "kernel instance per batch (the product's behaviour), 1 = the instance that transposes across lanes, 2 = the instance for dense units (for A/B runs)")
     ap.add_argument("--pin-numa", type=int, default=1, help="1: bind the rank to the cores of the NUMA node its GPU is attached to")
     ap.add_argument("--check", type=int, default=1, help="verify the final frames against the oracle (rank 0)")
     ap.add_argument("--share-devices", action="store_true",

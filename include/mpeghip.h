@@ -131,9 +131,10 @@ int mpeghip_video_set_quant(mpeghip_video *v, uint32_t stream,
                             const uint8_t intra[64], const uint8_t non_intra[64]);
 
 /* Tuning knob: which instance of the reconstruction kernel a submit / batch of this handle runs on.  The library picks
- * per batch (AUTO): batches with more than a third of their coded blocks dense (more than 32 non-zero
- * levels) take the instance that is built for vector-ALU-bound work (int32 coefficient tile, 7 waves per SIMD); the others
- * the one built for latency-bound work (int16 tile, 8 waves per SIMD); and a launch small enough to leave most of the device
+ * per batch (AUTO): batches with more than an eighth of their coded blocks dense (more than 32 non-zero
+ * levels) take the instance that is built for vector-ALU-bound work (the IDCT's transposition through LDS, a short dequantisation
+ * of dense units: MPEGHIP_TILE_INT32 — the name is history, both instances keep an int16 coefficient tile and run 8 waves per
+ * SIMD); the others the one that transposes across lanes (MPEGHIP_TILE_INT16); and a launch small enough to leave most of the device
  * empty (one or two 1080p pictures) runs on a third kernel that puts four waves on every chunk of 4 macroblocks (recon_wide_kernel: the
  * launch lasts one chunk's chain of dependent steps, which four waves walk in parallel).  Results are identical bit for bit
  * either way; the override pins one of the two instances at any size and exists for measurements (bench.py --tile) and for
