@@ -89,7 +89,7 @@ def lib():
 
 def set_tile_policy(policy=0):
     """Which instance of the reconstruction kernel the emulator runs (mpeghip_video_set_tile_policy): 0 = the library's
-    per-batch rule, 1 = int16 coefficient tile, 2 = int32 tile."""
+    per-batch rule, 1 = the instance that transposes across lanes, 2 = the instance for dense units (transposition through LDS)."""
     lib().emu_set_tile_policy(policy)
 
 

@@ -1,5 +1,6 @@
-"""The two instances of the reconstruction kernel (video_recon_lane.h: int16 coefficient tile + transposition across lanes,
-int32 tile + transposition through LDS; the library picks one per batch, mpeghip_video_set_tile_policy pins one) keep the
+"""The two instances of the reconstruction kernel (video_recon_lane.h: int16 coefficient tile in both; transposition across lanes,
+or through LDS in two halves + the short dequantisation of dense units; the library picks one per batch,
+mpeghip_video_set_tile_policy pins one) keep the
 reference's results bit for bit on the same cases: prediction windows, windows that leave their plane (the linear reads),
 stores of runs and of single macroblocks, the fused and the whole-frame RGBA, snapshot blocks, dense units."""
 import numpy as np

@@ -2,8 +2,8 @@
 """Where the two instances of the reconstruction kernel cross over (mpeghip.hip: kDenseBatchShare, kDenseWordsPerMb).
 
 Launches in which a share of the STREAMS carries the dense worst-case content (every block full: dense units) and the rest
-typical content, all at their own GOP phases (mpeg_amd/mixed.py), timed on the int16-tile instance and on the int32-tile one,
-interleaved on one box (mpeghip_video_set_tile_policy).  Prints, per share: the batch's share of dense BLOCKS (what
+typical content, all at their own GOP phases (mpeg_amd/mixed.py), timed on the instance that transposes across lanes (policy 1, column
+'int16') and on the instance for dense units (policy 2, column 'int32': the name of its first form), interleaved on one box (mpeghip_video_set_tile_policy).  Prints, per share: the batch's share of dense BLOCKS (what
 launch_batch looks at), its sparse-form dwords per macroblock (what a device-packed commit looks at), ms per step on either
 instance.   python tools/sweep_dense_share.py [streams [share of dense streams in per cent ...]] > profiles/round4_c_dense_share_crossover.txt"""
 import sys
