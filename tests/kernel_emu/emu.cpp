@@ -616,6 +616,30 @@ void emu_audio_slice_range(uint32_t n_frames, uint32_t n_chunks, int32_t vpos0, 
 uint32_t emu_avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return avg4_u8x4(a, b, c, d); }
 uint32_t emu_avg2(uint32_t a, uint32_t b) { return avg_ceil_u8x4(a, b); }
 uint32_t emu_xcd_chunk(uint32_t b, uint32_t n) { return xcd_chunk(b, n); }
+// The transposition through LDS (rc_tpose_store / rc_tpose_load, the kernel's rc_transpose8_lds): v[64 lanes][8] in place, half a wave
+// at a time over ONE buffer of kRcTposeBytes; touched[dword] = 1 + the number of the store instruction (r) that wrote it last.
+uint32_t emu_tpose(int32_t *v, uint8_t *touched)
+{
+    alignas(16) int32_t T[kRcTposeBytes / 4];
+    for (int h = 0; h < 2; h++) {
+        for (int i = 0; i < kRcTposeBytes / 4; i++)
+            T[i] = 0x5a5a5a5a;
+        for (int lane = 32 * h; lane < 32 * h + 32; lane++) {
+            int32_t x[8];
+            memcpy(x, v + lane * 8, sizeof(x));
+            rc_tpose_store(T, lane, x);
+            for (int r = 0; r < 8; r++) // where instruction r of this lane went: found by its value
+                if (touched && h == 0)
+                    touched[((lane >> 3) & 3) * kRcTposeStride + (lane & 7) + r * 8] = (uint8_t)(1 + r);
+        }
+        for (int lane = 32 * h; lane < 32 * h + 32; lane++) {
+            int32_t x[8];
+            rc_tpose_load(T, lane, x);
+            memcpy(v + lane * 8, x, sizeof(x));
+        }
+    }
+    return kRcTposeBytes;
+}
 uint32_t emu_ycbcr(uint32_t y, uint32_t cb, uint32_t cr) { return ycbcr_to_rgba(y, cb, cr); }
 
 }

@@ -70,6 +70,26 @@ def test_avg4_identity(emu):
             assert (got >> (8 * k)) & 0xff == (s + 2) >> 2
 
 
+def test_transposition_through_lds_in_halves(emu):
+    """rc_tpose_store / rc_tpose_load (the instance for dense units): lane (g, j) enters with column j of block g and leaves with row
+    j; half a wave at a time fits 1 152 bytes; the 32 lanes of each of the 8 store instructions fall on 32 different LDS banks
+    (dword index mod 32 — and mod 64), and no two stores of a half share a dword."""
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    v = rng.integers(-2 ** 31, 2 ** 31, size=(64, 8), dtype=np.int64).astype(np.int32)
+    want = v.reshape(8, 8, 8).transpose(0, 2, 1).reshape(64, 8).copy()   # [g][j][r] -> [g][r as lane][j as register]
+    got = v.copy()
+    touched = np.zeros(4 * 72, np.uint8)
+    lib = emu.lib()
+    lib.emu_tpose.restype = C.c_uint32
+    assert lib.emu_tpose(got.ctypes.data_as(C.c_void_p), touched.ctypes.data_as(C.c_void_p)) == 1152
+    assert np.array_equal(got, want)
+    assert (touched != 0).sum() == 32 * 8                                # 256 values of a half, 256 distinct dwords
+    for r in range(8):
+        idx = np.nonzero(touched == 1 + r)[0]
+        assert len(idx) == 32 and len(set(idx % 32)) == 32 and len(set(idx % 64)) == 32
+
+
 def test_xcd_chunk_is_a_permutation(emu):
     L = emu.lib()
     for g8 in (1, 2, 7, 8, 9, 128, 513):     # the grid is 8 * g8 workgroups (launch_batch rounds it up)
