@@ -27,23 +27,23 @@ void Video::SetDefaultSparse(bool v) { g_default_sparse.store(v); }
 
 namespace {
 
-const VlcTable &tabMba() { static const VlcTable t(mpg_vlc_mba_increment); return t; }
-const VlcTable &tabType(int picture_type)
-{
-    static const VlcTable ti(mpg_vlc_mb_type_i), tp(mpg_vlc_mb_type_p), tb(mpg_vlc_mb_type_b);
-    return picture_type == 1 ? ti : (picture_type == 2 ? tp : tb);
-}
-const VlcTable &tabCbp() { static const VlcTable t(mpg_vlc_coded_block_pattern); return t; }
-const VlcTable &tabMotion() { static const VlcTable t(mpg_vlc_motion_code); return t; }
-const VlcTable &tabDcSize(int plane)
-{
-    static const VlcTable tl(mpg_vlc_dct_dc_size_luma), tc(mpg_vlc_dct_dc_size_chroma);
-    return plane == 0 ? tl : tc;
-}
+// The tables are objects of this translation unit, built when the library is loaded (a millisecond), not function-local statics:
+// a macroblock reads five of them and a block three, and each accessor of the old form was a call with a guard check in the
+// parser's inner loops (four calls per block: 8 % of the parse).
+const VlcTable kTabMba(mpg_vlc_mba_increment), kTabTypeI(mpg_vlc_mb_type_i), kTabTypeP(mpg_vlc_mb_type_p), kTabTypeB(mpg_vlc_mb_type_b),
+    kTabCbp(mpg_vlc_coded_block_pattern), kTabMotion(mpg_vlc_motion_code), kTabDcLuma(mpg_vlc_dct_dc_size_luma),
+    kTabDcChroma(mpg_vlc_dct_dc_size_chroma);
+const CoeffTable kTabCoeffFirst(mpg_vlc_dct_coeff, true), kTabCoeffNext(mpg_vlc_dct_coeff, false);
+const CoeffPairTable kTabCoeffPairs(kTabCoeffNext); // (after the table it is built from: objects of one unit are built in order)
+inline const VlcTable &tabMba() { return kTabMba; }
+inline const VlcTable &tabType(int picture_type) { return picture_type == 1 ? kTabTypeI : (picture_type == 2 ? kTabTypeP : kTabTypeB); }
+inline const VlcTable &tabCbp() { return kTabCbp; }
+inline const VlcTable &tabMotion() { return kTabMotion; }
+inline const VlcTable &tabDcSize(int plane) { return plane == 0 ? kTabDcLuma : kTabDcChroma; }
 const VlcTable &tabCoeff() { static const VlcTable t(mpg_vlc_dct_coeff); return t; }   // (the plain table: only the self-check reads it)
-const CoeffTable &tabCoeffFirst() { static const CoeffTable t(mpg_vlc_dct_coeff, true); return t; }
-const CoeffTable &tabCoeffNext() { static const CoeffTable t(mpg_vlc_dct_coeff, false); return t; }
-const CoeffPairTable &tabCoeffPairs() { static const CoeffPairTable t(tabCoeffNext()); return t; }
+inline const CoeffTable &tabCoeffFirst() { return kTabCoeffFirst; }
+inline const CoeffTable &tabCoeffNext() { return kTabCoeffNext; }
+inline const CoeffPairTable &tabCoeffPairs() { return kTabCoeffPairs; }
 
 // the code a prefix starts with, found the slow way: the first code of the list that the prefix's leading bits spell out
 // (the lists are prefix-free: the reference's tree walk, buffer.go:352-376, ends at exactly that code)
