@@ -154,3 +154,17 @@ def test_dense_units_take_the_short_dequantisation_only_under_the_default_non_in
         o.set_quant(0, iq, nq)
         e.set_quant(0, iq, nq)
     run_and_compare(o, e, seq)
+
+
+def test_the_emulator_picks_the_instance_by_the_library_s_rule():
+    """launch_batch (mpeghip.hip) and the emulator's copy of its rule name the same share of dense blocks (the emulator's choice
+    decides which lane functions the CPU suite runs under the automatic policy)."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    hip = (root / "mpeg_amd" / "csrc" / "mpeghip.hip").read_text()
+    emu_src = (root / "tests" / "kernel_emu" / "emu.cpp").read_text()
+    num, den = map(int, re.search(r"kDenseShareNum = (\d+), kDenseShareDen = (\d+);", hip).groups())
+    assert "b->dense_blocks * kDenseShareDen <= b->coded_blocks * kDenseShareNum" in hip
+    m = re.search(r"bool t16 = dense \* (\d+) <= coded( \* (\d+))?;", emu_src)
+    assert m and int(m.group(1)) == den and int(m.group(3) or 1) == num
