@@ -45,7 +45,7 @@ KERNEL = {False: "recon_kernel<1, false, T> (a wave reconstructs one chunk of 4 
           True: "recon_kernel<1, true, T> / recon_wide_kernel<true> (the instances with Frame.RGBA fused; pictures flagged MPEGHIP_PIC_RGBA)"}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=26)
@@ -81,15 +81,25 @@ def parse_args():
                     help="allow ranks to share a physical GPU (functional runs of the N>1 path on a smaller box): without it a launch "
                          "with more ranks than distinct devices exits non-zero; with it the line reports n_gpus = the distinct devices")
     ap.add_argument("--gop-prewarm", type=int, default=1, help="1: one untimed GOP in front of the --warmup steps when --warmup is shorter than a GOP (clock ramp)")
-    return ap.parse_args()
+    ap.add_argument("--sif-streams", type=int, default=8192, help="streams of the SIF 352x240 leg (BASELINE config 2's geometry; N=1 only; 0 = skip)")
+    ap.add_argument("--sidecar", default=str(ROOT / "bench_legs.json"),
+                    help="where the FULL result goes (every leg with its prose: metric, sample, kernel, parity sentences); the one "
+                         "JSON line on stdout is the compact form of it (< 7 500 characters); '' = do not write")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rendezvous only: start the ranks, form the gloo group, print {\"dry_launch\": true, \"ranks\": N} from rank 0 — "
+                         "no GPU is touched (the CPU test of the N > 1 launch path)")
+    return ap.parse_args(argv)
 
 
 def cpu_baseline(args, seq):
     """Time the oracle (CPU restatement of the reference's noasm algorithm) on a bounded
     sample of the same workload: T host threads, one independent stream each."""
     from oracle import pyoracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, cores)
+    from mpeg_amd.shard import effective_cores
+    # one thread per core's worth of CPU time the process really gets (the cgroup quota, capped by the affinity mask), as the
+    # library sizes its own pools: BENCH_r05 started 256 threads under a 16-core quota, which handicaps the baseline
+    eff = effective_cores()
+    threads = max(1, int(np.ceil(eff["effective_cores"])))
     # single thread first: one stream, as many GOP pictures as fit in a quarter of the budget
     st1 = pyoracle.OracleStore(args.width, args.height, 1, threads=1)
     t0, n1, i = time.perf_counter(), 0, 0
@@ -115,12 +125,10 @@ def cpu_baseline(args, seq):
         i += 1
     rT = nT / (time.perf_counter() - t0)
     stT.close()
-    from mpeg_amd.shard import effective_cores
-    eff = effective_cores()
     return {
         "value": rT, "unit": "macroblocks/s", "cores": threads, "kind": "port",
-        # `cores` = the threads started (the affinity mask); what the container's CPU-time quota lets them have:
-        "effective_cores": eff["effective_cores"], "cgroup_quota_cores": eff["cgroup_quota_cores"],
+        # `cores` = the threads started = ceil(effective_cores): the quota if there is one, else the affinity mask
+        "effective_cores": eff["effective_cores"], "cgroup_quota_cores": eff["cgroup_quota_cores"], "affinity_cpus": eff["affinity_cpus"],
         "sample": "oracle (C restatement of the reference's pure-Go noasm path, gcc -O2): %d host threads x 1 "
                   "1080p stream each over the bench GOP (%s profile), %d macroblocks in %.1f s; single thread: %.3g "
                   "macroblocks/s" % (threads, args.profile, nT, args.cpu_seconds * 0.75, r1),
@@ -138,7 +146,8 @@ def cpu_baseline_audio(args, seconds):
     from mpeg_amd import synth
     from oracle import pyoracle
     L = pyoracle.lib()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from mpeg_amd.shard import effective_cores
+    cores = max(1, int(np.ceil(effective_cores()["effective_cores"])))
     frames = 20
     smp = synth.audio_frames(min(cores, 64), frames)     # (streams beyond 64 reuse the samples: each has its own state and output)
 
@@ -222,13 +231,15 @@ def traffic_of(profile, rgba, streams, args):
     WRITE_SIZE, separate passes, tools/gpu_traffic.sh): a figure of the named profile run, not measured in this process.
     -> (bytes, source, the run's kernel sources are the ones this process loaded)"""
     tp = ROOT / "profiles" / "pmc_traffic.json"
-    if not tp.exists() or (args.width, args.height) != (1920, 1080):
+    if not tp.exists():
         return None, None, None
+    # (keys: the 1080p workloads by their profile name; another geometry carries it: "typical_352x240")
+    geom = "" if (args.width, args.height) == (1920, 1080) else "_%dx%d" % (args.width, args.height)
     try:
         j = json.loads(tp.read_text())
         if "current" in j:  # (a pointer to the profile set of the shipped sources, not a copy of it)
             j = json.loads((ROOT / "profiles" / j["current"]).read_text())
-        t = j.get(profile + ("_rgba" if rgba else ""), {})
+        t = j.get(profile + ("_rgba" if rgba else "") + geom, {})
         if t.get("streams") == streams:
             return t.get("hbm_bytes_per_launch"), t.get("source"), j.get("csrc_sha256") == sources_sha256()
     except Exception:
@@ -236,7 +247,7 @@ def traffic_of(profile, rgba, streams, args):
     return None, None, None
 
 
-def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, steps=None, ramp_ms=0.0):
+def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, steps=None, ramp_ms=0.0, geometry=None):
     """Upload the GOP for `streams` streams, warm up, time `--steps` steps.  With `ranks` the timed region is bracketed
     by barrier + device sync on both sides and the elapsed time is the MAX over ranks (the primary leg).
     ramp_ms: for legs whose warm-up steps take microseconds (one stream) — the same pictures run on a throw-away store for that
@@ -244,6 +255,8 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
     (the 1024-stream legs' 13 warm-up steps are 25-50 ms of work: they need none, profiles/round4_o_bench_steps104_warmup52.json)."""
     from mpeg_amd import abi
     steps = args.steps if steps is None else steps
+    if geometry is not None:   # (a leg at another picture size: the SIF legs)
+        args = argparse.Namespace(**{**vars(args), "width": geometry[0], "height": geometry[1]})
     seq, prime = build_sequence(args, profile, rgba)
     store = abi.VideoStore(ctx, args.width, args.height, streams)
     store.set_tile_policy(args.tile)
@@ -512,6 +525,27 @@ def single_stream_leg(ctx, args):
                         "macroblocks_per_s": leg["mbs"] / 100 / (r["avg_launch_ms"] * 1e-3), "achieved_GBps": r["achieved"],
                         "frac": r["frac"], "alg_bytes_per_launch": r["alg_bytes_per_launch"], "pictures_timed": 100,
                         "wall_us_per_picture": leg["elapsed"] * 1e4, "parity": leg["parity"]}
+    return out
+
+
+def sif_leg(ctx, args):
+    """The other named resolution (BASELINE config 2: 352x240 SIF, 22 x 15 = 330 macroblocks per picture; SURVEY section 8(d)'s
+    generator and seed): `--sif-streams` streams' typical GOP resident, one picture of every stream per launch — the roofline leg —
+    and ONE SIF stream per launch (83 chunks: recon_wide_kernel's home ground, a latency figure).  mb_w = 22 is not a multiple of
+    the chunk's 4 macroblocks: every row's last chunk carries on into the next row (a run for the plane stores all the same)."""
+    geo, n = (352, 240), args.sif_streams
+    leg = video_leg(ctx, args, "typical", False, n, geometry=geo)
+    out = secondary(leg, "SIF 352x240 (BASELINE config 2's geometry), typical GOP, %d streams resident, one picture each per launch" % n, n, args)
+    out["metric"] = "352x240 macroblocks/sec"
+    del out["realtime_1080p30_streams"]
+    out["realtime_sif30_streams"] = out["value"] / (330 * 30)
+    out["pictures_per_s"] = out["value"] / 330
+    one = video_leg(ctx, args, "typical", False, 1, steps=100, ramp_ms=40.0, geometry=geo)
+    r = one["roofline"]
+    out["single"] = {"us_per_picture": r["avg_launch_ms"] * 1e3, "pictures_per_s": 1e3 / r["avg_launch_ms"], "achieved_GBps": r["achieved"],
+                     "frac": r["frac"], "alg_bytes_per_launch": r["alg_bytes_per_launch"], "pictures_timed": 100,
+                     "wall_us_per_picture": one["elapsed"] * 1e4, "parity": one["parity"],
+                     "what": "ONE 352x240 stream, one picture (330 macroblocks = 83 chunks) per launch"}
     return out
 
 
@@ -784,8 +818,177 @@ def audio_host_parsed_leg(args, device, streams=256, threads=16):
 
 
 
-def main():
-    args = parse_args()
+COMPACT_LIMIT = 7500   # characters: the driver's record keeps a tail of ~8 000
+
+
+def _r(x, digits=5):
+    """Numbers of the compact line: `digits` significant digits (floats), everything else as it is."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    return x
+
+
+def _leg(full, tag, value_key="value"):
+    """One leg of the compact line: value, frac of the HBM roofline, ms per launch, algorithmic and counter bytes per launch,
+    parity as a boolean (a leg whose frames differ from the oracle never gets here: bench.py exits), a short tag."""
+    if not full:
+        return None
+    r = full.get("roofline") or {}
+    out = {"tag": tag, "value": full.get(value_key), "frac": r.get("frac", full.get("frac")),
+           "ms": r.get("avg_launch_ms", full.get("ms_per_launch")), "alg_bytes": r.get("alg_bytes_per_launch"), "traffic": r.get("traffic"),
+           "parity_ok": bool(full.get("parity")) if "parity" in full else None}
+    if r.get("traffic") is not None:
+        out["traffic_matches_build"] = r.get("traffic_source_matches_build")
+    if "streams" in full:
+        out["streams"] = full["streams"]
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def compact_line(full):
+    """The ONE line on stdout: the contract's fields + roofline + cpu_baseline + every leg as numbers and booleans — the prose
+    (metric sentences, samples, kernel descriptions, parity sentences, traffic sources) lives in the sidecar (--sidecar,
+    bench_legs.json) and under profiles/.  Order of the extra keys: the second half of BASELINE's metric (audio, config 4, no FMA)
+    and the worst-case / fused video legs first.  Stays under COMPACT_LIMIT characters (tests/test_bench_line.py)."""
+    roof = full.get("roofline") or {}
+    cpu = full.get("cpu_baseline")
+    cfg = full.get("config") or {}
+    line = {
+        "metric": full["metric"], "value": full["value"], "unit": full["unit"], "n_gpus": full["n_gpus"], "ranks": full.get("ranks"),
+        "steps": full["steps"], "warmup": full["warmup"], "ms_per_step": full["ms_per_step"], "higher_is_better": True,
+        "scaling": full["scaling"], "vs_baseline": full.get("vs_baseline"), "dtype": full["dtype"], "data": full["data"],
+        "config": {"workload": cfg.get("workload"), "streams_per_gpu": cfg.get("streams_per_gpu"),
+                   "macroblocks_per_step_per_gpu": cfg.get("macroblocks_per_step_per_gpu"), "profile": cfg.get("profile"),
+                   "rgba_fused": cfg.get("rgba_fused"), "sharding": "by stream, no collective", "devices": cfg.get("devices"),
+                   "devices_shared": cfg.get("devices_shared"), "untimed_prewarm_steps": cfg.get("untimed_prewarm_steps")},
+        "realtime_1080p30_streams": full.get("realtime_1080p30_streams"), "per_rank_value": full.get("per_rank_value"),
+        "roofline": {"bound": roof.get("bound"), "achieved": roof.get("achieved"), "peak": roof.get("peak"), "unit": roof.get("unit"),
+                     "frac": roof.get("frac"), "traffic": roof.get("traffic"), "traffic_matches_build": roof.get("traffic_source_matches_build"),
+                     "alg_bytes_per_launch": roof.get("alg_bytes_per_launch"), "avg_launch_ms": roof.get("avg_launch_ms"),
+                     "kernel": "recon_kernel<1,%s,T>" % ("true" if cfg.get("rgba_fused") else "false")},
+        "parity_ok": bool(full.get("parity")),
+    }
+    if cpu:
+        c = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+             "sample": "oracle (C port of the reference's noasm path, gcc -O2), %d threads x 1 stream, bench GOP, ~%.0f s" %
+                       (cpu["cores"], 0.75 * full.get("cpu_seconds", 12.0)),
+             "effective_cores": cpu.get("effective_cores"), "single_thread": cpu.get("single_thread")}
+        a = cpu.get("audio")
+        if a:
+            c["audio"] = {"value": a["value"], "unit": "sample pairs/s", "cores": a["cores"], "single_thread": a.get("single_thread")}
+        t = cpu.get("test_mpg")
+        if t:
+            c["test_mpg"] = {"video_frames_per_s": t.get("video_frames_per_s"), "audio_frames_per_s": t.get("audio_frames_per_s"), "cores": 1}
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    # ---- the legs
+    line["audio"] = _leg(full.get("audio"), "config4 256 streams x 100 frames, no FMA; sample pairs/s")
+    if line["audio"] and full["audio"].get("ranks", 1) > 1:
+        line["audio"]["per_rank_value"] = full["audio"].get("per_rank_value")
+    line["dense"] = _leg(full.get("dense"), "1080p dense worst case, MB/s")
+    line["dense_rgba_fused"] = _leg(full.get("dense_rgba_fused"), "1080p dense + Frame.RGBA fused, MB/s")
+    line["rgba_fused"] = _leg(full.get("rgba_fused"), "1080p typical + Frame.RGBA fused, MB/s")
+    line["mixed"] = _leg(full.get("mixed"), "1080p, stream s at its own GOP phase/content, MB/s")
+    sif = full.get("sif")
+    if sif:
+        line["sif"] = _leg(sif, "352x240 typical GOP, MB/s")
+        line["sif"]["pictures_per_s"] = sif.get("pictures_per_s")
+        one = sif.get("single") or {}
+        line["sif_single"] = {"tag": "ONE 352x240 stream, one picture per launch", "us_per_picture": one.get("us_per_picture"),
+                              "frac": one.get("frac"), "parity_ok": bool(one.get("parity"))}
+    line["audio_large"] = _leg(full.get("audio_large"), "2048 streams (beyond the Infinity Cache), sample pairs/s")
+    line["audio_fma_window"] = _leg(full.get("audio_fma_window"), "config4 with the reference's AVX2 FMA window arithmetic")
+    single = full.get("single_stream")
+    if single:
+        line["single_stream"] = {"tag": "ONE 1080p stream, picture per launch, RGBA fused (config 3)"}
+        for k in ("typical", "dense"):
+            v = single.get(k) or {}
+            line["single_stream"][k] = {"us_per_picture": v.get("us_per_picture"), "frac": v.get("frac"), "parity_ok": bool(v.get("parity"))}
+    rb = full.get("reference_benchmarks")
+    if rb:
+        c = {"copy_macroblock_frac": {k: v.get("frac") for k, v in (rb.get("copy_macroblock") or {}).items()},
+             "copy_macroblock_parity_ok": all(bool(v.get("parity")) for v in (rb.get("copy_macroblock") or {}).values())}
+        for k, f in (("decode_video_test_mpg", "pictures_per_s"), ("decode_audio_test_mpg", "frames_per_s"), ("rgba_test_mpeg1video", "frames_per_s")):
+            if rb.get(k):
+                c[k] = rb[k].get(f)
+        line["reference_benchmarks"] = c
+    hf = full.get("host_fed")
+    if hf:
+        line["host_fed"] = {"tag": "device-packed stages from host threads, PCIe inclusive, NOT value", "value": hf.get("value"),
+                            "pictures_per_s": hf.get("pictures_per_s"), "pcie_frac_of_bare_copy": hf.get("pcie_frac_of_bare_copy"),
+                            "in_place_pictures_per_s": (hf.get("in_place") or {}).get("pictures_per_s"),
+                            "host_packed_pictures_per_s": (hf.get("host_packed") or {}).get("pictures_per_s_32_threads"),
+                            "per_rank_pictures_per_s": hf.get("per_rank_pictures_per_s")}
+        line["host_fed"] = {k: v for k, v in line["host_fed"].items() if v is not None}
+    hp = full.get("host_parsed")
+    if hp:
+        line["host_parsed"] = {"tag": "1080p pictures/s from BITSTREAMS (parse threads -> stages -> GPU), NOT value", "value": hp.get("value"),
+                               "default_arm": hp.get("default_arm"), "effective_cores": hp.get("effective_cores")}
+        for k in ("device_packed", "host_packed", "device_packed_few_streams"):
+            if hp.get(k):
+                line["host_parsed"][k] = {"pictures_per_s": hp[k]["pictures_per_s"], "parse_threads": hp[k]["parse_threads"],
+                                          "ms_parse_per_picture_per_core": hp[k]["ms_parse_per_picture_per_core"]}
+    ap = full.get("audio_host_parsed")
+    if ap:
+        line["audio_host_parsed"] = {"tag": "MP2 frames/s from BITSTREAMS, samples back on the host, NOT value", "value": ap.get("value"),
+                                     "one_thread": (ap.get("one_thread") or {}).get("frames_per_s")}
+    line["csrc_sha256"] = (full.get("csrc_sha256") or "")[:16]
+    line["sidecar"] = full.get("sidecar")
+    line = _r({k: v for k, v in line.items() if v is not None or k in ("vs_baseline", "cpu_baseline")})
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:   # (cannot happen with the legs above; if a future leg grows: drop the tags, never the numbers)
+        for v in line.values():
+            if isinstance(v, dict):
+                v.pop("tag", None)
+    return line
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves — the command the driver's contract names
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same argv>)
+    on a free port.  Rank 0 prints the ONE JSON line, the other ranks print nothing; the exit code is the launcher's (non-zero
+    if any rank failed — e.g. the device census refusing ranks that share a GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")   # (what the launcher would set itself, with a notice on stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args):
+    """--dry-launch: the ranks rendezvous over gloo and report who is there; nothing else runs (no GPU needed)."""
+    from mpeg_amd.shard import Ranks
+    ranks = Ranks(backend="gloo")
+    who = ranks.gather_object({"rank": ranks.rank, "local_rank": ranks.local_rank, "pid": os.getpid()})
+    total = ranks.sum(1.0)
+    ranks.barrier()
+    if ranks.rank == 0:
+        print(json.dumps({"dry_launch": True, "gpus_asked": args.gpus, "ranks": ranks.world, "ranks_counted": int(total),
+                          "local_ranks": [w["local_rank"] for w in who], "distinct_pids": len({w["pid"] for w in who})}))
+    ranks.close()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, argv))
+    if args.dry_launch:
+        return dry_launch(args)
     import torch
 
     from mpeg_amd.shard import Ranks
@@ -797,8 +1000,8 @@ def main():
     torch.cuda.set_device(local_rank)
     ranks = Ranks(backend="gloo")  # control plane only: barrier + reductions of timings (no collective on the data path)
     world, rank = ranks.world, ranks.rank
-    if args.gpus != world:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world and rank == 0:  # (a launcher's WORLD_SIZE is what runs; the line reports ranks and distinct devices)
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: running %d" % (args.gpus, world, world), file=sys.stderr)
 
     from mpeg_amd import abi
     from mpeg_amd.shard import device_census
@@ -851,6 +1054,7 @@ def main():
     # the reference's other arithmetic: its amd64 AVX2 window routine uses fused multiply-adds (what it runs on any recent x86)
     audio_fma = audio_leg(ctx, args, args.audio_streams, fma=1) if args.audio_streams > 0 and alone else None
     single = single_stream_leg(ctx, args) if alone and args.single_stream else None
+    sif = sif_leg(ctx, args) if alone and args.single_stream and args.sif_streams > 0 else None
     ref_bench = reference_benchmarks(ctx, args, local_rank) if alone and args.reference_benchmarks and args.single_stream else None
 
     # ---- host-fed rate (NOT `value`): the same pictures handed over by host threads through the staged submit,
@@ -879,7 +1083,7 @@ def main():
             "metric": "1080p macroblocks/sec", "value": value, "unit": "macroblocks/s",
             "n_gpus": census["n_gpus"], "ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": prim["elapsed"] * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8 pixels / int16 levels / int32 IDCT", "data": "synthetic",
             "config": {"workload": "%d independent %dx%d MPEG-1 streams per GPU, one picture each per step, decode-order "
                                    "GOP of %d pictures (%s macroblock mix%s), descriptors resident in HBM" %
                                    (args.streams, args.width, args.height, prim["gop_len"], args.profile,
@@ -895,11 +1099,12 @@ def main():
             "per_rank_value": per_rank,
             "roofline": prim["roofline"],
             "cpu_baseline": cpu,
-            "dense": legs.get("dense"),
-            "rgba_fused": legs.get("rgba_fused"),
-            "dense_rgba_fused": legs.get("dense_rgba_fused"),
-            "mixed": legs.get("mixed"),
             "audio": audio,
+            "dense": legs.get("dense"),
+            "dense_rgba_fused": legs.get("dense_rgba_fused"),
+            "rgba_fused": legs.get("rgba_fused"),
+            "mixed": legs.get("mixed"),
+            "sif": sif,
             "audio_large": audio_large,
             "audio_fma_window": audio_fma,
             "single_stream": single,
@@ -908,8 +1113,16 @@ def main():
             "host_parsed": host_parsed,
             "audio_host_parsed": audio_host_parsed,
             "parity": prim["parity"],
+            "cpu_seconds": args.cpu_seconds,
         }
-        print(json.dumps(line))
+        line["csrc_sha256"] = sources_sha256()
+        if args.sidecar:
+            try:   # the FULL result (every leg with its prose) next to the script; stdout carries the compact form
+                Path(args.sidecar).write_text(json.dumps(line, indent=1) + "\n")
+                line["sidecar"] = os.path.relpath(args.sidecar, ROOT) if str(args.sidecar).startswith(str(ROOT)) else str(args.sidecar)
+            except OSError as e:
+                print("bench.py: sidecar not written: %s" % e, file=sys.stderr)
+        print(json.dumps(compact_line(line), separators=(",", ":")))
     ctx.close()
     ranks.close()
 
