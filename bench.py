@@ -890,7 +890,9 @@ def compact_line(full):
     else:
         line["cpu_baseline"] = None
     # ---- the legs
-    line["audio"] = _leg(full.get("audio"), "config4 256 streams x 100 frames, no FMA; sample pairs/s")
+    au = full.get("audio") or {}
+    line["audio"] = _leg(full.get("audio"), "%sMP2 synthesis, %s streams x %s frames per launch, no FMA; sample pairs/s" %
+                         ("config 4: " if au.get("streams") == 256 else "", au.get("streams"), au.get("frames_per_launch")))
     if line["audio"] and full["audio"].get("ranks", 1) > 1:
         line["audio"]["per_rank_value"] = full["audio"].get("per_rank_value")
     line["dense"] = _leg(full.get("dense"), "1080p dense worst case, MB/s")
@@ -1117,10 +1119,11 @@ def main(argv=None):
         }
         line["csrc_sha256"] = sources_sha256()
         if args.sidecar:
+            line["sidecar"] = os.path.relpath(args.sidecar, ROOT) if str(args.sidecar).startswith(str(ROOT)) else str(args.sidecar)
             try:   # the FULL result (every leg with its prose) next to the script; stdout carries the compact form
                 Path(args.sidecar).write_text(json.dumps(line, indent=1) + "\n")
-                line["sidecar"] = os.path.relpath(args.sidecar, ROOT) if str(args.sidecar).startswith(str(ROOT)) else str(args.sidecar)
             except OSError as e:
+                line["sidecar"] = None
                 print("bench.py: sidecar not written: %s" % e, file=sys.stderr)
         print(json.dumps(compact_line(line), separators=(",", ":")))
     ctx.close()

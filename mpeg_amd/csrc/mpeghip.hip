@@ -312,11 +312,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         if (!run)
             wave_lds_handoff();
         uint8_t *const img = rc_rgba_image(a, c);
-        if (run) {
+        if (run && rc_run_in_one_row(c)) {
 #pragma unroll
             for (uint32_t q = 0; q < 4; q++)
                 rc_rgba_run_rows(a, c, img, q, lane, lds);
-        } else {
+        } else { // (also a run that wraps a row end: its planes left as a run, its image rows are per macroblock)
 #pragma unroll
             for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++)
                 if (m < n_live)
@@ -513,8 +513,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             rc_store_run_luma(a, c, lane, lds);
         if (w == 1)
             rc_store_run_chroma(a, c, lane, lds);
-        if (kRgba && to_rgba)
-            rc_rgba_run_rows(a, c, rc_rgba_image(a, c), w, lane, lds);
+        if (kRgba && to_rgba) {
+            if (rc_run_in_one_row(c))
+                rc_rgba_run_rows(a, c, rc_rgba_image(a, c), w, lane, lds);
+            else // a run that wraps a row end: wave w converts macroblock w
+                by_wave([&](auto M) { rc_rgba_mb(a, c, rc_rgba_image(a, c), (uint32_t)decltype(M)::value, lane, lds); });
+        }
     } else if (w < n_live) {
         by_wave([&](auto M) {
             constexpr uint32_t m = (uint32_t)decltype(M)::value;

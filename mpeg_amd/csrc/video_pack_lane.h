@@ -354,7 +354,7 @@ MPG_HD void pk_emit(const PackArgs &a, const mpeghip_pic_desc &p, const PkPic &x
         ne += entsj;
         def_total += defj;
         any |= s[0];
-        run = run && (s[0] & kPkXRunOk) && (s[2] >> 16) == (q[2] >> 16) && (s[2] & 0xffffu) == (q[2] & 0xffffu) + j;
+        run = run && (s[0] & kPkXRunOk) && rc_run_follows(a.mb_w, q[2] & 0xffffu, q[2] >> 16, s[2] & 0xffffu, s[2] >> 16, j);
     }
     uint32_t *h = a.chunks + (size_t)(x.chunk_first + (k0 >> 2)) * kRcChunkDwords;
     uint32_t *d = h + kRcHeadDwords + m * kRcRecDwords;

@@ -1,7 +1,7 @@
 // video_recon_lane.h — the reconstruction kernel: device format, host-side packer, lane functions.
 //
 // One WAVE reconstructs a CHUNK = 4 consecutive macroblocks of one picture (normally 4 horizontal
-// neighbours) at a time — two consecutive chunks one after the other (mpeghip.hip) — with wave-private LDS and no barrier.  What the kernel reads is not the C ABI's arrays but
+// neighbours) — one chunk per wave (mpeghip.hip) — with wave-private LDS and no barrier.  What the kernel reads is not the C ABI's arrays but
 // the library's own device format, which the host half of the library (rc_pack_picture, called from the
 // validation pass of every submit / upload) writes straight into the buffer the H2D copy reads:
 //
@@ -61,19 +61,20 @@
 //   2  residual pass (8 coded blocks at a time): zero the wave's tile T[8][64]; one entry per lane:
 //      dequantise (video.go:719-744) and scatter to T[slot & 7][position]; an intra block's DC from its block word; lane
 //      (g, j): column j of block g, column pass, transposition, row j, row pass (+128 >> 8).  Dense units are dequantised
-//      straight from the words, two levels at a time on packed 16-bit halves.  The tile comes in two forms = two kernel
-//      instances (below: int16 + transposition across lanes, int32 + transposition through the tile).
+//      straight from the words, two levels at a time on packed 16-bit halves.  The tile is int16 in both kernel instances; they
+//      differ in the transposition between the two IDCT passes (below: across lanes by DPP / through LDS in two halves).
 //   3  motion compensation, per macroblock with WAVE-UNIFORM half-pel modes (video_noasm.go:48-80): luma
 //      by 64 lanes x 4 pixels, chroma by 32 lanes x 4 pixels, taps read from the window in LDS, result written
 //      over it (every lane has its taps before any lane writes): the macroblock's 384 output bytes O_m.
 //      Intra macroblocks put zeros.
 //   4  lane (g, j) adds its residual row to the 8 prediction bytes in O and clamps (video.go:943-971).
 //      (Passes 1, 2 of a chunk with more than 8 coded blocks repeat steps 2 and 4.)
-//   5  the four O_m leave as whole 64-byte luma / 32-byte chroma rows when the chunk is a horizontal run
-//      (kCRun), else as 8-byte rows per block; pictures flagged MPEGHIP_PIC_RGBA are colour-converted from them.
+//   5  the four O_m leave as 1 024 contiguous luma / 512 chroma bytes when the chunk is a run (kCRun: 4 macroblocks consecutive
+//      in raster order = 4 consecutive tiles, also across a row end), else as 8-byte rows per block; pictures flagged
+//      MPEGHIP_PIC_RGBA are colour-converted from them (4 macroblocks wide if the run sits in one row, else per macroblock).
 //
-// Wave-private LDS, 4 672 or 5 696 bytes (32 / 28 waves per CU = 8 / 7 per SIMD):
-//      [   0,  192) table    [ 192 + 864 m, + 864) window m -> O_m    [3648, 4672 / 5696) T
+// Wave-private LDS, 4 672 or 4 800 bytes (32 waves per CU = 8 per SIMD in both instances):
+//      [   0,  192) table    [ 192 + 864 m, + 864) window m -> O_m    [3648, 4672 / 4800) T (int16 tile / transposition buffer over it)
 #pragma once
 
 #include "video_lane.h"
@@ -305,6 +306,16 @@ MPG_HD uint32_t rc_header_flags(uint32_t n_slots, uint32_t live, bool any_raw, b
     return n_slots | (live << kHLiveShift) | (any_raw ? kHAnyRaw : 0u) | (any_dense ? kHAnyDense : 0u) | (any_dcword ? kHAnyDcWord : 0u) |
            (cur_slot << kHCurShift) | (stream << kHStreamShift);
 }
+// Is macroblock (x, y) the j-th tile behind the chunk's first macroblock (x0, y0)?  A RUN (kCRun) is 4 macroblocks whose tiles are
+// consecutive in the frame store: tiles lie in raster order, so the 4 neighbours of one row are a run — and so is a chunk that
+// wraps from the end of one macroblock row to the head of the next (mb_w % 4 != 0: SIF's 22, the golden streams' 10; until round 6
+// such a chunk — one in 5.5 at SIF, two in five at 160x120 — took the per-block stores).  The plane stores of a run are 1 024 + 512
+// contiguous bytes from h6 / h7 either way; only the fused colour conversion, which writes IMAGE rows, asks whether the run sits
+// in one row (rc_run_in_one_row).  One function for both packers.
+MPG_HD bool rc_run_follows(uint32_t mb_w, uint32_t x0, uint32_t y0, uint32_t x, uint32_t y, uint32_t j)
+{
+    return y * mb_w + x == y0 * mb_w + x0 + j;
+}
 // a chunk that does nothing (a refused device-packed commit; padding)
 MPG_HD void rc_make_dead_chunk(uint32_t *h)
 {
@@ -405,7 +416,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
         }
         uint32_t *e0 = bw + n_coded, ne = 0, counts = 0, pass_start = 0;
         bool any_raw = false, any_dense = false, any_dcword = false;
-        bool run = live == (uint32_t)kRcMbs; // 4 consecutive macroblocks of one row = 4 consecutive tiles
+        bool run = live == (uint32_t)kRcMbs; // 4 macroblocks consecutive in raster order = 4 consecutive tiles (rc_run_follows)
         for (uint32_t m = 0; m < (uint32_t)kRcMbs; m++) {
             uint32_t *d = h + kRcHeadDwords + m * kRcRecDwords;
             if (m >= live) { // padding behind the picture's last macroblock
@@ -422,7 +433,7 @@ static inline RcPacked rc_pack_picture(const RcGeom &g, const mpeghip_pic_desc &
                 for (int i = 0; i < kRcRecDwords; i++)
                     d[i] = rec[i];
             }
-            run = run && mb.mb_y == mbs[k0].mb_y && mb.mb_x == mbs[k0].mb_x + m &&
+            run = run && rc_run_follows(g.mb_w, mbs[k0].mb_x, mbs[k0].mb_y, mb.mb_x, mb.mb_y, m) &&
                   (!intra || mb.cbp == 0x3f); // an invalid intra block keeps the old pixels: no whole rows
             uint64_t unit = mb.coef_off;
             if (kSparseIn) { // a macroblock's data begins where the previous one's ended, or later (every macroblock's coef_off
@@ -634,6 +645,10 @@ MPG_HD bool rc_any_dcword(const RcChunk &c) { return (c.h[5] & kHAnyDcWord) != 0
 MPG_HD bool rc_any_special(const RcChunk &c) { return (c.h[5] & (kHAnyRaw | kHAnyDense | kHAnyDcWord)) != 0; }
 MPG_HD uint32_t rc_cur_slot(const RcChunk &c) { return (c.h[5] >> kHCurShift) & 3; }
 MPG_HD uint32_t rc_stream(const RcChunk &c) { return c.h[5] >> kHStreamShift; }
+// a run whose 4 macroblocks share a macroblock row (mb_y: the top byte of a record's first dword; a run's macroblocks are consecutive
+// in raster order, so first and last in one row = all in one row): the fused colour conversion may write its image rows 4
+// macroblocks wide.  A run that wraps a row end converts macroblock by macroblock.
+MPG_HD bool rc_run_in_one_row(const RcChunk &c) { return ((c.r[0][0] ^ c.r[kRcMbs - 1][0]) >> 24) == 0; }
 MPG_HD uint32_t rc_pass_entries(const RcChunk &c, uint32_t pass) { return (c.h[4] >> (10 * pass)) & 0x3ff; }
 // the wave's scalar bases: the stream's frames (moved back by kRcDmaBias: every offset below carries that bias) and the chunk's words
 MPG_HD uint8_t *rc_frame_base(const VideoArgs &a, const RcChunk &c) { return a.frames_b + c.off[0]; }
@@ -768,10 +783,18 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
 }
 
 // ---- step 1: the vector loads.  ONE scalar base for the chunk's words: its block words, then (n_slots dwords on) its entries
-MPG_HD uint32_t rc_ent_lane_offset(const RcChunk &c, uint32_t at, int lane) { return (rc_n_blocks(c) + at + (uint32_t)lane) * 4; } // bytes
+// (MPG_PROBE_ENTRY16, a TIMING-ONLY tool build — frames are wrong: lanes 2i and 2i + 1 fetch the same dword, so a wave's entry
+// loads touch half the bytes, as 16-bit entries would, at one extra shift and none of the work a real 16-bit form needs to find an
+// entry's block: the UPPER BOUND of what halving the entries can buy.  profiles/round6_b_*.)
+#ifdef MPG_PROBE_ENTRY16
+#define MPG_ENT_INDEX(at, lane) (((at) + (uint32_t)(lane)) >> 1)
+#else
+#define MPG_ENT_INDEX(at, lane) ((at) + (uint32_t)(lane))
+#endif
+MPG_HD uint32_t rc_ent_lane_offset(const RcChunk &c, uint32_t at, int lane) { return (rc_n_blocks(c) + MPG_ENT_INDEX(at, lane)) * 4; } // bytes
 MPG_HD const uint32_t *rc_ent_src(const VideoArgs &a, const RcChunk &c, uint32_t at, int lane)
 {
-    return rc_word_base(a, c) + rc_n_blocks(c) + at + (uint32_t)lane; // (beyond the pass's entries: ignored; the array is padded)
+    return rc_word_base(a, c) + rc_n_blocks(c) + MPG_ENT_INDEX(at, lane); // (beyond the pass's entries: ignored; the array is padded)
 }
 // The five direct-to-LDS loads of a wave, issued by lanes 0..53 in this order: the table (12 pieces), windows 0..3 (54
 // pieces each).  All 54 lanes take part in every one of them (one asm statement, one EXEC): the table's surplus lanes

@@ -408,11 +408,11 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
         }
         if (rgba_on) {
             uint8_t *img = rc_rgba_image(a, c);
-            if (run) {
+            if (run && rc_run_in_one_row(c)) {
                 for (uint32_t q = 0; q < 4; q++)
                     for (int lane = 0; lane < 64; lane++)
                         rc_rgba_run_rows(a, c, img, q, lane, lds);
-            } else {
+            } else { // (also a run that wraps a row end)
                 for (uint32_t m = 0; m < n_live; m++)
                     for (int lane = 0; lane < 64; lane++)
                         rc_rgba_mb(a, c, img, m, lane, lds);

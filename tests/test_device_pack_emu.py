@@ -253,3 +253,68 @@ def test_mutated_pictures_host_and_device_agree(emu):
             _compare_packed(host, dc, dw, 16)
             agreed_ok += 1
     assert agreed_bad >= 30 and agreed_ok >= 30, (agreed_bad, agreed_ok)
+
+
+K_CRUN = 1 << 30   # video_recon_lane.h: kCRun (header h4)
+
+
+def _chunk_positions(chunks):
+    """-> per chunk the (mb_x, mb_y) of its live records (record dword 0: mb_x << 16 | mb_y << 24; kRDead = 2)"""
+    out = []
+    for c in chunks:
+        recs = [int(c[8 + 6 * m]) for m in range(4)]
+        out.append([((r >> 16) & 0xff, r >> 24) for r in recs if not (r & 2)])
+    return out
+
+
+@pytest.mark.parametrize("w,h", [(352, 240), (160, 120), (176, 144)])   # mb_w = 22, 10, 11: not multiples of the chunk's 4
+@pytest.mark.parametrize("rgba", [False, True])
+def test_a_chunk_that_wraps_a_row_end_is_a_run(oracle, emu, w, h, rgba):
+    """Tiles lie in raster order in the frame store, so 4 macroblocks consecutive in raster order are 4 consecutive tiles also when
+    the chunk starts at the end of one macroblock row and ends in the next: both packers flag it kCRun (rc_run_follows — until
+    round 6 only chunks inside one row were runs; at SIF one chunk in 5.5 took the per-block stores), the planes leave as 1 024 +
+    512 contiguous bytes, and the fused colour conversion of such a chunk goes macroblock by macroblock (rc_run_in_one_row)."""
+    g, stride, rgba_stride = _geom(emu, w, h)
+    mb_w = g["luma_w"] // 16
+    seq = synth.generate_sequence(w, h, 4, profile="typical", rgba=rgba, seed=0x77)
+    wrapped_runs = 0
+    for s in seq:
+        mbs, words = desc.to_sparse(s.mbs, s.coefs)
+        host = emu.pack_sparse_host(g, stride, rgba_stride, s.pics[0], mbs, words)
+        err, dc, dw, _ = emu.pack_sparse_device(g, stride, rgba_stride, s.pics[0], mbs, words)
+        assert host is not None and err == NO_ERROR
+        _compare_packed(host, dc, dw, 0)
+        for c, pos in zip(host[0], _chunk_positions(host[0])):
+            if len(pos) < 4:
+                continue
+            raster = [y * mb_w + x for x, y in pos]
+            consecutive = raster == list(range(raster[0], raster[0] + 4))
+            wraps = pos[0][1] != pos[3][1]
+            if bool(int(c[4]) & K_CRUN):
+                assert consecutive                          # a run's tiles are consecutive, in one row or across a row end
+                wrapped_runs += wraps
+            if consecutive and s.picture_type != desc.PIC_I:
+                # predicted macroblocks write all their blocks: every such chunk is a run (an intra macroblock with an invalid block is not)
+                intra = [int(c[8 + 6 * m]) & 1 for m in range(4)]
+                cbp = [(int(c[8 + 6 * m]) >> 8) & 0x3f for m in range(4)]
+                assert bool(int(c[4]) & K_CRUN) == all((not i) or b == 0x3f for i, b in zip(intra, cbp))
+    assert wrapped_runs > 0
+    # ... and the pictures reconstruct like the oracle's, planes and RGBA, through both packers and both kernel instances
+    for device_pack in (0, 1):
+        emu.set_device_pack(device_pack)
+        try:
+            for tile in (1, 2):
+                emu.set_tile_policy(tile)
+                ref, dut = oracle.OracleStore(w, h), emu.EmuStore(w, h)
+                for i, s in enumerate(seq):
+                    mbs, words = desc.to_sparse(s.mbs, s.coefs)
+                    ref.submit(s.pics, s.mbs, s.coefs)
+                    dut.submit_sparse(s.pics[0], mbs, words)
+                    for slot in range(3):
+                        for a, b in zip(ref.read_planes(0, slot), dut.read_planes(0, slot)):
+                            assert np.array_equal(a, b), (device_pack, tile, i, slot)
+                    if rgba:
+                        assert np.array_equal(ref.read_rgba(0, s.cur), dut.read_rgba(0, s.cur)), (device_pack, tile, i)
+        finally:
+            emu.set_tile_policy(0)
+            emu.set_device_pack(0)

@@ -34,6 +34,36 @@ def test_reconstruction_bit_exact(oracle, hip_ctx, w, h, n, profile, raw, rgba, 
         ref.close()
 
 
+@pytest.mark.parametrize("w,h", [(352, 240), (160, 120)])                       # mb_w = 22, 10: a row's last chunk carries on into the next row
+@pytest.mark.parametrize("rgba", [False, True], ids=["planes", "rgba_fused"])
+@pytest.mark.parametrize("policy", [0, 1, 2], ids=["auto_wide", "pinned_dpp", "pinned_lds"])
+def test_runs_across_row_ends(oracle, hip_ctx, w, h, rgba, policy):
+    """A chunk whose 4 macroblocks are consecutive in raster order across a row end is a run for the plane stores (round 6:
+    rc_run_follows) and converts to RGBA macroblock by macroblock (rc_run_in_one_row): all three kernels (recon_wide_kernel, both
+    recon_kernel instances), host-packed units and device-packed sparse pictures, against the oracle."""
+    seq = synth.generate_sequence(w, h, 7, profile="typical", rgba=rgba, seed=0x77)
+    ref, units, packed = oracle.OracleStore(w, h), abi.VideoStore(hip_ctx, w, h), abi.VideoStore(hip_ctx, w, h)
+    units.set_tile_policy(policy)
+    packed.set_tile_policy(policy)
+    try:
+        for i, s in enumerate(seq):
+            ref.submit(s.pics, s.mbs, s.coefs)
+            units.submit(s.pics, s.mbs, s.coefs)
+            mbs, words = desc.to_sparse(s.mbs, s.coefs)
+            packed.submit_staged_device([(s.pics[0], mbs, words)])
+            for slot in range(3):
+                want = ref.read_planes(0, slot)
+                assert_planes_equal(want, units.read_planes(0, slot), "units, picture %d slot %d" % (i, slot))
+                assert_planes_equal(want, packed.read_planes(0, slot), "device-packed, picture %d slot %d" % (i, slot))
+            if rgba:
+                want = ref.read_rgba(0, s.cur)
+                assert np.array_equal(want, units.read_rgba(0, s.cur)) and np.array_equal(want, packed.read_rgba(0, s.cur)), i
+    finally:
+        units.close()
+        packed.close()
+        ref.close()
+
+
 def test_custom_quant_matrices(oracle, hip_ctx):
     rng = np.random.default_rng(5)
     iq, nq = rng.integers(1, 256, 64), rng.integers(1, 256, 64)

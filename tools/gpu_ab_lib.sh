@@ -16,7 +16,7 @@ for r in $(seq 1 $ROUNDS); do
 import json
 try:
     d = json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1])
-    print("round $r %-10s $prof: %.4g MB/s  frac %.4f  launch %.3f ms  %s" % ("$which", d['value'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['parity']))
+    print("round $r %-10s $prof: %.4g MB/s  frac %.4f  launch %.3f ms  %s" % ("$which", d['value'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d.get('parity', d.get('parity_ok'))))
 except Exception as e:
     print("round $r $which $prof: FAILED", e)
 PY
