@@ -36,7 +36,10 @@ extern "C" {
 
 /* 2: the sparse hand-over's snapshot blocks carry a count word, a sparse picture's macroblocks name their words in order;
  *    the device-packed stage (mpeghip_video_stage_begin_device) and its deferred errors; chroma as Cb|Cr pairs in device memory */
-#define MPEGHIP_ABI_VERSION 2
+/* 3: (round 6) asynchronous read-back and synthesis for a lone decoder that works one picture / frame ahead —
+ *    mpeghip_video_read_planes_async / _read_wait, mpeghip_audio_synth_async / _synth_wait / _undo_last — and
+ *    mpeghip_ctx_pci_bus_id (added during round 5 without a bump).  Nothing of version 2 changed. */
+#define MPEGHIP_ABI_VERSION 3
 
 #define MPEGHIP_OK             0
 #define MPEGHIP_ERR_INVALID   (-1) /* bad argument / malformed descriptor            */
@@ -353,6 +356,15 @@ uint64_t mpeghip_video_batch_device_bytes(const mpeghip_batch *b);
  * NULL. */
 int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
                               uint8_t *y, uint8_t *cb, uint8_t *cr);
+/* The same read-back, ASYNCHRONOUS (ABI 3; replaces nothing in the reference — it is what lets the Go shim's Video.Decode,
+ * video.go:209-268, parse picture N+1 while picture N is on the device): queued behind everything submitted so far, the
+ * planes of (stream, slot) as they are at that point land in `dst` — luma | Cb | Cr in the reference's linear layout,
+ * luma_bytes + 2 * chroma_bytes — and the call returns at once.  `dst` should be memory of mpeghip_pinned_alloc (the untiling
+ * kernel then stores straight into it; other memory works through a copy).  *ticket names the read-back;
+ * mpeghip_video_read_wait(ticket) blocks until it is in `dst` (and reports a deferred device-packed verdict, like every
+ * synchronising call).  Read-backs complete in the order they were queued. */
+int mpeghip_video_read_planes_async(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *dst, uint64_t *ticket);
+int mpeghip_video_read_wait(mpeghip_video *v, uint64_t ticket);
 int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
                                const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
                                const uint8_t *pad);
@@ -428,6 +440,16 @@ int mpeghip_audio_device_buffers(mpeghip_audio *a, uint32_t n_frames, int format
                                  int32_t **d_samples, void **d_out);
 int mpeghip_audio_upload(mpeghip_audio *a, int32_t *d_dst, const int32_t *src, size_t n_ints);
 int mpeghip_audio_download(mpeghip_audio *a, void *dst, const void *d_src, size_t bytes);
+/* mpeghip_audio_synth, ASYNCHRONOUS (ABI 3; what lets the Go shim's Audio.Decode, audio.go:163-182, parse frame N+1 while
+ * frame N is synthesised): `samples` and `out` laid out as for mpeghip_audio_synth, in memory of mpeghip_pinned_alloc that
+ * stays untouched until mpeghip_audio_synth_wait(ticket) returns (the kernel reads and writes pinned memory in place; other
+ * memory works through copies).  Launches run in the order they were queued. */
+int mpeghip_audio_synth_async(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames, int format, void *out, uint64_t *ticket);
+int mpeghip_audio_synth_wait(mpeghip_audio *a, uint64_t ticket);
+/* Forget the LAST launch: every stream's V ring and vPos are again what they were before it (one level).  For a decoder that
+ * synthesised one frame ahead and is rewound: the reference's ring (never cleared by Rewind, audio.go:149-154) is what the
+ * frames it RETURNED left behind. */
+int mpeghip_audio_undo_last(mpeghip_audio *a);
 /* V ring + vPos of one stream: v[2][1024] float32, vpos in [0,1024) multiple of 64.
  * set_state takes what get_state returned (or zeros): every 64-entry slot of Audio.v is idct36's
  * signed mirror of 32 DCT outputs (audio.go:708-771: d[48-k] == d[48+k], d[k-16] == -d[48-k],

@@ -55,7 +55,16 @@ void mpeghost_set_default_sparse(int sparse);
 uint64_t mpeghost_debug_vlc_self_check(void);
 int mpeghost_video_decode(void *video, mpeghost_frame *out);         /* 1 frame, 0 none / end, -1 error */
 const uint8_t *mpeghost_video_rgba(void *video);                     /* Frame.RGBA() of the last decoded frame */
+double mpeghost_video_time(void *video);                             /* video.go:183: the time of the next frame */
+int mpeghost_video_has_ended(void *video);                           /* video.go:203 */
+void mpeghost_video_rewind(void *video);                             /* video.go:195 */
+/* Video.Decode works one picture ahead on the host (parse of picture N+1 while picture N is on the device; that picture's work
+ * is held back until the next call, so Rewind / Seek see the reference's state).  0 switches it off: parse, submit, read back. */
+void mpeghost_video_set_lookahead(void *video, int on);
 void mpeghost_video_stats(void *video, uint64_t out[8]);
+/* wall seconds of the decoder's three host phases so far: [0] bitstream parse, [1] hand-over of the pictures' work (submit),
+ * [2] waiting for / copying frames back */
+void mpeghost_video_phase_seconds(void *video, double out[3]);
 
 /* ---- Audio (audio.go:83 NewAudio, :163 Decode); format: 0 F32N, 1 F32NLR, 2 F32, 3 S16 (audio.go:12-23) */
 void *mpeghost_audio_open(void *device, const uint8_t *data, size_t len, int fma_mode, int format);
@@ -64,6 +73,10 @@ void mpeghost_audio_close(void *audio);
 int mpeghost_audio_samplerate(void *audio);
 int mpeghost_audio_channels(void *audio);
 const void *mpeghost_audio_decode(void *audio, double *time);        /* 2304 samples of the format, or NULL at the end */
+double mpeghost_audio_time(void *audio);                             /* audio.go:136 */
+int mpeghost_audio_has_ended(void *audio);                           /* audio.go:156 */
+void mpeghost_audio_rewind(void *audio);                             /* audio.go:149: the V ring stays */
+void mpeghost_audio_set_lookahead(void *audio, int on);              /* Audio.Decode's one frame ahead (as the video decoder's) */
 
 /* ---- MPEG (mpeg.go:85 New over a program stream, :356 Decode, :416 DecodeVideo, :438 DecodeAudio, :460/:524 seeks) */
 void *mpeghost_mpeg_open(void *device, const uint8_t *data, size_t len);

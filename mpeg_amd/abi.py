@@ -14,7 +14,7 @@ from . import desc
 from ._build import LIBMPEGHIP
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RANGE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 2  # include/mpeghip.h: MPEGHIP_ABI_VERSION this binding was written against (checked at load)
+ABI_VERSION = 3  # include/mpeghip.h: MPEGHIP_ABI_VERSION this binding was written against (checked at load)
 
 
 class MpegHipError(RuntimeError):
@@ -70,6 +70,8 @@ SYMBOLS = {
     "mpeghip_video_batch_mbs": (C.c_uint64, [_P]),
     "mpeghip_video_batch_device_bytes": (C.c_uint64, [_P]),
     "mpeghip_video_read_planes": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "mpeghip_video_read_planes_async": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
+    "mpeghip_video_read_wait": (C.c_int, [_P, C.c_uint64]),
     "mpeghip_video_write_planes": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "mpeghip_video_broadcast_slot": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mpeghip_video_hash_slots": (C.c_int, [_P, C.c_uint32, _P]),
@@ -82,6 +84,9 @@ SYMBOLS = {
     "mpeghip_audio_synth": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P]),
     "mpeghip_audio_synth_masked": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, _P]),
     "mpeghip_audio_synth_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P]),
+    "mpeghip_audio_synth_async": (C.c_int, [_P, _P, C.c_uint32, C.c_int, _P, C.POINTER(C.c_uint64)]),
+    "mpeghip_audio_synth_wait": (C.c_int, [_P, C.c_uint64]),
+    "mpeghip_audio_undo_last": (C.c_int, [_P]),
     "mpeghip_audio_device_buffers": (C.c_int, [_P, C.c_uint32, C.c_int, C.POINTER(_P), C.POINTER(_P)]),
     "mpeghip_audio_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mpeghip_audio_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -153,10 +158,33 @@ class Context:
         _check(self.lib.mpeghip_timer_stop_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def pinned(self, nbytes: int) -> "PinnedBuffer":
+        """Pinned host memory of the context (mpeghip_pinned_alloc) as a numpy view: what the asynchronous entries read and write."""
+        return PinnedBuffer(self, nbytes)
+
     def close(self):
         if self.h:
             self.lib.mpeghip_ctx_destroy(self.h)
             self.h = None
+
+
+class PinnedBuffer:
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = ctx.lib.mpeghip_pinned_alloc(ctx.h, self.nbytes)
+        if not p:
+            raise MpegHipError(ERR_INVALID, ctx.lib.mpeghip_last_error().decode(errors="replace"))
+        self.ptr = C.c_void_p(p)
+        self.u8 = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(self.nbytes,))
+
+    def view(self, dtype):
+        return self.u8.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.u8 = None
+            self.ctx.lib.mpeghip_pinned_free(self.ctx.h, self.ptr)
+            self.ptr = None
 
 
 class Batch:
@@ -321,6 +349,20 @@ class VideoStore:
         _check(self.lib.mpeghip_video_read_planes(self.h, stream, slot, _ptr(y), _ptr(cb), _ptr(cr)))
         return y, cb, cr
 
+    def read_planes_async(self, stream: int, slot: int, pinned: "PinnedBuffer") -> int:
+        """Queue the read-back of (stream, slot) into `pinned` (Context.pinned: luma | Cb | Cr, linear) -> ticket."""
+        assert pinned.nbytes >= self.info.luma_bytes + 2 * self.info.chroma_bytes
+        t = C.c_uint64()
+        _check(self.lib.mpeghip_video_read_planes_async(self.h, stream, slot, pinned.ptr, C.byref(t)))
+        return t.value
+
+    def read_wait(self, ticket: int):
+        _check(self.lib.mpeghip_video_read_wait(self.h, ticket))
+
+    def split_planes(self, flat):
+        L, Cb = self.info.luma_bytes, self.info.chroma_bytes
+        return flat[:L], flat[L:L + Cb], flat[L + Cb:L + 2 * Cb]
+
     def write_planes(self, stream: int, slot: int, y, cb, cr, pad=None):
         y, cb, cr = (np.ascontiguousarray(a, np.uint8) for a in (y, cb, cr))
         pad = None if pad is None else np.ascontiguousarray(pad, np.uint8)
@@ -369,6 +411,18 @@ class AudioSynth:
         out = np.empty((self.n_streams, n_frames, 2304), self.out_dtype(fmt))
         _check(self.lib.mpeghip_audio_synth(self.h, _ptr(s), n_frames, fmt, _ptr(out)))
         return out
+
+    def synth_async(self, pinned_in: "PinnedBuffer", n_frames: int, fmt: int, pinned_out: "PinnedBuffer") -> int:
+        """Queue the synthesis of the samples in `pinned_in` (int32 [n_streams, n_frames, 2, 36, 32]) into `pinned_out` -> ticket."""
+        t = C.c_uint64()
+        _check(self.lib.mpeghip_audio_synth_async(self.h, pinned_in.ptr, n_frames, fmt, pinned_out.ptr, C.byref(t)))
+        return t.value
+
+    def synth_wait(self, ticket: int):
+        _check(self.lib.mpeghip_audio_synth_wait(self.h, ticket))
+
+    def undo_last(self):
+        _check(self.lib.mpeghip_audio_undo_last(self.h))
 
     def synth_masked(self, samples: np.ndarray, active, fmt: int = desc.AUDIO_F32N, out=None) -> np.ndarray:
         """Like synth() for the streams with active[i] != 0; the others keep their state and their rows of `out`."""

@@ -894,6 +894,10 @@ struct mpeghip_video {
     uint8_t *bounce = nullptr;             // pinned: read_planes / read_rgba land here first
     size_t bounce_cap = 0;
     uint8_t *d_linear = nullptr;           // one slot's planes in the reference's linear layout (read / write_planes)
+    // mpeghip_video_read_planes_async: tickets count the read-backs queued; ticket t's event is read_done[t % 4] (events complete
+    // in stream order, so a slot that a later read-back has taken over answers for the earlier one too)
+    hipEvent_t read_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t reads_issued = 0;
     int tile_policy = MPEGHIP_TILE_AUTO;   // mpeghip_video_set_tile_policy
     int n_cu = 256;                        // compute units of the device (asked once, at open)
 };
@@ -943,6 +947,10 @@ struct mpeghip_audio {
     size_t cap_samples = 0, cap_out = 0;
     uint8_t *d_active = nullptr;   // [n_streams] mask of mpeghip_audio_synth_masked
     int n_cu = 256;                // compute units of the device (asked once, at open)
+    // mpeghip_audio_synth_async: ticket t's event is synth_done[t % 4] (stream order: a later one answers for an earlier one)
+    hipEvent_t synth_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t synths_issued = 0;
+    bool can_undo = false;         // exactly one launch since the state in the alternate buffers was current (mpeghip_audio_undo_last)
 };
 
 static const uint8_t k_default_intra[64] = { // ISO 11172-2 default intra matrix (video.go:1055-1064)
@@ -1224,6 +1232,9 @@ void mpeghip_video_close(mpeghip_video *v)
         (void)hipHostFree(v->bounce);
     if (v->d_linear)
         (void)hipFree(v->d_linear);
+    for (auto &e : v->read_done)
+        if (e)
+            (void)hipEventDestroy(e);
     for (auto &sg : v->staging) {
         batch_release(&sg.batch);
         if (sg.d_raw)
@@ -2667,6 +2678,48 @@ int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, 
     return MPEGHIP_OK;
 }
 
+// ---- the asynchronous read-back (ABI 3): what lets a lone decoder parse picture N + 1 while picture N is on the device
+int mpeghip_video_read_planes_async(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *dst, uint64_t *ticket)
+{
+    if (!v || !dst || !ticket || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
+        return fail(MPEGHIP_ERR_INVALID, "read_planes_async: bad argument");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    hipStream_t st = v->ctx->stream;
+    const size_t bytes = v->info.luma_bytes + 2 * v->info.chroma_bytes;
+    // `dst` is pinned memory of mpeghip_pinned_alloc: the untiling kernel stores the linear planes straight into it (the device
+    // sees pinned host memory) — ONE launch, no copy call; any other memory takes the untile + copy of mpeghip_video_read_planes
+    void *d_dst = nullptr;
+    if (hipHostGetDevicePointer(&d_dst, dst, 0) == hipSuccess && d_dst) {
+        hipLaunchKernelGGL(relayout_kernel, dim3(((uint32_t)bytes / 4 + 255) / 256), dim3(256), 0, st, slot_ptr(v, stream, slot),
+                           static_cast<uint8_t *>(d_dst), 0u, (uint32_t)bytes, v->info.mb_w, (uint32_t)v->info.luma_bytes,
+                           (uint32_t)v->info.chroma_bytes, 1);
+        HIP_TRY(hipGetLastError());
+    } else {
+        (void)hipGetLastError();
+        int rc = ensure_linear(v);
+        if (rc != MPEGHIP_OK)
+            return rc;
+        launch_relayout(v, slot_ptr(v, stream, slot), 0, (uint32_t)bytes, 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(dst, v->d_linear, bytes, hipMemcpyDeviceToHost, st));
+    }
+    hipEvent_t &ev = v->read_done[v->reads_issued & 3];
+    if (!ev)
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, st));
+    *ticket = v->reads_issued++;
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_read_wait(mpeghip_video *v, uint64_t ticket)
+{
+    if (!v || ticket >= v->reads_issued)
+        return fail(MPEGHIP_ERR_INVALID, "read_wait: no such read-back");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    HIP_TRY(hipEventSynchronize(v->read_done[ticket & 3])); // (this read-back's event, or a later one's: both say it is done)
+    return reap_all(v); // a device-packed commit that was refused: the caller learns it here at the latest
+}
+
 int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot, const uint8_t *y, const uint8_t *cb,
                                const uint8_t *cr, const uint8_t *pad)
 {
@@ -2828,6 +2881,9 @@ void mpeghip_audio_close(mpeghip_audio *a)
             (void)hipFree(p);
     if (a->d_active)
         (void)hipFree(a->d_active);
+    for (auto &e : a->synth_done)
+        if (e)
+            (void)hipEventDestroy(e);
     delete a;
 }
 
@@ -2926,6 +2982,7 @@ static int audio_launch(mpeghip_audio *a, const int32_t *d_samples, uint32_t n_f
     }
 #undef LAUNCH_AUDIO
     HIP_TRY(hipGetLastError());
+    a->can_undo = true;
     { // the launch wrote the new state into the alternate buffers
         float *r = a->d_ring;
         a->d_ring = a->d_ring_alt;
@@ -2974,6 +3031,75 @@ int mpeghip_audio_synth_masked(mpeghip_audio *a, const int32_t *samples, uint32_
     return MPEGHIP_OK;
 }
 
+// ---- asynchronous synthesis (ABI 3): a lone Audio decoder parses frame N + 1 while frame N is on the device.  `samples` and `out`
+// are pinned memory of mpeghip_pinned_alloc; the kernel reads and writes them in place (the device sees pinned host memory): one
+// launch, no copy calls.  Other memory: staged through the handle's device buffers with asynchronous copies.
+int mpeghip_audio_synth_async(mpeghip_audio *a, const int32_t *samples, uint32_t n_frames, int format, void *out, uint64_t *ticket)
+{
+    if (!a || !samples || !out || !ticket || n_frames == 0 || format < 0 || format > MPEGHIP_AUDIO_S16)
+        return fail(MPEGHIP_ERR_INVALID, "synth_async: bad argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    hipStream_t st = a->ctx->stream;
+    const size_t n = (size_t)a->n_streams * n_frames * MPEGHIP_AUDIO_FRAME_INTS;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if (hipHostGetDevicePointer(&d_in, const_cast<int32_t *>(samples), 0) == hipSuccess && d_in &&
+        hipHostGetDevicePointer(&d_out, out, 0) == hipSuccess && d_out) {
+        rc = audio_launch(a, static_cast<const int32_t *>(d_in), n_frames, format, d_out, nullptr);
+        if (rc != MPEGHIP_OK)
+            return rc;
+    } else {
+        (void)hipGetLastError();
+        if (a->cap_samples < n * sizeof(int32_t) || a->cap_out < n * audio_elem_size(format)) { // (grows: waits for what is queued)
+            int32_t *ds;
+            void *dout;
+            if ((rc = mpeghip_audio_device_buffers(a, n_frames, format, &ds, &dout)) != MPEGHIP_OK)
+                return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(a->d_samples, samples, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        rc = audio_launch(a, a->d_samples, n_frames, format, a->d_out, nullptr);
+        if (rc != MPEGHIP_OK)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(out, a->d_out, n * audio_elem_size(format), hipMemcpyDeviceToHost, st));
+    }
+    hipEvent_t &ev = a->synth_done[a->synths_issued & 3];
+    if (!ev)
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, st));
+    *ticket = a->synths_issued++;
+    return MPEGHIP_OK;
+}
+
+int mpeghip_audio_synth_wait(mpeghip_audio *a, uint64_t ticket)
+{
+    if (!a || ticket >= a->synths_issued)
+        return fail(MPEGHIP_ERR_INVALID, "synth_wait: no such launch");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipEventSynchronize(a->synth_done[ticket & 3]));
+    return MPEGHIP_OK;
+}
+
+// Forget the LAST launch: the synthesis state (V ring, vPos of every stream) is again what it was before it — a launch writes the
+// new state into the alternate buffers, so the old one is still there.  For a decoder that synthesised one frame ahead and is
+// told to rewind: the reference (audio.go:149-154) keeps the ring as the frames it RETURNED left it.  One level only.
+int mpeghip_audio_undo_last(mpeghip_audio *a)
+{
+    if (!a)
+        return fail(MPEGHIP_ERR_INVALID, "NULL argument");
+    if (!a->can_undo)
+        return fail(MPEGHIP_ERR_INVALID, "undo_last: no launch to undo (one level only)");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    float *r = a->d_ring;
+    a->d_ring = a->d_ring_alt;
+    a->d_ring_alt = r;
+    int32_t *vp = a->d_vpos;
+    a->d_vpos = a->d_vpos_alt;
+    a->d_vpos_alt = vp;
+    a->can_undo = false;
+    return MPEGHIP_OK;
+}
+
 int mpeghip_audio_get_state(mpeghip_audio *a, uint32_t stream, float *v, int32_t *vpos)
 {
     if (!a || stream >= a->n_streams)
@@ -3005,6 +3131,7 @@ int mpeghip_audio_set_state(mpeghip_audio *a, uint32_t stream, const float *v, i
             }
     }
     HIP_TRY(hipSetDevice(a->ctx->device));
+    a->can_undo = false; // (the state is the caller's from here on)
     HIP_TRY(hipStreamSynchronize(a->ctx->stream));
     if (v)
         HIP_TRY(hipMemcpy(a->d_ring + (size_t)stream * 2048, v, 2048 * sizeof(float), hipMemcpyHostToDevice));

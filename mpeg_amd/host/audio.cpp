@@ -41,17 +41,27 @@ const Audio::QuantizerSpec Audio::quant_tab_[17] = {
 
 Audio::Audio(Buffer *buf, Device *dev, int fma_mode) : buf_(buf), backend_(dev->newAudioBackend(fma_mode)) { init(); }
 Audio::Audio(Buffer *buf, std::unique_ptr<AudioBackend> backend) : buf_(buf), backend_(std::move(backend)) { init(); }
-Audio::~Audio() {}
+Audio::~Audio()
+{
+    for (int32_t *p : in_)
+        if (p)
+            backend_->freeSamples(p);
+}
 
 void Audio::init()
 { // audio.go:83-104
     samplerate_index_ = 3;
-    samples_.S16.assign(SamplesPerFrame * 2, 0);
-    samples_.F32.assign(SamplesPerFrame * 2, 0);
-    samples_.Left.assign(SamplesPerFrame, 0);
-    samples_.Right.assign(SamplesPerFrame, 0);
-    samples_.Interleaved.assign(SamplesPerFrame * 2, 0);
-    memset(frame_samples_, 0, sizeof(frame_samples_));
+    for (int i = 0; i < 2; i++) {
+        Samples &sm = samples_[i];
+        sm.S16.assign(SamplesPerFrame * 2, 0);
+        sm.F32.assign(SamplesPerFrame * 2, 0);
+        sm.Left.assign(SamplesPerFrame, 0);
+        sm.Right.assign(SamplesPerFrame, 0);
+        sm.Interleaved.assign(SamplesPerFrame * 2, 0);
+        in_[i] = backend_->allocSamples();
+        if (!in_[i])
+            throw std::bad_alloc();
+    }
     next_frame_data_size_ = decodeHeader();
 }
 
@@ -69,10 +79,17 @@ void Audio::SetTime(double t)
 { // audio.go:143-146
     samples_decoded_ = (int)(t * (double)kSamplerate[samplerate_index_]);
     time_ = t;
+    if (ahead_valid_) { // (a frame parsed ahead is the next one the reference would decode: it carries the new time)
+        ahead_time_ = time_;
+        samples_decoded_ += SamplesPerFrame;
+        time_ = (double)samples_decoded_ / (double)kSamplerate[samplerate_index_];
+    }
 }
 
 void Audio::Rewind()
 { // audio.go:149-154 — the V ring and vPos are NOT cleared, exactly like the reference
+    ahead_tried_ = false;
+    ahead_valid_ = ahead_failed_ = false; // a frame parsed ahead was never synthesised: the ring is what the frames RETURNED left behind
     buf_->Rewind();
     time_ = 0;
     samples_decoded_ = 0;
@@ -97,18 +114,70 @@ const uint8_t *Samples::Bytes(size_t *len) const
     }
 }
 
-Samples *Audio::Decode()
-{ // audio.go:163-182
+bool Audio::parseNext(int *buf, double *time)
+{ // audio.go:163-182, up to the synthesis
     if (next_frame_data_size_ == 0)
         next_frame_data_size_ = decodeHeader();
     if (next_frame_data_size_ == 0 || !buf_->has((size_t)next_frame_data_size_ << 3))
-        return nullptr;
-    decodeFrame();
+        return false;
+    const int b = in_next_;
+    in_next_ ^= 1;
+    decodeFrame(reinterpret_cast<int32_t(*)[36][32]>(in_[b]));
     next_frame_data_size_ = 0;
-    samples_.Time = time_;
+    *buf = b;
+    *time = time_;
     samples_decoded_ += SamplesPerFrame;
     time_ = (double)samples_decoded_ / (double)kSamplerate[samplerate_index_];
-    return &samples_;
+    return true;
+}
+
+Samples *Audio::Decode()
+{ // audio.go:163-182, one frame ahead on the host (mpeg.hpp)
+    int b;
+    double t;
+    ahead_tried_ = false;
+    if (ahead_failed_) { // the attempt this call stands for has been made (and has consumed what it consumed): it found no frame
+        ahead_failed_ = false;
+        return nullptr;
+    }
+    if (ahead_valid_) { // parsed during the previous call
+        b = ahead_buf_;
+        t = ahead_time_;
+        ahead_valid_ = false;
+    } else if (!parseNext(&b, &t)) {
+        return nullptr;
+    }
+    // synthesis of the whole frame on the device (audio.go:378-422): queued now, waited for after the next frame's parse
+    static const int kFormat[] = {MPEGHIP_AUDIO_F32N, MPEGHIP_AUDIO_F32NLR, MPEGHIP_AUDIO_F32, MPEGHIP_AUDIO_S16};
+    const int fmt = format_ == AudioF32N ? kFormat[0] : format_ == AudioF32NLR ? kFormat[1] : format_ == AudioF32 ? kFormat[2] : kFormat[3];
+    const uint64_t ticket = backend_->synthAsync(in_[b], fmt);
+    if (lookahead_) {
+        // An attempt that fails for lack of data consumes nothing and is simply made again by the next call, which then sees what
+        // the reference's call would see.  One that fails on a bad header HAS consumed bits (decodeHeader's hunt for a frame sync,
+        // audio.go:184-272): it is the next call's attempt, made early — that call returns nil and does not hunt again.
+        const size_t before = buf_->bitIndex();
+        ended_before_ahead_ = buf_->HasEnded();
+        ahead_tried_ = true;
+        ahead_valid_ = parseNext(&ahead_buf_, &ahead_time_);
+        ahead_failed_ = !ahead_valid_ && next_frame_data_size_ == 0 && buf_->bitIndex() != before;
+    }
+    Samples &sm = samples_[b];
+    switch (format_) {
+    case AudioF32N:
+        backend_->synthWait(ticket, sm.Interleaved.data(), nullptr);
+        break;
+    case AudioF32NLR:
+        backend_->synthWait(ticket, sm.Left.data(), sm.Right.data());
+        break;
+    case AudioS16:
+        backend_->synthWait(ticket, sm.S16.data(), nullptr);
+        break;
+    case AudioF32:
+        backend_->synthWait(ticket, sm.F32.data(), nullptr);
+        break;
+    }
+    sm.Time = t;
+    return &sm;
 }
 
 int Audio::decodeHeader()
@@ -198,7 +267,7 @@ void Audio::readSamples(int ch, int sb, int part)
     }
 }
 
-void Audio::decodeFrame()
+void Audio::decodeFrame(int32_t (*frame_samples_)[36][32])
 { // audio.go:274-427
     const int tab1 = mode_ == kModeMono ? 0 : 1;
     const int tab2 = kQuantLutStep1[tab1][bitrate_index_];
@@ -276,21 +345,6 @@ void Audio::decodeFrame()
     }
     buf_->align();
 
-    // Synthesis of the whole frame on the device (audio.go:378-422)
-    switch (format_) {
-    case AudioF32N:
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32N, samples_.Interleaved.data(), nullptr);
-        break;
-    case AudioF32NLR:
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32NLR, samples_.Left.data(), samples_.Right.data());
-        break;
-    case AudioS16:
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_S16, samples_.S16.data(), nullptr);
-        break;
-    case AudioF32:
-        backend_->synth(&frame_samples_[0][0][0], MPEGHIP_AUDIO_F32, samples_.F32.data(), nullptr);
-        break;
-    }
 }
 
 } // namespace mpeg

@@ -677,6 +677,7 @@ Audio *AudioBatch::AddStream(Buffer *buf)
         throw std::runtime_error("AudioBatch: more streams than the batch was opened for");
     const uint32_t idx = (uint32_t)audios_.size();
     audios_.emplace_back(new Audio(buf, std::unique_ptr<AudioBackend>(new Port(this, idx))));
+    audios_.back()->SetLookahead(false); // (a tick parses ONE frame of every stream: the batch is the overlap)
     audios_.back()->SetFormat(format_);
     return audios_.back().get();
 }

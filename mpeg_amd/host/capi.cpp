@@ -154,6 +154,25 @@ void mpeghost_video_stats(void *hv, uint64_t out[8])
     out[7] = s.range_skips;
 }
 
+// video.go:178-201 on a lone decoder: Time / Rewind / HasEnded, and the look-ahead switch of Video::Decode
+double mpeghost_video_time(void *h) { return static_cast<VideoHandle *>(h)->video->Time(); }
+int mpeghost_video_has_ended(void *h) { return static_cast<VideoHandle *>(h)->video->HasEnded() ? 1 : 0; }
+void mpeghost_video_rewind(void *hv)
+{
+    auto *h = static_cast<VideoHandle *>(hv);
+    h->last = nullptr;
+    h->video->Rewind();
+}
+void mpeghost_video_set_lookahead(void *h, int on) { static_cast<VideoHandle *>(h)->video->SetLookahead(on != 0); }
+// wall seconds of the decoder's host phases so far: parse, hand-over (submit), frames back (read)
+void mpeghost_video_phase_seconds(void *hv, double out[3])
+{
+    const VideoStats &s = static_cast<VideoHandle *>(hv)->video->Stats();
+    out[0] = s.seconds_parse;
+    out[1] = s.seconds_submit;
+    out[2] = s.seconds_read;
+}
+
 // NewAudio over a complete elementary stream (TestAudioGolden, mpeg_test.go:167-173)
 void *mpeghost_audio_open(void *device, const uint8_t *data, size_t len, int fma_mode, int format)
 {
@@ -196,6 +215,11 @@ const void *mpeghost_audio_decode(void *ha, double *time)
         }
     }, (const void *)nullptr);
 }
+
+double mpeghost_audio_time(void *h) { return static_cast<AudioHandle *>(h)->audio->Time(); }
+int mpeghost_audio_has_ended(void *h) { return static_cast<AudioHandle *>(h)->audio->HasEnded() ? 1 : 0; }
+void mpeghost_audio_rewind(void *h) { static_cast<AudioHandle *>(h)->audio->Rewind(); }
+void mpeghost_audio_set_lookahead(void *h, int on) { static_cast<AudioHandle *>(h)->audio->SetLookahead(on != 0); }
 
 // mpeg.New over a complete program stream
 void *mpeghost_mpeg_open(void *device, const uint8_t *data, size_t len)

@@ -48,6 +48,22 @@ public:
         check(mpeghip_video_rgba_convert(store_, slot, 0, 1), "mpeghip_video_rgba_convert");
         check(mpeghip_video_read_rgba(store_, 0, slot, dst), "mpeghip_video_read_rgba");
     }
+    // Video::Decode's frames: pinned memory, filled by the device itself (mpeghip_video_read_planes_async), waited for by ticket
+    uint8_t *allocPlanes(size_t bytes) override
+    {
+        uint8_t *p = static_cast<uint8_t *>(mpeghip_pinned_alloc(ctx_, bytes ? bytes : 1));
+        if (p)
+            memset(p, 0, bytes);
+        return p;
+    }
+    void freePlanes(uint8_t *p) override { mpeghip_pinned_free(ctx_, p); }
+    uint64_t readPlanesAsync(uint32_t slot, uint8_t *dst, size_t, size_t) override
+    {
+        uint64_t ticket = 0;
+        check(mpeghip_video_read_planes_async(store_, 0, slot, dst, &ticket), "mpeghip_video_read_planes_async");
+        return ticket;
+    }
+    void readWait(uint64_t ticket) override { check(mpeghip_video_read_wait(store_, ticket), "mpeghip_video_read_wait"); }
 
 private:
     mpeghip_ctx *ctx_;
@@ -126,11 +142,50 @@ private:
 
 class HipAudioBackend : public AudioBackend {
 public:
-    HipAudioBackend(mpeghip_ctx *ctx, int fma_mode)
+    HipAudioBackend(mpeghip_ctx *ctx, int fma_mode) : ctx_(ctx)
     {
         check(mpeghip_audio_open(ctx, 1, fma_mode, &synth_), "mpeghip_audio_open");
+        for (auto &o : out_) {
+            o = static_cast<uint8_t *>(mpeghip_pinned_alloc(ctx_, 2304 * sizeof(float)));
+            if (!o)
+                throw std::runtime_error(std::string("mpeghip_pinned_alloc: ") + mpeghip_last_error());
+        }
     }
-    ~HipAudioBackend() override { mpeghip_audio_close(synth_); }
+    ~HipAudioBackend() override
+    {
+        mpeghip_audio_close(synth_);
+        for (uint8_t *o : out_)
+            mpeghip_pinned_free(ctx_, o);
+    }
+    // Audio::Decode's frames: sub-band samples in pinned memory, read by the kernel in place; its output lands in one of two
+    // pinned buffers here and is copied to the caller's Samples at the wait (9 KB)
+    int32_t *allocSamples() override
+    {
+        int32_t *p = static_cast<int32_t *>(mpeghip_pinned_alloc(ctx_, MPEGHIP_AUDIO_FRAME_INTS * sizeof(int32_t)));
+        if (p)
+            memset(p, 0, MPEGHIP_AUDIO_FRAME_INTS * sizeof(int32_t));
+        return p;
+    }
+    void freeSamples(int32_t *p) override { mpeghip_pinned_free(ctx_, p); }
+    uint64_t synthAsync(const int32_t *samples, int format) override
+    {
+        uint64_t ticket = 0;
+        check(mpeghip_audio_synth_async(synth_, samples, 1, format, out_[queued_ & 1], &ticket), "mpeghip_audio_synth_async");
+        format_[queued_ & 1] = format;
+        ticket_[queued_ & 1] = ticket;
+        return queued_++;
+    }
+    void synthWait(uint64_t n, void *out, void *out2) override
+    {
+        check(mpeghip_audio_synth_wait(synth_, ticket_[n & 1]), "mpeghip_audio_synth_wait");
+        const uint8_t *o = out_[n & 1];
+        if (format_[n & 1] == MPEGHIP_AUDIO_F32NLR) {
+            memcpy(out, o, 1152 * sizeof(float));
+            memcpy(out2, o + 1152 * sizeof(float), 1152 * sizeof(float));
+        } else {
+            memcpy(out, o, 2304 * (format_[n & 1] == MPEGHIP_AUDIO_S16 ? sizeof(int16_t) : sizeof(float)));
+        }
+    }
     void synth(const int32_t *samples, int format, void *out, void *out2) override
     {
         if (format == MPEGHIP_AUDIO_F32NLR) {
@@ -144,7 +199,11 @@ public:
     }
 
 private:
+    mpeghip_ctx *ctx_;
     mpeghip_audio *synth_ = nullptr;
+    uint8_t *out_[2] = {nullptr, nullptr};
+    int format_[2] = {0, 0};
+    uint64_t ticket_[2] = {0, 0}, queued_ = 0;
 };
 
 class HipAudioBatchStore : public AudioBatchStore {

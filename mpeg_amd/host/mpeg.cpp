@@ -121,10 +121,15 @@ Frame *MPEG::SeekFrame(double tm, bool seek_exact)
     video_->Rewind();
     video_->SetTime(packet->Pts - start_time);
     video_buf_->Write(packet->Data, packet->Len);
+    // (nothing parsed ahead in here: a look-ahead would pull packets through the load callback while the audio packet type is
+    // switched off, and audio packets the reference still delivers later would be dropped)
+    const bool lookahead = video_->Lookahead();
+    video_->SetLookahead(false);
     Frame *frame = video_->Decode();
     if (seek_exact)
         while (frame && frame->Time < tm)
             frame = video_->Decode();
+    video_->SetLookahead(lookahead);
     audio_packet_type_ = prev_audio_packet_type;
     if (frame)
         time_ = frame->Time;

@@ -190,6 +190,9 @@ struct Frame {                // video.go:11-23
 struct VideoStats {
     uint64_t pictures = 0, submits = 0, macroblocks = 0, coded_blocks = 0, raw_macroblocks = 0;
     uint64_t invalid_blocks = 0, duplicate_splits = 0, range_skips = 0;
+    // wall time of a lone Video's three host phases (bench.py's single-stream legs say where a picture's microseconds go): the
+    // bitstream parse of its pictures, the hand-over of their work (VideoBackend::submit*), waiting for / copying frames back
+    double seconds_parse = 0, seconds_submit = 0, seconds_read = 0;
 };
 
 // What the decoders need from the reconstruction device.  The product ships exactly
@@ -212,6 +215,18 @@ public:
     }
     virtual void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) = 0;
     virtual void readRGBA(uint32_t slot, uint8_t *dst) = 0;  // Frame.RGBA of the slot
+    // Video::Decode works one picture ahead (round 6): the frame it returns is read back ASYNCHRONOUSLY into one of two buffers
+    // of allocPlanes() — luma | Cb | Cr, linear — while the next picture is parsed; readWait(ticket) blocks until it is there.
+    // The defaults make any backend work (the read-back happens at once): the HIP backend hands out pinned memory and queues
+    // mpeghip_video_read_planes_async.
+    virtual uint8_t *allocPlanes(size_t bytes) { return static_cast<uint8_t *>(calloc(bytes ? bytes : 1, 1)); }
+    virtual void freePlanes(uint8_t *p) { free(p); }
+    virtual uint64_t readPlanesAsync(uint32_t slot, uint8_t *dst, size_t luma_bytes, size_t chroma_bytes)
+    {
+        readPlanes(slot, dst, dst + luma_bytes, dst + luma_bytes + chroma_bytes);
+        return 0;
+    }
+    virtual void readWait(uint64_t ticket) { (void)ticket; }
 };
 
 // Frame stores of MANY streams of one picture size behind one reconstruction call (libmpeghip's
@@ -245,6 +260,27 @@ public:
     // MPEGHIP_AUDIO_F32NLR the two halves go to `out` (left, 1152 floats) and `out2` (right).  The backend
     // may complete the writes later, but before anything reads them (AudioBatch: at its Flush()).
     virtual void synth(const int32_t *samples, int format, void *out, void *out2) = 0;
+    // Audio::Decode works one frame ahead (round 6): frame N's samples — in one of two buffers of allocSamples() — are handed
+    // over with synthAsync, frame N + 1 is parsed, synthWait(ticket, out, out2) blocks until frame N's output is in `out` (/
+    // `out2`, as for synth).  The defaults make any backend work (the synthesis runs inside synthWait): the HIP backend hands out
+    // pinned memory and queues mpeghip_audio_synth_async.
+    virtual int32_t *allocSamples() { return static_cast<int32_t *>(calloc(2 * 36 * 32, sizeof(int32_t))); }
+    virtual void freeSamples(int32_t *p) { free(p); }
+    virtual uint64_t synthAsync(const int32_t *samples, int format)
+    {
+        held_samples_ = samples;
+        held_format_ = format;
+        return 0;
+    }
+    virtual void synthWait(uint64_t ticket, void *out, void *out2)
+    {
+        (void)ticket;
+        synth(held_samples_, held_format_, out, out2);
+    }
+
+private:
+    const int32_t *held_samples_ = nullptr;
+    int held_format_ = 0;
 };
 
 // Synthesis state of MANY streams behind one call (libmpeghip's mpeghip_audio with n_streams > 1):
@@ -300,11 +336,24 @@ public:
     // test hook: every VLC table of the parser against a walk over its code list, for every possible look at the stream
     // (all 2^L prefixes of the table's longest code).  Returns the number of prefixes that decode differently (0).
     static uint64_t VlcSelfCheck();
-    double Time() const { return time_; }
+    // (a picture parsed ahead — Decode below — is the reference's NEXT picture: its time is the decoder's time, and the stream
+    // has not ended while it waits to be returned)
+    double Time() const { return ahead_.valid ? ahead_.time : time_; }
     void SetTime(double t);
     void Rewind();
-    bool HasEnded() const { return buf_->HasEnded(); }
-    Frame *Decode();                                 // video.go:209-268
+    // (... nor when the attempt to parse ahead found nothing: the reference learns that in its NEXT call — until then the answer
+    // is what it was before the attempt)
+    bool HasEnded() const { return ahead_.valid ? false : ahead_tried_ ? ended_before_ahead_ : buf_->HasEnded(); }
+    // video.go:209-268.  Works ONE PICTURE AHEAD on the host: a call hands the picture parsed during the previous call to the
+    // device, queues the read-back of the frame it returns (asynchronous, into one of two pinned buffers), parses the NEXT
+    // picture while the device works — that picture's work is held back until the next call, so the device's frame store is
+    // never ahead of the frames returned: Rewind / Seek drop the parsed picture and everything is as the reference has it — and
+    // only then waits.  The returned Frame (one of two, alternating) and its planes are valid until the next Decode call
+    // (mpeg.go:413-415).  SetLookahead(false): parse, submit, read back, return — nothing parsed ahead (MPEG::SeekFrame needs
+    // that: it must not pull packets while it keeps audio packets out).
+    Frame *Decode();
+    void SetLookahead(bool v) { lookahead_ = v; }
+    bool Lookahead() const { return lookahead_; }
     // Decode() in two halves, for VideoBatch: DecodeDeferred parses up to and including the picture that
     // completes the next output frame and hands its work to the backend WITHOUT reading anything back;
     // Fetch copies that frame's planes to the host (what makes Frame.Y/Cb/Cr.Data valid).
@@ -419,6 +468,24 @@ private:
     std::vector<uint8_t> host_planes_[3];
     std::vector<uint8_t> host_rgba_;
     VideoStats stats_;
+
+    // ---- Decode's look-ahead
+    struct Deferred { mpeghip_pic_desc pic; std::vector<mpeghip_mb_desc> mbs; CoefBytes coefs; };
+    std::vector<Deferred> deferred_;      // hand-overs recorded while defer_submits_ (storage is kept and reused)
+    size_t n_deferred_ = 0;
+    bool defer_submits_ = false, lookahead_ = true;
+    bool ahead_tried_ = false, ended_before_ahead_ = false; // an attempt to parse ahead was made in the last Decode call / HasEnded() before it
+    struct Ahead { bool valid = false; uint32_t slot = 0; double time = 0; } ahead_; // the frame the parsed-ahead picture completes
+    // what a dropped look-ahead must give back (Rewind): the parser state that outlives a picture
+    struct Undo { uint32_t cur, fwd, bwd; int picture_type; bool has_reference_frame, block_dirty; int32_t block_data[64];
+                  Motion motion_forward, motion_backward; VideoStats stats; } undo_;
+    bool undo_valid_ = false;
+    uint8_t *out_planes_[2] = {nullptr, nullptr};  // VideoBackend::allocPlanes: the two frames Decode alternates between
+    Frame out_frames_[2];
+    int out_next_ = 0;
+    void parseAhead();
+    void replayDeferred();
+    void dropLookahead();
 };
 
 // Many independent streams of one picture size on one GPU: every DecodeAll() advances each stream by
@@ -550,17 +617,23 @@ public:
     bool HasHeader();
     int Samplerate();
     int Channels() const { return channels_; }
-    double Time() const { return time_; }
+    double Time() const { return ahead_valid_ ? ahead_time_ : time_; }   // (a frame parsed ahead is the reference's NEXT frame)
     void SetTime(double t);
     void Rewind();
-    bool HasEnded() const { return buf_->HasEnded(); }
-    void SetFormat(AudioFormat f) { format_ = f; samples_.format = f; } // MPEG.SetAudioFormat (mpeg.go:234)
-    Samples *Decode();                            // audio.go:163-182
+    bool HasEnded() const { return ahead_valid_ ? false : ahead_tried_ ? ended_before_ahead_ : buf_->HasEnded(); }
+    void SetFormat(AudioFormat f) { format_ = f; samples_[0].format = samples_[1].format = f; } // MPEG.SetAudioFormat (mpeg.go:234)
+    // audio.go:163-182.  Works ONE FRAME AHEAD on the host, like Video::Decode: a call hands the frame parsed during the previous
+    // call to the device (asynchronous synthesis from / into pinned memory), parses the NEXT frame while the device works — held
+    // back until the next call: the V ring is never ahead of the frames returned (Rewind keeps it, audio.go:149-154) — then
+    // waits.  The returned Samples (one of two, alternating) are valid until the next Decode call (mpeg.go:435-437).
+    Samples *Decode();
+    void SetLookahead(bool v) { lookahead_ = v; }
 
 private:
     struct QuantizerSpec { uint16_t Levels; uint8_t Group, Bits; };
     int decodeHeader();
-    void decodeFrame();
+    void decodeFrame(int32_t (*frame_samples)[36][32]);   // the parse of one frame: its 2 x 36 x 32 sub-band samples
+    bool parseNext(int *buf, double *time);                // audio.go:163-182 up to the synthesis: frame -> in_[*buf]
     const QuantizerSpec *readAllocation(int sb, int tab3);
     void readSamples(int ch, int sb, int part);
 
@@ -575,8 +648,13 @@ private:
     uint8_t scale_factor_info_[2][32] = {};
     int scale_factor_[2][32][3] = {};
     int sample_[2][32][3] = {};
-    int32_t frame_samples_[2][36][32];
-    Samples samples_;
+    int32_t *in_[2] = {nullptr, nullptr};   // AudioBackend::allocSamples: [2][36][32] each
+    int in_next_ = 0;
+    Samples samples_[2];
+    bool lookahead_ = true, ahead_valid_ = false, ahead_failed_ = false;
+    bool ahead_tried_ = false, ended_before_ahead_ = false; // as Video's
+    int ahead_buf_ = 0;
+    double ahead_time_ = 0;
     AudioFormat format_ = AudioF32N;
     static const QuantizerSpec quant_tab_[17];
 };

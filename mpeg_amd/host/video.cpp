@@ -16,6 +16,8 @@
 #include <stdexcept>
 #include <string.h>
 
+#include <chrono>
+
 #include "mpeg.hpp"
 #include "vlc.hpp"
 
@@ -246,7 +248,12 @@ void Video::init()
         decodeSequenceHeader();
 }
 
-Video::~Video() {}
+Video::~Video()
+{
+    for (uint8_t *p : out_planes_)
+        if (p)
+            backend_->freePlanes(p);
+}
 
 bool Video::HasHeader()
 { // video.go:130-147
@@ -263,10 +270,38 @@ void Video::SetTime(double t)
 { // video.go:189-192
     frames_decoded_ = (int)(frame_rate_ * t);
     time_ = t;
+    if (ahead_.valid) { // (a picture parsed ahead completes the next frame the reference would return: it carries the new time)
+        ahead_.time = time_;
+        frames_decoded_++;
+        time_ = (double)frames_decoded_ / frame_rate_;
+    }
+}
+
+// A picture parsed ahead (Decode) has not reached the device: forgetting it takes the recorded hand-overs and the parser state
+// that outlives a picture — the frame store, and so every later prediction, is as the reference has it.
+void Video::dropLookahead()
+{
+    ahead_.valid = false;
+    ahead_tried_ = false;
+    n_deferred_ = 0;
+    if (!undo_valid_)
+        return;
+    undo_valid_ = false;
+    slot_cur_ = undo_.cur;
+    slot_fwd_ = undo_.fwd;
+    slot_bwd_ = undo_.bwd;
+    picture_type_ = undo_.picture_type;
+    has_reference_frame_ = undo_.has_reference_frame;
+    block_dirty_ = undo_.block_dirty;
+    memcpy(block_data_, undo_.block_data, sizeof(block_data_));
+    motion_forward_ = undo_.motion_forward;
+    motion_backward_ = undo_.motion_backward;
+    stats_ = undo_.stats;
 }
 
 void Video::Rewind()
 { // video.go:195-201
+    dropLookahead();
     buf_->Rewind();
     time_ = 0;
     frames_decoded_ = 0;
@@ -328,6 +363,20 @@ bool Video::decodeSequenceHeader()
         f.Cb = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + luma_bytes_, chroma_bytes_};
         f.Cr = Plane{chroma_width_, chroma_height_, host_planes_[s].data() + luma_bytes_ + chroma_bytes_, chroma_bytes_};
     }
+    for (int i = 0; i < 2; i++) { // the two frames Decode alternates between (video.go:209-268: "valid until the next call")
+        if (out_planes_[i])
+            backend_->freePlanes(out_planes_[i]);
+        out_planes_[i] = backend_->allocPlanes(luma_bytes_ + 2 * chroma_bytes_);
+        if (!out_planes_[i])
+            throw std::bad_alloc();
+        Frame &f = out_frames_[i];
+        f.owner = this;
+        f.Width = width_;
+        f.Height = height_;
+        f.Y = Plane{luma_width_, luma_height_, out_planes_[i], luma_bytes_};
+        f.Cb = Plane{chroma_width_, chroma_height_, out_planes_[i] + luma_bytes_, chroma_bytes_};
+        f.Cr = Plane{chroma_width_, chroma_height_, out_planes_[i] + luma_bytes_ + chroma_bytes_, chroma_bytes_};
+    }
     host_rgba_.assign((size_t)width_ * (size_t)height_ * 4, 0);
     written_.assign((size_t)mb_size_, 0);
     slot_cur_ = 0;
@@ -341,7 +390,9 @@ Frame *Video::frameForSlot(uint32_t slot)
 {
     // Frame.Y/Cb/Cr.Data are host-visible: fetch the slot's planes (synchronises with the device)
     uint8_t *base = host_planes_[slot].data();
+    const auto t0 = std::chrono::steady_clock::now();
     backend_->readPlanes(slot, base, base + luma_bytes_, base + luma_bytes_ + chroma_bytes_);
+    stats_.seconds_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return &frames_[slot];
 }
 
@@ -354,12 +405,68 @@ const uint8_t *Video::fetchRGBA(uint32_t slot)
 const uint8_t *Frame::RGBA() { return owner->fetchRGBA(slot); }
 
 Frame *Video::Decode()
-{ // video.go:209-268
+{ // video.go:209-268, one picture ahead on the host (mpeg.hpp)
     uint32_t slot;
     double t;
-    if (!DecodeDeferred(&slot, &t))
+    ahead_tried_ = false;
+    replayDeferred(); // what the previous call parsed ahead goes to the device now
+    if (ahead_.valid) {
+        slot = ahead_.slot;
+        t = ahead_.time;
+        ahead_.valid = false;
+    } else if (!DecodeDeferred(&slot, &t)) {
         return nullptr;
-    return Fetch(slot, t);
+    }
+    // the frame's read-back, queued behind the picture that completes it ...
+    const int b = out_next_;
+    out_next_ ^= 1;
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t ticket = backend_->readPlanesAsync(slot, out_planes_[b], luma_bytes_, chroma_bytes_);
+    stats_.seconds_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // ... the next picture's parse while the device works (its hand-over waits for the next call) ...
+    if (lookahead_)
+        parseAhead();
+    // ... and only then the wait
+    t0 = std::chrono::steady_clock::now();
+    backend_->readWait(ticket);
+    stats_.seconds_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    Frame *f = &out_frames_[b];
+    f->slot = slot;
+    f->Time = t;
+    return f;
+}
+
+void Video::parseAhead()
+{
+    undo_ = Undo{slot_cur_, slot_fwd_, slot_bwd_, picture_type_, has_reference_frame_, block_dirty_, {}, motion_forward_, motion_backward_, stats_};
+    memcpy(undo_.block_data, block_data_, sizeof(block_data_));
+    undo_valid_ = true;
+    ended_before_ahead_ = buf_->HasEnded();
+    ahead_tried_ = true;
+    defer_submits_ = true;
+    try {
+        ahead_.valid = DecodeDeferred(&ahead_.slot, &ahead_.time);
+    } catch (...) {
+        defer_submits_ = false;
+        throw;
+    }
+    defer_submits_ = false;
+    if (!ahead_.valid && n_deferred_ == 0)
+        undo_valid_ = false; // nothing was consumed that a Rewind would have to give back
+}
+
+void Video::replayDeferred()
+{
+    undo_valid_ = false;
+    for (size_t i = 0; i < n_deferred_; i++) {
+        Deferred &d = deferred_[i];
+        const auto t0 = std::chrono::steady_clock::now();
+        backend_->submitOwned(d.pic, d.mbs, d.coefs);
+        stats_.seconds_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        d.mbs.clear();
+        d.coefs.clear();
+    }
+    n_deferred_ = 0;
 }
 
 bool Video::DecodeDeferred(uint32_t *slot, double *time)
@@ -392,7 +499,13 @@ int Video::DecodeStep(uint32_t *slot, double *time)
             return 0;
         buf_->discardReadBytes();
 
-        decodePicture();
+        {   // (the picture's parse = this call minus the hand-overs it makes: flushSubmit keeps their time apart)
+            const auto t0 = std::chrono::steady_clock::now();
+            const double submits_before = stats_.seconds_submit;
+            decodePicture();
+            stats_.seconds_parse += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() -
+                                    (stats_.seconds_submit - submits_before);
+        }
 
         if (assume_no_b_frames_)
             out_slot = (int)slot_bwd_;
@@ -485,7 +598,18 @@ void Video::flushSubmit()
     pic.flags = sparse_ ? MPEGHIP_PIC_SPARSE : 0;
     const size_t n_mbs = mbs_.size();
     coefs_.resize(coef_len_); // (it ran ahead of the recording: coefRoom)
-    backend_->submitOwned(pic, mbs_, coefs_); // (may swap the arrays for others)
+    if (defer_submits_) { // a picture parsed ahead: its hand-over is kept (the arrays change places with the kept slot's empty ones)
+        if (n_deferred_ == deferred_.size())
+            deferred_.emplace_back();
+        Deferred &d = deferred_[n_deferred_++];
+        d.pic = pic;
+        d.mbs.swap(mbs_);
+        d.coefs.swap(coefs_);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        backend_->submitOwned(pic, mbs_, coefs_); // (may swap the arrays for others)
+        stats_.seconds_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     stats_.submits++;
     stats_.macroblocks += n_mbs;
     mbs_.clear();

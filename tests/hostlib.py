@@ -40,6 +40,11 @@ def host():
             "mpeghost_debug_vlc_self_check": (C.c_uint64, []),
             "mpeghost_video_decode": (C.c_int, [P, C.POINTER(HostFrame)]), "mpeghost_video_rgba": (P, [P]),
             "mpeghost_video_stats": (None, [P, C.POINTER(C.c_uint64 * 8)]),
+            "mpeghost_video_phase_seconds": (None, [P, C.POINTER(C.c_double * 3)]),
+            "mpeghost_video_time": (C.c_double, [P]), "mpeghost_video_has_ended": (C.c_int, [P]), "mpeghost_video_rewind": (None, [P]),
+            "mpeghost_video_set_lookahead": (None, [P, C.c_int]),
+            "mpeghost_audio_time": (C.c_double, [P]), "mpeghost_audio_has_ended": (C.c_int, [P]), "mpeghost_audio_rewind": (None, [P]),
+            "mpeghost_audio_set_lookahead": (None, [P, C.c_int]),
             "mpeghost_audio_open": (P, [P, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
             "mpeghost_audio_open_backend": (P, [P, C.c_char_p, C.c_size_t, C.c_int]),
             "mpeghost_audio_close": (None, [P]), "mpeghost_audio_samplerate": (C.c_int, [P]), "mpeghost_audio_channels": (C.c_int, [P]),
@@ -167,6 +172,15 @@ class HostVideo:
             raise RuntimeError(host().mpeghost_last_error().decode())
         return f if rc == 1 else None
 
+    time = property(lambda s: host().mpeghost_video_time(s.h))
+    has_ended = property(lambda s: bool(host().mpeghost_video_has_ended(s.h)))
+
+    def rewind(self):
+        host().mpeghost_video_rewind(self.h)
+
+    def set_lookahead(self, on):
+        host().mpeghost_video_set_lookahead(self.h, 1 if on else 0)
+
     def rgba(self, w, h):
         p = host().mpeghost_video_rgba(self.h)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h, w, 4)).copy()
@@ -205,6 +219,21 @@ class HostAudio:
         if self.fmt == 3:
             return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(2304,)).copy()
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(2304,)).copy()
+
+    time = property(lambda s: host().mpeghost_audio_time(s.h))
+    has_ended = property(lambda s: bool(host().mpeghost_audio_has_ended(s.h)))
+
+    def rewind(self):
+        host().mpeghost_audio_rewind(self.h)
+
+    def set_lookahead(self, on):
+        host().mpeghost_audio_set_lookahead(self.h, 1 if on else 0)
+
+    def decode_view(self):
+        """-> (pointer value, time) of the decoder's own Samples buffer, or None: no copy (lifetime tests)"""
+        t = C.c_double()
+        p = host().mpeghost_audio_decode(self.h, C.byref(t))
+        return (p, t.value) if p else None
 
     samplerate = property(lambda s: host().mpeghost_audio_samplerate(s.h))
     channels = property(lambda s: host().mpeghost_audio_channels(s.h))

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libmpeghip.so does not export %s" % n
         assert n in abi.SYMBOLS, "mpeg_amd.abi does not bind %s" % n
-    assert lib.mpeghip_abi_version() == abi.ABI_VERSION == 2
+    assert lib.mpeghip_abi_version() == abi.ABI_VERSION == 3
 
 
 def test_host_library_exports_exactly_what_its_header_declares():
