@@ -874,6 +874,7 @@ struct mpeghip_video {
     struct Staging {
         mpeghip_batch batch;
         uint8_t *h = nullptr;      // pinned
+        uint8_t *d_h = nullptr;    // ... as the device sees it (small submits are read in place: upload_into); nullptr: not mapped
         size_t cap_h = 0;
         hipEvent_t done = nullptr; // recorded after the batch's kernel
         hipEvent_t copied = nullptr; // staged commits: recorded on the context's copy stream behind the buffer's H2D copy
@@ -1583,11 +1584,14 @@ static int grow_pinned(mpeghip_video::Staging *sg, size_t need)
         return MPEGHIP_OK;
     if (sg->h)
         (void)hipHostFree(sg->h);
-    sg->h = nullptr;
+    sg->h = sg->d_h = nullptr;
     sg->cap_h = 0;
     const size_t cap = need + need / 2;
     HIP_TRY(hipHostMalloc((void **)&sg->h, cap, hipHostMallocDefault));
     sg->cap_h = cap;
+    void *d = nullptr;
+    sg->d_h = hipHostGetDevicePointer(&d, sg->h, 0) == hipSuccess ? static_cast<uint8_t *>(d) : nullptr;
+    (void)hipGetLastError();
     return MPEGHIP_OK;
 }
 
@@ -1789,6 +1793,12 @@ static BlobLayout blob_layout(uint64_t n_pics, uint64_t n_chunks)
 // `sg` != nullptr: b is that staging slot's batch; the submit is packed into its pinned buffer and the call
 // returns with the copy still in flight.  Otherwise (resident batches) the image is packed in pageable memory,
 // copied, replicated on the device, and the call waits.
+// submits out of pinned staging up to this size are read by the kernel in place (upload_into); MPEGHIP_ZERO_COPY_SUBMIT=0 in the
+// environment switches it off (A/B runs)
+static const size_t kZeroCopySubmitBytes = [] {
+    const char *e = getenv("MPEGHIP_ZERO_COPY_SUBMIT");
+    return e && e[0] == '0' ? (size_t)0 : (size_t)(e && atol(e) > 1 ? atol(e) : 64 << 10);
+}();
 static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_desc *pics, uint32_t n_pics,
                        const mpeghip_mb_desc *mbs, uint32_t n_mbs, const void *coefs, size_t coef_bytes,
                        uint32_t replicas, mpeghip_video::Staging *sg = nullptr)
@@ -1846,15 +1856,25 @@ static int upload_into(mpeghip_video *v, mpeghip_batch *b, const mpeghip_pic_des
     if (pb)
         memcpy(h, pics, pb);
     if (replicas == 1) {
-        // the device image is the host image: one copy
+        // the device image is the host image: one copy — or, for a SMALL submit out of pinned staging (a lone decoder's picture:
+        // 160x120 is 3 KB, SIF 15 KB), none: the kernel reads the chunks and their words from the pinned buffer itself (the device
+        // sees pinned host memory; every byte is read once).  The copy call costs the host 3 - 4 us, more than the picture's
+        // parse is worth at that size; the staging slot stays untouched until its `done` event has passed either way (retire).
         const size_t total = l.w_at + (size_t)n_words * 4;
-        if ((rc = grow((void **)&b->d_blob, &b->cap_blob, total + kRcWordsPad * 4)) != 0)
-            return rc;
-        b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
-        b->d_chunks = reinterpret_cast<uint32_t *>(b->d_blob + l.c_at);
-        b->d_words = reinterpret_cast<uint32_t *>(b->d_blob + l.w_at);
-        if (total)
-            HIP_TRY(hipMemcpyAsync(b->d_blob, h, total, hipMemcpyHostToDevice, st));
+        if (sg && sg->d_h && total && total <= kZeroCopySubmitBytes) {
+            uint8_t *d = sg->d_h;
+            b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(d);
+            b->d_chunks = reinterpret_cast<uint32_t *>(d + l.c_at);
+            b->d_words = reinterpret_cast<uint32_t *>(d + l.w_at);
+        } else {
+            if ((rc = grow((void **)&b->d_blob, &b->cap_blob, total + kRcWordsPad * 4)) != 0)
+                return rc;
+            b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(b->d_blob);
+            b->d_chunks = reinterpret_cast<uint32_t *>(b->d_blob + l.c_at);
+            b->d_words = reinterpret_cast<uint32_t *>(b->d_blob + l.w_at);
+            if (total)
+                HIP_TRY(hipMemcpyAsync(b->d_blob, h, total, hipMemcpyHostToDevice, st));
+        }
     } else {
         const BlobLayout lr = blob_layout((uint64_t)n_pics * replicas, n_chunks * replicas);
         const size_t total = lr.w_at + (size_t)n_words * 4 * replicas;

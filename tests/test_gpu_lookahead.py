@@ -85,7 +85,7 @@ def test_audio_lookahead_changes_nothing_on_gpu(golden_dir, device, fmt, script)
                 if s is None:
                     out.append((None, dec.time, dec.has_ended))
                     break
-                out.append((hash(s.tobytes()), dec.time, dec.has_ended))
+                out.append((hash(s[:1152 if fmt == 1 else 2304].tobytes()), dec.time, dec.has_ended))   # (F32NLR: the C API hands out Left)
         return out
     data = (golden_dir / "test.mp2").read_bytes()
     a, b = hostlib.HostAudio(data, device=device, fmt=fmt), hostlib.HostAudio(data, device=device, fmt=fmt)
