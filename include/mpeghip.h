@@ -37,8 +37,9 @@ extern "C" {
 /* 2: the sparse hand-over's snapshot blocks carry a count word, a sparse picture's macroblocks name their words in order;
  *    the device-packed stage (mpeghip_video_stage_begin_device) and its deferred errors; chroma as Cb|Cr pairs in device memory */
 /* 3: (round 6) asynchronous read-back and synthesis for a lone decoder that works one picture / frame ahead —
- *    mpeghip_video_read_planes_async / _read_wait, mpeghip_audio_synth_async / _synth_wait / _undo_last — and
- *    mpeghip_ctx_pci_bus_id (added during round 5 without a bump).  Nothing of version 2 changed. */
+ *    mpeghip_video_read_planes_async / _read_wait, mpeghip_audio_synth_async / _synth_wait / _undo_last; a device-packed commit's
+ *    refusal is per picture (the commit's other pictures are reconstructed: mpeghip_video_verdict / _refused); and
+ *    mpeghip_ctx_pci_bus_id (added during round 5 without a bump).  Nothing else of version 2 changed. */
 #define MPEGHIP_ABI_VERSION 3
 
 #define MPEGHIP_OK             0
@@ -308,12 +309,16 @@ int mpeghip_video_submit_sparse(mpeghip_video *v, const mpeghip_pic_desc *pic, c
  *   mpeghip_video_stage_commit         one H2D copy, pack, reconstruct; returns with all of it in flight
  * DEFERRED ERRORS.  put / put_mapped check the picture descriptor only.  Everything the host path refuses with
  * MPEGHIP_ERR_INVALID / MPEGHIP_ERR_RANGE at `put` or `commit` — macroblock fields, vectors that leave the frame buffer, a
- * position addressed twice, malformed block data, dependent pictures — is found by the device AFTER the commit has returned
- * MPEGHIP_OK.  Such a commit reconstructs NOTHING (all of its pictures are dropped, the frame store is as before it), later
- * commits run as queued, and the error — with the first offending picture and macroblock in mpeghip_last_error() — is returned
- * ONCE by the next call on the handle that waits for the device: mpeghip_video_sync, read_planes, read_rgba, hash_slots, or the
- * stage_begin / submit that reuses the commit's staging buffer (the second one after it).  A caller that must know before it
- * goes on calls mpeghip_video_sync.
+ * position addressed twice, malformed block data, a picture that reads what another picture of its stream in the same commit
+ * writes — is found by the device AFTER the commit has returned MPEGHIP_OK.  The unit of failure is the PICTURE, as in the
+ * reference (video.go:374-460; ABI 3 — until then a refusal dropped the whole commit): a refused picture is not reconstructed
+ * (its stream's frame store is as before it), every OTHER picture of the commit — they belong to other streams — is; later
+ * commits run as queued.  The error — the first refused picture, its stream and macroblock, and how many pictures were refused,
+ * in mpeghip_last_error() — is returned ONCE by the next call on the handle that waits for the device: mpeghip_video_verdict,
+ * mpeghip_video_sync, read_planes, read_rgba, hash_slots, or the stage_begin / submit that reuses the commit's staging buffer (the
+ * second one after it); mpeghip_video_refused then names the refused pictures and their streams.  A caller that must know
+ * before it goes on calls mpeghip_video_verdict: it waits for the validation only (the packing kernels in front of the
+ * reconstruction), not for the reconstruction.
  * The sparse form's rule that macroblocks name their words in order and without overlap is what lets the device place a
  * chunk's words without a scan; cbp == 0 macroblocks take part in it (their coef_off: anything from the previous
  * macroblock's end to the picture's n_words). */
@@ -323,6 +328,13 @@ int mpeghip_video_stage_map(mpeghip_stage *s, uint32_t i, mpeghip_mb_desc **mbs,
 int mpeghip_video_stage_put_mapped(mpeghip_stage *s, uint32_t i, const mpeghip_pic_desc *pic);
 /* Wait for everything queued on this handle; returns (once) the deferred error of a device-packed commit, if any. */
 int mpeghip_video_sync(mpeghip_video *v);
+/* (ABI 3) Wait until the device has VALIDATED the device-packed commits queued so far — not until it has reconstructed them —
+ * and return (once) their deferred error, if any.  What a batch of decoders calls before it parses its next pictures. */
+int mpeghip_video_verdict(mpeghip_video *v);
+/* (ABI 3) The pictures refused by the error last returned for a device-packed commit: up to `cap` of them, as (index of the picture
+ * in its commit, its stream), in picture order (either array may be NULL); returns how many were refused (the library names the
+ * first 1 020 of a commit). */
+uint64_t mpeghip_video_refused(const mpeghip_video *v, uint32_t *pics, uint32_t *streams, uint32_t cap);
 
 /* Device-resident batches: validate + upload once, replay many times
  * (synthetic benchmark batches; a real decoder double-buffers two). */

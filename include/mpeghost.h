@@ -121,13 +121,22 @@ int mpeghost_batch_decode_all(void *batch, int fetch);               /* frames p
 void mpeghost_batch_set_threads(void *batch, uint32_t n);
 uint32_t mpeghost_batch_threads(void *batch);                        /* what the request became */
 double mpeghost_effective_cores(void);                               /* that CPU time, in cores */
+/* its cgroup part: the tightest CPU-time quota (cores; 0 = none) of the process's cgroup and every ancestor (v2 cpu.max, v1 cfs
+ * quota / period), found through /proc/self/cgroup; root / proc_file: stand-ins for /sys/fs/cgroup and that file (NULL = the real ones) */
+double mpeghost_cgroup_quota_cores(const char *root, const char *proc_file);
 int mpeghost_batch_frame(void *batch, uint32_t stream, mpeghost_frame *out);
 void mpeghost_batch_counters(void *batch, uint64_t out[2]);          /* device submits, pictures queued */
 void mpeghost_batch_phase_seconds(void *batch, double out[4]);       /* parse rounds, stage begin, puts, commits */
 /* staged submits of sparse pictures validated + packed on the host (default: a refused picture fails the decode_all that sent it) or,
- * with on = 1, on the DEVICE (mpeghip_video_stage_begin_device): errors are then DEFERRED to mpeghost_batch_sync / the next fetch */
+ * with on = 1 (the default since round 6), on the DEVICE (mpeghip_video_stage_begin_device): errors are then DEFERRED, per picture, to
+ * the next round's start (the next mpeghost_batch_decode_all) / mpeghost_batch_sync */
 void mpeghost_batch_set_device_pack(void *batch, int on);
 int mpeghost_batch_sync(void *batch);                                /* wait; -1 + mpeghost_last_error(): a device-packed commit's deferred error */
+/* streams whose picture the device refused, as named by the refusal last reported (decode_all / sync returning -1): a refusal is
+ * per picture — the other streams' pictures of that commit were reconstructed, and it is reported BEFORE the next round parses */
+uint32_t mpeghost_batch_refused_streams(void *batch, uint32_t *out, uint32_t cap);
+int mpeghost_batch_device_pack(void *batch);                         /* 1 (the default): sparse pictures are validated and packed on the device */
+void mpeghost_batch_debug_damage_next_picture(void *batch, uint32_t stream); /* test hook: that stream's next picture arrives damaged */
 void mpeghost_batch_numa_pins(void *batch, uint32_t out[2]);         /* pool threads asked to bind to the NUMA node, bindings that failed */
 
 /* ---- ShardedVideoBatch: streams sharded over SEVERAL devices (stream s -> device s mod G), one host thread and one
@@ -136,7 +145,8 @@ void *mpeghost_sharded_open(void *const *devices, uint32_t n_devices, uint32_t n
 void *mpeghost_sharded_open_stores(void *const *stores, uint32_t n_stores, uint32_t n_streams); /* test stores; takes ownership */
 void mpeghost_sharded_close(void *sharded);
 int mpeghost_sharded_add_stream(void *sharded, const uint8_t *data, size_t len);
-void mpeghost_sharded_set_threads(void *sharded, unsigned n);       /* parse threads of EVERY shard (each shard's pool runs on its GPU's NUMA node) */
+void mpeghost_sharded_set_threads(void *sharded, unsigned n);       /* parse threads of ALL shards together (0 = as many as fit): divided among them */
+uint32_t mpeghost_sharded_threads(void *sharded);                   /* what the shards' pools add up to */
 int mpeghost_sharded_decode_all(void *sharded, int fetch);
 void mpeghost_sharded_set_device_pack(void *sharded, int on);        /* mpeghost_batch_set_device_pack of every shard */
 int mpeghost_sharded_sync(void *sharded);                            /* mpeghost_batch_sync of every shard: -1 + the first deferred error */

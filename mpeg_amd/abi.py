@@ -62,6 +62,8 @@ SYMBOLS = {
     "mpeghip_video_stage_map": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(_P)]),
     "mpeghip_video_stage_put_mapped": (C.c_int, [_P, C.c_uint32, _P]),
     "mpeghip_video_sync": (C.c_int, [_P]),
+    "mpeghip_video_verdict": (C.c_int, [_P]),
+    "mpeghip_video_refused": (C.c_uint64, [_P, _P, _P, C.c_uint32]),
     "mpeghip_video_batch_upload": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.POINTER(_P)]),
     "mpeghip_video_batch_upload_replicated": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     "mpeghip_video_batch_run": (C.c_int, [_P, _P]),
@@ -334,6 +336,18 @@ class VideoStore:
     def sync(self):
         """mpeghip_video_sync: wait for the handle's queued work; raises the deferred error of a device-packed commit."""
         _check(self.lib.mpeghip_video_sync(self.h))
+
+    def verdict(self):
+        """mpeghip_video_verdict: wait for the VALIDATION of the device-packed commits queued so far (not their reconstruction);
+        raises their deferred error."""
+        _check(self.lib.mpeghip_video_verdict(self.h))
+
+    def refused(self, cap: int = 1024):
+        """-> (how many pictures the last reported verdict refused, [(picture index in its commit, stream), ...])"""
+        pics, streams = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        n = int(self.lib.mpeghip_video_refused(self.h, _ptr(pics), _ptr(streams), cap))
+        k = min(n, cap)
+        return n, list(zip(pics[:k].tolist(), streams[:k].tolist()))
 
     def upload(self, pics, mbs, coefs, replicate: int = 1) -> Batch:
         pics, mbs, coefs = self._args(pics, mbs, coefs)

@@ -635,39 +635,53 @@ __global__ __launch_bounds__(64) void pack_kernel(const PackArgs a)
         out.glob[out.base + i] = wout[i];
 }
 
-// Behind pack_kernel: pictures of one stream that depend on each other (the host lists the candidates: picture, which of its
-// references another picture of the commit writes; whether a macroblock reads it, only pack_kernel knows), the verdict
-// where the host finds it, and — if anything was wrong — every chunk of the commit turned into a dead one: recon_kernel,
-// next on the stream, then writes nothing.
+// Behind pack_kernel, one workgroup per picture: is the picture refused — by its own report, or because a macroblock of it reads a
+// slot that another picture of its stream in this commit writes (the host lists the candidates: picture, which of its references;
+// whether a macroblock reads it, only pack_kernel knows)?  Then every chunk of it becomes a dead one: recon_kernel, next on the
+// stream, writes nothing of it.  The last workgroup to finish publishes the verdict where the host finds it (pinned memory):
+// [0] the first report in submit order (kPkNoError: none), [1] the number of refused pictures, then their indices.
 struct PkDep { uint32_t pic, mask; };
+constexpr uint32_t kPkVerdictList = 1020; // refused pictures named per commit (the count is exact beyond that)
 __global__ __launch_bounds__(256) void pack_gate_kernel(const unsigned long long *err, const PkPic *aux, const mpeghip_pic_desc *pics,
-                                                        const PkDep *deps, uint32_t n_deps, uint32_t *chunks, uint32_t n_chunks,
+                                                        const PkDep *deps, uint32_t n_deps, uint32_t *chunks, uint32_t n_pics,
+                                                        unsigned long long *scratch /* [0] first report, [1] refused, [2] workgroups done */,
                                                         unsigned long long *verdict)
 {
     __shared__ unsigned long long key;
+    const uint32_t pic = blockIdx.x;
     if (threadIdx.x == 0)
-        key = *err;
+        key = err[pic];
     __syncthreads();
     unsigned long long mine = kPkNoError;
     for (uint32_t i = threadIdx.x; i < n_deps; i += 256)
-        if (aux[deps[i].pic].use & deps[i].mask) {
-            const unsigned long long k = ((unsigned long long)pics[deps[i].pic].mb_first << 8) | kPkDepends;
+        if (deps[i].pic == pic && (aux[pic].use & deps[i].mask)) {
+            const unsigned long long k = ((unsigned long long)pics[pic].mb_first << 8) | kPkDepends;
             mine = k < mine ? k : mine;
         }
     if (mine != kPkNoError)
         atomicMin(&key, mine);
     __syncthreads();
     const unsigned long long found = key;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *verdict = found; // (pinned host memory)
+    if (found != kPkNoError) {
+        const uint32_t c0 = aux[pic].chunk_first, nc = (pics[pic].mb_count + kRcMbs - 1) / kRcMbs;
+        for (uint32_t c = threadIdx.x; c < nc; c += 256)
+            rc_make_dead_chunk(chunks + (size_t)(c0 + c) * kRcChunkDwords);
+    }
+    if (threadIdx.x != 0)
+        return;
+    if (found != kPkNoError) {
+        atomicMin(&scratch[0], found);
+        const unsigned long long at = atomicAdd(&scratch[1], 1ull);
+        if (at < kPkVerdictList)
+            reinterpret_cast<uint32_t *>(verdict + 2)[at] = pic; // (pinned host memory)
+    }
+    __threadfence_system();
+    if (atomicAdd(&scratch[2], 1ull) + 1 == n_pics) { // the last one: everybody's reports are in
+        __threadfence();
+        verdict[1] = atomicAdd(&scratch[1], 0ull);
+        verdict[0] = atomicMin(&scratch[0], kPkNoError);
         __threadfence_system();
     }
-    if (found == kPkNoError)
-        return;
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_chunks)
-        return;
-    rc_make_dead_chunk(chunks + (size_t)c * kRcChunkDwords);
 }
 
 struct ReplicateSteps {
@@ -885,16 +899,23 @@ struct mpeghip_video {
         size_t cap_raw = 0;
         uint32_t *d_seen = nullptr;
         size_t cap_seen = 0;
-        unsigned long long *d_err = nullptr;
-        unsigned long long *h_verdict = nullptr; // pinned
-        bool packed_on_device = false;           // the commit in flight was: h_verdict is meaningful once `done` has passed
+        unsigned long long *d_err = nullptr;     // [pictures of the commit] + the gate's three scratch words
+        size_t cap_err = 0;
+        unsigned long long *h_verdict = nullptr; // pinned: [0] first report, [1] refused pictures, then their indices (pack_gate_kernel)
+        hipEvent_t gated = nullptr;              // recorded behind pack_gate_kernel: the verdict is there (mpeghip_video_verdict)
+        bool packed_on_device = false;           // the commit in flight was: h_verdict is meaningful once `gated` has passed
         std::vector<uint32_t> pk_mb_first;       // per picture of that commit: its first macroblock (to name the picture of a report)
+        std::vector<uint32_t> pk_stream;         // ... and its stream
+        mpeghip_video *owner = nullptr;          // (whose mpeghip_video_refused list a verdict fills)
     } staging[2];
     int next_staging = 0;
     struct mpeghip_stage *stage = nullptr; // the open mpeghip_video_stage_begin, if any
     uint8_t *bounce = nullptr;             // pinned: read_planes / read_rgba land here first
     size_t bounce_cap = 0;
     uint8_t *d_linear = nullptr;           // one slot's planes in the reference's linear layout (read / write_planes)
+    // the refused pictures of the verdict last returned (mpeghip_video_refused): (picture index in its commit, stream)
+    std::vector<std::pair<uint32_t, uint32_t>> refused;
+    uint64_t refused_total = 0;
     // mpeghip_video_read_planes_async: tickets count the read-backs queued; ticket t's event is read_done[t % 4] (events complete
     // in stream order, so a slot that a later read-back has taken over answers for the earlier one too)
     hipEvent_t read_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1246,6 +1267,8 @@ void mpeghip_video_close(mpeghip_video *v)
             (void)hipFree(sg.d_err);
         if (sg.h_verdict)
             (void)hipHostFree(sg.h_verdict);
+        if (sg.gated)
+            (void)hipEventDestroy(sg.gated);
         if (sg.h)
             (void)hipHostFree(sg.h);
         if (sg.done)
@@ -1595,21 +1618,36 @@ static int grow_pinned(mpeghip_video::Staging *sg, size_t need)
     return MPEGHIP_OK;
 }
 
-// ---- the verdict of a device-packed commit (mpeghip_video_stage_begin_device): known once the staging slot's `done` event has
-// passed.  Reasons are those of validate_mb / rc_pack_picture (video_pack_lane.h: kPk*).
+// ---- the verdict of a device-packed commit (mpeghip_video_stage_begin_device): known once the staging slot's `gated` event has
+// passed.  Reasons are those of validate_mb / rc_pack_picture (video_pack_lane.h: kPk*).  A refusal is PER PICTURE (round 6): the
+// commit's other pictures — other streams — were reconstructed; which pictures were refused: mpeghip_video_refused.
 static int reap_verdict(mpeghip_video::Staging *sg)
 {
     if (!sg->packed_on_device)
         return MPEGHIP_OK;
     sg->packed_on_device = false;
-    const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(sg->h_verdict);
+    const volatile unsigned long long *hv = sg->h_verdict;
+    const unsigned long long key = hv[0];
     if (key == kPkNoError)
         return MPEGHIP_OK;
+    const unsigned long long n_refused = hv[1];
     const uint32_t mb = (uint32_t)(key >> 8), reason = (uint32_t)(key & 0xff);
     uint32_t pic = 0;
     if (!sg->pk_mb_first.empty())
         pic = (uint32_t)(std::upper_bound(sg->pk_mb_first.begin(), sg->pk_mb_first.end(), mb) - sg->pk_mb_first.begin()) - 1;
     const uint32_t k = sg->pk_mb_first.empty() ? mb : mb - sg->pk_mb_first[pic];
+    const uint32_t stream = pic < sg->pk_stream.size() ? sg->pk_stream[pic] : 0;
+    if (sg->owner) { // which pictures (mpeghip_video_refused): the gate's list, in picture order
+        auto &out = sg->owner->refused;
+        out.clear();
+        const volatile uint32_t *list = reinterpret_cast<const volatile uint32_t *>(hv + 2);
+        for (unsigned long long i = 0; i < n_refused && i < kPkVerdictList; i++) {
+            const uint32_t p = list[i];
+            out.emplace_back(p, p < sg->pk_stream.size() ? sg->pk_stream[p] : 0u);
+        }
+        std::sort(out.begin(), out.end());
+        sg->owner->refused_total = n_refused;
+    }
     static const char *const why[] = {
         "", "position outside the picture", "flags name no or two references (or one for an intra macroblock)", "cbp beyond 0x3f",
         "quantiser_scale outside 1..31", "predicts from the slot its picture writes", "motion vector reads outside the frame buffer",
@@ -1618,8 +1656,8 @@ static int reap_verdict(mpeghip_video::Staging *sg)
         "malformed sparse block data: its data begins before the previous macroblock's ends (macroblocks name their words in order)",
         "its picture and another picture of the same stream in this commit depend on each other: they need separate commits"};
     return fail(reason == kPkRange ? MPEGHIP_ERR_RANGE : MPEGHIP_ERR_INVALID,
-                "device-packed commit refused, nothing of it was reconstructed: picture %u, macroblock %u: %s", pic, k,
-                reason < sizeof(why) / sizeof(why[0]) ? why[reason] : "?");
+                "device-packed commit: %llu of its %zu pictures refused and not reconstructed (the others were): picture %u (stream %u), "
+                "macroblock %u: %s", n_refused, sg->pk_mb_first.size(), pic, stream, k, reason < sizeof(why) / sizeof(why[0]) ? why[reason] : "?");
 }
 // a staging slot is about to be reused, or the caller waits for the device: its last commit has finished
 static int retire(mpeghip_video::Staging *sg)
@@ -1634,10 +1672,8 @@ static int retire(mpeghip_video::Staging *sg)
 static int reap_all(mpeghip_video *v)
 {
     const int older = reap_verdict(&v->staging[v->next_staging]);
-    if (older != MPEGHIP_OK) {
-        v->staging[v->next_staging ^ 1].packed_on_device = false; // (it ran on what the refused commit left undone)
+    if (older != MPEGHIP_OK) // (the newer commit's verdict, if it has one, is the next synchronising call's)
         return older;
-    }
     return reap_verdict(&v->staging[v->next_staging ^ 1]);
 }
 
@@ -2361,15 +2397,21 @@ static int stage_commit_device(mpeghip_stage *s)
         (rc = grow((void **)&b->d_blob, &b->cap_blob, c_bytes + ((size_t)s->words_total + kRcWordsPad) * 4)) != 0 ||
         (rc = grow((void **)&sg->d_seen, &sg->cap_seen, (size_t)s->n_pics * seen_stride * 4)) != 0)
         return rc;
-    if (!sg->d_err)
-        HIP_TRY(hipMalloc((void **)&sg->d_err, 8));
+    // per picture its report word, then the gate's scratch: [n] first report, [n + 1] refused pictures, [n + 2] workgroups done
+    if ((rc = grow((void **)&sg->d_err, &sg->cap_err, ((size_t)s->n_pics + 3) * 8)) != 0)
+        return rc;
     if (!sg->h_verdict)
-        HIP_TRY(hipHostMalloc((void **)&sg->h_verdict, 64, hipHostMallocDefault));
-    *sg->h_verdict = kPkNoError;
+        HIP_TRY(hipHostMalloc((void **)&sg->h_verdict, 16 + kPkVerdictList * 4, hipHostMallocDefault));
+    if (!sg->gated)
+        HIP_TRY(hipEventCreateWithFlags(&sg->gated, hipEventDisableTiming));
+    sg->h_verdict[0] = kPkNoError;
+    sg->h_verdict[1] = 0;
+    sg->owner = v;
     hipStream_t st = v->ctx->stream;
     // (the packer's scratch is reset while the copy runs; the kernels wait for the copy)
     HIP_TRY(hipMemsetAsync(sg->d_seen, 0, (size_t)s->n_pics * seen_stride * 4, st));
-    HIP_TRY(hipMemsetAsync(sg->d_err, 0xff, 8, st));
+    HIP_TRY(hipMemsetAsync(sg->d_err, 0xff, ((size_t)s->n_pics + 1) * 8, st));
+    HIP_TRY(hipMemsetAsync(sg->d_err + s->n_pics + 1, 0, 16, st));
     if ((rc = send_staging(v, sg, sg->d_raw, raw_total)) != MPEGHIP_OK) {
         (void)hipStreamSynchronize(v->ctx->copy_stream); // (what was queued of the copy has read the staging buffer)
         return rc;
@@ -2416,9 +2458,10 @@ static int stage_commit_device(mpeghip_stage *s)
     }
     hipLaunchKernelGGL(pack_kernel, dim3(s->n_pics * a.groups_per_pic), dim3(64), (64 * kPkXchDwords + 2 * a.win_dwords) * 4, st, a);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(pack_gate_kernel, dim3((s->n_chunks + 255) / 256), dim3(256), 0, st, sg->d_err, a.aux, a.pics,
-                       reinterpret_cast<const PkDep *>(sg->d_raw + s->d_at), n_deps, a.chunks, s->n_chunks, sg->h_verdict);
+    hipLaunchKernelGGL(pack_gate_kernel, dim3(s->n_pics), dim3(256), 0, st, sg->d_err, a.aux, a.pics,
+                       reinterpret_cast<const PkDep *>(sg->d_raw + s->d_at), n_deps, a.chunks, s->n_pics, sg->d_err + s->n_pics, sg->h_verdict);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sg->gated, st));
     fill_notes(v, b, pics, s->n_pics);
     b->d_pics = reinterpret_cast<mpeghip_pic_desc *>(sg->d_raw);
     b->d_chunks = a.chunks;
@@ -2444,6 +2487,9 @@ static int stage_commit_device(mpeghip_stage *s)
     sg->in_flight = true;
     sg->packed_on_device = true;
     sg->pk_mb_first = s->mb_first;
+    sg->pk_stream.resize(s->n_pics);
+    for (uint32_t i = 0; i < s->n_pics; i++)
+        sg->pk_stream[i] = pics[i].stream;
     return MPEGHIP_OK;
     }();
     if (rc != MPEGHIP_OK) { // keep the error text: the synchronisation calls below do not touch it
@@ -2553,6 +2599,39 @@ int mpeghip_video_sync(mpeghip_video *v)
     for (auto &sg : v->staging)
         sg.in_flight = false;
     return reap_all(v);
+}
+
+// Wait until the device has VALIDATED every device-packed commit queued so far — pack_kernel + pack_gate_kernel: a fraction of the
+// commit's time on the device — not until it has reconstructed them; the deferred refusal, if any, like mpeghip_video_sync.
+int mpeghip_video_verdict(mpeghip_video *v)
+{
+    if (!v)
+        return fail(MPEGHIP_ERR_INVALID, "video is NULL");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    for (int i = 0; i < 2; i++) { // older first
+        mpeghip_video::Staging *sg = &v->staging[v->next_staging ^ i];
+        if (!sg->packed_on_device)
+            continue;
+        if (sg->in_flight)
+            HIP_TRY(hipEventSynchronize(sg->gated));
+        const int rc = reap_verdict(sg);
+        if (rc != MPEGHIP_OK)
+            return rc;
+    }
+    return MPEGHIP_OK;
+}
+
+uint64_t mpeghip_video_refused(const mpeghip_video *v, uint32_t *pics, uint32_t *streams, uint32_t cap)
+{
+    if (!v)
+        return 0;
+    for (size_t i = 0; i < v->refused.size() && i < cap; i++) {
+        if (pics)
+            pics[i] = v->refused[i].first;
+        if (streams)
+            streams[i] = v->refused[i].second;
+    }
+    return v->refused_total;
 }
 
 static int mpeghip_video_batch_upload_replicated_impl(mpeghip_video *v, const mpeghip_pic_desc *pics, uint32_t n_pics,

@@ -25,10 +25,12 @@
 // start at the dword index of its first macroblock's coef_off, in a words array as long as the input's.
 //
 // Errors cannot make the call fail — it has returned by the time the device looks at the data.  Every lane that finds
-// something wrong reports (global macroblock index, reason) into ONE 64-bit word by atomic minimum (so the report names
-// the first bad macroblock in submit order, as the host's would); pack_gate_kernel, behind pack_kernel on the stream,
-// turns every chunk of the commit into a dead one if that word is set — nothing is reconstructed — and copies the word
-// where the host finds it at its next synchronisation point (mpeghip_video_sync and friends).
+// something wrong reports (global macroblock index, reason) into its PICTURE's 64-bit word by atomic minimum (so a picture's
+// report names its first bad macroblock in submit order, as the host's would); pack_gate_kernel, behind pack_kernel on the
+// stream, turns every chunk of a refused picture into a dead one — that picture is not reconstructed, the commit's other
+// pictures (other streams: pictures of one stream never share a commit) are — and puts the first report, the number of refused
+// pictures and their indices where the host finds them at its next synchronisation point (mpeghip_video_verdict / _sync and
+// friends).
 #pragma once
 
 #include "video_recon_lane.h"
@@ -51,7 +53,7 @@ struct PackArgs {
     uint32_t *chunks;    // out: kRcChunkDwords per chunk
     uint32_t *words_out; // out
     uint32_t *seen;      // [n_pics][seen_stride] dwords, zeroed: one bit per macroblock position
-    unsigned long long *err; // ~0 = nothing wrong; else (first bad macroblock's index in the submit) << 8 | kPk* reason
+    unsigned long long *err; // [n_pics], per picture: ~0 = nothing wrong; else (its first bad macroblock's index in the submit) << 8 | kPk* reason
     uint32_t n_pics, groups_per_pic, seen_stride;
     uint32_t win_dwords; // the waves' LDS window (PkWin)
     uint32_t mb_w, mb_h, luma_w, chroma_w, luma_bytes, chroma_bytes;
@@ -63,14 +65,16 @@ constexpr uint32_t kPkPosition = 1, kPkRefs = 2, kPkCbp = 3, kPkQscale = 4, kPkS
                    kPkOrder = 9, kPkDepends = 10;
 constexpr unsigned long long kPkNoError = ~0ull;
 
-MPG_HD void pk_report(const PackArgs &a, uint32_t mb_index, uint32_t reason)
+// (one word PER PICTURE: a refusal is the picture's own — the commit's other pictures, which belong to other streams, are
+// reconstructed; round 6)
+MPG_HD void pk_report(const PackArgs &a, uint32_t pic, uint32_t mb_index, uint32_t reason)
 {
     const unsigned long long key = ((unsigned long long)mb_index << 8) | reason;
 #if MPG_ON_DEVICE
-    atomicMin(a.err, key);
+    atomicMin(a.err + pic, key);
 #else
-    if (key < *a.err)
-        *a.err = key;
+    if (key < a.err[pic])
+        a.err[pic] = key;
 #endif
 }
 MPG_HD uint32_t pk_fetch_or(uint32_t *p, uint32_t bits)
@@ -149,6 +153,7 @@ struct PkLane {
     uint32_t live;      // the lane has a macroblock (k < the picture's count)
     uint32_t ok;        // ... and nothing is wrong with it: its words are packed
     uint32_t gi;        // its index in the submit's macroblock array
+    uint32_t pic;       // its picture's index in the submit
     uint32_t d[kRcRecDwords]; // its record
     uint32_t cbp, intra, raw, qscale, mb_x, mb_y;
     uint32_t coef_off;  // dwords from the picture's first word
@@ -168,6 +173,7 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
     L.live = k < p.mb_count ? 1u : 0u;
     L.ok = 0;
     L.gi = p.mb_first + k;
+    L.pic = pic;
     L.d[0] = kRDead;
     L.d[1] = L.d[2] = L.d[3] = L.d[4] = L.d[5] = 0;
     L.cbp = L.intra = L.raw = L.qscale = L.mb_x = L.mb_y = 0;
@@ -220,7 +226,7 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
     if (!reason && mb.coef_off > x.n_words)
         reason = kPkSparse;
     if (reason) {
-        pk_report(a, L.gi, reason);
+        pk_report(a, L.pic, L.gi, reason);
         return L;
     }
     L.cbp = mb.cbp;
@@ -275,7 +281,7 @@ MPG_HD PkLane pk_scan(const PackArgs &a, uint32_t pic, const mpeghip_pic_desc &p
         at += 1 + cnt;
     }
     if (bad) {
-        pk_report(a, L.gi, kPkSparse);
+        pk_report(a, L.pic, L.gi, kPkSparse);
         L.ents = L.def_dw = 0;
         return L;
     }
@@ -331,7 +337,7 @@ MPG_HD void pk_emit(const PackArgs &a, const mpeghip_pic_desc &p, const PkPic &x
         const bool last = k + 1 >= p.mb_count;
         const uint32_t next = last ? x.n_words : (lane < 63 ? xch[(lane + 1) * kPkXchDwords + 3] : next_coef_off);
         if (L.end > next)
-            pk_report(a, last ? L.gi : L.gi + 1, last ? kPkSparse : kPkOrder);
+            pk_report(a, L.pic, last ? L.gi : L.gi + 1, last ? kPkSparse : kPkOrder);
     }
     // the chunk is packed if all its macroblocks are fine and in order INSIDE it (then its packed words fit between its first
     // macroblock's offset and its last one's end)
@@ -431,7 +437,7 @@ MPG_HD void pk_emit(const PackArgs &a, const mpeghip_pic_desc &p, const PkPic &x
         pk_put(out, bw + s++, word);
     }
     if (stray & 0xff03u) // bits outside a pair's two fields
-        pk_report(a, L.gi, kPkSparse);
+        pk_report(a, L.pic, L.gi, kPkSparse);
 }
 
 } // namespace mpg

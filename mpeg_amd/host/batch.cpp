@@ -26,6 +26,8 @@
 #include <sched.h>
 #include <stdio.h>
 
+#include <errno.h>
+
 #include "mpeg.hpp"
 
 namespace mpeg {
@@ -171,36 +173,107 @@ bool pinThisThreadToNode(int node)
 // cpu.cfs_quota_us / cpu.cfs_period_us).  A container that shows 256 hardware threads under a 10-core quota runs a 64-thread
 // pool 26 % SLOWER than a 16-thread one (BENCH_r04 host_parsed: the threads are throttled in turn and every round waits for the
 // last of them), so pools are sized by this, not by the number asked for.
+// One cgroup directory's quota in cores (0: none there).  v2: "<quota> <period>" or "max <period>" in cpu.max; v1: cpu.cfs_quota_us
+// (-1: none) / cpu.cfs_period_us.
+static double quotaOfCgroupDir(const std::string &dir, bool v2)
+{
+    if (v2) {
+        double out = 0;
+        if (FILE *f = fopen((dir + "/cpu.max").c_str(), "r")) {
+            char q[32] = {0};
+            double period = 0;
+            if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+                out = atof(q) / period;
+            fclose(f);
+        }
+        return out;
+    }
+    double q = 0, period = 0;
+    if (FILE *fq = fopen((dir + "/cpu.cfs_quota_us").c_str(), "r")) {
+        if (fscanf(fq, "%lf", &q) != 1)
+            q = 0;
+        fclose(fq);
+    }
+    if (FILE *fp = fopen((dir + "/cpu.cfs_period_us").c_str(), "r")) {
+        if (fscanf(fp, "%lf", &period) != 1)
+            period = 0;
+        fclose(fp);
+    }
+    return q > 0 && period > 0 ? q / period : 0;
+}
+
+// The tightest CPU-time quota that applies to this process: its own cgroup's AND every ancestor's (a quota set on a parent slice
+// binds the children; a process without a cgroup namespace — a systemd slice, a pod without cgroupns — sits in a NESTED directory
+// that the mount's root files say nothing about).  /proc/self/cgroup names the directory: "0::/a/b" (v2) or "N:cpu,cpuacct:/a/b"
+// (v1); the walk goes from there up to the mount's root.  `root` / `proc_file`: the tests' stand-ins for /sys/fs/cgroup and
+// /proc/self/cgroup.
+double CgroupQuotaCores(const char *root, const char *proc_file)
+{
+    const std::string base = root ? root : "/sys/fs/cgroup";
+    std::string v2_path, v1_path;
+    bool have_v2 = false, have_v1 = false;
+    if (FILE *f = fopen(proc_file ? proc_file : "/proc/self/cgroup", "r")) {
+        char line[4096];
+        while (fgets(line, sizeof(line), f)) {
+            std::string l(line);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r'))
+                l.pop_back();
+            const size_t a = l.find(':'), b = a == std::string::npos ? a : l.find(':', a + 1);
+            if (b == std::string::npos)
+                continue;
+            const std::string ctrl = l.substr(a + 1, b - a - 1), path = l.substr(b + 1);
+            if (ctrl.empty() && l.compare(0, a, "0") == 0) {
+                v2_path = path;
+                have_v2 = true;
+            } else if (("," + ctrl + ",").find(",cpu,") != std::string::npos) {
+                v1_path = path;
+                have_v1 = true;
+            }
+        }
+        fclose(f);
+    }
+    double tightest = 0;
+    auto walk = [&](const std::string &mount, std::string path, bool v2) {
+        for (;;) { // the process's directory, then its parents, then the mount's root
+            const double q = quotaOfCgroupDir(mount + (path == "/" ? "" : path), v2);
+            if (q > 0 && (tightest == 0 || q < tightest))
+                tightest = q;
+            if (path.empty() || path == "/")
+                break;
+            const size_t cut = path.find_last_of('/');
+            path = cut == 0 || cut == std::string::npos ? "/" : path.substr(0, cut);
+        }
+    };
+    // (a directory named by /proc/self/cgroup that the mount does not show — a cgroup namespace — simply has no files: the walk
+    // still reaches the mount's root, which is what round 5 looked at)
+    walk(base, have_v2 ? v2_path : "/", true);
+    walk(base + "/cpu", have_v1 ? v1_path : "/", false);
+    return tightest;
+}
+
+// The CPU time this process really gets, in cores: the affinity mask, capped by the cgroup CPU-time quota that applies to it
+// (CgroupQuotaCores).  A container that shows 256 hardware threads under a 10-core quota runs a 64-thread pool 26 % SLOWER than a
+// 16-thread one (BENCH_r04 host_parsed: the threads are throttled in turn and every round waits for the last of them), so pools
+// are sized by this, not by the number asked for.
 double EffectiveCores()
 {
     double cores = (double)std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0)
-        cores = (double)CPU_COUNT(&set);
+    // (a fixed cpu_set_t holds 1 024 CPUs: on a larger host the call fails with EINVAL — ask with a mask sized for the machine)
+    for (size_t n = 1024; n <= (1u << 20); n *= 4) {
+        cpu_set_t *set = CPU_ALLOC(n);
+        if (!set)
+            break;
+        const size_t bytes = CPU_ALLOC_SIZE(n);
+        const int rc = sched_getaffinity(0, bytes, set);
+        if (rc == 0)
+            cores = (double)CPU_COUNT_S(bytes, set);
+        CPU_FREE(set);
+        if (rc == 0 || errno != EINVAL)
+            break;
+    }
     if (cores < 1)
         cores = 1;
-    double quota = 0;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[32] = {0};
-        double period = 0;
-        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
-            quota = atof(q) / period;
-        fclose(f);
-    } else {
-        double q = 0, period = 0;
-        if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-            if (fscanf(fq, "%lf", &q) != 1)
-                q = 0;
-            fclose(fq);
-        }
-        if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-            if (fscanf(fp, "%lf", &period) != 1)
-                period = 0;
-            fclose(fp);
-        }
-        if (q > 0 && period > 0)
-            quota = q / period;
-    }
+    const double quota = CgroupQuotaCores(nullptr, nullptr);
     return quota > 0 && quota < cores ? quota : cores;
 }
 // threads a pool gets when `asked` are asked for (0 = as many as there is CPU time for): never more than the quota rounded up
@@ -446,10 +519,48 @@ void VideoBatch::Flush()
     std::fill(pending_.begin(), pending_.end(), 0);
 }
 
+// the verdict of the device-packed commits so far (their validation; the reconstruction goes on behind it)
+void VideoBatch::reapVerdict()
+{
+    if (!verdict_owed_)
+        return;
+    verdict_owed_ = false;
+    try {
+        store_->verdict();
+    } catch (...) {
+        refused_streams_ = store_->refusedStreams();
+        throw;
+    }
+}
+
+void VideoBatch::Sync()
+{
+    if (held_refusal_) {
+        std::exception_ptr e = held_refusal_;
+        held_refusal_ = nullptr;
+        std::rethrow_exception(e);
+    }
+    verdict_owed_ = false;
+    try {
+        store_->sync();
+    } catch (...) {
+        refused_streams_ = store_->refusedStreams();
+        throw;
+    }
+}
+
 size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
 {
     const size_t n = videos_.size();
     frames.assign(n, nullptr);
+    // A picture refused by the device in the previous round is reported HERE, before any stream parses its next picture: the
+    // streams are where they were, nothing of a healthy stream is lost, the caller's next DecodeAll goes on (mpeg.hpp).
+    if (held_refusal_) {
+        std::exception_ptr e = held_refusal_;
+        held_refusal_ = nullptr;
+        std::rethrow_exception(e);
+    }
+    reapVerdict();
     std::vector<uint32_t> slot(n, 0);
     std::vector<double> time(n, 0.0);
     std::vector<uint8_t> got(n, 0);
@@ -460,8 +571,18 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
     for (size_t i = 0; i < n; i++)
         todo[i] = (uint32_t)i;
     std::vector<int> result(n, 0);
+    bool first_round = true;
     while (!todo.empty()) {
         std::vector<uint32_t> again;
+        if (!first_round) { // (a later round of this call — streams at their start need two pictures for a frame: the verdict of
+                            // the round before it is asked for all the same, but thrown by the NEXT call: this one's frames are due)
+            try {
+                reapVerdict();
+            } catch (...) {
+                held_refusal_ = std::current_exception();
+            }
+        }
+        first_round = false;
         if (pool_ && todo.size() > 1) {
             // parse on the pool, every stream recording its own device requests ...
             for (uint32_t i : todo)
@@ -522,7 +643,8 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                         for (size_t g = 0; g < gn; g++)
                             all_sparse = all_sparse && (group[g0 + g]->pic.flags & MPEGHIP_PIC_SPARSE) != 0;
                         const double s0 = nowSeconds();
-                        store_->stageBegin(n_mbs, bytes, device_pack_ && all_sparse);
+                        const bool on_device = device_pack_ && all_sparse;
+                        store_->stageBegin(n_mbs, bytes, on_device);
                         const double s1 = nowSeconds();
                         t_begin_ += s1 - s0;
                         std::exception_ptr put_failed;
@@ -531,6 +653,13 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                                 const Port::Event *e = group[g0 + g];
                                 mpeghip_pic_desc p = e->pic;
                                 p.stream = group_stream[g0 + g];
+                                if (__builtin_expect(debug_damage_.load(std::memory_order_relaxed) == (int64_t)p.stream && !e->mbs.empty(), 0)) { // (test hook)
+                                    debug_damage_.store(-1);
+                                    std::vector<mpeghip_mb_desc> bad(e->mbs);
+                                    bad[bad.size() / 2].qscale = 0;
+                                    store_->stagePut((uint32_t)g, p, bad.data(), e->coefs.data());
+                                    return;
+                                }
                                 store_->stagePut((uint32_t)g, p, e->mbs.data(), e->coefs.data());
                             });
                         } catch (...) {
@@ -547,6 +676,7 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                         t_commit_ += nowSeconds() - s2;
                         if (put_failed)
                             std::rethrow_exception(put_failed);
+                        verdict_owed_ = verdict_owed_ || on_device;
                         device_submits_++;
                         queued_pictures_ += gn;
                     }
@@ -860,10 +990,28 @@ Video *ShardedVideoBatch::AddStream(Buffer *buf)
     return v;
 }
 
+// The shards' pools share ONE budget — the CPU time of the process (EffectiveCores): n threads in all (0: as many as fit), divided
+// among the shards, at least one each.  (Round 5 forwarded n to every shard: G shards started up to G x the quota, the throttled
+// oversubscription the cap exists to prevent.)
 void ShardedVideoBatch::SetThreads(unsigned n)
 {
+    const unsigned shards = (unsigned)shards_.size();
+    if (!shards)
+        return;
+    const unsigned fit = (unsigned)std::ceil(EffectiveCores());
+    const unsigned total = n == 0 || n > fit ? (fit < 1 ? 1 : fit) : n;
+    for (unsigned i = 0; i < shards; i++) {
+        const unsigned share = total / shards + (i < total % shards ? 1 : 0);
+        shards_[i]->batch->SetThreads(share < 1 ? 1 : share);
+    }
+}
+
+unsigned ShardedVideoBatch::Threads() const
+{
+    unsigned total = 0;
     for (auto &sh : shards_)
-        sh->batch->SetThreads(n);
+        total += sh->batch->Threads();
+    return total;
 }
 
 void ShardedVideoBatch::SetDevicePack(bool on)

@@ -390,6 +390,8 @@ int mpeghost_batch_decode_all(void *hv, int fetch)
 }
 // CPU time the process gets, in cores (affinity mask capped by the cgroup quota): what pools are sized by
 double mpeghost_effective_cores(void) { return mpeg::EffectiveCores(); }
+// its cgroup part over a stand-in hierarchy (tests): root = what /sys/fs/cgroup would be, proc_file = /proc/self/cgroup's text
+double mpeghost_cgroup_quota_cores(const char *root, const char *proc_file) { return mpeg::CgroupQuotaCores(root, proc_file); }
 uint32_t mpeghost_batch_threads(void *hv) { return static_cast<BatchHandle *>(hv)->batch->Threads(); }
 // host threads of the parse (VideoBatch::SetThreads)
 void mpeghost_batch_set_threads(void *hv, uint32_t n)
@@ -424,6 +426,17 @@ int mpeghost_batch_sync(void *hv)
         return 0;
     }, -1);
 }
+// the streams whose picture the refusal last reported (a -1 of decode_all / sync) named: up to cap of them; returns their number
+uint32_t mpeghost_batch_refused_streams(void *hv, uint32_t *out, uint32_t cap)
+{
+    const std::vector<uint32_t> &r = static_cast<BatchHandle *>(hv)->batch->RefusedStreams();
+    for (size_t i = 0; i < r.size() && i < cap; i++)
+        out[i] = r[i];
+    return (uint32_t)r.size();
+}
+int mpeghost_batch_device_pack(void *hv) { return static_cast<BatchHandle *>(hv)->batch->DevicePack() ? 1 : 0; }
+// test hook (VideoBatch::DebugDamageNextPicture): the next picture of `stream` is damaged on its way to the device
+void mpeghost_batch_debug_damage_next_picture(void *hv, uint32_t stream) { static_cast<BatchHandle *>(hv)->batch->DebugDamageNextPicture(stream); }
 void mpeghost_batch_numa_pins(void *hv, uint32_t out[2])
 {
     unsigned p[2];
@@ -472,6 +485,7 @@ void mpeghost_sharded_set_threads(void *hv, unsigned n)
         return 0;
     }, -1);
 }
+uint32_t mpeghost_sharded_threads(void *hv) { return static_cast<ShardedHandle *>(hv)->batch->Threads(); }
 void mpeghost_sharded_set_device_pack(void *hv, int on)
 {
     guard([&]() -> int {

@@ -133,6 +133,14 @@ public:
         check(mpeghip_video_stage_commit(s), "mpeghip_video_stage_commit");
     }
     void sync() override { check(mpeghip_video_sync(store_), "mpeghip_video_sync"); }
+    void verdict() override { check(mpeghip_video_verdict(store_), "mpeghip_video_verdict"); }
+    std::vector<uint32_t> refusedStreams() override
+    {
+        std::vector<uint32_t> streams(1024);
+        const uint64_t n = mpeghip_video_refused(store_, nullptr, streams.data(), (uint32_t)streams.size());
+        streams.resize(n < streams.size() ? (size_t)n : streams.size());
+        return streams;
+    }
 
 private:
     mpeghip_ctx *ctx_;

@@ -29,6 +29,7 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <atomic>
 #include <exception>
 
 #include "mpeghip.h"
@@ -251,6 +252,10 @@ public:
     virtual void stagePut(uint32_t, const mpeghip_pic_desc &, const mpeghip_mb_desc *, const uint8_t *) {}
     virtual void stageCommit() {}
     virtual void sync() {}                          // wait for queued work; throws a device-packed commit's deferred error
+    // wait until the device-packed commits so far are VALIDATED (not reconstructed); throws their deferred error — a refusal is per
+    // picture: refusedStreams() then names the streams whose picture was refused (the commit's other pictures were reconstructed)
+    virtual void verdict() { sync(); }
+    virtual std::vector<uint32_t> refusedStreams() { return {}; }
 };
 
 class AudioBackend {
@@ -499,6 +504,9 @@ class HostPool;
 // pools never start more threads than this (rounded up): SetThreads(n) is a request, Threads() says what it became;
 // SetThreads(0) asks for "as many as fit".
 double EffectiveCores();
+// ... its cgroup part: the tightest CPU-time quota (in cores; 0: none) of the process's cgroup and all its ancestors, v2 and v1
+// (root / proc_file: stand-ins for /sys/fs/cgroup and /proc/self/cgroup — tests; nullptr = the real ones)
+double CgroupQuotaCores(const char *root, const char *proc_file);
 
 class VideoBatch {
 public:
@@ -528,15 +536,22 @@ public:
     int NumaNode() const { return numa_node_; }
     // threads of this batch that asked to be bound to the node / whose binding failed (no such node, sched_setaffinity refused)
     void NumaPins(unsigned out[2]) const;
-    // Staged submits of sparse pictures are validated and packed by the pool's threads on the host (default: a picture the
-    // validator refuses makes the DecodeAll that sent it throw, as a refused mpeghip_video_submit does) or — opt-in — ON THE
-    // DEVICE (mpeghip_video_stage_begin_device: the host side of the hand-over shrinks to a copy).  Device-packed commits report
-    // DEFERRED: a refused picture surfaces at Sync() / the next fetch / a later DecodeAll, the whole commit (other streams'
-    // healthy pictures too) has reconstructed nothing, and the parsers have moved on — call Sync() after every DecodeAll
-    // whose verdict matters.  (The product's parser does not emit pictures the validator refuses)
+    // Staged submits of sparse pictures are validated and packed ON THE DEVICE (the default since round 6:
+    // mpeghip_video_stage_begin_device — the host side of the hand-over shrinks to a copy; 16 % more pictures per second from
+    // bitstreams than the other form) or, SetDevicePack(false), by the pool's threads on the host (a picture the validator refuses
+    // then makes the DecodeAll that sent it throw, as a refused mpeghip_video_submit does).  The device reports DEFERRED, and per
+    // PICTURE — the unit of failure of the reference (video.go:374-460): the refused picture is not reconstructed, the commit's
+    // other pictures (other streams) are.  Every round of a DecodeAll first waits for the verdict of the commit before it (its
+    // validation, not its reconstruction), so a picture refused in round k is reported — DecodeAll throws, RefusedStreams() names
+    // the streams — BEFORE round k + 1 parses anything: no parser has moved on, no healthy stream has lost a picture, and the next
+    // DecodeAll simply goes on.  (The product's parser does not emit pictures the validator refuses)
     void SetDevicePack(bool on) { device_pack_ = on; }
     bool DevicePack() const { return device_pack_; }
-    void Sync() { store_->sync(); }
+    void Sync();
+    const std::vector<uint32_t> &RefusedStreams() const { return refused_streams_; } // of the refusal last thrown
+    // test hook: the next picture stream `stream` hands over is damaged on its way (a quantiser scale of 0: what the parser cannot
+    // produce and every validator refuses) — the error contract above, end to end
+    void DebugDamageNextPicture(uint32_t stream) { debug_damage_.store((int64_t)stream); }
     void Flush();                                  // submit whatever is queued
     uint64_t DeviceSubmits() const { return device_submits_; }
     uint64_t QueuedPictures() const { return queued_pictures_; }
@@ -561,7 +576,12 @@ private:
     std::vector<mpeghip_mb_desc> mbs_;
     std::vector<uint8_t> coefs_;
     bool any_sparse_queued_ = false;
-    bool device_pack_ = false;
+    bool device_pack_ = true;
+    bool verdict_owed_ = false;                    // a device-packed commit whose verdict has not been asked for
+    std::exception_ptr held_refusal_;              // a refusal learnt between two rounds of one DecodeAll: thrown by the next one
+    std::vector<uint32_t> refused_streams_;
+    std::atomic<int64_t> debug_damage_{-1};
+    void reapVerdict();
     std::vector<uint8_t> pending_;                 // stream already has a picture in the open batch
     uint64_t device_submits_ = 0, queued_pictures_ = 0;
     double t_parse_ = 0, t_put_ = 0, t_commit_ = 0, t_begin_ = 0; // wall time per phase (PhaseSeconds)
@@ -582,7 +602,10 @@ public:
     uint32_t Shards() const { return (uint32_t)shards_.size(); }
     uint32_t ShardOf(uint32_t stream) const { return stream % Shards(); }
     VideoBatch &Shard(uint32_t g);
-    void SetThreads(unsigned n);                   // parse threads of every shard
+    // parse threads of ALL shards together (0: as many as the process has CPU time for — EffectiveCores — and never more): the
+    // budget is divided among the shards, at least one thread each; Threads() = what the shards' pools add up to
+    void SetThreads(unsigned n);
+    unsigned Threads() const;
     void SetDevicePack(bool on);                   // VideoBatch::SetDevicePack of every shard
     void Sync();                                   // VideoBatch::Sync of every shard: waits; throws the first deferred error
     // one tick of every shard, concurrently; frames[s] = the next frame of global stream s (or nullptr)

@@ -50,24 +50,60 @@ def pin_to_node(node: int):
         return 0
 
 
-def effective_cores():
-    """The CPU time this process can really get, in cores: the cgroup quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) if one
-    is set, capped by the affinity mask; None for the quota part if there is none.  A container that exposes 256 hardware
-    threads under a 10-core quota runs 256 threads at 10 cores' worth of time: pools are sized, and baselines quoted, by this."""
-    mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    quota = None
+def _quota_of_cgroup_dir(path: str, v2: bool):
+    """One cgroup directory's CPU-time quota in cores, or 0.0 (none there)."""
     try:
-        txt = open("/sys/fs/cgroup/cpu.max").read().split()
-        if txt and txt[0] != "max":
-            quota = float(txt[0]) / float(txt[1])
+        if v2:
+            txt = open(os.path.join(path, "cpu.max")).read().split()
+            return float(txt[0]) / float(txt[1]) if len(txt) == 2 and txt[0] != "max" and float(txt[1]) > 0 else 0.0
+        q = float(open(os.path.join(path, "cpu.cfs_quota_us")).read())
+        per = float(open(os.path.join(path, "cpu.cfs_period_us")).read())
+        return q / per if q > 0 and per > 0 else 0.0
     except (OSError, ValueError, IndexError):
-        try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0 and per > 0:
-                quota = q / per
-        except (OSError, ValueError):
-            quota = None
+        return 0.0
+
+
+def cgroup_quota_cores(root: str = "/sys/fs/cgroup", proc_file: str = "/proc/self/cgroup") -> float:
+    """The tightest CPU-time quota (cores; 0.0 = none) that applies to this process: its own cgroup's and every ancestor's, v2
+    (cpu.max) and v1 (cpu/cpu.cfs_*), found through /proc/self/cgroup — a process in a nested cgroup (no cgroup namespace: a
+    systemd slice, a pod without cgroupns) never sees its quota in the mount's root files.  The library's rule
+    (mpeg::CgroupQuotaCores, batch.cpp), restated: tests compare the two on made-up hierarchies."""
+    v2_path = v1_path = None
+    try:
+        for line in open(proc_file).read().splitlines():
+            parts = line.split(":", 2)
+            if len(parts) != 3:
+                continue
+            if parts[0] == "0" and parts[1] == "":
+                v2_path = parts[2]
+            elif "cpu" in parts[1].split(","):
+                v1_path = parts[2]
+    except OSError:
+        pass
+    tightest = 0.0
+
+    def walk(mount, path, v2):
+        nonlocal tightest
+        while True:
+            q = _quota_of_cgroup_dir(mount + ("" if path == "/" else path), v2)
+            if q > 0 and (tightest == 0 or q < tightest):
+                tightest = q
+            if path in ("", "/"):
+                return
+            cut = path.rfind("/")
+            path = "/" if cut <= 0 else path[:cut]
+
+    walk(root, v2_path if v2_path is not None else "/", True)
+    walk(os.path.join(root, "cpu"), v1_path if v1_path is not None else "/", False)
+    return tightest
+
+
+def effective_cores():
+    """The CPU time this process can really get, in cores: the cgroup quota that applies to it (cgroup_quota_cores) if one is set,
+    capped by the affinity mask; None for the quota part if there is none.  A container that exposes 256 hardware threads under a
+    10-core quota runs 256 threads at 10 cores' worth of time: pools are sized, and baselines quoted, by this."""
+    mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_quota_cores() or None
     return {"affinity_cpus": mask, "cgroup_quota_cores": quota, "effective_cores": min(float(mask), quota) if quota else float(mask)}
 
 

@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <stdexcept>
+#include <string>
 
 #include <vector>
 
@@ -145,13 +147,35 @@ public:
     {
         if (stage_puts_.load() != st_pics_.size())
             abort();
-        // a device-packed stage: the pictures go through the DEVICE packer's lane functions (video_pack_lane.h), wave by wave
-        emu_set_device_pack(st_device_pack_ ? 1 : 0);
-        submit(st_pics_.data(), (uint32_t)st_pics_.size(), st_mbs_.data(), (uint32_t)st_mbs_.size(), st_coefs_.data(),
-               st_coefs_.size());
-        emu_set_device_pack(0);
+        // a device-packed stage: the pictures go through the DEVICE packer's lane functions (video_pack_lane.h), wave by wave —
+        // picture by picture here, because a refusal is the picture's own (pack_gate_kernel): the others are reconstructed, the
+        // refused one's stream is remembered for verdict() / sync(), which report it once
+        if (st_device_pack_) {
+            emu_set_device_pack(1);
+            for (size_t i = 0; i < st_pics_.size(); i++) {
+                const int rc = emu_video_run(frames_.data(), stride_, lw_, lh_, w_, h_, &st_pics_[i], 1, st_mbs_.data(), (uint32_t)st_mbs_.size(),
+                                             st_coefs_.data(), qt_, rgba_.data(), rgba_stride_);
+                if (rc != 0)
+                    pending_refused_.push_back(st_pics_[i].stream);
+            }
+            emu_set_device_pack(0);
+        } else {
+            submit(st_pics_.data(), (uint32_t)st_pics_.size(), st_mbs_.data(), (uint32_t)st_mbs_.size(), st_coefs_.data(),
+                   st_coefs_.size());
+        }
         staged_commits_++;
     }
+    void sync() override { verdict(); }
+    void verdict() override
+    {
+        if (pending_refused_.empty())
+            return;
+        refused_ = pending_refused_;
+        pending_refused_.clear();
+        throw std::runtime_error("device-packed commit: " + std::to_string(refused_.size()) + " picture(s) refused and not reconstructed "
+                                 "(the others were): stream " + std::to_string(refused_[0]));
+    }
+    std::vector<uint32_t> refusedStreams() override { return refused_; }
     void readPlanes(uint32_t stream, uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
         std::vector<uint8_t> lin(luma_ + 2 * chroma_);
@@ -178,6 +202,7 @@ private:
     std::atomic<size_t> stage_puts_{0};
 
     bool st_device_pack_ = false;
+    std::vector<uint32_t> pending_refused_, refused_;
 
 public:
     uint64_t staged_commits_ = 0, device_pack_stages_ = 0;

@@ -79,6 +79,9 @@ def host():
             "mpeghost_batch_set_device_pack": (None, [P, C.c_int]), "mpeghost_batch_sync": (C.c_int, [P]),
             "mpeghost_batch_numa_pins": (None, [P, C.POINTER(C.c_uint32 * 2)]),
             "mpeghost_batch_threads": (C.c_uint32, [P]), "mpeghost_effective_cores": (C.c_double, []),
+            "mpeghost_cgroup_quota_cores": (C.c_double, [C.c_char_p, C.c_char_p]),
+            "mpeghost_batch_refused_streams": (C.c_uint32, [P, C.POINTER(C.c_uint32), C.c_uint32]), "mpeghost_batch_device_pack": (C.c_int, [P]),
+            "mpeghost_batch_debug_damage_next_picture": (None, [P, C.c_uint32]), "mpeghost_sharded_threads": (C.c_uint32, [P]),
             "mpeghost_sharded_set_device_pack": (None, [P, C.c_int]), "mpeghost_sharded_sync": (C.c_int, [P]),
             "mpeghost_sharded_open": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
             "mpeghost_sharded_open_stores": (P, [C.POINTER(P), C.c_uint32, C.c_uint32]),
@@ -426,6 +429,16 @@ class HostBatch:
     def sync(self):
         if host().mpeghost_batch_sync(self.h) != 0:
             raise RuntimeError(host().mpeghost_last_error().decode())
+
+    device_pack = property(lambda s: bool(host().mpeghost_batch_device_pack(s.h)))
+
+    def refused_streams(self):
+        out = (C.c_uint32 * 1024)()
+        n = host().mpeghost_batch_refused_streams(self.h, out, 1024)
+        return list(out[:min(n, 1024)])
+
+    def damage_next_picture(self, stream: int):
+        host().mpeghost_batch_debug_damage_next_picture(self.h, stream)
 
     def counters(self):
         out = (C.c_uint64 * 2)()

@@ -126,10 +126,12 @@ def _cases(good_mbs, words, k):
     return out
 
 
-def test_malformed_pictures_are_refused_at_the_next_sync_and_nothing_is_reconstructed(oracle, hip_ctx):
-    """Every kind of damage, in a commit of three streams of which ONE is damaged: the commit returns OK, mpeghip_video_sync
-    returns the error ONCE, none of the three pictures was reconstructed, and the handle goes on working — the same pictures,
-    undamaged, then reconstruct bit-exactly.  The host-packed stage refuses the same input at its put / commit."""
+def test_malformed_pictures_are_refused_at_the_next_sync_and_the_other_pictures_are_reconstructed(oracle, hip_ctx):
+    """Every kind of damage, in a commit of three streams of which ONE is damaged: the commit returns OK, mpeghip_video_verdict /
+    mpeghip_video_sync return the error ONCE and mpeghip_video_refused names the picture and its stream; the damaged picture was
+    not reconstructed (its stream's slots are untouched), the two healthy streams' pictures WERE (ABI 3: the unit of failure is the
+    picture, video.go:374-460), and the handle goes on working — the same pictures, undamaged, then reconstruct bit-exactly.  The
+    host-packed stage refuses the same input at its put / commit."""
     w, h, n_streams = 96, 64, 3
     seq = synth.generate_sequence(w, h, 3, seed=8, profile="dense")
     ref = oracle.OracleStore(w, h)
@@ -152,17 +154,21 @@ def test_malformed_pictures_are_refused_at_the_next_sync_and_nothing_is_reconstr
         k = next(i for i in range(1, len(good_mbs) - 1)
                  if good_mbs[i]["cbp"] and not (good_mbs[i]["flags"] & (desc.MB_COEF_RAW | desc.MB_INTRA)))
         before = [[dut.read_planes(st, slot) for slot in range(3)] for st in range(n_streams)]
-        for name, mbs, words, code in _cases(good_mbs, good_words, k):
+        ref.submit(s.pics, s.mbs, s.coefs)                            # (what the healthy streams hold after the commit: the P picture, submitted again and again)
+        for i, (name, mbs, words, code) in enumerate(_cases(good_mbs, good_words, k)):
             rcs = dut.submit_staged_device(parts_of(s, mbs, words, bad_stream=1), threads=2, sync=False)   # the commit itself: OK
             assert all(rc == 0 for rc in rcs), name
             with pytest.raises(abi.MpegHipError) as e:
-                dut.sync()
+                dut.verdict() if i % 2 else dut.sync()                # (the verdict alone waits for the validation only)
             assert e.value.code == code, (name, str(e.value))
-            assert "picture 1" in str(e.value) and "nothing of it was reconstructed" in str(e.value), (name, str(e.value))
-            dut.sync()                                                # reported once
-            for st in range(n_streams):
-                for slot in range(3):
-                    assert_planes_equal(before[st][slot], dut.read_planes(st, slot), "%s: stream %d slot %d was touched" % (name, st, slot))
+            assert "picture 1 (stream 1)" in str(e.value) and "1 of its 3 pictures refused" in str(e.value), (name, str(e.value))
+            assert dut.refused() == (1, [(1, 1)]), name
+            dut.verdict()                                             # reported once
+            dut.sync()
+            for slot in range(3):
+                assert_planes_equal(before[1][slot], dut.read_planes(1, slot), "%s: the refused picture's stream, slot %d, was touched" % (name, slot))
+                for st in (0, 2):
+                    assert_planes_equal(ref.read_planes(0, slot), dut.read_planes(st, slot), "%s: healthy stream %d slot %d" % (name, st, slot))
             with pytest.raises(abi.MpegHipError) as e:                # the host-packed stage: the same input, refused in the call
                 hostside.submit_staged_sparse(parts_of(s, mbs, words, bad_stream=1))
             assert e.value.code == code, (name, str(e.value))
@@ -172,9 +178,16 @@ def test_malformed_pictures_are_refused_at_the_next_sync_and_nothing_is_reconstr
         with pytest.raises(abi.MpegHipError):
             dut.read_planes(0, 0)
         dut.read_planes(0, 0)
-        # and the stream continues bit-exactly
-        for s in seq[1:]:
-            ref.submit(s.pics, s.mbs, s.coefs)
+        # two damaged pictures in one commit: both named, the third picture reconstructed
+        dut.submit_staged_device([(p, mbs, words) if st != 0 else (p, good_mbs, good_words)
+                                  for st, (p, _, _) in enumerate(parts_of(s))], sync=False)
+        with pytest.raises(abi.MpegHipError) as e:
+            dut.verdict()
+        assert "2 of its 3 pictures refused" in str(e.value) and dut.refused() == (2, [(1, 1), (2, 2)])
+        # and the streams continue bit-exactly
+        for i, s in enumerate(seq[1:]):
+            if i:
+                ref.submit(s.pics, s.mbs, s.coefs)
             dut.submit_staged_device(parts_of(s))
         for st in range(n_streams):
             for slot in range(3):
@@ -204,11 +217,13 @@ def test_pictures_that_depend_on_each_other_are_refused(oracle, hip_ctx):
         dut.submit_staged_device([a, b], sync=False)
         with pytest.raises(abi.MpegHipError) as e:
             dut.sync()
-        assert e.value.code == abi.ERR_INVALID and "depend" in str(e.value)
-        for slot in range(3):
-            assert not any(p.any() for p in dut.read_planes(0, slot)), "the refused commit wrote something"
-        # the same two pictures in two commits
+        assert e.value.code == abi.ERR_INVALID and "depend" in str(e.value) and "picture 1" in str(e.value)
+        assert dut.refused() == (1, [(1, 0)])
+        # the P picture — the one that reads what the other writes — was refused, the I picture reconstructed
         ref.submit(i_pic.pics, i_pic.mbs, i_pic.coefs)
+        for slot in range(3):
+            assert_planes_equal(ref.read_planes(0, slot), dut.read_planes(0, slot), "after the refused P picture: slot %d" % slot)
+        # the same two pictures in two commits
         ref.submit(p_pic.pics, p_pic.mbs, p_pic.coefs)
         dut.submit_staged_device([a])
         dut.submit_staged_device([b])
@@ -250,6 +265,13 @@ def test_golden_and_written_streams_through_the_parser_and_the_device_packer(ora
     for device_pack in (True, False):
         h, n, c = run_batch(oracle, [es] * 4, [0, 0, 1, 5], device=device, threads=3, device_pack=device_pack)
         assert h == [VIDEO_HASH] * 4 and n == [260] * 4, device_pack
+
+
+def test_a_refused_picture_is_reported_before_the_next_round_parses_on_gpu(oracle, golden_dir, device):
+    """tests/test_host_batch.py's contract on the HIP store: pack_gate_kernel refuses the damaged picture alone, mpeghip_video_verdict
+    reports it at the start of the next DecodeAll, the other streams' frames are the golden ones to the end."""
+    from test_host_batch import run_refusal
+    run_refusal(oracle, (golden_dir / "test.mpeg1video").read_bytes(), device, 3)
 
 
 def test_the_damaged_golden_stream_on_recon_kernel_too(oracle, golden_dir, device):

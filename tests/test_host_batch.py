@@ -231,3 +231,98 @@ def test_audio_batch_with_a_pool_flushes_a_frame_decoded_outside_the_batch_tick(
         got[threads] = h
         b.close()
     assert got[1] == got[3] and got[1][0] == got[1][2] != got[1][1]
+
+
+def _cgroup_tree(tmp_path, files, proc_text):
+    root = tmp_path / "cg"
+    for rel, text in files.items():
+        f = root / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(text)
+    root.mkdir(exist_ok=True)
+    proc = tmp_path / "proc_self_cgroup"
+    proc.write_text(proc_text)
+    return str(root).encode(), str(proc).encode()
+
+
+@pytest.mark.parametrize("files,proc,want", [
+    ({"cpu.max": "1000000 100000\n"}, "0::/\n", 10.0),                                              # the mount's root (a container with a cgroup namespace)
+    ({"cpu.max": "max 100000\n", "kube/pod1/cpu.max": "400000 100000\n", "kube/pod1/ctr/cpu.max": "max 100000\n"},
+     "0::/kube/pod1/ctr\n", 4.0),                                                                    # nested, the quota on the PARENT (round-5 advisor)
+    ({"cpu.max": "max 100000\n", "a/cpu.max": "800000 100000\n", "a/b/cpu.max": "250000 100000\n"}, "0::/a/b\n", 2.5),   # the tightest of the chain
+    ({"cpu.max": "max 100000\n", "a/cpu.max": "200000 100000\n"}, "0::/other\n", 0.0),               # not our branch
+    ({"cpu/cpu.cfs_quota_us": "-1\n", "cpu/cpu.cfs_period_us": "100000\n", "cpu/docker/x/cpu.cfs_quota_us": "350000\n",
+      "cpu/docker/x/cpu.cfs_period_us": "100000\n"}, "12:pids:/docker/x\n5:cpu,cpuacct:/docker/x\n", 3.5),               # v1, nested
+    ({"cpu/cpu.cfs_quota_us": "600000\n", "cpu/cpu.cfs_period_us": "100000\n"}, "5:cpuacct,cpu:/\n", 6.0),               # v1, root
+    ({}, "0::/nowhere\n", 0.0),
+])
+def test_the_cgroup_quota_is_the_tightest_of_the_process_and_its_ancestors(tmp_path, files, proc, want):
+    """mpeg::CgroupQuotaCores and its Python restatement (bench.py's effective_cores) on made-up hierarchies: the process's cgroup
+    from /proc/self/cgroup, every ancestor up to the mount's root, v2 and v1."""
+    from mpeg_amd.shard import cgroup_quota_cores
+    root, procf = _cgroup_tree(tmp_path, files, proc)
+    got = hostlib.host().mpeghost_cgroup_quota_cores(root, procf)
+    assert abs(got - want) < 1e-9, got
+    assert abs(cgroup_quota_cores(root.decode(), procf.decode()) - want) < 1e-9
+
+
+def test_sharded_pools_share_one_thread_budget():
+    """ShardedVideoBatch::SetThreads(n): n threads for ALL shards together, never more than the process has CPU time for, at least
+    one per shard (round-5 advisor: n went to EVERY shard — G x the quota on a G-GPU node)."""
+    import math
+    L = hostlib.host()
+    cap = max(1, math.ceil(L.mpeghost_effective_cores()))
+    for shards in (2, 3):
+        b = hostlib.HostSharded(6, shards)
+        for asked in (0, 1, shards, 4096):
+            b.set_threads(asked)
+            total = L.mpeghost_sharded_threads(b.h)
+            want = max(shards, cap if asked == 0 else min(asked, cap))
+            assert total == want, (shards, asked, total, want)
+        b.close()
+
+
+@pytest.mark.parametrize("threads", [2, 4])
+def test_a_refused_picture_is_reported_before_the_next_round_parses_and_costs_the_other_streams_nothing(oracle, golden_dir, threads):
+    """Device-packed hand-over is the default (round 6), and its error contract is the reference's unit of failure — the picture:
+    stream 2's picture of round k arrives damaged (test hook: a quantiser scale of 0, what no parser emits and every validator
+    refuses).  Round k itself returns normally (the verdict is deferred); the NEXT DecodeAll throws BEFORE it parses anything —
+    RefusedStreams() = [2], no stream has moved — and the one after that goes on.  Every other stream's frames, all the way to
+    the end, are the golden ones: the commit that carried the damaged picture reconstructed theirs."""
+    run_refusal(oracle, (golden_dir / "test.mpeg1video").read_bytes(), None, threads)
+
+
+def run_refusal(oracle, es, device, threads):
+    n_streams, victim, at_tick = 5, 2, 20
+    b = hostlib.HostBatch(n_streams, device=device, threads=threads)
+    assert b.device_pack                                       # the default
+    for _ in range(n_streams):
+        b.add_stream(es)
+    h, n = [oracle.FNV_OFFSET] * n_streams, [0] * n_streams
+    tick, reported_at = 0, None
+    while True:
+        if tick == at_tick:
+            b.damage_next_picture(victim)
+        try:
+            produced = b.decode_all()
+        except RuntimeError as e:
+            assert reported_at is None and tick == at_tick + 1, (tick, str(e))      # the round right after: before it parsed
+            assert "refused" in str(e) and b.refused_streams() == [victim]
+            reported_at = tick
+            tick += 1
+            continue
+        for i in range(n_streams):
+            f = b.frame(i)
+            if f is not None:
+                for p in hostlib.frame_planes(f):
+                    h[i] = oracle.fnv1a64(p, h[i])
+                n[i] += 1
+        tick += 1
+        if produced == 0:
+            break
+    b.sync()
+    b.close()
+    assert reported_at == at_tick + 1
+    assert n == [260] * n_streams                                                   # nobody lost a frame (the victim's is a stale one)
+    assert [h[i] for i in range(n_streams) if i != victim] == [VIDEO_HASH] * (n_streams - 1)
+    assert h[victim] != VIDEO_HASH                                                  # (its picture really was dropped)
