@@ -553,37 +553,39 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
 {
     const size_t n = videos_.size();
     frames.assign(n, nullptr);
-    // A picture refused by the device in the previous round is reported HERE, before any stream parses its next picture: the
-    // streams are where they were, nothing of a healthy stream is lost, the caller's next DecodeAll goes on (mpeg.hpp).
-    if (held_refusal_) {
+    // The state of a tick lives in the batch (round_): a call that throws a REFUSAL — the device's verdict on the round before —
+    // has parsed its round already and keeps it; the next call takes up exactly there (it commits the held round instead of
+    // parsing) and returns the tick's frames.
+    if (held_refusal_) { // (learnt while the previous tick's frames were fetched)
         std::exception_ptr e = held_refusal_;
         held_refusal_ = nullptr;
         std::rethrow_exception(e);
     }
-    reapVerdict();
-    std::vector<uint32_t> slot(n, 0);
-    std::vector<double> time(n, 0.0);
-    std::vector<uint8_t> got(n, 0);
-    // Rounds of "every stream that still owes a frame parses ONE picture, then one device call": a tick
-    // costs as many calls as the neediest stream has pictures in it (1; 2 at a stream's start), not one
-    // per stream.
-    std::vector<uint32_t> todo(n);
-    for (size_t i = 0; i < n; i++)
-        todo[i] = (uint32_t)i;
-    std::vector<int> result(n, 0);
-    bool first_round = true;
+    std::vector<uint32_t> &slot = round_.slot, &todo = round_.todo;
+    std::vector<double> &time = round_.time;
+    std::vector<uint8_t> &got = round_.got;
+    std::vector<int> &result = round_.result;
+    if (!round_.held) {
+        slot.assign(n, 0);
+        time.assign(n, 0.0);
+        got.assign(n, 0);
+        // Rounds of "every stream that still owes a frame parses ONE picture, then one device call": a tick
+        // costs as many calls as the neediest stream has pictures in it (1; 2 at a stream's start), not one
+        // per stream.
+        todo.resize(n);
+        for (size_t i = 0; i < n; i++)
+            todo[i] = (uint32_t)i;
+        result.assign(n, 0);
+    } else if (got.size() != n) { // (a stream was added while a round was held: it joins at the next tick)
+        slot.resize(n, 0);
+        time.resize(n, 0.0);
+        got.resize(n, 0);
+        result.resize(n, 0);
+    }
     while (!todo.empty()) {
         std::vector<uint32_t> again;
-        if (!first_round) { // (a later round of this call — streams at their start need two pictures for a frame: the verdict of
-                            // the round before it is asked for all the same, but thrown by the NEXT call: this one's frames are due)
-            try {
-                reapVerdict();
-            } catch (...) {
-                held_refusal_ = std::current_exception();
-            }
-        }
-        first_round = false;
         if (pool_ && todo.size() > 1) {
+            if (!round_.held) {
             // parse on the pool, every stream recording its own device requests ...
             for (uint32_t i : todo)
                 ports_[i]->recording = true;
@@ -604,6 +606,19 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
                 for (uint32_t i : todo)
                     ports_[i]->n_events = 0;
                 std::rethrow_exception(failed);
+            }
+            }
+            round_.held = false;
+            // ... the device's verdict on the commit BEFORE this round (its pictures have been there for a whole parse: no wait in
+            // practice — asked for before the parse, the same question cost 1.4 ms of idle host per round, 14 % of the
+            // pictures per second).  A refusal is thrown here, with this round parsed but not handed over: nothing of it is
+            // lost, the next call commits it.  RefusedStreams() names the streams; every other stream's picture of the
+            // refused commit was reconstructed.
+            try {
+                reapVerdict();
+            } catch (...) {
+                round_.held = true;
+                throw;
             }
             // ... then replay them here: the k-th request of every stream, in stream order (requests of
             // different streams commute; two pictures of one stream never share a device call).  Pictures go
@@ -712,6 +727,7 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
             for (uint32_t i : todo)
                 ports_[i]->n_events = 0;
         } else {
+            reapVerdict(); // (this path hands over through submit(): a verdict can only be owed from a pooled round before it)
             for (uint32_t i : todo)
                 result[i] = videos_[i]->DecodeStep(&slot[i], &time[i]);
         }
@@ -723,6 +739,15 @@ size_t VideoBatch::DecodeAll(std::vector<Frame *> &frames, bool fetch)
         }
         Flush();
         todo.swap(again);
+    }
+    // With fetch the frames' read-backs below wait for the device, and the first of them would report a refusal of THIS tick's
+    // commit from the middle of the loop: ask now, keep the answer for the next call (which throws it before it parses).
+    if (fetch) {
+        try {
+            reapVerdict();
+        } catch (...) {
+            held_refusal_ = std::current_exception();
+        }
     }
     size_t produced = 0;
     for (size_t i = 0; i < n; i++)

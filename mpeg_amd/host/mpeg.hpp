@@ -541,10 +541,11 @@ public:
     // bitstreams than the other form) or, SetDevicePack(false), by the pool's threads on the host (a picture the validator refuses
     // then makes the DecodeAll that sent it throw, as a refused mpeghip_video_submit does).  The device reports DEFERRED, and per
     // PICTURE — the unit of failure of the reference (video.go:374-460): the refused picture is not reconstructed, the commit's
-    // other pictures (other streams) are.  Every round of a DecodeAll first waits for the verdict of the commit before it (its
-    // validation, not its reconstruction), so a picture refused in round k is reported — DecodeAll throws, RefusedStreams() names
-    // the streams — BEFORE round k + 1 parses anything: no parser has moved on, no healthy stream has lost a picture, and the next
-    // DecodeAll simply goes on.  (The product's parser does not emit pictures the validator refuses)
+    // other pictures (other streams) are.  Every round asks for the verdict on the commit before it between its parse and its
+    // own hand-over (the verdict has been there for a whole parse by then: no wait), so a picture refused in round k is reported —
+    // DecodeAll throws, RefusedStreams() names the streams — BEFORE anything of round k + 1 reaches the device; that round is
+    // parsed and HELD: the next DecodeAll commits it instead of parsing and returns the tick's frames.  No healthy stream loses a
+    // picture or a frame.  (The product's parser does not emit pictures the validator refuses)
     void SetDevicePack(bool on) { device_pack_ = on; }
     bool DevicePack() const { return device_pack_; }
     void Sync();
@@ -578,7 +579,10 @@ private:
     bool any_sparse_queued_ = false;
     bool device_pack_ = true;
     bool verdict_owed_ = false;                    // a device-packed commit whose verdict has not been asked for
-    std::exception_ptr held_refusal_;              // a refusal learnt between two rounds of one DecodeAll: thrown by the next one
+    // a tick's state: a DecodeAll that throws a refusal keeps its parsed round (held) for the next call
+    struct Round { std::vector<uint32_t> slot, todo; std::vector<double> time; std::vector<uint8_t> got; std::vector<int> result;
+                   bool held = false; } round_;
+    std::exception_ptr held_refusal_;              // learnt while a tick's frames were fetched: thrown by the next call, before it parses
     std::vector<uint32_t> refused_streams_;
     std::atomic<int64_t> debug_damage_{-1};
     void reapVerdict();

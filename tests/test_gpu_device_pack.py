@@ -267,11 +267,13 @@ def test_golden_and_written_streams_through_the_parser_and_the_device_packer(ora
         assert h == [VIDEO_HASH] * 4 and n == [260] * 4, device_pack
 
 
-def test_a_refused_picture_is_reported_before_the_next_round_parses_on_gpu(oracle, golden_dir, device):
-    """tests/test_host_batch.py's contract on the HIP store: pack_gate_kernel refuses the damaged picture alone, mpeghip_video_verdict
-    reports it at the start of the next DecodeAll, the other streams' frames are the golden ones to the end."""
+@pytest.mark.parametrize("fetch_around", [True, False], ids=["fetch", "frames_stay_on_the_device"])
+def test_a_refused_picture_is_reported_by_the_next_call_on_gpu(oracle, golden_dir, device, fetch_around):
+    """tests/test_host_batch.py's contract on the HIP store: pack_gate_kernel refuses the damaged picture alone, the next DecodeAll
+    reports it (mpeghip_video_verdict: before its own round reaches the device), the other streams' frames are the golden ones
+    to the end."""
     from test_host_batch import run_refusal
-    run_refusal(oracle, (golden_dir / "test.mpeg1video").read_bytes(), device, 3)
+    run_refusal(oracle, (golden_dir / "test.mpeg1video").read_bytes(), device, 3, fetch_around)
 
 
 def test_the_damaged_golden_stream_on_recon_kernel_too(oracle, golden_dir, device):
