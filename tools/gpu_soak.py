@@ -15,26 +15,59 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+class Via:
+    """the device store behind one of the three hand-over forms"""
+    def __init__(self, store, form):
+        self.store, self.form = store, form
+        self.read_planes, self.read_rgba = store.read_planes, store.read_rgba
+
+    def submit(self, pics, mbs, coefs):
+        from mpeg_amd import desc
+        if self.form == 0:
+            return self.store.submit(pics, mbs, coefs)
+        m, w = desc.to_sparse(mbs, coefs)
+        if self.form == 1:
+            return self.store.submit_sparse(pics[0], m, w)
+        return self.store.submit_staged_device([(pics[0], m, w)], mapped=bool(len(m) & 1))
+
+
+def video_case(ctx, rng, allow_big=True):
+    """One seeded case, drawn from `rng`, through the device and the oracle; AssertionError (with the case's parameters) on a
+    mismatch.  -> (pictures, macroblocks, policy, form).  tests/test_gpu_soak.py runs a fixed number of them under -m gpu."""
+    from mpeg_amd import abi, synth
+    from oracle import pyoracle
+    from parity import run_and_compare
+    big = allow_big and rng.random() < 0.08
+    w = int(rng.integers(16, 1921 if big else 420))
+    h = int(rng.integers(16, 1089 if big else 300))
+    n = int(rng.integers(2, 4 if big else 9))
+    profile = "dense" if rng.random() < 0.3 else "typical"
+    raw = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
+    rgba = bool(rng.random() < 0.5)
+    policy = int(rng.integers(0, 3))
+    form = int(rng.integers(0, 3))
+    seed = int(rng.integers(1, 1 << 30))
+    types = None
+    if rng.random() < 0.5:  # any order of picture types behind the leading I picture (B pictures need two anchors)
+        types = [1, 2] + [int(x) for x in rng.choice([1, 2, 3], size=n)]
+    seq = synth.generate_sequence(w, h, n, seed=seed, profile=profile, raw_fraction=raw, rgba=rgba, types=types)
+    ref, dut = pyoracle.OracleStore(w, h, threads=4), abi.VideoStore(ctx, w, h)
+    dut.set_tile_policy(policy)
+    try:
+        run_and_compare(ref, Via(dut, form), seq, check_rgba=rgba)
+    except AssertionError as e:
+        raise AssertionError("MISMATCH: w=%d h=%d n=%d profile=%s raw=%.2f rgba=%d policy=%d form=%d seed=%d types=%s: %s" %
+                             (w, h, n, profile, raw, rgba, policy, form, seed, types, e))
+    finally:
+        dut.close()
+        ref.close()
+    return len(seq), sum(len(s.mbs) for s in seq), policy, form
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     master = int(sys.argv[2]) if len(sys.argv) > 2 else 20260928
-    from mpeg_amd import abi, desc, synth
-    from oracle import pyoracle
-    from parity import run_and_compare
-
-    class Via:
-        """the device store behind one of the three hand-over forms"""
-        def __init__(self, store, form):
-            self.store, self.form = store, form
-            self.read_planes, self.read_rgba = store.read_planes, store.read_rgba
-
-        def submit(self, pics, mbs, coefs):
-            if self.form == 0:
-                return self.store.submit(pics, mbs, coefs)
-            m, w = desc.to_sparse(mbs, coefs)
-            if self.form == 1:
-                return self.store.submit_sparse(pics[0], m, w)
-            return self.store.submit_staged_device([(pics[0], m, w)], mapped=bool(len(m) & 1))
+    from mpeg_amd import abi
 
     ctx = abi.Context(0)
     rng = np.random.default_rng(master)
@@ -43,33 +76,14 @@ def main():
     by_policy = {0: 0, 1: 0, 2: 0}
     by_form = {0: 0, 1: 0, 2: 0}
     while time.time() - t0 < budget:
-        big = rng.random() < 0.08
-        w = int(rng.integers(16, 1921 if big else 420))
-        h = int(rng.integers(16, 1089 if big else 300))
-        n = int(rng.integers(2, 4 if big else 9))
-        profile = "dense" if rng.random() < 0.3 else "typical"
-        raw = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
-        rgba = bool(rng.random() < 0.5)
-        policy = int(rng.integers(0, 3))
-        form = int(rng.integers(0, 3))
-        seed = int(rng.integers(1, 1 << 30))
-        types = None
-        if rng.random() < 0.5:  # any order of picture types behind the leading I picture (B pictures need two anchors)
-            types = [1, 2] + [int(x) for x in rng.choice([1, 2, 3], size=n)]
-        seq = synth.generate_sequence(w, h, n, seed=seed, profile=profile, raw_fraction=raw, rgba=rgba, types=types)
-        ref, dut = pyoracle.OracleStore(w, h, threads=4), abi.VideoStore(ctx, w, h)
-        dut.set_tile_policy(policy)
         try:
-            run_and_compare(ref, Via(dut, form), seq, check_rgba=rgba)
+            p, m, policy, form = video_case(ctx, rng)
         except AssertionError as e:
-            print("MISMATCH: w=%d h=%d n=%d profile=%s raw=%.2f rgba=%d policy=%d form=%d seed=%d types=%s: %s" % (w, h, n, profile, raw, rgba, policy, form, seed, types, e))
+            print(e)
             sys.exit(1)
-        finally:
-            dut.close()
-            ref.close()
         cases += 1
-        pictures += len(seq)
-        mbs += sum(len(s.mbs) for s in seq)
+        pictures += p
+        mbs += m
         by_policy[policy] += 1
         by_form[form] += 1
         if cases % 25 == 0:
@@ -82,48 +96,55 @@ def main():
     ctx.close()
 
 
-def audio_soak(ctx, budget, master):
+def audio_case(ctx, rng):
+    """One seeded synthesis case (stream count, 1 - 3 calls on one state, frames per call, format, window arithmetic, sblimit, masked
+    one-frame calls) against the oracle's synthesis, V ring state included; AssertionError on a mismatch.  -> stream-frames."""
     from mpeg_amd import abi, desc
     from oracle import pyoracle
     from parity import bits_equal
+    frames = 0
+    n_streams = int(rng.choice([1, 2, 3, 7, 33, 130, 600])) if rng.random() < 0.7 else int(rng.integers(1, 400))
+    fma = int(rng.integers(0, 2))
+    fmt = int(rng.choice([desc.AUDIO_F32N, desc.AUDIO_F32NLR, desc.AUDIO_F32, desc.AUDIO_S16]))
+    calls = int(rng.integers(1, 4))
+    ref, dut = pyoracle.OracleSynth(n_streams, fma), abi.AudioSynth(ctx, n_streams, fma)
+    try:
+        for _ in range(calls):
+            n_frames = int(rng.integers(1, 40 if n_streams < 50 else 6))
+            sblimit = int(rng.choice([8, 12, 27, 30, 32]))
+            smp = rng.integers(-32768, 32768, size=(n_streams, n_frames, 2, 36, 32), dtype=np.int32)
+            smp[..., sblimit:] = 0
+            if rng.random() < 0.3 and n_frames == 1:  # (a masked call is one frame per stream: AudioBatch's tick)
+                active = (rng.random(n_streams) < 0.7).astype(np.uint8)
+                b = np.asarray(dut.synth_masked(smp, active, fmt))[active != 0]
+                rows = []
+                for i in np.nonzero(active)[0]:  # the oracle: the active streams one by one, each on its own state
+                    one = pyoracle.OracleSynth(1, fma)
+                    one.states = [ref.states[i]]
+                    rows.append(one.synth(smp[i:i + 1], fmt)[0])
+                a = np.stack(rows) if rows else b
+            else:
+                a, b = ref.synth(smp, fmt), dut.synth(smp, fmt)
+            assert bits_equal(a, b), "AUDIO MISMATCH: streams=%d fma=%d fmt=%d frames=%d sblimit=%d" % (n_streams, fma, fmt, n_frames, sblimit)
+            frames += n_streams * n_frames
+        for st in sorted({0, n_streams - 1, int(rng.integers(0, n_streams))}):
+            (va, pa), (vb, pb) = ref.get_state(st), dut.get_state(st)
+            assert pa == pb and bits_equal(va, vb), "AUDIO STATE MISMATCH: streams=%d fma=%d stream %d" % (n_streams, fma, st)
+    finally:
+        dut.close()
+    return frames
 
+
+def audio_soak(ctx, budget, master):
     rng = np.random.default_rng(master + 1)
     t0 = time.time()
     cases = frames = 0
     while time.time() - t0 < budget:
-        n_streams = int(rng.choice([1, 2, 3, 7, 33, 130, 600])) if rng.random() < 0.7 else int(rng.integers(1, 400))
-        fma = int(rng.integers(0, 2))
-        fmt = int(rng.choice([desc.AUDIO_F32N, desc.AUDIO_F32NLR, desc.AUDIO_F32, desc.AUDIO_S16]))
-        calls = int(rng.integers(1, 4))
-        ref, dut = pyoracle.OracleSynth(n_streams, fma), abi.AudioSynth(ctx, n_streams, fma)
         try:
-            for _ in range(calls):
-                n_frames = int(rng.integers(1, 40 if n_streams < 50 else 6))
-                sblimit = int(rng.choice([8, 12, 27, 30, 32]))
-                smp = rng.integers(-32768, 32768, size=(n_streams, n_frames, 2, 36, 32), dtype=np.int32)
-                smp[..., sblimit:] = 0
-                if rng.random() < 0.3 and n_frames == 1:  # (a masked call is one frame per stream: AudioBatch's tick)
-                    active = (rng.random(n_streams) < 0.7).astype(np.uint8)
-                    b = np.asarray(dut.synth_masked(smp, active, fmt))[active != 0]
-                    rows = []
-                    for i in np.nonzero(active)[0]:  # the oracle: the active streams one by one, each on its own state
-                        one = pyoracle.OracleSynth(1, fma)
-                        one.states = [ref.states[i]]
-                        rows.append(one.synth(smp[i:i + 1], fmt)[0])
-                    a = np.stack(rows) if rows else b
-                else:
-                    a, b = ref.synth(smp, fmt), dut.synth(smp, fmt)
-                if not bits_equal(a, b):
-                    print("AUDIO MISMATCH: streams=%d fma=%d fmt=%d frames=%d sblimit=%d" % (n_streams, fma, fmt, n_frames, sblimit))
-                    sys.exit(1)
-                frames += n_streams * n_frames
-            for st in sorted({0, n_streams - 1, int(rng.integers(0, n_streams))}):
-                (va, pa), (vb, pb) = ref.get_state(st), dut.get_state(st)
-                if pa != pb or not bits_equal(va, vb):
-                    print("AUDIO STATE MISMATCH: streams=%d fma=%d stream %d" % (n_streams, fma, st))
-                    sys.exit(1)
-        finally:
-            dut.close()
+            frames += audio_case(ctx, rng)
+        except AssertionError as e:
+            print(e)
+            sys.exit(1)
         cases += 1
     print("audio soak done: master seed %d, %d cases, %d stream-frames (%d stereo sample pairs) bit-identical with the oracle's synthesis, "
           "V ring state included, in %.0f s" % (master + 1, cases, frames, frames * 1152, time.time() - t0))
