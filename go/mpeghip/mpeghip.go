@@ -75,8 +75,10 @@ type Context struct{ h *C.mpeghip_ctx }
 
 // ABIVersion is the MPEGHIP_ABI_VERSION this binding was written against; NewContext refuses a libmpeghip of another version
 // (version 2: snapshot blocks of the sparse form carry a count word, macroblocks name their words in order, chroma as
-// Cb|Cr pairs in device memory, device-packed stages with deferred errors).
-const ABIVersion = 2
+// Cb|Cr pairs in device memory, device-packed stages with deferred errors; version 3: asynchronous read-back and synthesis for a
+// decoder that works one picture / frame ahead, a device-packed commit refuses single PICTURES — Verdict / Refused —,
+// mpeghip_ctx_pci_bus_id).
+const ABIVersion = 3
 
 func NewContext(device int) (*Context, error) {
 	if int(C.mpeghip_abi_version()) != ABIVersion || C.MPEGHIP_ABI_VERSION != ABIVersion {
@@ -102,6 +104,21 @@ func (c *Context) PCIBusID() (string, error) {
 		return "", err
 	}
 	return C.GoString(&buf[0]), nil
+}
+
+// PinnedAlloc hands out n bytes of pinned host memory of the library (C-allocated: Go's collector neither moves nor frees it) as a
+// Go slice: what the asynchronous entries below read and write while the caller goes on; PinnedFree gives it back.
+func (c *Context) PinnedAlloc(n int) []byte {
+	p := C.mpeghip_pinned_alloc(c.h, C.size_t(n))
+	if p == nil {
+		return nil
+	}
+	return unsafe.Slice((*byte)(p), n)
+}
+func (c *Context) PinnedFree(b []byte) {
+	if len(b) > 0 {
+		C.mpeghip_pinned_free(c.h, unsafe.Pointer(&b[0]))
+	}
 }
 
 // Video is the 3-slot frame store + reconstruction of one stream.
@@ -170,6 +187,16 @@ func (v *Video) ReadPlanes(slot int, y, cb, cr []byte) error {
 		(*C.uint8_t)(&y[0]), (*C.uint8_t)(&cb[0]), (*C.uint8_t)(&cr[0])))
 }
 
+// ReadPlanesAsync queues the read-back of the slot's planes — luma | Cb | Cr, linear, Info.luma_bytes + 2 * Info.chroma_bytes — into
+// dst (memory of Context.PinnedAlloc) behind everything submitted so far and returns at once; ReadWait(ticket) blocks until the
+// planes are there.  What lets Video.Decode parse picture N+1 while picture N is on the device (go/patch/frame_hip.go).
+func (v *Video) ReadPlanesAsync(slot int, dst []byte) (uint64, error) {
+	var ticket C.uint64_t
+	err := lastError(C.mpeghip_video_read_planes_async(v.h, 0, C.uint32_t(slot), (*C.uint8_t)(&dst[0]), &ticket))
+	return uint64(ticket), err
+}
+func (v *Video) ReadWait(ticket uint64) error { return lastError(C.mpeghip_video_read_wait(v.h, C.uint64_t(ticket))) }
+
 // RGBA converts the slot on the device (Frame.RGBA) and copies width*height*4 bytes into dst.
 func (v *Video) RGBA(slot int, dst []byte) error {
 	if err := lastError(C.mpeghip_video_rgba_convert(v.h, C.uint32_t(slot), 0, 1)); err != nil {
@@ -194,6 +221,17 @@ func (a *Audio) Close() { C.mpeghip_audio_close(a.h) }
 func (a *Audio) Synth(samples *[2][36][32]int32, format int, out unsafe.Pointer) error {
 	return lastError(C.mpeghip_audio_synth(a.h, (*C.int32_t)(unsafe.Pointer(samples)), 1, C.int(format), out))
 }
+
+// SynthAsync queues the synthesis of one frame: samples and out are memory of Context.PinnedAlloc (9 216 bytes of sub-band samples;
+// 2 304 elements of the format's type) that stays untouched until SynthWait(ticket) returns.  UndoLast forgets the last launch: the V
+// ring and vPos are again what they were before it (one level).
+func (a *Audio) SynthAsync(samples []byte, format int, out []byte) (uint64, error) {
+	var ticket C.uint64_t
+	err := lastError(C.mpeghip_audio_synth_async(a.h, (*C.int32_t)(unsafe.Pointer(&samples[0])), 1, C.int(format), unsafe.Pointer(&out[0]), &ticket))
+	return uint64(ticket), err
+}
+func (a *Audio) SynthWait(ticket uint64) error { return lastError(C.mpeghip_audio_synth_wait(a.h, C.uint64_t(ticket))) }
+func (a *Audio) UndoLast() error               { return lastError(C.mpeghip_audio_undo_last(a.h)) }
 
 // ---- many streams on one GPU (the shape of mpeg_amd/host/batch.cpp's VideoBatch / AudioBatch)
 
@@ -338,6 +376,20 @@ func (s *Stage) PutMapped(i int, pic *PicDesc) error {
 
 // Sync waits for everything queued on the handle and returns (once) the deferred error of a device-packed commit, if any.
 func (v *Video) Sync() error { return lastError(C.mpeghip_video_sync(v.h)) }
+
+// Verdict waits until the device has VALIDATED the device-packed commits queued so far — not until it has reconstructed them — and
+// returns (once) their deferred error.  A refusal is per picture (ABI 3): the refused picture is not reconstructed, the commit's
+// other pictures (other streams) are; Refused names the refused pictures (index in their commit) and their streams.
+func (v *Video) Verdict() error { return lastError(C.mpeghip_video_verdict(v.h)) }
+func (v *Video) Refused() (pics, streams []uint32, total uint64) {
+	pics, streams = make([]uint32, 1024), make([]uint32, 1024)
+	total = uint64(C.mpeghip_video_refused(v.h, (*C.uint32_t)(&pics[0]), (*C.uint32_t)(&streams[0]), 1024))
+	n := total
+	if n > 1024 {
+		n = 1024
+	}
+	return pics[:n], streams[:n], total
+}
 
 // Commit sends the staged pictures and reconstructs them (asynchronous, like Submit); the Stage is over.
 func (s *Stage) Commit() error {

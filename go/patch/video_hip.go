@@ -38,6 +38,25 @@ type blockRec struct {
 	raw      [64]int32 // snapshot of blockData as idct() / the DC fast path would consume it
 }
 
+// heldSubmit is one hand-over recorded while a picture is parsed ahead.
+type heldSubmit struct {
+	pic   mpeghip.PicDesc
+	mbs   []mpeghip.MbDesc
+	words []uint32
+}
+
+// hipUndo is the parser state that outlives a picture: a look-ahead that is dropped (Rewind) puts it back.
+type hipUndo struct {
+	cur, fwd, bwd     Frame
+	pictureType       int
+	hasReferenceFrame bool
+	blockDirty        bool
+	blockData         [64]int
+	motionForward     motion
+	motionBackward    motion
+	stats             [8]int
+}
+
 // hipVideo is embedded in Video (field `hip hipVideo`) under the hip tag.
 type hipVideo struct {
 	dev *mpeghip.Video
@@ -52,7 +71,25 @@ type hipVideo struct {
 	mbX, mbY, mvX, mvY, qscale, cbp  int
 	blocks                           [6]blockRec
 
-	blockDirty bool // blockData holds stale coefficients of an earlier invalid block
+	blockDirty   bool      // blockData holds stale coefficients of an earlier invalid block
+	cur          *blockRec // the block between blockBegin and blockEnd
+	dirtyAtStart bool      // blockDirty when that block began
+
+	// Decode's look-ahead (frame_hip.go): the hand-overs of a picture parsed ahead are kept, not submitted
+	deferring bool
+	held      []heldSubmit
+	nHeld     int
+	lookahead bool // on after open; Video.SetLookahead(false): parse, submit, read back
+	ahead     struct {
+		valid bool
+		slot  uint8
+		time  float64
+	}
+	aheadTried, endedBeforeAhead bool
+	undo                         *hipUndo // what a dropped look-ahead gives back (Rewind)
+	out                          [2]Frame // the two frames Decode alternates between (valid until the next call, mpeg.go:413-415)
+	outPlanes                    [2][]byte // pinned (mpeghip.Context.PinnedAlloc): luma | Cb | Cr
+	outNext                      int
 
 	have     [3]bool // Frame.Y/Cb/Cr.Data of the Frame holding slot s equal the device's slot s
 	NoPlanes bool    // the consumer only wants Frame.RGBA(): Decode skips the plane read-back
@@ -88,6 +125,23 @@ func (h *hipVideo) open(v *Video) bool {
 	}
 	h.written = make([]bool, v.mbSize)
 	h.blockDirty = false
+	// Decode's two frames: pinned planes the device fills itself (ReadPlanesAsync), Frame values set up like the decoder's own
+	luma, chroma := v.lumaWidth*v.lumaHeight, v.chromaWidth*v.chromaHeight
+	for i := range h.out {
+		if h.outPlanes[i] != nil {
+			ctx.PinnedFree(h.outPlanes[i])
+		}
+		if h.outPlanes[i] = ctx.PinnedAlloc(luma + 2*chroma); h.outPlanes[i] == nil {
+			return false
+		}
+		f := &h.out[i]
+		v.initFrame(f) // geometry, image headers, the RGBA buffer ...
+		p := h.outPlanes[i]
+		f.Y.Data, f.Cb.Data, f.Cr.Data = p[:luma:luma], p[luma:luma+chroma:luma+chroma], p[luma+chroma:luma+2*chroma]
+		f.imYCbCr.Y, f.imYCbCr.Cb, f.imYCbCr.Cr = f.Y.Data, f.Cb.Data, f.Cr.Data // ... over the pinned planes
+		f.hipOwner = v
+	}
+	h.lookahead, h.ahead.valid, h.nHeld, h.undo, h.aheadTried = true, false, 0, nil, false
 	return true
 }
 
@@ -111,6 +165,22 @@ func (h *hipVideo) flush(v *Video) {
 	// frameForward / frameBackward are what copyMacroblock would read
 	cur := v.frameCurrent.hipSlot
 	pic := mpeghip.PicDesc{Cur: cur, Fwd: v.frameForward.hipSlot, Bwd: v.frameBackward.hipSlot, MbCount: uint32(len(h.mbs))}
+	if h.deferring { // a picture parsed ahead (frame_hip.go: decode): its hand-over is kept; the arrays change places with the kept slot's
+		if h.nHeld == len(h.held) {
+			h.held = append(h.held, heldSubmit{})
+		}
+		k := &h.held[h.nHeld]
+		h.nHeld++
+		k.pic = pic
+		k.mbs, h.mbs = h.mbs, k.mbs[:0]
+		k.words, h.words = h.words, k.words[:0]
+		h.Stats.Submits++
+		h.Stats.Macroblocks += len(k.mbs)
+		for i := range h.written {
+			h.written[i] = false
+		}
+		return
+	}
 	if err := h.dev.SubmitSparse(&pic, h.mbs, h.words); err != nil {
 		// descriptors are validated by the library; the recorder never produces an invalid one.  A
 		// device failure leaves the slot as it was (the reference has no error path here either).
@@ -188,39 +258,53 @@ func dequantPremult(level int, intra bool, qscale int, q byte, idx int) int32 {
 	return int32(level * int(videoPremultiplierMatrix[idx]))
 }
 
-// decodeBlock replaces Video.decodeBlock under the hip tag: the same bits are read in the same order
-// (video.go:643-707), but levels are STORED, not dequantised, and nothing is reconstructed here.
+// ---- the hooks inside the reference's OWN decodeBlock (video.go:639-797; go/patch/PATCH.md lists where they go).  The VLC loop is
+// NOT restated here (round 5 did, line for line — two loops that must read identical bits): the reference's loop runs as it is, keeps
+// v.blockData exactly as the reference has it, and tells the recorder
+//   blockBegin    (before the call, decodeMacroblock's block loop :556-561)  a coded block starts
+//   blockLevel    (after deZigZagged is known, :716-717)                      one coded level, before it is dequantised
+//   blockInvalid  (the invalid-block return, :711-714)                         nothing is reconstructed, blockData stays dirty
+//   blockEnd      (in front of "Move block to its place", :747)                what idct() / the *ToDest functions would consume
+// Nothing is reconstructed on the CPU: blockEnd makes decodeBlock return.
 //
-// v.blockData is all zero between blocks except after an invalid block (video.go:711-714 returns
-// before the clears): only then — or when this block ends invalid itself, holds an explicit zero level
-// (which dequantises to +-1) or an intra DC outside int16 — do its exact contents matter, and the block
-// travels as an int32 snapshot of what idct() / the DC fast path would consume (MPEGHIP_MB_COEF_RAW).
-func (h *hipVideo) decodeBlock(v *Video, block int) {
+// v.blockData is all zero between blocks except after an invalid block (:711-714 returns before the clears): only then — or
+// when this block holds an intra DC outside int16 — do its exact contents matter, and the block travels as an int32 snapshot of
+// what idct() / the DC fast path would consume (MPEGHIP_MB_COEF_RAW).  Every other block travels as its (position, level) pairs.
+func (h *hipVideo) blockBegin(v *Video, block int) {
 	br := &h.blocks[block]
 	br.valid, br.needsRaw, br.nTouched = false, false, 0
 	br.q = [64]int16{}
 	h.cbp |= 0x20 >> uint(block)
+	h.cur = br
+	h.dirtyAtStart = h.blockDirty
+}
 
-	n := 0
-	var quant *[64]byte
-	dirtyAtStart := h.blockDirty
-	dc256 := 0
+// blockLevel: video.go:716-717 — position deZigZagged (natural order, row*8+column) holds `level`, not yet dequantised (a coded
+// zero level included: it travels as a pair and dequantises to +-1 like any other).
+func (h *hipVideo) blockLevel(deZigZagged, level int) {
+	br := h.cur
+	br.q[deZigZagged] = int16(level)
+	br.touched[br.nTouched] = uint8(deZigZagged)
+	br.nTouched++
+}
 
-	if v.macroblockIntra {
+// blockInvalid: video.go:711-714 — no reconstruction, and blockData is NOT cleared.
+func (h *hipVideo) blockInvalid(v *Video) {
+	h.Stats.InvalidBlocks++
+	h.blockDirty = true
+}
+
+// blockEnd: video.go:747 — the block's levels are in blockData (dequantised and premultiplied by the reference's own code,
+// :719-744; an intra block's DC as predictor << 8, :656-672), n is the reference's scan position.  Records the block and clears
+// blockData the way the reference's write-back does (:774-796).
+func (h *hipVideo) blockEnd(v *Video, block, n int) {
+	br := h.cur
+	if v.macroblockIntra { // the DC level: the predictor the reference just saved (:669)
 		plane := 0
 		if block > 3 {
 			plane = block - 3
 		}
 		dc := v.dcPredictor[plane]
-		if size := v.buf.readVlc(videoDctSize[plane]); size > 0 {
-			diff := v.buf.read(size)
-			if diff&(1<<uint(size-1)) != 0 {
-				dc += diff
-			} else {
-				dc += (-1 << uint(size)) | (diff + 1)
-			}
-		}
-		v.dcPredictor[plane] = dc
 		switch {
 		case dc < -32768:
 			br.needsRaw, br.q[0] = true, -32768
@@ -229,102 +313,42 @@ func (h *hipVideo) decodeBlock(v *Video, block int) {
 		default:
 			br.q[0] = int16(dc)
 		}
-		// blockData[0] = dc << 8; beyond +-2^30 the pixel saturates whatever the AC terms add, so the
-		// clamp is exact and keeps the snapshot in int32
-		dc256 = dc << 8
-		if dc256 > 1<<30 {
-			dc256 = 1 << 30
-		} else if dc256 < -(1 << 30) {
-			dc256 = -(1 << 30)
-		}
-		if dirtyAtStart {
-			v.blockData[0] = dc256
-		}
-		quant = &v.intraQuantMatrix
-		n = 1
-	} else {
-		quant = &v.nonIntraQuantMatrix
 	}
-
-	invalid := false
-	for {
-		run, level := 0, 0
-		coeff := int(v.buf.readVlcUint(videoDctCoeff))
-		if coeff == 0x0001 && n > 0 && v.buf.read1() == 0 {
-			break // end_of_block
-		}
-		if coeff == 0xffff { // escape
-			run = v.buf.read(6)
-			level = v.buf.read(8)
-			switch {
-			case level == 0:
-				level = v.buf.read(8)
-			case level == 128:
-				level = v.buf.read(8) - 256
-			case level > 128:
-				level -= 256
-			}
-		} else {
-			run, level = coeff>>8, coeff&0xff
-			if v.buf.read1() != 0 {
-				level = -level
-			}
-		}
-		n += run
-		if n < 0 || n >= 64 {
-			invalid = true
-			break
-		}
-		dz := int(videoZigZag[n]) & 63
-		n++
-		br.q[dz] = int16(level) // (a coded zero level included: it travels as a pair and dequantises to +-1 like any other)
-		br.touched[br.nTouched] = uint8(dz)
-		br.nTouched++
-		if dirtyAtStart {
-			v.blockData[dz] = int(dequantPremult(level, v.macroblockIntra, v.quantizerScale, quant[dz], dz))
-		}
-	}
-
-	materialize := func() { // bring blockData up to date when it was not maintained on the fly
-		if dirtyAtStart {
+	clear := func() { // video.go:774-777 / 787-790: only blockData[0] is used, and only it is cleared; :781-783 / 794-796: all of it
+		if n == 1 {
+			v.blockData[0] = 0
 			return
 		}
-		if v.macroblockIntra {
-			v.blockData[0] = dc256
-		}
-		for k := 0; k < br.nTouched; k++ {
-			dz := int(br.touched[k])
-			v.blockData[dz] = int(dequantPremult(int(br.q[dz]), v.macroblockIntra, v.quantizerScale, quant[dz], dz))
+		for i := 0; i < 64; i++ {
+			v.blockData[i] = 0
 		}
 	}
-
-	if invalid { // video.go:711-714: no reconstruction, and blockData is NOT cleared
-		h.Stats.InvalidBlocks++
-		materialize()
-		h.blockDirty = true
+	if !h.dirtyAtStart && !br.needsRaw {
+		clear() // the common case: nothing of blockData survives this block
+		br.valid = true
 		return
 	}
-	if !dirtyAtStart && !br.needsRaw { // (a coded zero level travels as a pair: only units, 0 = absent, would need a snapshot for it)
-		br.valid = true // the common case: nothing of blockData survives this block (video.go:777-796)
-		return
-	}
-
-	materialize()
 	br.needsRaw = true
-	if n == 1 { // video.go:774-777 / 787-790: only blockData[0] is used, and only it is cleared
-		br.raw = [64]int32{}
-		br.raw[0] = int32(v.blockData[0])
-		v.blockData[0] = 0
+	clamp := func(x int) int32 { // beyond +-2^30 the pixel saturates whatever else is added: the clamp is exact, the snapshot int32
+		if x > 1<<30 {
+			return 1 << 30
+		} else if x < -(1 << 30) {
+			return -(1 << 30)
+		}
+		return int32(x)
+	}
+	br.raw = [64]int32{}
+	if n == 1 {
+		br.raw[0] = clamp(v.blockData[0])
 	} else {
 		for i := 0; i < 64; i++ {
 			if n < 10 && (i>>3 >= 4 || i&7 >= 4) { // video.go:807-866: the reduced idct ignores rows, columns >= 4
-				br.raw[i] = 0
-			} else {
-				br.raw[i] = int32(v.blockData[i])
+				continue
 			}
-			v.blockData[i] = 0 // video.go:781-783 / 794-796
+			br.raw[i] = clamp(v.blockData[i])
 		}
 	}
+	clear()
 	h.blockDirty = false
 	for i := 0; i < 64; i++ {
 		if v.blockData[i] != 0 {
