@@ -93,6 +93,12 @@ def set_tile_policy(policy=0):
     lib().emu_set_tile_policy(policy)
 
 
+def set_wide(on=0):
+    """1: every chunk runs as recon_wide_kernel runs it (four waves per chunk, two workgroup barriers) instead of as recon_kernel's
+    one wave does."""
+    lib().emu_set_wide(int(on))
+
+
 def set_device_pack(on=0):
     """1: sparse pictures go through the DEVICE packer's lane functions (video_pack_lane.h: what pack_kernel runs) instead of the
     host packer."""

@@ -49,6 +49,10 @@ static int g_tile_policy = 0; // as mpeghip_video_set_tile_policy: 0 = pick per 
 extern "C" {
 
 void emu_set_tile_policy(int policy) { g_tile_policy = policy; }
+static int g_wide = 0; // 1: every chunk runs as recon_wide_kernel runs it — four waves, two barriers (emu_wide_chunk)
+static uint64_t g_wide_chunks = 0; // chunks run that way so far (tests ask: did the switch take?)
+void emu_set_wide(int on) { g_wide = on; }
+uint64_t emu_wide_chunks_run(void) { return g_wide_chunks; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 void emu_set_pack_window(uint32_t dwords) { g_pack_window = dwords; }
 
@@ -151,6 +155,150 @@ int emu_video_run_sparse(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w
     return emu_video_run_form(frames, frame_stride, luma_w, luma_h, width, height, pics, n_pics, mbs, n_mbs,
                               reinterpret_cast<const uint8_t *>(words), qtable, rgba, rgba_stride, n_words + 1);
 }
+// recon_wide_kernel (mpeghip.hip), one chunk: FOUR waves.  Wave w fetches the table and window w, runs residual pass w (its own
+// int16 tile behind the four windows) and the motion compensation of macroblock w; a workgroup barrier; every wave adds its
+// residual rows to the output bytes (whichever macroblock's they are); a barrier; the stores, every wave its share (a run: luma by
+// wave 0, chroma by wave 1, four image rows of the colour conversion each — macroblock w if the run wraps a row end; any other
+// chunk: macroblock w).  Between two barriers the waves run concurrently on the device and touch disjoint LDS (the table: the same
+// bytes): here one after the other, in the kernel's statement order.  Poisoned LDS, as in the one-wave emulation.
+static void emu_wide_chunk(const VideoArgs &a, uint32_t chunk, bool any_rgba)
+{
+    alignas(16) uint8_t lds[kRcTileAt + 3 * kRcTileBytes16];
+    memset(lds, 0xCD, sizeof(lds));
+    const RcChunk c = rc_load_chunk(a, chunk);
+    const uint32_t n_blocks = rc_n_blocks(c);
+    RcLane k[64];
+    for (int lane = 0; lane < 64; lane++)
+        k[lane] = rc_lane(a, lane);
+    int32_t v[4][64][8];
+    uint32_t bw[4][64];
+    const int win_at[4] = {kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes};
+    // ---- up to the first barrier: wave w's loads, pass and motion compensation
+    for (uint32_t w = 0; w < 4; w++) {
+        const bool my_pass = w * 8 < n_blocks;
+        uint32_t ent_at = 0, np = 0;
+        for (uint32_t p = 0; p < w && p < 3; p++)
+            ent_at += rc_pass_entries(c, p);
+        if (w < 3)
+            np = rc_pass_entries(c, w);
+        for (int lane = 0; lane < kRcQtabBytes / kRcPiece; lane++) // (its own 12 lanes only: another wave's window is not written over)
+            memcpy(lds + kRcQtabAt + 16 * lane, a.qmat + rc_table_lane_offset(c, lane), 16);
+        for (int lane = 0; lane < kRcWinLanes; lane++) {
+            const uint32_t off[4] = {rc_win_offset(c, 0, k[lane]), rc_win_offset(c, 1, k[lane]), rc_win_offset(c, 2, k[lane]), rc_win_offset(c, 3, k[lane])};
+            memcpy(lds + win_at[w] + 16 * lane, rc_frame_base(a, c) + off[w] + win_at[w], 16);
+        }
+        if (my_pass) {
+            int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt + w * kRcTileBytes16);
+            uint32_t e[64];
+            for (int lane = 0; lane < 64; lane++) {
+                e[lane] = load32_uncounted(rc_word_base(a, c), rc_ent_lane_offset(c, ent_at, lane));
+                bw[w][lane] = load32_uncounted(rc_word_base(a, c), rc_blk_lane_offset(w, lane));
+            }
+            if (np) {
+                for (int lane = 0; lane < 64; lane++)
+                    rc_zero_tile16(T16, lane);
+                for (uint32_t r = 0; r < np; r += 64)
+                    for (int lane = 0; lane < 64; lane++) {
+                        if (r > 0)
+                            e[lane] = *rc_ent_src(a, c, ent_at + r, lane);
+                        if (r + (uint32_t)lane < np)
+                            rc_scatter16(T16, lds, e[lane]);
+                    }
+            }
+            for (int lane = 0; lane < 64; lane++) {
+                const bool mine = w * 8 + ((uint32_t)lane >> 3) < n_blocks;
+                if (np)
+                    rc_cols_load16(T16, lds, lane, v[w][lane]);
+                else
+                    for (int r = 0; r < 8; r++)
+                        v[w][lane][r] = 0;
+                if (rc_any_special(c)) {
+                    if (rc_any_dcword(c) && mine)
+                        rc_dc_from_word(bw[w][lane], lane, v[w][lane]);
+                    if (rc_any_raw(c) && mine && (bw[w][lane] & kBRaw))
+                        rc_raw_cols(a, c, bw[w][lane], lane, v[w][lane]);
+                    if (rc_any_dense(c) && mine && (bw[w][lane] & kBDense))
+                        rc_dense_cols<false>(rc_dense_read(a, c, bw[w][lane], lane), lds, bw[w][lane], lane, v[w][lane]);
+                }
+                idct8<false>(v[w][lane]);
+            }
+            for (int g = 0; g < 8; g++) { // the transposition across the block's 8 lanes: lane j leaves with row j
+                int32_t m[8][8];
+                for (int j = 0; j < 8; j++)
+                    for (int r = 0; r < 8; r++)
+                        m[r][j] = v[w][g * 8 + j][r];
+                for (int j = 0; j < 8; j++)
+                    for (int col = 0; col < 8; col++)
+                        v[w][g * 8 + j][col] = m[j][col];
+            }
+            for (int lane = 0; lane < 64; lane++)
+                idct8<true>(v[w][lane]);
+        }
+        // motion compensation of macroblock w
+        const uint32_t r0 = c.r[w][0];
+        if (r0 & kRDead)
+            continue;
+        uint8_t *win = lds + rc_win_at(w);
+        uint32_t yl[64], yc[64];
+        if (r0 & kRSlow) {
+            u32x4 piece[52];
+            for (int lane = 0; lane < 52; lane++)
+                piece[lane] = rc_gather_piece(a, c, (int)w, k[lane], lane);
+            for (int lane = 0; lane < 52; lane++)
+                memcpy(win + lane * 16, &piece[lane], 16);
+        }
+        for (int lane = 0; lane < 64; lane++) {
+            yl[lane] = yc[lane] = 0;
+            if (!(r0 & (kRIntra | kRSlow))) {
+                switch (w) { // (the kernel's by_wave: the macroblock is a template argument)
+                case 0: yl[lane] = rc_mc_luma<0>(lds, k[lane], r0, c.r[0][3]), yc[lane] = rc_mc_chroma<0>(lds, k[lane], lane, r0, c.r[0][4], c.r[0][5]); break;
+                case 1: yl[lane] = rc_mc_luma<1>(lds, k[lane], r0, c.r[1][3]), yc[lane] = rc_mc_chroma<1>(lds, k[lane], lane, r0, c.r[1][4], c.r[1][5]); break;
+                case 2: yl[lane] = rc_mc_luma<2>(lds, k[lane], r0, c.r[2][3]), yc[lane] = rc_mc_chroma<2>(lds, k[lane], lane, r0, c.r[2][4], c.r[2][5]); break;
+                default: yl[lane] = rc_mc_luma<3>(lds, k[lane], r0, c.r[3][3]), yc[lane] = rc_mc_chroma<3>(lds, k[lane], lane, r0, c.r[3][4], c.r[3][5]); break;
+                }
+            } else if (r0 & kRSlow) {
+                yl[lane] = rc_mc_luma_slow(win, k[lane], r0, c.r[w][3]);
+                yc[lane] = rc_mc_chroma_slow(win, k[lane], r0, c.r[w][4]);
+            }
+        }
+        for (int lane = 0; lane < 64; lane++) { // (over the window: only after every lane has its taps)
+            memcpy(win + k[lane].out_luma, &yl[lane], 4);
+            memcpy(win + k[lane].out_chroma, &yc[lane], 4);
+        }
+    }
+    // ---- barrier: the four O_m are complete; every wave's residual rows onto them
+    for (uint32_t w = 0; w < 4; w++)
+        if (w * 8 < n_blocks)
+            for (int lane = 0; lane < 64; lane++)
+                if (w * 8 + ((uint32_t)lane >> 3) < n_blocks)
+                    rc_rmw(lds, bw[w][lane], lane, v[w][lane]);
+    // ---- barrier: the stores, every wave its share
+    const bool run = (c.h[4] & kCRun) != 0, to_rgba = any_rgba && (c.h[4] & kCRgba) != 0;
+    const uint32_t n_live = rc_n_live(c);
+    for (uint32_t w = 0; w < 4; w++) {
+        if (run) {
+            for (int lane = 0; lane < 64; lane++) {
+                if (w == 0)
+                    rc_store_run_luma(a, c, lane, lds);
+                if (w == 1)
+                    rc_store_run_chroma(a, c, lane, lds);
+                if (to_rgba) {
+                    if (rc_run_in_one_row(c))
+                        rc_rgba_run_rows(a, c, rc_rgba_image(a, c), w, lane, lds);
+                    else
+                        rc_rgba_mb(a, c, rc_rgba_image(a, c), w, lane, lds);
+                }
+            }
+        } else if (w < n_live) {
+            for (int lane = 0; lane < 64; lane++)
+                rc_store_mb(a, c, w, lane, lds, to_rgba);
+            if (to_rgba)
+                for (int lane = 0; lane < 64; lane++)
+                    rc_rgba_mb(a, c, rc_rgba_image(a, c), w, lane, lds);
+        }
+    }
+}
+
 static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t luma_w, uint32_t luma_h,
                   uint32_t width, uint32_t height,
                   const mpeghip_pic_desc *pics, uint32_t n_pics, const mpeghip_mb_desc *mbs, uint32_t n_mbs,
@@ -257,6 +405,11 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
 
     alignas(16) uint8_t lds[kRcLdsBytesMax]; // (no statics: ShardedVideoBatch tests run two emulator stores on two threads)
     for (uint32_t chunk = 0; chunk < nc; chunk++) {
+        if (g_wide) { // recon_wide_kernel's orchestration of the same lane functions over the same chunk
+            emu_wide_chunk(a, chunk, any_rgba);
+            g_wide_chunks++;
+            continue;
+        }
         memset(lds, 0xCD, sizeof(lds)); // poison: reads of unwritten LDS must not matter
         int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt);
         const RcChunk c = rc_load_chunk(a, chunk);

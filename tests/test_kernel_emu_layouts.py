@@ -168,3 +168,53 @@ def test_the_emulator_picks_the_instance_by_the_library_s_rule():
     assert "b->dense_blocks * kDenseShareDen <= b->coded_blocks * kDenseShareNum" in hip
     m = re.search(r"bool t16 = dense \* (\d+) <= coded( \* (\d+))?;", emu_src)
     assert m and int(m.group(1)) == den and int(m.group(3) or 1) == num
+
+
+@pytest.fixture
+def emu_wide(emu):
+    emu.set_wide(1)
+    yield emu
+    emu.set_wide(0)
+
+
+@pytest.mark.parametrize("w,h,n,profile,raw,rgba", [
+    (352, 240, 6, "typical", 0.0, False),     # SIF: chunks that wrap a row end are runs (luma by wave 0, chroma by wave 1)
+    (352, 240, 4, "typical", 0.15, True),     # snapshot blocks; fused RGBA: four image rows per wave / macroblock w of a wrapped run
+    (352, 240, 3, "dense", 0.0, False),       # dense units through rc_dense_cols<false>, three passes = three waves with a tile each
+    (160, 120, 5, "typical", 0.05, True),
+    (176, 144, 4, "typical", 0.0, True),
+    (24, 40, 4, "typical", 0.0, True),        # chunks with dead records: waves beyond the live macroblocks store nothing
+    (50, 35, 3, "typical", 0.0, True),
+])
+def test_the_wide_kernels_four_wave_orchestration_matches_the_oracle(oracle, emu_wide, w, h, n, profile, raw, rgba):
+    """recon_wide_kernel (what every launch of at most two 1080p pictures runs) on the CPU: its per-wave table and window loads,
+    pass w on tile w, the two barriers' hand-over of the output bytes and the split stores, in the kernel's order over the same
+    chunk format and lane functions (tests/kernel_emu/emu.cpp: emu_wide_chunk) — until round 6 only the -m gpu tests ran this
+    kernel's orchestration (round-5 advisor)."""
+    seq = synth.generate_sequence(w, h, n, profile=profile, raw_fraction=raw, rgba=rgba)
+    run_and_compare(oracle.OracleStore(w, h), emu_wide.EmuStore(w, h), seq, check_rgba=rgba)
+
+
+def test_the_wide_orchestration_equals_the_one_wave_form_on_the_golden_streams_pictures(oracle, emu, golden_dir):
+    """... and through the host parser on the damaged golden stream (windows that leave their plane, invalid intra blocks, re-submits):
+    the reference's hash with every chunk run the four-wave way."""
+    import hostlib
+    E = hostlib.host_emu()     # (the parser's test backend carries its own copy of the lane emulator: its switch, not emu's)
+    E.emu_set_wide(1)
+    try:
+        dec = hostlib.HostVideo((golden_dir / "test.mpeg1video").read_bytes(), emu_flavour=0)
+        h, n = oracle.FNV_OFFSET, 0
+        while True:
+            f = dec.decode()
+            if f is None:
+                break
+            for p in hostlib.frame_planes(f):
+                h = oracle.fnv1a64(p, h)
+            n += 1
+        dec.close()
+        import ctypes as C
+        E.emu_wide_chunks_run.restype = C.c_uint64
+        assert E.emu_wide_chunks_run() >= 5000               # every chunk of the 261 pictures (20 each, but for the damage) went the four-wave way
+    finally:
+        E.emu_set_wide(0)
+    assert (h, n) == (0xea6d7fcb1340ba3f, 260)
