@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--gop", type=int, default=13, help="pictures in the cycled decode-order GOP")
-    ap.add_argument("--profile", default="typical", choices=["typical", "dense", "typical_nocoef", "typical_fullpel", "mc_copy", "mc_horiz", "mc_vert", "mc_bilin"],
+    ap.add_argument("--profile", default="typical", choices=["typical", "dense", "typical_nocoef", "typical_fullpel", "typical_inside", "mc_copy", "mc_horiz", "mc_vert", "mc_bilin"],
                     help="workload of the PRIMARY leg (`value`): typical is the reported one; the others are diagnostics")
     ap.add_argument("--rgba", type=int, default=0, help="1: the primary leg fuses Frame.RGBA into the reconstruction kernel")
     ap.add_argument("--legs", default="dense,rgba_fused,dense_rgba_fused,mixed",

@@ -30,7 +30,9 @@
 //                      (v_alignbit_b32 / v_lshrrev_b64 read 5 / 6 bits), a multiplicand in a 16-bit half (v_mad_u32_u16 op_sel)
 //                   kRSlow records (a window that leaves its plane: the reference reads on, linearly, into the next
 //                   row / plane / the pad, video_noasm.go:48-80): r1 = the reference slot's offset, r2 = 0, r3 / r4 = the window
-//                   origins as LINEAR byte offsets of the reference's layout; the kernel gathers those windows dword by dword
+//                   origins of the reference's LINEAR layout as column | row << 16 (luma: rows of luma_w bytes from the slot's
+//                   start; chroma: Cb | Cr | pad as one array of chroma_w-byte rows from the Cb plane's start), r5 = mb_h;
+//                   the kernel gathers those windows dword by dword
 //   words   per chunk, one after the other (a wave's loads share cache lines):
 //           block words, one per coded block, in (macroblock, block) order = "slot" order:
 //                   LDS byte offset / 8 of the block's row 0 in the output bytes | chroma << 9 | snapshot << 10
@@ -285,10 +287,17 @@ MPG_HD void rc_make_record(uint32_t mb_w, uint32_t mb_h, uint32_t luma_w, uint32
     } else { // the reference's linear reads (validated: inside [plane start, end of base))
         const int32_t dst_luma = (int32_t)(mb_y << 4) * (int32_t)luma_w + (int32_t)(mb_x << 4);
         const int32_t dst_chroma = (int32_t)(mb_y << 3) * (int32_t)chroma_w + (int32_t)(mb_x << 3);
+        // the window origins as LINEAR byte offsets of the reference's layout (from the slot's start / from the Cb plane's start),
+        // handed over as (column, row) of the array they lie in — rows of luma_w bytes from the slot's start; Cb | Cr | pad as ONE
+        // array of chroma_w-byte rows — so that the kernel's gather needs no division (round 6: it made two per dword, ~250
+        // vector instructions per lane and window; the two here are the packer's, once per macroblock)
+        const uint32_t l0 = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)luma_w + (mvx >> 1));
+        const uint32_t c0 = (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)chroma_w + (cmx >> 1));
         r[0] = r0 | f | kRSlow;
         r[1] = ref_off;
-        r[3] = (uint32_t)(dst_luma + (mvy >> 1) * (int32_t)luma_w + (mvx >> 1));
-        r[4] = luma_bytes + (uint32_t)(dst_chroma + (cmy >> 1) * (int32_t)chroma_w + (cmx >> 1));
+        r[3] = (l0 % luma_w) | ((l0 / luma_w) << 16);
+        r[4] = (c0 % chroma_w) | ((c0 / chroma_w) << 16);
+        r[5] = mb_h;
     }
 }
 // the header dwords that do not depend on the chunk's blocks.  mb0: raster index of the chunk's first macroblock (a run's tiles)
@@ -815,28 +824,54 @@ MPG_HD uint32_t rc_win_offset(const RcChunk &c, int m, const RcLane &k)
     return x + mad_u24(u >> k.wrap_shift, k.below, k.cterm[m]); // (u >> wrap_shift is 0 or 1: the tile below)
 }
 
-// a kRSlow window (it leaves its plane): the reference's LINEAR reads, gathered dword by dword through
-// linear_to_tiled.  Lane < 52 = piece of the linear window layout: luma 17 rows x 32 bytes from the dword below the
-// origin, then per chroma plane 9 rows x 16 bytes.  Returns the piece's 16 bytes.
+// a kRSlow window (it leaves its plane): the reference's LINEAR reads, gathered dword by dword.  Lane < 52 = piece of the linear
+// window layout: luma 17 rows x 32 bytes from the dword below the origin, then per chroma plane 9 rows x 16 bytes.  Returns the
+// piece's 16 bytes.  The record names the origins as (column, row) — rc_make_record — so a dword's place is found by compares and
+// shifts: a column beyond the row's end is the next row's head (the linear wrap), a luma row beyond the plane is two rows of Cb | Cr
+// | pad (half as wide), a chroma row beyond Cb is Cr's, beyond Cr the pad's (which lies linearly).
+MPG_HD uint32_t rc_gather_chroma_at(uint32_t mb_w, uint32_t luma_bytes, uint32_t chroma_h, uint32_t x, uint32_t t)
+{
+    const uint32_t in_cr = t >= chroma_h ? 1u : 0u, y = t - (in_cr ? chroma_h : 0u);
+    const uint32_t tiled = luma_bytes + in_cr * kChromaCrAt + mad_u24(y >> 3, mb_w * kChromaBlockStep, (x >> 3) * kChromaBlockStep + (y & 7) * 8 + (x & 7));
+    const uint32_t linear = luma_bytes + mad_u24(t, mb_w * 8, x); // (the pad, and the slack behind it: as the reference's layout has them)
+    return t >= 2 * chroma_h ? linear : tiled;
+}
 MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, int lane)
 {
     (void)k;
-    // (rare: the plane geometry from the two values the kernel keeps)
-    const uint32_t mb_w = a.mb_w, luma_bytes = a.luma_bytes, chroma_bytes = luma_bytes >> 2;
-    const uint32_t luma_w = mb_w * 16, chroma_w = mb_w * 8;
+    // (rare: the plane geometry from the two values the kernel keeps and the record's mb_h)
+    const uint32_t mb_w = a.mb_w, luma_bytes = a.luma_bytes;
+    const uint32_t luma_w = mb_w * 16, chroma_w = mb_w * 8, luma_h = c.r[m][5] * 16, chroma_h = c.r[m][5] * 8;
     const uint8_t *ref = rc_frame_base(a, c) + kRcDmaBias + c.r[m][1];
     const uint32_t l = (uint32_t)lane, ci = l - 34, plane = ci >= 9 ? 1u : 0u;
     const bool chroma = l >= 34;
-    // the piece of a LINEAR window (lanes < 52): luma row * luma_w + column * 16 / plane * chroma_bytes + row * chroma_w (17 rows x
-    // 2, then 9 rows per plane)
-    const uint32_t lin_off = chroma ? plane * chroma_bytes + (ci - plane * 9) * chroma_w : (l >> 1) * luma_w + (l & 1) * kRcPiece;
     // (no select between two record dwords: the compiler makes an indexed load of it and moves the whole chunk to scratch)
     const uint32_t r3 = c.r[m][3], r4 = c.r[m][4];
-    const uint32_t origin = ((r3 + ((0u - (uint32_t)chroma) & (r4 - r3))) & ~3u) + lin_off;
+    const uint32_t o = r3 + ((0u - (uint32_t)chroma) & (r4 - r3));
+    // the piece's first dword: the origin's dword, + 16 bytes for the second luma piece of a row; its row: the origin's + the
+    // lane's (a Cr piece: chroma_h rows further down the Cb | Cr | pad array)
+    const uint32_t col = ((o & 0xffffu) & ~3u) + (chroma ? 0u : (l & 1) * kRcPiece);
+    const uint32_t row = (o >> 16) + (chroma ? plane * chroma_h + (ci - plane * 9) : (l >> 1));
+    const uint32_t w = chroma ? chroma_w : luma_w;
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        v.v[i] = *reinterpret_cast<const uint32_t *>(ref + linear_to_tiled(mb_w, luma_bytes, chroma_bytes, origin + 4 * i));
+    for (int i = 0; i < 4; i++) {
+        uint32_t x = col + 4 * (uint32_t)i, y = row;
+        if (x >= w) // the linear wrap (twice: a 16-pixel-wide picture's luma piece can begin in the next row but one)
+            x -= w, y++;
+        if (x >= w)
+            x -= w, y++;
+        uint32_t at;
+        if (chroma) {
+            at = rc_gather_chroma_at(mb_w, luma_bytes, chroma_h, x, y);
+        } else if (y < luma_h) {
+            at = mad_u24(y >> 4, mb_w * 256, (x >> 4) * 256 + (y & 15) * 16 + (x & 15));
+        } else { // below the luma plane the linear reads run on into Cb | Cr | pad: two of its rows per luma-width row
+            const uint32_t second = x >= chroma_w ? 1u : 0u;
+            at = rc_gather_chroma_at(mb_w, luma_bytes, chroma_h, x - (second ? chroma_w : 0u), (y - luma_h) * 2 + second);
+        }
+        v.v[i] = *reinterpret_cast<const uint32_t *>(ref + at);
+    }
     return v;
 }
 

@@ -103,6 +103,19 @@ def _levels(rng, n_blocks, counts, first_pos, natural=False):
     return nat
 
 
+def windows_inside(g, mb_x, mb_y, mvx, mvy):
+    """True where the luma and chroma prediction windows of a macroblock lie inside their planes (rc_make_record's `inside`,
+    video_recon_lane.h): the others are read the reference's way — linearly on, into the next row / plane / the pad
+    (video_noasm.go:48-80) — which the kernels gather dword by dword (kRSlow)."""
+    mvx, mvy = np.asarray(mvx, np.int64), np.asarray(mvy, np.int64)
+    cmx, cmy = np.trunc(mvx / 2).astype(np.int64), np.trunc(mvy / 2).astype(np.int64)       # toward zero, video_noasm.go:35-36
+    x0, y0 = mb_x * 16 + (mvx >> 1), mb_y * 16 + (mvy >> 1)
+    cx0, cy0 = mb_x * 8 + (cmx >> 1), mb_y * 8 + (cmy >> 1)
+    lw, lh = g["mb_w"] * 16, g["mb_h"] * 16
+    return ((x0 >= 0) & (y0 >= 0) & (x0 + 16 + (mvx & 1) <= lw) & (y0 + 16 + (mvy & 1) <= lh) &
+            (cx0 >= 0) & (cy0 >= 0) & (cx0 + 8 + (cmx & 1) <= lw // 2) & (cy0 + 8 + (cmy & 1) <= lh // 2))
+
+
 def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", raw_fraction: float = 0.0,
                      prev_flags=None):
     """Macroblock descriptors + coefficient stream for one picture (pic index 0)."""
@@ -157,6 +170,9 @@ def generate_picture(g: dict, picture_type: int, rng, profile: str = "typical", 
             else:
                 mvx[i], mvy[i] = 0, 0
     mvx[intra], mvy[intra] = 0, 0
+    if profile == "typical_inside":  # diagnostic: no prediction window leaves its plane (what MPEG-1 allows an encoder: ISO 11172-2 2.4.4.2)
+        mvx[~windows_inside(g, mb_x, mb_y, mvx, mvy)] = 0
+        mvy[~windows_inside(g, mb_x, mb_y, mvx, mvy)] = 0
     if profile == "typical_fullpel":  # diagnostic: no half-pel interpolation anywhere
         mvx, mvy = mvx & ~1, mvy & ~1
         bad = ~mv_in_range(g, mb_x, mb_y, mvx, mvy)
