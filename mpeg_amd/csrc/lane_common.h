@@ -327,6 +327,29 @@ template <int kAt> MPG_HD void dma16_to_lds(const uint8_t *base, uint32_t off, v
     __builtin_memcpy(static_cast<char *>(lds_wave_base) + kAt + 16 * lane, base + off + kAt, 16);
 #endif
 }
+// FOUR one-dword loads (global_load_lds_dword): lane l's dword i from base + off[i] (+ its offset field, as above) lands at LDS
+// offset kAt + i * kStride + 4 l — the gather of a prediction window that leaves its plane (video_recon_lane.h), issued behind
+// the wave's other direct-to-LDS loads: in flight together with them, no registers held, waited for by the same wait_loads.
+template <int kAt, int kStride> MPG_HD void dma4x4_to_lds(const uint8_t *base, const uint32_t (&off)[4], void *lds_wave_base, int lane)
+{
+    static_assert(kAt >= 0 && kAt + 3 * kStride < 4096, "13-bit signed offset field");
+#if MPG_ON_DEVICE
+    (void)lane;
+    const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %0, %4 offset:%6\n\t"
+                 "global_load_lds_dword %1, %4 offset:%7\n\t"
+                 "global_load_lds_dword %2, %4 offset:%8\n\t"
+                 "global_load_lds_dword %3, %4 offset:%9"
+                 :
+                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(base), "s"(lbase), "n"(kAt), "n"(kAt + kStride), "n"(kAt + 2 * kStride),
+                   "n"(kAt + 3 * kStride)
+                 : "memory");
+#else
+    for (int i = 0; i < 4; i++)
+        __builtin_memcpy(static_cast<char *>(lds_wave_base) + kAt + i * kStride + 4 * lane, base + off[i] + kAt + i * kStride, 4);
+#endif
+}
 // one dword per lane into a register; only valid after wait_loads + settle() — and settle() it on EVERY path, used or
 // not: until then the register belongs to the load, and the compiler must not hand it to something else
 MPG_HD uint32_t load32_uncounted(const uint32_t *uniform_base, uint32_t byte_off)

@@ -149,6 +149,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         dma_table_and_windows<kRcQtabAt, kRcWinAt, kRcWinAt + kRcWinBytes, kRcWinAt + 2 * kRcWinBytes, kRcWinAt + 3 * kRcWinBytes>(a.qmat, fbase, off,
                                                                                                                               lds, lane);
     }
+    // windows that leave their plane (the reference reads on linearly: rare in streams, 1 - 6 % of the bench's macroblocks): gathered
+    // by one-dword loads straight into the window's place, behind the loads above and in flight with them
+    if (rc_any_slow(c)) {
+        if (lane < kRcGatherLanes) {
+            if (c.r[0][0] & kRSlow)
+                rc_gather_to_lds<0>(a, c, fbase, lds, lane);
+            if (c.r[1][0] & kRSlow)
+                rc_gather_to_lds<1>(a, c, fbase, lds, lane);
+            if (c.r[2][0] & kRSlow)
+                rc_gather_to_lds<2>(a, c, fbase, lds, lane);
+            if (c.r[3][0] & kRSlow)
+                rc_gather_to_lds<3>(a, c, fbase, lds, lane);
+        }
+    }
     MPG_STAMP(2);
 
     int32_t v[8];
@@ -268,13 +282,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         } else {
             if (r0 & kRDead)
                 return;
-            if (r0 & kRSlow) { // the window leaves its plane: the reference's linear reads, gathered (rare)
-                uint8_t *win = lds + rc_win_at(m);
-                if (lane < 52)
-                    *reinterpret_cast<u32x4 *>(win + lane * 16) = rc_gather_piece(a, c, m, k, lane);
-                wave_lds_handoff();
-                yl = rc_mc_luma_slow(win, k, r0, c.r[m][3]);
-                yc = rc_mc_chroma_slow(win, k, r0, c.r[m][4]);
+            if (r0 & kRSlow) { // the window leaves its plane: the reference's linear reads, gathered in step 1 (rare)
+                const uint8_t *win = lds + rc_win_at(m);
+                yl = rc_mc_luma_slow(win, lane, r0, c.r[m][3], k.ones);
+                yc = rc_mc_chroma_slow(win, lane, r0, c.r[m][4], k.ones);
             }
         }
         wave_lds_handoff(); // every lane has its taps
@@ -435,6 +446,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         by_wave([&](auto M) {
             constexpr int m = decltype(M)::value;
             dma16_to_lds<kRcWinAt + m * kRcWinBytes>(fbase, rc_win_offset(c, m, k), lds, lane);
+            if ((c.r[m][0] & kRSlow) && lane < kRcGatherLanes) // (recon_kernel: a window that leaves its plane, gathered behind it)
+                rc_gather_to_lds<m>(a, c, fbase, lds, lane);
         });
     // step 2: residual pass w (recon_kernel's int16-tile form) -> row j of block g in lane (g, j)
     int32_t v[8];
@@ -489,11 +502,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             yl = rc_mc_luma<m>(lds, k, r0, c.r[m][3]);
             yc = rc_mc_chroma<m>(lds, k, lane, r0, c.r[m][4], c.r[m][5]);
         } else if (r0 & kRSlow) {
-            if (lane < 52)
-                *reinterpret_cast<u32x4 *>(win + lane * 16) = rc_gather_piece(a, c, m, k, lane);
-            wave_lds_handoff();
-            yl = rc_mc_luma_slow(win, k, r0, c.r[m][3]);
-            yc = rc_mc_chroma_slow(win, k, r0, c.r[m][4]);
+            yl = rc_mc_luma_slow(win, lane, r0, c.r[m][3], k.ones);
+            yc = rc_mc_chroma_slow(win, lane, r0, c.r[m][4], k.ones);
         }
         wave_lds_handoff(); // every lane has its taps
         *reinterpret_cast<uint32_t *>(win + k.out_luma) = yl;

@@ -744,7 +744,6 @@ struct RcLane {
     uint32_t mc_plane;     // plane * 160 — tiled chroma pieces
     uint32_t mc_c0, mc_dr, mc_dc;
     int32_t mc_cs, mc_cs2, mc_ck, mc_ck2;
-    uint32_t mc_lin;       // linear chroma rows (kRSlow): kRcWinLuma + (plane*9 + row)*16 + half*4
     uint32_t ones;         // 0x01010101 in a vector register: the rounding byte of v_lerp_u8 (a literal would be a scalar move per use)
     uint32_t out_luma;     // where the lane's 4 luma bytes go inside O_m: lane * 4
     uint32_t out_chroma;   // 4 chroma bytes: 256 + (lane & 31) * 4
@@ -784,7 +783,6 @@ MPG_HD RcLane rc_lane(const VideoArgs &a, int lane)
         k.mc_cs = 4 + 8 * h;
         k.mc_cs2 = 8 - 16 * h;
     }
-    k.mc_lin = kRcWinLuma + (((l >> 4) & 1) * 9 + ((l >> 1) & 7)) * kRcPiece + (l & 1) * 4;
     k.ones = opaque(0x01010101u);
     k.out_luma = l * 4;
     k.out_chroma = 256 + (l & 31) * 4;
@@ -836,13 +834,17 @@ MPG_HD uint32_t rc_gather_chroma_at(uint32_t mb_w, uint32_t luma_bytes, uint32_t
     const uint32_t linear = luma_bytes + mad_u24(t, mb_w * 8, x); // (the pad, and the slack behind it: as the reference's layout has them)
     return t >= 2 * chroma_h ? linear : tiled;
 }
-MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const RcLane &k, int lane)
+// In LDS a gathered window is NOT laid out like the linear window (pieces of 16 bytes): dword i of piece `lane` sits at
+// i * kRcGatherStride + 4 * lane — where one-dword direct-to-LDS loads put it (lane_common.h: dma4x4_to_lds).  832 of the
+// window's 864 bytes.
+constexpr int kRcGatherLanes = 52, kRcGatherStride = kRcGatherLanes * 4;
+static_assert(4 * kRcGatherStride <= kRcWinBytes, "a gathered window fits the window's place in LDS");
+// byte offsets, from the reference SLOT's start, of the four dwords of `lane`'s piece
+MPG_HD void rc_gather_offsets(const VideoArgs &a, const RcChunk &c, int m, int lane, uint32_t (&at)[4])
 {
-    (void)k;
     // (rare: the plane geometry from the two values the kernel keeps and the record's mb_h)
     const uint32_t mb_w = a.mb_w, luma_bytes = a.luma_bytes;
     const uint32_t luma_w = mb_w * 16, chroma_w = mb_w * 8, luma_h = c.r[m][5] * 16, chroma_h = c.r[m][5] * 8;
-    const uint8_t *ref = rc_frame_base(a, c) + kRcDmaBias + c.r[m][1];
     const uint32_t l = (uint32_t)lane, ci = l - 34, plane = ci >= 9 ? 1u : 0u;
     const bool chroma = l >= 34;
     // (no select between two record dwords: the compiler makes an indexed load of it and moves the whole chunk to scratch)
@@ -853,7 +855,6 @@ MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const 
     const uint32_t col = ((o & 0xffffu) & ~3u) + (chroma ? 0u : (l & 1) * kRcPiece);
     const uint32_t row = (o >> 16) + (chroma ? plane * chroma_h + (ci - plane * 9) : (l >> 1));
     const uint32_t w = chroma ? chroma_w : luma_w;
-    u32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         uint32_t x = col + 4 * (uint32_t)i, y = row;
@@ -861,19 +862,31 @@ MPG_HD u32x4 rc_gather_piece(const VideoArgs &a, const RcChunk &c, int m, const 
             x -= w, y++;
         if (x >= w)
             x -= w, y++;
-        uint32_t at;
         if (chroma) {
-            at = rc_gather_chroma_at(mb_w, luma_bytes, chroma_h, x, y);
+            at[i] = rc_gather_chroma_at(mb_w, luma_bytes, chroma_h, x, y);
         } else if (y < luma_h) {
-            at = mad_u24(y >> 4, mb_w * 256, (x >> 4) * 256 + (y & 15) * 16 + (x & 15));
+            at[i] = mad_u24(y >> 4, mb_w * 256, (x >> 4) * 256 + (y & 15) * 16 + (x & 15));
         } else { // below the luma plane the linear reads run on into Cb | Cr | pad: two of its rows per luma-width row
             const uint32_t second = x >= chroma_w ? 1u : 0u;
-            at = rc_gather_chroma_at(mb_w, luma_bytes, chroma_h, x - (second ? chroma_w : 0u), (y - luma_h) * 2 + second);
+            at[i] = rc_gather_chroma_at(mb_w, luma_bytes, chroma_h, x - (second ? chroma_w : 0u), (y - luma_h) * 2 + second);
         }
-        v.v[i] = *reinterpret_cast<const uint32_t *>(ref + at);
     }
-    return v;
 }
+// window kM of the chunk, gathered: four one-dword direct-to-LDS loads by lanes 0..51, issued BEHIND the wave's regular window
+// loads (loads complete in order: what the regular load of this window fetched — the head of the reference slot — is
+// written over) and waited for with them.  Until round 6 the gather ran when the motion compensation got to the macroblock:
+// four dependent loads into registers, a wait, a round trip through LDS — per such macroblock, one after the other.
+template <int kM> MPG_HD void rc_gather_to_lds(const VideoArgs &a, const RcChunk &c, const uint8_t *fbase, uint8_t *lds, int lane)
+{
+    constexpr int kAt = kRcWinAt + kM * kRcWinBytes;
+    uint32_t at[4], off[4];
+    rc_gather_offsets(a, c, kM, lane, at);
+#pragma unroll
+    for (int i = 0; i < 4; i++) // (fbase sits kRcDmaBias below the stream's frames; the instruction adds its offset field to the global address too)
+        off[i] = kRcDmaBias + c.r[kM][1] + at[i] - (uint32_t)(kAt + i * kRcGatherStride);
+    dma4x4_to_lds<kAt, kRcGatherStride>(fbase, off, lds, lane);
+}
+MPG_HD bool rc_any_slow(const RcChunk &c) { return ((c.r[0][0] | c.r[1][0] | c.r[2][0] | c.r[3][0]) & kRSlow) != 0; }
 
 // ---- step 2: the residual pass
 struct __attribute__((packed, aligned(4))) i32x4_a4 { int32_t v[4]; }; // 16 bytes at dword alignment (the words array)
@@ -1467,15 +1480,22 @@ MPG_HD uint32_t rc_mc4_any(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, u
         return oh ? rc_mc4_hv(a0, a1, b0, b1, sh, sh8, ones) : rc_mc4_v(a0, a1, b0, b1, sh, ones);
     return oh ? rc_mc4_h(a0, a1, sh, sh8, ones) : funnel32(a1, a0, sh);
 }
-MPG_HD uint32_t rc_mc_luma_slow(const uint8_t *win, const RcLane &k, uint32_t r0, uint32_t r3)
+// dword d (0..7 luma, 0..3 chroma) of linear row `piece0`'s pieces in the gathered layout: piece = piece0 + (d >> 2), dword d & 3
+MPG_HD uint32_t rc_gathered_dword(const uint8_t *win, uint32_t piece0, uint32_t d)
 {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_luma);
-    return rc_mc4_any(p[0], p[1], p[8], p[9], r3 & 3, k.ones, (r0 & kROhL) != 0, (r0 & kROvL) != 0); // (+ 8 dwords: the row below)
+    return *reinterpret_cast<const uint32_t *>(win + (d & 3) * kRcGatherStride + 4 * (piece0 + (d >> 2)));
 }
-MPG_HD uint32_t rc_mc_chroma_slow(const uint8_t *win, const RcLane &k, uint32_t r0, uint32_t r4)
+MPG_HD uint32_t rc_mc_luma_slow(const uint8_t *win, int lane, uint32_t r0, uint32_t r3, uint32_t ones)
 {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(win + k.mc_lin);
-    return rc_mc4_any(p[0], p[1], p[4], p[5], r4 & 3, k.ones, (r0 & kROhC) != 0, (r0 & kROvC) != 0); // (+ 4 dwords: the row below)
+    const uint32_t row = (uint32_t)lane >> 2, q = (uint32_t)lane & 3; // luma row r's two pieces: 2 r, 2 r + 1
+    return rc_mc4_any(rc_gathered_dword(win, 2 * row, q), rc_gathered_dword(win, 2 * row, q + 1), rc_gathered_dword(win, 2 * row + 2, q),
+                      rc_gathered_dword(win, 2 * row + 2, q + 1), r3 & 3, ones, (r0 & kROhL) != 0, (r0 & kROvL) != 0);
+}
+MPG_HD uint32_t rc_mc_chroma_slow(const uint8_t *win, int lane, uint32_t r0, uint32_t r4, uint32_t ones)
+{
+    const uint32_t l = (uint32_t)lane, piece = 34 + ((l >> 4) & 1) * 9 + ((l >> 1) & 7), h = l & 1; // (plane, row) -> its one piece
+    return rc_mc4_any(rc_gathered_dword(win, piece, h), rc_gathered_dword(win, piece, h + 1), rc_gathered_dword(win, piece + 1, h),
+                      rc_gathered_dword(win, piece + 1, h + 1), r4 & 3, ones, (r0 & kROhC) != 0, (r0 & kROvC) != 0);
 }
 
 // ---- step 4: residual row + the 8 prediction bytes in O_m -> clamped bytes (video.go:943-971)

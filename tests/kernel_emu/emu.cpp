@@ -187,6 +187,14 @@ static void emu_wide_chunk(const VideoArgs &a, uint32_t chunk, bool any_rgba)
             const uint32_t off[4] = {rc_win_offset(c, 0, k[lane]), rc_win_offset(c, 1, k[lane]), rc_win_offset(c, 2, k[lane]), rc_win_offset(c, 3, k[lane])};
             memcpy(lds + win_at[w] + 16 * lane, rc_frame_base(a, c) + off[w] + win_at[w], 16);
         }
+        if (c.r[w][0] & kRSlow) // a window that leaves its plane: gathered behind the regular load, into its place
+            for (int lane = 0; lane < kRcGatherLanes; lane++)
+                switch (w) {
+                case 0: rc_gather_to_lds<0>(a, c, rc_frame_base(a, c), lds, lane); break;
+                case 1: rc_gather_to_lds<1>(a, c, rc_frame_base(a, c), lds, lane); break;
+                case 2: rc_gather_to_lds<2>(a, c, rc_frame_base(a, c), lds, lane); break;
+                default: rc_gather_to_lds<3>(a, c, rc_frame_base(a, c), lds, lane); break;
+                }
         if (my_pass) {
             int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt + w * kRcTileBytes16);
             uint32_t e[64];
@@ -240,13 +248,6 @@ static void emu_wide_chunk(const VideoArgs &a, uint32_t chunk, bool any_rgba)
             continue;
         uint8_t *win = lds + rc_win_at(w);
         uint32_t yl[64], yc[64];
-        if (r0 & kRSlow) {
-            u32x4 piece[52];
-            for (int lane = 0; lane < 52; lane++)
-                piece[lane] = rc_gather_piece(a, c, (int)w, k[lane], lane);
-            for (int lane = 0; lane < 52; lane++)
-                memcpy(win + lane * 16, &piece[lane], 16);
-        }
         for (int lane = 0; lane < 64; lane++) {
             yl[lane] = yc[lane] = 0;
             if (!(r0 & (kRIntra | kRSlow))) {
@@ -257,8 +258,8 @@ static void emu_wide_chunk(const VideoArgs &a, uint32_t chunk, bool any_rgba)
                 default: yl[lane] = rc_mc_luma<3>(lds, k[lane], r0, c.r[3][3]), yc[lane] = rc_mc_chroma<3>(lds, k[lane], lane, r0, c.r[3][4], c.r[3][5]); break;
                 }
             } else if (r0 & kRSlow) {
-                yl[lane] = rc_mc_luma_slow(win, k[lane], r0, c.r[w][3]);
-                yc[lane] = rc_mc_chroma_slow(win, k[lane], r0, c.r[w][4]);
+                yl[lane] = rc_mc_luma_slow(win, lane, r0, c.r[w][3], k[lane].ones);
+                yc[lane] = rc_mc_chroma_slow(win, lane, r0, c.r[w][4], k[lane].ones);
             }
         }
         for (int lane = 0; lane < 64; lane++) { // (over the window: only after every lane has its taps)
@@ -429,6 +430,17 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
                 const uint8_t *src = i == 0 ? a.qmat + off[0] : rc_frame_base(a, c) + off[i] + at[i];
                 memcpy(lds + at[i] + 16 * lane, src, 16);
             }
+        // ... and, behind them, the gather of every window that leaves its plane (four one-dword loads by lanes 0..51 each)
+        for (int lane = 0; lane < kRcGatherLanes; lane++) {
+            if (c.r[0][0] & kRSlow)
+                rc_gather_to_lds<0>(a, c, rc_frame_base(a, c), lds, lane);
+            if (c.r[1][0] & kRSlow)
+                rc_gather_to_lds<1>(a, c, rc_frame_base(a, c), lds, lane);
+            if (c.r[2][0] & kRSlow)
+                rc_gather_to_lds<2>(a, c, rc_frame_base(a, c), lds, lane);
+            if (c.r[3][0] & kRSlow)
+                rc_gather_to_lds<3>(a, c, rc_frame_base(a, c), lds, lane);
+        }
         int32_t v[64][8];
         uint32_t ent_at = 0;
         bool table_flat = !t16 && rc_any_dense(c); // (as the kernel — the instance for dense units: the wave's AND over its lanes' columns)
@@ -513,21 +525,14 @@ static int emu_video_run_form(uint8_t *frames, uint64_t frame_stride, uint32_t l
             uint8_t *win = lds + rc_win_at(m);
             uint32_t yl[64], yc[64];
             const bool fast = !(r0 & (kRIntra | kRDead | kRSlow));
-            if (!fast && (r0 & kRSlow)) {
-                u32x4 piece[52];
-                for (int lane = 0; lane < 52; lane++)
-                    piece[lane] = rc_gather_piece(a, c, m, k[lane], lane);
-                for (int lane = 0; lane < 52; lane++)
-                    memcpy(win + lane * 16, &piece[lane], 16);
-            }
             for (int lane = 0; lane < 64; lane++) {
                 yl[lane] = yc[lane] = 0;
                 if (fast) {
                     yl[lane] = rc_mc_luma<m>(lds, k[lane], r0, c.r[m][3]);
                     yc[lane] = rc_mc_chroma<m>(lds, k[lane], lane, r0, c.r[m][4], c.r[m][5]);
                 } else if (r0 & kRSlow) {
-                    yl[lane] = rc_mc_luma_slow(win, k[lane], r0, c.r[m][3]);
-                    yc[lane] = rc_mc_chroma_slow(win, k[lane], r0, c.r[m][4]);
+                    yl[lane] = rc_mc_luma_slow(win, lane, r0, c.r[m][3], k[lane].ones);
+                    yc[lane] = rc_mc_chroma_slow(win, lane, r0, c.r[m][4], k[lane].ones);
                 }
             }
             for (int lane = 0; lane < 32; lane++) // (lanes 32..63 repeat lanes 0..31's chroma: the same bytes to the same place)
