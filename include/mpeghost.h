@@ -53,6 +53,11 @@ void mpeghost_set_default_sparse(int sparse);
 /* Test hook: every VLC table of the parser (two-level lookups, mpeg_amd/host/vlc.hpp) against a walk over its ISO 11172-2
  * code list, for all 2^L looks at the stream; returns the number that decode differently (0). */
 uint64_t mpeghost_debug_vlc_self_check(void);
+/* Test hook: ONE look at the stream through one of the parser's tables — table 0 .. 8 = macroblock_address_increment,
+ * macroblock_type I / P / B, coded_block_pattern, motion code, dct_dc_size luma / chroma, the coefficient codes (video.go:1088-1419
+ * in that order); `window` = the next 64 bits of the stream, first bit on top.  Yields what buffer.go:352-376's tree walk would
+ * return and how many bits it would consume (tests/test_vlc_known_answers.py: every path of the reference's trees).  -1: no such table. */
+int mpeghost_debug_vlc_decode(int table, uint64_t window, int *value, int *len);
 int mpeghost_video_decode(void *video, mpeghost_frame *out);         /* 1 frame, 0 none / end, -1 error */
 const uint8_t *mpeghost_video_rgba(void *video);                     /* Frame.RGBA() of the last decoded frame */
 double mpeghost_video_time(void *video);                             /* video.go:183: the time of the next frame */

@@ -111,6 +111,7 @@ void mpeghost_video_set_no_delay(void *h, int v) { static_cast<VideoHandle *>(h)
 void mpeghost_video_set_sparse(void *h, int v) { static_cast<VideoHandle *>(h)->video->SetSparse(v != 0); }
 void mpeghost_set_default_sparse(int v) { Video::SetDefaultSparse(v != 0); }
 uint64_t mpeghost_debug_vlc_self_check(void) { return Video::VlcSelfCheck(); }
+int mpeghost_debug_vlc_decode(int table, uint64_t window, int *value, int *len) { return Video::VlcDecode(table, window, value, len) ? 0 : -1; }
 int mpeghost_video_decode(void *hv, mpeghost_frame *out)
 {
     return guard([&]() -> int {

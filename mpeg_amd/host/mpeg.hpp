@@ -341,6 +341,9 @@ public:
     // test hook: every VLC table of the parser against a walk over its code list, for every possible look at the stream
     // (all 2^L prefixes of the table's longest code).  Returns the number of prefixes that decode differently (0).
     static uint64_t VlcSelfCheck();
+    // test hook: the symbol table `table` (0 .. 8: address increment, type I / P / B, coded block pattern, motion code, DC size
+    // luma / chroma, coefficient codes) finds at the top of `window`; false: no such table
+    static bool VlcDecode(int table, uint64_t window, int *value, int *len);
     // (a picture parsed ahead — Decode below — is the reference's NEXT picture: its time is the decoder's time, and the stream
     // has not ended while it waits to be returned)
     double Time() const { return ahead_.valid ? ahead_.time : time_; }

@@ -234,6 +234,30 @@ uint64_t Video::VlcSelfCheck()
            pairMismatches(tabCoeffPairs(), tabCoeffNext());
 }
 
+// test hook: ONE look at the stream through one of the parser's tables (tests/test_vlc_known_answers.py walks the reference's code
+// trees through it).  Table order: address increment, macroblock type I / P / B, coded block pattern, motion code, DC size
+// luma / chroma, coefficients (as the plain code table: what follows a code — sign, end_of_block — is coeffMismatches' matter).
+bool Video::VlcDecode(int table, uint64_t window, int *value, int *len)
+{
+    const VlcTable *t = nullptr;
+    switch (table) {
+    case 0: t = &tabMba(); break;
+    case 1: t = &tabType(1); break;
+    case 2: t = &tabType(2); break;
+    case 3: t = &tabType(3); break;
+    case 4: t = &tabCbp(); break;
+    case 5: t = &tabMotion(); break;
+    case 6: t = &tabDcSize(0); break;
+    case 7: t = &tabDcSize(1); break;
+    case 8: t = &tabCoeff(); break;
+    default: return false;
+    }
+    const VlcTable::Symbol s = t->at(window);
+    *value = s.value;
+    *len = s.len;
+    return true;
+}
+
 Video::Video(Buffer *buf, Device *dev) : buf_(buf), backend_(dev->newVideoBackend()) { init(); }
 Video::Video(Buffer *buf, std::unique_ptr<VideoBackend> backend) : buf_(buf), backend_(std::move(backend)) { init(); }
 

@@ -38,6 +38,7 @@ def host():
             "mpeghost_video_framerate": (C.c_double, [P]), "mpeghost_video_set_no_delay": (None, [P, C.c_int]),
             "mpeghost_video_set_sparse": (None, [P, C.c_int]), "mpeghost_set_default_sparse": (None, [C.c_int]),
             "mpeghost_debug_vlc_self_check": (C.c_uint64, []),
+            "mpeghost_debug_vlc_decode": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "mpeghost_video_decode": (C.c_int, [P, C.POINTER(HostFrame)]), "mpeghost_video_rgba": (P, [P]),
             "mpeghost_video_stats": (None, [P, C.POINTER(C.c_uint64 * 8)]),
             "mpeghost_video_phase_seconds": (None, [P, C.POINTER(C.c_double * 3)]),
