@@ -128,6 +128,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     int16_t *T16 = reinterpret_cast<int16_t *>(lds + kRcTileAt); // the int16 tile (and, for !kT16, the transposition buffer over it)
     uint32_t ahead = 0;
     bool ahead_pending = false;
+#ifdef MPG_PROBE_PAIRS
+    uint64_t probe_read_bias = 0;
+#endif
     auto one_chunk = [&](const RcChunk &c, const uint32_t chunk) {
     (void)chunk; // (the instrumented build's stamps)
     // what depends on the lane only: worked out while the header is on its way
@@ -140,7 +143,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 #endif
     MPG_STAMP(1);
     const uint32_t *const wbase = rc_word_base(a, c); // the chunk's block words; its entries n_blocks dwords further on
+#ifdef MPG_PROBE_PAIRS
+    // (probe, tools/ab: waves 2j and 2j + 1 of an XCD's range take chunk j of the launch's first and second half, and the second
+    // half READS the first half's frames — what two B pictures of one stream between the same anchors, launched together, would
+    // do to the windows' L2 hit rate.  Results are right only while both halves hold the same frames, as bench.py's streams do.)
+    uint8_t *const fbase = rc_frame_base(a, c) - probe_read_bias;
+#else
     uint8_t *const fbase = rc_frame_base(a, c);       // the stream's frames (biased: kRcDmaBias)
+#endif
     uint32_t e = load32_uncounted(wbase, rc_ent_lane_offset(c, 0, lane));
     uint32_t bw = load32_uncounted(wbase, rc_blk_lane_offset(0, lane)); // (pass 0's block words)
     if (lane < kRcWinLanes) {
@@ -358,9 +368,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     };
     // XCD-aware remap (block b runs on XCD b % 8; each XCD has its own L2): every XCD gets one contiguous range of chunks.  The
     // grid is a multiple of 8 (launch_batch rounds it up: at most 7 waves find nothing to do), so the map is a multiply-add.
+#ifdef MPG_PROBE_PAIRS
+    const uint32_t logical = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8));
+    if (logical >= a.n_chunks)
+        return;
+    const uint32_t first = (logical & 1u) * (a.n_chunks >> 1) + (logical >> 1);
+#ifndef MPG_PROBE_PAIRS_NOSHARE // (the control: the same order of chunks, every stream reads its own frames)
+    probe_read_bias = (logical & 1u) ? rgba_stride : 0; // (launch_batch passes half the streams' frames in this argument)
+#endif
+#else
     const uint32_t first = __builtin_amdgcn_readfirstlane(xcd_chunk(blockIdx.x, grid8));
     if (first >= a.n_chunks)
         return;
+#endif
     pull_ahead(first, a.n_chunks);
     // step 1: one round of scalar loads (the chunk), then its vector loads
     const RcChunk c0 = rc_load_chunk(a, first);
@@ -1785,6 +1805,9 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     // the at most 7 surplus waves return at once.
     const uint32_t grid8 = ((a.n_chunks + kReconWaves - 1) / kReconWaves + 7) / 8;
     const uint32_t grid = grid8 * 8;
+#ifdef MPG_PROBE_PAIRS
+    a.rgba_stride = (uint64_t)(in.n_streams / 2) * MPEGHIP_SLOTS * in.frame_stride; // (the probe's read bias; no RGBA in its runs)
+#endif
 #define LAUNCH_RECON(RGBA, T16) \
     hipLaunchKernelGGL((recon_kernel<kReconWaves, RGBA, T16>), dim3(grid), dim3(kReconWaves * 64), 0, st, grid8, a.n_chunks, a.chunks, a.words, \
                        a.qmat, a.frames_b, a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height)
