@@ -291,6 +291,9 @@ MPG_HD void dma16x5_to_lds(const uint8_t *const (&g_base)[5], const uint32_t (&o
 // (kRcDmaBias - kAt_i) already (RcLane::cterm): the instruction's offset field, added to the LDS address AND to the global
 // one, restores the difference — no scalar arithmetic per load.  off[i] INCLUDES that correction: lane l's piece i is at
 // frame_base + off[i] + kAt_i.
+#ifndef MPG_WINDOW_LOAD_BITS
+#define MPG_WINDOW_LOAD_BITS "" // (cache-policy bits of the four window loads: sc0 / sc1 / nt measured, profiles/round6_e_*)
+#endif
 template <int kAtT, int kAt1, int kAt2, int kAt3, int kAt4>
 MPG_HD void dma_table_and_windows(const uint8_t *table_base, const uint8_t *frame_base, const uint32_t (&off)[5], void *lds_wave_base, int lane)
 {
@@ -300,10 +303,10 @@ MPG_HD void dma_table_and_windows(const uint8_t *table_base, const uint8_t *fram
     const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_wave_base); // LDS aperture: low 32 bits = offset
     asm volatile("s_mov_b32 m0, %7\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %0, %5\n\t"
-                 "global_load_lds_dwordx4 %1, %6 offset:%8\n\t"
-                 "global_load_lds_dwordx4 %2, %6 offset:%9\n\t"
-                 "global_load_lds_dwordx4 %3, %6 offset:%10\n\t"
-                 "global_load_lds_dwordx4 %4, %6 offset:%11"
+                 "global_load_lds_dwordx4 %1, %6 offset:%8" MPG_WINDOW_LOAD_BITS "\n\t"
+                 "global_load_lds_dwordx4 %2, %6 offset:%9" MPG_WINDOW_LOAD_BITS "\n\t"
+                 "global_load_lds_dwordx4 %3, %6 offset:%10" MPG_WINDOW_LOAD_BITS "\n\t"
+                 "global_load_lds_dwordx4 %4, %6 offset:%11" MPG_WINDOW_LOAD_BITS
                  :
                  : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "s"(table_base), "s"(frame_base), "s"(base), "n"(kAt1), "n"(kAt2),
                    "n"(kAt3), "n"(kAt4)
@@ -414,13 +417,16 @@ MPG_HD uint32_t opaque(uint32_t v)
 // 16 bytes per lane to (wave-uniform base) + (32-bit lane offset): the scalar-base form of the store, so that no lane
 // builds a 64-bit address (the compiler prefers v_lshl_add_u64 per lane when it sees base + offset itself)
 // kStream: non-temporal — the bytes are not read again in this launch and should not push lines that are out of L2
+#ifndef MPG_STREAM_STORE_BITS
+#define MPG_STREAM_STORE_BITS "nt" // (with sc1 / sc0 sc1 — a wider scope, write-through — nothing changes: profiles/round6_e_*)
+#endif
 template <bool kStream> MPG_HD void store16_at(uint8_t *uniform_base, uint32_t off, const u32x4 &v)
 {
 #if MPG_ON_DEVICE
     typedef uint32_t vec4 __attribute__((ext_vector_type(4)));
     const vec4 d = {v.v[0], v.v[1], v.v[2], v.v[3]};
     if (kStream)
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(off), "v"(d), "s"(uniform_base) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 " MPG_STREAM_STORE_BITS : : "v"(off), "v"(d), "s"(uniform_base) : "memory");
     else
         asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(off), "v"(d), "s"(uniform_base) : "memory");
 #else

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     static_assert(WAVES == 1, "one wave per workgroup: the wave's LDS starts at 0 (lds_read32x2 / dma_table_and_windows)");
     // Everything a wave needs of the launch: the first 14 dwords arrive preloaded in SGPRs; the plane geometry follows from mb_w and
     // luma_bytes where a rare path wants it (a gathered window, a chunk that is not a run).
+#ifdef MPG_PRIO_EARLY
+    __builtin_amdgcn_s_setprio(MPG_PRIO_EARLY);
+#endif
     VideoArgs a;
     a.frames = nullptr; // (waves address frames through frames_b + the chunk's stream offset only)
     a.frames_b = frames_b;
@@ -174,6 +177,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
         }
     }
     MPG_STAMP(2);
+#ifdef MPG_PRIO_EARLY // (probe: issue priority while a wave sets up and issues its loads; profiles/round6_e_*)
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     int32_t v[8];
     bool table_flat = false;
@@ -272,6 +278,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
     MPG_STAMP(3);
     // step 3: motion compensation, half-pel modes wave-uniform per macroblock: window in LDS -> O_m over it
     wait_loads<0>(); // all four windows are there
+#ifdef MPG_PRIO_LATE // (probe: issue priority once a wave has all its data — it only computes and stores from here)
+    __builtin_amdgcn_s_setprio(MPG_PRIO_LATE);
+#endif
     settle(e);       // (on every path: until here the entries' and block words' registers belong to loads in flight)
     settle(bw);
 #if MPG_CHUNK_AHEAD
