@@ -63,6 +63,7 @@ stats dense --profile dense --legs "" --audio-streams 0 --cpu-seconds 0 --check 
 stats fused --profile typical --rgba 1 --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats dense_fused --profile dense --rgba 1 --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats audio --streams 16 --legs "" --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 2 --warmup 1 --audio-tile 8
+stats sif --profile typical --width 352 --height 240 --streams 8192 --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats mixed --profile typical --legs mixed --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 20 --warmup 5
 stats bench_default --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --check 0 --host-fed-seconds 0
 # the device-packed hand-over under the kernel trace: pack_kernel / pack_gate_kernel / recon_kernel per commit of 64 pictures
@@ -70,11 +71,11 @@ cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $R
 for f in $(find $OUT/trace_hand_over -name "*kernel_stats.csv" | head -1); do ( echo "# csrc_sha256 $SHA   tools/hostbench/sweep.py quick (64 typical 1080p pictures per commit)"; cat $f ) > $OUT/kernel_stats_hand_over.csv; done
 find $OUT/trace_hand_over -name "*kernel_trace.csv" -delete
-# the N > 1 code on this ONE GPU: eight ranks share it (128 streams each): audio + video + host_fed per rank, cpu_baseline on rank 0
-timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --share-devices --steps 20 --warmup 5 --streams 128 --audio-streams 32 --host-fed-seconds 1 --cpu-seconds 6 > $OUT/bench_8_ranks_sharing_one_gpu.json 2> $OUT/bench_8_ranks.err; echo "8 ranks rc=$?"
+# the N > 1 code on this ONE GPU (bench.py --gpus N starts its ranks by itself since round 6): eight ranks share it (128 streams each): audio + video + host_fed per rank, cpu_baseline on rank 0
+timeout 900 python bench.py --gpus 8 --share-devices --sidecar "" --steps 20 --warmup 5 --streams 128 --audio-streams 32 --host-fed-seconds 1 --cpu-seconds 6 > $OUT/bench_8_ranks_sharing_one_gpu.json 2> $OUT/bench_8_ranks.err; echo "8 ranks rc=$?"
 tail -2 $OUT/bench_8_ranks.err
 # ... and the same launch WITHOUT --share-devices: refused (ranks on one physical GPU), non-zero exit, no line
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 2 --warmup 1 --streams 16 > $OUT/bench_2_ranks_refused.out 2> $OUT/bench_2_ranks_refused.err; echo "2 ranks on one GPU without --share-devices: rc=$?" | tee $OUT/bench_2_ranks_refused.txt
+timeout 300 python bench.py --gpus 2 --sidecar "" --steps 2 --warmup 1 --streams 16 > $OUT/bench_2_ranks_refused.out 2> $OUT/bench_2_ranks_refused.err; echo "2 ranks on one GPU without --share-devices: rc=$?" | tee $OUT/bench_2_ranks_refused.txt
 grep -h "bench.py:" $OUT/bench_2_ranks_refused.err | head -2 >> $OUT/bench_2_ranks_refused.txt
 # ONE 1080p picture per launch (BASELINE config 3 as written): recon_wide_kernel under the kernel trace
 stats single_picture --streams 1 --rgba 1 --profile typical --legs "" --audio-streams 0 --cpu-seconds 0 --check 0 --host-fed-seconds 0 --single-stream 0 --steps 40 --warmup 10
@@ -91,6 +92,10 @@ for PROF in typical dense; do for RGBA in 0 1; do for SET in FETCH_SIZE WRITE_SI
   timeout 600 rocprofv3 --pmc $SET --output-format csv -d $OUT/traffic/${PROF}_${RGBA}_$SET -o pmc -- python $R/bench.py --profile $PROF --rgba $RGBA --steps 6 --warmup 2 --cpu-seconds 0 --check 0 --audio-streams 0 --legs "" --host-fed-seconds 0 --single-stream 0 > $OUT/traffic_${PROF}_${RGBA}_$SET.log 2>&1
   echo "traffic $PROF rgba=$RGBA $SET rc=$?"
 done; done; done
+for SET in FETCH_SIZE WRITE_SIZE; do   # SIF 352x240, 8192 streams (bench.py's sif leg)
+  timeout 600 rocprofv3 --pmc $SET --output-format csv -d $OUT/traffic/sif_$SET -o pmc -- python $R/bench.py --profile typical --width 352 --height 240 --streams 8192 --steps 6 --warmup 2 --cpu-seconds 0 --check 0 --audio-streams 0 --legs "" --host-fed-seconds 0 --single-stream 0 > $OUT/traffic_sif_$SET.log 2>&1
+  echo "traffic sif $SET rc=$?"
+done
 for SET in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $SET --output-format csv -d $OUT/traffic/audio_$SET -o pmc -- python $R/bench.py --streams 16 --steps 2 --warmup 1 --cpu-seconds 0 --check 0 --legs "" --host-fed-seconds 0 --single-stream 0 --audio-tile 8 > $OUT/traffic_audio_$SET.log 2>&1
   echo "traffic audio $SET rc=$?"
@@ -122,6 +127,14 @@ for prof in ("typical", "dense"):
                     "hbm_bytes_per_launch_raw": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
                     "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
                     "source": "profiles/${T}_pmc_traffic.json (rocprofv3 --pmc, separate passes; a figure of that run of the same kernel sources, not measured by bench.py)"}
+v = {}
+for s in ("FETCH_SIZE", "WRITE_SIZE"):
+    xs = rows("gpurun_out/$T/traffic/sif_%s/**/*counter_collection.csv" % s, "recon_kernel", s)
+    v[s] = sum(x[2] for x in xs) / max(1, len(xs))
+if v["WRITE_SIZE"]:
+    out["typical_352x240"] = {"streams": 8192, "kernel": "recon_kernel<1, false, true>", "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
+                              "hbm_bytes_per_launch_raw": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+                              "source": "profiles/${T}_pmc_traffic.json (rocprofv3 --pmc, separate passes; a figure of that run of the same kernel sources, not measured by bench.py)"}
 # audio: the launches of 256 streams and of 2048 streams are told apart by their grid size
 by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
 for s in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -143,3 +156,11 @@ PY
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*.db" -delete
 ls $OUT | head -40
+# the driver's command once more, now that the traffic figures of THESE sources exist: the line whose roofline.traffic is of the build it ran
+# (round 5's cited line had been taken before its traffic file: traffic_matches_build false)
+cp $OUT/pmc_traffic.json $R/profiles/${T}_pmc_traffic.json
+echo "{\"current\": \"${T}_pmc_traffic.json\"}" > $R/profiles/pmc_traffic.json
+cd $R
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default_with_traffic.json 2> $OUT/bench_default_with_traffic.err; echo "bench (with traffic) rc=$?"
+cp bench_legs.json $OUT/bench_legs.json 2>/dev/null
+ls $OUT | head -60
