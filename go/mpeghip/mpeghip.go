@@ -197,6 +197,29 @@ func (v *Video) ReadPlanesAsync(slot int, dst []byte) (uint64, error) {
 }
 func (v *Video) ReadWait(ticket uint64) error { return lastError(C.mpeghip_video_read_wait(v.h, C.uint64_t(ticket))) }
 
+// HostMirror gives every slot a copy of its planes — luma | Cb | Cr, linear — in pinned host memory of the library, which the
+// reconstruction launch itself keeps up to date (for submits small enough for the library's four-waves-per-chunk kernel: a lone
+// decoder's); MirrorAsync names the slot's copy (C memory, valid while the mirror is on) and a ticket: ReadWait(ticket) returns when
+// the copy holds the slot as it is after everything submitted so far.  No untiling launch, no copy — unless something else wrote
+// the slot since.  The copy is overwritten by the next picture reconstructed into the slot: the lifetime the reference gives a
+// returned *Frame (mpeg.go:413-415).
+func (v *Video) HostMirror(on bool) error {
+	flag := C.int(0)
+	if on {
+		flag = 1
+	}
+	return lastError(C.mpeghip_video_host_mirror(v.h, flag))
+}
+func (v *Video) MirrorAsync(slot int) ([]byte, uint64, error) {
+	var planes *C.uint8_t
+	var ticket C.uint64_t
+	if err := lastError(C.mpeghip_video_mirror_async(v.h, 0, C.uint32_t(slot), &planes, &ticket)); err != nil {
+		return nil, 0, err
+	}
+	n := int(v.Info.luma_bytes + 2*v.Info.chroma_bytes)
+	return unsafe.Slice((*byte)(unsafe.Pointer(planes)), n), uint64(ticket), nil
+}
+
 // RGBA converts the slot on the device (Frame.RGBA) and copies width*height*4 bytes into dst.
 func (v *Video) RGBA(slot int, dst []byte) error {
 	if err := lastError(C.mpeghip_video_rgba_convert(v.h, C.uint32_t(slot), 0, 1)); err != nil {

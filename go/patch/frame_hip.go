@@ -18,13 +18,16 @@ import "image"
 // (tests/test_host_lookahead.py, tests/test_gpu_lookahead.py):
 //
 //	1  the hand-overs of the picture parsed during the previous call go to the device (replayHeld)
-//	2  the read-back of the frame this call returns is queued behind them, asynchronously, into one of two pinned frames
+//	2  the frame this call returns is the slot's copy in the device store's HOST MIRROR, which the reconstruction launch itself
+//	   keeps (mpeghip.Video.MirrorAsync: nothing is queued but a completion ticket) — or, without a mirror, a read-back queued
+//	   behind them, asynchronously, into one of two pinned frames
 //	3  the NEXT picture is parsed while the device works; its hand-overs are kept (flush, h.deferring), so the device's frame
 //	   store is never ahead of the frames returned: Rewind / Seek drop the parsed picture (dropLookahead) and everything is as
 //	   the reference has it — Frame.RGBA() of the frame in hand still finds its slot intact
 //	4  only then the wait for (2)
 //
-// The returned *Frame is one of h.out[0..1], alternating: valid until the next Decode call (mpeg.go:413-415).  Go cannot
+// The returned *Frame is one of h.out[0..1], alternating; with the mirror its planes are the SLOT's copy — one of three, as the
+// reference's returned *Frame is one of its three frames: valid until the next Decode call (mpeg.go:413-415) either way.  Go cannot
 // intercept the access to Frame.Y.Data, so the read-back is eager unless the consumer opted out (Video.hip.NoPlanes, for players
 // that only call Frame.RGBA()).
 func (h *hipVideo) decode(v *Video) *Frame {
@@ -46,8 +49,13 @@ func (h *hipVideo) decode(v *Video) *Frame {
 	h.outNext ^= 1
 	var ticket uint64
 	var err error
+	planes := h.outPlanes[b]
 	if !h.NoPlanes {
-		ticket, err = h.dev.ReadPlanesAsync(int(slot), h.outPlanes[b])
+		if h.mirrored {
+			planes, ticket, err = h.dev.MirrorAsync(int(slot))
+		} else {
+			ticket, err = h.dev.ReadPlanesAsync(int(slot), planes)
+		}
 	}
 	if h.lookahead {
 		h.parseAhead(v)
@@ -57,6 +65,11 @@ func (h *hipVideo) decode(v *Video) *Frame {
 	}
 	out := &h.out[b]
 	out.Time, out.hipSlot = t, slot
+	if h.mirrored && !h.NoPlanes && err == nil { // the frame's planes ARE the slot's copy in the mirror
+		luma, chroma := v.lumaWidth*v.lumaHeight, v.chromaWidth*v.chromaHeight
+		out.Y.Data, out.Cb.Data, out.Cr.Data = planes[:luma:luma], planes[luma:luma+chroma:luma+chroma], planes[luma+chroma:luma+2*chroma]
+		out.imYCbCr.Y, out.imYCbCr.Cb, out.imYCbCr.Cr = out.Y.Data, out.Cb.Data, out.Cr.Data
+	}
 	return out
 }
 

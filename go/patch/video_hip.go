@@ -90,6 +90,7 @@ type hipVideo struct {
 	out                          [2]Frame // the two frames Decode alternates between (valid until the next call, mpeg.go:413-415)
 	outPlanes                    [2][]byte // pinned (mpeghip.Context.PinnedAlloc): luma | Cb | Cr
 	outNext                      int
+	mirrored                     bool // the device store keeps a host mirror (mpeghip.Video.HostMirror): Decode's frames point into it
 
 	have     [3]bool // Frame.Y/Cb/Cr.Data of the Frame holding slot s equal the device's slot s
 	NoPlanes bool    // the consumer only wants Frame.RGBA(): Decode skips the plane read-back
@@ -142,6 +143,9 @@ func (h *hipVideo) open(v *Video) bool {
 		f.hipOwner = v
 	}
 	h.lookahead, h.ahead.valid, h.nHeld, h.undo, h.aheadTried = true, false, 0, nil, false
+	// the host mirror: the reconstruction launch writes every frame once more, linearly, into pinned host memory — Decode then hands
+	// out that copy and queues no read-back at all (frame_hip.go); without it (no pinned memory to be had) the two frames above serve
+	h.mirrored = h.dev.HostMirror(true) == nil
 	return true
 }
 

@@ -39,7 +39,8 @@ extern "C" {
 /* 3: (round 6) asynchronous read-back and synthesis for a lone decoder that works one picture / frame ahead —
  *    mpeghip_video_read_planes_async / _read_wait, mpeghip_audio_synth_async / _synth_wait / _undo_last; a device-packed commit's
  *    refusal is per picture (the commit's other pictures are reconstructed: mpeghip_video_verdict / _refused); and
- *    mpeghip_ctx_pci_bus_id (added during round 5 without a bump).  Nothing else of version 2 changed. */
+ *    mpeghip_ctx_pci_bus_id (added during round 5 without a bump); mpeghip_video_host_mirror / _mirror_async (a lone decoder's frames
+ *    written linearly into pinned host memory by the reconstruction launch itself).  Nothing else of version 2 changed. */
 #define MPEGHIP_ABI_VERSION 3
 
 #define MPEGHIP_OK             0
@@ -377,6 +378,21 @@ int mpeghip_video_read_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
  * synchronising call).  Read-backs complete in the order they were queued. */
 int mpeghip_video_read_planes_async(mpeghip_video *v, uint32_t stream, uint32_t slot, uint8_t *dst, uint64_t *ticket);
 int mpeghip_video_read_wait(mpeghip_video *v, uint64_t ticket);
+/* The HOST MIRROR (round 6, within ABI 3; for a lone decoder's store — what makes the Go shim's Video.Decode, video.go:209-268,
+ * one launch per picture): mpeghip_video_host_mirror(v, 1) gives every (stream, slot) a copy of its planes in pinned host memory,
+ * in the reference's linear layout (luma | Cb | Cr, luma_bytes + 2 * chroma_bytes; at most 1 GiB in all), and from then on the
+ * reconstruction launch itself writes every macroblock there as well — for submits small enough for the library's four-waves-per-
+ * chunk kernel (up to two 1080p pictures; no MPEGHIP_PIC_RGBA picture among them).  mpeghip_video_mirror_async names the copy of
+ * (stream, slot) — *planes, valid memory until the mirror is switched off or the store closed — and a ticket:
+ * mpeghip_video_read_wait(ticket) returns when the copy holds the slot as it is after everything submitted so far.  No untiling
+ * launch and no copy are queued, unless something else wrote the slot since (a large or colour-converting submit, write_planes,
+ * broadcast_slot, or nothing yet): then one untiling launch into the copy makes it right again.  The copy of a slot is overwritten by
+ * the next picture reconstructed into that slot — which is the lifetime the reference gives a returned *Frame (mpeg.go:413-415). */
+int mpeghip_video_host_mirror(mpeghip_video *v, int on);
+int mpeghip_video_mirror_async(mpeghip_video *v, uint32_t stream, uint32_t slot, const uint8_t **planes, uint64_t *ticket);
+/* out[0]: mpeghip_video_mirror_async calls so far; out[1]: those that had to queue an untiling launch first (a lone decoder in its
+ * stride: three, one per slot) */
+void mpeghip_video_mirror_counters(const mpeghip_video *v, uint64_t out[2]);
 int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
                                const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
                                const uint8_t *pad);

@@ -66,6 +66,14 @@ void mpeghost_video_rewind(void *video);                             /* video.go
 /* Video.Decode works one picture ahead on the host (parse of picture N+1 while picture N is on the device; that picture's work
  * is held back until the next call, so Rewind / Seek see the reference's state).  0 switches it off: parse, submit, read back. */
 void mpeghost_video_set_lookahead(void *video, int on);
+/* The frames Video.Decode returns come out of the device store's HOST MIRROR (mpeghip_video_host_mirror: the reconstruction launch
+ * writes every frame once more, linearly, into pinned host memory — no read-back is queued; the default).  0: the asynchronous
+ * read-back into two pinned frames (mpeghip_video_read_planes_async).  Same frames either way. */
+void mpeghost_video_set_host_mirror(void *video, int on);
+/* A lone decoder's hand-overs of n_mbs macroblocks and more (sparse form) are validated and packed by the DEVICE — a device-packed
+ * stage of one picture, include/mpeghip.h — instead of by the thread that parses; 0 = never.  Default: 3 000, where the two ways cost the same
+ * (a 1080p picture has 8 160 macroblocks, a SIF picture 330).  Same frames either way; what the device would refuse the parser does not hand over. */
+void mpeghost_video_set_device_pack_from(void *video, uint32_t n_mbs);
 void mpeghost_video_stats(void *video, uint64_t out[8]);
 /* wall seconds of the decoder's three host phases so far: [0] bitstream parse, [1] hand-over of the pictures' work (submit),
  * [2] waiting for / copying frames back */

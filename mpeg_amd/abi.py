@@ -74,6 +74,9 @@ SYMBOLS = {
     "mpeghip_video_read_planes": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "mpeghip_video_read_planes_async": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
     "mpeghip_video_read_wait": (C.c_int, [_P, C.c_uint64]),
+    "mpeghip_video_host_mirror": (C.c_int, [_P, C.c_int]),
+    "mpeghip_video_mirror_async": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "mpeghip_video_mirror_counters": (None, [_P, C.POINTER(C.c_uint64 * 2)]),
     "mpeghip_video_write_planes": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, _P, _P]),
     "mpeghip_video_broadcast_slot": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mpeghip_video_hash_slots": (C.c_int, [_P, C.c_uint32, _P]),
@@ -372,6 +375,25 @@ class VideoStore:
 
     def read_wait(self, ticket: int):
         _check(self.lib.mpeghip_video_read_wait(self.h, ticket))
+
+    def host_mirror(self, on: bool = True):
+        """mpeghip_video_host_mirror: every (stream, slot)'s planes once more, linear, in pinned host memory, written by the
+        reconstruction launches themselves (small submits: the library's four-waves-per-chunk kernel)."""
+        _check(self.lib.mpeghip_video_host_mirror(self.h, 1 if on else 0))
+
+    def mirror_counters(self):
+        """-> (mirror_async calls, those that had to untile the slot first)"""
+        out = (C.c_uint64 * 2)()
+        self.lib.mpeghip_video_mirror_counters(self.h, C.byref(out))
+        return out[0], out[1]
+
+    def mirror_async(self, stream: int, slot: int):
+        """-> (numpy view of the slot's linear copy in pinned host memory: luma | Cb | Cr, ticket); the view holds the slot as it
+        is after everything submitted so far once read_wait(ticket) has returned."""
+        p, t = _P(), C.c_uint64()
+        _check(self.lib.mpeghip_video_mirror_async(self.h, stream, slot, C.byref(p), C.byref(t)))
+        n = self.info.luma_bytes + 2 * self.info.chroma_bytes
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)), t.value
 
     def split_planes(self, flat):
         L, Cb = self.info.luma_bytes, self.info.chroma_bytes

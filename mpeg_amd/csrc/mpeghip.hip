@@ -405,12 +405,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(8, 8
 // rows are added by the wave that made them; then every wave stores its share: luma / chroma of a run, four image rows each of
 // a fused colour conversion).  The lane functions, the device format and the arithmetic are recon_kernel's own (int16 tile);
 // launch_batch takes this kernel when four waves per chunk still fit the device's slots and no instance is pinned.
-template <bool kRgba>
+// kMirror (mpeghip_video_host_mirror: a lone decoder's store): every macroblock written is also written, linearly, into the frame's
+// copy in pinned host memory — the frame Video.Decode returns is then in the caller's hands when the launch is over, with no
+// untiling launch behind it (rc_mirror_mb).
+template <bool kRgba, bool kMirror>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void recon_wide_kernel(
     const uint32_t grid8, const uint32_t n_chunks, const uint32_t *const chunks, const uint32_t *const words, const uint8_t *const qmat,
     uint8_t *const frames_b, const uint32_t mb_w, const uint32_t luma_bytes, uint8_t *const rgba, const uint64_t rgba_stride,
     const uint32_t width, const uint32_t height)
 {
+    static_assert(!(kRgba && kMirror), "the mirrored instance carries no colour conversion (launch_batch)");
+    // (the mirroring instance converts no colours: the two arguments that name the RGBA images name the host mirror there, and the
+    // kernel's signature — its preloaded arguments — is the same for every instance)
+    uint8_t *const mirror = rgba;
+    const uint64_t mirror_stride = rgba_stride;
     VideoArgs a;
     a.frames = nullptr;
     a.frames_b = frames_b;
@@ -547,6 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool run = (c.h[4] & kCRun) != 0;
     const bool to_rgba = kRgba && (c.h[4] & kCRgba) != 0;
     const uint32_t n_live = rc_n_live(c);
+    uint8_t *const mirror_frame = kMirror ? mirror + ((uint64_t)rc_stream(c) * MPEGHIP_SLOTS + rc_cur_slot(c)) * mirror_stride : nullptr;
     if (run) {
         if (w == 0)
             rc_store_run_luma(a, c, lane, lds);
@@ -558,13 +567,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             else // a run that wraps a row end: wave w converts macroblock w
                 by_wave([&](auto M) { rc_rgba_mb(a, c, rc_rgba_image(a, c), (uint32_t)decltype(M)::value, lane, lds); });
         }
+        if (kMirror) // (a run has four live macroblocks, every byte of them written)
+            by_wave([&](auto M) { rc_mirror_mb(a, c, mirror_frame, (uint32_t)decltype(M)::value, lane, lds); });
     } else if (w < n_live) {
         by_wave([&](auto M) {
             constexpr uint32_t m = (uint32_t)decltype(M)::value;
-            rc_store_mb(a, c, m, lane, lds, to_rgba);
+            rc_store_mb(a, c, m, lane, lds, to_rgba || kMirror);
             if (kRgba && to_rgba) {
                 wave_lds_handoff();
                 rc_rgba_mb(a, c, rc_rgba_image(a, c), m, lane, lds);
+            }
+            if (kMirror) {
+                wave_lds_handoff(); // (the pixels an invalid intra block keeps are in O_m now)
+                rc_mirror_mb(a, c, mirror_frame, m, lane, lds);
             }
         });
     }
@@ -961,6 +976,13 @@ struct mpeghip_video {
     uint64_t reads_issued = 0;
     int tile_policy = MPEGHIP_TILE_AUTO;   // mpeghip_video_set_tile_policy
     int n_cu = 256;                        // compute units of the device (asked once, at open)
+    // mpeghip_video_host_mirror: every (stream, slot)'s planes once more, LINEAR, in pinned host memory, written by the
+    // reconstruction launch itself (recon_wide_kernel<false, true>).  mirror_valid[stream*3 + slot]: the copy equals the slot —
+    // kept by launches that mirror, lost to anything else that writes the slot, restored by an untiling launch when asked for.
+    uint8_t *h_mirror = nullptr, *d_mirror = nullptr;
+    uint64_t mirror_stride = 0;
+    std::vector<uint8_t> mirror_valid;
+    uint64_t mirror_requests = 0, mirror_repairs = 0; // mpeghip_video_mirror_async calls / those that had to untile the slot first
 };
 
 // what validation learns about a picture (the dependency check across pictures needs it)
@@ -1293,6 +1315,8 @@ void mpeghip_video_close(mpeghip_video *v)
         (void)hipHostFree(v->bounce);
     if (v->d_linear)
         (void)hipFree(v->d_linear);
+    if (v->h_mirror)
+        (void)hipHostFree(v->h_mirror);
     for (auto &e : v->read_done)
         if (e)
             (void)hipEventDestroy(e);
@@ -1758,6 +1782,16 @@ static int finish_rgba_bookkeeping(mpeghip_video *v, const mpeghip_batch *b, con
     return MPEGHIP_OK;
 }
 
+// the slots a batch writes are no longer what their host mirrors hold (a launch without the mirror code wrote them)
+static void mirror_lost(mpeghip_video *v, const mpeghip_batch *b)
+{
+    if (!v->h_mirror)
+        return;
+    for (uint32_t r = 0; r < b->replicas; r++)
+        for (const mpeghip_batch::PicNote &n : b->notes)
+            v->mirror_valid[((size_t)n.stream + r) * MPEGHIP_SLOTS + n.cur] = 0;
+}
+
 static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
 {
     if (b->n_chunks == 0)
@@ -1802,14 +1836,20 @@ static int launch_batch(mpeghip_video *v, const mpeghip_batch *b)
     if (v->tile_policy == MPEGHIP_TILE_AUTO && a.n_chunks * 4 <= (uint64_t)(v->n_cu > 0 ? v->n_cu : 256) * 4 * 8 * 2) {
         const uint32_t g8 = (a.n_chunks + 7) / 8;
         if (b->any_rgba)
-            hipLaunchKernelGGL((recon_wide_kernel<true>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat, a.frames_b,
-                               a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height);
+            hipLaunchKernelGGL((recon_wide_kernel<true, false>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat,
+                               a.frames_b, a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height);
+        else if (v->d_mirror) // a store with a host mirror: the launch writes the frames' linear copies too (they stay valid)
+            hipLaunchKernelGGL((recon_wide_kernel<false, true>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat,
+                               a.frames_b, a.mb_w, a.luma_bytes, v->d_mirror, v->mirror_stride, a.width, a.height);
         else
-            hipLaunchKernelGGL((recon_wide_kernel<false>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat, a.frames_b,
-                               a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height);
+            hipLaunchKernelGGL((recon_wide_kernel<false, false>), dim3(g8 * 8), dim3(256), 0, st, g8, a.n_chunks, a.chunks, a.words, a.qmat,
+                               a.frames_b, a.mb_w, a.luma_bytes, a.rgba, a.rgba_stride, a.width, a.height);
         HIP_TRY(hipGetLastError());
+        if (b->any_rgba)
+            mirror_lost(v, b);
         return finish_rgba_bookkeeping(v, b, a);
     }
+    mirror_lost(v, b); // (recon_kernel carries no mirror code: launches that fill the device are not a lone decoder's)
     // One chunk per wave (the comment at recon_kernel).  A multiple of 8 workgroups: the kernel's XCD remap is then a multiply-add;
     // the at most 7 surplus waves return at once.
     const uint32_t grid8 = ((a.n_chunks + kReconWaves - 1) / kReconWaves + 7) / 8;
@@ -2852,6 +2892,76 @@ int mpeghip_video_read_planes_async(mpeghip_video *v, uint32_t stream, uint32_t 
     return MPEGHIP_OK;
 }
 
+int mpeghip_video_host_mirror(mpeghip_video *v, int on)
+{
+    if (!v)
+        return fail(MPEGHIP_ERR_INVALID, "host_mirror: no store");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    if (!on) {
+        if (v->h_mirror) {
+            HIP_TRY(hipStreamSynchronize(v->ctx->stream)); // (launches that write it)
+            (void)hipHostFree(v->h_mirror);
+        }
+        v->h_mirror = v->d_mirror = nullptr;
+        v->mirror_valid.clear();
+        return MPEGHIP_OK;
+    }
+    if (v->h_mirror)
+        return MPEGHIP_OK;
+    const uint64_t stride = align_up(v->info.luma_bytes + 2 * v->info.chroma_bytes, 256);
+    const uint64_t total = stride * MPEGHIP_SLOTS * v->info.n_streams;
+    if (total > (1ull << 30)) // a lone decoder's store (or a few): a thousand streams' frames do not belong in pinned host memory
+        return fail(MPEGHIP_ERR_INVALID, "host_mirror: %llu bytes of pinned memory for %u streams (limit 1 GiB)", (unsigned long long)total,
+                    v->info.n_streams);
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, total, hipHostMallocDefault) != hipSuccess)
+        return fail(MPEGHIP_ERR_OOM, "host_mirror: hipHostMalloc(%llu) failed", (unsigned long long)total);
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        return fail(MPEGHIP_ERR_HIP, "host_mirror: pinned memory is not visible to the device");
+    }
+    v->h_mirror = static_cast<uint8_t *>(h);
+    v->d_mirror = static_cast<uint8_t *>(d);
+    v->mirror_stride = stride;
+    v->mirror_valid.assign((size_t)v->info.n_streams * MPEGHIP_SLOTS, 0); // (every slot's first request untiles it once)
+    return MPEGHIP_OK;
+}
+
+int mpeghip_video_mirror_async(mpeghip_video *v, uint32_t stream, uint32_t slot, const uint8_t **planes, uint64_t *ticket)
+{
+    if (!v || !planes || !ticket || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
+        return fail(MPEGHIP_ERR_INVALID, "mirror_async: bad argument");
+    if (!v->h_mirror)
+        return fail(MPEGHIP_ERR_INVALID, "mirror_async: the store has no host mirror (mpeghip_video_host_mirror)");
+    HIP_TRY(hipSetDevice(v->ctx->device));
+    hipStream_t st = v->ctx->stream;
+    const size_t at = ((size_t)stream * MPEGHIP_SLOTS + slot);
+    v->mirror_requests++;
+    if (!v->mirror_valid[at]) { // something other than a mirroring launch wrote the slot (or nothing has yet): untile it once
+        v->mirror_repairs++;
+        const size_t bytes = v->info.luma_bytes + 2 * v->info.chroma_bytes;
+        hipLaunchKernelGGL(relayout_kernel, dim3(((uint32_t)bytes / 4 + 255) / 256), dim3(256), 0, st, slot_ptr(v, stream, slot),
+                           v->d_mirror + at * v->mirror_stride, 0u, (uint32_t)bytes, v->info.mb_w, (uint32_t)v->info.luma_bytes,
+                           (uint32_t)v->info.chroma_bytes, 1);
+        HIP_TRY(hipGetLastError());
+        v->mirror_valid[at] = 1;
+    }
+    hipEvent_t &ev = v->read_done[v->reads_issued & 3];
+    if (!ev)
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, st));
+    *ticket = v->reads_issued++;
+    *planes = v->h_mirror + at * v->mirror_stride;
+    return MPEGHIP_OK;
+}
+
+void mpeghip_video_mirror_counters(const mpeghip_video *v, uint64_t out[2])
+{
+    out[0] = v ? v->mirror_requests : 0;
+    out[1] = v ? v->mirror_repairs : 0;
+}
+
 int mpeghip_video_read_wait(mpeghip_video *v, uint64_t ticket)
 {
     if (!v || ticket >= v->reads_issued)
@@ -2867,6 +2977,8 @@ int mpeghip_video_write_planes(mpeghip_video *v, uint32_t stream, uint32_t slot,
     if (!v || stream >= v->info.n_streams || slot >= MPEGHIP_SLOTS)
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
     v->rgba_sync[(size_t)stream * MPEGHIP_SLOTS + slot] = 0; // the slot's RGBA image is out of date now
+    if (v->h_mirror)
+        v->mirror_valid[(size_t)stream * MPEGHIP_SLOTS + slot] = 0; // ... and its host mirror
     HIP_TRY(hipSetDevice(v->ctx->device));
     int rc = ensure_linear(v);
     if (rc != MPEGHIP_OK)
@@ -2900,8 +3012,11 @@ int mpeghip_video_broadcast_slot(mpeghip_video *v, uint32_t src, uint32_t slot, 
         return fail(MPEGHIP_ERR_INVALID, "bad stream/slot");
     HIP_TRY(hipSetDevice(v->ctx->device));
     for (uint32_t s = dst0; s < dst0 + n; s++)
-        if (s != src)
+        if (s != src) {
             v->rgba_sync[(size_t)s * MPEGHIP_SLOTS + slot] = 0;
+            if (v->h_mirror)
+                v->mirror_valid[(size_t)s * MPEGHIP_SLOTS + slot] = 0;
+        }
     for (uint32_t s = dst0; s < dst0 + n; s++) {
         if (s == src)
             continue;

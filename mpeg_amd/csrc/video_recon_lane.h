@@ -1554,6 +1554,23 @@ MPG_HD void rc_store_mb(const VideoArgs &a, const RcChunk &c, uint32_t m, int la
         *reinterpret_cast<uint64_t *>(t) = *reinterpret_cast<const uint64_t *>(cur);
 }
 
+// The host mirror (mpeghip_video_host_mirror; recon_wide_kernel<false, true>): macroblock m's 384 output bytes once more, into the
+// reference's LINEAR planes (video.go:347-355: Y | Cb | Cr, rows of luma_w / chroma_w bytes) of a frame in pinned host memory —
+// lanes 0..15: luma row `lane` (16 bytes), 16..23: Cb row (8 bytes), 24..31: Cr row.  O_m must hold the macroblock as the frame
+// store holds it: always so in a run; in any other chunk rc_store_mb has parked the pixels an invalid intra block keeps (mirror).
+MPG_HD void rc_mirror_mb(const VideoArgs &a, const RcChunk &c, uint8_t *frame, uint32_t m, int lane, const uint8_t *lds)
+{
+    const uint32_t d0 = c.r[m][0], mb_x = (d0 >> 16) & 0xff, mb_y = d0 >> 24, l = (uint32_t)lane;
+    const uint8_t *O = lds + rc_win_at(m);
+    if (l < 16) {
+        *reinterpret_cast<u32x4 *>(frame + (size_t)((mb_y << 4) + l) * a.luma_w + (mb_x << 4)) = *reinterpret_cast<const u32x4 *>(O + l * 16);
+    } else if (l < 32) {
+        const uint32_t plane = (l >> 3) & 1, r = l & 7;
+        *reinterpret_cast<uint64_t *>(frame + a.luma_bytes + (size_t)plane * a.chroma_bytes + (size_t)((mb_y << 3) + r) * a.chroma_w + (mb_x << 3)) =
+            *reinterpret_cast<const uint64_t *>(O + 256 + plane * 64 + r * 8);
+    }
+}
+
 // Frame.RGBA fused (pictures flagged MPEGHIP_PIC_RGBA): macroblock m from O_m, 4 pixels per lane (lane = row*4 +
 // segment), one 16-byte store each — a macroblock row is 64 contiguous bytes of the image.  Pixels outside
 // width x height are not stored.

@@ -165,6 +165,8 @@ void mpeghost_video_rewind(void *hv)
     h->video->Rewind();
 }
 void mpeghost_video_set_lookahead(void *h, int on) { static_cast<VideoHandle *>(h)->video->SetLookahead(on != 0); }
+void mpeghost_video_set_host_mirror(void *h, int on) { static_cast<VideoHandle *>(h)->video->SetHostMirror(on != 0); }
+void mpeghost_video_set_device_pack_from(void *h, uint32_t n_mbs) { static_cast<VideoHandle *>(h)->video->SetDevicePackFrom(n_mbs); }
 // wall seconds of the decoder's host phases so far: parse, hand-over (submit), frames back (read)
 void mpeghost_video_phase_seconds(void *hv, double out[3])
 {

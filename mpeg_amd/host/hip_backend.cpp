@@ -15,6 +15,13 @@ void check(int rc, const char *what)
         throw std::runtime_error(std::string(what) + ": " + mpeghip_last_error());
 }
 
+// From how many macroblocks on a lone decoder's hand-over is packed by the device.  Measured on the GPU box with written streams
+// (tools/single_stream_phases.py, profiles/round6_f_lone_decoder_phases.txt): the host packs at 50 ns per macroblock and nothing
+// else (16 us of a SIF picture's hand-over, 0.42 ms of a 1080p picture's), a device-packed stage of one picture costs 90 us of
+// calls, copy and waiting whatever its size plus 15 ns per macroblock (1080p: 0.12 ms; SIF: 50 us + 40 us more wait) — they cross
+// near 2 500 macroblocks.
+constexpr uint32_t kDevicePackFromDefault = 3000;
+
 class HipVideoBackend : public VideoBackend {
 public:
     explicit HipVideoBackend(mpeghip_ctx *ctx) : ctx_(ctx) {}
@@ -29,6 +36,24 @@ public:
             mpeghip_video_close(store_);
         store_ = nullptr;
         check(mpeghip_video_open(ctx_, (uint32_t)width, (uint32_t)height, 1, &store_), "mpeghip_video_open");
+        mirrored_ = false;
+        setMirror(mirror_wanted_);
+    }
+    // a lone decoder's three frames once more in pinned host memory, written by the reconstruction launches (mpeghip_video_host_mirror);
+    // without it (no pinned memory to be had) Decode reads back as before
+    void setMirror(bool on) override
+    {
+        mirror_wanted_ = on;
+        if (store_ && on != mirrored_ && mpeghip_video_host_mirror(store_, on ? 1 : 0) == MPEGHIP_OK)
+            mirrored_ = on;
+    }
+    const uint8_t *mirrorAsync(uint32_t slot, uint64_t *ticket) override
+    {
+        if (!mirrored_)
+            return nullptr;
+        const uint8_t *planes = nullptr;
+        check(mpeghip_video_mirror_async(store_, 0, slot, &planes, ticket), "mpeghip_video_mirror_async");
+        return planes;
     }
     void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override
     {
@@ -37,8 +62,28 @@ public:
     void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs,
                 size_t coef_bytes) override
     {
+        // A large picture in the parser's sparse form goes through a DEVICE-PACKED stage of one picture: validating and packing it
+        // costs this thread — the one that parses — 50 ns per macroblock (0.4 ms of a 1080p picture's 1.4), the device does it
+        // beside the next picture's parse.  Its verdict is deferred (include/mpeghip.h) to the next call that waits for the device:
+        // the frame's readWait — the parser hands over nothing the device refuses (video.cpp: emitPrediction drops what would).
+        if (device_pack_from_ && n_mbs >= device_pack_from_ && (pic.flags & MPEGHIP_PIC_SPARSE)) {
+            const size_t n_words = coef_bytes / 4;
+            mpeghip_stage *stage = nullptr;
+            check(mpeghip_video_stage_begin_device(store_, 1, &n_mbs, &n_words, &stage), "mpeghip_video_stage_begin_device");
+            mpeghip_pic_desc p = pic;
+            p.mb_first = 0;
+            p.mb_count = n_mbs;
+            const int put = mpeghip_video_stage_put_sparse(stage, 0, &p, mbs, reinterpret_cast<const uint32_t *>(coefs));
+            const std::string why = put != MPEGHIP_OK ? mpeghip_last_error() : "";
+            const int commit = mpeghip_video_stage_commit(stage); // (ends the stage whatever the put said)
+            if (put != MPEGHIP_OK)
+                throw std::runtime_error("mpeghip_video_stage_put_sparse: " + why);
+            check(commit, "mpeghip_video_stage_commit");
+            return;
+        }
         check(mpeghip_video_submit(store_, &pic, 1, mbs, n_mbs, coefs, coef_bytes), "mpeghip_video_submit");
     }
+    void setDevicePackFrom(uint32_t n_mbs) override { device_pack_from_ = n_mbs; }
     void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
         check(mpeghip_video_read_planes(store_, 0, slot, y, cb, cr), "mpeghip_video_read_planes");
@@ -68,6 +113,8 @@ public:
 private:
     mpeghip_ctx *ctx_;
     mpeghip_video *store_ = nullptr;
+    bool mirror_wanted_ = true, mirrored_ = false;
+    uint32_t device_pack_from_ = kDevicePackFromDefault; // macroblocks per hand-over from which the device packs (0: never)
 };
 
 class HipBatchStore : public BatchStore {

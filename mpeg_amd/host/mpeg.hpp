@@ -228,6 +228,20 @@ public:
         return 0;
     }
     virtual void readWait(uint64_t ticket) { (void)ticket; }
+    // The HOST MIRROR (mpeghip_video_host_mirror): a backend whose reconstruction writes every frame once more, linearly, into host
+    // memory hands out THAT copy of the slot — no read-back is queued at all; readWait(*ticket) blocks until the copy holds the slot
+    // as it is after everything submitted so far.  It stays as it is until the next picture is reconstructed into the slot.
+    // nullptr: no such copy (the default; the HIP backend with the mirror switched off) — Decode reads back as above.
+    virtual const uint8_t *mirrorAsync(uint32_t slot, uint64_t *ticket)
+    {
+        (void)slot;
+        (void)ticket;
+        return nullptr;
+    }
+    virtual void setMirror(bool on) { (void)on; }
+    // From how many macroblocks on a hand-over of the sparse form is validated and packed by the DEVICE (a device-packed stage of one
+    // picture; 0 = never).  Backends without such a stage ignore it.
+    virtual void setDevicePackFrom(uint32_t n_mbs) { (void)n_mbs; }
 };
 
 // Frame stores of MANY streams of one picture size behind one reconstruction call (libmpeghip's
@@ -362,6 +376,17 @@ public:
     Frame *Decode();
     void SetLookahead(bool v) { lookahead_ = v; }
     bool Lookahead() const { return lookahead_; }
+    // Decode's frames straight out of the backend's host mirror (VideoBackend::mirrorAsync; the default where the backend has one):
+    // the reconstruction launch has written them, nothing is read back.  false: the asynchronous read-back into two pinned frames.
+    void SetHostMirror(bool v)
+    {
+        host_mirror_ = v;
+        backend_->setMirror(v);
+    }
+    bool HostMirror() const { return host_mirror_; }
+    // a lone decoder's large pictures are validated and packed on the device (VideoBackend::setDevicePackFrom): from n_mbs
+    // macroblocks per hand-over on; 0 = the host packs everything
+    void SetDevicePackFrom(uint32_t n_mbs) { backend_->setDevicePackFrom(n_mbs); }
     // Decode() in two halves, for VideoBatch: DecodeDeferred parses up to and including the picture that
     // completes the next output frame and hands its work to the backend WITHOUT reading anything back;
     // Fetch copies that frame's planes to the host (what makes Frame.Y/Cb/Cr.Data valid).
@@ -481,7 +506,7 @@ private:
     struct Deferred { mpeghip_pic_desc pic; std::vector<mpeghip_mb_desc> mbs; CoefBytes coefs; };
     std::vector<Deferred> deferred_;      // hand-overs recorded while defer_submits_ (storage is kept and reused)
     size_t n_deferred_ = 0;
-    bool defer_submits_ = false, lookahead_ = true;
+    bool defer_submits_ = false, lookahead_ = true, host_mirror_ = true;
     bool ahead_tried_ = false, ended_before_ahead_ = false; // an attempt to parse ahead was made in the last Decode call / HasEnded() before it
     struct Ahead { bool valid = false; uint32_t slot = 0; double time = 0; } ahead_; // the frame the parsed-ahead picture completes
     // what a dropped look-ahead must give back (Rewind): the parser state that outlives a picture

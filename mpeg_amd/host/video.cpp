@@ -441,11 +441,17 @@ Frame *Video::Decode()
     } else if (!DecodeDeferred(&slot, &t)) {
         return nullptr;
     }
-    // the frame's read-back, queued behind the picture that completes it ...
+    // the frame: the slot's copy in the backend's host mirror, which the reconstruction launches write themselves, or a read-back
+    // queued behind the picture that completes it ...
     const int b = out_next_;
     out_next_ ^= 1;
     auto t0 = std::chrono::steady_clock::now();
-    const uint64_t ticket = backend_->readPlanesAsync(slot, out_planes_[b], luma_bytes_, chroma_bytes_);
+    uint64_t ticket = 0;
+    const uint8_t *planes = host_mirror_ ? backend_->mirrorAsync(slot, &ticket) : nullptr;
+    if (!planes) {
+        planes = out_planes_[b];
+        ticket = backend_->readPlanesAsync(slot, out_planes_[b], luma_bytes_, chroma_bytes_);
+    }
     stats_.seconds_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // ... the next picture's parse while the device works (its hand-over waits for the next call) ...
     if (lookahead_)
@@ -457,6 +463,9 @@ Frame *Video::Decode()
     Frame *f = &out_frames_[b];
     f->slot = slot;
     f->Time = t;
+    f->Y.Data = planes;
+    f->Cb.Data = planes + luma_bytes_;
+    f->Cr.Data = planes + luma_bytes_ + chroma_bytes_;
     return f;
 }
 

@@ -19,6 +19,9 @@ extern "C" {
 int emu_video_run(uint8_t *, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const mpeghip_pic_desc *, uint32_t,
                   const mpeghip_mb_desc *, uint32_t, const uint8_t *, const uint8_t *, uint8_t *, uint64_t);
 void emu_set_device_pack(int);
+void emu_set_wide(int);
+int emu_get_wide(void);
+void emu_set_mirror(uint8_t *, uint64_t);
 void emu_make_qtable(uint8_t *, const uint8_t *, const uint8_t *);
 void emu_rgba_convert(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
 void emu_relayout(uint8_t *, uint8_t *, uint32_t, uint32_t, int);
@@ -45,6 +48,8 @@ public:
         rgba_stride_ = ((size_t)width * height * 4 + 255) / 256 * 256;
         rgba_.assign(rgba_stride_ * 3, 0);
         dump_.assign(512, 0);
+        mirror_stride_ = (luma_ + 2 * chroma_ + 255) / 256 * 256;
+        mirror_.assign(mirror_stride_ * 3, 0); // (the frame store starts out zeroed: the copies are right from the start)
     }
     void setQuant(const uint8_t intra[64], const uint8_t non_intra[64]) override { emu_make_qtable(qt_, intra, non_intra); }
     void submit(const mpeghip_pic_desc &pic, const mpeghip_mb_desc *mbs, uint32_t n_mbs, const uint8_t *coefs, size_t) override
@@ -52,7 +57,29 @@ public:
         mpeghip_pic_desc p = pic; // (the emulator packs each picture's own range)
         p.mb_first = 0;
         p.mb_count = n_mbs;
+        const int wide_before = emu_get_wide();
+        if (mirrored_) { // the host mirror: every chunk as recon_wide_kernel<false, true> runs it (a lone decoder's launches are small)
+            emu_set_wide(1);
+            emu_set_mirror(mirror_.data(), mirror_stride_);
+        }
         emu_video_run(frames_.data(), stride_, lw_, lh_, w_, h_, &p, 1, mbs, n_mbs, coefs, qt_, rgba_.data(), rgba_stride_);
+        if (mirrored_) {
+            emu_set_wide(wide_before);
+            emu_set_mirror(nullptr, 0);
+        }
+    }
+    // (mpeghip_video_host_mirror's stand-in: the emulated launches keep the three linear copies; switching it on later untiles them)
+    void setMirror(bool on) override
+    {
+        if (on && !mirrored_ && !frames_.empty())
+            for (uint32_t slot = 0; slot < 3; slot++)
+                emu_relayout(frames_.data() + slot * stride_, mirror_.data() + slot * mirror_stride_, lw_, lh_, 1);
+        mirrored_ = on;
+    }
+    const uint8_t *mirrorAsync(uint32_t slot, uint64_t *ticket) override
+    {
+        *ticket = 0;
+        return mirrored_ ? mirror_.data() + slot * mirror_stride_ : nullptr;
     }
     void readPlanes(uint32_t slot, uint8_t *y, uint8_t *cb, uint8_t *cr) override
     {
@@ -70,8 +97,9 @@ public:
 private:
     int flavour_;
     uint32_t w_ = 0, h_ = 0, lw_ = 0, lh_ = 0;
-    size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0;
-    std::vector<uint8_t> frames_, rgba_, dump_;
+    size_t luma_ = 0, chroma_ = 0, stride_ = 0, rgba_stride_ = 0, mirror_stride_ = 0;
+    std::vector<uint8_t> frames_, rgba_, dump_, mirror_;
+    bool mirrored_ = false; // (off unless a test asks: Video::SetHostMirror(true) -> setMirror)
     alignas(16) uint8_t qt_[256 + 1024] = {}; // (+ the padding surplus lanes of the table load may read, as on the device)
 };
 

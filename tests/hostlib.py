@@ -43,7 +43,8 @@ def host():
             "mpeghost_video_stats": (None, [P, C.POINTER(C.c_uint64 * 8)]),
             "mpeghost_video_phase_seconds": (None, [P, C.POINTER(C.c_double * 3)]),
             "mpeghost_video_time": (C.c_double, [P]), "mpeghost_video_has_ended": (C.c_int, [P]), "mpeghost_video_rewind": (None, [P]),
-            "mpeghost_video_set_lookahead": (None, [P, C.c_int]),
+            "mpeghost_video_set_lookahead": (None, [P, C.c_int]), "mpeghost_video_set_host_mirror": (None, [P, C.c_int]),
+            "mpeghost_video_set_device_pack_from": (None, [P, C.c_uint32]),
             "mpeghost_audio_time": (C.c_double, [P]), "mpeghost_audio_has_ended": (C.c_int, [P]), "mpeghost_audio_rewind": (None, [P]),
             "mpeghost_audio_set_lookahead": (None, [P, C.c_int]),
             "mpeghost_audio_open": (P, [P, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
@@ -184,6 +185,12 @@ class HostVideo:
 
     def set_lookahead(self, on):
         host().mpeghost_video_set_lookahead(self.h, 1 if on else 0)
+
+    def set_host_mirror(self, on):
+        host().mpeghost_video_set_host_mirror(self.h, 1 if on else 0)
+
+    def set_device_pack_from(self, n_mbs):
+        host().mpeghost_video_set_device_pack_from(self.h, n_mbs)
 
     def rgba(self, w, h):
         p = host().mpeghost_video_rgba(self.h)

@@ -52,6 +52,12 @@ void emu_set_tile_policy(int policy) { g_tile_policy = policy; }
 static int g_wide = 0; // 1: every chunk runs as recon_wide_kernel runs it — four waves, two barriers (emu_wide_chunk)
 static uint64_t g_wide_chunks = 0; // chunks run that way so far (tests ask: did the switch take?)
 void emu_set_wide(int on) { g_wide = on; }
+int emu_get_wide(void) { return g_wide; }
+// the host mirror (mpeghip_video_host_mirror): where emu_wide_chunk writes every macroblock once more, linearly — recon_wide_kernel<false,
+// true>'s rc_mirror_mb — for submits without a colour-converting picture; (nullptr, 0) = off
+static uint8_t *g_mirror = nullptr;
+static uint64_t g_mirror_stride = 0;
+void emu_set_mirror(uint8_t *base, uint64_t stride) { g_mirror = base, g_mirror_stride = stride; }
 uint64_t emu_wide_chunks_run(void) { return g_wide_chunks; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 void emu_set_pack_window(uint32_t dwords) { g_pack_window = dwords; }
@@ -275,6 +281,8 @@ static void emu_wide_chunk(const VideoArgs &a, uint32_t chunk, bool any_rgba)
                     rc_rmw(lds, bw[w][lane], lane, v[w][lane]);
     // ---- barrier: the stores, every wave its share
     const bool run = (c.h[4] & kCRun) != 0, to_rgba = any_rgba && (c.h[4] & kCRgba) != 0;
+    const bool mirror = g_mirror && !any_rgba; // (launch_batch: the mirroring instance carries no colour conversion)
+    uint8_t *const mirror_frame = mirror ? g_mirror + ((uint64_t)rc_stream(c) * MPEGHIP_SLOTS + rc_cur_slot(c)) * g_mirror_stride : nullptr;
     const uint32_t n_live = rc_n_live(c);
     for (uint32_t w = 0; w < 4; w++) {
         if (run) {
@@ -289,13 +297,18 @@ static void emu_wide_chunk(const VideoArgs &a, uint32_t chunk, bool any_rgba)
                     else
                         rc_rgba_mb(a, c, rc_rgba_image(a, c), w, lane, lds);
                 }
+                if (mirror)
+                    rc_mirror_mb(a, c, mirror_frame, w, lane, lds);
             }
         } else if (w < n_live) {
             for (int lane = 0; lane < 64; lane++)
-                rc_store_mb(a, c, w, lane, lds, to_rgba);
+                rc_store_mb(a, c, w, lane, lds, to_rgba || mirror);
             if (to_rgba)
                 for (int lane = 0; lane < 64; lane++)
                     rc_rgba_mb(a, c, rc_rgba_image(a, c), w, lane, lds);
+            if (mirror)
+                for (int lane = 0; lane < 64; lane++)
+                    rc_mirror_mb(a, c, mirror_frame, w, lane, lds);
         }
     }
 }

@@ -39,6 +39,27 @@ def test_video_golden_hash_on_gpu(oracle, golden_dir, device):
     assert st["invalid_blocks"] == 53 and st["raw_macroblocks"] > 0
 
 
+@pytest.mark.parametrize("pack_from", [0, 1], ids=["host_packed", "device_packed"])
+@pytest.mark.parametrize("mirror", [True, False], ids=["mirror", "read_back"])
+def test_video_golden_hash_through_either_hand_over_and_either_way_back(oracle, golden_dir, device, pack_from, mirror):
+    """a lone decoder's pictures validated and packed on the host or — every one of them, also these 80-macroblock ones — by the
+    device (a device-packed stage of one picture: mpeghost_video_set_device_pack_from), its frames out of the store's host mirror
+    or read back: the reference's hash of the damaged golden stream all four ways"""
+    dec = hostlib.HostVideo((golden_dir / "test.mpeg1video").read_bytes(), device=device)
+    dec.set_device_pack_from(pack_from)
+    dec.set_host_mirror(mirror)
+    h, n = oracle.FNV_OFFSET, 0
+    while True:
+        f = dec.decode()
+        if f is None:
+            break
+        for p in hostlib.frame_planes(f):
+            h = oracle.fnv1a64(p, h)
+        n += 1
+    dec.close()
+    assert (h, n) == (VIDEO_HASH, 260)
+
+
 def test_frame_rgba_on_gpu_matches_oracle(oracle, golden_dir, device):
     data = (golden_dir / "test.mpeg1video").read_bytes()
     ref, dut = oracle.VideoDecoder(data), hostlib.HostVideo(data, device=device)
@@ -152,14 +173,17 @@ def test_written_1080p_stream_through_the_parser_and_the_gpu(oracle, device):
     es = mpeg1_writer.write_sequence(w, h, seq)
     want = expected_frames(oracle, w, h, seq)
     assert len(want) == 3                      # I, B, B (the P picture is still held when the stream ends on a B)
-    dut = hostlib.HostVideo(es, device=device)
-    got = decode_all(dut, hostlib.frame_planes)
-    st = dut.stats()
-    dut.close()
-    assert len(got) == len(want) and st["pictures"] == 4 and st["invalid_blocks"] == 0 and st["range_skips"] == 0
-    for i, (a, b) in enumerate(zip(want, got)):
-        for pa, pb in zip(a, b):
-            assert np.array_equal(pa, pb), "frame %d" % i
+    for pack_from in (None, 0):                # the default (a 1080p picture is packed by the device), and packed on the host
+        dut = hostlib.HostVideo(es, device=device)
+        if pack_from is not None:
+            dut.set_device_pack_from(pack_from)
+        got = decode_all(dut, hostlib.frame_planes)
+        st = dut.stats()
+        dut.close()
+        assert len(got) == len(want) and st["pictures"] == 4 and st["invalid_blocks"] == 0 and st["range_skips"] == 0
+        for i, (a, b) in enumerate(zip(want, got)):
+            for pa, pb in zip(a, b):
+                assert np.array_equal(pa, pb), "frame %d (device_pack_from %s)" % (i, pack_from)
     b = hostlib.HostBatch(6, device=device, threads=3)
     for _ in range(6):
         b.add_stream(es)

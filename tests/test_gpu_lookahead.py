@@ -56,8 +56,9 @@ def test_video_frames_equal_the_oracles_with_the_lookahead_on(oracle, golden_dir
 
 
 def test_video_frame_is_valid_until_the_next_decode_call_on_gpu(golden_dir, device):
-    """two PINNED frames alternate; the one in the caller's hands does not change while the next call runs"""
+    """without the host mirror: two PINNED frames alternate; the one in the caller's hands does not change while the next call runs"""
     dec = hostlib.HostVideo((golden_dir / "test.mpeg1video").read_bytes(), device=device)
+    dec.set_host_mirror(False)
     prev_view, prev_copy, ptrs = None, None, []
     for i in range(40):
         f = dec.decode()
@@ -68,6 +69,37 @@ def test_video_frame_is_valid_until_the_next_decode_call_on_gpu(golden_dir, devi
         prev_view, prev_copy = _view(f), _view(f).copy()
     assert len(set(ptrs)) == 2 and ptrs[0::2] == [ptrs[0]] * 20 and ptrs[1::2] == [ptrs[1]] * 20
     dec.close()
+
+
+def test_video_mirrored_frame_has_the_references_lifetime_on_gpu(golden_dir, device):
+    """the default: the returned frame is the slot's copy in the device store's host mirror (mpeghip_video_host_mirror) — one of
+    three addresses, as the reference's returned *Frame is one of its three frames; nothing is in flight when Decode returns, so the
+    bytes stay as they are until the next decode call begins"""
+    import time
+    dec = hostlib.HostVideo((golden_dir / "test.mpeg1video").read_bytes(), device=device)
+    prev_view, prev_copy, ptrs = None, None, []
+    for i in range(60):
+        if prev_view is not None:
+            if i % 10 == 0:
+                time.sleep(0.002)
+            assert np.array_equal(prev_view, prev_copy), "frame %d changed before the next decode call" % (i - 1)
+        f = dec.decode()
+        assert f is not None
+        ptrs.append(f.y)
+        prev_view, prev_copy = _view(f), _view(f).copy()
+    assert len(set(ptrs)) == 3
+    dec.close()
+
+
+@pytest.mark.parametrize("script", SCRIPTS, ids=[str(i) for i in range(len(SCRIPTS))])
+def test_video_host_mirror_changes_nothing_on_gpu(golden_dir, device, script):
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    a, b = hostlib.HostVideo(data, device=device), hostlib.HostVideo(data, device=device)
+    b.set_host_mirror(False)
+    ra, rb = run_script(a, script), run_script(b, script)
+    a.close()
+    b.close()
+    assert ra == rb
 
 
 @pytest.mark.parametrize("fmt", [0, 1, 2, 3], ids=["F32N", "F32NLR", "F32", "S16"])

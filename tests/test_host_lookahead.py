@@ -81,6 +81,45 @@ def test_video_frame_is_valid_until_the_next_decode_call(golden_dir):
     dec.close()
 
 
+@pytest.mark.parametrize("script", SCRIPTS[:3], ids=["0", "1", "2"])
+@pytest.mark.parametrize("lookahead", [True, False], ids=["ahead", "plain"])
+def test_video_host_mirror_changes_nothing(golden_dir, script, lookahead):
+    """Decode's frames out of the backend's HOST MIRROR (VideoBackend::mirrorAsync — on the device: mpeghip_video_host_mirror, the
+    reconstruction launch writes every frame once more, linearly, into pinned host memory; here: the lane emulator's
+    rc_mirror_mb through emu_wide_chunk) against the read-back: identical frames, times, Time(), HasEnded(), across Rewinds —
+    through the damaged golden stream's partial pictures and the blocks that keep their old pixels."""
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    a, b = hostlib.HostVideo(data, emu_flavour=0), hostlib.HostVideo(data, emu_flavour=0)
+    a.set_host_mirror(True)     # (the emulator backend's mirror is off until asked for; the HIP backend's is on by default)
+    b.set_host_mirror(False)
+    for d in (a, b):
+        d.set_lookahead(lookahead)
+    ra, rb = run_script(a, script), run_script(b, script)
+    a.close()
+    b.close()
+    assert ra == rb
+    assert sum(1 for r in ra if r[0] not in (None, "rewind")) >= 3
+
+
+def test_video_mirrored_frame_has_the_references_lifetime(golden_dir):
+    """With the host mirror the returned frame IS the slot's copy — as in the reference, where the returned *Frame is one of the
+    decoder's three (video.go:247-256): it keeps its bytes until the next decode call begins (the picture parsed ahead has not been
+    handed over), consecutive B frames come back at the same address, and there are three addresses in all."""
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    dec = hostlib.HostVideo(data, emu_flavour=0)
+    dec.set_host_mirror(True)
+    ptrs, prev_view, prev_copy = [], None, None
+    for i in range(40):
+        if prev_view is not None:
+            assert np.array_equal(prev_view, prev_copy), "frame %d changed before the next decode call" % (i - 1)
+        f = dec.decode()
+        assert f is not None
+        ptrs.append(f.y)
+        prev_view, prev_copy = _view(f), _view(f).copy()
+    assert len(set(ptrs)) == 3
+    dec.close()
+
+
 def test_video_rgba_of_the_returned_frame_with_a_picture_parsed_ahead(oracle, golden_dir):
     """Frame.RGBA() converts the returned frame's slot on the device: the picture parsed ahead has not been handed over, so the
     slot still holds that frame (B pictures follow one another in ONE slot)."""

@@ -30,9 +30,17 @@ def main():
     for w, h in ((352, 240), (1920, 1080)):
         seq = synth.generate_sequence(w, h, 7, seed=0x5a, profile="natural")
         cases.append(("written %dx%d" % (w, h), mpeg1_writer.write_sequence(w, h, seq, repeat=4)))
-    for name, es in cases:
+    H.mpeghost_video_set_host_mirror.argtypes = [P, C.c_int]
+    H.mpeghost_video_set_device_pack_from.argtypes = [P, C.c_uint32]
+    modes = [("default", None, None), ("host-packed", None, 0), ("device-packed", None, 1), ("no mirror", 0, None)]
+    for name, es in [(n + " [" + m[0] + "]", (e, m)) for n, e in cases for m in modes]:
+        es, mode = es
         for rep in range(3):
             v = H.mpeghost_video_open(dev, es, len(es))
+            if mode[1] is not None:
+                H.mpeghost_video_set_host_mirror(v, mode[1])
+            if mode[2] is not None:
+                H.mpeghost_video_set_device_pack_from(v, mode[2])
             n, t0 = 0, time.perf_counter()
             while H.mpeghost_video_decode(v, frame) == 1:
                 n += 1
@@ -40,7 +48,7 @@ def main():
             ph = (C.c_double * 3)()
             H.mpeghost_video_phase_seconds(v, C.byref(ph))
             H.mpeghost_video_close(v)
-            print("%-26s run %d: %5d frames  %8.1f frames/s  %7.1f us/frame = parse %6.1f + submit %6.1f + read %6.1f + other %5.1f" %
+            print("%-42s run %d: %5d frames  %8.1f frames/s  %7.1f us/frame = parse %6.1f + submit %6.1f + read %6.1f + other %5.1f" %
                   (name, rep, n, n / dt, dt / n * 1e6, ph[0] / n * 1e6, ph[1] / n * 1e6, ph[2] / n * 1e6, (dt - ph[0] - ph[1] - ph[2]) / n * 1e6))
 
 
