@@ -3,7 +3,7 @@ import re
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md"]
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "docs/history/rounds_1_to_4.md"]
 
 
 def test_every_cited_profile_exists():
@@ -12,7 +12,7 @@ def test_every_cited_profile_exists():
     missing = []
     for doc in DOCS:
         text = (ROOT / doc).read_text()
-        for m in re.finditer(r"`(?:profiles/)?((?:r\d\w*?|round[45]_[a-z]+)_[\w.\-]+\.(?:txt|json|csv|log))`", text):  # full file names
+        for m in re.finditer(r"`(?:profiles/)?((?:r\d\w*?|round[456]_[a-z]+)_[\w.\-]+\.(?:txt|json|csv|log))`", text):  # full file names
             name = m.group(1)
             if "*" in name or "…" in name:
                 continue

@@ -1,5 +1,5 @@
 """Randomised differential soak of the reconstruction path on the GPU: seeded (geometry, content, picture types, snapshot
-share, fused RGBA, kernel policy, hand-over form: dense units / sparse words packed on the host / sparse words packed on the device) cases beyond the fixed parametrisations of tests/, every picture of every case compared with
+share, fused RGBA, kernel policy, the host mirror, hand-over form: dense units / sparse words packed on the host / sparse words packed on the device) cases beyond the fixed parametrisations of tests/, every picture of every case compared with
 the oracle on all three slots (and the RGBA image when fused) through the C ABI.  Test infrastructure: the oracle is the checker.
 A second phase does the same for the MP2 synthesis (stream counts, frames per call, calls in a row on one state, the four output
 formats, both window arithmetics, streams masked out of a call): bit equality with the oracle's synthesis and of the V ring state.
@@ -17,9 +17,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 class Via:
     """the device store behind one of the three hand-over forms"""
-    def __init__(self, store, form):
-        self.store, self.form = store, form
-        self.read_planes, self.read_rgba = store.read_planes, store.read_rgba
+    def __init__(self, store, form, mirror=False):
+        self.store, self.form, self.mirror = store, form, mirror
+        self.read_rgba = store.read_rgba
+        if mirror:
+            store.host_mirror()
+
+    def read_planes(self, stream, slot):
+        """the slot's planes; with the host mirror on (mpeghip_video_host_mirror) its copy in pinned host memory — written by the
+        launch itself where the library's four-waves-per-chunk kernel ran without a colour conversion, repaired by an untiling
+        launch elsewhere — must say the same"""
+        planes = self.store.read_planes(stream, slot)
+        if self.mirror:
+            view, ticket = self.store.mirror_async(stream, slot)
+            self.store.read_wait(ticket)
+            assert np.array_equal(np.concatenate(planes), view), "the host mirror of slot %d differs from the frame store" % slot
+        return planes
 
     def submit(self, pics, mbs, coefs):
         from mpeg_amd import desc
@@ -53,11 +66,12 @@ def video_case(ctx, rng, allow_big=True):
     seq = synth.generate_sequence(w, h, n, seed=seed, profile=profile, raw_fraction=raw, rgba=rgba, types=types)
     ref, dut = pyoracle.OracleStore(w, h, threads=4), abi.VideoStore(ctx, w, h)
     dut.set_tile_policy(policy)
+    mirror = (seed & 3) == 0  # a quarter of the cases with the host mirror on (from the case's seed: the sequence of draws is as it was)
     try:
-        run_and_compare(ref, Via(dut, form), seq, check_rgba=rgba)
+        run_and_compare(ref, Via(dut, form, mirror), seq, check_rgba=rgba)
     except AssertionError as e:
-        raise AssertionError("MISMATCH: w=%d h=%d n=%d profile=%s raw=%.2f rgba=%d policy=%d form=%d seed=%d types=%s: %s" %
-                             (w, h, n, profile, raw, rgba, policy, form, seed, types, e))
+        raise AssertionError("MISMATCH: w=%d h=%d n=%d profile=%s raw=%.2f rgba=%d policy=%d form=%d mirror=%d seed=%d types=%s: %s" %
+                             (w, h, n, profile, raw, rgba, policy, form, mirror, seed, types, e))
     finally:
         dut.close()
         ref.close()
