@@ -993,6 +993,26 @@ double orc_video_framerate(orc_video *v) { return orc_video_has_header(v) ? v->f
 void orc_video_set_no_delay(orc_video *v, int nd) { v->no_delay = nd; }
 const orc_video_stats *orc_video_get_stats(const orc_video *v) { return &v->st; }
 
+/* Buffer.Rewind (buffer.go:105-107 -> seek(0), :158-176) over the resident stream: the reader is back at byte 0, nothing is loaded,
+ * hasEnded is cleared. */
+static void bits_rewind(orc_bits *b)
+{
+    b->bit = 0;
+    b->ended = 0;
+}
+/* Video.Rewind (video.go:195-201).  The three frames keep their bytes and the rotation its state: what the first pictures after a
+ * rewind predict from — on a stream that does not open with an intra picture, or a damaged one — is what was decoded before it. */
+void orc_video_rewind(orc_video *v)
+{
+    bits_rewind(&v->buf);
+    v->time = 0;
+    v->frames_decoded = 0;
+    v->has_ref = 0;
+    v->start_code = -1;
+}
+double orc_video_time(const orc_video *v) { return v->time; }             /* video.go:183 */
+int orc_video_has_ended(const orc_video *v) { return v->buf.ended; }        /* video.go:203 */
+
 const orc_frame *orc_video_decode(orc_video *v)
 { /* video.go:209-268 */
     if (!orc_video_has_header(v))
@@ -1423,6 +1443,19 @@ int orc_audio_samplerate(orc_audio *a)
 }
 
 int orc_audio_channels(orc_audio *a) { return a->channels; }
+
+/* Audio.Rewind (audio.go:149-154): the V ring and vPos are NOT cleared — the first frames after a rewind are synthesised on top
+ * of what the frames before it left behind. */
+void orc_audio_rewind(orc_audio *a)
+{
+    a->buf.bit = 0;
+    a->buf.ended = 0;
+    a->time = 0;
+    a->samples_decoded = 0;
+    a->next_frame_data_size = 0;
+}
+double orc_audio_time(const orc_audio *a) { return a->time; }              /* audio.go:137 */
+int orc_audio_has_ended(const orc_audio *a) { return a->buf.ended; }        /* audio.go:157 */
 
 const float *orc_audio_decode(orc_audio *a, int32_t *samples_out)
 { /* audio.go:163-182 */

@@ -110,6 +110,10 @@ double orc_video_framerate(orc_video *v);
 void   orc_video_set_no_delay(orc_video *v, int no_delay);
 /* Video.Decode (video.go:209-268): NULL at end. The frame aliases decoder storage. */
 const orc_frame *orc_video_decode(orc_video *v);
+/* Video.Rewind / Time / HasEnded (video.go:195-201, 183, 203) */
+void   orc_video_rewind(orc_video *v);
+double orc_video_time(const orc_video *v);
+int    orc_video_has_ended(const orc_video *v);
 const orc_video_stats *orc_video_get_stats(const orc_video *v);
 
 typedef struct orc_audio orc_audio;
@@ -122,6 +126,10 @@ int orc_audio_channels(orc_audio *a);
  * (2304 floats) or NULL. `samples_out`, if not NULL, receives the frame's
  * requantised sub-band samples as int32 [2][36][32] (the device input layout). */
 const float *orc_audio_decode(orc_audio *a, int32_t *samples_out);
+/* Audio.Rewind / Time / HasEnded (audio.go:149-154, 137, 157) */
+void   orc_audio_rewind(orc_audio *a);
+double orc_audio_time(const orc_audio *a);
+int    orc_audio_has_ended(const orc_audio *a);
 void orc_audio_get_state(const orc_audio *a, float v[2][1024], int *vpos);
 
 /* demux.go:473-584 subset — pull the payload of every PES packet of `type`

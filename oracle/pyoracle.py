@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
             "orc_video_framerate": (C.c_double, [P]),
             "orc_video_set_no_delay": (None, [P, C.c_int]),
             "orc_video_decode": (C.POINTER(Frame), [P]),
+            "orc_video_rewind": (None, [P]), "orc_video_time": (C.c_double, [P]), "orc_video_has_ended": (C.c_int, [P]),
+            "orc_audio_rewind": (None, [P]), "orc_audio_time": (C.c_double, [P]), "orc_audio_has_ended": (C.c_int, [P]),
             "orc_video_get_stats": (C.POINTER(VideoStats), [P]),
             "orc_audio_open": (P, [C.c_char_p, C.c_size_t, C.c_int]),
             "orc_audio_close": (None, [P]),
@@ -136,6 +138,12 @@ class VideoDecoder:
     def stats(self) -> VideoStats:
         return lib().orc_video_get_stats(self.h).contents
 
+    def rewind(self):
+        lib().orc_video_rewind(self.h)
+
+    time = property(lambda s: lib().orc_video_time(s.h))
+    has_ended = property(lambda s: bool(lib().orc_video_has_ended(s.h)))
+
     def close(self):
         if self.h:
             lib().orc_video_close(self.h)
@@ -158,6 +166,12 @@ class AudioDecoder:
             return None
         out = np.ctypeslib.as_array(p, shape=(2304,)).copy()
         return (out, samples) if want_samples else out
+
+    def rewind(self):
+        lib().orc_audio_rewind(self.h)
+
+    time = property(lambda s: lib().orc_audio_time(s.h))
+    has_ended = property(lambda s: bool(lib().orc_audio_has_ended(s.h)))
 
     def close(self):
         if self.h:

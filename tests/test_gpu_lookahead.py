@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import hostlib
-from test_host_lookahead import SCRIPTS, _view, run_script
+from test_host_lookahead import SCRIPTS, _view, oracle_script, run_script
 
 pytestmark = pytest.mark.gpu
 
@@ -30,6 +30,18 @@ def test_video_lookahead_changes_nothing_on_gpu(golden_dir, device, script):
     a.close()
     b.close()
     assert ra == rb
+
+
+@pytest.mark.parametrize("script", SCRIPTS, ids=[str(i) for i in range(len(SCRIPTS))])
+def test_video_rewinds_against_the_oracle_on_gpu(oracle, golden_dir, device, script):
+    """tests/test_host_lookahead.py::test_video_rewinds_against_the_oracle on the HIP backend (look-ahead and host mirror on): what a
+    Rewind leaves in the device's frame store is what the reference's leaves in its three frames (video.go:195-201)"""
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    ref, dut = oracle.VideoDecoder(data), hostlib.HostVideo(data, device=device)
+    want, got = oracle_script(ref, script, oracle.frame_planes), run_script(dut, script)
+    ref.close()
+    dut.close()
+    assert got == want
 
 
 def test_video_frames_equal_the_oracles_with_the_lookahead_on(oracle, golden_dir, device):

@@ -120,6 +120,67 @@ def test_video_mirrored_frame_has_the_references_lifetime(golden_dir):
     dec.close()
 
 
+def oracle_script(dec, script, planes):
+    """run_script's sequence on the ORACLE's decoder (oracle/mpeg_oracle.c: orc_video_rewind restates video.go:195-201)"""
+    out = []
+    for step in script:
+        if step == "rewind":
+            dec.rewind()
+            out.append(("rewind", dec.time, dec.has_ended))
+            continue
+        for _ in range(step):
+            f = dec.decode()
+            if f is None:
+                out.append((None, dec.time, dec.has_ended))
+                break
+            out.append((hash(np.concatenate(planes(f)).tobytes()), f.time, dec.time, dec.has_ended))
+    return out
+
+
+@pytest.mark.parametrize("script", SCRIPTS, ids=[str(i) for i in range(len(SCRIPTS))])
+@pytest.mark.parametrize("mirror", [False, True], ids=["read_back", "mirror"])
+def test_video_rewinds_against_the_oracle(oracle, golden_dir, script, mirror):
+    """Rewind keeps the three frames' bytes and the rotation (video.go:195-201 resets the buffer, the time, hasReferenceFrame and
+    the start code only): what the damaged golden stream's first pictures predict from after a rewind in mid-stream is what was
+    decoded before it — the whole stream then hashes to something else than a fresh decoder's.  The product one picture ahead
+    (the picture parsed ahead never reached the device), with and without the host mirror, against the restated reference: frames,
+    frame times, Time() and HasEnded() after every call."""
+    data = (golden_dir / "test.mpeg1video").read_bytes()
+    ref, dut = oracle.VideoDecoder(data), hostlib.HostVideo(data, emu_flavour=0)
+    dut.set_host_mirror(mirror)
+    want, got = oracle_script(ref, script, oracle.frame_planes), run_script(dut, script)
+    ref.close()
+    dut.close()
+    assert got == want
+
+
+@pytest.mark.parametrize("script", [[5, "rewind", 7, "rewind", "rewind", 3], [1, "rewind", 2], [400], [355, 1, "rewind", 2]],
+                         ids=["mid", "first", "to_end", "at_end"])
+def test_audio_rewinds_against_the_oracle(oracle, golden_dir, script):
+    """audio.go:149-154: Rewind does not clear the V ring — the first frames after it are synthesised on top of what the frames
+    RETURNED before it left behind (a frame parsed ahead was never synthesised)."""
+    def run(dec, bits):
+        out = []
+        for step in script:
+            if step == "rewind":
+                dec.rewind()
+                out.append(("rewind", dec.time, dec.has_ended))
+                continue
+            for _ in range(step):
+                s = dec.decode()
+                if s is None:
+                    out.append((None, dec.time, dec.has_ended))
+                    break
+                out.append((hash(bits(s)), dec.time, dec.has_ended))
+        return out
+    ref, dut = oracle.AudioDecoder((golden_dir / "test.mp2").read_bytes(), 0), _audio(golden_dir)
+    want = run(ref, lambda s: np.asarray(s, np.float32).tobytes())
+    got = run(dut, lambda s: np.asarray(s, np.float32)[:2304].tobytes())
+    ref.close()
+    dut.close()
+    assert got == want
+
+
 def test_video_rgba_of_the_returned_frame_with_a_picture_parsed_ahead(oracle, golden_dir):
     """Frame.RGBA() converts the returned frame's slot on the device: the picture parsed ahead has not been handed over, so the
     slot still holds that frame (B pictures follow one another in ONE slot)."""
