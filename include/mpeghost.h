@@ -68,7 +68,8 @@ void mpeghost_video_rewind(void *video);                             /* video.go
 void mpeghost_video_set_lookahead(void *video, int on);
 /* The frames Video.Decode returns come out of the device store's HOST MIRROR (mpeghip_video_host_mirror: the reconstruction launch
  * writes every frame once more, linearly, into pinned host memory — no read-back is queued; the default).  0: the asynchronous
- * read-back into two pinned frames (mpeghip_video_read_planes_async).  Same frames either way. */
+ * read-back into two pinned frames (mpeghip_video_read_planes_async).  Same frames either way; switching ends the life of the frame
+ * in hand. */
 void mpeghost_video_set_host_mirror(void *video, int on);
 /* A lone decoder's hand-overs of n_mbs macroblocks and more (sparse form) are validated and packed by the DEVICE — a device-packed
  * stage of one picture, include/mpeghip.h — instead of by the thread that parses; 0 = never.  Default: 3 000, where the two ways cost the same

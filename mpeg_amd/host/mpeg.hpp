@@ -378,6 +378,7 @@ public:
     bool Lookahead() const { return lookahead_; }
     // Decode's frames straight out of the backend's host mirror (VideoBackend::mirrorAsync; the default where the backend has one):
     // the reconstruction launch has written them, nothing is read back.  false: the asynchronous read-back into two pinned frames.
+    // (Switching ends the life of the frame in hand: the mirror's memory goes with it.)
     void SetHostMirror(bool v)
     {
         host_mirror_ = v;
