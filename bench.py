@@ -80,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="allow ranks to share a physical GPU (functional runs of the N>1 path on a smaller box): without it a launch "
                          "with more ranks than distinct devices exits non-zero; with it the line reports n_gpus = the distinct devices")
-    ap.add_argument("--gop-prewarm", type=int, default=1, help="1: one untimed GOP in front of the --warmup steps when --warmup is shorter than a GOP (clock ramp)")
+    ap.add_argument("--gop-prewarm", type=int, default=1, help="1: whole untimed GOPs (40 ms of device work) in front of the --warmup steps when --warmup is shorter than a GOP (clock ramp)")
     ap.add_argument("--sif-streams", type=int, default=8192, help="streams of the SIF 352x240 leg (BASELINE config 2's geometry; N=1 only; 0 = skip)")
     ap.add_argument("--sidecar", default=str(ROOT / "bench_legs.json"),
                     help="where the FULL result goes (every leg with its prose: metric, sample, kernel, parity sentences); the one "
@@ -289,12 +289,18 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
         step(i)
     prewarm_steps = 0
     if ramp_ms == 0 and args.warmup < cycle and args.gop_prewarm:
-        prewarm_steps = cycle
         # The upload above left the GPU's compute clocks parked; W warm-up steps of 2 - 4 ms do not bring them back when W is small
-        # (the driver's W = 5: 0.612 where W = 13 gives 0.617, profiles/round4_v_bench_repeatability.txt / round4_o_*).  One whole
-        # GOP, untimed, in front of the W warm-up steps: the pictures are part of `order`, so the oracle replays them too.
-        for i in range(cycle):
-            step(i)
+        # (the driver's W = 5: 0.612 where W = 13 gives 0.617, profiles/round4_v_bench_repeatability.txt / round4_o_*).  Whole
+        # GOPs, untimed, in front of the W warm-up steps until the device has worked for 40 ms (round 6: one GOP of SIF pictures
+        # is 7 ms, one of the dense leg's 11 ms — those legs moved by 3 % from run to run; 1080p typical: two GOPs): the pictures
+        # are part of `order`, so the oracle replays them too.
+        warm_ms = 0.0
+        while warm_ms < 40.0 and prewarm_steps < 8 * cycle:
+            ctx.timer_start()
+            for i in range(cycle):
+                step(i)
+            warm_ms += ctx.timer_stop_ms()
+            prewarm_steps += cycle
     for i in range(args.warmup):
         step(i)
     acc = {"mbs": 0, "alg": 0, "ev_ms": 0.0}
@@ -399,13 +405,22 @@ def mixed_leg(ctx, args, streams, n_seeds=16):
         order.append(t)
         return b
 
-    for t in range(args.gop):           # one whole cycle: every stream has decoded its references
-        step(t)
+    # Whole cycles, untimed, until the device has worked for 80 ms: every stream has decoded its references after the first, and
+    # the setup above (seconds of host work) left the GPU's clocks parked — one cycle of 21 ms does not always bring them back
+    # (the leg read 0.55 - 0.62 on two boxes of round 6 where its kernel runs at 0.69: gpurun_out/r6o, r6y; the primary leg has
+    # --gop-prewarm for the same reason).  The pictures are part of `order`: the oracle replays them too.
+    warm_ms, t_next = 0.0, 0
+    while warm_ms < 80.0 and t_next < 8 * args.gop:
+        ctx.timer_start()
+        for t in range(t_next, t_next + args.gop):
+            step(t)
+        warm_ms += ctx.timer_stop_ms()
+        t_next += args.gop
     ctx.sync()
     mbs = alg = 0
     w0 = time.perf_counter()
     ctx.timer_start()
-    for t in range(args.gop, args.gop + args.steps):
+    for t in range(t_next, t_next + args.steps):
         b = step(t)
         mbs += b.n_mbs
         alg += b.alg_bytes
@@ -426,7 +441,7 @@ def mixed_leg(ctx, args, streams, n_seeds=16):
                       "pictures of different streams in every launch" % (args.gop, n_seeds),
             "value": mbs / elapsed, "unit": "macroblocks/s", "streams": streams, "steps": args.steps,
             "ms_per_step": elapsed * 1e3 / args.steps, "realtime_1080p30_streams": mbs / elapsed / MB_PER_1080P30_STREAM,
-            "distinct_seeds": n_seeds, "distinct_combinations": len(wl.combos()), "setup_s": setup_s,
+            "distinct_seeds": n_seeds, "distinct_combinations": len(wl.combos()), "setup_s": setup_s, "untimed_warm_steps": t_next,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": KERNEL[False], "alg_bytes_per_launch": alg // args.steps, "avg_launch_ms": launch_ms},
             "parity": parity}
