@@ -80,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="allow ranks to share a physical GPU (functional runs of the N>1 path on a smaller box): without it a launch "
                          "with more ranks than distinct devices exits non-zero; with it the line reports n_gpus = the distinct devices")
-    ap.add_argument("--gop-prewarm", type=int, default=1, help="1: whole untimed GOPs (40 ms of device work) in front of the --warmup steps when --warmup is shorter than a GOP (clock ramp)")
+    ap.add_argument("--gop-prewarm", type=int, default=1, help="1: whole untimed GOPs (40 ms of device work) in front of the --warmup steps (clock ramp)")
     ap.add_argument("--sif-streams", type=int, default=8192, help="streams of the SIF 352x240 leg (BASELINE config 2's geometry; N=1 only; 0 = skip)")
     ap.add_argument("--sidecar", default=str(ROOT / "bench_legs.json"),
                     help="where the FULL result goes (every leg with its prose: metric, sample, kernel, parity sentences); the one "
@@ -288,7 +288,7 @@ def video_leg(ctx, args, profile, rgba, streams, ranks=None, device_sync=None, s
     for i in range(-prime, 0):
         step(i)
     prewarm_steps = 0
-    if ramp_ms == 0 and args.warmup < cycle and args.gop_prewarm:
+    if ramp_ms == 0 and args.gop_prewarm:  # (whatever --warmup is: 13 warm-up steps of a SIF leg are 7 ms)
         # The upload above left the GPU's compute clocks parked; W warm-up steps of 2 - 4 ms do not bring them back when W is small
         # (the driver's W = 5: 0.612 where W = 13 gives 0.617, profiles/round4_v_bench_repeatability.txt / round4_o_*).  Whole
         # GOPs, untimed, in front of the W warm-up steps until the device has worked for 40 ms (round 6: one GOP of SIF pictures
